@@ -1,0 +1,249 @@
+"""State containers: ``SamplerState`` and ``ThermodynamicState``.
+
+Same names, constructor arguments, properties and error behaviour as the
+reference (chiron/states.py:8-174 and :177-329); arrays are ``torch`` tensors
+(fp32, on the ROCm device when one is visible) instead of ``jax`` arrays, and
+the PRNG key is a Philox key pair (see ``chiron_amd.rng``).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Union
+
+import numpy as np
+import torch
+
+from . import unit
+from ._device import as_tensor
+from .rng import PRNGKey, split
+
+
+def _shape_of(q) -> tuple:
+    v = q._value if isinstance(q, unit.Quantity) else q
+    if hasattr(v, "shape"):
+        return tuple(v.shape)
+    return tuple(np.asarray(v).shape)
+
+
+class SamplerState:
+    """Positions / velocities / box vectors / PRNG key of one replica.
+
+    Reference: chiron/states.py:8-174.
+    """
+
+    def __init__(
+        self,
+        positions: unit.Quantity,
+        current_PRNG_key: PRNGKey = None,
+        velocities: Optional[unit.Quantity] = None,
+        box_vectors: Optional[unit.Quantity] = None,
+    ) -> None:
+        # validation order follows chiron/states.py:44-87
+        if not isinstance(positions, unit.Quantity):
+            raise TypeError(f"positions must be a unit.Quantity, got {type(positions)} instead.")
+        if velocities is not None and not isinstance(velocities, unit.Quantity):
+            raise TypeError(f"velocities must be a unit.Quantity, got {type(velocities)} instead.")
+        if box_vectors is not None and not isinstance(box_vectors, unit.Quantity):
+            if isinstance(box_vectors, list):
+                try:
+                    box_vectors = self._convert_from_openmm_box(box_vectors)
+                except Exception:
+                    raise TypeError(f"Unable to parse box_vectors {box_vectors}.")
+            else:
+                raise TypeError(
+                    f"box_vectors must be a unit.Quantity or openMM box, got {type(box_vectors)} instead."
+                )
+        if not positions.unit.is_compatible(unit.nanometer):
+            raise ValueError(f"positions must have units of distance, got {positions.unit} instead.")
+        if velocities is not None and not velocities.unit.is_compatible(unit.nanometer / unit.picosecond):
+            raise ValueError(
+                f"velocities must have units of distance/time, got {velocities.unit} instead."
+            )
+        if box_vectors is not None and not box_vectors.unit.is_compatible(unit.nanometer):
+            raise ValueError(f"box_vectors must have units of distance, got {box_vectors.unit} instead.")
+        if box_vectors is not None and _shape_of(box_vectors) != (3, 3):
+            raise ValueError(f"box_vectors must be a 3x3 array, got {_shape_of(box_vectors)} instead.")
+        if velocities is not None and _shape_of(positions) != _shape_of(velocities):
+            raise ValueError(
+                f"positions and velocities must have the same shape, got {_shape_of(positions)} and {_shape_of(velocities)} instead."
+            )
+        if current_PRNG_key is None:
+            raise ValueError("random_seed must be set.")
+
+        self._distance_unit = unit.nanometer
+        self._time_unit = unit.picosecond
+        # stored canonically as fp32 device tensors in nm / nm ps^-1, so the
+        # properties below are O(1) instead of a unit conversion per access
+        self._positions = self._to_md(positions)
+        self._velocities = None if velocities is None else self._to_md(velocities)
+        self._box_vectors = None if box_vectors is None else self._to_md(box_vectors)
+        self._current_PRNG_key = current_PRNG_key
+
+    def _to_md(self, q: unit.Quantity) -> unit.Quantity:
+        value = q.value_in_unit_system(unit.md_unit_system)
+        target = self._distance_unit
+        if q.unit.is_compatible(unit.nanometer / unit.picosecond):
+            target = self._distance_unit / self._time_unit
+        return unit.Quantity(as_tensor(value), target)
+
+    # -- read-only views ---------------------------------------------------
+    @property
+    def number_of_particles(self) -> int:
+        return self._positions.shape[0]
+
+    @property
+    def positions(self) -> torch.Tensor:
+        return self._positions._value
+
+    @property
+    def velocities(self) -> Optional[torch.Tensor]:
+        if self._velocities is None:
+            return None
+        return self._velocities._value
+
+    @property
+    def box_vectors(self) -> Optional[torch.Tensor]:
+        if self._box_vectors is None:
+            return None
+        return self._box_vectors._value
+
+    # -- setters (accept raw arrays in md units or Quantities) -------------
+    @positions.setter
+    def positions(self, x0: Union[torch.Tensor, np.ndarray, unit.Quantity]) -> None:
+        if isinstance(x0, unit.Quantity):
+            self._positions = self._to_md(x0)
+        else:
+            self._positions = unit.Quantity(as_tensor(x0), self._distance_unit)
+
+    @box_vectors.setter
+    def box_vectors(self, box_vectors) -> None:
+        if isinstance(box_vectors, unit.Quantity):
+            self._box_vectors = self._to_md(box_vectors)
+        else:
+            self._box_vectors = unit.Quantity(as_tensor(box_vectors), self._distance_unit)
+
+    @velocities.setter
+    def velocities(self, velocities) -> None:
+        if _shape_of(velocities) != _shape_of(self._positions):
+            raise ValueError(
+                f"velocities must have the same shape as positions, got {_shape_of(velocities)} and {_shape_of(self._positions)} instead."
+            )
+        if isinstance(velocities, unit.Quantity):
+            self._velocities = self._to_md(velocities)
+        else:
+            self._velocities = unit.Quantity(as_tensor(velocities), self._distance_unit / self._time_unit)
+
+    @property
+    def distance_unit(self) -> unit.Unit:
+        return self._distance_unit
+
+    def velocity_unit(self) -> unit.Unit:
+        return self._distance_unit / self._time_unit
+
+    @property
+    def current_PRNG_key(self) -> PRNGKey:
+        return self._current_PRNG_key
+
+    @current_PRNG_key.setter
+    def current_PRNG_key(self, key: PRNGKey) -> None:
+        self._current_PRNG_key = key
+
+    @property
+    def new_PRNG_key(self) -> PRNGKey:
+        """Split the stored key, keep one half, return the other (chiron/states.py:150-154)."""
+        key, subkey = split(self._current_PRNG_key)
+        self._current_PRNG_key = key
+        return subkey
+
+    def _convert_from_openmm_box(self, openmm_box_vectors: List) -> unit.Quantity:
+        # chiron/states.py:165-174
+        box_vec = []
+        u0 = openmm_box_vectors[0].unit
+        for i in range(3):
+            layer = []
+            for j in range(3):
+                layer.append(float(openmm_box_vectors[i][j].value_in_unit(u0)))
+            box_vec.append(layer)
+        return unit.Quantity(np.asarray(box_vec), u0)
+
+
+class ThermodynamicState:
+    """Potential + (T, V, p); provides the reduced potential (chiron/states.py:177-329)."""
+
+    def __init__(
+        self,
+        potential,
+        temperature: Optional[unit.Quantity] = None,
+        volume: Optional[unit.Quantity] = None,
+        pressure: Optional[unit.Quantity] = None,
+    ):
+        self.potential = potential
+
+        if temperature is not None and not isinstance(temperature, unit.Quantity):
+            raise TypeError(f"temperature must be a unit.Quantity, got {type(temperature)} instead.")
+        elif temperature is not None:
+            if not temperature.unit.is_compatible(unit.kelvin):
+                raise ValueError(
+                    f"temperature must have units of temperature, got {temperature.unit} instead."
+                )
+        if volume is not None and not isinstance(volume, unit.Quantity):
+            raise TypeError(f"volume must be a unit.Quantity, got {type(volume)} instead.")
+        elif volume is not None:
+            if not volume.unit.is_compatible(unit.nanometer**3):
+                raise ValueError(f"volume must have units of distance**3, got {volume.unit} instead.")
+        if pressure is not None and not isinstance(pressure, unit.Quantity):
+            raise TypeError(f"pressure must be a unit.Quantity, got {type(pressure)} instead.")
+        elif pressure is not None:
+            if not pressure.unit.is_compatible(unit.atmosphere):
+                raise ValueError(f"pressure must have units of pressure, got {pressure.unit} instead.")
+
+        self.temperature = temperature
+        if temperature is not None:
+            self.beta = 1.0 / (unit.BOLTZMANN_CONSTANT_kB * self.temperature)
+        else:
+            self.beta = None
+        self.volume = volume
+        self.pressure = pressure
+
+        from .utils import get_nr_of_particles
+
+        self.nr_of_particles = get_nr_of_particles(self.potential.topology)
+
+    def check_variables(self) -> List[str]:
+        variables = ["temperature", "volume", "pressure"]
+        return [var for var in variables if getattr(self, var) is not None]
+
+    def get_reduced_potential(self, sampler_state: SamplerState, nbr_list=None):
+        """u = beta (U/N_A + p V)  (chiron/states.py:275-325).
+
+        The potential energy comes back from the HIP kernel as a device scalar
+        and is read to the host here (the reference also synchronises at this
+        point: every caller branches on the value).
+        """
+        if self.beta is None:
+            self.beta = 1.0 / (unit.BOLTZMANN_CONSTANT_kB * (self.temperature * unit.kelvin))
+        energy = self.potential.compute_energy(sampler_state.positions, nbr_list)
+        energy = float(energy)
+        reduced_potential = unit.Quantity(energy, unit.kilojoule_per_mole) / unit.AVOGADRO_CONSTANT_NA
+        if self.pressure is not None:
+            box = sampler_state.box_vectors
+            if isinstance(box, torch.Tensor):
+                box = box.detach().cpu().numpy()
+            self.volume = (float(box[0][0]) * float(box[1][1]) * float(box[2][2])) * unit.nanometer**3
+            reduced_potential = reduced_potential + self.pressure * self.volume
+        return self.beta * reduced_potential
+
+    def kT_to_kJ_per_mol(self, energy):
+        energy = energy * unit.AVOGADRO_CONSTANT_NA
+        return energy / self.beta
+
+
+def calculate_reduced_potential_at_states(
+    sampler_state: SamplerState,
+    thermodynamic_states: List[ThermodynamicState],
+    nbr_list=None,
+) -> np.ndarray:
+    """Reduced potential of one configuration at every state (chiron/states.py:335-366)."""
+    reduced_potentials = np.zeros(len(thermodynamic_states))
+    for state_idx, state in enumerate(thermodynamic_states):
+        reduced_potentials[state_idx] = state.get_reduced_potential(sampler_state, nbr_list)
+    return reduced_potentials

@@ -1,0 +1,119 @@
+"""Minimal ``openmm.app.Topology`` / ``Element`` stand-in.
+
+The hot path only reads the particle count and per-atom element masses from a
+topology (reference: chiron/utils.py:101-113), and the tests build one with
+``Topology().addChain()/addResidue()/addAtom()`` (reference:
+chiron/tests/test_mcmc.py:382-389, Examples/LJ_MCMC.py:15-21).
+"""
+from __future__ import annotations
+
+from typing import Iterator, List, Optional
+
+from . import unit
+
+# standard atomic weights (amu) of the elements the reference systems use
+_MASSES = {
+    "H": (1, "hydrogen", 1.007947),
+    "He": (2, "helium", 4.003),
+    "C": (6, "carbon", 12.01078),
+    "N": (7, "nitrogen", 14.00672),
+    "O": (8, "oxygen", 15.99943),
+    "F": (9, "fluorine", 18.99840325),
+    "Ne": (10, "neon", 20.17976),
+    "Na": (11, "sodium", 22.989769282),
+    "P": (15, "phosphorus", 30.9737622),
+    "S": (16, "sulfur", 32.0655),
+    "Cl": (17, "chlorine", 35.4532),
+    "Ar": (18, "argon", 39.948),
+    "K": (19, "potassium", 39.09831),
+    "Kr": (36, "krypton", 83.7982),
+    "Xe": (54, "xenon", 131.2936),
+}
+
+
+class Element:
+    _by_symbol = {}
+
+    def __init__(self, number: int, name: str, symbol: str, mass):
+        self.atomic_number = number
+        self.name = name
+        self.symbol = symbol
+        if not isinstance(mass, unit.Quantity):
+            mass = unit.Quantity(mass, unit.dalton)
+        self.mass = mass
+
+    @classmethod
+    def getBySymbol(cls, symbol: str) -> "Element":
+        if symbol not in cls._by_symbol:
+            if symbol not in _MASSES:
+                raise KeyError(f"Unknown element symbol {symbol}")
+            n, name, m = _MASSES[symbol]
+            cls._by_symbol[symbol] = Element(n, name, symbol, m)
+        return cls._by_symbol[symbol]
+
+    def __repr__(self):
+        return f"<Element {self.name}>"
+
+
+class Atom:
+    def __init__(self, name: str, element: Element, index: int, residue):
+        self.name = name
+        self.element = element
+        self.index = index
+        self.residue = residue
+
+
+class Residue:
+    def __init__(self, name: str, index: int, chain):
+        self.name = name
+        self.index = index
+        self.chain = chain
+        self._atoms: List[Atom] = []
+
+
+class Chain:
+    def __init__(self, index: int, topology):
+        self.index = index
+        self.topology = topology
+        self._residues: List[Residue] = []
+
+
+class Topology:
+    def __init__(self):
+        self._chains: List[Chain] = []
+        self._atoms: List[Atom] = []
+        self._n_residues = 0
+
+    def addChain(self, id: Optional[str] = None) -> Chain:
+        c = Chain(len(self._chains), self)
+        self._chains.append(c)
+        return c
+
+    def addResidue(self, name: str, chain: Chain) -> Residue:
+        r = Residue(name, self._n_residues, chain)
+        self._n_residues += 1
+        chain._residues.append(r)
+        return r
+
+    def addAtom(self, name: str, element: Element, residue: Residue) -> Atom:
+        a = Atom(name, element, len(self._atoms), residue)
+        self._atoms.append(a)
+        residue._atoms.append(a)
+        return a
+
+    def atoms(self) -> Iterator[Atom]:
+        return iter(self._atoms)
+
+    def getNumAtoms(self) -> int:
+        return len(self._atoms)
+
+    @classmethod
+    def homogeneous(cls, n: int, symbol: str = "Ar") -> "Topology":
+        """``n`` atoms of one element in one chain/residue (LJ fluid / ideal gas)."""
+        top = cls()
+        el = Element.getBySymbol(symbol)
+        chain = top.addChain()
+        res = top.addResidue("system", chain)
+        for _ in range(n):
+            top.addAtom(symbol, el, res)
+        return top

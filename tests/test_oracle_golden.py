@@ -1,0 +1,199 @@
+"""Pin the CPU oracle against every known answer the reference's tests hold."""
+import numpy as np
+import pytest
+
+from oracle import chiron_oracle as O
+from conftest import cube_coordinates
+
+f32 = np.float32
+
+
+def test_periodic_displacement_and_wrap(golden):
+    g = golden["displacement_periodic"]
+    r, d = O.periodic_displacement(g["p1"], g["p2"], g["box"])
+    assert np.array_equal(r, np.array(g["r_ij"], dtype=f32))
+    assert np.array_equal(d, np.array(g["dist"], dtype=f32))
+    w = golden["wrap_periodic"]
+    for case in w["cases"]:
+        assert np.array_equal(O.periodic_wrap(case["x"], w["box"]), np.array(case["wrapped"], dtype=f32))
+    with pytest.raises(ValueError):
+        O.periodic_displacement(g["p1"], g["p2"], None)
+
+
+def test_nonperiodic_displacement(golden):
+    g = golden["displacement_nonperiodic"]
+    r, d = O.nonperiodic_displacement(g["p1"], g["p2"])
+    assert np.array_equal(r, np.array(g["r_ij"], dtype=f32))
+    assert np.array_equal(d, np.array(g["dist"], dtype=f32))
+
+
+def test_neighborlist_pair(golden):
+    g = golden["neighborlist_pair"]
+    x = np.array(g["coordinates"], dtype=f32)
+    nl_mask, nl, n_nbr, n_max = O.neighborlist_build(x, g["box"], g["cutoff"], g["skin"], g["n_max_neighbors"])
+    assert n_max == g["n_max_neighbors"]
+    assert nl.dtype == np.uint32
+    assert np.array_equal(nl, np.array(g["neighbor_list"]))
+    assert np.array_equal(n_nbr, np.array(g["n_neighbors"]))
+    assert np.array_equal(nl_mask, np.array(g["neighbor_mask"]))
+    n_pairs, mask, d, r = O.neighborlist_calculate(x, nl, nl_mask, g["box"], g["cutoff"])
+    assert np.array_equal(n_pairs, np.array(g["calc_n_neighbors"]))
+    assert np.array_equal(mask, np.array(g["padding_mask"]))
+    assert np.array_equal(d, np.array(g["dist"], dtype=f32))
+    assert np.array_equal(r[0], np.tile(np.array(g["r_ij_row0"], dtype=f32), (5, 1)))
+    assert np.array_equal(r[1], np.tile(np.array(g["r_ij_row1"], dtype=f32), (5, 1)))
+    assert O.neighborlist_check(x, x, g["box"], g["skin"]) is g["check_same"]
+    assert O.neighborlist_check(x + f32(g["check_shift"]), x, g["box"], g["skin"]) is g["check_shifted"]
+    assert O.neighborlist_check(np.array(g["check_changed_n"], dtype=f32), x, g["box"], g["skin"]) is True
+
+
+def test_neighborlist_cube(golden):
+    g = golden["neighborlist_cube"]
+    x = cube_coordinates(g["n_xyz"], g["scale_factor"])
+    c = g["case_all"]
+    nl_mask, nl, n_nbr, n_max = O.neighborlist_build(x, g["box"], c["cutoff"], c["skin"], c["n_max_neighbors"])
+    assert np.array_equal(n_nbr, np.array(c["n_neighbors"]))
+    n_int, _, _, _ = O.neighborlist_calculate(x, nl, nl_mask, g["box"], c["cutoff"])
+    assert np.array_equal(n_int, np.array(c["n_interacting"]))
+    c = g["case_subset"]
+    nl_mask, nl, n_nbr, n_max = O.neighborlist_build(x, g["box"], c["cutoff"], c["skin"], c["n_max_neighbors"])
+    assert n_max == c["grown_n_max"]  # growth 5 -> 7 + 10
+    assert np.array_equal(n_nbr, np.array(c["n_neighbors"]))
+    assert np.array_equal(nl, np.array(c["neighbor_list"]))
+    n_int, _, _, _ = O.neighborlist_calculate(x, nl, nl_mask, g["box"], c["cutoff"])
+    assert np.array_equal(n_int, np.array(c["n_interacting"]))
+
+
+def test_pairlist_pair(golden):
+    g = golden["pairlist_pair"]
+    x = np.array(g["coordinates"], dtype=f32)
+    all_pairs, red = O.pairlist_build(2)
+    assert np.array_equal(all_pairs, np.array(g["all_pairs"]))
+    assert np.array_equal(red, np.array(g["reduction_mask"]))
+    for cutoff in (g["cutoff"], None):
+        n_pairs, mask, d, r = O.pairlist_calculate(x, all_pairs, red, g["box"], cutoff)
+        assert np.array_equal(n_pairs, np.array(g["n_pairs"]))
+        assert np.array_equal(mask, np.array(g["mask"]))
+        assert np.array_equal(d, np.array(g["dist"], dtype=f32))
+        assert np.array_equal(r, np.array(g["displacement"], dtype=f32))
+    _, mask, _, _ = O.pairlist_calculate(x, all_pairs, red, g["box"], g["short_cutoff"])
+    assert np.array_equal(mask, np.array(g["short_cutoff_mask"]))
+    _, mask, _, _ = O.pairlist_calculate(x, all_pairs, red, g["box"], None)
+    assert np.array_equal(mask, np.array(g["no_cutoff_mask"]))
+
+
+def test_pairlist_cube(golden):
+    g = golden["pairlist_cube"]
+    box = golden["neighborlist_cube"]["box"]
+    x = cube_coordinates()
+    all_pairs, red = O.pairlist_build(8)
+    assert np.array_equal(all_pairs, np.array(g["all_pairs"]))
+    n_int, mask, d, r = O.pairlist_calculate(x, all_pairs, red, box, g["cutoff"])
+    assert np.array_equal(n_int, np.array(g["n_interacting"]))
+    assert np.array_equal(d, np.array(g["dist"], dtype=f32))
+    # mask-weighted distance sum equals the neighbor list's (test_pairs.py:471)
+    nl_mask, nl, n_nbr, n_max = O.neighborlist_build(x, box, g["cutoff"], g["skin"], 20)
+    _, mask1, d1, _ = O.neighborlist_calculate(x, nl, nl_mask, box, g["cutoff"])
+    assert np.where(mask, d, 0).sum(dtype=f32) == np.where(mask1, d1, 0).sum(dtype=f32)
+
+
+def test_nopbc_pairlist(golden):
+    g = golden["nopbc_pairlist"]
+    for case in g["two_particles_cases"]:
+        d, r, pairs = O.nopbc_pairlist(np.array(g["two_particles_nm"]), case["cutoff"])
+        assert pairs[0].size == case["n_pairs"] and pairs[1].size == case["n_pairs"]
+    d, r, pairs = O.nopbc_pairlist(np.array(g["ethanol_nm"]), g["ethanol_cutoff"])
+    assert pairs[0].size == g["ethanol_n_pairs"]
+    assert np.all(pairs[0] < pairs[1])
+
+
+def test_lennard_jones_two_particles(golden):
+    g = golden["lennard_jones_two_particles"]
+    sigma, eps, cutoff, skin = g["sigma"], g["epsilon"], g["cutoff"], g["skin"]
+    for i in range(1, 11):
+        x = np.array([[0, 0, 0], [i * 0.25 * 2 ** (1 / 6), 0, 0]], dtype=f32)
+        nl_mask, nl, n_nbr, n_max = O.neighborlist_build(x, g["box"], cutoff, skin, g["n_max_neighbors"])
+        e_pair = O.lj_energy_nopbc_f32(x, sigma, eps, cutoff)
+        e_nbr = O.lj_energy_nbrlist_f32(x, nl, nl_mask, g["box"], sigma, eps, cutoff)
+        disp = x[0] - x[1]
+        dist = np.linalg.norm(disp)
+        e_ref = 4.0 * eps * ((sigma / dist) ** 12 - (sigma / dist) ** 6)
+        assert np.isclose(e_pair, e_ref, rtol=g["energy_rtol"], atol=g["energy_atol"])
+        assert np.isclose(e_nbr, e_ref, rtol=g["energy_rtol"], atol=g["energy_atol"])
+        if i == 4:
+            assert np.isclose(e_nbr, g["energy_at_i4"], rtol=1e-5)
+        f = (24 * (eps / (dist * dist)) * (2 * (sigma / dist) ** 12 - (sigma / dist) ** 6)) * disp
+        f_ref = np.array([f, -f])
+        assert np.allclose(O.lj_force_nopbc_f32(x, sigma, eps, cutoff), f_ref, atol=g["force_atol"])
+        assert np.allclose(
+            O.lj_force_nbrlist_f32(x, nl, nl_mask, g["box"], sigma, eps, cutoff), f_ref, atol=g["force_atol"]
+        )
+        e64, f64, _, _ = O.lj_bruteforce_f64(x, g["box"], sigma, eps, cutoff)
+        assert np.isclose(e64, e_ref, rtol=1e-5) and np.allclose(f64, f_ref, atol=g["force_atol"], rtol=1e-5)
+
+
+def test_lj_default_two_particles(golden):
+    g = golden["lj_two_particle_default"]
+    # two particles closer than the 1.0 nm default cutoff (test_testsystems.py:138-156)
+    x = np.array([[0.0, 0.0, 0.0], [0.31, 0.12, -0.05]], dtype=f32)
+    d = np.linalg.norm(x[0].astype(np.float64) - x[1])
+    e_ref = 4 * g["epsilon_kj_mol"] * ((g["sigma_nm"] / d) ** 12 - (g["sigma_nm"] / d) ** 6)
+    assert np.isclose(O.lj_energy_nopbc_f32(x, g["sigma_nm"], g["epsilon_kj_mol"], g["cutoff_nm"]), e_ref, rtol=1e-5)
+
+
+def test_minimized_pair(golden):
+    g = golden["minimized_pair"]
+    x = np.array([[0, 0, 0], [g["separation"], 0, 0]], dtype=f32)
+    assert np.isclose(O.lj_energy_nopbc_f32(x, 1.0, 1.0, 3.0), g["energy"], rtol=1e-6)
+    assert np.allclose(O.lj_force_nopbc_f32(x, 1.0, 1.0, 3.0), 0.0, atol=1e-5)
+
+
+def test_methane_fixture_crosscheck(golden, methane_coords):
+    g = golden["methane"]
+    L = g["box_edge"]
+    box = np.diag([L, L, L])
+    eps = g["epsilon_kcal_mol"] * 4.184
+    e64, f64, eabs, fmax = O.lj_bruteforce_f64(methane_coords, box, g["sigma"], eps, g["cutoff"])
+    assert abs(e64 - g["build_crosscheck_energy_kj_mol"]) < 1e-3
+    # fp32 neighbor-list restatement (reference op order) agrees with fp64 within the stated tolerance
+    x = methane_coords.astype(f32)
+    nl_mask, nl, n_nbr, n_max = O.neighborlist_build(x, box, g["cutoff"], 0.4, 200)
+    e32 = O.lj_energy_nbrlist_f32(x, nl, nl_mask, box, g["sigma"], eps, g["cutoff"])
+    assert abs(float(e32) - e64) <= 1e-5 * eabs
+    f32_ = O.lj_force_nbrlist_f32(x, nl, nl_mask, box, g["sigma"], eps, g["cutoff"])
+    assert np.abs(f32_ - f64).max() <= 1e-5 * max(1.0, fmax)
+    n_pairs, _, _, _ = O.neighborlist_calculate(x, nl, nl_mask, box, g["cutoff"])
+    assert abs(int(n_pairs.sum()) - g["build_crosscheck_pairs_within_cutoff"]) <= 2
+
+
+def test_ipow_matches_repeated_multiplication():
+    x = np.linspace(0.3, 1.7, 101, dtype=f32)
+    assert np.array_equal(O.ipow(x, 6), (x * x) * ((x * x) * (x * x)))
+    x2 = x * x; x4 = x2 * x2; x8 = x4 * x4
+    assert np.array_equal(O.ipow(x, 12), x4 * x8)
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors for philox4x32-10
+    out = O.philox4x32(0, 0, 0, 0, 0, 0)
+    assert [int(v) for v in out] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    out = O.philox4x32(0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF)
+    assert [int(v) for v in out] == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    out = O.philox4x32(0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344, 0xA4093822, 0x299F31D0)
+    assert [int(v) for v in out] == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def test_philox_normals_statistics():
+    z = O.philox_normals3(200000, 7, O.STREAM_LANGEVIN, (1234, 0))
+    assert abs(z.mean()) < 5e-3 and abs(z.std() - 1.0) < 5e-3
+    assert abs(np.corrcoef(z[:, 0], z[:, 1])[0, 1]) < 1e-2
+
+
+def test_metropolis_and_reduced_potential():
+    assert O.metropolis_accept(0.5, 0.999) is True  # downhill always accepted
+    assert O.metropolis_accept(-1.0, 0.3) is True and O.metropolis_accept(-1.0, 0.4) is False
+    # ideal gas: u = beta p V (test_mcmc.py:440-448)
+    u = O.reduced_potential(0.0, 300.0, 1.0, 1000.0)
+    assert np.isclose(u, 101325.0 * 1000e-27 / (O.KB * 300.0))
+    x, box, v0, v1 = O.barostat_propose(np.ones((4, 3)), np.diag([10.0, 10.0, 10.0]), 0.1, 0.75)
+    assert np.isclose(v1 / v0, 1.05) and np.allclose(box[0, 0] ** 3, v1, rtol=1e-5)
