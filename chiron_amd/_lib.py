@@ -1,0 +1,128 @@
+"""ctypes binding of ``libchx.so`` (the C ABI declared in ``include/chx.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``chiron_amd.build``.
+There is no fallback: if the shared object is missing or a symbol cannot be
+resolved, importing the binding raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libchx.so")
+
+
+class Box(C.Structure):
+    _fields_ = [("periodic", C.c_int32), ("lx", C.c_float), ("ly", C.c_float), ("lz", C.c_float)]
+
+
+class LangevinParams(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32),
+        ("g", C.c_int32),
+        ("x4", C.c_void_p),
+        ("v", C.c_void_p),
+        ("f", C.c_void_p),
+        ("ref4", C.c_void_p),
+        ("mass", C.c_void_p),
+        ("perm", C.c_void_p),
+        ("fl", C.c_void_p),
+        ("deg", C.c_void_p),
+        ("box", Box),
+        ("wrap", C.c_int32),
+        ("skin", C.c_float),
+        ("half_dt", C.c_float),
+        ("a", C.c_float),
+        ("b", C.c_float),
+        ("kT", C.c_float),
+        ("sigma", C.c_float),
+        ("epsilon", C.c_float),
+        ("cutoff", C.c_float),
+        ("k0", C.c_uint32),
+        ("k1", C.c_uint32),
+        ("noise", C.c_void_p),
+        ("noise_step0", C.c_int64),
+        ("ctrl", C.c_void_p),
+        ("ws", C.c_void_p),
+        ("external_force", C.c_int32),
+    ]
+
+
+_P = C.c_void_p
+_I32 = C.c_int32
+_I64 = C.c_int64
+_U32 = C.c_uint32
+_F = C.c_float
+
+# name -> (restype, argtypes); must list every symbol include/chx.h declares
+SIGNATURES = {
+    "chx_version": (C.c_int, []),
+    "chx_last_error": (C.c_char_p, []),
+    "chx_cutoff_threshold_h": (_F, [_F]),
+    "chx_displacement": (C.c_int, [_P, _P, _I64, Box, _P, _P, _P]),
+    "chx_wrap": (C.c_int, [_P, _P, _I64, Box, _P]),
+    "chx_nl_build_nsq": (C.c_int, [_P, _I32, _I32, Box, _F, _P, _P, _P, _P]),
+    "chx_cell_grid_h": (_I64, [Box, _F, _I32, C.POINTER(_I32)]),
+    "chx_nl_build_cell": (
+        C.c_int,
+        [_P, _I32, _I32, Box, _F, C.POINTER(_I32), _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    ),
+    "chx_nl_calculate": (C.c_int, [_P, _P, _P, _I32, _I32, Box, _F, _P, _P, _P, _P, _P]),
+    "chx_nl_check": (C.c_int, [_P, _P, _I32, Box, _F, _P, _P]),
+    "chx_pl_build": (C.c_int, [_I32, _P, _P, _P]),
+    "chx_pl_calculate": (C.c_int, [_P, _I32, Box, _F, _P, _P, _P, _P, _P]),
+    "chx_fl_count": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P, _P]),
+    "chx_fl_fill": (C.c_int, [_P, _P, _I32, _I32, _P, _I32, _P, _P, _P]),
+    "chx_fl_sort": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
+    "chx_permute_pack": (C.c_int, [_P, _P, _I32, _P, _I32, _P]),
+    "chx_permute_unpack": (C.c_int, [_P, _I32, _P, _I32, _P, _P]),
+    "chx_invert_perm": (C.c_int, [_P, _I32, _P, _P]),
+    "chx_lj_ws_count": (_I64, [_I32]),
+    "chx_lj_fl_energy_force": (C.c_int, [_P, _P, _P, _I32, _I32, Box, _F, _F, _F, _P, _P, _P, _P]),
+    "chx_lj_allpairs_energy_force": (C.c_int, [_P, _I32, Box, _F, _F, _F, _P, _P, _P, _P]),
+    "chx_init_velocities": (C.c_int, [_P, _P, _I32, _F, _U32, _U32, _P, _P]),
+    "chx_kick": (C.c_int, [_P, _P, _P, _I32, _F, _P]),
+    "chx_langevin_chunk": (C.c_int, [C.POINTER(LangevinParams), _I64, _I32, _I32, _P]),
+    "chx_langevin_resume": (C.c_int, [C.POINTER(LangevinParams), _P]),
+    "chx_mc_displace": (C.c_int, [_P, _P, _P, _I32, _F, Box, _U32, _U32, _U32, _P, _P]),
+    "chx_scale": (C.c_int, [_P, _P, _I64, _F, _P]),
+    "chx_metropolis_select": (
+        C.c_int,
+        [_P, _P, _I64, _P, _P, _P, _U32, _U32, _U32, _F, _P, _P, _P],
+    ),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class ChxError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libchx.so and bind every symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ChxError(
+            f"{LIB_PATH} not found: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.chx_version() != 1:
+        raise ChxError(f"libchx ABI version {lib.chx_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().chx_last_error()
+        raise ChxError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,173 @@
+// Shared device helpers for libchx (gfx950 only; wavefront = 64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/chx.h"
+
+#define CHX_WAVE 64
+
+void chx_set_error(const char* fmt, ...);
+int chx_check_launch(const char* what);
+
+#define CHX_REQUIRE(cond, msg)             \
+  do {                                     \
+    if (!(cond)) {                         \
+      chx_set_error("%s: %s", __func__, msg); \
+      return CHX_ERR_INVALID;              \
+    }                                      \
+  } while (0)
+
+static inline hipStream_t chx_stream(chx_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+struct Box3 {
+  int periodic;
+  float lx, ly, lz;
+  float hx, hy, hz;  // L * 0.5f (exact)
+};
+
+static inline Box3 make_box3(chx_box_t b) {
+  Box3 r;
+  r.periodic = b.periodic;
+  r.lx = b.lx;
+  r.ly = b.ly;
+  r.lz = b.lz;
+  r.hx = b.lx * 0.5f;
+  r.hy = b.ly * 0.5f;
+  r.hz = b.lz * 0.5f;
+  return r;
+}
+
+// ---------------------------------------------------------------------------
+// exact fp32 building blocks (one IEEE rounding per operation, never contracted)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float fadd(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float fsub(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ float fmul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float fdiv(float a, float b) { return __fdiv_rn(a, b); }
+__device__ __forceinline__ float fsqrt(float a) { return __fsqrt_rn(a); }
+
+// jnp.mod(t, L) for L > 0 (lax.rem == fmod, then the sign fix-up).  fmod is
+// exact; for |t| < 2L it reduces to a compare and one exact subtraction.
+__device__ __forceinline__ float mod_floor(float t, float L) {
+  float a = fabsf(t);
+  float m;
+  if (a < L) {
+    m = t;
+  } else if (a < fmul(2.0f, L)) {
+    m = copysignf(fsub(a, L), t);  // exact by Sterbenz
+  } else {
+    m = fmodf(t, L);
+  }
+  if (m < 0.0f) m = fadd(m, L);  // (m != 0) & ((m < 0) != (L < 0)), L > 0
+  return m;
+}
+
+// chiron/neighbors.py:79: mod(r + L/2, L) - L/2
+__device__ __forceinline__ float min_image(float d, float L, float hL) {
+  return fsub(mod_floor(fadd(d, hL), L), hL);
+}
+
+// displacement r = a - b under the space's boundary conditions
+__device__ __forceinline__ void displacement(const Box3& box, float ax, float ay, float az, float bx,
+                                             float by, float bz, float& rx, float& ry, float& rz) {
+  rx = fsub(ax, bx);
+  ry = fsub(ay, by);
+  rz = fsub(az, bz);
+  if (box.periodic) {
+    rx = min_image(rx, box.lx, box.hx);
+    ry = min_image(ry, box.ly, box.hy);
+    rz = min_image(rz, box.lz, box.hz);
+  }
+}
+
+// jnp.linalg.norm squared: (x*x + y*y) + z*z
+__device__ __forceinline__ float norm2(float rx, float ry, float rz) {
+  return fadd(fadd(fmul(rx, rx), fmul(ry, ry)), fmul(rz, rz));
+}
+
+// chiron/neighbors.py:110: x - floor(x / L) * L
+__device__ __forceinline__ float wrap1(float x, float L) {
+  return fsub(x, fmul(floorf(fdiv(x, L)), L));
+}
+
+// ---------------------------------------------------------------------------
+// wavefront helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (CHX_WAVE - 1); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, CHX_WAVE);
+  return v;
+}
+
+// block-wide sum of one double per thread; result valid in thread 0
+template <int BLOCK>
+__device__ __forceinline__ double block_sum(double v) {
+  __shared__ double red[BLOCK / CHX_WAVE];
+  v = wave_sum(v);
+  if (lane_id() == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < BLOCK / CHX_WAVE; ++w) t += red[w];
+  }
+  return t;
+}
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 (Random123) and the normal draw shared by every stochastic kernel
+// ---------------------------------------------------------------------------
+#define CHX_STREAM_VELOCITY 0u
+#define CHX_STREAM_LANGEVIN 1u
+#define CHX_STREAM_MC_DISPLACE 2u
+#define CHX_STREAM_UNIFORM 3u
+
+__device__ __forceinline__ uint4 philox4x32(uint4 c, uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
+    uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+
+__device__ __forceinline__ float u32_to_uniform(uint32_t x) {
+  // 23 random bits: (x>>9) + 0.5 and the 2^-23 scale are both exact in fp32
+  return fmul(fadd((float)(x >> 9), 0.5f), 1.0f / 8388608.0f);
+}
+
+// three N(0,1) for (index, step) of `stream`: Box-Muller on one Philox block
+__device__ __forceinline__ void philox_normals3(uint32_t index, uint32_t step, uint32_t stream,
+                                                uint32_t k0, uint32_t k1, float& z0, float& z1,
+                                                float& z2) {
+  uint4 o = philox4x32(make_uint4(index, step, 0u, stream), k0, k1);
+  float u0 = u32_to_uniform(o.x), u1 = u32_to_uniform(o.y);
+  float u2 = u32_to_uniform(o.z), u3 = u32_to_uniform(o.w);
+  const float two_pi = 6.283185307179586f;
+  float r01 = fsqrt(fmul(-2.0f, logf(u0)));
+  float r23 = fsqrt(fmul(-2.0f, logf(u2)));
+  float t1 = fmul(two_pi, u1), t3 = fmul(two_pi, u3);
+  z0 = fmul(r01, cosf(t1));
+  z1 = fmul(r01, sinf(t1));
+  z2 = fmul(r23, cosf(t3));
+}
+
+// LJ pair terms from r2 (within cutoff): e = 4 eps (s^12 - s^6), fs = 24 eps (2 s^12 - s^6) / r2
+__device__ __forceinline__ void lj_pair(float r2, float sig2, float eps4, float eps24, float& e,
+                                        float& fs) {
+  float inv = 1.0f / r2;
+  float s2 = sig2 * inv;
+  float s6 = s2 * s2 * s2;
+  float s12 = s6 * s6;
+  e = eps4 * (s12 - s6);
+  fs = eps24 * (2.0f * s12 - s6) * inv;
+}

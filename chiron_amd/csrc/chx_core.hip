@@ -1,0 +1,177 @@
+// libchx: error plumbing, host helpers, Space kernels (displacement / wrap),
+// permutation helpers and small elementwise kernels.
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include "chx_common.h"
+
+static thread_local char g_err[512] = "";
+
+void chx_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int chx_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    chx_set_error("%s: %s", what, hipGetErrorString(e));
+    return CHX_ERR_LAUNCH;
+  }
+  return CHX_OK;
+}
+
+extern "C" int chx_version(void) { return CHX_ABI_VERSION; }
+extern "C" const char* chx_last_error(void) { return g_err; }
+
+// Largest fp32 t with sqrtf(t) < c.  Host sqrtf is correctly rounded and
+// monotone, as is the device __fsqrt_rn, so the equivalence is exact.
+extern "C" float chx_cutoff_threshold_h(float c) {
+  if (!(c > 0.0f)) return -1.0f;  // sqrt(t) < c impossible for t >= 0 -> r2 <= -1 never true
+  if (isinf(c)) return INFINITY;
+  float t = c * c;
+  while (sqrtf(t) < c) t = nextafterf(t, INFINITY);
+  while (!(sqrtf(t) < c)) t = nextafterf(t, -INFINITY);
+  return t;
+}
+
+// ---------------------------------------------------------------------------
+// Space.displacement / Space.wrap
+// ---------------------------------------------------------------------------
+__global__ void k_displacement(const float* __restrict__ x1, const float* __restrict__ x2, int64_t n,
+                               Box3 box, float* __restrict__ rij, float* __restrict__ dist) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float rx, ry, rz;
+  displacement(box, x1[3 * i], x1[3 * i + 1], x1[3 * i + 2], x2[3 * i], x2[3 * i + 1],
+               x2[3 * i + 2], rx, ry, rz);
+  rij[3 * i] = rx;
+  rij[3 * i + 1] = ry;
+  rij[3 * i + 2] = rz;
+  dist[i] = fsqrt(norm2(rx, ry, rz));
+}
+
+extern "C" int chx_displacement(const float* x1, const float* x2, int64_t n, chx_box_t box,
+                                float* rij_out, float* dist_out, chx_stream_t stream) {
+  CHX_REQUIRE(n >= 0, "n < 0");
+  if (n == 0) return CHX_OK;
+  CHX_REQUIRE(x1 && x2 && rij_out && dist_out, "null pointer");
+  CHX_REQUIRE(!box.periodic || (box.lx > 0 && box.ly > 0 && box.lz > 0), "box lengths must be > 0");
+  int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(k_displacement, dim3((unsigned)blocks), dim3(256), 0, chx_stream(stream), x1, x2,
+                     n, make_box3(box), rij_out, dist_out);
+  return chx_check_launch("chx_displacement");
+}
+
+__global__ void k_wrap(const float* __restrict__ xin, float* __restrict__ xout, int64_t n, Box3 box) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x = xin[3 * i], y = xin[3 * i + 1], z = xin[3 * i + 2];
+  if (box.periodic) {
+    x = wrap1(x, box.lx);
+    y = wrap1(y, box.ly);
+    z = wrap1(z, box.lz);
+  }
+  xout[3 * i] = x;
+  xout[3 * i + 1] = y;
+  xout[3 * i + 2] = z;
+}
+
+extern "C" int chx_wrap(const float* xin, float* xout, int64_t n, chx_box_t box,
+                        chx_stream_t stream) {
+  CHX_REQUIRE(n >= 0, "n < 0");
+  if (n == 0) return CHX_OK;
+  CHX_REQUIRE(xin && xout, "null pointer");
+  CHX_REQUIRE(!box.periodic || (box.lx > 0 && box.ly > 0 && box.lz > 0), "box lengths must be > 0");
+  int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(k_wrap, dim3((unsigned)blocks), dim3(256), 0, chx_stream(stream), xin, xout, n,
+                     make_box3(box));
+  return chx_check_launch("chx_wrap");
+}
+
+// ---------------------------------------------------------------------------
+// permutation helpers (internal particle order <-> user order)
+// ---------------------------------------------------------------------------
+__global__ void k_permute_pack(const float* __restrict__ src3, const uint32_t* __restrict__ perm,
+                               int n, float* __restrict__ dst, int stride) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  uint32_t o = perm ? perm[p] : (uint32_t)p;
+  float a = src3[3 * (size_t)o], b = src3[3 * (size_t)o + 1], c = src3[3 * (size_t)o + 2];
+  if (stride == 4) {
+    reinterpret_cast<float4*>(dst)[p] = make_float4(a, b, c, 0.0f);
+  } else {
+    dst[3 * (size_t)p] = a;
+    dst[3 * (size_t)p + 1] = b;
+    dst[3 * (size_t)p + 2] = c;
+  }
+}
+
+extern "C" int chx_permute_pack(const float* src3, const uint32_t* perm, int32_t n, float* dst,
+                                int32_t dst_stride, chx_stream_t stream) {
+  CHX_REQUIRE(n >= 0, "n < 0");
+  CHX_REQUIRE(dst_stride == 3 || dst_stride == 4, "dst_stride must be 3 or 4");
+  if (n == 0) return CHX_OK;
+  CHX_REQUIRE(src3 && dst, "null pointer");
+  hipLaunchKernelGGL(k_permute_pack, dim3((n + 255) / 256), dim3(256), 0, chx_stream(stream), src3,
+                     perm, n, dst, dst_stride);
+  return chx_check_launch("chx_permute_pack");
+}
+
+__global__ void k_permute_unpack(const float* __restrict__ src, int stride,
+                                 const uint32_t* __restrict__ perm, int n, float* __restrict__ dst3) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  uint32_t o = perm ? perm[p] : (uint32_t)p;
+  float a = src[(size_t)stride * p], b = src[(size_t)stride * p + 1], c = src[(size_t)stride * p + 2];
+  dst3[3 * (size_t)o] = a;
+  dst3[3 * (size_t)o + 1] = b;
+  dst3[3 * (size_t)o + 2] = c;
+}
+
+extern "C" int chx_permute_unpack(const float* src, int32_t src_stride, const uint32_t* perm,
+                                  int32_t n, float* dst3, chx_stream_t stream) {
+  CHX_REQUIRE(n >= 0, "n < 0");
+  CHX_REQUIRE(src_stride == 3 || src_stride == 4, "src_stride must be 3 or 4");
+  if (n == 0) return CHX_OK;
+  CHX_REQUIRE(src && dst3, "null pointer");
+  hipLaunchKernelGGL(k_permute_unpack, dim3((n + 255) / 256), dim3(256), 0, chx_stream(stream), src,
+                     src_stride, perm, n, dst3);
+  return chx_check_launch("chx_permute_unpack");
+}
+
+__global__ void k_invert_perm(const uint32_t* __restrict__ perm, int n, uint32_t* __restrict__ inv) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) inv[perm[p]] = (uint32_t)p;
+}
+
+extern "C" int chx_invert_perm(const uint32_t* perm, int32_t n, uint32_t* inv_out,
+                               chx_stream_t stream) {
+  CHX_REQUIRE(n >= 0, "n < 0");
+  if (n == 0) return CHX_OK;
+  CHX_REQUIRE(perm && inv_out, "null pointer");
+  hipLaunchKernelGGL(k_invert_perm, dim3((n + 255) / 256), dim3(256), 0, chx_stream(stream), perm, n,
+                     inv_out);
+  return chx_check_launch("chx_invert_perm");
+}
+
+// ---------------------------------------------------------------------------
+// barostat geometry: out = in * s  (chiron/mcmc.py:977-983)
+// ---------------------------------------------------------------------------
+__global__ void k_scale(const float* __restrict__ in, float* __restrict__ out, int64_t count, float s) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = fmul(in[i], s);
+}
+
+extern "C" int chx_scale(const float* in, float* out, int64_t count, float s, chx_stream_t stream) {
+  CHX_REQUIRE(count >= 0, "count < 0");
+  if (count == 0) return CHX_OK;
+  CHX_REQUIRE(in && out, "null pointer");
+  int64_t blocks = (count + 255) / 256;
+  hipLaunchKernelGGL(k_scale, dim3((unsigned)blocks), dim3(256), 0, chx_stream(stream), in, out,
+                     count, s);
+  return chx_check_launch("chx_scale");
+}

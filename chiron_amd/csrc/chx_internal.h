@@ -1,0 +1,15 @@
+// Internal (non-exported) launch helpers shared between translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/chx.h"
+
+// ctrl != NULL: the kernel is part of a Langevin chunk and turns into a no-op
+// (setting ctrl[1]) when ctrl[0] says the skin check fired.
+int chx_launch_lj_fl(const float* x4, const uint32_t* fl, const int32_t* deg, int n, int g,
+                     chx_box_t box, float sigma, float epsilon, float cutoff, float* f3,
+                     float* energy, double* ws, int32_t* ctrl, hipStream_t st);
+int chx_launch_lj_allpairs(const float* x, int stride, int n, chx_box_t box, float sigma,
+                           float epsilon, float cutoff, float* f3, float* energy, double* ws,
+                           int32_t* ctrl, hipStream_t st);

@@ -1,0 +1,310 @@
+// libchx: BAOAB Langevin integrator (chiron/integrators.py:126-195), velocity
+// initialisation (chiron/utils.py:116-144), Monte-Carlo proposal / Metropolis
+// kernels (chiron/mcmc.py:531-548, :724-755).
+//
+// One MD step = two launches: a fused per-particle integrate kernel
+//   [B (trailing, previous step)] B A O A wrap skin-check
+// and the pair-force kernel.  The arithmetic keeps the reference's operation
+// order and one rounding per operation, so with injected noise a trajectory
+// matches the fp32 oracle up to the force summation order.
+#include "chx_common.h"
+#include "chx_internal.h"
+
+// ---------------------------------------------------------------------------
+// velocities
+// ---------------------------------------------------------------------------
+__global__ void k_init_velocities(float* __restrict__ v, const float* __restrict__ mass, int n,
+                                  float kT, uint32_t k0, uint32_t k1,
+                                  const float* __restrict__ normals) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float z0, z1, z2;
+  if (normals) {
+    z0 = normals[3 * (size_t)i];
+    z1 = normals[3 * (size_t)i + 1];
+    z2 = normals[3 * (size_t)i + 2];
+  } else {
+    philox_normals3((uint32_t)i, 0u, CHX_STREAM_VELOCITY, k0, k1, z0, z1, z2);
+  }
+  const float sv = fsqrt(fdiv(kT, mass[i]));  // chiron/utils.py:140
+  v[3 * (size_t)i] = fmul(sv, z0);
+  v[3 * (size_t)i + 1] = fmul(sv, z1);
+  v[3 * (size_t)i + 2] = fmul(sv, z2);
+}
+
+extern "C" int chx_init_velocities(float* v_out, const float* mass, int32_t n, float kT,
+                                   uint32_t k0, uint32_t k1, const float* normals,
+                                   chx_stream_t stream) {
+  CHX_REQUIRE(n >= 0, "n < 0");
+  if (n == 0) return CHX_OK;
+  CHX_REQUIRE(v_out && mass, "null pointer");
+  hipLaunchKernelGGL(k_init_velocities, dim3((n + 255) / 256), dim3(256), 0, chx_stream(stream),
+                     v_out, mass, n, kT, k0, k1, normals);
+  return chx_check_launch("chx_init_velocities");
+}
+
+__global__ void k_kick(float* __restrict__ v, const float* __restrict__ f,
+                       const float* __restrict__ mass, int n, float hdt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float m = mass[i];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const size_t a = 3 * (size_t)i + c;
+    v[a] = fadd(v[a], fdiv(fmul(hdt, f[a]), m));  // chiron/integrators.py:195
+  }
+}
+
+extern "C" int chx_kick(float* v, const float* f, const float* mass, int32_t n, float half_dt,
+                        chx_stream_t stream) {
+  CHX_REQUIRE(n >= 0, "n < 0");
+  if (n == 0) return CHX_OK;
+  CHX_REQUIRE(v && f && mass, "null pointer");
+  hipLaunchKernelGGL(k_kick, dim3((n + 255) / 256), dim3(256), 0, chx_stream(stream), v, f, mass, n,
+                     half_dt);
+  return chx_check_launch("chx_kick");
+}
+
+// ---------------------------------------------------------------------------
+// fused integrate kernel
+// ---------------------------------------------------------------------------
+struct BaoabArgs {
+  int n;
+  float4* x4;
+  float* v;
+  const float* f;
+  const float4* ref4;
+  const float* mass;
+  const uint32_t* perm;
+  Box3 box;
+  int wrap;
+  float T_half_skin;
+  float hdt, a, b, kT;
+  uint32_t k0, k1;
+  const float* noise;
+  long long noise_step0;
+  int32_t* ctrl;
+};
+
+__global__ __launch_bounds__(256) void k_baoab(BaoabArgs p, long long step, int n_kicks) {
+  if (p.ctrl[1] != 0) return;  // halted by an earlier step of this chunk
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= p.n) return;
+  float4 x = p.x4[s];
+  float vx = p.v[3 * (size_t)s], vy = p.v[3 * (size_t)s + 1], vz = p.v[3 * (size_t)s + 2];
+  const float fx = p.f[3 * (size_t)s], fy = p.f[3 * (size_t)s + 1], fz = p.f[3 * (size_t)s + 2];
+  const float m = p.mass[s];
+  const float hdt = p.hdt;
+  // B: v += (dt/2) F / m            chiron/integrators.py:181 (and :195 of the previous step)
+  for (int k = 0; k < n_kicks; ++k) {
+    vx = fadd(vx, fdiv(fmul(hdt, fx), m));
+    vy = fadd(vy, fdiv(fmul(hdt, fy), m));
+    vz = fadd(vz, fdiv(fmul(hdt, fz), m));
+  }
+  // A: x += (dt/2) v                :183
+  x.x = fadd(x.x, fmul(hdt, vx));
+  x.y = fadd(x.y, fmul(hdt, vy));
+  x.z = fadd(x.z, fmul(hdt, vz));
+  // O: v = a v + b sigma_v xi       :185-186
+  const uint32_t o = p.perm ? p.perm[s] : (uint32_t)s;
+  float z0, z1, z2;
+  if (p.noise) {
+    const size_t row = ((size_t)(step - p.noise_step0) * (size_t)p.n + o) * 3;
+    z0 = p.noise[row];
+    z1 = p.noise[row + 1];
+    z2 = p.noise[row + 2];
+  } else {
+    philox_normals3(o, (uint32_t)step, CHX_STREAM_LANGEVIN, p.k0, p.k1, z0, z1, z2);
+  }
+  const float bs = fmul(p.b, fsqrt(fdiv(p.kT, m)));  // b * sigma_v, sigma_v = sqrt(kT/m) (:131)
+  vx = fadd(fmul(p.a, vx), fmul(bs, z0));
+  vy = fadd(fmul(p.a, vy), fmul(bs, z1));
+  vz = fadd(fmul(p.a, vz), fmul(bs, z2));
+  // A                               :188
+  x.x = fadd(x.x, fmul(hdt, vx));
+  x.y = fadd(x.y, fmul(hdt, vy));
+  x.z = fadd(x.z, fmul(hdt, vz));
+  // wrap                            :239
+  if (p.wrap && p.box.periodic) {
+    x.x = wrap1(x.x, p.box.lx);
+    x.y = wrap1(x.y, p.box.ly);
+    x.z = wrap1(x.z, p.box.lz);
+  }
+  p.x4[s] = x;
+  p.v[3 * (size_t)s] = vx;
+  p.v[3 * (size_t)s + 1] = vy;
+  p.v[3 * (size_t)s + 2] = vz;
+  // skin check                      :241, chiron/neighbors.py:864-868
+  if (p.ref4) {
+    const float4 r = p.ref4[s];
+    float rx, ry, rz;
+    displacement(p.box, x.x, x.y, x.z, r.x, r.y, r.z, rx, ry, rz);
+    if (norm2(rx, ry, rz) > p.T_half_skin) {
+      p.ctrl[2] = (int32_t)step;
+      p.ctrl[0] = 1;
+    }
+  }
+}
+
+static int validate_langevin(const chx_langevin_t* p) {
+  CHX_REQUIRE(p, "null params");
+  CHX_REQUIRE(p->n >= 1, "n < 1");
+  CHX_REQUIRE(p->x4 && p->v && p->f && p->mass && p->ctrl, "null pointer");
+  CHX_REQUIRE(!p->fl || p->deg, "force list without degrees");
+  CHX_REQUIRE(!p->box.periodic || (p->box.lx > 0 && p->box.ly > 0 && p->box.lz > 0),
+              "box lengths must be > 0");
+  CHX_REQUIRE(!(p->fl) || p->g >= 1, "bad g");
+  return CHX_OK;
+}
+
+static int launch_force(const chx_langevin_t* p, int32_t* ctrl, hipStream_t st) {
+  if (p->external_force) return CHX_OK;
+  if (p->fl) {
+    return chx_launch_lj_fl(p->x4, p->fl, p->deg, p->n, p->g, p->box, p->sigma, p->epsilon, p->cutoff,
+                            p->f, nullptr, p->ws, ctrl, st);
+  }
+  // no neighbor list: reference semantics are the no-PBC all-pairs branch when no list was
+  // given (box.periodic == 0) and the PBC pair list otherwise
+  return chx_launch_lj_allpairs(p->x4, 4, p->n, p->box, p->sigma, p->epsilon, p->cutoff, p->f, nullptr,
+                                p->ws, ctrl, st);
+}
+
+extern "C" int chx_langevin_chunk(const chx_langevin_t* p, int64_t step0, int32_t n_steps,
+                                  int32_t kicks_first, chx_stream_t stream) {
+  int rc = validate_langevin(p);
+  if (rc != CHX_OK) return rc;
+  CHX_REQUIRE(n_steps >= 0, "n_steps < 0");
+  CHX_REQUIRE(kicks_first >= 0 && kicks_first <= 2, "kicks_first must be 0, 1 or 2");
+  CHX_REQUIRE(step0 >= 0 && step0 + n_steps < (1ll << 31), "step index out of range");
+  hipStream_t st = chx_stream(stream);
+  BaoabArgs a;
+  a.n = p->n;
+  a.x4 = reinterpret_cast<float4*>(p->x4);
+  a.v = p->v;
+  a.f = p->f;
+  a.ref4 = reinterpret_cast<const float4*>(p->ref4);
+  a.mass = p->mass;
+  a.perm = p->perm;
+  a.box = make_box3(p->box);
+  a.wrap = p->wrap;
+  a.T_half_skin = chx_cutoff_threshold_h(p->skin * 0.5f);
+  a.hdt = p->half_dt;
+  a.a = p->a;
+  a.b = p->b;
+  a.kT = p->kT;
+  a.k0 = p->k0;
+  a.k1 = p->k1;
+  a.noise = p->noise;
+  a.noise_step0 = p->noise_step0;
+  a.ctrl = p->ctrl;
+  const unsigned blocks = (unsigned)((p->n + 255) / 256);
+  for (int s = 0; s < n_steps; ++s) {
+    hipLaunchKernelGGL(k_baoab, dim3(blocks), dim3(256), 0, st, a, (long long)(step0 + s),
+                       s == 0 ? kicks_first : 2);
+    rc = launch_force(p, p->ctrl, st);
+    if (rc != CHX_OK) return rc;
+  }
+  return chx_check_launch("chx_langevin_chunk");
+}
+
+extern "C" int chx_langevin_resume(const chx_langevin_t* p, chx_stream_t stream) {
+  int rc = validate_langevin(p);
+  if (rc != CHX_OK) return rc;
+  rc = launch_force(p, nullptr, chx_stream(stream));
+  if (rc != CHX_OK) return rc;
+  return chx_check_launch("chx_langevin_resume");
+}
+
+// ---------------------------------------------------------------------------
+// Monte Carlo
+// ---------------------------------------------------------------------------
+__global__ void k_mc_displace(const float* __restrict__ x, float* __restrict__ xo,
+                              const float* __restrict__ subset, int n, float sigma_d, Box3 box,
+                              uint32_t k0, uint32_t k1, uint32_t ctr,
+                              const float* __restrict__ normals) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float z0, z1, z2;
+  if (normals) {
+    z0 = normals[3 * (size_t)i];
+    z1 = normals[3 * (size_t)i + 1];
+    z2 = normals[3 * (size_t)i + 2];
+  } else {
+    philox_normals3((uint32_t)i, ctr, CHX_STREAM_MC_DISPLACE, k0, k1, z0, z1, z2);
+  }
+  // normal * sigma [* mask] then x + d   (chiron/mcmc.py:733-748)
+  float dx = fmul(z0, sigma_d), dy = fmul(z1, sigma_d), dz = fmul(z2, sigma_d);
+  if (subset) {
+    const float mk = subset[i];
+    dx = fmul(dx, mk);
+    dy = fmul(dy, mk);
+    dz = fmul(dz, mk);
+  }
+  float a = fadd(x[3 * (size_t)i], dx), b = fadd(x[3 * (size_t)i + 1], dy),
+        c = fadd(x[3 * (size_t)i + 2], dz);
+  if (box.periodic) {  // wrap only when a neighbor list is in play (:751-755)
+    a = wrap1(a, box.lx);
+    b = wrap1(b, box.ly);
+    c = wrap1(c, box.lz);
+  }
+  xo[3 * (size_t)i] = a;
+  xo[3 * (size_t)i + 1] = b;
+  xo[3 * (size_t)i + 2] = c;
+}
+
+extern "C" int chx_mc_displace(const float* x, float* x_out, const float* subset_mask, int32_t n,
+                               float sigma_d, chx_box_t box, uint32_t k0, uint32_t k1, uint32_t ctr,
+                               const float* normals, chx_stream_t stream) {
+  CHX_REQUIRE(n >= 0, "n < 0");
+  if (n == 0) return CHX_OK;
+  CHX_REQUIRE(x && x_out, "null pointer");
+  CHX_REQUIRE(!box.periodic || (box.lx > 0 && box.ly > 0 && box.lz > 0), "box lengths must be > 0");
+  hipLaunchKernelGGL(k_mc_displace, dim3((n + 255) / 256), dim3(256), 0, chx_stream(stream), x, x_out,
+                     subset_mask, n, sigma_d, make_box3(box), k0, k1, ctr, normals);
+  return chx_check_launch("chx_mc_displace");
+}
+
+__global__ void k_metropolis_decide(const float* __restrict__ log_ratio, float* __restrict__ u_cur,
+                                    const float* __restrict__ u_prop, uint32_t k0, uint32_t k1,
+                                    uint32_t ctr, float uniform_h, int32_t* __restrict__ accepted,
+                                    int32_t* __restrict__ counters) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const float lp = log_ratio[0];
+  const float up = u_prop ? u_prop[0] : 0.0f;
+  float U = uniform_h;
+  if (!(U >= 0.0f)) U = u32_to_uniform(philox4x32(make_uint4(0u, ctr, 0u, CHX_STREAM_UNIFORM), k0, k1).x);
+  int acc = 0;
+  if (!isnan(up) && !isnan(lp)) {             // chiron/mcmc.py:428-429
+    acc = (-lp <= 0.0f || U < expf(lp)) ? 1 : 0;  // :544-545
+  }
+  accepted[0] = acc;
+  if (counters) {
+    counters[0] += acc;
+    counters[1] += 1;
+  }
+  if (acc && u_cur && u_prop) u_cur[0] = up;
+}
+
+__global__ void k_select(float* __restrict__ cur, const float* __restrict__ prop, int64_t count,
+                         const int32_t* __restrict__ accepted) {
+  if (accepted[0] == 0) return;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) cur[i] = prop[i];
+}
+
+extern "C" int chx_metropolis_select(float* x_cur, const float* x_prop, int64_t count,
+                                     const float* log_ratio, float* u_cur, const float* u_prop,
+                                     uint32_t k0, uint32_t k1, uint32_t ctr, float uniform_h,
+                                     int32_t* accepted_out, int32_t* counters, chx_stream_t stream) {
+  CHX_REQUIRE(count >= 0, "count < 0");
+  CHX_REQUIRE(log_ratio && accepted_out, "null pointer");
+  hipStream_t st = chx_stream(stream);
+  hipLaunchKernelGGL(k_metropolis_decide, dim3(1), dim3(64), 0, st, log_ratio, u_cur, u_prop, k0, k1,
+                     ctr, uniform_h, accepted_out, counters);
+  if (count > 0) {
+    CHX_REQUIRE(x_cur && x_prop, "null pointer");
+    hipLaunchKernelGGL(k_select, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, x_cur, x_prop,
+                       count, accepted_out);
+  }
+  return chx_check_launch("chx_metropolis_select");
+}

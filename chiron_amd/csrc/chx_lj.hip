@@ -1,0 +1,435 @@
+// libchx: Lennard-Jones energy/force kernels.
+//
+//  * force list (full neighbor table derived from the reference half list)
+//  * list kernel: G lanes cooperate on one particle, coalesced index reads,
+//    float4 gathers of neighbor positions, DPP/shuffle reduction, no atomics
+//  * all-pairs kernel: LDS-staged particle tiles, 16 lanes per particle
+//
+// Pair geometry always follows the reference: r_ij = x_lo - x_hi (lo/hi by ORIGINAL
+// particle id, chiron/neighbors.py:773-779), min-imaged as in :79, and the cutoff
+// mask is the exact `d < cutoff` of :782, so the set of interacting pairs is
+// bit-identical to the reference's; only the summation order differs.
+#include "chx_common.h"
+#include "chx_internal.h"
+
+// ---------------------------------------------------------------------------
+// force list construction
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ size_t fl_addr(int p, int k, int n, int g) {
+  return ((size_t)(k / g) * (size_t)n + (size_t)p) * (size_t)g + (size_t)(k % g);
+}
+
+__global__ __launch_bounds__(256) void k_fl_count(const uint32_t* __restrict__ nl,
+                                                  const int32_t* __restrict__ n_nbr, int n, int m,
+                                                  const uint32_t* __restrict__ inv,
+                                                  int32_t* __restrict__ deg) {
+  const int lane = lane_id();
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (i >= n) return;
+  int cnt = n_nbr[i];
+  cnt = cnt < m ? cnt : m;
+  for (int k = lane; k < cnt; k += CHX_WAVE) {
+    uint32_t j = nl[(size_t)i * m + k];
+    atomicAdd(&deg[inv ? inv[j] : j], 1);
+  }
+  if (lane == 0 && cnt > 0) atomicAdd(&deg[inv ? inv[i] : (uint32_t)i], cnt);
+}
+
+__global__ void k_imax(const int32_t* __restrict__ v, int n, int32_t* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int x = i < n ? v[i] : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    int y = __shfl_xor(x, o, CHX_WAVE);
+    x = y > x ? y : x;
+  }
+  if (lane_id() == 0 && x > 0) atomicMax(out, x);
+}
+
+extern "C" int chx_fl_count(const uint32_t* nl, const int32_t* n_nbr, int32_t n, int32_t m,
+                            const uint32_t* inv, int32_t* deg_out, int32_t* maxdeg_out,
+                            chx_stream_t stream) {
+  CHX_REQUIRE(n >= 0 && m >= 1, "need n >= 0, m >= 1");
+  CHX_REQUIRE(maxdeg_out, "null pointer");
+  hipStream_t st = chx_stream(stream);
+  if (hipMemsetAsync(maxdeg_out, 0, sizeof(int32_t), st) != hipSuccess) {
+    chx_set_error("chx_fl_count: hipMemsetAsync failed");
+    return CHX_ERR_LAUNCH;
+  }
+  if (n == 0) return CHX_OK;
+  CHX_REQUIRE(nl && n_nbr && deg_out, "null pointer");
+  if (hipMemsetAsync(deg_out, 0, sizeof(int32_t) * (size_t)n, st) != hipSuccess) {
+    chx_set_error("chx_fl_count: hipMemsetAsync failed");
+    return CHX_ERR_LAUNCH;
+  }
+  const unsigned wb = (unsigned)(((int64_t)n * CHX_WAVE + 255) / 256);
+  hipLaunchKernelGGL(k_fl_count, dim3(wb), dim3(256), 0, st, nl, n_nbr, n, m, inv, deg_out);
+  hipLaunchKernelGGL(k_imax, dim3((n + 255) / 256), dim3(256), 0, st, deg_out, n, maxdeg_out);
+  return chx_check_launch("chx_fl_count");
+}
+
+__global__ __launch_bounds__(256) void k_fl_fill(const uint32_t* __restrict__ nl,
+                                                 const int32_t* __restrict__ n_nbr, int n, int m,
+                                                 const uint32_t* __restrict__ inv, int g,
+                                                 int32_t* __restrict__ cursor,
+                                                 uint32_t* __restrict__ fl) {
+  const int lane = lane_id();
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (i >= n) return;
+  int cnt = n_nbr[i];
+  cnt = cnt < m ? cnt : m;
+  if (cnt == 0) return;
+  const uint32_t si = inv ? inv[i] : (uint32_t)i;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(&cursor[si], cnt);
+  base = __shfl(base, 0, CHX_WAVE);
+  for (int k = lane; k < cnt; k += CHX_WAVE) {
+    const uint32_t j = nl[(size_t)i * m + k];  // j > i in original ids
+    const uint32_t sj = inv ? inv[j] : j;
+    fl[fl_addr((int)si, base + k, n, g)] = sj | CHX_FL_HI;
+    const int slot = atomicAdd(&cursor[sj], 1);
+    fl[fl_addr((int)sj, slot, n, g)] = si;
+  }
+}
+
+extern "C" int chx_fl_fill(const uint32_t* nl, const int32_t* n_nbr, int32_t n, int32_t m,
+                           const uint32_t* inv, int32_t g, int32_t* cursor_ws, uint32_t* fl_out,
+                           chx_stream_t stream) {
+  CHX_REQUIRE(n >= 0 && m >= 1, "need n >= 0, m >= 1");
+  CHX_REQUIRE(g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64,
+              "g must be a power of two <= 64");
+  if (n == 0) return CHX_OK;
+  CHX_REQUIRE(nl && n_nbr && cursor_ws && fl_out, "null pointer");
+  hipStream_t st = chx_stream(stream);
+  if (hipMemsetAsync(cursor_ws, 0, sizeof(int32_t) * (size_t)n, st) != hipSuccess) {
+    chx_set_error("chx_fl_fill: hipMemsetAsync failed");
+    return CHX_ERR_LAUNCH;
+  }
+  const unsigned wb = (unsigned)(((int64_t)n * CHX_WAVE + 255) / 256);
+  hipLaunchKernelGGL(k_fl_fill, dim3(wb), dim3(256), 0, st, nl, n_nbr, n, m, inv, g, cursor_ws,
+                     fl_out);
+  return chx_check_launch("chx_fl_fill");
+}
+
+// 64 particles per block, each thread insertion-sorts its own column of an LDS tile
+__global__ __launch_bounds__(64) void k_fl_sort(uint32_t* __restrict__ fl,
+                                                const int32_t* __restrict__ deg, int n, int g) {
+  extern __shared__ uint32_t tile[];  // [maxdeg][64]
+  const int t = threadIdx.x;
+  const int p = blockIdx.x * 64 + t;
+  if (p >= n) return;
+  const int d = deg[p];
+  for (int k = 0; k < d; ++k) tile[k * 64 + t] = fl[fl_addr(p, k, n, g)];
+  for (int a = 1; a < d; ++a) {
+    const uint32_t v = tile[a * 64 + t];
+    const uint32_t key = v & ~CHX_FL_HI;
+    int b = a - 1;
+    while (b >= 0 && (tile[b * 64 + t] & ~CHX_FL_HI) > key) {
+      tile[(b + 1) * 64 + t] = tile[b * 64 + t];
+      --b;
+    }
+    tile[(b + 1) * 64 + t] = v;
+  }
+  for (int k = 0; k < d; ++k) fl[fl_addr(p, k, n, g)] = tile[k * 64 + t];
+}
+
+extern "C" int chx_fl_sort(uint32_t* fl, const int32_t* deg, int32_t n, int32_t g, int32_t maxdeg,
+                           chx_stream_t stream) {
+  CHX_REQUIRE(n >= 0 && maxdeg >= 0, "need n >= 0, maxdeg >= 0");
+  if (n == 0 || maxdeg <= 1) return CHX_OK;
+  CHX_REQUIRE(fl && deg, "null pointer");
+  const size_t lds = (size_t)maxdeg * 64 * sizeof(uint32_t);
+  if (lds > 64 * 1024) {
+    chx_set_error("chx_fl_sort: maxdeg %d exceeds the on-chip tile (rows stay unsorted)", maxdeg);
+    return CHX_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(k_fl_sort, dim3((n + 63) / 64), dim3(64), lds, chx_stream(stream), fl, deg, n, g);
+  return chx_check_launch("chx_fl_sort");
+}
+
+// ---------------------------------------------------------------------------
+// energy reduction: per-block fp64 partials -> one fp32 scalar (fixed order)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sum_ws(const double* __restrict__ ws, int count,
+                                                float* __restrict__ out) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < count; i += 256) s += ws[i];
+  s = block_sum<256>(s);
+  if (threadIdx.x == 0) out[0] = (float)s;
+}
+
+extern "C" int64_t chx_lj_ws_count(int32_t n) {
+  // enough for the list kernel at g = 64 (one particle per wave) and the all-pairs kernel
+  return n > 0 ? ((int64_t)n * 64 + 255) / 256 + 1 : 1;
+}
+
+// ---------------------------------------------------------------------------
+// list kernel
+// ---------------------------------------------------------------------------
+struct LJParams {
+  float T;      // r2 <= T  <=>  d < cutoff
+  float sig2;   // sigma^2
+  float eps4;   // 4 eps
+  float eps24;  // 24 eps
+};
+
+template <int G, bool WANT_F, bool WANT_E>
+__global__ __launch_bounds__(256) void k_lj_fl(const float4* __restrict__ x4,
+                                               const uint32_t* __restrict__ fl,
+                                               const int32_t* __restrict__ deg, int n, Box3 box,
+                                               LJParams lj, float* __restrict__ f3,
+                                               double* __restrict__ ws, int32_t* ctrl) {
+  if (ctrl != nullptr && ctrl[0] != 0) {  // skin check fired in this step's integrate kernel
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctrl[1] = 1;
+    return;
+  }
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  const int p = tid / G;
+  const int q = tid % G;
+  const bool valid = p < n;
+  const int d = valid ? deg[p] : 0;
+  float4 xi = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid) xi = x4[p];
+  const size_t stride = (size_t)n * G;
+  const uint32_t* col = fl + (size_t)p * G + q;
+  float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
+  const int nt = (d + G - 1) / G;
+  uint32_t ent = (q < d) ? col[0] : 0u;
+  for (int t = 0; t < nt; ++t) {
+    const int k = t * G + q;
+    const int kn = k + G;
+    uint32_t ent_next = 0u;
+    if (kn < d) ent_next = col[(size_t)(t + 1) * stride];
+    if (k < d) {
+      const uint32_t j = ent & ~CHX_FL_HI;
+      const bool hi = (ent & CHX_FL_HI) != 0u;
+      const float4 xj = x4[j];
+      float rx, ry, rz;
+      if (hi) {
+        displacement(box, xi.x, xi.y, xi.z, xj.x, xj.y, xj.z, rx, ry, rz);
+      } else {
+        displacement(box, xj.x, xj.y, xj.z, xi.x, xi.y, xi.z, rx, ry, rz);
+      }
+      const float r2 = norm2(rx, ry, rz);
+      if (r2 <= lj.T) {
+        float e, fs;
+        lj_pair(r2, lj.sig2, lj.eps4, lj.eps24, e, fs);
+        if (!hi) fs = -fs;  // reaction on the higher-id particle
+        fx += fs * rx;
+        fy += fs * ry;
+        fz += fs * rz;
+        en += e;
+      }
+    }
+    ent = ent_next;
+  }
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) {
+    if (WANT_F) {
+      fx += __shfl_xor(fx, o, CHX_WAVE);
+      fy += __shfl_xor(fy, o, CHX_WAVE);
+      fz += __shfl_xor(fz, o, CHX_WAVE);
+    }
+    if (WANT_E) en += __shfl_xor(en, o, CHX_WAVE);
+  }
+  if (WANT_F && valid && q == 0) {
+    f3[3 * (size_t)p] = fx;
+    f3[3 * (size_t)p + 1] = fy;
+    f3[3 * (size_t)p + 2] = fz;
+  }
+  if (WANT_E) {
+    // every pair is visited from both ends
+    double mine = (valid && q == 0) ? 0.5 * (double)en : 0.0;
+    mine = block_sum<256>(mine);
+    if (threadIdx.x == 0) ws[blockIdx.x] = mine;
+  }
+}
+
+template <int G>
+static int launch_lj_fl_g(const float4* x4, const uint32_t* fl, const int32_t* deg, int n, Box3 box,
+                          LJParams lj, float* f3, float* energy, double* ws, int32_t* ctrl,
+                          hipStream_t st) {
+  const unsigned blocks = (unsigned)(((int64_t)n * G + 255) / 256);
+  if (f3 && energy) {
+    hipLaunchKernelGGL((k_lj_fl<G, true, true>), dim3(blocks), dim3(256), 0, st, x4, fl, deg, n, box,
+                       lj, f3, ws, ctrl);
+  } else if (f3) {
+    hipLaunchKernelGGL((k_lj_fl<G, true, false>), dim3(blocks), dim3(256), 0, st, x4, fl, deg, n, box,
+                       lj, f3, ws, ctrl);
+  } else {
+    hipLaunchKernelGGL((k_lj_fl<G, false, true>), dim3(blocks), dim3(256), 0, st, x4, fl, deg, n, box,
+                       lj, f3, ws, ctrl);
+  }
+  if (energy) {
+    hipLaunchKernelGGL(k_sum_ws, dim3(1), dim3(256), 0, st, ws, (int)blocks, energy);
+  }
+  return CHX_OK;
+}
+
+static LJParams make_lj(float sigma, float epsilon, float cutoff) {
+  LJParams lj;
+  lj.T = chx_cutoff_threshold_h(cutoff);
+  lj.sig2 = sigma * sigma;
+  lj.eps4 = 4.0f * epsilon;
+  lj.eps24 = 24.0f * epsilon;
+  return lj;
+}
+
+int chx_launch_lj_fl(const float* x4, const uint32_t* fl, const int32_t* deg, int n, int g,
+                     chx_box_t box, float sigma, float epsilon, float cutoff, float* f3,
+                     float* energy, double* ws, int32_t* ctrl, hipStream_t st) {
+  const float4* xx = reinterpret_cast<const float4*>(x4);
+  const Box3 b3 = make_box3(box);
+  const LJParams lj = make_lj(sigma, epsilon, cutoff);
+  switch (g) {
+    case 1: return launch_lj_fl_g<1>(xx, fl, deg, n, b3, lj, f3, energy, ws, ctrl, st);
+    case 2: return launch_lj_fl_g<2>(xx, fl, deg, n, b3, lj, f3, energy, ws, ctrl, st);
+    case 4: return launch_lj_fl_g<4>(xx, fl, deg, n, b3, lj, f3, energy, ws, ctrl, st);
+    case 8: return launch_lj_fl_g<8>(xx, fl, deg, n, b3, lj, f3, energy, ws, ctrl, st);
+    case 16: return launch_lj_fl_g<16>(xx, fl, deg, n, b3, lj, f3, energy, ws, ctrl, st);
+    case 32: return launch_lj_fl_g<32>(xx, fl, deg, n, b3, lj, f3, energy, ws, ctrl, st);
+    case 64: return launch_lj_fl_g<64>(xx, fl, deg, n, b3, lj, f3, energy, ws, ctrl, st);
+  }
+  chx_set_error("chx_launch_lj_fl: unsupported g = %d", g);
+  return CHX_ERR_INVALID;
+}
+
+extern "C" int chx_lj_fl_energy_force(const float* x4, const uint32_t* fl, const int32_t* deg,
+                                      int32_t n, int32_t g, chx_box_t box, float sigma,
+                                      float epsilon, float cutoff, float* force3_out,
+                                      float* energy_out, double* ws, chx_stream_t stream) {
+  CHX_REQUIRE(n >= 0, "n < 0");
+  CHX_REQUIRE(force3_out || energy_out, "nothing to compute");
+  CHX_REQUIRE(!energy_out || ws, "energy needs a workspace");
+  if (n == 0) {
+    if (energy_out) (void)hipMemsetAsync(energy_out, 0, sizeof(float), chx_stream(stream));
+    return CHX_OK;
+  }
+  CHX_REQUIRE(x4 && fl && deg, "null pointer");
+  CHX_REQUIRE(!box.periodic || (box.lx > 0 && box.ly > 0 && box.lz > 0), "box lengths must be > 0");
+  int rc = chx_launch_lj_fl(x4, fl, deg, n, g, box, sigma, epsilon, cutoff, force3_out, energy_out,
+                            ws, nullptr, chx_stream(stream));
+  if (rc != CHX_OK) return rc;
+  return chx_check_launch("chx_lj_fl_energy_force");
+}
+
+// ---------------------------------------------------------------------------
+// all-pairs kernel: 16 lanes per particle (4 particles per wavefront, 16 per
+// block), j-tiles of 256 particles staged through LDS
+// ---------------------------------------------------------------------------
+#define AP_SLICES 16
+#define AP_TILE 256
+
+template <bool WANT_F, bool WANT_E>
+__global__ __launch_bounds__(256) void k_lj_allpairs(const float* __restrict__ x, int stride, int n,
+                                                     Box3 box, LJParams lj, int use_cutoff,
+                                                     float* __restrict__ f3, double* __restrict__ ws,
+                                                     int32_t* ctrl) {
+  if (ctrl != nullptr && ctrl[0] != 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctrl[1] = 1;
+    return;
+  }
+  __shared__ float4 tile[AP_TILE];
+  const int il = threadIdx.x / AP_SLICES;
+  const int sl = threadIdx.x % AP_SLICES;
+  const int i = blockIdx.x * (256 / AP_SLICES) + il;
+  const bool valid = i < n;
+  float xi = 0.f, yi = 0.f, zi = 0.f;
+  if (valid) {
+    xi = x[(size_t)stride * i];
+    yi = x[(size_t)stride * i + 1];
+    zi = x[(size_t)stride * i + 2];
+  }
+  float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
+  for (int j0 = 0; j0 < n; j0 += AP_TILE) {
+    __syncthreads();
+    const int jj = j0 + threadIdx.x;
+    if (jj < n) {
+      tile[threadIdx.x] = make_float4(x[(size_t)stride * jj], x[(size_t)stride * jj + 1],
+                                      x[(size_t)stride * jj + 2], 0.f);
+    }
+    __syncthreads();
+    const int cnt = (n - j0) < AP_TILE ? (n - j0) : AP_TILE;
+    if (valid) {
+      for (int u = sl; u < cnt; u += AP_SLICES) {
+        const int j = j0 + u;
+        if (j == i) continue;
+        const float4 xj = tile[u];
+        const bool hi = j > i;
+        float rx, ry, rz;
+        if (hi) {
+          displacement(box, xi, yi, zi, xj.x, xj.y, xj.z, rx, ry, rz);
+        } else {
+          displacement(box, xj.x, xj.y, xj.z, xi, yi, zi, rx, ry, rz);
+        }
+        const float r2 = norm2(rx, ry, rz);
+        if (!use_cutoff || r2 <= lj.T) {
+          float e, fs;
+          lj_pair(r2, lj.sig2, lj.eps4, lj.eps24, e, fs);
+          if (!hi) fs = -fs;
+          fx += fs * rx;
+          fy += fs * ry;
+          fz += fs * rz;
+          en += e;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = AP_SLICES / 2; o > 0; o >>= 1) {
+    if (WANT_F) {
+      fx += __shfl_xor(fx, o, CHX_WAVE);
+      fy += __shfl_xor(fy, o, CHX_WAVE);
+      fz += __shfl_xor(fz, o, CHX_WAVE);
+    }
+    if (WANT_E) en += __shfl_xor(en, o, CHX_WAVE);
+  }
+  if (WANT_F && valid && sl == 0) {
+    f3[3 * (size_t)i] = fx;
+    f3[3 * (size_t)i + 1] = fy;
+    f3[3 * (size_t)i + 2] = fz;
+  }
+  if (WANT_E) {
+    double mine = (valid && sl == 0) ? 0.5 * (double)en : 0.0;
+    mine = block_sum<256>(mine);
+    if (threadIdx.x == 0) ws[blockIdx.x] = mine;
+  }
+}
+
+int chx_launch_lj_allpairs(const float* x, int stride, int n, chx_box_t box, float sigma,
+                           float epsilon, float cutoff, float* f3, float* energy, double* ws,
+                           int32_t* ctrl, hipStream_t st) {
+  const Box3 b3 = make_box3(box);
+  const int use_cutoff = cutoff >= 0.0f ? 1 : 0;
+  const LJParams lj = make_lj(sigma, epsilon, use_cutoff ? cutoff : 1.0f);
+  const unsigned blocks = (unsigned)((n + 15) / 16);
+  if (f3 && energy) {
+    hipLaunchKernelGGL((k_lj_allpairs<true, true>), dim3(blocks), dim3(256), 0, st, x, stride, n, b3,
+                       lj, use_cutoff, f3, ws, ctrl);
+  } else if (f3) {
+    hipLaunchKernelGGL((k_lj_allpairs<true, false>), dim3(blocks), dim3(256), 0, st, x, stride, n,
+                       b3, lj, use_cutoff, f3, ws, ctrl);
+  } else {
+    hipLaunchKernelGGL((k_lj_allpairs<false, true>), dim3(blocks), dim3(256), 0, st, x, stride, n,
+                       b3, lj, use_cutoff, f3, ws, ctrl);
+  }
+  if (energy) hipLaunchKernelGGL(k_sum_ws, dim3(1), dim3(256), 0, st, ws, (int)blocks, energy);
+  return CHX_OK;
+}
+
+extern "C" int chx_lj_allpairs_energy_force(const float* xyz, int32_t n, chx_box_t box, float sigma,
+                                            float epsilon, float cutoff, float* force_out,
+                                            float* energy_out, double* ws, chx_stream_t stream) {
+  CHX_REQUIRE(n >= 0, "n < 0");
+  CHX_REQUIRE(force_out || energy_out, "nothing to compute");
+  CHX_REQUIRE(!energy_out || ws, "energy needs a workspace");
+  if (n == 0) {
+    if (energy_out) (void)hipMemsetAsync(energy_out, 0, sizeof(float), chx_stream(stream));
+    return CHX_OK;
+  }
+  CHX_REQUIRE(xyz, "null pointer");
+  CHX_REQUIRE(!box.periodic || (box.lx > 0 && box.ly > 0 && box.lz > 0), "box lengths must be > 0");
+  chx_launch_lj_allpairs(xyz, 3, n, box, sigma, epsilon, cutoff, force_out, energy_out, ws, nullptr,
+                         chx_stream(stream));
+  return chx_check_launch("chx_lj_allpairs_energy_force");
+}

@@ -1,0 +1,450 @@
+// libchx: NeighborListNsqrd build (O(N^2) and cell list, bit-identical outputs),
+// calculate, check; PairListNsqrd build / calculate.
+//
+// Every distance predicate is the reference's `sqrt(fl(rx^2+ry^2+rz^2)) < c` on
+// fp32 min-imaged differences (chiron/neighbors.py:79-81, :600-602), evaluated
+// as `r2 <= T` with T = chx_cutoff_threshold_h(c) -- exactly equivalent because
+// the correctly-rounded sqrt is monotone.
+#include <math.h>
+
+#include "chx_common.h"
+
+// ---------------------------------------------------------------------------
+// shared row epilogue: padding (chiron/neighbors.py:603-620) and mask (:623)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void nl_finish_row(uint32_t* __restrict__ nl_row,
+                                              int32_t* __restrict__ mask_row, int m, int count,
+                                              uint32_t first, uint32_t i, int lane) {
+  uint32_t fill = count > 0 ? first : 0u;  // argmax of the bool row (:606)
+  if (fill == i) fill += 1u;               // :609
+  int stored = count < m ? count : m;
+  for (int t = stored + lane; t < m; t += CHX_WAVE) nl_row[t] = fill;
+  for (int t = lane; t < m; t += CHX_WAVE) mask_row[t] = t < count ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
+// O(N^2) build: one wavefront per row i, lanes sweep j = i+1 .. n-1 in order,
+// ballot + prefix popcount emits the ascending list directly.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_nl_build_nsq(const float* __restrict__ xyz, int n, int m,
+                                                      Box3 box, float T, uint32_t* __restrict__ nl,
+                                                      int32_t* __restrict__ nl_mask,
+                                                      int32_t* __restrict__ n_nbr) {
+  const int lane = lane_id();
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (i >= n) return;
+  const float xi = xyz[3 * (size_t)i], yi = xyz[3 * (size_t)i + 1], zi = xyz[3 * (size_t)i + 2];
+  uint32_t* nl_row = nl + (size_t)i * m;
+  int count = 0;
+  uint32_t first = 0;
+  for (int j0 = i + 1; j0 < n; j0 += CHX_WAVE) {
+    const int j = j0 + lane;
+    bool ok = false;
+    if (j < n) {
+      float rx, ry, rz;
+      displacement(box, xi, yi, zi, xyz[3 * (size_t)j], xyz[3 * (size_t)j + 1],
+                   xyz[3 * (size_t)j + 2], rx, ry, rz);
+      ok = norm2(rx, ry, rz) <= T;
+    }
+    const unsigned long long b = __ballot(ok);
+    if (b) {
+      if (count == 0) first = (uint32_t)(j0 + __ffsll((long long)b) - 1);
+      const int slot = count + __popcll(b & ((1ull << lane) - 1ull));
+      if (ok && slot < m) nl_row[slot] = (uint32_t)j;
+      count += __popcll(b);
+    }
+  }
+  nl_finish_row(nl_row, nl_mask + (size_t)i * m, m, count, first, (uint32_t)i, lane);
+  if (lane == 0) n_nbr[i] = count;
+}
+
+extern "C" int chx_nl_build_nsq(const float* xyz, int32_t n, int32_t m, chx_box_t box,
+                                float cutoff_plus_skin, uint32_t* nl_out, int32_t* nl_mask_out,
+                                int32_t* n_nbr_out, chx_stream_t stream) {
+  CHX_REQUIRE(n >= 0 && m >= 1, "need n >= 0, m >= 1");
+  if (n == 0) return CHX_OK;
+  CHX_REQUIRE(xyz && nl_out && nl_mask_out && n_nbr_out, "null pointer");
+  CHX_REQUIRE(!box.periodic || (box.lx > 0 && box.ly > 0 && box.lz > 0), "box lengths must be > 0");
+  const float T = chx_cutoff_threshold_h(cutoff_plus_skin);
+  const unsigned blocks = (unsigned)(((int64_t)n * CHX_WAVE + 255) / 256);
+  hipLaunchKernelGGL(k_nl_build_nsq, dim3(blocks), dim3(256), 0, chx_stream(stream), xyz, n, m,
+                     make_box3(box), T, nl_out, nl_mask_out, n_nbr_out);
+  return chx_check_launch("chx_nl_build_nsq");
+}
+
+// ---------------------------------------------------------------------------
+// cell-list build
+// ---------------------------------------------------------------------------
+extern "C" int64_t chx_cell_grid_h(chx_box_t box, float cs, int32_t n, int32_t* nc_h) {
+  if (!nc_h) return 0;
+  nc_h[0] = nc_h[1] = nc_h[2] = 0;
+  if (!box.periodic || !(cs > 0.0f) || n <= 0) return 0;
+  const float L[3] = {box.lx, box.ly, box.lz};
+  int64_t total = 1;
+  for (int d = 0; d < 3; ++d) {
+    if (!(L[d] > 0.0f)) return 0;
+    // cell edge >= cs with a margin that dominates every fp32 rounding in the
+    // wrapped coordinate, the cell index and the min-image distance
+    const double ulpL = (double)(nextafterf(L[d], INFINITY) - L[d]);
+    const double w = (double)cs * 1.0001 + 64.0 * ulpL;
+    int64_t nc = (int64_t)floor((double)L[d] / w);
+    if (nc < 3) return 0;
+    if (nc > 1024) nc = 1024;
+    nc_h[d] = (int32_t)nc;
+    total *= nc;
+  }
+  // do not let an almost-empty grid dominate the workspace
+  while (total > 8 * (int64_t)n + 4096) {
+    int big = 0;
+    for (int d = 1; d < 3; ++d)
+      if (nc_h[d] > nc_h[big]) big = d;
+    if (nc_h[big] <= 3) break;
+    nc_h[big] -= 1;
+    total = (int64_t)nc_h[0] * nc_h[1] * nc_h[2];
+  }
+  return total;
+}
+
+struct CellGrid {
+  int ncx, ncy, ncz;
+  float sx, sy, sz;  // nc / L
+};
+
+__device__ __forceinline__ int cell_coord(float x, float L, float s, int nc) {
+  float w = wrap1(x, L);
+  int c = (int)floorf(w * s);
+  c = c < 0 ? 0 : c;
+  return c >= nc ? nc - 1 : c;
+}
+
+__global__ void k_cell_assign(const float* __restrict__ xyz, int n, Box3 box, CellGrid g,
+                              int32_t* __restrict__ cell_of, int32_t* __restrict__ cell_count) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int cx = cell_coord(xyz[3 * (size_t)i], box.lx, g.sx, g.ncx);
+  int cy = cell_coord(xyz[3 * (size_t)i + 1], box.ly, g.sy, g.ncy);
+  int cz = cell_coord(xyz[3 * (size_t)i + 2], box.lz, g.sz, g.ncz);
+  int c = (cz * g.ncy + cy) * g.ncx + cx;
+  cell_of[i] = c;
+  atomicAdd(&cell_count[c], 1);
+}
+
+// single-block exclusive scan: cell_start[0..ncell] from cell_count; zeroes cell_count (reused as cursor)
+__global__ __launch_bounds__(1024) void k_cell_scan(int32_t* __restrict__ cell_count,
+                                                    int32_t* __restrict__ cell_start, int ncell) {
+  __shared__ int32_t part[1024];
+  const int t = threadIdx.x;
+  const int chunk = (ncell + 1023) / 1024;
+  const int lo = t * chunk;
+  const int hi = lo + chunk < ncell ? lo + chunk : ncell;
+  int32_t s = 0;
+  for (int c = lo; c < hi; ++c) s += cell_count[c];
+  part[t] = s;
+  __syncthreads();
+  // Hillis-Steele inclusive scan over the 1024 partials
+  for (int o = 1; o < 1024; o <<= 1) {
+    int32_t v = t >= o ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int32_t run = t > 0 ? part[t - 1] : 0;
+  for (int c = lo; c < hi; ++c) {
+    int32_t k = cell_count[c];
+    cell_start[c] = run;
+    run += k;
+    cell_count[c] = 0;
+  }
+  if (t == 1023) cell_start[ncell] = part[1023];
+}
+
+__global__ void k_cell_scatter(const int32_t* __restrict__ cell_of, int n,
+                               const int32_t* __restrict__ cell_start,
+                               int32_t* __restrict__ cursor, uint32_t* __restrict__ sorted_ids) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int c = cell_of[i];
+  int pos = cell_start[c] + atomicAdd(&cursor[c], 1);
+  sorted_ids[pos] = (uint32_t)i;
+}
+
+// ascending particle id inside each cell: makes the internal order (and with it
+// every floating-point summation order downstream) reproducible run to run
+__global__ void k_cell_sort(const int32_t* __restrict__ cell_start, int ncell,
+                            uint32_t* __restrict__ sorted_ids) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncell) return;
+  const int s = cell_start[c], e = cell_start[c + 1];
+  for (int a = s + 1; a < e; ++a) {
+    uint32_t v = sorted_ids[a];
+    int b = a - 1;
+    while (b >= s && sorted_ids[b] > v) {
+      sorted_ids[b + 1] = sorted_ids[b];
+      --b;
+    }
+    sorted_ids[b + 1] = v;
+  }
+}
+
+#define CHX_CELL_CAP 1024  // candidates kept on chip per row
+
+__global__ __launch_bounds__(256) void k_nl_build_cell(
+    const float* __restrict__ xyz, int n, int m, Box3 box, float T, CellGrid g,
+    const int32_t* __restrict__ cell_of, const int32_t* __restrict__ cell_start,
+    const uint32_t* __restrict__ sorted_ids, uint32_t* __restrict__ nl,
+    int32_t* __restrict__ nl_mask, int32_t* __restrict__ n_nbr, int32_t* __restrict__ status) {
+  __shared__ uint32_t cand_all[4][CHX_CELL_CAP];
+  const int lane = lane_id();
+  const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (w >= n) return;
+  uint32_t* cand = cand_all[threadIdx.x >> 6];
+  const uint32_t i = sorted_ids[w];
+  const float xi = xyz[3 * (size_t)i], yi = xyz[3 * (size_t)i + 1], zi = xyz[3 * (size_t)i + 2];
+  const int c = cell_of[i];
+  const int cx = c % g.ncx, cy = (c / g.ncx) % g.ncy, cz = c / (g.ncx * g.ncy);
+  int count = 0;
+  for (int dz = -1; dz <= 1; ++dz) {
+    const int zz = (cz + dz + g.ncz) % g.ncz;
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int yy = (cy + dy + g.ncy) % g.ncy;
+      const int row = (zz * g.ncy + yy) * g.ncx;
+      // the three x-adjacent cells are contiguous in memory except across the periodic seam
+      int r0[2], r1[2], nr;
+      if (g.ncx == 3) {
+        r0[0] = row; r1[0] = row + 3; nr = 1;
+      } else if (cx == 0) {
+        r0[0] = row + g.ncx - 1; r1[0] = row + g.ncx; r0[1] = row; r1[1] = row + 2; nr = 2;
+      } else if (cx == g.ncx - 1) {
+        r0[0] = row + cx - 1; r1[0] = row + cx + 1; r0[1] = row; r1[1] = row + 1; nr = 2;
+      } else {
+        r0[0] = row + cx - 1; r1[0] = row + cx + 2; nr = 1;
+      }
+      for (int q = 0; q < nr; ++q) {
+        const int s = cell_start[r0[q]], e = cell_start[r1[q]];
+        for (int k0 = s; k0 < e; k0 += CHX_WAVE) {
+          const int k = k0 + lane;
+          bool ok = false;
+          uint32_t j = 0;
+          if (k < e) {
+            j = sorted_ids[k];
+            if (j > i) {
+              float rx, ry, rz;
+              displacement(box, xi, yi, zi, xyz[3 * (size_t)j], xyz[3 * (size_t)j + 1],
+                           xyz[3 * (size_t)j + 2], rx, ry, rz);
+              ok = norm2(rx, ry, rz) <= T;
+            }
+          }
+          const unsigned long long b = __ballot(ok);
+          if (b) {
+            const int slot = count + __popcll(b & ((1ull << lane) - 1ull));
+            if (ok && slot < CHX_CELL_CAP) cand[slot] = j;
+            count += __popcll(b);
+          }
+        }
+      }
+    }
+  }
+  if (count > CHX_CELL_CAP && lane == 0) atomicOr(&status[0], 1);
+  const int kept = count < CHX_CELL_CAP ? count : CHX_CELL_CAP;
+  __threadfence_block();  // candidate stores visible to the whole wavefront
+  // rank sort (ids are distinct): ascending j, as jnp.where(mask, size=M) returns them
+  uint32_t* nl_row = nl + (size_t)i * m;
+  uint32_t mn = 0xFFFFFFFFu;
+  for (int t = lane; t < kept; t += CHX_WAVE) {
+    const uint32_t v = cand[t];
+    mn = v < mn ? v : mn;
+    int rank = 0;
+    for (int u = 0; u < kept; ++u) rank += cand[u] < v ? 1 : 0;
+    if (rank < m) nl_row[rank] = v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    uint32_t other = __shfl_xor(mn, o, CHX_WAVE);
+    mn = other < mn ? other : mn;
+  }
+  nl_finish_row(nl_row, nl_mask + (size_t)i * m, m, count, mn, i, lane);
+  if (lane == 0) n_nbr[i] = count;
+}
+
+extern "C" int chx_nl_build_cell(const float* xyz, int32_t n, int32_t m, chx_box_t box,
+                                 float cutoff_plus_skin, const int32_t* nc_h, int32_t* cell_of,
+                                 int32_t* cell_count, int32_t* cell_start, uint32_t* sorted_ids,
+                                 int32_t* status, uint32_t* nl_out, int32_t* nl_mask_out,
+                                 int32_t* n_nbr_out, chx_stream_t stream) {
+  CHX_REQUIRE(n >= 1 && m >= 1, "need n >= 1, m >= 1");
+  CHX_REQUIRE(xyz && nc_h && cell_of && cell_count && cell_start && sorted_ids && status &&
+                  nl_out && nl_mask_out && n_nbr_out,
+              "null pointer");
+  CHX_REQUIRE(box.periodic && box.lx > 0 && box.ly > 0 && box.lz > 0, "periodic box required");
+  CHX_REQUIRE(nc_h[0] >= 3 && nc_h[1] >= 3 && nc_h[2] >= 3, "need >= 3 cells per axis");
+  const int64_t ncell64 = (int64_t)nc_h[0] * nc_h[1] * nc_h[2];
+  CHX_REQUIRE(ncell64 < (1ll << 30), "too many cells");
+  // the grid must respect the geometric guarantee (edge >= cutoff + skin)
+  CHX_REQUIRE(box.lx / nc_h[0] >= cutoff_plus_skin && box.ly / nc_h[1] >= cutoff_plus_skin &&
+                  box.lz / nc_h[2] >= cutoff_plus_skin,
+              "cell edge smaller than cutoff + skin");
+  const int ncell = (int)ncell64;
+  hipStream_t st = chx_stream(stream);
+  const Box3 b3 = make_box3(box);
+  CellGrid g;
+  g.ncx = nc_h[0]; g.ncy = nc_h[1]; g.ncz = nc_h[2];
+  g.sx = (float)nc_h[0] / box.lx; g.sy = (float)nc_h[1] / box.ly; g.sz = (float)nc_h[2] / box.lz;
+  const float T = chx_cutoff_threshold_h(cutoff_plus_skin);
+  if (hipMemsetAsync(cell_count, 0, sizeof(int32_t) * ((size_t)ncell + 1), st) != hipSuccess ||
+      hipMemsetAsync(status, 0, sizeof(int32_t) * 4, st) != hipSuccess) {
+    chx_set_error("chx_nl_build_cell: hipMemsetAsync failed");
+    return CHX_ERR_LAUNCH;
+  }
+  const unsigned pb = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_cell_assign, dim3(pb), dim3(256), 0, st, xyz, n, b3, g, cell_of, cell_count);
+  hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, st, cell_count, cell_start, ncell);
+  hipLaunchKernelGGL(k_cell_scatter, dim3(pb), dim3(256), 0, st, cell_of, n, cell_start, cell_count,
+                     sorted_ids);
+  hipLaunchKernelGGL(k_cell_sort, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, cell_start,
+                     ncell, sorted_ids);
+  const unsigned wb = (unsigned)(((int64_t)n * CHX_WAVE + 255) / 256);
+  hipLaunchKernelGGL(k_nl_build_cell, dim3(wb), dim3(256), 0, st, xyz, n, m, b3, T, g, cell_of,
+                     cell_start, sorted_ids, nl_out, nl_mask_out, n_nbr_out, status);
+  return chx_check_launch("chx_nl_build_cell");
+}
+
+// ---------------------------------------------------------------------------
+// NeighborListNsqrd.calculate / check
+// ---------------------------------------------------------------------------
+__global__ void k_nl_calculate(const float* __restrict__ xyz, const uint32_t* __restrict__ nl,
+                               const int32_t* __restrict__ nl_mask, int n, int m, Box3 box, float T,
+                               int32_t* __restrict__ n_pairs, int32_t* __restrict__ mask_out,
+                               float* __restrict__ dist, float* __restrict__ rij) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n * m) return;
+  const int i = (int)(idx / m);
+  uint32_t j = nl[idx];
+  if (j >= (uint32_t)n) j = (uint32_t)(n - 1);  // JAX gathers clamp out-of-range indices
+  float rx, ry, rz;
+  displacement(box, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2],
+               xyz[3 * (size_t)j], xyz[3 * (size_t)j + 1], xyz[3 * (size_t)j + 2], rx, ry, rz);
+  const float r2 = norm2(rx, ry, rz);
+  const int mk = (r2 <= T && nl_mask[idx] != 0) ? 1 : 0;  // chiron/neighbors.py:782
+  mask_out[idx] = mk;
+  dist[idx] = fsqrt(r2);
+  rij[3 * idx] = rx;
+  rij[3 * idx + 1] = ry;
+  rij[3 * idx + 2] = rz;
+  if (mk) atomicAdd(&n_pairs[i], 1);
+}
+
+extern "C" int chx_nl_calculate(const float* xyz, const uint32_t* nl, const int32_t* nl_mask,
+                                int32_t n, int32_t m, chx_box_t box, float cutoff,
+                                int32_t* n_pairs_out, int32_t* mask_out, float* dist_out,
+                                float* rij_out, chx_stream_t stream) {
+  CHX_REQUIRE(n >= 0 && m >= 1, "need n >= 0, m >= 1");
+  if (n == 0) return CHX_OK;
+  CHX_REQUIRE(xyz && nl && nl_mask && n_pairs_out && mask_out && dist_out && rij_out, "null pointer");
+  CHX_REQUIRE(!box.periodic || (box.lx > 0 && box.ly > 0 && box.lz > 0), "box lengths must be > 0");
+  hipStream_t st = chx_stream(stream);
+  if (hipMemsetAsync(n_pairs_out, 0, sizeof(int32_t) * (size_t)n, st) != hipSuccess) {
+    chx_set_error("chx_nl_calculate: hipMemsetAsync failed");
+    return CHX_ERR_LAUNCH;
+  }
+  const int64_t total = (int64_t)n * m;
+  hipLaunchKernelGGL(k_nl_calculate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, xyz, nl,
+                     nl_mask, n, m, make_box3(box), chx_cutoff_threshold_h(cutoff), n_pairs_out,
+                     mask_out, dist_out, rij_out);
+  return chx_check_launch("chx_nl_calculate");
+}
+
+__global__ void k_nl_check(const float* __restrict__ xyz, const float* __restrict__ ref, int n,
+                           Box3 box, float T, int32_t* __restrict__ flag) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float rx, ry, rz;
+  displacement(box, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2],
+               ref[3 * (size_t)i], ref[3 * (size_t)i + 1], ref[3 * (size_t)i + 2], rx, ry, rz);
+  if (norm2(rx, ry, rz) > T) flag[0] = 1;  // d >= skin/2  (chiron/neighbors.py:868)
+}
+
+extern "C" int chx_nl_check(const float* xyz, const float* ref_xyz, int32_t n, chx_box_t box,
+                            float skin, int32_t* flag_out, chx_stream_t stream) {
+  CHX_REQUIRE(n >= 0, "n < 0");
+  CHX_REQUIRE(flag_out, "null pointer");
+  hipStream_t st = chx_stream(stream);
+  if (hipMemsetAsync(flag_out, 0, sizeof(int32_t), st) != hipSuccess) {
+    chx_set_error("chx_nl_check: hipMemsetAsync failed");
+    return CHX_ERR_LAUNCH;
+  }
+  if (n == 0) return CHX_OK;
+  CHX_REQUIRE(xyz && ref_xyz, "null pointer");
+  CHX_REQUIRE(!box.periodic || (box.lx > 0 && box.ly > 0 && box.lz > 0), "box lengths must be > 0");
+  // skin / 2.0 is formed in fp32 inside the jitted function (chiron/neighbors.py:868)
+  const float T = chx_cutoff_threshold_h(skin * 0.5f);
+  hipLaunchKernelGGL(k_nl_check, dim3((n + 255) / 256), dim3(256), 0, st, xyz, ref_xyz, n,
+                     make_box3(box), T, flag_out);
+  return chx_check_launch("chx_nl_check");
+}
+
+// ---------------------------------------------------------------------------
+// PairListNsqrd
+// ---------------------------------------------------------------------------
+__global__ void k_pl_build(int n, uint32_t* __restrict__ all_pairs, uint8_t* __restrict__ red) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = n - 1;
+  if (idx >= (int64_t)n * w) return;
+  const int i = (int)(idx / w), k = (int)(idx % w);
+  const int j = k < i ? k : k + 1;
+  all_pairs[idx] = (uint32_t)j;
+  red[idx] = i < j ? 1 : 0;
+}
+
+extern "C" int chx_pl_build(int32_t n, uint32_t* all_pairs_out, uint8_t* reduction_mask_out,
+                            chx_stream_t stream) {
+  CHX_REQUIRE(n >= 0, "n < 0");
+  if (n <= 1) return CHX_OK;
+  CHX_REQUIRE(all_pairs_out && reduction_mask_out, "null pointer");
+  const int64_t total = (int64_t)n * (n - 1);
+  hipLaunchKernelGGL(k_pl_build, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     chx_stream(stream), n, all_pairs_out, reduction_mask_out);
+  return chx_check_launch("chx_pl_build");
+}
+
+__global__ void k_pl_calculate(const float* __restrict__ xyz, int n, Box3 box, int use_cutoff, float T,
+                               int32_t* __restrict__ n_pairs, int32_t* __restrict__ mask_out,
+                               float* __restrict__ dist, float* __restrict__ rij) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = n - 1;
+  if (idx >= (int64_t)n * w) return;
+  const int i = (int)(idx / w), k = (int)(idx % w);
+  const int j = k < i ? k : k + 1;
+  float rx, ry, rz;
+  displacement(box, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2],
+               xyz[3 * (size_t)j], xyz[3 * (size_t)j + 1], xyz[3 * (size_t)j + 2], rx, ry, rz);
+  const float r2 = norm2(rx, ry, rz);
+  const int mk = (i < j && (!use_cutoff || r2 <= T)) ? 1 : 0;  // chiron/neighbors.py:1156, :1211
+  mask_out[idx] = mk;
+  dist[idx] = fsqrt(r2);
+  rij[3 * idx] = rx;
+  rij[3 * idx + 1] = ry;
+  rij[3 * idx + 2] = rz;
+  if (mk) atomicAdd(&n_pairs[i], 1);
+}
+
+extern "C" int chx_pl_calculate(const float* xyz, int32_t n, chx_box_t box, float cutoff,
+                                int32_t* n_pairs_out, int32_t* mask_out, float* dist_out,
+                                float* rij_out, chx_stream_t stream) {
+  CHX_REQUIRE(n >= 0, "n < 0");
+  if (n == 0) return CHX_OK;
+  CHX_REQUIRE(n_pairs_out, "null pointer");
+  hipStream_t st = chx_stream(stream);
+  if (hipMemsetAsync(n_pairs_out, 0, sizeof(int32_t) * (size_t)n, st) != hipSuccess) {
+    chx_set_error("chx_pl_calculate: hipMemsetAsync failed");
+    return CHX_ERR_LAUNCH;
+  }
+  if (n == 1) return CHX_OK;
+  CHX_REQUIRE(xyz && mask_out && dist_out && rij_out, "null pointer");
+  CHX_REQUIRE(!box.periodic || (box.lx > 0 && box.ly > 0 && box.lz > 0), "box lengths must be > 0");
+  const int use_cutoff = cutoff >= 0.0f ? 1 : 0;
+  const float T = use_cutoff ? chx_cutoff_threshold_h(cutoff) : 0.0f;
+  const int64_t total = (int64_t)n * (n - 1);
+  hipLaunchKernelGGL(k_pl_calculate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, xyz, n,
+                     make_box3(box), use_cutoff, T, n_pairs_out, mask_out, dist_out, rij_out);
+  return chx_check_launch("chx_pl_calculate");
+}

@@ -1,0 +1,422 @@
+"""MCMC moves and sampler: same classes, arguments and bookkeeping as chiron/mcmc.py.
+
+``MCMCMove`` (:11-88), ``LangevinDynamicsMove`` (:91-199), ``MCMove`` (:202-548),
+``MonteCarloDisplacementMove`` (:551-787), ``MonteCarloBarostatMove`` (:790-1009),
+``MoveSchedule`` (:1036-1071), ``MCMCSampler`` (:1074-1155).  Proposals, wrapping,
+neighbor-list checks/rebuilds and energies are HIP kernels; the accept/reject
+decision and the statistics are host logic exactly as in the reference.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops, unit
+from .rng import uniform as host_uniform
+from .states import SamplerState, ThermodynamicState
+
+
+class MCMCMove:
+    def __init__(self, number_of_moves: int, reporter=None, report_interval: Optional[int] = 100):
+        self.number_of_moves = number_of_moves
+        self.reporter = reporter
+        self.report_interval = report_interval
+        self._move_iteration = 0
+        self._number_of_attempts_made = 0
+        if self.reporter is not None:
+            assert self.report_interval is not None
+
+    def update(self, sampler_state, thermodynamic_state, nbr_list=None):
+        raise NotImplementedError
+
+    @property
+    def number_of_attemps_made(self):
+        return self._number_of_attempts_made
+
+
+class LangevinDynamicsMove(MCMCMove):
+    """chiron/mcmc.py:91-199"""
+
+    def __init__(
+        self,
+        timestep: unit.Quantity = 1.0 * unit.femtoseconds,
+        collision_rate: unit.Quantity = 1.0 / unit.picoseconds,
+        refresh_velocities: bool = False,
+        reporter=None,
+        report_interval: int = 100,
+        number_of_steps: int = 1_000,
+        save_traj_in_memory: bool = False,
+    ):
+        super().__init__(number_of_moves=number_of_steps, reporter=reporter, report_interval=report_interval)
+        self.timestep = timestep
+        self.collision_rate = collision_rate
+        self.save_traj_in_memory = save_traj_in_memory
+        self.traj = []
+        from .integrators import LangevinIntegrator
+
+        self.integrator = LangevinIntegrator(
+            timestep=self.timestep,
+            collision_rate=self.collision_rate,
+            refresh_velocities=refresh_velocities,
+            report_interval=report_interval,
+            reporter=reporter,
+            save_traj_in_memory=save_traj_in_memory,
+        )
+
+    def update(self, sampler_state, thermodynamic_state, nbr_list=None):
+        assert isinstance(sampler_state, SamplerState), f"Sampler state must be SamplerState, not {type(sampler_state)}"
+        assert isinstance(
+            thermodynamic_state, ThermodynamicState
+        ), f"Thermodynamic state must be ThermodynamicState, not {type(thermodynamic_state)}"
+        updated_sampler_state, updated_nbr_list = self.integrator.run(
+            thermodynamic_state=thermodynamic_state,
+            sampler_state=sampler_state,
+            number_of_steps=self.number_of_moves,
+            nbr_list=nbr_list,
+        )
+        self._number_of_attempts_made += self.number_of_moves
+        if self.save_traj_in_memory:
+            self.traj.append(self.integrator.traj)
+            self.integrator.traj = []
+        self._move_iteration += 1
+        return updated_sampler_state, thermodynamic_state, updated_nbr_list
+
+
+class MCMove(MCMCMove):
+    """chiron/mcmc.py:202-548"""
+
+    def __init__(
+        self,
+        number_of_moves: int,
+        reporter,
+        report_interval: int = 1,
+        autotune: bool = False,
+        autotune_interval: int = 100,
+        acceptance_method: str = "Metropolis-Hastings",
+    ) -> None:
+        super().__init__(number_of_moves=number_of_moves, reporter=reporter, report_interval=report_interval)
+        self.acceptance_method = acceptance_method
+        self.reset_statistics()
+        self.autotune = autotune
+        self.autotune_interval = autotune_interval
+
+    def update(self, sampler_state, thermodynamic_state, nbr_list=None):
+        """chiron/mcmc.py:243-306"""
+        self._current_reduced_potential = None
+        for i in range(self.number_of_moves):
+            sampler_state, thermodynamic_state, nbr_list = self._step(sampler_state, thermodynamic_state, nbr_list)
+            self._number_of_attempts_made += 1
+            if hasattr(self, "reporter"):
+                if self.reporter is not None:
+                    if self._number_of_attempts_made % self.report_interval == 0:
+                        self._report(
+                            i,
+                            self._move_iteration,
+                            self._number_of_attempts_made,
+                            self.n_accepted / self.n_proposed,
+                            sampler_state,
+                            thermodynamic_state,
+                            nbr_list,
+                        )
+            if self.autotune:
+                if self._number_of_attempts_made % self.autotune_interval == 0 and self._number_of_attempts_made > 0:
+                    self._autotune()
+        self._move_iteration += 1
+        return sampler_state, thermodynamic_state, nbr_list
+
+    def _report(self, step, iteration, number_of_attempts_made, acceptance_probability, sampler_state,
+                thermodynamic_state, nbr_list=None):
+        raise NotImplementedError
+
+    def _autotune(self):
+        raise NotImplementedError
+
+    def _propose(self, current_sampler_state, current_thermodynamic_state, current_reduced_potential,
+                 current_nbr_list=None):
+        raise NotImplementedError
+
+    def _step(self, current_sampler_state, current_thermodynamic_state, current_nbr_list=None):
+        """chiron/mcmc.py:357-463"""
+        if self._current_reduced_potential is None:
+            current_reduced_potential = current_thermodynamic_state.get_reduced_potential(
+                current_sampler_state, current_nbr_list
+            )
+            self._current_reduced_potential = current_reduced_potential
+        else:
+            current_reduced_potential = self._current_reduced_potential
+
+        (
+            proposed_sampler_state,
+            proposed_thermodynamic_state,
+            proposed_reduced_potential,
+            log_proposal_ratio,
+            proposed_nbr_list,
+        ) = self._propose(
+            current_sampler_state, current_thermodynamic_state, current_reduced_potential, current_nbr_list
+        )
+
+        if math.isnan(float(proposed_reduced_potential)):  # :428-429
+            decision = False
+        else:
+            decision = self._accept_or_reject(
+                log_proposal_ratio, proposed_sampler_state.new_PRNG_key, acceptance_method=self.acceptance_method
+            )
+        self._update_statistics(decision)
+
+        if decision:
+            self._current_reduced_potential = proposed_reduced_potential
+            return proposed_sampler_state, proposed_thermodynamic_state, proposed_nbr_list
+        else:
+            # the rejected branch still advances the PRNG key (:459-461)
+            current_sampler_state._current_PRNG_key = proposed_sampler_state._current_PRNG_key
+            return current_sampler_state, current_thermodynamic_state, current_nbr_list
+
+    def _update_statistics(self, decision):
+        if decision:
+            self.n_accepted += 1
+        self.n_proposed += 1
+
+    @property
+    def statistics(self):
+        return dict(n_accepted=self.n_accepted, n_proposed=self.n_proposed)
+
+    @statistics.setter
+    def statistics(self, value):
+        self.n_accepted = value["n_accepted"]
+        self.n_proposed = value["n_proposed"]
+
+    def reset_statistics(self):
+        self.n_accepted = 0
+        self.n_proposed = 0
+
+    def _accept_or_reject(self, log_proposal_ratio, key, acceptance_method):
+        """chiron/mcmc.py:531-548: the uniform is drawn even when the move is downhill."""
+        if acceptance_method == "Metropolis-Hastings":
+            compare_to = host_uniform(key)
+            log_proposal_ratio = float(log_proposal_ratio)
+            if -log_proposal_ratio <= 0.0 or compare_to < math.exp(log_proposal_ratio):
+                return True
+            else:
+                return False
+
+
+class MonteCarloDisplacementMove(MCMove):
+    """All particles (or ``atom_subset``) displaced by N(0, sigma) at once (chiron/mcmc.py:551-787)."""
+
+    def __init__(
+        self,
+        displacement_sigma=1.0 * unit.nanometer,
+        number_of_moves: int = 100,
+        atom_subset: Optional[List[int]] = None,
+        report_interval: int = 1,
+        reporter=None,
+        autotune: bool = False,
+        autotune_interval: int = 100,
+        acceptance_method="Metropolis-Hastings",
+    ):
+        super().__init__(
+            number_of_moves=number_of_moves,
+            reporter=reporter,
+            report_interval=report_interval,
+            autotune=autotune,
+            autotune_interval=autotune_interval,
+            acceptance_method=acceptance_method,
+        )
+        self.displacement_sigma = displacement_sigma
+        self.atom_subset = atom_subset
+        self.atom_subset_mask = None
+
+    def _report(self, step, iteration, number_of_attempts_made, acceptance_probability, sampler_state,
+                thermodynamic_state, nbr_list=None):
+        potential = thermodynamic_state.potential.compute_energy(sampler_state.positions, nbr_list)
+        self.reporter.report(
+            {
+                "step": step,
+                "iteration": iteration,
+                "number_of_attempts_made": number_of_attempts_made,
+                "potential_energy": potential,
+                "displacement_sigma": self.displacement_sigma.value_in_unit_system(unit.md_unit_system),
+                "acceptance_probability": acceptance_probability,
+            }
+        )
+
+    def _autotune(self):
+        acceptance_ratio = self.n_accepted / self.n_proposed
+        if acceptance_ratio > 0.6:
+            self.displacement_sigma *= 1.1
+        elif acceptance_ratio < 0.4:
+            self.displacement_sigma /= 1.1
+
+    def _propose(self, current_sampler_state, current_thermodynamic_state, current_reduced_potential,
+                 current_nbr_list=None):
+        """chiron/mcmc.py:680-787"""
+        n = current_sampler_state.number_of_particles
+        if self.atom_subset is not None and self.atom_subset_mask is None:
+            # per-particle 0/1 mask (the reference's (N,3)*(N,) product only broadcasts for N in {1,3}; :717-722, :743)
+            mask = np.zeros(n, dtype=np.float32)
+            for atom in self.atom_subset:
+                mask[atom] = 1.0
+            self.atom_subset_mask = torch.as_tensor(mask, device=current_sampler_state.positions.device)
+
+        key = current_sampler_state.new_PRNG_key
+        unitless_displacement_sigma = float(self.displacement_sigma.value_in_unit_system(unit.md_unit_system))
+        proposed_sampler_state = copy.deepcopy(current_sampler_state)
+
+        # displacement (+ wrap when a pair structure is present, :751-755) in one kernel
+        if current_nbr_list is not None:
+            box = ops.make_box(proposed_sampler_state.box_vectors, current_nbr_list.space.periodic)
+            if current_nbr_list.space.periodic and proposed_sampler_state.box_vectors is None:
+                raise ValueError("box_vectors must be provided for a periodic system")
+        else:
+            box = ops.make_box(None, False)
+        proposed_sampler_state.positions = ops.mc_displace(
+            current_sampler_state.positions, unitless_displacement_sigma, box, key, 0,
+            self.atom_subset_mask if self.atom_subset is not None else None,
+        )
+
+        if current_nbr_list is not None:
+            if current_nbr_list.check(proposed_sampler_state.positions):
+                proposed_nbr_list = copy.deepcopy(current_nbr_list)
+                proposed_nbr_list.build(proposed_sampler_state.positions, proposed_sampler_state.box_vectors)
+            else:
+                proposed_nbr_list = current_nbr_list
+        else:
+            proposed_nbr_list = None
+
+        proposed_reduced_potential = current_thermodynamic_state.get_reduced_potential(
+            proposed_sampler_state, proposed_nbr_list
+        )
+        log_proposal_ratio = -proposed_reduced_potential + current_reduced_potential
+        return (
+            proposed_sampler_state,
+            current_thermodynamic_state,
+            proposed_reduced_potential,
+            log_proposal_ratio,
+            proposed_nbr_list,
+        )
+
+
+class MonteCarloBarostatMove(MCMove):
+    """Isotropic volume move, atomic scaling (chiron/mcmc.py:790-1009)."""
+
+    def __init__(
+        self,
+        volume_max_scale=0.01,
+        number_of_moves: int = 100,
+        report_interval: int = 1,
+        reporter=None,
+        autotune: bool = False,
+        autotune_interval: int = 100,
+        acceptance_method="Metropolis-Hastings",
+    ):
+        super().__init__(
+            number_of_moves=number_of_moves,
+            reporter=reporter,
+            report_interval=report_interval,
+            autotune=autotune,
+            autotune_interval=autotune_interval,
+            acceptance_method=acceptance_method,
+        )
+        self.volume_max_scale = volume_max_scale
+
+    @staticmethod
+    def _volume(box) -> float:
+        b = box.detach().cpu().numpy() if isinstance(box, torch.Tensor) else np.asarray(box)
+        return float(b[0][0]) * float(b[1][1]) * float(b[2][2])
+
+    def _report(self, step, iteration, number_of_attempts_made, acceptance_probability, sampler_state,
+                thermodynamic_state, nbr_list=None):
+        potential = thermodynamic_state.potential.compute_energy(sampler_state.positions, nbr_list)
+        self.reporter.report(
+            {
+                "step": step,
+                "iteration": iteration,
+                "number_of_attempts_made": number_of_attempts_made,
+                "potential_energy": potential,
+                "volume": self._volume(sampler_state.box_vectors),
+                "box_vectors": sampler_state.box_vectors,
+                "max_volume_scale": self.volume_max_scale,
+                "acceptance_probability": acceptance_probability,
+            }
+        )
+
+    def _autotune(self):
+        acceptance_ratio = self.n_accepted / self.n_proposed
+        if acceptance_ratio < 0.25:
+            self.volume_max_scale /= 1.1
+        elif acceptance_ratio > 0.75:
+            self.volume_max_scale = min(self.volume_max_scale * 1.1, 0.3)
+
+    def _propose(self, current_sampler_state, current_thermodynamic_state, current_reduced_potential,
+                 current_nbr_list=None):
+        """chiron/mcmc.py:913-1009"""
+        key = current_sampler_state.new_PRNG_key
+        nr_of_atoms = current_sampler_state.number_of_particles
+        initial_volume = self._volume(current_sampler_state.box_vectors)
+        delta_volume_max = self.volume_max_scale * initial_volume
+        # uniform(-1, 1) * dV_max  (:967)
+        delta_volume = (2.0 * host_uniform(key) - 1.0) * delta_volume_max
+        proposed_volume = initial_volume + delta_volume
+        length_scaling_factor = (proposed_volume / initial_volume) ** (1.0 / 3.0)
+
+        proposed_sampler_state = copy.deepcopy(current_sampler_state)
+        proposed_sampler_state.positions = ops.scale(current_sampler_state.positions, length_scaling_factor)
+        proposed_sampler_state.box_vectors = ops.scale(current_sampler_state.box_vectors, length_scaling_factor)
+
+        proposed_nbr_list = None
+        if current_nbr_list is not None:
+            proposed_nbr_list = copy.deepcopy(current_nbr_list)
+            # scaling the box always invalidates the list (:985-990)
+            proposed_nbr_list.build(proposed_sampler_state.positions, proposed_sampler_state.box_vectors)
+
+        proposed_reduced_potential = current_thermodynamic_state.get_reduced_potential(
+            proposed_sampler_state, proposed_nbr_list
+        )
+        log_proposal_ratio = -(proposed_reduced_potential - current_reduced_potential) + nr_of_atoms * math.log(
+            proposed_volume / initial_volume
+        )
+        return (
+            proposed_sampler_state,
+            current_thermodynamic_state,
+            proposed_reduced_potential,
+            log_proposal_ratio,
+            proposed_nbr_list,
+        )
+
+
+class MoveSchedule:
+    """chiron/mcmc.py:1036-1071"""
+
+    def __init__(self, move_schedule: List[Tuple[str, MCMCMove]]) -> None:
+        self.move_schedule = move_schedule
+        self._validate_sequence()
+
+    def _validate_sequence(self):
+        for move_name, move_class in self.move_schedule:
+            if not isinstance(move_class, MCMCMove):
+                raise ValueError(f"Move {move_name} in the sequence is not available.")
+
+
+class MCMCSampler:
+    """chiron/mcmc.py:1074-1155"""
+
+    def __init__(self, move_set: MoveSchedule):
+        self.move = move_set
+
+    def run(self, sampler_state, thermodynamic_state, n_iterations: int = 1, nbr_list=None):
+        sampler_state = copy.deepcopy(sampler_state)
+        thermodynamic_state = copy.deepcopy(thermodynamic_state)
+        nbr_list = copy.deepcopy(nbr_list)
+        for iteration in range(n_iterations):
+            for move_name, move in self.move.move_schedule:
+                sampler_state, thermodynamic_state, nbr_list = move.update(
+                    sampler_state, thermodynamic_state, nbr_list
+                )
+        for _, move in self.move.move_schedule:
+            if move.reporter is not None:
+                move.reporter.flush_buffer()
+        return sampler_state, thermodynamic_state, nbr_list

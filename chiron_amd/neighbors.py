@@ -1,0 +1,373 @@
+"""Simulation spaces and pair structures behind the reference's operator API.
+
+Mirrors chiron/neighbors.py: ``Space`` / ``OrthogonalPeriodicSpace`` /
+``OrthogonalNonPeriodicSpace`` (:15-175), ``PairsBase`` (:178-375),
+``NeighborListNsqrd`` (:378-907) and ``PairListNsqrd`` (:910-1289) -- same
+constructor arguments, attributes, return tuples and exceptions -- plus
+``NeighborListCell``, an O(N) cell-list build that the reference lacks (its
+comments at :529-530 anticipate one) and that returns the *bit-identical* list.
+All arithmetic runs in the HIP kernels of ``csrc/chx_neighbors.hip``.
+"""
+from __future__ import annotations
+
+import logging
+from abc import ABC, abstractmethod
+from typing import Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import ops, unit
+from ._device import as_tensor, is_array
+from .states import SamplerState
+
+log = logging.getLogger("chiron_amd")
+
+
+# ---------------------------------------------------------------------------
+# spaces
+# ---------------------------------------------------------------------------
+class Space(ABC):
+    """chiron/neighbors.py:15-36"""
+
+    periodic = False
+
+    @abstractmethod
+    def displacement(self, xyz_1, xyz_2, box_vectors):
+        pass
+
+    @abstractmethod
+    def wrap(self, xyz, box_vectors):
+        pass
+
+
+class OrthogonalPeriodicSpace(Space):
+    """chiron/neighbors.py:39-112"""
+
+    periodic = True
+
+    def displacement(self, xyz_1, xyz_2, box_vectors) -> Tuple[torch.Tensor, torch.Tensor]:
+        if box_vectors is None:
+            raise ValueError("box_vectors must be provided for a periodic system")
+        return ops.displacement(as_tensor(xyz_1), as_tensor(xyz_2), ops.make_box(box_vectors, True))
+
+    def wrap(self, xyz, box_vectors) -> torch.Tensor:
+        if box_vectors is None:
+            raise ValueError("box_vectors must be provided for a periodic system")
+        return ops.wrap(as_tensor(xyz), ops.make_box(box_vectors, True))
+
+
+class OrthogonalNonPeriodicSpace(Space):
+    """chiron/neighbors.py:115-175"""
+
+    periodic = False
+
+    def displacement(self, xyz_1, xyz_2, box_vectors=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        return ops.displacement(as_tensor(xyz_1), as_tensor(xyz_2), ops.make_box(None, False))
+
+    def wrap(self, xyz, box_vectors=None) -> torch.Tensor:
+        return as_tensor(xyz)
+
+
+# ---------------------------------------------------------------------------
+# pairs base
+# ---------------------------------------------------------------------------
+def _strip_positions(positions):
+    if isinstance(positions, unit.Quantity):
+        if not positions.unit.is_compatible(unit.nanometer):
+            raise ValueError(f"Positions require distance units, not {positions.unit}")
+        positions = positions.value_in_unit_system(unit.md_unit_system)
+    return positions
+
+
+def _strip_box(box_vectors):
+    if isinstance(box_vectors, unit.Quantity):
+        if not box_vectors.unit.is_compatible(unit.nanometer):
+            raise ValueError(f"Box vectors require distance unit, not {box_vectors.unit}")
+        box_vectors = box_vectors.value_in_unit_system(unit.md_unit_system)
+    if is_array(box_vectors):
+        if tuple(box_vectors.shape) != (3, 3):
+            raise ValueError(f"box_vectors should be a 3x3 array, shape provided: {tuple(box_vectors.shape)}")
+    return box_vectors
+
+
+class PairsBase(ABC):
+    """chiron/neighbors.py:178-375"""
+
+    def __init__(self, space: Space, cutoff: Optional[unit.Quantity] = unit.Quantity(1.2, unit.nanometer)):
+        if not isinstance(space, Space):
+            raise TypeError(f"space must be of type Space, found {type(space)}")
+        if not cutoff.unit.is_compatible(unit.angstrom):
+            raise ValueError(
+                f"cutoff must be a unit.Quantity with units of distance, cutoff.unit = {cutoff.unit}"
+            )
+        self.cutoff = cutoff
+        self.space = space
+
+    @abstractmethod
+    def build(self, positions, box_vectors):
+        pass
+
+    def _validate_build_inputs(self, positions, box_vectors):
+        # chiron/neighbors.py:262-308
+        positions = _strip_positions(positions)
+        if is_array(positions):
+            if positions.shape[1] != 3:
+                raise ValueError(f"positions should be a Nx3 array, shape provided: {tuple(positions.shape)}")
+        self.ref_positions = as_tensor(positions)
+        box_vectors = _strip_box(box_vectors)
+        self.box_vectors = None if box_vectors is None else as_tensor(box_vectors)
+
+    def build_from_state(self, sampler_state: SamplerState):
+        # chiron/neighbors.py:310-331
+        if not isinstance(sampler_state, SamplerState):
+            raise TypeError(f"Expected SamplerState, got {type(sampler_state)} instead")
+        self.build(sampler_state.positions, sampler_state.box_vectors)
+
+    @abstractmethod
+    def calculate(self, positions):
+        pass
+
+    @abstractmethod
+    def check(self, positions) -> bool:
+        pass
+
+    def _box(self) -> ops.Box:
+        return self._box_h
+
+
+# ---------------------------------------------------------------------------
+# Verlet neighbor list
+# ---------------------------------------------------------------------------
+class NeighborListNsqrd(PairsBase):
+    """Half (unique-pair) Verlet list with skin, padded to ``n_max_neighbors``.
+
+    Reference: chiron/neighbors.py:378-907.  ``build`` here runs the O(N^2)
+    wave-per-row HIP kernel; outputs (``neighbor_list`` (N,M), ``neighbor_mask``
+    (N,M) int32, ``n_neighbors`` (N,) int32) are bit-identical to the reference's
+    ``vmap(_build_neighborlist)`` including padding and the growth loop.
+    Neighbor ids are stored in an int32 tensor holding the uint32 payload.
+    """
+
+    _use_cell_list = False
+
+    def __init__(
+        self,
+        space: Space,
+        cutoff: unit.Quantity = unit.Quantity(1.2, unit.nanometer),
+        skin: unit.Quantity = unit.Quantity(0.4, unit.nanometer),
+        n_max_neighbors: int = 200,
+    ):
+        if not isinstance(space, Space):
+            raise TypeError(f"space must be of type Space, found {type(space)}")
+        if not skin.unit.is_compatible(unit.angstrom):
+            raise ValueError(
+                f"cutoff must be a unit.Quantity with units of distance, skin.unit = {skin.unit}"
+            )
+        self.cutoff = cutoff
+        self.skin = skin
+        self.n_max_neighbors = n_max_neighbors
+        self.space = space
+        self.is_built = False
+        self._force_list = None
+        self.n_builds = 0
+
+    @property
+    def cutoff(self) -> unit.Quantity:
+        return self._cutoff
+
+    @cutoff.setter
+    def cutoff(self, cutoff: unit.Quantity) -> None:
+        if not cutoff.unit.is_compatible(unit.nanometer):
+            raise ValueError(
+                f"cutoff must be a unit.Quantity with units of distance, cutoff.unit = {cutoff.unit}"
+            )
+        self._cutoff = cutoff
+        self.is_built = False  # chiron/neighbors.py:485
+
+    @property
+    def skin(self) -> unit.Quantity:
+        return self._skin
+
+    @skin.setter
+    def skin(self, skin: unit.Quantity) -> None:
+        if not skin.unit.is_compatible(unit.nanometer):
+            raise ValueError(f"skin must be a unit.Quantity with units of distance, skin.unit = {skin.unit}")
+        self._skin = skin
+        self.is_built = False  # chiron/neighbors.py:502
+
+    # -- build -------------------------------------------------------------
+    def _build_pass(self, m: int):
+        """One fixed-width pass; returns (nl, mask, n_nbr, perm or None)."""
+        cs = self._cutoff_and_skin
+        if self._use_cell_list and self._box_h.periodic:
+            ncell, nc = ops.cell_grid(self._box_h, cs, self.ref_positions.shape[0])
+            if ncell > 0:
+                nl, mask, n_nbr, sorted_ids, status = ops.nl_build_cell(self.ref_positions, self._box_h, cs, m, ncell, nc)
+                if int(status[0].item()) == 0:
+                    return nl, mask, n_nbr, sorted_ids
+                log.debug("cell build overflowed its on-chip candidate buffer; using the O(N^2) kernel")
+        nl, mask, n_nbr = ops.nl_build_nsq(self.ref_positions, self._box_h, cs, m)
+        return nl, mask, n_nbr, None
+
+    def build(self, positions, box_vectors):
+        """chiron/neighbors.py:628-729"""
+        positions = _strip_positions(positions)
+        box_vectors = _strip_box(box_vectors)
+        self.ref_positions = as_tensor(positions).clone()
+        self.box_vectors = None if box_vectors is None else as_tensor(box_vectors)
+        if self.space.periodic and self.box_vectors is None:
+            # the reference raises from Space.displacement (chiron/neighbors.py:71-72)
+            raise ValueError("box_vectors must be provided for a periodic system")
+        self._box_h = ops.make_box(self.box_vectors, self.space.periodic)
+        cutoff_and_skin = self.cutoff + self.skin
+        self._cutoff_and_skin = float(cutoff_and_skin.value_in_unit_system(unit.md_unit_system))
+        n = self.ref_positions.shape[0]
+        self.particle_ids = torch.arange(n, dtype=torch.int32, device=self.ref_positions.device)
+
+        nl, mask, n_nbr, perm = self._build_pass(int(self.n_max_neighbors))
+        # growth loop, chiron/neighbors.py:709-727 (equality test, as in the reference)
+        while bool((n_nbr == self.n_max_neighbors).any().item()):
+            new_max = int(n_nbr.max().item()) + 10
+            log.debug(f"Increasing n_max_neighbors from {self.n_max_neighbors} to at {new_max}")
+            self.n_max_neighbors = new_max
+            nl, mask, n_nbr, perm = self._build_pass(int(self.n_max_neighbors))
+        if bool((n_nbr > self.n_max_neighbors).any().item()):
+            log.warning(
+                "NeighborListNsqrd: some rows hold more than n_max_neighbors entries and none holds exactly "
+                "that many; like the reference (chiron/neighbors.py:709) the list is truncated silently."
+            )
+        self.neighbor_mask, self.neighbor_list, self.n_neighbors = mask, nl, n_nbr
+        self._perm = perm
+        self._force_list = None
+        self.is_built = True
+        self.n_builds += 1
+
+    @property
+    def force_list(self) -> ops.ForceList:
+        """Internal full table for the force kernel, derived lazily from the half list."""
+        if self._force_list is None:
+            self._force_list = ops.ForceList(self.neighbor_list, self.n_neighbors, self._perm)
+        return self._force_list
+
+    # -- calculate / check -------------------------------------------------
+    def calculate(self, positions):
+        """chiron/neighbors.py:789-826 -> (n_neighbors, neighbor_list, padding_mask, dist, r_ij)"""
+        positions = as_tensor(positions)
+        cutoff = float(self.cutoff.value_in_unit_system(unit.md_unit_system))
+        n_pairs, mask, dist, rij = ops.nl_calculate(positions, self.neighbor_list, self.neighbor_mask, self._box_h, cutoff)
+        return n_pairs, self.neighbor_list, mask, dist, rij
+
+    def check_device(self, positions) -> Optional[torch.Tensor]:
+        """Device flag (int32[1]) of the displacement test, or None when N changed."""
+        positions = as_tensor(positions)
+        if self.ref_positions.shape[0] != positions.shape[0]:
+            return None
+        skin = float(self.skin.value_in_unit_system(unit.md_unit_system))
+        return ops.nl_check(positions, self.ref_positions, self._box_h, skin)
+
+    def check(self, positions) -> bool:
+        """chiron/neighbors.py:872-907"""
+        flag = self.check_device(positions)
+        if flag is None:
+            return True
+        return bool(flag.item())
+
+    def __deepcopy__(self, memo):
+        import copy
+
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k == "_force_list":
+                new._force_list = None  # rebuilt lazily; it is a pure function of the list
+            elif isinstance(v, torch.Tensor):
+                setattr(new, k, v.clone())
+            else:
+                setattr(new, k, copy.deepcopy(v, memo))
+        return new
+
+
+class NeighborListCell(NeighborListNsqrd):
+    """Same contract as ``NeighborListNsqrd`` with an O(N) cell-list build.
+
+    The reference has no cell list; this one bins the reference positions into
+    cells of edge >= cutoff+skin, scans the 27 surrounding cells with the same
+    fp32 predicate, and emits each row in ascending-id order with the same
+    padding, so ``neighbor_list`` / ``neighbor_mask`` / ``n_neighbors`` are
+    bit-identical to ``NeighborListNsqrd`` on the same input.  Falls back to the
+    O(N^2) kernel when the box holds fewer than 3 cells per axis.
+    """
+
+    _use_cell_list = True
+
+
+# ---------------------------------------------------------------------------
+# all-pairs list
+# ---------------------------------------------------------------------------
+class PairListNsqrd(PairsBase):
+    """chiron/neighbors.py:910-1289"""
+
+    def __init__(self, space: Space, cutoff: Optional[unit.Quantity] = None):
+        if not isinstance(space, Space):
+            raise TypeError(f"space must be of type Space, found {type(space)}")
+        self.cutoff = cutoff
+        self.space = space
+        self.is_built = False
+
+    @property
+    def cutoff(self):
+        return self._cutoff
+
+    @cutoff.setter
+    def cutoff(self, cutoff):
+        if cutoff is not None:
+            if not cutoff.unit.is_compatible(unit.angstrom):
+                raise ValueError(
+                    f"cutoff must be a unit.Quantity with units of distance, cutoff.unit = {cutoff.unit}"
+                )
+        self._cutoff = cutoff  # no rebuild needed (chiron/neighbors.py:1006-1007)
+
+    def build(self, positions, box_vectors):
+        """chiron/neighbors.py:1069-1104"""
+        self._validate_build_inputs(positions, box_vectors)
+        if self.space.periodic and self.box_vectors is None:
+            raise ValueError("box_vectors must be provided for a periodic system")
+        self._box_h = ops.make_box(self.box_vectors, self.space.periodic)
+        self.n_particles = self.ref_positions.shape[0]
+        dev = self.ref_positions.device
+        self.particle_ids = torch.arange(self.n_particles, dtype=torch.int32, device=dev)
+        self.all_pairs, self.reduction_mask = ops.pl_build(self.n_particles, dev)
+        self.is_built = True
+
+    def _cutoff_md(self) -> Optional[float]:
+        if self.cutoff is None:
+            return None
+        return float(self.cutoff.value_in_unit_system(unit.md_unit_system))
+
+    def calculate(self, positions):
+        """chiron/neighbors.py:1218-1270 -> (n_neighbors, all_pairs, padding_mask, dist, r_ij)"""
+        positions = as_tensor(positions)
+        if positions.shape[0] != self.n_particles:
+            raise ValueError(
+                f"Number of particles cannot changes without rebuilding. "
+                f"Positions must have shape ({self.n_particles}, 3), found {tuple(positions.shape)}"
+            )
+        n_pairs, mask, dist, rij = ops.pl_calculate(positions, self._box_h, self._cutoff_md())
+        return n_pairs, self.all_pairs, mask, dist, rij
+
+    def check(self, positions) -> bool:
+        """chiron/neighbors.py:1272-1289"""
+        return positions.shape[0] != self.n_particles
+
+    def __deepcopy__(self, memo):
+        import copy
+
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if isinstance(v, torch.Tensor):
+                setattr(new, k, v.clone())
+            else:
+                setattr(new, k, copy.deepcopy(v, memo))
+        return new

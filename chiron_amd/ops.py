@@ -1,0 +1,338 @@
+"""Tensor-level entry points: thin wrappers that hand device pointers to libchx.
+
+Every function here launches hand-written HIP kernels through the C ABI on the
+caller's current HIP stream.  Inputs must be ROCm device tensors; there is no CPU
+implementation behind these calls (a CPU tensor or a missing ``libchx.so`` raises).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Box, LangevinParams, check
+from .rng import PRNGKey
+
+
+# ---------------------------------------------------------------------------
+# plumbing
+# ---------------------------------------------------------------------------
+def _require_device(*tensors) -> None:
+    for t in tensors:
+        if t is None:
+            continue
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise _lib.ChxError(
+                "chiron_amd kernels run on the ROCm device only: got a "
+                f"{type(t).__name__} on {getattr(t, 'device', 'host')}. There is no CPU fallback."
+            )
+        if not t.is_contiguous():
+            raise _lib.ChxError("chiron_amd kernels need contiguous tensors")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(x: torch.Tensor) -> torch.Tensor:
+    if x.dtype != torch.float32:
+        x = x.to(torch.float32)
+    return x.contiguous()
+
+
+def make_box(box_vectors, periodic: bool = True) -> Box:
+    """Host-side ``chx_box_t`` from a (3,3) box (tensor / ndarray) -- diag only (neighbors.py:74-76)."""
+    if box_vectors is None or not periodic:
+        return Box(0, 0.0, 0.0, 0.0)
+    if isinstance(box_vectors, torch.Tensor):
+        b = box_vectors.detach().to("cpu", torch.float32).numpy()
+    else:
+        b = np.asarray(box_vectors, dtype=np.float32)
+    if b.shape != (3, 3):
+        raise ValueError(f"box_vectors should be a 3x3 array, shape provided: {b.shape}")
+    return Box(1, float(b[0, 0]), float(b[1, 1]), float(b[2, 2]))
+
+
+def cutoff_threshold(c: float) -> float:
+    return float(_lib.load().chx_cutoff_threshold_h(C.c_float(c)))
+
+
+# ---------------------------------------------------------------------------
+# spaces
+# ---------------------------------------------------------------------------
+def displacement(x1: torch.Tensor, x2: torch.Tensor, box: Box) -> Tuple[torch.Tensor, torch.Tensor]:
+    x1, x2 = torch.broadcast_tensors(_f32(x1), _f32(x2))
+    x1, x2 = x1.contiguous(), x2.contiguous()
+    _require_device(x1, x2)
+    if x1.shape[-1] != 3:
+        raise ValueError(f"last axis must have length 3, got {tuple(x1.shape)}")
+    r = torch.empty_like(x1)
+    d = torch.empty(x1.shape[:-1], dtype=torch.float32, device=x1.device)
+    n = d.numel()
+    check(_lib.load().chx_displacement(_ptr(x1), _ptr(x2), n, box, _ptr(r), _ptr(d), _stream()), "chx_displacement")
+    return r, d
+
+
+def wrap(x: torch.Tensor, box: Box) -> torch.Tensor:
+    x = _f32(x)
+    _require_device(x)
+    out = torch.empty_like(x)
+    check(_lib.load().chx_wrap(_ptr(x), _ptr(out), x.numel() // 3, box, _stream()), "chx_wrap")
+    return out
+
+
+def scale(x: torch.Tensor, s: float) -> torch.Tensor:
+    x = _f32(x)
+    _require_device(x)
+    out = torch.empty_like(x)
+    check(_lib.load().chx_scale(_ptr(x), _ptr(out), x.numel(), C.c_float(s), _stream()), "chx_scale")
+    return out
+
+
+# ---------------------------------------------------------------------------
+# neighbor list
+# ---------------------------------------------------------------------------
+def cell_grid(box: Box, cutoff_plus_skin: float, n: int):
+    nc = (C.c_int32 * 3)()
+    total = _lib.load().chx_cell_grid_h(box, C.c_float(cutoff_plus_skin), n, nc)
+    return int(total), nc
+
+
+def nl_build_nsq(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: int):
+    xyz = _f32(xyz)
+    _require_device(xyz)
+    n = xyz.shape[0]
+    dev = xyz.device
+    nl = torch.empty((n, m), dtype=torch.int32, device=dev)  # uint32 payload
+    mask = torch.empty((n, m), dtype=torch.int32, device=dev)
+    n_nbr = torch.empty((n,), dtype=torch.int32, device=dev)
+    check(
+        _lib.load().chx_nl_build_nsq(_ptr(xyz), n, m, box, C.c_float(cutoff_plus_skin), _ptr(nl), _ptr(mask), _ptr(n_nbr), _stream()),
+        "chx_nl_build_nsq",
+    )
+    return nl, mask, n_nbr
+
+
+def nl_build_cell(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: int, ncell: int, nc):
+    """Returns (nl, mask, n_nbr, sorted_ids, status)."""
+    xyz = _f32(xyz)
+    _require_device(xyz)
+    n = xyz.shape[0]
+    dev = xyz.device
+    nl = torch.empty((n, m), dtype=torch.int32, device=dev)
+    mask = torch.empty((n, m), dtype=torch.int32, device=dev)
+    n_nbr = torch.empty((n,), dtype=torch.int32, device=dev)
+    cell_of = torch.empty((n,), dtype=torch.int32, device=dev)
+    cell_count = torch.empty((ncell + 1,), dtype=torch.int32, device=dev)
+    cell_start = torch.empty((ncell + 1,), dtype=torch.int32, device=dev)
+    sorted_ids = torch.empty((n,), dtype=torch.int32, device=dev)
+    status = torch.empty((4,), dtype=torch.int32, device=dev)
+    check(
+        _lib.load().chx_nl_build_cell(
+            _ptr(xyz), n, m, box, C.c_float(cutoff_plus_skin), nc, _ptr(cell_of), _ptr(cell_count),
+            _ptr(cell_start), _ptr(sorted_ids), _ptr(status), _ptr(nl), _ptr(mask), _ptr(n_nbr), _stream(),
+        ),
+        "chx_nl_build_cell",
+    )
+    return nl, mask, n_nbr, sorted_ids, status
+
+
+def nl_calculate(xyz, nl, nl_mask, box: Box, cutoff: float):
+    xyz = _f32(xyz)
+    _require_device(xyz, nl, nl_mask)
+    n, m = nl.shape
+    if xyz.shape[0] != n:
+        raise ValueError(f"positions have {xyz.shape[0]} rows but the neighbor list was built for {n}")
+    dev = xyz.device
+    n_pairs = torch.empty((n,), dtype=torch.int32, device=dev)
+    mask = torch.empty((n, m), dtype=torch.int32, device=dev)
+    dist = torch.empty((n, m), dtype=torch.float32, device=dev)
+    rij = torch.empty((n, m, 3), dtype=torch.float32, device=dev)
+    check(
+        _lib.load().chx_nl_calculate(_ptr(xyz), _ptr(nl), _ptr(nl_mask), n, m, box, C.c_float(cutoff), _ptr(n_pairs), _ptr(mask), _ptr(dist), _ptr(rij), _stream()),
+        "chx_nl_calculate",
+    )
+    return n_pairs, mask, dist, rij
+
+
+def nl_check(xyz, ref, box: Box, skin: float) -> torch.Tensor:
+    xyz, ref = _f32(xyz), _f32(ref)
+    _require_device(xyz, ref)
+    flag = torch.empty((1,), dtype=torch.int32, device=xyz.device)
+    check(_lib.load().chx_nl_check(_ptr(xyz), _ptr(ref), xyz.shape[0], box, C.c_float(skin), _ptr(flag), _stream()), "chx_nl_check")
+    return flag
+
+
+def pl_build(n: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    w = max(n - 1, 0)
+    all_pairs = torch.empty((n, w), dtype=torch.int32, device=device)
+    red = torch.empty((n, w), dtype=torch.uint8, device=device)
+    _require_device(all_pairs)
+    check(_lib.load().chx_pl_build(n, _ptr(all_pairs), _ptr(red), _stream()), "chx_pl_build")
+    return all_pairs, red.to(torch.bool)
+
+
+def pl_calculate(xyz, box: Box, cutoff: Optional[float]):
+    xyz = _f32(xyz)
+    _require_device(xyz)
+    n = xyz.shape[0]
+    w = max(n - 1, 0)
+    dev = xyz.device
+    n_pairs = torch.empty((n,), dtype=torch.int32, device=dev)
+    mask = torch.empty((n, w), dtype=torch.int32, device=dev)
+    dist = torch.empty((n, w), dtype=torch.float32, device=dev)
+    rij = torch.empty((n, w, 3), dtype=torch.float32, device=dev)
+    c = -1.0 if cutoff is None else float(cutoff)
+    check(_lib.load().chx_pl_calculate(_ptr(xyz), n, box, C.c_float(c), _ptr(n_pairs), _ptr(mask), _ptr(dist), _ptr(rij), _stream()), "chx_pl_calculate")
+    return n_pairs, mask, dist, rij
+
+
+# ---------------------------------------------------------------------------
+# force list + LJ kernels
+# ---------------------------------------------------------------------------
+def _choose_g(maxdeg: int) -> int:
+    env = os.environ.get("CHX_FL_G")
+    if env:
+        return int(env)
+    target = max(1.0, maxdeg / 6.0)
+    g = 1 << int(round(math.log2(target)))
+    return max(1, min(64, g))
+
+
+class ForceList:
+    """Internal full neighbor table (see include/chx.h) built from the public half list."""
+
+    def __init__(self, nl: torch.Tensor, n_nbr: torch.Tensor, perm: Optional[torch.Tensor] = None):
+        _require_device(nl, n_nbr, perm)
+        lib = _lib.load()
+        n, m = nl.shape
+        dev = nl.device
+        self.n = n
+        self.perm = perm
+        self.inv = None
+        if perm is not None:
+            self.inv = torch.empty_like(perm)
+            check(lib.chx_invert_perm(_ptr(perm), n, _ptr(self.inv), _stream()), "chx_invert_perm")
+        self.deg = torch.empty((n,), dtype=torch.int32, device=dev)
+        maxdeg_t = torch.empty((1,), dtype=torch.int32, device=dev)
+        check(lib.chx_fl_count(_ptr(nl), _ptr(n_nbr), n, m, _ptr(self.inv), _ptr(self.deg), _ptr(maxdeg_t), _stream()), "chx_fl_count")
+        self.maxdeg = int(maxdeg_t.item())  # build-time sync (the reference syncs here too, neighbors.py:709)
+        self.g = _choose_g(self.maxdeg)
+        chunks = max(1, -(-self.maxdeg // self.g))
+        self.fl = torch.zeros((chunks, n, self.g), dtype=torch.int32, device=dev)
+        cursor = torch.empty((n,), dtype=torch.int32, device=dev)
+        check(lib.chx_fl_fill(_ptr(nl), _ptr(n_nbr), n, m, _ptr(self.inv), self.g, _ptr(cursor), _ptr(self.fl), _stream()), "chx_fl_fill")
+        rc = lib.chx_fl_sort(_ptr(self.fl), _ptr(self.deg), n, self.g, self.maxdeg, _stream())
+        self.sorted = rc == 0
+        if rc not in (0, -3):
+            check(rc, "chx_fl_sort")
+        self.ws = torch.empty((int(lib.chx_lj_ws_count(n)),), dtype=torch.float64, device=dev)
+
+    def pack(self, x3: torch.Tensor, stride: int = 4) -> torch.Tensor:
+        """User-order (n,3) -> internal order (n,stride)."""
+        x3 = _f32(x3)
+        _require_device(x3)
+        out = torch.empty((self.n, stride), dtype=torch.float32, device=x3.device)
+        check(_lib.load().chx_permute_pack(_ptr(x3), _ptr(self.perm), self.n, _ptr(out), stride, _stream()), "chx_permute_pack")
+        return out
+
+    def unpack(self, x: torch.Tensor) -> torch.Tensor:
+        """Internal order (n,3|4) -> user order (n,3)."""
+        _require_device(x)
+        out = torch.empty((self.n, 3), dtype=torch.float32, device=x.device)
+        check(_lib.load().chx_permute_unpack(_ptr(x), x.shape[1], _ptr(self.perm), self.n, _ptr(out), _stream()), "chx_permute_unpack")
+        return out
+
+    def energy_force(self, x4: torch.Tensor, box: Box, sigma: float, epsilon: float, cutoff: float,
+                     want_force: bool = True, want_energy: bool = True):
+        """Run the list kernel on internal-order positions; returns (force3_internal, energy[1])."""
+        _require_device(x4)
+        dev = x4.device
+        f3 = torch.empty((self.n, 3), dtype=torch.float32, device=dev) if want_force else None
+        e = torch.empty((1,), dtype=torch.float32, device=dev) if want_energy else None
+        check(
+            _lib.load().chx_lj_fl_energy_force(
+                _ptr(x4), _ptr(self.fl), _ptr(self.deg), self.n, self.g, box, C.c_float(sigma),
+                C.c_float(epsilon), C.c_float(cutoff), _ptr(f3), _ptr(e), _ptr(self.ws), _stream(),
+            ),
+            "chx_lj_fl_energy_force",
+        )
+        return f3, e
+
+
+def lj_allpairs(xyz: torch.Tensor, box: Box, sigma: float, epsilon: float, cutoff: Optional[float],
+                want_force: bool = True, want_energy: bool = True):
+    xyz = _f32(xyz)
+    _require_device(xyz)
+    lib = _lib.load()
+    n = xyz.shape[0]
+    dev = xyz.device
+    f = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_force else None
+    e = torch.empty((1,), dtype=torch.float32, device=dev) if want_energy else None
+    ws = torch.empty((int(lib.chx_lj_ws_count(n)),), dtype=torch.float64, device=dev)
+    c = -1.0 if cutoff is None else float(cutoff)
+    check(
+        lib.chx_lj_allpairs_energy_force(_ptr(xyz), n, box, C.c_float(sigma), C.c_float(epsilon), C.c_float(c), _ptr(f), _ptr(e), _ptr(ws), _stream()),
+        "chx_lj_allpairs_energy_force",
+    )
+    return f, e
+
+
+# ---------------------------------------------------------------------------
+# Langevin
+# ---------------------------------------------------------------------------
+def init_velocities(mass: torch.Tensor, kT: float, key: PRNGKey, normals: Optional[torch.Tensor] = None) -> torch.Tensor:
+    mass = _f32(mass)
+    _require_device(mass, normals)
+    n = mass.shape[0]
+    v = torch.empty((n, 3), dtype=torch.float32, device=mass.device)
+    check(_lib.load().chx_init_velocities(_ptr(v), _ptr(mass), n, C.c_float(kT), key[0], key[1], _ptr(normals), _stream()), "chx_init_velocities")
+    return v
+
+
+def kick(v: torch.Tensor, f: torch.Tensor, mass: torch.Tensor, half_dt: float) -> None:
+    _require_device(v, f, mass)
+    check(_lib.load().chx_kick(_ptr(v), _ptr(f), _ptr(mass), v.shape[0], C.c_float(half_dt), _stream()), "chx_kick")
+
+
+def langevin_chunk(params: LangevinParams, step0: int, n_steps: int, kicks_first: int) -> None:
+    check(_lib.load().chx_langevin_chunk(C.byref(params), step0, n_steps, kicks_first, _stream()), "chx_langevin_chunk")
+
+
+def langevin_resume(params: LangevinParams) -> None:
+    check(_lib.load().chx_langevin_resume(C.byref(params), _stream()), "chx_langevin_resume")
+
+
+# ---------------------------------------------------------------------------
+# Monte Carlo
+# ---------------------------------------------------------------------------
+def mc_displace(x: torch.Tensor, sigma_d: float, box: Box, key: PRNGKey, ctr: int = 0,
+                subset_mask: Optional[torch.Tensor] = None, normals: Optional[torch.Tensor] = None) -> torch.Tensor:
+    x = _f32(x)
+    _require_device(x, subset_mask, normals)
+    out = torch.empty_like(x)
+    check(
+        _lib.load().chx_mc_displace(_ptr(x), _ptr(out), _ptr(subset_mask), x.shape[0], C.c_float(sigma_d), box, key[0], key[1], ctr, _ptr(normals), _stream()),
+        "chx_mc_displace",
+    )
+    return out
+
+
+def metropolis_select(x_cur, x_prop, log_ratio, u_cur, u_prop, key: PRNGKey, ctr: int, accepted, counters, uniform: float = -1.0) -> None:
+    _require_device(x_cur, x_prop, log_ratio, u_cur, u_prop, accepted, counters)
+    check(
+        _lib.load().chx_metropolis_select(
+            _ptr(x_cur), _ptr(x_prop), x_cur.numel(), _ptr(log_ratio), _ptr(u_cur), _ptr(u_prop),
+            key[0], key[1], ctr, C.c_float(uniform), _ptr(accepted), _ptr(counters), _stream(),
+        ),
+        "chx_metropolis_select",
+    )

@@ -41,8 +41,9 @@ def philox4x32(counter: Tuple[int, int, int, int], key: Tuple[int, int]) -> Tupl
 
 
 def u32_to_uniform(x: int) -> float:
-    """(0,1) uniform with 24 random bits, exactly representable in fp32."""
-    return ((int(x) >> 8) + 0.5) * (1.0 / 16777216.0)
+    """(0,1) uniform with 23 random bits: (x>>9 + 1/2) 2^-23 is exact in fp32, so the
+    host, the oracle and the device produce the very same number."""
+    return ((int(x) >> 9) + 0.5) * (1.0 / 8388608.0)
 
 
 class PRNGKey(tuple):
@@ -50,6 +51,15 @@ class PRNGKey(tuple):
 
     def __new__(cls, k0: int, k1: int = 0):
         return super().__new__(cls, (int(k0) & _MASK, int(k1) & _MASK))
+
+    def __getnewargs__(self):
+        return (self[0], self[1])
+
+    def __copy__(self):
+        return self
+
+    def __deepcopy__(self, memo):
+        return self  # immutable
 
     @classmethod
     def from_seed(cls, seed: int) -> "PRNGKey":

@@ -45,9 +45,10 @@ class Unit:
 
     __slots__ = ("dims", "scale", "name")
 
-    def __init__(self, dims, scale: float, name: str):
+    def __init__(self, dims, scale, name: str):
         self.dims = tuple(Fraction(d) for d in dims)
-        self.scale = float(scale)
+        # exact rational scale whenever possible so that e.g. 10 angstrom == 1 nm exactly
+        self.scale = _exact(scale)
         self.name = name
 
     # -- algebra -----------------------------------------------------------
@@ -60,7 +61,7 @@ class Unit:
     def conversion_factor_to(self, other: "Unit") -> float:
         if not self.is_compatible(other):
             raise TypeError(f'Unit "{self.name}" is not compatible with Unit "{other.name}".')
-        return self.scale / other.scale
+        return float(self.scale / other.scale)
 
     def __mul__(self, other):
         if isinstance(other, Unit):
@@ -94,24 +95,41 @@ class Unit:
 
     def __pow__(self, p):
         p = Fraction(p).limit_denominator(1000)
-        return Unit(tuple(d * p for d in self.dims), self.scale ** float(p), f"({self.name})**{p}")
+        if p.denominator == 1 and isinstance(self.scale, Fraction):
+            scale = self.scale ** int(p)
+        else:
+            scale = float(self.scale) ** float(p)
+        return Unit(tuple(d * p for d in self.dims), scale, f"({self.name})**{p}")
 
     def __eq__(self, other):
         return isinstance(other, Unit) and self.dims == other.dims and math.isclose(
-            self.scale, other.scale, rel_tol=1e-12
+            float(self.scale), float(other.scale), rel_tol=1e-12
         )
 
     def __ne__(self, other):
         return not self.__eq__(other)
 
     def __hash__(self):
-        return hash((self.dims, round(math.log(self.scale) if self.scale > 0 else 0.0, 9)))
+        return hash((self.dims, round(math.log(float(self.scale)) if self.scale > 0 else 0.0, 9)))
 
     def __repr__(self):
         return f"Unit({self.name})"
 
     def __str__(self):
         return self.name
+
+
+def _exact(scale):
+    if isinstance(scale, Fraction):
+        return scale
+    if isinstance(scale, int):
+        return Fraction(scale)
+    if isinstance(scale, str):
+        return Fraction(scale)
+    f = float(scale)
+    # decimal literals such as 1e-9 or 4184.0 are meant exactly
+    fr = Fraction(repr(f))
+    return fr if float(fr) == f and fr.denominator <= 10**30 else f
 
 
 def _scale_value(value, factor: float):
@@ -133,18 +151,21 @@ class UnitSystem:
         self.base_scales = base_scales
 
     def scale_for(self, dims) -> float:
-        l, m, t, th, n, a, q = (float(d) for d in dims)
+        l, m, t, th, n, a, q = dims
         s = self.base_scales
         # mass^m is expressed as dalton^m * mole^m (dalton = mass/amount)
-        return (
-            s["length"] ** l
-            * s["dalton"] ** m
-            * s["amount"] ** (n + m)
-            * s["time"] ** t
-            * s["temperature"] ** th
-            * s["angle"] ** a
-            * s["charge"] ** q
-        )
+        out = Fraction(1)
+        for base, p in (("length", l), ("dalton", m), ("amount", n + m), ("time", t),
+                        ("temperature", th), ("angle", a), ("charge", q)):
+            p = Fraction(p)
+            if p == 0:
+                continue
+            b = _exact(s[base])
+            if p.denominator == 1 and isinstance(b, Fraction) and not isinstance(out, float):
+                out = out * b ** int(p)
+            else:
+                out = float(out) * float(b) ** float(p)
+        return out
 
 
 class Quantity:
@@ -180,14 +201,14 @@ class Quantity:
         return _scale_value(self._value, self.unit.conversion_factor_to(unit))
 
     def value_in_unit_system(self, system: UnitSystem):
-        return _scale_value(self._value, self.unit.scale / system.scale_for(self.unit.dims))
+        return _scale_value(self._value, float(self.unit.scale / system.scale_for(self.unit.dims)))
 
     def in_units_of(self, unit: Unit) -> "Quantity":
         return Quantity(self.value_in_unit(unit), unit)
 
     def _collapse(self):
         if self.unit.is_dimensionless():
-            return _scale_value(self._value, self.unit.scale)
+            return _scale_value(self._value, float(self.unit.scale))
         return self
 
     # -- container behaviour ----------------------------------------------

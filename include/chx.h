@@ -1,0 +1,234 @@
+/*
+ * chx.h -- C ABI of libchx.so, the MI355X (gfx950) implementation of chiron's
+ * Lennard-Jones / neighbor-list / Langevin / Metropolis hot path.
+ *
+ * The reference (choderalab/chiron) is pure Python on JAX and has no FFI of its
+ * own; each entry point below replaces one jitted function / eager op chain of
+ * the reference (cited as file:line relative to the reference checkout) and is
+ * what a ctypes binding on the reference side would call.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - every pointer is a DEVICE pointer unless the name ends in _h.
+ *   - all launches go to `stream` (a hipStream_t; NULL = default stream) and
+ *     are asynchronous; no entry point allocates or synchronises unless it says so.
+ *   - return value: 0 = CHX_OK, negative = error (chx_last_error() has text).
+ *   - arrays are C-contiguous fp32 / int32 / uint32; xyz arrays are (n,3).
+ *   - boxes are orthorhombic: chx_box_t{periodic, lx, ly, lz} by value.
+ */
+#ifndef CHX_H
+#define CHX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* chx_stream_t;
+
+#define CHX_OK 0
+#define CHX_ERR_INVALID (-1)
+#define CHX_ERR_LAUNCH (-2)
+#define CHX_ERR_UNSUPPORTED (-3)
+
+#define CHX_ABI_VERSION 1
+
+/* high bit of a force-list entry: neighbor has the HIGHER original particle id */
+#define CHX_FL_HI 0x80000000u
+
+typedef struct {
+  int32_t periodic; /* 0: OrthogonalNonPeriodicSpace, else OrthogonalPeriodicSpace */
+  float lx, ly, lz; /* diag(box_vectors), chiron/neighbors.py:74-76 */
+} chx_box_t;
+
+/* --------------------------------------------------------------------- misc */
+int chx_version(void);
+const char* chx_last_error(void);
+
+/* Largest fp32 t with sqrtf(t) < c (host helper, exact).  `d < c` on the
+ * reference's d = sqrt(r2) is then equivalent to `r2 <= T` (neighbors.py:600-602,
+ * :782, :1156); `d >= c` is `r2 > T` (:868). */
+float chx_cutoff_threshold_h(float c);
+
+/* ------------------------------------------------------------------- spaces */
+/* Space.displacement: r = x1 - x2 [min-image], dist = |r|.
+ * chiron/neighbors.py:45-83 (periodic), :116-150 (non-periodic). n rows of 3. */
+int chx_displacement(const float* x1, const float* x2, int64_t n, chx_box_t box,
+                     float* rij_out, float* dist_out, chx_stream_t stream);
+
+/* OrthogonalPeriodicSpace.wrap: x - floor(x/L)*L (identity when !periodic).
+ * chiron/neighbors.py:85-112, :152-175.  xin may equal xout. */
+int chx_wrap(const float* xin, float* xout, int64_t n, chx_box_t box, chx_stream_t stream);
+
+/* ---------------------------------------------- NeighborListNsqrd (Verlet) */
+/* One pass of vmap(_build_neighborlist), O(N^2): chiron/neighbors.py:548-626,
+ * :694-704.  Per row i: ascending j>i with d(ref_i,ref_j) < cutoff+skin, the
+ * first m of them, padded with the fill value of :606-609; nl_mask = arange(m)
+ * < n_i; n_nbr = full (untruncated) count. */
+int chx_nl_build_nsq(const float* xyz, int32_t n, int32_t m, chx_box_t box, float cutoff_plus_skin,
+                     uint32_t* nl_out, int32_t* nl_mask_out, int32_t* n_nbr_out,
+                     chx_stream_t stream);
+
+/* Cell-list geometry for chx_nl_build_cell (host helper).  Writes the grid
+ * dimensions to nc_h[3]; returns the number of cells, or 0 when the cell path
+ * does not apply (non-periodic box or fewer than 3 cells along an axis) and
+ * the caller must use chx_nl_build_nsq. */
+int64_t chx_cell_grid_h(chx_box_t box, float cutoff_plus_skin, int32_t n, int32_t* nc_h);
+
+/* New (the reference has no cell list, chiron/neighbors.py:529-530): O(N)
+ * build that produces BIT-IDENTICAL nl/nl_mask/n_nbr to chx_nl_build_nsq.
+ * Workspace (caller-allocated): cell_of[n] i32, cell_count[ncell+1] i32,
+ * cell_start[ncell+1] i32, sorted_ids[n] u32 (out: particle ids in cell
+ * order, ascending id inside a cell), status[4] i32 (out: [0]!=0 -> a row
+ * overflowed the on-chip candidate buffer, results invalid, rebuild with
+ * chx_nl_build_nsq). */
+int chx_nl_build_cell(const float* xyz, int32_t n, int32_t m, chx_box_t box, float cutoff_plus_skin,
+                      const int32_t* nc_h, int32_t* cell_of, int32_t* cell_count,
+                      int32_t* cell_start, uint32_t* sorted_ids, int32_t* status,
+                      uint32_t* nl_out, int32_t* nl_mask_out, int32_t* n_nbr_out,
+                      chx_stream_t stream);
+
+/* NeighborListNsqrd.calculate: chiron/neighbors.py:731-826.  For every slot
+ * (i,k): r = disp(x_i, x_nl[i,k]); mask = (d < cutoff) & nl_mask; n_pairs = row sum. */
+int chx_nl_calculate(const float* xyz, const uint32_t* nl, const int32_t* nl_mask, int32_t n,
+                     int32_t m, chx_box_t box, float cutoff, int32_t* n_pairs_out,
+                     int32_t* mask_out, float* dist_out, float* rij_out, chx_stream_t stream);
+
+/* NeighborListNsqrd.check body: flag_out[0] = any_i |disp(x_i, ref_i)| >= skin/2.
+ * chiron/neighbors.py:828-907.  (The n-changed test of :890 is host logic.) */
+int chx_nl_check(const float* xyz, const float* ref_xyz, int32_t n, chx_box_t box, float skin,
+                 int32_t* flag_out, chx_stream_t stream);
+
+/* ------------------------------------------------------------ PairListNsqrd */
+/* _pairs_and_mask: all_pairs[i] = all j != i ascending, reduction_mask = i < j.
+ * chiron/neighbors.py:1018-1067. */
+int chx_pl_build(int32_t n, uint32_t* all_pairs_out, uint8_t* reduction_mask_out,
+                 chx_stream_t stream);
+
+/* PairListNsqrd.calculate: chiron/neighbors.py:1106-1270.  cutoff < 0 means
+ * cutoff=None (mask = i<j only).  Outputs are (n, n-1[,3]). */
+int chx_pl_calculate(const float* xyz, int32_t n, chx_box_t box, float cutoff,
+                     int32_t* n_pairs_out, int32_t* mask_out, float* dist_out, float* rij_out,
+                     chx_stream_t stream);
+
+/* ----------------------------------------------------- LJ energy and force */
+/* Force list: an internal FULL neighbor table derived from the public half
+ * list, laid out for the force kernel: particle p (internal order, p =
+ * inv[original id], inv may be NULL = identity) owns deg[p] entries; entry k
+ * lives at fl[((k / g) * n + p) * g + (k % g)], g lanes cooperate on one
+ * particle.  Entry = internal index of the neighbor | CHX_FL_HI when the
+ * neighbor's ORIGINAL id is the larger one (the pair is then stored in this
+ * particle's row of the reference half list and r_ij = x_p - x_q as in
+ * chiron/neighbors.py:777-779; otherwise r_ij = x_q - x_p and the force on p
+ * is the reaction).  Exactly the pairs of nl[:, :min(n_nbr, m)] are present. */
+int chx_fl_count(const uint32_t* nl, const int32_t* n_nbr, int32_t n, int32_t m,
+                 const uint32_t* inv, int32_t* deg_out, int32_t* maxdeg_out, chx_stream_t stream);
+int chx_fl_fill(const uint32_t* nl, const int32_t* n_nbr, int32_t n, int32_t m,
+                const uint32_t* inv, int32_t g, int32_t* cursor_ws, uint32_t* fl_out,
+                chx_stream_t stream);
+/* sort each particle's entries by neighbor index (locality + reproducible sums) */
+int chx_fl_sort(uint32_t* fl, const int32_t* deg, int32_t n, int32_t g, int32_t maxdeg,
+                chx_stream_t stream);
+
+/* dst[p] = src[perm[p]] (rows of 3 floats in, rows of dst_stride floats out, pad = 0),
+ * and the inverse dst[perm[p]] = src[p].  perm NULL = identity. */
+int chx_permute_pack(const float* src3, const uint32_t* perm, int32_t n, float* dst,
+                     int32_t dst_stride, chx_stream_t stream);
+int chx_permute_unpack(const float* src, int32_t src_stride, const uint32_t* perm, int32_t n,
+                       float* dst3, chx_stream_t stream);
+int chx_invert_perm(const uint32_t* perm, int32_t n, uint32_t* inv_out, chx_stream_t stream);
+
+/* LJPotential.compute_energy / compute_force over the neighbor list:
+ * E = sum over listed pairs with d < cutoff of 4 eps ((s/d)^12 - (s/d)^6)
+ * (chiron/potential.py:193-213, :260-279), F = -dE/dx (chiron/potential.py:21-24,
+ * closed form :322-332).  x4 is (n,4) in internal order; force3_out (n,3) in
+ * internal order (NULL = energy only); energy_out[1] (NULL = force only);
+ * ws: >= chx_lj_ws_count(n) doubles. */
+int64_t chx_lj_ws_count(int32_t n);
+int chx_lj_fl_energy_force(const float* x4, const uint32_t* fl, const int32_t* deg, int32_t n,
+                           int32_t g, chx_box_t box, float sigma, float epsilon, float cutoff,
+                           float* force3_out, float* energy_out, double* ws, chx_stream_t stream);
+
+/* All-pairs kernel: the nbr_list=None branch (no PBC, chiron/potential.py:26-63,
+ * :235-258) and the PairListNsqrd branch (PBC, chiron/neighbors.py:1106-1216).
+ * cutoff < 0: no cutoff.  xyz/force are (n,3) in user order. */
+int chx_lj_allpairs_energy_force(const float* xyz, int32_t n, chx_box_t box, float sigma,
+                                 float epsilon, float cutoff, float* force_out,
+                                 float* energy_out, double* ws, chx_stream_t stream);
+
+/* ------------------------------------------------------- Langevin (BAOAB) */
+/* initialize_velocities: v = sqrt(kT/m) * N(0,1), chiron/utils.py:116-144.
+ * normals (n,3) optional injected noise; otherwise Philox stream 0 keyed (k0,k1). */
+int chx_init_velocities(float* v_out, const float* mass, int32_t n, float kT, uint32_t k0,
+                        uint32_t k1, const float* normals, chx_stream_t stream);
+
+/* v += (dt/2) F / m, chiron/integrators.py:181,195 */
+int chx_kick(float* v, const float* f, const float* mass, int32_t n, float half_dt,
+             chx_stream_t stream);
+
+typedef struct {
+  int32_t n;
+  int32_t g;             /* force-list lanes per particle */
+  float* x4;             /* (n,4) positions, internal order            (in/out) */
+  float* v;              /* (n,3) velocities, internal order           (in/out) */
+  float* f;              /* (n,3) forces, internal order               (in/out) */
+  const float* ref4;     /* (n,4) positions at the last list build, or NULL (no list) */
+  const float* mass;     /* (n)   masses, internal order */
+  const uint32_t* perm;  /* (n)   internal -> original id (RNG counter / noise row), NULL = identity */
+  const uint32_t* fl;    /* force list (see above), NULL -> all-pairs kernel */
+  const int32_t* deg;
+  chx_box_t box;
+  int32_t wrap;          /* apply Space.wrap + skin check each step (nbr_list given) */
+  float skin;            /* Verlet skin (check uses >= skin/2) */
+  float half_dt, a, b, kT;
+  float sigma, epsilon, cutoff;
+  uint32_t k0, k1;       /* Philox key of this run */
+  const float* noise;    /* optional injected O-step noise, (n_noise_steps, n, 3) in ORIGINAL order */
+  int64_t noise_step0;   /* step index of noise row 0 */
+  int32_t* ctrl;         /* [0] violation seen by integrate, [1] halt (set by force kernel),
+                            [2] step at which the skin check fired, [3] reserved */
+  double* ws;            /* energy workspace, >= chx_lj_ws_count(n) */
+  int32_t external_force; /* != 0: do not launch the LJ force kernel (the caller fills f
+                             between single-step chunks: IdealGasPotential and other potentials) */
+} chx_langevin_t;
+
+/* Enqueue n_steps BAOAB steps (chiron/integrators.py:179-195) starting at global
+ * step index step0: per step one fused integrate kernel [n_kicks x B, A, O, A,
+ * wrap, skin check] and one force kernel.  The first step applies kicks_first
+ * half-kicks (1 at the start of a run or after a rebuild-resume that already
+ * applied the trailing kick, else 2: the trailing kick of the previous step
+ * merged with the leading one).  When the skin check fires at step s the
+ * remaining launches of the chunk are no-ops: ctrl[1]=1, ctrl[2]=s, positions
+ * and velocities are those after the A-O-A-wrap of step s (force NOT yet
+ * recomputed) -- the caller rebuilds the list and resumes with
+ * chx_langevin_resume.  Asynchronous; the caller synchronises and reads ctrl. */
+int chx_langevin_chunk(const chx_langevin_t* p_h, int64_t step0, int32_t n_steps,
+                       int32_t kicks_first, chx_stream_t stream);
+/* force evaluation that completes a halted step after the list was rebuilt */
+int chx_langevin_resume(const chx_langevin_t* p_h, chx_stream_t stream);
+
+/* ------------------------------------------------------------ Monte Carlo */
+/* MonteCarloDisplacementMove proposal: x' = wrap(x + sigma_d * N(0,1) [* mask_i]),
+ * chiron/mcmc.py:724-755.  Philox stream 2, counter word 1 = ctr. */
+int chx_mc_displace(const float* x, float* x_out, const float* subset_mask, int32_t n,
+                    float sigma_d, chx_box_t box, uint32_t k0, uint32_t k1, uint32_t ctr,
+                    const float* normals, chx_stream_t stream);
+
+/* MonteCarloBarostatMove geometry: out = in * s, chiron/mcmc.py:977-983 */
+int chx_scale(const float* in, float* out, int64_t count, float s, chx_stream_t stream);
+
+/* Metropolis accept/select on the device (no host sync on the accept branch):
+ * accept iff !isnan(u_prop) and (-logp <= 0 or U < exp(logp)) with
+ * logp = log_ratio[0]; on accept x_cur <- x_prop (count floats), u_cur <- u_prop;
+ * counters[0] += accepted, counters[1] += 1.  chiron/mcmc.py:428-436, :531-548.
+ * uniform_h < 0: draw U from Philox stream 3 (k0,k1,ctr). */
+int chx_metropolis_select(float* x_cur, const float* x_prop, int64_t count,
+                          const float* log_ratio, float* u_cur, const float* u_prop,
+                          uint32_t k0, uint32_t k1, uint32_t ctr, float uniform_h,
+                          int32_t* accepted_out, int32_t* counters, chx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHX_H */

@@ -341,7 +341,7 @@ def philox4x32(c0, c1, c2, c3, k0: int, k1: int):
 
 
 def u32_to_uniform(u: np.ndarray) -> np.ndarray:
-    return ((u >> np.uint32(8)).astype(f32) + f32(0.5)) * f32(1.0 / 16777216.0)
+    return ((u >> np.uint32(9)).astype(f32) + f32(0.5)) * f32(1.0 / 8388608.0)
 
 
 def philox_normals3(n: int, step: int, stream: int, key) -> np.ndarray:

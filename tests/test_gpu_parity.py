@@ -1,0 +1,744 @@
+"""GPU parity tests: HIP kernels (through the C ABI / the reference-shaped classes)
+against the CPU oracle, the reference's golden literals, and fp64 brute force.
+
+Bars: neighbor indices / masks / counts / dist / r_ij bit-exact;
+energies |E32 - E64| <= 1e-5 * sum|e_ij|; forces max|F32 - F64| <= 1e-5 * max(1, max_i sum_j |f_ij|).
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import cube_coordinates
+
+pytestmark = pytest.mark.gpu
+
+f32 = np.float32
+SIGMA, EPS_KCAL = 0.34, 0.238
+EPS = EPS_KCAL * 4.184
+CUTOFF, SKIN = 3 * SIGMA, 0.5
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import chiron_oracle
+
+    return chiron_oracle
+
+
+@pytest.fixture(scope="module")
+def ca():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import chiron_amd
+    from chiron_amd import _lib, integrators, mcmc, neighbors, ops, potential, states, testsystems, unit, utils
+
+    _lib.load()
+    return type("NS", (), dict(unit=unit, neighbors=neighbors, potential=potential, states=states, ops=ops,
+                               utils=utils, integrators=integrators, mcmc=mcmc, testsystems=testsystems))
+
+
+def u32(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(a), dtype=dtype).cuda()
+
+
+def nm(x, ca):
+    return ca.unit.Quantity(x, ca.unit.nanometer)
+
+
+def make_state(ca, x, box):
+    ca.utils.PRNG.set_seed(1234)
+    return ca.states.SamplerState(nm(np.asarray(x, dtype=f32), ca), ca.utils.PRNG.get_random_key(),
+                                  box_vectors=None if box is None else nm(np.asarray(box, dtype=f32), ca))
+
+
+def lj_pot(ca, n, sigma=SIGMA, eps_kj=EPS, cutoff=CUTOFF):
+    u = ca.unit
+    from chiron_amd.topology import Topology
+
+    return ca.potential.LJPotential(Topology.homogeneous(n), sigma=sigma * u.nanometer,
+                                    epsilon=eps_kj * u.kilojoule_per_mole, cutoff=cutoff * u.nanometer)
+
+
+# ---------------------------------------------------------------------------
+# spaces
+# ---------------------------------------------------------------------------
+def test_spaces_golden(ca, golden):
+    g = golden["displacement_periodic"]
+    sp = ca.neighbors.OrthogonalPeriodicSpace()
+    r, d = sp.displacement(np.array(g["p1"], f32), np.array(g["p2"], f32), np.array(g["box"], f32))
+    assert np.array_equal(r.cpu().numpy(), np.array(g["r_ij"], f32))
+    assert np.array_equal(d.cpu().numpy(), np.array(g["dist"], f32))
+    w = golden["wrap_periodic"]
+    for case in w["cases"]:
+        out = sp.wrap(np.array([case["x"]], f32), np.array(w["box"], f32))
+        assert np.array_equal(out.cpu().numpy()[0], np.array(case["wrapped"], f32))
+    with pytest.raises(ValueError):
+        sp.displacement(np.array(g["p1"], f32), np.array(g["p2"], f32), None)
+    g = golden["displacement_nonperiodic"]
+    sp = ca.neighbors.OrthogonalNonPeriodicSpace()
+    r, d = sp.displacement(np.array(g["p1"], f32), np.array(g["p2"], f32), None)
+    assert np.array_equal(r.cpu().numpy(), np.array(g["r_ij"], f32))
+    assert np.array_equal(d.cpu().numpy(), np.array(g["dist"], f32))
+    assert np.array_equal(sp.wrap(np.array([g["wrap_x"]], f32)).cpu().numpy()[0], np.array(g["wrap_expected"], f32))
+
+
+def test_spaces_random_bitexact(ca, O):
+    rng = np.random.default_rng(7)
+    box = np.diag([3.7, 4.1, 5.3]).astype(f32)
+    a = (rng.uniform(-12, 12, size=(5000, 3))).astype(f32)  # deliberately unwrapped, several box lengths away
+    b = (rng.uniform(-12, 12, size=(5000, 3))).astype(f32)
+    sp = ca.neighbors.OrthogonalPeriodicSpace()
+    r, d = sp.displacement(a, b, box)
+    r0, d0 = O.periodic_displacement(a, b, box)
+    assert np.array_equal(r.cpu().numpy(), r0) and np.array_equal(d.cpu().numpy(), d0)
+    assert np.array_equal(sp.wrap(a, box).cpu().numpy(), O.periodic_wrap(a, box))
+
+
+# ---------------------------------------------------------------------------
+# neighbor list: golden literals
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("cls_name", ["NeighborListNsqrd", "NeighborListCell"])
+def test_neighborlist_pair_golden(ca, golden, cls_name):
+    g = golden["neighborlist_pair"]
+    u = ca.unit
+    cls = getattr(ca.neighbors, cls_name)
+    x = np.array(g["coordinates"], f32)
+    state = make_state(ca, x, g["box"])
+    nbr = cls(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=g["cutoff"] * u.nanometer, skin=g["skin"] * u.nanometer,
+              n_max_neighbors=g["n_max_neighbors"])
+    assert nbr.cutoff == g["cutoff"] * u.nanometer and nbr.skin == g["skin"] * u.nanometer
+    nbr.build_from_state(state)
+    assert nbr.is_built and nbr.n_max_neighbors == 5
+    assert np.array_equal(nbr.ref_positions.cpu().numpy(), x)
+    assert np.array_equal(u32(nbr.neighbor_list), np.array(g["neighbor_list"]))
+    assert np.array_equal(nbr.n_neighbors.cpu().numpy(), np.array(g["n_neighbors"]))
+    assert np.array_equal(nbr.neighbor_mask.cpu().numpy(), np.array(g["neighbor_mask"]))
+    n_nb, nl, mask, dist, rij = nbr.calculate(x)
+    assert np.array_equal(n_nb.cpu().numpy(), np.array(g["calc_n_neighbors"]))
+    assert nl.shape == (2, 5)
+    assert np.array_equal(mask.cpu().numpy(), np.array(g["padding_mask"]))
+    assert np.array_equal(dist.cpu().numpy(), np.array(g["dist"], f32))
+    assert np.array_equal(rij.cpu().numpy()[0], np.tile(np.array(g["r_ij_row0"], f32), (5, 1)))
+    assert np.array_equal(rij.cpu().numpy()[1], np.tile(np.array(g["r_ij_row1"], f32), (5, 1)))
+    assert nbr.check(x) is False
+    assert nbr.check(x + f32(0.1)) is True
+    assert nbr.check(np.array(g["check_changed_n"], f32)) is True
+
+
+@pytest.mark.parametrize("cls_name", ["NeighborListNsqrd", "NeighborListCell"])
+def test_neighborlist_cube_golden(ca, golden, cls_name):
+    g = golden["neighborlist_cube"]
+    u = ca.unit
+    cls = getattr(ca.neighbors, cls_name)
+    x = cube_coordinates(g["n_xyz"], g["scale_factor"])
+    state = make_state(ca, x, g["box"])
+    c = g["case_all"]
+    nbr = cls(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=c["cutoff"] * u.nanometer, skin=c["skin"] * u.nanometer,
+              n_max_neighbors=c["n_max_neighbors"])
+    nbr.build_from_state(state)
+    assert np.array_equal(nbr.n_neighbors.cpu().numpy(), np.array(c["n_neighbors"]))
+    assert np.array_equal(nbr.calculate(x)[0].cpu().numpy(), np.array(c["n_interacting"]))
+    c = g["case_subset"]
+    nbr = cls(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=c["cutoff"] * u.nanometer, skin=c["skin"] * u.nanometer,
+              n_max_neighbors=c["n_max_neighbors"])
+    nbr.build_from_state(state)
+    assert nbr.n_max_neighbors == c["grown_n_max"]
+    n_int, nl, mask, dist, rij = nbr.calculate(x)
+    assert np.array_equal(n_int.cpu().numpy(), np.array(c["n_interacting"]))
+    assert nl.shape == (8, 17)
+    assert np.array_equal(u32(nl), np.array(c["neighbor_list"]))
+    nbr.build(state.positions, state.box_vectors)
+    assert np.array_equal(nbr.n_neighbors.cpu().numpy(), np.array(c["n_neighbors"]))
+
+
+def test_neighborlist_input_errors(ca):
+    u = ca.unit
+    N = ca.neighbors
+    space = N.OrthogonalPeriodicSpace()
+    nbr = N.NeighborListNsqrd(space, cutoff=2.1 * u.nanometer, skin=0.1 * u.nanometer, n_max_neighbors=5)
+    with pytest.raises(TypeError):
+        nbr.build_from_state(123)
+    x = np.array([[1, 2, 3], [0, 0, 0]], f32)
+    with pytest.raises(ValueError):
+        nbr.build_from_state(make_state(ca, x, None))
+    with pytest.raises(ValueError):
+        nbr.build(x, np.zeros((4, 3), f32))
+    box = np.diag([10.0, 10.0, 10.0]).astype(f32)
+    with pytest.raises(ValueError):
+        nbr.build(u.Quantity(x, u.radians), box)
+    with pytest.raises(ValueError):
+        nbr.build(u.Quantity(x, u.nanometers), u.Quantity(box, u.radians))
+    with pytest.raises(TypeError):
+        N.NeighborListNsqrd(123, cutoff=2.1 * u.nanometer, skin=0.1 * u.nanometer)
+    with pytest.raises(ValueError):
+        N.NeighborListNsqrd(space, cutoff=u.Quantity(123, u.radian), skin=u.Quantity(123, u.nanometer))
+    with pytest.raises(ValueError):
+        N.NeighborListNsqrd(space, cutoff=u.Quantity(123, u.nanometer), skin=u.Quantity(123, u.radian))
+
+
+# ---------------------------------------------------------------------------
+# neighbor list: seeded random systems, bit-exact vs the oracle
+# ---------------------------------------------------------------------------
+def _systems(O):
+    out = []
+    for n, rho, seed in [(1500, 0.1, 1), (1200, 0.8, 2), (777, 0.02, 3)]:
+        x, box = O.lj_lattice(n, rho, SIGMA, seed=seed)
+        out.append((f"n{n}_rho{rho}", x, box))
+    # unwrapped coordinates: whole box lengths added at random
+    x, box = O.lj_lattice(1000, 0.3, SIGMA, seed=4)
+    rng = np.random.default_rng(5)
+    x = (x + rng.integers(-2, 3, size=x.shape) * box[0, 0]).astype(f32)
+    out.append(("unwrapped", x, box))
+    # non-cubic box
+    rng = np.random.default_rng(6)
+    box = np.diag([5.0, 6.5, 8.1]).astype(f32)
+    x = (rng.uniform(0, 1, size=(1400, 3)) * np.diag(box)).astype(f32)
+    out.append(("noncubic_random", x, box))
+    return out
+
+
+@pytest.mark.parametrize("cls_name", ["NeighborListNsqrd", "NeighborListCell"])
+def test_neighborlist_random_bitexact(ca, O, cls_name):
+    u = ca.unit
+    cls = getattr(ca.neighbors, cls_name)
+    for name, x, box in _systems(O):
+        for m0 in (180, 12):  # 12 forces the growth loop
+            nbr = cls(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer, skin=SKIN * u.nanometer,
+                      n_max_neighbors=m0)
+            nbr.build(x, box)
+            nl_mask, nl, n_nbr, n_max = O.neighborlist_build(x, box, CUTOFF, SKIN, m0)
+            assert nbr.n_max_neighbors == n_max, name
+            assert np.array_equal(nbr.n_neighbors.cpu().numpy(), n_nbr), name
+            assert np.array_equal(u32(nbr.neighbor_list), nl), name
+            assert np.array_equal(nbr.neighbor_mask.cpu().numpy(), nl_mask), name
+        # calculate() at displaced positions: every output bit-exact
+        rng = np.random.default_rng(11)
+        x2 = (x + rng.normal(0, 0.05, size=x.shape)).astype(f32)
+        n_p, _, mask, dist, rij = nbr.calculate(x2)
+        n_p0, mask0, d0, r0 = O.neighborlist_calculate(x2, nl, nl_mask, box, CUTOFF)
+        assert np.array_equal(n_p.cpu().numpy(), n_p0), name
+        assert np.array_equal(mask.cpu().numpy(), mask0), name
+        assert np.array_equal(dist.cpu().numpy(), d0), name
+        assert np.array_equal(rij.cpu().numpy(), r0), name
+        assert nbr.check(x2) == O.neighborlist_check(x2, x, box, SKIN), name
+        assert nbr.check(x) is False
+
+
+def test_neighborlist_nonperiodic_and_truncation(ca, O):
+    u = ca.unit
+    x, box = O.lj_lattice(900, 0.6, SIGMA, seed=9)
+    nbr = ca.neighbors.NeighborListNsqrd(ca.neighbors.OrthogonalNonPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+                                         skin=SKIN * u.nanometer, n_max_neighbors=400)
+    nbr.build(x, None)
+    nl_mask, nl, n_nbr, n_max = O.neighborlist_build(x, None, CUTOFF, SKIN, 400, periodic=False)
+    assert np.array_equal(u32(nbr.neighbor_list), nl) and np.array_equal(nbr.n_neighbors.cpu().numpy(), n_nbr)
+    # fixed-width pass with rows longer than m: first m ascending ids, mask all ones (reference quirk)
+    nlk, maskk, n_nbrk = ca.ops.nl_build_nsq(dev(x), ca.ops.make_box(box, True), CUTOFF + SKIN, 7)
+    mask0, nl0, n0 = O.neighborlist_build_fixed(x, box, CUTOFF + SKIN, 7)
+    assert np.array_equal(u32(nlk), nl0) and np.array_equal(maskk.cpu().numpy(), mask0)
+    assert np.array_equal(n_nbrk.cpu().numpy(), n0)
+
+
+def test_cell_equals_nsq_medium(ca, O):
+    """Cell build == O(N^2) build on the GPU itself at a size the NumPy oracle would crawl through."""
+    u = ca.unit
+    x, box = O.lj_lattice(32768, 0.1, SIGMA, seed=1234)
+    a = ca.neighbors.NeighborListNsqrd(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+                                       skin=SKIN * u.nanometer, n_max_neighbors=180)
+    b = ca.neighbors.NeighborListCell(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+                                      skin=SKIN * u.nanometer, n_max_neighbors=180)
+    a.build(x, box)
+    b.build(x, box)
+    assert b._perm is not None, "cell path was not taken"
+    assert torch.equal(a.neighbor_list, b.neighbor_list)
+    assert torch.equal(a.n_neighbors, b.n_neighbors) and torch.equal(a.neighbor_mask, b.neighbor_mask)
+    assert abs(int(a.n_neighbors.sum()) - 613000) < 20000  # ~6.13e5 list pairs
+
+
+# ---------------------------------------------------------------------------
+# pair list
+# ---------------------------------------------------------------------------
+def test_pairlist_golden(ca, golden):
+    u = ca.unit
+    g = golden["pairlist_pair"]
+    x = np.array(g["coordinates"], f32)
+    state = make_state(ca, x, g["box"])
+    space = ca.neighbors.OrthogonalPeriodicSpace()
+    pl = ca.neighbors.PairListNsqrd(space, cutoff=g["cutoff"] * u.nanometer)
+    assert pl.cutoff == g["cutoff"] * u.nanometer
+    pl.build_from_state(state)
+    assert np.array_equal(u32(pl.all_pairs), np.array(g["all_pairs"]))
+    assert np.array_equal(pl.reduction_mask.cpu().numpy(), np.array(g["reduction_mask"]))
+    for cutoff in (g["cutoff"] * u.nanometer, None):
+        pl.cutoff = cutoff
+        n_pairs, all_pairs, mask, dist, disp = pl.calculate(state.positions)
+        assert np.array_equal(n_pairs.cpu().numpy(), np.array(g["n_pairs"]))
+        assert all_pairs.shape == (2, 1)
+        assert np.array_equal(mask.cpu().numpy(), np.array(g["mask"]))
+        assert np.array_equal(dist.cpu().numpy(), np.array(g["dist"], f32))
+        assert disp.shape == (2, 1, 3)
+        assert np.array_equal(disp.cpu().numpy(), np.array(g["displacement"], f32))
+    assert pl.check(x) is False
+    assert pl.check(np.zeros((3, 3), f32)) is True
+    with pytest.raises(ValueError):
+        pl.calculate(np.zeros((3, 3), f32))
+    pl.cutoff = g["short_cutoff"] * u.nanometer
+    assert np.array_equal(pl.calculate(state.positions)[2].cpu().numpy(), np.array(g["short_cutoff_mask"]))
+    pl.cutoff = None
+    assert np.array_equal(pl.calculate(state.positions)[2].cpu().numpy(), np.array(g["no_cutoff_mask"]))
+
+    g = golden["pairlist_cube"]
+    x = cube_coordinates()
+    box = golden["neighborlist_cube"]["box"]
+    pl = ca.neighbors.PairListNsqrd(space, cutoff=g["cutoff"] * u.nanometer)
+    pl.build(x, np.array(box, f32))
+    n_int, all_pairs, mask, dist, rij = pl.calculate(x)
+    assert np.array_equal(n_int.cpu().numpy(), np.array(g["n_interacting"]))
+    assert np.array_equal(u32(all_pairs), np.array(g["all_pairs"]))
+    assert np.array_equal(dist.cpu().numpy(), np.array(g["dist"], f32))
+    nbr = ca.neighbors.NeighborListNsqrd(space, cutoff=g["cutoff"] * u.nanometer, skin=g["skin"] * u.nanometer,
+                                         n_max_neighbors=20)
+    nbr.build(x, np.array(box, f32))
+    _, _, mask1, dist1, _ = nbr.calculate(x)
+    s0 = np.where(mask.cpu().numpy(), dist.cpu().numpy(), 0).sum(dtype=f32)
+    s1 = np.where(mask1.cpu().numpy(), dist1.cpu().numpy(), 0).sum(dtype=f32)
+    assert s0 == s1
+
+
+def test_pairlist_random_bitexact(ca, O):
+    u = ca.unit
+    x, box = O.lj_lattice(300, 0.5, SIGMA, seed=21)
+    pl = ca.neighbors.PairListNsqrd(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer)
+    pl.build(x, box)
+    ap, red = O.pairlist_build(300)
+    assert np.array_equal(u32(pl.all_pairs), ap) and np.array_equal(pl.reduction_mask.cpu().numpy(), red)
+    for cutoff in (CUTOFF, None):
+        pl.cutoff = None if cutoff is None else cutoff * u.nanometer
+        n_p, _, mask, dist, rij = pl.calculate(x)
+        n0, m0, d0, r0 = O.pairlist_calculate(x, ap, red, box, cutoff)
+        assert np.array_equal(n_p.cpu().numpy(), n0) and np.array_equal(mask.cpu().numpy(), m0)
+        assert np.array_equal(dist.cpu().numpy(), d0) and np.array_equal(rij.cpu().numpy(), r0)
+
+
+def test_nopbc_pairlist_golden(ca, golden):
+    g = golden["nopbc_pairlist"]
+    pot = ca.potential.NeuralNetworkPotential(model=None)
+    for case in g["two_particles_cases"]:
+        d, r, pairs = pot.compute_pairlist(np.array(g["two_particles_nm"], f32), case["cutoff"])
+        assert pairs[0].numel() == case["n_pairs"] and pairs[1].numel() == case["n_pairs"]
+    d, r, pairs = pot.compute_pairlist(np.array(g["ethanol_nm"], f32), g["ethanol_cutoff"])
+    assert pairs[0].numel() == g["ethanol_n_pairs"]
+
+
+# ---------------------------------------------------------------------------
+# LJ energy / force
+# ---------------------------------------------------------------------------
+def test_lj_input_errors(ca):
+    u = ca.unit
+    LJ = ca.potential.LJPotential
+    with pytest.raises(TypeError):
+        LJ(1)
+    with pytest.raises(TypeError):
+        LJ(None, sigma=1.0)
+    with pytest.raises(TypeError):
+        LJ(None, epsilon=1.0)
+    with pytest.raises(TypeError):
+        LJ(None, cutoff=1.0)
+    with pytest.raises(ValueError):
+        LJ(None, sigma=1.0 * u.kilocalories_per_mole)
+    with pytest.raises(ValueError):
+        LJ(None, epsilon=1.0 * u.nanometer)
+    with pytest.raises(ValueError):
+        LJ(None, cutoff=1.0 * u.kilocalories_per_mole)
+    x = np.array([[0, 0, 0], [1, 0, 0]], f32)
+    box = np.diag([10.0, 10.0, 10.0]).astype(f32)
+    lj = LJ(None, sigma=1.0 * u.nanometer)
+    nbr = ca.neighbors.NeighborListNsqrd(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=2.0 * u.nanometer)
+    with pytest.raises(ValueError):
+        lj.compute_energy(x, nbr)  # not built
+    nbr.build(x, box)
+    with pytest.raises(ValueError):
+        lj.compute_energy(x, nbr)  # cutoff mismatch
+
+
+def test_lennard_jones_two_particles_golden(ca, golden):
+    g = golden["lennard_jones_two_particles"]
+    u = ca.unit
+    sigma, eps, cutoff, skin = g["sigma"], g["epsilon"], g["cutoff"], g["skin"]
+    pot = ca.potential.LJPotential(None, u.Quantity(sigma, u.nanometer), u.Quantity(eps, u.kilojoules_per_mole),
+                                   u.Quantity(cutoff, u.nanometer))
+    space = ca.neighbors.OrthogonalPeriodicSpace()
+    for i in range(1, 11):
+        x = np.array([[0, 0, 0], [i * 0.25 * 2 ** (1 / 6), 0, 0]], f32)
+        state = make_state(ca, x, g["box"])
+        nbr = ca.neighbors.NeighborListNsqrd(space, cutoff=u.Quantity(cutoff, u.nanometer),
+                                             skin=u.Quantity(skin, u.nanometer), n_max_neighbors=5)
+        nbr.build_from_state(state)
+        e = float(pot.compute_energy(state.positions))
+        e_nbr = float(pot.compute_energy(state.positions, nbr))
+        disp = x[0] - x[1]
+        dist = np.linalg.norm(disp)
+        e_ref = 4.0 * eps * ((sigma / dist) ** 12 - (sigma / dist) ** 6)
+        assert np.isclose(e, e_ref, rtol=g["energy_rtol"], atol=g["energy_atol"])
+        assert np.isclose(e_nbr, e_ref, rtol=g["energy_rtol"], atol=g["energy_atol"])
+        f = (24 * (eps / (dist * dist)) * (2 * (sigma / dist) ** 12 - (sigma / dist) ** 6)) * disp
+        f_ref = np.array([f, -f])
+        # the reference's atol=1e-5 sits on top of jnp.allclose's default rtol=1e-5
+        for got in (pot.compute_force(state.positions), pot.compute_force(state.positions, nbr),
+                    pot.compute_force_analytical(state.positions)):
+            assert np.allclose(got.cpu().numpy(), f_ref, atol=g["force_atol"], rtol=1e-5), i
+
+
+def _check_vs_f64(O, e, f, x, box, sigma, eps, cutoff, periodic=True, pair_filter=None):
+    e64, f64, eabs, fmax = O.lj_bruteforce_f64(x, box, sigma, eps, cutoff, periodic=periodic, pair_filter=pair_filter)
+    assert abs(float(e) - e64) <= 1e-5 * max(eabs, 1e-12), (float(e), e64, eabs)
+    assert np.abs(f - f64).max() <= 1e-5 * max(1.0, fmax), (np.abs(f - f64).max(), fmax)
+
+
+@pytest.mark.parametrize("cls_name", ["NeighborListNsqrd", "NeighborListCell"])
+def test_lj_nbrlist_energy_force(ca, O, cls_name):
+    u = ca.unit
+    cls = getattr(ca.neighbors, cls_name)
+    for name, x, box in _systems(O):
+        n = x.shape[0]
+        pot = lj_pot(ca, n)
+        nbr = cls(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer, skin=SKIN * u.nanometer,
+                  n_max_neighbors=180)
+        nbr.build(x, box)
+        # evaluate at displaced (still inside the skin guarantee) positions
+        rng = np.random.default_rng(3)
+        x2 = (x + rng.normal(0, 0.03, size=x.shape)).astype(f32)
+        e = pot.compute_energy(x2, nbr)
+        f = pot.compute_force(x2, nbr).cpu().numpy()
+        # vs the fp32 restatement of the reference
+        nl_mask, nl, n_nbr, n_max = O.neighborlist_build(x, box, CUTOFF, SKIN, 180)
+        e32 = O.lj_energy_nbrlist_f32(x2, nl, nl_mask, box, SIGMA, EPS, CUTOFF)
+        f32o = O.lj_force_nbrlist_f32(x2, nl, nl_mask, box, SIGMA, EPS, CUTOFF)
+        e64, f64, eabs, fmax = O.lj_bruteforce_f64(x2, box, SIGMA, EPS, CUTOFF)
+        assert abs(float(e) - float(e32)) <= 2e-5 * eabs, name
+        assert np.abs(f - f32o).max() <= 2e-5 * max(1.0, fmax), name
+        _check_vs_f64(O, e, f, x2, box, SIGMA, EPS, CUTOFF)
+        e2, f2 = pot.compute_energy_and_force(x2, nbr)
+        assert float(e2) == float(e) and np.array_equal(f2.cpu().numpy(), f)
+
+
+def test_lj_stale_list_uses_list_pairs_only(ca, O):
+    """Pairs that drift inside the cutoff without being in the list do not interact (reference semantics)."""
+    u = ca.unit
+    x, box = O.lj_lattice(800, 0.4, SIGMA, seed=31)
+    nbr = ca.neighbors.NeighborListNsqrd(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+                                         skin=0.05 * u.nanometer, n_max_neighbors=300)
+    nbr.build(x, box)
+    rng = np.random.default_rng(8)
+    x2 = (x + rng.normal(0, 0.2, size=x.shape)).astype(f32)  # far beyond skin/2
+    pot = lj_pot(ca, 800)
+    e = pot.compute_energy(x2, nbr)
+    f = pot.compute_force(x2, nbr).cpu().numpy()
+    nl_mask, nl, n_nbr, _ = O.neighborlist_build(x, box, CUTOFF, 0.05, 300)
+    listed = np.zeros((800, 800), bool)
+    for i in range(800):
+        listed[i, nl[i, : n_nbr[i]]] = True
+    listed |= listed.T
+    _check_vs_f64(O, e, f, x2, box, SIGMA, EPS, CUTOFF, pair_filter=lambda ii, jj: listed[ii, jj])
+
+
+def test_lj_pairlist_and_nolist(ca, O, methane_coords, golden):
+    u = ca.unit
+    x, box = O.lj_lattice(512, 0.1, SIGMA, seed=1234)  # config C2
+    pot = lj_pot(ca, 512)
+    pl = ca.neighbors.PairListNsqrd(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer)
+    pl.build(x, box)
+    e = pot.compute_energy(x, pl)
+    f = pot.compute_force(x, pl).cpu().numpy()
+    _check_vs_f64(O, e, f, x, box, SIGMA, EPS, CUTOFF)
+    # no list: no PBC
+    e = pot.compute_energy(x)
+    f = pot.compute_force(x).cpu().numpy()
+    _check_vs_f64(O, e, f, x, None, SIGMA, EPS, CUTOFF, periodic=False)
+    assert np.isclose(float(e), float(O.lj_energy_nopbc_f32(x, SIGMA, EPS, CUTOFF)), rtol=2e-5)
+    # methane fixture (Examples/LJ_MCMC.py): dense liquid
+    g = golden["methane"]
+    L = g["box_edge"]
+    box = np.diag([L, L, L]).astype(f32)
+    eps = g["epsilon_kcal_mol"] * 4.184
+    xm = methane_coords.astype(f32)
+    pot = lj_pot(ca, 1100, g["sigma"], eps, g["cutoff"])
+    nbr = ca.neighbors.NeighborListCell(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=g["cutoff"] * u.nanometer,
+                                        skin=0.4 * u.nanometer, n_max_neighbors=200)
+    nbr.build(xm, box)
+    e = pot.compute_energy(xm, nbr)
+    f = pot.compute_force(xm, nbr).cpu().numpy()
+    _check_vs_f64(O, e, f, xm, box, g["sigma"], eps, g["cutoff"])
+    assert abs(float(e) - g["build_crosscheck_energy_kj_mol"]) < 0.2
+
+
+def test_lj_empty_and_tiny(ca):
+    u = ca.unit
+    pot = lj_pot(ca, 2)
+    x = np.array([[0, 0, 0], [5, 0, 0]], f32)  # beyond cutoff: energy 0 (potential.py:249-250)
+    assert float(pot.compute_energy(x)) == 0.0
+    assert np.array_equal(pot.compute_force(x).cpu().numpy(), np.zeros((2, 3), f32))
+    pot1 = lj_pot(ca, 1)
+    assert float(pot1.compute_energy(np.zeros((1, 3), f32))) == 0.0
+
+
+# ---------------------------------------------------------------------------
+# RNG stream, velocities
+# ---------------------------------------------------------------------------
+def test_velocity_init_matches_oracle_stream(ca, O):
+    from chiron_amd.rng import PRNGKey
+
+    key = PRNGKey(0xDEADBEEF, 0x1234)
+    n = 4096
+    mass = np.full(n, 39.948, f32)
+    kT = O.R_KJ * 300.0
+    v = ca.ops.init_velocities(dev(mass), kT, key).cpu().numpy()
+    z = O.philox_normals3(n, 0, O.STREAM_VELOCITY, key)
+    v0 = O.initial_velocities(mass, kT, z)
+    assert np.allclose(v, v0, rtol=2e-5, atol=2e-6)
+    # injected normals: bit-exact
+    v = ca.ops.init_velocities(dev(mass), kT, key, dev(z)).cpu().numpy()
+    assert np.array_equal(v, v0)
+    # Maxwell-Boltzmann: <m v^2> = kT per degree of freedom
+    assert abs((39.948 * v ** 2).mean() / kT - 1.0) < 0.03
+
+
+# ---------------------------------------------------------------------------
+# Langevin
+# ---------------------------------------------------------------------------
+def _langevin_setup(ca, O, n, rho, seed, skin, dt_fs, nbr_cls="NeighborListCell", m=180):
+    u = ca.unit
+    x, box = O.lj_lattice(n, rho, SIGMA, seed=seed)
+    pot = lj_pot(ca, n)
+    state = make_state(ca, x, box)
+    thermo = ca.states.ThermodynamicState(pot, temperature=300 * u.kelvin)
+    nbr = getattr(ca.neighbors, nbr_cls)(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+                                         skin=skin * u.nanometer, n_max_neighbors=m)
+    integ = ca.integrators.LangevinIntegrator(timestep=dt_fs * u.femtoseconds, collision_rate=1.0 / u.picoseconds,
+                                              chunk_size=7)
+    return x, box, pot, state, thermo, nbr, integ
+
+
+def test_langevin_injected_noise_matches_oracle(ca, O):
+    n, steps = 600, 12
+    x, box, pot, state, thermo, nbr, integ = _langevin_setup(ca, O, n, 0.6, 41, SKIN, 2.0)
+    rng = np.random.default_rng(99)
+    noise = rng.normal(size=(steps, n, 3)).astype(f32)
+    mass = np.full(n, 39.948, f32)
+    kT = O.R_KJ * 300.0
+    v0 = O.initial_velocities(mass, kT, rng.normal(size=(n, 3)).astype(f32))
+    state.velocities = v0
+    out, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr, noise=noise)
+    xo, vo, rebuilds, _ = O.langevin_run(x, v0, box, mass, SIGMA, EPS, CUTOFF, SKIN, 180, 0.002, 1.0, 300.0, steps,
+                                         lambda s: noise[s])
+    assert integ.n_rebuilds == rebuilds
+    assert np.abs(out.positions.cpu().numpy() - xo).max() < 2e-6
+    assert np.abs(out.velocities.cpu().numpy() - vo).max() < 2e-4 * max(1.0, np.abs(vo).max())
+
+
+def test_langevin_rebuild_step_matches_oracle(ca, O):
+    """Tiny skin + large timestep: the device flag must stop the chunk at the reference's rebuild step."""
+    n, steps = 400, 30
+    skin = 0.02
+    x, box, pot, state, thermo, nbr, integ = _langevin_setup(ca, O, n, 0.3, 43, skin, 4.0, "NeighborListNsqrd", 250)
+    rng = np.random.default_rng(5)
+    noise = rng.normal(size=(steps, n, 3)).astype(f32)
+    mass = np.full(n, 39.948, f32)
+    kT = O.R_KJ * 300.0
+    v0 = O.initial_velocities(mass, kT, rng.normal(size=(n, 3)).astype(f32))
+    state.velocities = v0
+    out, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr, noise=noise)
+    xo, vo, rebuilds, (nl_mask, nl, n_max) = O.langevin_run(x, v0, box, mass, SIGMA, EPS, CUTOFF, skin, 250, 0.004,
+                                                            1.0, 300.0, steps, lambda s: noise[s])
+    assert rebuilds >= 2, "test needs rebuilds to be meaningful"
+    assert integ.n_rebuilds == rebuilds
+    assert np.abs(out.positions.cpu().numpy() - xo).max() < 1e-5
+    assert nbr.n_max_neighbors == n_max
+    assert np.array_equal(u32(nbr.neighbor_list), nl)  # same list => same rebuild steps and same ref positions
+
+
+def test_langevin_device_rng_matches_oracle_stream(ca, O):
+    n, steps = 300, 5
+    x, box, pot, state, thermo, nbr, integ = _langevin_setup(ca, O, n, 0.5, 47, SKIN, 1.0)
+    mass = np.full(n, 39.948, f32)
+    state.velocities = np.zeros((n, 3), f32)
+    import chiron_amd.rng as R
+
+    key_before = state.current_PRNG_key
+    out, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr)
+    _, run_key = R.split(key_before)  # what new_PRNG_key handed to run()
+    xo, vo, _, _ = O.langevin_run(x, np.zeros((n, 3), f32), box, mass, SIGMA, EPS, CUTOFF, SKIN, 180, 0.001, 1.0, 300.0,
+                                  steps, lambda s: O.philox_normals3(n, s, O.STREAM_LANGEVIN, run_key))
+    assert np.abs(out.positions.cpu().numpy() - xo).max() < 2e-6
+    assert np.abs(out.velocities.cpu().numpy() - vo).max() < 1e-4
+
+
+def test_langevin_nolist_and_pairlist(ca, O):
+    u = ca.unit
+    n, steps = 200, 6
+    x, box = O.lj_lattice(n, 0.5, SIGMA, seed=51)
+    pot = lj_pot(ca, n)
+    thermo = ca.states.ThermodynamicState(pot, temperature=300 * u.kelvin)
+    rng = np.random.default_rng(1)
+    noise = rng.normal(size=(steps, n, 3)).astype(f32)
+    mass = np.full(n, 39.948, f32)
+    integ = ca.integrators.LangevinIntegrator(timestep=1.0 * u.femtoseconds)
+    state = make_state(ca, x, box)
+    state.velocities = np.zeros((n, 3), f32)
+    out, _ = integ.run(state, thermo, number_of_steps=steps, nbr_list=None, noise=noise)
+    xo, vo, _, _ = O.langevin_run(x, np.zeros((n, 3), f32), box, mass, SIGMA, EPS, CUTOFF, SKIN, 180, 0.001, 1.0, 300.0,
+                                  steps, lambda s: noise[s], use_nbr_list=False)
+    assert np.abs(out.positions.cpu().numpy() - xo).max() < 2e-6
+    assert np.abs(out.velocities.cpu().numpy() - vo).max() < 1e-4
+    # PairListNsqrd: PBC all-pairs + wrap each step
+    pl = ca.neighbors.PairListNsqrd(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer)
+    state = make_state(ca, x, box)
+    out, pl = integ.run(state, thermo, number_of_steps=steps, nbr_list=pl)
+    xw = out.positions.cpu().numpy()
+    assert np.isfinite(xw).all() and (xw >= 0).all() and (xw <= box[0, 0]).all()
+
+
+def test_langevin_ideal_gas_external_force_path(ca):
+    u = ca.unit
+    ig = ca.testsystems.IdealGas(64)
+    pot = ca.potential.IdealGasPotential(ig.topology)
+    thermo = ca.states.ThermodynamicState(pot, temperature=298 * u.kelvin)
+    ca.utils.PRNG.set_seed(1234)
+    state = ca.states.SamplerState(ig.positions, ca.utils.PRNG.get_random_key(), box_vectors=ig.box_vectors)
+    out, _ = ca.integrators.LangevinIntegrator().run(state, thermo, number_of_steps=10)
+    assert torch.isfinite(out.positions).all() and out.velocities.shape == (64, 3)
+
+
+def test_langevin_kinetic_temperature(ca, O):
+    """Statistical pin of BAOAB with the device PRNG: <m v^2> = kT per dof after equilibration."""
+    n = 4096
+    x, box, pot, state, thermo, nbr, integ = _langevin_setup(ca, O, n, 0.1, 1234, SKIN, 2.0)
+    integ = ca.integrators.LangevinIntegrator(timestep=2.0 * ca.unit.femtoseconds,
+                                              collision_rate=5.0 / ca.unit.picoseconds)
+    out, nbr = integ.run(state, thermo, number_of_steps=1500, nbr_list=nbr)
+    kT = O.R_KJ * 300.0
+    v = out.velocities.cpu().numpy()
+    assert abs((39.948 * v ** 2).mean() / kT - 1.0) < 0.04
+    assert integ.n_rebuilds >= 1
+
+
+# ---------------------------------------------------------------------------
+# Monte Carlo
+# ---------------------------------------------------------------------------
+def test_mc_displace_matches_oracle(ca, O):
+    from chiron_amd.rng import PRNGKey
+
+    key = PRNGKey(77, 1)
+    x, box = O.lj_lattice(500, 0.2, SIGMA, seed=61)
+    z = O.philox_normals3(500, 0, O.STREAM_MC_DISPLACE, key)
+    bx = ca.ops.make_box(box, True)
+    got = ca.ops.mc_displace(dev(x), 0.05, bx, key, 0, None, dev(z)).cpu().numpy()
+    assert np.array_equal(got, O.mc_displace(x, 0.05, z, box))
+    mask = (np.arange(500) % 3 == 0).astype(f32)
+    got = ca.ops.mc_displace(dev(x), 0.05, bx, key, 0, dev(mask), dev(z)).cpu().numpy()
+    assert np.array_equal(got, O.mc_displace(x, 0.05, z, box, mask))
+    got = ca.ops.mc_displace(dev(x), 0.05, bx, key, 0).cpu().numpy()  # device Philox
+    assert np.allclose(got, O.mc_displace(x, 0.05, z, box), atol=2e-6)
+    got = ca.ops.mc_displace(dev(x), 0.05, ca.ops.make_box(None, False), key, 0, None, dev(z)).cpu().numpy()
+    assert np.array_equal(got, O.mc_displace(x, 0.05, z, None))
+
+
+def test_mc_displacement_move_lj(ca, O):
+    u = ca.unit
+    n = 500
+    x, box = O.lj_lattice(n, 0.1, SIGMA, seed=71)
+    pot = lj_pot(ca, n)
+    state = make_state(ca, x, box)
+    thermo = ca.states.ThermodynamicState(pot, temperature=300 * u.kelvin)
+    nbr = ca.neighbors.NeighborListCell(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+                                        skin=SKIN * u.nanometer, n_max_neighbors=180)
+    nbr.build_from_state(state)
+    rep = ca_reporter(ca)
+    move = ca.mcmc.MonteCarloDisplacementMove(displacement_sigma=0.002 * u.nanometer, number_of_moves=40,
+                                              reporter=rep, report_interval=1, autotune=True, autotune_interval=20)
+    s2, t2, n2 = move.update(state, thermo, nbr)
+    st = move.statistics
+    assert st["n_proposed"] == 40 and 0 < st["n_accepted"] <= 40
+    # Metropolis bookkeeping: the cached reduced potential equals a fresh evaluation of the final state
+    assert np.isclose(float(move._current_reduced_potential), float(thermo.get_reduced_potential(s2, n2)), rtol=1e-5)
+    assert rep.get_property("potential_energy").shape == (40,)
+    # every decision is consistent with the oracle rule on the recorded numbers
+    sampler = ca.mcmc.MCMCSampler(ca.mcmc.MoveSchedule([("mc", move)]))
+    sampler.run(state, thermo, n_iterations=1, nbr_list=nbr)
+    with pytest.raises(ValueError):
+        ca.mcmc.MoveSchedule([("bad", 123)])
+
+
+def ca_reporter(ca):
+    from chiron_amd.reporters import MCReporter
+
+    return MCReporter("mc_test", 1)
+
+
+def test_ideal_gas_barostat(ca):
+    """Config C1 plumbing: NPT ideal gas, PE == 0, reduced potential == beta p V (test_mcmc.py:340-452)."""
+    u = ca.unit
+    from chiron_amd.topology import Topology
+
+    positions = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 0], [1, 0, 1], [0, 1, 1], [1, 1, 1]], f32)
+    box = np.diag([10.0, 10.0, 10.0]).astype(f32)
+    pot = ca.potential.IdealGasPotential(Topology.homogeneous(8))
+    ca.utils.PRNG.set_seed(1234)
+    state = ca.states.SamplerState(nm(positions, ca), ca.utils.PRNG.get_random_key(), box_vectors=nm(box, ca))
+    thermo = ca.states.ThermodynamicState(pot, temperature=300 * u.kelvin, pressure=1.0 * u.atmosphere)
+    rep = ca_reporter(ca)
+    move = ca.mcmc.MonteCarloBarostatMove(volume_max_scale=0.1, number_of_moves=10, reporter=rep, report_interval=1)
+    nbr = ca.neighbors.PairListNsqrd(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=0 * u.nanometer)
+    state, thermo, nbr = move.update(state, thermo, nbr)
+    pe = rep.get_property("potential_energy")
+    vol = rep.get_property("volume")
+    assert pe[0] == 0 and pe[-1] == 0
+    expect = thermo.pressure * thermo.beta * (vol[-1] * u.nanometer ** 3)
+    assert np.isclose(thermo.get_reduced_potential(state), expect, rtol=1e-3)
+    assert move.statistics["n_proposed"] == 10
+    assert 5 <= move.statistics["n_accepted"] <= 10  # the reference's 8/10 depends on the JAX stream
+    # positions scaled with the box
+    assert np.isclose(float(state.box_vectors[0][0]) ** 3, vol[-1], rtol=1e-4)
+
+
+def test_metropolis_select_kernel(ca):
+    from chiron_amd.rng import PRNGKey
+
+    key = PRNGKey(5, 6)
+    x_cur = dev(np.zeros((10, 3), f32))
+    x_prop = dev(np.ones((10, 3), f32))
+    acc = torch.zeros(1, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(2, dtype=torch.int32, device="cuda")
+    u_cur = dev([5.0])
+    u_prop = dev([4.0])
+    ca.ops.metropolis_select(x_cur, x_prop, dev([1.0]), u_cur, u_prop, key, 0, acc, cnt)  # downhill: accept
+    assert int(acc) == 1 and float(u_cur) == 4.0 and torch.equal(x_cur, x_prop)
+    x_cur.zero_()
+    ca.ops.metropolis_select(x_cur, x_prop, dev([-1.0]), u_cur, u_prop, key, 0, acc, cnt, uniform=0.9)
+    assert int(acc) == 0 and float(x_cur.abs().sum()) == 0.0
+    ca.ops.metropolis_select(x_cur, x_prop, dev([-1.0]), u_cur, u_prop, key, 0, acc, cnt, uniform=0.3)
+    assert int(acc) == 1
+    ca.ops.metropolis_select(x_cur, x_prop, dev([float("nan")]), u_cur, dev([float("nan")]), key, 0, acc, cnt)
+    assert int(acc) == 0
+    assert cnt.cpu().tolist() == [2, 4]
+    # device uniform == host twin
+    import chiron_amd.rng as R
+
+    uu = R.uniform(key, 3)
+    lp = float(np.log(uu))  # U < exp(lp) is false at equality, true just above
+    ca.ops.metropolis_select(x_cur, x_prop, dev([lp * 0.999]), u_cur, u_prop, key, 3, acc, cnt)
+    assert int(acc) == 1
+    ca.ops.metropolis_select(x_cur, x_prop, dev([lp * 1.001]), u_cur, u_prop, key, 3, acc, cnt)
+    assert int(acc) == 0
+
+
+def test_cpu_tensors_are_refused(ca):
+    from chiron_amd._lib import ChxError
+
+    with pytest.raises(ChxError):
+        ca.ops.wrap(torch.zeros(4, 3), ca.ops.make_box(np.eye(3, dtype=f32), True))

@@ -1,0 +1,310 @@
+"""CPU-side tests: unit shim, state containers, error conventions, PRNG keys, and that
+libchx.so loads and exports every symbol include/chx.h declares (no kernels run here)."""
+import copy
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from chiron_amd import unit
+from chiron_amd.rng import PRNGKey, fold_in, philox4x32, split, uniform
+from chiron_amd.states import SamplerState, ThermodynamicState
+from chiron_amd.topology import Element, Topology
+from chiron_amd.utils import PRNG, get_list_of_mass, get_nr_of_particles
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------------------
+# unit shim against the values openmm.unit produces
+# ---------------------------------------------------------------------------
+def test_unit_conversions_md_system():
+    md = unit.md_unit_system
+    assert math.isclose((0.238 * unit.kilocalories_per_mole).value_in_unit_system(md), 0.995792)
+    assert math.isclose((3.4 * unit.angstrom).value_in_unit_system(md), 0.34)
+    assert math.isclose((1.0 * unit.femtoseconds).value_in_unit_system(md), 0.001)
+    assert math.isclose((1.0 / unit.picoseconds).value_in_unit_system(md), 1.0)
+    assert math.isclose((39.948 * unit.amu).value_in_unit_system(md), 39.948)
+    kT = (unit.BOLTZMANN_CONSTANT_kB * unit.AVOGADRO_CONSTANT_NA * (300 * unit.kelvin)).value_in_unit_system(md)
+    assert math.isclose(kT, 8.31446261815324e-3 * 300, rel_tol=1e-12)
+    k = 100.0 * unit.kilocalories_per_mole / unit.angstroms**2
+    assert math.isclose(k.value_in_unit_system(md), 41840.0)
+    assert math.isclose((16.04 * unit.gram / unit.mole).value_in_unit(unit.amu), 16.04)
+
+
+def test_unit_algebra_and_collapse():
+    beta = 1.0 / (unit.BOLTZMANN_CONSTANT_kB * (300 * unit.kelvin))
+    red = unit.Quantity(-1000.0, unit.kilojoule_per_mole) / unit.AVOGADRO_CONSTANT_NA
+    red = red + (1.0 * unit.atmosphere) * (1000.0 * unit.nanometer**3)
+    u = beta * red
+    assert isinstance(u, float)
+    assert math.isclose(u, (-1000.0e3 / 6.02214076e23 + 101325.0 * 1000e-27) / (1.380649e-23 * 300), rel_tol=1e-12)
+    assert (1.0 * unit.nanometer) == (10.0 * unit.angstrom)
+    assert not ((1.1 * unit.nanometer) == (1.0 * unit.kelvin))
+    assert (3.0 * (0.34 * unit.nanometer)).value_in_unit(unit.nanometer) == pytest.approx(1.02)
+    q = 0.1 * unit.nanometer
+    q *= 1.1
+    q /= 1.1
+    assert q.value_in_unit(unit.nanometer) == pytest.approx(0.1)
+    assert unit.nanometer.is_compatible(unit.angstrom) and not unit.nanometer.is_compatible(unit.radian)
+    with pytest.raises(TypeError):
+        (1.0 * unit.nanometer).value_in_unit(unit.kelvin)
+    arr = np.ones((2, 3)) * unit.angstrom
+    assert isinstance(arr, unit.Quantity) and arr.shape == (2, 3)
+    assert np.allclose(arr.value_in_unit_system(unit.md_unit_system), 0.1)
+    t = torch.ones(2, 3) * unit.nanometer
+    assert isinstance(t, unit.Quantity) and isinstance(t[0][0], unit.Quantity)
+    box = np.diag([10.0, 10.0, 10.0]) * unit.nanometer
+    vol = box[0][0] * box[1][1] * box[2][2]
+    assert vol.unit.is_compatible(unit.nanometer**3) and float(vol.value_in_unit(unit.nanometer**3)) == 1000.0
+    assert np.all(copy.deepcopy(arr) == arr)
+
+
+def test_topology_and_masses():
+    top = Topology()
+    el = Element.getBySymbol("Ar")
+    chain = top.addChain()
+    res = top.addResidue("system", chain)
+    for _ in range(8):
+        top.addAtom("Ar", el, res)
+    assert get_nr_of_particles(top) == 8
+    m = get_list_of_mass(top)
+    assert np.allclose(m.value_in_unit_system(unit.md_unit_system), 39.948)
+    ch4 = Element(1000, "CH4", "CH4", unit.Quantity(16.04, unit.gram / unit.mole))
+    assert math.isclose(ch4.mass.value_in_unit(unit.amu), 16.04)
+
+
+# ---------------------------------------------------------------------------
+# PRNG keys
+# ---------------------------------------------------------------------------
+def test_prng_keys():
+    PRNG.set_seed(1234)
+    a = PRNG.get_random_key()
+    b = PRNG.get_random_key()
+    PRNG.set_seed(1234)
+    assert PRNG.get_random_key() == a and a != b
+    k = PRNGKey.from_seed(1234)
+    k1, s1 = split(k)
+    assert k1 != s1 and split(k) == (k1, s1)
+    assert fold_in(k, 5) != fold_in(k, 6)
+    assert 0.0 < uniform(k) < 1.0
+    assert philox4x32((0, 0, 0, 0), (0, 0)) == (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)
+
+
+def test_host_philox_matches_oracle():
+    from oracle import chiron_oracle as O
+
+    key = PRNGKey(123456789, 987654321)
+    o = O.philox4x32(np.arange(5), 7, 0, 3, key[0], key[1])
+    for i in range(5):
+        assert philox4x32((i, 7, 0, 3), key) == tuple(int(w[i]) for w in o)
+    assert uniform(key, 7) == float(O.u32_to_uniform(np.uint32(philox4x32((0, 7, 0, 3), key)[0])))
+
+
+# ---------------------------------------------------------------------------
+# state containers (reference: chiron/tests/test_states.py, test_mcmc.py:289-324)
+# ---------------------------------------------------------------------------
+def _key():
+    PRNG.set_seed(1234)
+    return PRNG.get_random_key()
+
+
+def test_sampler_state_conversion_and_inputs():
+    s = SamplerState(unit.Quantity(np.array([[10.0, 10.0, 10.0]]), unit.nanometer), _key())
+    assert torch.allclose(s.positions.cpu(), torch.tensor([[10.0, 10.0, 10.0]]))
+    s = SamplerState(unit.Quantity(np.array([[10.0, 10.0, 10.0]]), unit.angstrom), _key())
+    assert torch.allclose(s.positions.cpu(), torch.tensor([[1.0, 1.0, 1.0]]))
+    assert s.positions.dtype == torch.float32 and s.number_of_particles == 1
+    with pytest.raises(TypeError):
+        SamplerState(positions=np.array([1, 2, 3]))
+    with pytest.raises(ValueError):
+        SamplerState(unit.Quantity(np.array([[1, 2, 3]]), unit.radians), _key())
+    with pytest.raises(TypeError):
+        SamplerState(unit.Quantity(np.array([[1, 2, 3]]), unit.nanometers), _key(), velocities=np.array([1, 2, 3]))
+    with pytest.raises(ValueError):
+        SamplerState(unit.Quantity(np.array([[1, 2, 3]]), unit.nanometers), _key(),
+                     velocities=unit.Quantity(np.array([1, 2, 3]), unit.nanometers))
+    with pytest.raises(TypeError):
+        SamplerState(unit.Quantity(np.array([[1, 2, 3]]), unit.nanometers), _key(), box_vectors=np.array([1, 2, 3]))
+    with pytest.raises(ValueError):
+        SamplerState(unit.Quantity(np.array([[1, 2, 3]]), unit.nanometers), _key(),
+                     box_vectors=unit.Quantity(np.eye(3), unit.radians))
+    with pytest.raises(ValueError):
+        SamplerState(unit.Quantity(np.array([[1, 2, 3]]), unit.nanometers), _key(),
+                     box_vectors=unit.Quantity(np.array([[1, 0, 0], [0, 1, 0]]), unit.nanometers))
+    with pytest.raises(ValueError):
+        SamplerState(unit.Quantity(np.array([[1, 2, 3]]), unit.nanometers), None)
+    openmm_box = [
+        unit.Quantity([4.031145745088737, 0.0, 0.0], unit.nanometer),
+        unit.Quantity([0.0, 4.031145745088737, 0.0], unit.nanometer),
+        unit.Quantity([0.0, 0.0, 4.031145745088737], unit.nanometer),
+    ]
+    st = SamplerState(unit.Quantity(np.array([[1, 2, 3]]), unit.nanometers), _key(), box_vectors=openmm_box)
+    assert np.allclose(st.box_vectors.cpu().numpy(), np.eye(3) * 4.0311456, atol=1e-4)
+    with pytest.raises(TypeError):
+        SamplerState(unit.Quantity(np.array([[1, 2, 3]]), unit.nanometers), _key(), box_vectors=[123])
+    # setters and key advance
+    st.positions = np.zeros((1, 3))
+    with pytest.raises(ValueError):
+        st.velocities = np.zeros((2, 3))
+    st.velocities = np.ones((1, 3))
+    k0 = st.current_PRNG_key
+    sub = st.new_PRNG_key
+    assert st.current_PRNG_key != k0 and sub != st.current_PRNG_key
+    c = copy.deepcopy(st)
+    c.positions = np.ones((1, 3))
+    assert float(st.positions.sum()) == 0.0
+
+
+def test_thermodynamic_state_inputs_and_reduced_potential():
+    from chiron_amd.potential import IdealGasPotential, LJPotential
+
+    pot = IdealGasPotential(Topology.homogeneous(8))
+    with pytest.raises(TypeError):
+        ThermodynamicState(pot, temperature=300)
+    with pytest.raises(ValueError):
+        ThermodynamicState(pot, temperature=300 * unit.angstrom)
+    with pytest.raises(TypeError):
+        ThermodynamicState(pot, volume=1000)
+    with pytest.raises(ValueError):
+        ThermodynamicState(pot, volume=1000 * unit.kelvin)
+    with pytest.raises(TypeError):
+        ThermodynamicState(pot, pressure=100)
+    with pytest.raises(ValueError):
+        ThermodynamicState(pot, pressure=100 * unit.kelvin)
+    ts = ThermodynamicState(pot, temperature=300 * unit.kelvin, volume=30 * unit.angstrom**3)
+    assert ts.temperature == 300 * unit.kelvin and ts.pressure is None and ts.nr_of_particles == 8
+    assert ts.check_variables() == ["temperature", "volume"]
+    ts = ThermodynamicState(pot, temperature=300 * unit.kelvin, pressure=1.0 * unit.atmosphere)
+    st = SamplerState(unit.Quantity(np.zeros((8, 3)), unit.nanometer), _key(),
+                      box_vectors=unit.Quantity(np.diag([10.0, 10.0, 10.0]), unit.nanometer))
+    from oracle import chiron_oracle as O
+
+    assert math.isclose(ts.get_reduced_potential(st), O.reduced_potential(0.0, 300.0, 1.0, 1000.0), rel_tol=1e-9)
+    with pytest.raises(TypeError):
+        LJPotential(1)
+    with pytest.raises(TypeError):
+        IdealGasPotential(1)
+
+
+def test_lj_and_neighbor_constructor_errors_without_gpu():
+    from chiron_amd.neighbors import NeighborListNsqrd, OrthogonalPeriodicSpace, PairListNsqrd
+    from chiron_amd.potential import LJPotential
+
+    with pytest.raises(ValueError):
+        LJPotential(None, sigma=1.0 * unit.kilocalories_per_mole)
+    lj = LJPotential(None, sigma=0.34 * unit.nanometer, epsilon=0.238 * unit.kilocalories_per_mole,
+                     cutoff=1.02 * unit.nanometer)
+    assert math.isclose(lj.epsilon, 0.995792) and lj.cutoff == 1.02
+    sp = OrthogonalPeriodicSpace()
+    with pytest.raises(TypeError):
+        NeighborListNsqrd(123)
+    with pytest.raises(ValueError):
+        NeighborListNsqrd(sp, cutoff=unit.Quantity(1, unit.radian))
+    nbr = NeighborListNsqrd(sp, cutoff=1.0 * unit.nanometer, skin=0.2 * unit.nanometer, n_max_neighbors=7)
+    assert not nbr.is_built and nbr.n_max_neighbors == 7
+    nbr.is_built = True
+    nbr.cutoff = 1.1 * unit.nanometer  # setters invalidate the list (neighbors.py:485)
+    assert nbr.is_built is False
+    with pytest.raises(TypeError):
+        nbr.build_from_state(123)
+    with pytest.raises(ValueError):
+        PairListNsqrd(sp, cutoff=1.0 * unit.kelvin)
+    with pytest.raises(TypeError):
+        PairListNsqrd(5)
+    with pytest.raises(ValueError):
+        lj.compute_energy(np.zeros((2, 3), np.float32), nbr)  # unbuilt list
+
+
+def test_kernels_refuse_cpu_tensors():
+    """No CPU fallback: the product path fails loudly without the device."""
+    from chiron_amd import ops
+    from chiron_amd._lib import ChxError
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ChxError):
+        ops.wrap(torch.zeros(4, 3), ops.make_box(np.eye(3, dtype=np.float32), True))
+    with pytest.raises(ChxError):
+        ops.lj_allpairs(torch.zeros(4, 3), ops.make_box(None, False), 1.0, 1.0, 1.0)
+
+
+# ---------------------------------------------------------------------------
+# Metropolis / autotune host logic
+# ---------------------------------------------------------------------------
+def test_mcmove_accept_rule_and_autotune():
+    from chiron_amd.mcmc import MonteCarloBarostatMove, MonteCarloDisplacementMove, MoveSchedule
+
+    mv = MonteCarloDisplacementMove(displacement_sigma=0.1 * unit.nanometer, number_of_moves=1)
+    key = PRNGKey(1, 2)
+    u = uniform(key)
+    assert mv._accept_or_reject(0.3, key, "Metropolis-Hastings") is True
+    assert mv._accept_or_reject(math.log(u) * 0.99, key, "Metropolis-Hastings") is True
+    assert mv._accept_or_reject(math.log(u) * 1.01, key, "Metropolis-Hastings") is False
+    mv.statistics = dict(n_accepted=7, n_proposed=10)
+    mv._autotune()
+    assert mv.displacement_sigma.value_in_unit(unit.nanometer) == pytest.approx(0.11)
+    mv.statistics = dict(n_accepted=3, n_proposed=10)
+    mv._autotune()
+    assert mv.displacement_sigma.value_in_unit(unit.nanometer) == pytest.approx(0.1)
+    b = MonteCarloBarostatMove(volume_max_scale=0.29, number_of_moves=1)
+    b.statistics = dict(n_accepted=9, n_proposed=10)
+    b._autotune()
+    assert b.volume_max_scale == 0.3
+    b.statistics = dict(n_accepted=1, n_proposed=10)
+    b._autotune()
+    assert b.volume_max_scale == pytest.approx(0.3 / 1.1)
+    with pytest.raises(ValueError):
+        MoveSchedule([("x", object())])
+
+
+# ---------------------------------------------------------------------------
+# the C ABI: library loads and exports everything the header declares
+# ---------------------------------------------------------------------------
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "chx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(chx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+
+    from chiron_amd import _lib
+
+    names = _header_functions()
+    assert len(names) >= 25
+    lib = _lib.load()  # raises if libchx.so is missing or a bound symbol does not resolve
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/chx.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
+    assert lib.chx_version() == 1
+    # struct layouts agree with the header (x86-64 SysV)
+    assert ctypes.sizeof(_lib.Box) == 16
+    assert ctypes.sizeof(_lib.LangevinParams) == 176
+
+
+def test_cutoff_threshold_helper_is_exact():
+    from chiron_amd import ops
+
+    rng = np.random.default_rng(0)
+    for c in list(rng.uniform(0.01, 5.0, 200).astype(np.float32)) + [np.float32(1.52), np.float32(1.02), np.float32(0.25)]:
+        T = np.float32(ops.cutoff_threshold(float(c)))
+        assert np.sqrt(T) < c and not (np.sqrt(np.nextafter(T, np.float32(np.inf))) < c)
+    assert ops.cutoff_threshold(0.0) < 0.0
+
+
+def test_cell_grid_helper():
+    from chiron_amd import ops
+
+    total, nc = ops.cell_grid(ops.make_box(np.diag([46.8805] * 3).astype(np.float32), True), 1.52, 262144)
+    assert list(nc) == [30, 30, 30] and total == 27000
+    total, nc = ops.cell_grid(ops.make_box(np.diag([23.4402] * 3).astype(np.float32), True), 1.52, 32768)
+    assert list(nc) == [15, 15, 15]
+    total, nc = ops.cell_grid(ops.make_box(np.diag([4.0] * 3).astype(np.float32), True), 1.52, 100)
+    assert total == 0  # fewer than 3 cells per axis -> O(N^2) kernel
+    total, nc = ops.cell_grid(ops.make_box(None, False), 1.52, 100)
+    assert total == 0
