@@ -1,0 +1,285 @@
+#!/usr/bin/env python
+"""Benchmark of the LJ pair-force / Langevin hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" is one BAOAB Langevin step (fused integrate kernel + pair-force kernel, with
+neighbor-list rebuilds whenever the skin check fires) of a synthetic LJ fluid; the default
+workload is BASELINE.json's metric configuration: N = 32,768 argon-like particles at
+rho* = 0.1, Verlet list (cutoff 1.02 nm + skin 0.5 nm), 300 K, dt = 1 fs, fp32.  With
+N > 1 GPUs every rank propagates its own replica (temperature ladder 300*1.05^r K) and the
+replicas exchange labels every --exchange-interval steps through one RCCL all-gather
+(weak scaling: value = total replica-steps per second).
+
+Rank 0 prints ONE JSON line with the throughput, the roofline of the dominant kernel
+(pair force, algorithmic bytes 24 N + 16 P_nl per launch, HIP-event timed) and a CPU
+baseline (the C restatement of the reference algorithm, oracle/oracle.c, 1 thread).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+WORKLOADS = {
+    # name: (N, reduced density)
+    "c2": (512, 0.1),
+    "c3": (32768, 0.1),
+    "c4": (262144, 0.1),
+    "c3_liquid": (32768, 0.8),
+    "c4_liquid": (262144, 0.8),
+}
+SIGMA_NM, EPS_KCAL, SKIN_NM = 0.34, 0.238, 0.5
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--build", default="cell", choices=["cell", "nsq"], help="neighbor-list build kernel")
+    ap.add_argument("--chunk", type=int, default=32, help="steps enqueued per host round trip")
+    ap.add_argument("--exchange-interval", type=int, default=500)
+    ap.add_argument("--kernel-reps", type=int, default=200)
+    ap.add_argument("--cpu-steps", type=int, default=-1, help="steps of the CPU baseline (-1 = auto, 0 = skip)")
+    ap.add_argument("--extra-c4", type=int, default=1, help="also report the N=262,144 pair-force roofline (1 GPU runs)")
+    return ap.parse_args()
+
+
+def make_system(workload: str, temperature_K: float, chunk: int, build: str):
+    from chiron_amd import unit
+    from chiron_amd.integrators import LangevinIntegrator
+    from chiron_amd.neighbors import NeighborListCell, NeighborListNsqrd, OrthogonalPeriodicSpace
+    from chiron_amd.potential import LJPotential
+    from chiron_amd.states import SamplerState, ThermodynamicState
+    from chiron_amd.testsystems import LennardJonesFluid
+    from chiron_amd.utils import PRNG
+
+    n, rho = WORKLOADS[workload]
+    sigma = SIGMA_NM * unit.nanometer
+    eps = EPS_KCAL * unit.kilocalories_per_mole
+    cutoff = 3.0 * sigma
+    fluid = LennardJonesFluid(n, reduced_density=rho, sigma=sigma, epsilon=eps, seed=1234)
+    pot = LJPotential(fluid.topology, sigma=sigma, epsilon=eps, cutoff=cutoff)
+    PRNG.set_seed(1234)
+    state = SamplerState(fluid.positions, PRNG.get_random_key(), box_vectors=fluid.box_vectors)
+    thermo = ThermodynamicState(pot, temperature=temperature_K * unit.kelvin)
+    cls = NeighborListCell if build == "cell" else NeighborListNsqrd
+    m0 = 180 if rho <= 0.2 else 400
+    nbr = cls(OrthogonalPeriodicSpace(), cutoff=cutoff, skin=SKIN_NM * unit.nanometer, n_max_neighbors=m0)
+    integ = LangevinIntegrator(timestep=1.0 * unit.femtoseconds, collision_rate=1.0 / unit.picoseconds, chunk_size=chunk)
+    return fluid, pot, state, thermo, nbr, integ
+
+
+def time_force_kernel(pot, state, nbr, reps: int):
+    """Average duration of the pair-force kernel alone (HIP events on the launch stream)."""
+    fl = nbr.force_list
+    x4 = fl.pack(state.positions, 4)
+    box = nbr._box_h
+    for _ in range(10):
+        fl.energy_force(x4, box, pot.sigma, pot.epsilon, pot.cutoff, True, False)
+    torch.cuda.synchronize()
+    start = torch.cuda.Event(enable_timing=True)
+    stop = torch.cuda.Event(enable_timing=True)
+    from chiron_amd import _lib, ops
+    import ctypes as C
+
+    lib = _lib.load()
+    f3 = torch.empty((fl.n, 3), dtype=torch.float32, device=x4.device)
+    args = (ops._ptr(x4), ops._ptr(fl.fl), ops._ptr(fl.deg), fl.n, fl.g, box, C.c_float(pot.sigma),
+            C.c_float(pot.epsilon), C.c_float(pot.cutoff), ops._ptr(f3), None, ops._ptr(fl.ws))
+    start.record()
+    for _ in range(reps):
+        lib.chx_lj_fl_energy_force(*args, ops._stream())
+    stop.record()
+    torch.cuda.synchronize()
+    t = start.elapsed_time(stop) * 1e-3 / reps
+    p_nl = int(torch.minimum(nbr.n_neighbors, torch.tensor(nbr.n_max_neighbors, device=x4.device)).sum().item())
+    return t, p_nl, fl
+
+
+def roofline_entry(n: int, p_nl: int, seconds: float, extra=None):
+    algorithmic = 24 * n + 16 * p_nl
+    achieved = algorithmic / seconds / 1e9
+    d = {
+        "bound": "hbm",
+        "kernel": "k_lj_fl (pair force over the neighbor list)",
+        "achieved": round(achieved, 2),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5),
+        "traffic": None,
+        "algorithmic_bytes": algorithmic,
+        "kernel_us": round(seconds * 1e6, 3),
+        "n_particles": n,
+        "list_pairs": p_nl,
+    }
+    if extra:
+        d.update(extra)
+    return d
+
+
+def cpu_baseline(workload: str, steps: int):
+    """C restatement of the reference algorithm (O(N^2) build, padded-list forces, un-fused BAOAB)."""
+    from oracle import c_oracle as CO
+    from oracle import chiron_oracle as O
+
+    n, rho = WORKLOADS[workload]
+    x, box = O.lj_lattice(n, rho, SIGMA_NM, seed=1234)
+    eps = EPS_KCAL * 4.184
+    mass = np.full(n, 39.948, np.float32)
+    kT, a, b = O.langevin_constants(300.0, 0.001, 1.0)
+    v0 = O.initial_velocities(mass, kT, O.philox_normals3(n, 0, O.STREAM_VELOCITY, (1234, 0)))
+    t0 = time.perf_counter()
+    _, _, st = CO.langevin_run(x, v0, box, mass, SIGMA_NM, eps, 3 * SIGMA_NM, SKIN_NM, 180, 0.001, a, b, kT, steps,
+                               None, (1234, 1))
+    total = time.perf_counter() - t0
+    stepping = max(total - st["build_seconds"], 1e-9)
+    return {
+        "value": round(steps / stepping, 4),
+        "unit": "steps/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": (f"{steps} BAOAB steps of the same N={n} rho*={rho} box after one O(N^2) list build "
+                   f"({st['build_seconds']:.2f} s for {1 + st['rebuilds']} build(s), excluded from value); "
+                   "C restatement of the reference algorithm (oracle/oracle.c), 1 thread, -O2 -ffp-contract=off"),
+        "list_build_s": round(st["build_seconds"] / (1 + st["rebuilds"]), 3),
+        "host_cores_available": len(os.sched_getaffinity(0)),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs the MI355X: no CUDA/ROCm device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from chiron_amd import _lib, ops, unit
+    from chiron_amd.multistate import ReplicaExchange
+    from chiron_amd.rng import PRNGKey
+    from chiron_amd.states import ThermodynamicState
+
+    _lib.load()
+    temperature = 300.0 * (1.05 ** rank)
+    fluid, pot, state, thermo, nbr, integ = make_system(args.workload, temperature, args.chunk, args.build)
+    n = fluid.n_particles
+    ladder = [ThermodynamicState(pot, temperature=300.0 * (1.05 ** r) * unit.kelvin) for r in range(world)]
+    rex = ReplicaExchange(ladder, PRNGKey(2024, 7), rank=rank, world_size=world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def propagate(st, n_steps):
+        """n_steps Langevin steps; with several replicas, exchange every --exchange-interval steps."""
+        nb = nbr
+        done = 0
+        exchanges = 0
+        while done < n_steps:
+            seg = n_steps - done if world == 1 else min(args.exchange_interval, n_steps - done)
+            st, nb = integ.run(st, rex.my_state, number_of_steps=seg, nbr_list=nb)
+            done += seg
+            if world > 1 and done < n_steps + 1:
+                energy = pot.compute_energy(st.positions, nb)
+                _, vscale = rex.exchange(energy)
+                if vscale != 1.0:
+                    st.velocities = ops.scale(st.velocities, vscale)
+                exchanges += 1
+        return st, exchanges
+
+    # warm-up (untimed): builds the list, the force list, JIT-free anyway
+    state, _ = propagate(state, args.warmup)
+    rebuilds_before = nbr.n_builds
+    barrier()
+    t0 = time.perf_counter()
+    state, exchanges = propagate(state, args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * args.steps / elapsed
+
+    if rank == 0:
+        # dominant kernel, timed live on the same device / list state
+        t_k, p_nl, fl = time_force_kernel(pot, state, nbr, args.kernel_reps)
+        roof = roofline_entry(n, p_nl, t_k, {"lanes_per_particle": fl.g, "max_degree": fl.maxdeg})
+        out = {
+            "metric": "Langevin steps/sec + pair-force GB/s vs HBM roofline, LJ N=32k @1/8 GPU",
+            "value": round(value, 2),
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 6),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"LJ fluid N={n} rho*={WORKLOADS[args.workload][1]} (jittered lattice, seed 1234), "
+                            f"sigma=0.34 nm eps=0.238 kcal/mol cutoff=1.02 nm skin=0.5 nm, "
+                            f"NeighborList{'Cell' if args.build == 'cell' else 'Nsqrd'} + LangevinIntegrator "
+                            f"(BAOAB, dt=1 fs, gamma=1/ps, 300 K)",
+                "n_particles": n,
+                "replicas": world,
+                "parallelism": f"{world} independent replica(s), one per GPU" + (
+                    f", label exchange every {args.exchange_interval} steps via one RCCL all-gather" if world > 1 else ""),
+                "chunk_steps": args.chunk,
+                "list_rebuilds_in_timed_region": nbr.n_builds - rebuilds_before,
+                "replica_exchanges": exchanges,
+                "swap_acceptance": (float(rex.n_accepted.sum() / max(1, rex.n_proposed.sum())) if world > 1 else None),
+            },
+            "roofline": roof,
+        }
+        if world == 1 and args.extra_c4 and args.workload != "c4":
+            try:
+                fluid4, pot4, state4, thermo4, nbr4, integ4 = make_system("c4", 300.0, args.chunk, "cell")
+                nbr4.build_from_state(state4)
+                t4, p4, fl4 = time_force_kernel(pot4, state4, nbr4, args.kernel_reps)
+                out["roofline_262k"] = roofline_entry(fluid4.n_particles, p4, t4,
+                                                      {"lanes_per_particle": fl4.g, "max_degree": fl4.maxdeg})
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                integ4.run(state4, thermo4, number_of_steps=300, nbr_list=nbr4)
+                torch.cuda.synchronize()
+                out["steps_per_s_262k"] = round(300 / (time.perf_counter() - t0), 2)
+                del fluid4, pot4, state4, nbr4
+            except Exception as exc:  # pragma: no cover - diagnostics only
+                out["roofline_262k"] = {"error": repr(exc)}
+        if world == 1 and args.cpu_steps != 0:
+            steps = args.cpu_steps if args.cpu_steps > 0 else (30 if n <= 32768 else 3)
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.workload, steps)
+            except Exception as exc:  # pragma: no cover
+                out["cpu_baseline"] = {"error": repr(exc)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

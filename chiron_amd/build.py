@@ -12,7 +12,8 @@ OUT = os.path.join(HERE, "libchx.so")
 
 # -ffp-contract=off: the neighbor predicates and the BAOAB update must round once
 # per operation, like the reference's un-fused fp32 ops.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+         "-fPIC", "-shared", "-std=c++17"]
 
 
 def sources():

@@ -47,7 +47,9 @@ __device__ __forceinline__ float fadd(float a, float b) { return __fadd_rn(a, b)
 __device__ __forceinline__ float fsub(float a, float b) { return __fsub_rn(a, b); }
 __device__ __forceinline__ float fmul(float a, float b) { return __fmul_rn(a, b); }
 __device__ __forceinline__ float fdiv(float a, float b) { return __fdiv_rn(a, b); }
-__device__ __forceinline__ float fsqrt(float a) { return __fsqrt_rn(a); }
+// NB: HIP's __fsqrt_rn maps to the 1-ulp native sqrt; __builtin_sqrtf is IEEE under
+// -fhip-fp32-correctly-rounded-divide-sqrt (set explicitly in the build flags).
+__device__ __forceinline__ float fsqrt(float a) { return __builtin_sqrtf(a); }
 
 // jnp.mod(t, L) for L > 0 (lax.rem == fmod, then the sign fix-up).  fmod is
 // exact; for |t| < 2L it reduces to a compare and one exact subtraction.

@@ -1,0 +1,312 @@
+"""Multistate sampling: the reference's ``MultiStateSampler`` skeleton and a
+one-replica-per-GPU replica-exchange layer.
+
+``MultiStateSampler`` follows chiron/multistate.py:10-742 for what is on the hot
+path: ``create`` / ``_allocate_variables`` (:203-309), ``_propagate_replica(s)``
+(:414-445, :497-510), ``_compute_energies`` (:512-531), ``_mix_replicas`` /
+``_perform_swap_proposals`` (:447-495) and ``run`` (:563-599).  The reference's
+swap step is a placeholder that returns the state indices unchanged (:447-460);
+that behaviour is the default here (``swap=None``).  MBAR analysis, HDF5/XTC
+reporting and minimisation are out of scope.
+
+``ReplicaExchange`` is the multi-GPU path: rank r owns replica r; the
+only collective is one all-gather of K potential energies per exchange (RCCL over
+xGMI when the backend is ``nccl``), after which every rank takes the same
+deterministic neighbour-swap decisions from a shared Philox key and swaps *labels*
+(thermodynamic-state indices), rescaling its velocities by sqrt(T_new/T_old).
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import unit
+from .rng import PRNGKey, uniform as host_uniform
+from .states import SamplerState, ThermodynamicState, calculate_reduced_potential_at_states
+
+
+# ---------------------------------------------------------------------------
+# swap rule shared by the serial and the distributed paths
+# ---------------------------------------------------------------------------
+def neighbor_swap_decisions(u_kn: np.ndarray, state_of_replica: np.ndarray, iteration: int, key: PRNGKey):
+    """Metropolis neighbour swaps on the K x K reduced-potential matrix.
+
+    ``u_kn[r, k]`` = reduced potential of replica r's configuration at state k
+    (row r is what chiron/multistate.py:523-531 stores).  State pairs (k, k+1) with
+    k = iteration mod 2, +2, ... are attempted; pair (k, k+1) is accepted with
+    probability min(1, exp(-(u[a,k+1] + u[b,k] - u[a,k] - u[b,k+1]))) where a, b are
+    the replicas currently at k and k+1.  The uniform for pair k at this iteration
+    comes from the shared key, so every rank reaches the same decisions.
+    Returns (new_state_of_replica, n_proposed[K,K], n_accepted[K,K]).
+    """
+    K = len(state_of_replica)
+    new = np.array(state_of_replica, dtype=np.int64).copy()
+    n_prop = np.zeros((K, K), np.int64)
+    n_acc = np.zeros((K, K), np.int64)
+    replica_at_state = np.empty(K, np.int64)
+    replica_at_state[new] = np.arange(K)
+    for k in range(iteration % 2, K - 1, 2):
+        a, b = int(replica_at_state[k]), int(replica_at_state[k + 1])
+        log_p = -(u_kn[a, k + 1] + u_kn[b, k] - u_kn[a, k] - u_kn[b, k + 1])
+        n_prop[k, k + 1] += 1
+        n_prop[k + 1, k] += 1
+        u = host_uniform(key, (iteration << 8) + k)
+        if not math.isnan(log_p) and (log_p >= 0.0 or u < math.exp(log_p)):
+            new[a], new[b] = k + 1, k
+            replica_at_state[k], replica_at_state[k + 1] = b, a
+            n_acc[k, k + 1] += 1
+            n_acc[k + 1, k] += 1
+    return new, n_prop, n_acc
+
+
+class ReplicaExchange:
+    """One replica per process/GPU; temperature (and pressure) ladder exchange.
+
+    Works on any ``torch.distributed`` backend: ``nccl`` (= RCCL) on the GPU node,
+    ``gloo`` in the CPU tests.  With ``world_size == 1`` no process group is needed.
+    """
+
+    def __init__(self, thermodynamic_states: Sequence[ThermodynamicState], key: PRNGKey,
+                 rank: Optional[int] = None, world_size: Optional[int] = None, device=None):
+        import torch.distributed as dist
+
+        self.states = list(thermodynamic_states)
+        self.key = key
+        if world_size is None:
+            world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if rank is None:
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        self.rank, self.world_size = rank, world_size
+        if len(self.states) != world_size:
+            raise RuntimeError("Number of thermodynamic states and replicas (ranks) must be equal.")
+        self.device = device
+        self.state_of_replica = np.arange(world_size, dtype=np.int64)  # multistate.py:277-279
+        self.iteration = 0
+        self.n_proposed = np.zeros((world_size, world_size), np.int64)
+        self.n_accepted = np.zeros((world_size, world_size), np.int64)
+        self.u_kn = np.zeros((world_size, world_size))
+        self._betas = np.array(
+            [float((1.0 / (unit.BOLTZMANN_CONSTANT_kB * s.temperature * unit.AVOGADRO_CONSTANT_NA)).value_in_unit(
+                unit.kilojoule_per_mole ** -1)) for s in self.states]
+        )
+        self._pressures = [s.pressure for s in self.states]
+
+    @property
+    def my_state_index(self) -> int:
+        return int(self.state_of_replica[self.rank])
+
+    @property
+    def my_state(self) -> ThermodynamicState:
+        return self.states[self.my_state_index]
+
+    def _reduced_row(self, energy_kj_mol: np.ndarray, volume_nm3: Optional[np.ndarray]) -> np.ndarray:
+        """u[r, k] = beta_k (U_r + p_k V_r N_A) -- chiron/states.py:307-325 for T/p ladders."""
+        u = energy_kj_mol[:, None] * self._betas[None, :]
+        if volume_nm3 is not None:
+            for k, p in enumerate(self._pressures):
+                if p is not None:
+                    pv = float((p * (1.0 * unit.nanometer ** 3) * unit.AVOGADRO_CONSTANT_NA).value_in_unit(unit.kilojoule_per_mole))
+                    u[:, k] += self._betas[k] * pv * volume_nm3
+        return u
+
+    def gather_energies(self, energy: torch.Tensor) -> np.ndarray:
+        """The one collective of the path: all-gather of one fp32 per rank."""
+        import torch.distributed as dist
+
+        e = energy.detach().reshape(1).to(torch.float32)
+        if self.world_size == 1:
+            return e.cpu().numpy().astype(np.float64)
+        out = torch.empty(self.world_size, dtype=torch.float32, device=e.device)
+        dist.all_gather_into_tensor(out, e)
+        return out.cpu().numpy().astype(np.float64)
+
+    def exchange(self, energy: torch.Tensor, volume_nm3: Optional[float] = None):
+        """Gather, decide, relabel.  Returns (new_state_index, velocity_scale) for this rank."""
+        energies = self.gather_energies(energy)
+        vols = None
+        if volume_nm3 is not None:
+            vols = self.gather_energies(torch.as_tensor([volume_nm3], dtype=torch.float32, device=energy.device))
+        self.u_kn = self._reduced_row(energies, vols)
+        old = self.my_state_index
+        new, n_prop, n_acc = neighbor_swap_decisions(self.u_kn, self.state_of_replica, self.iteration, self.key)
+        self.state_of_replica = new
+        self.n_proposed += n_prop
+        self.n_accepted += n_acc
+        self.iteration += 1
+        new_idx = self.my_state_index
+        scale = 1.0
+        if new_idx != old:
+            t_old = self.states[old].temperature.value_in_unit(unit.kelvin)
+            t_new = self.states[new_idx].temperature.value_in_unit(unit.kelvin)
+            scale = math.sqrt(t_new / t_old)
+        return new_idx, scale
+
+
+# ---------------------------------------------------------------------------
+# the reference's serial sampler
+# ---------------------------------------------------------------------------
+class MultiStateSampler:
+    """chiron/multistate.py:10-742 (propagate / energy-matrix / mix skeleton)."""
+
+    def __init__(self, mcmc_sampler, reporter=None, swap: Optional[str] = None, key: Optional[PRNGKey] = None):
+        self._thermodynamic_states = None
+        self._sampler_states = None
+        self._replica_thermodynamic_states = None
+        self._iteration = None
+        self._energy_thermodynamic_states = None
+        self._n_accepted_matrix = None
+        self._n_proposed_matrix = None
+        self._nbr_lists = None
+        self._reporter = reporter
+        self._mcmc_sampler = copy.deepcopy(mcmc_sampler)
+        self._swap = swap  # None reproduces the reference (no swaps); "neighbors" enables the Metropolis rule
+        self._key = key or PRNGKey(0x5EED, 0)
+
+    @property
+    def number_of_thermodynamic_states(self) -> int:
+        return 0 if self._thermodynamic_states is None else len(self._thermodynamic_states)
+
+    @property
+    def number_of_replicas(self) -> int:
+        return 0 if self._sampler_states is None else len(self._sampler_states)
+
+    @property
+    def iteration(self):
+        return self._iteration
+
+    @property
+    def mcmc_sampler(self):
+        return copy.deepcopy(self._mcmc_sampler)
+
+    @property
+    def sampler_states(self) -> Optional[List[SamplerState]]:
+        return None if self._sampler_states is None else copy.deepcopy(self._sampler_states)
+
+    @property
+    def is_periodic(self):
+        if self._sampler_states is None:
+            return None
+        return self._sampler_states[0].box_vectors is not None
+
+    def create(self, thermodynamic_states, sampler_states, nbr_lists):
+        """chiron/multistate.py:203-238"""
+        if len(thermodynamic_states) != len(sampler_states):
+            raise RuntimeError("Number of thermodynamic states and sampler states must be equal.")
+        self._allocate_variables(thermodynamic_states, sampler_states, nbr_lists)
+        if self._reporter is None:
+            from .reporters import MultistateReporter
+
+            self._reporter = MultistateReporter()
+
+    def _allocate_variables(self, thermodynamic_states, sampler_states, nbr_lists) -> None:
+        """chiron/multistate.py:240-309"""
+        from .mcmc import MCMCSampler
+
+        self._thermodynamic_states = copy.deepcopy(thermodynamic_states)
+        self._sampler_states = copy.deepcopy(sampler_states)
+        self._nbr_lists = copy.deepcopy(nbr_lists)
+        assert len(self._thermodynamic_states) == len(self._sampler_states)
+        assert len(self._thermodynamic_states) == len(self._nbr_lists)
+        for nbr_list, state in zip(self._nbr_lists, self._sampler_states):
+            if nbr_list is not None:
+                nbr_list.build(state.positions, state.box_vectors)
+        K = len(thermodynamic_states)
+        self._replica_thermodynamic_states = np.arange(K, dtype=int)
+        self._n_accepted_matrix = np.zeros([K, K], np.int64)
+        self._n_proposed_matrix = np.zeros([K, K], np.int64)
+        self._energy_thermodynamic_states = np.zeros([self.number_of_replicas, K], np.float64)
+        self._traj = [[] for _ in range(self.number_of_replicas)]
+        if isinstance(self._mcmc_sampler, MCMCSampler):
+            self._mcmc_sampler = [copy.deepcopy(self._mcmc_sampler) for _ in range(K)]
+        elif len(self._mcmc_sampler) != K:
+            raise RuntimeError(
+                f"The number of MCMCMoves ({len(self._mcmc_sampler)}) and ThermodynamicStates ({K}) must be the same."
+            )
+        self._iteration = 0
+
+    def _compute_replica_reduced_potential(self, replica_id: int) -> np.ndarray:
+        """chiron/multistate.py:178-201 (with the replica's neighbor list, cf. the bug noted in SURVEY 3.3)."""
+        return calculate_reduced_potential_at_states(
+            self._sampler_states[replica_id], self._thermodynamic_states, self._nbr_lists[replica_id]
+        )
+
+    def _propagate_replica(self, replica_id: int):
+        """chiron/multistate.py:414-445"""
+        state_id = self._replica_thermodynamic_states[replica_id]
+        (
+            self._sampler_states[replica_id],
+            self._thermodynamic_states[state_id],
+            self._nbr_lists[replica_id],
+        ) = self._mcmc_sampler[state_id].run(
+            self._sampler_states[replica_id], self._thermodynamic_states[state_id], self.n_mcmc_iterations,
+            self._nbr_lists[replica_id],
+        )
+        self._traj[replica_id].append(self._sampler_states[replica_id].positions)
+
+    def _propagate_replicas(self) -> None:
+        for replica_id in range(self.number_of_replicas):
+            self._propagate_replica(replica_id)
+
+    def _perform_swap_proposals(self):
+        """Reference: placeholder returning the indices unchanged (chiron/multistate.py:447-460)."""
+        if self._swap is None:
+            return self._replica_thermodynamic_states
+        new, n_prop, n_acc = neighbor_swap_decisions(
+            self._energy_thermodynamic_states, self._replica_thermodynamic_states, self._iteration, self._key
+        )
+        self._n_proposed_matrix += n_prop
+        self._n_accepted_matrix += n_acc
+        return new
+
+    def _mix_replicas(self) -> np.ndarray:
+        """chiron/multistate.py:462-495"""
+        self._n_accepted_matrix[:, :] = 0
+        self._n_proposed_matrix[:, :] = 0
+        old = np.array(self._replica_thermodynamic_states)
+        new = np.array(self._perform_swap_proposals())
+        if self._swap is not None:
+            for r in np.nonzero(new != old)[0]:
+                t_old = self._thermodynamic_states[old[r]].temperature.value_in_unit(unit.kelvin)
+                t_new = self._thermodynamic_states[new[r]].temperature.value_in_unit(unit.kelvin)
+                st = self._sampler_states[r]
+                if st.velocities is not None and t_old != t_new:
+                    from . import ops
+
+                    st.velocities = ops.scale(st.velocities, math.sqrt(t_new / t_old))
+            self._replica_thermodynamic_states = new
+        return new
+
+    def _compute_energies(self) -> None:
+        """chiron/multistate.py:512-531"""
+        self._energy_thermodynamic_states = np.zeros((self.number_of_replicas, self.number_of_thermodynamic_states))
+        for replica_id in range(self.number_of_replicas):
+            self._energy_thermodynamic_states[replica_id, :] = self._compute_replica_reduced_potential(replica_id)
+
+    def _is_completed(self, iteration_limit: Optional[int] = None) -> bool:
+        return iteration_limit is not None and self._iteration >= iteration_limit
+
+    def _report_iteration(self):
+        if self._reporter is not None:
+            self._reporter.report({"u_kn": self._energy_thermodynamic_states.T.copy(),
+                                   "state_index": np.array(self._replica_thermodynamic_states)})
+
+    def run(self, n_iterations: int = 10, n_mcmc_iterations: Optional[int] = None) -> None:
+        """chiron/multistate.py:563-599.  The reference passes the *total* n_iterations as the
+        per-call MCMC iteration count (:441-443); ``n_mcmc_iterations`` overrides that."""
+        self.number_of_iterations = n_iterations
+        self.n_mcmc_iterations = n_iterations if n_mcmc_iterations is None else n_mcmc_iterations
+        if self._iteration == 0:
+            self._compute_energies()
+            self._report_iteration()
+        while not self._is_completed(n_iterations):
+            self._iteration += 1
+            self._mix_replicas()
+            self._propagate_replicas()
+            self._compute_energies()
+            self._report_iteration()
+        if self._reporter is not None:
+            self._reporter.flush_buffer()

@@ -1,0 +1,71 @@
+"""ctypes wrapper of oracle/_build/liboracle.so (TEST INFRASTRUCTURE / cpu_baseline only)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build_oracle
+
+
+class OrcBox(C.Structure):
+    _fields_ = [("periodic", C.c_int), ("lx", C.c_float), ("ly", C.c_float), ("lz", C.c_float)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = build_oracle.OUT if os.path.exists(build_oracle.OUT) else build_oracle.build()
+        _lib = C.CDLL(path)
+        _lib.orc_nl_build_fixed.restype = C.c_int
+        _lib.orc_lj_nl.restype = C.c_float
+        _lib.orc_langevin_run.restype = C.c_int
+    return _lib
+
+
+def _box(box, periodic=True):
+    if box is None or not periodic:
+        return OrcBox(0, 0, 0, 0)
+    b = np.asarray(box, dtype=np.float32)
+    return OrcBox(1, float(b[0, 0]), float(b[1, 1]), float(b[2, 2]))
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def nl_build_fixed(x, box, cutoff_and_skin, m, periodic=True):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n = x.shape[0]
+    nl = np.zeros((n, m), np.uint32)
+    mask = np.zeros((n, m), np.int32)
+    nnbr = np.zeros(n, np.int32)
+    lib().orc_nl_build_fixed(_p(x, C.c_float), n, m, _box(box, periodic), C.c_float(cutoff_and_skin),
+                             _p(nl, C.c_uint32), _p(mask, C.c_int32), _p(nnbr, C.c_int32))
+    return mask, nl, nnbr
+
+
+def lj_nl(x, nl, mask, box, sigma, eps, cutoff, periodic=True):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n, m = nl.shape
+    f = np.zeros((n, 3), np.float32)
+    e = lib().orc_lj_nl(_p(x, C.c_float), _p(np.ascontiguousarray(nl), C.c_uint32), _p(np.ascontiguousarray(mask), C.c_int32),
+                        n, m, _box(box, periodic), C.c_float(sigma), C.c_float(eps), C.c_float(cutoff), _p(f, C.c_float))
+    return float(e), f
+
+
+def langevin_run(x, v, box, mass, sigma, eps, cutoff, skin, m0, dt, a, b, kT, n_steps, noise=None, key=(0, 0)):
+    x = np.ascontiguousarray(x, dtype=np.float32).copy()
+    v = np.ascontiguousarray(v, dtype=np.float32).copy()
+    mass = np.ascontiguousarray(mass, dtype=np.float32)
+    stats = np.zeros(3, np.float64)
+    nz = None if noise is None else _p(np.ascontiguousarray(noise, dtype=np.float32), C.c_float)
+    rc = lib().orc_langevin_run(_p(x, C.c_float), _p(v, C.c_float), x.shape[0], _box(box), _p(mass, C.c_float),
+                                C.c_float(sigma), C.c_float(eps), C.c_float(cutoff), C.c_float(skin), int(m0),
+                                C.c_float(dt), C.c_float(a), C.c_float(b), C.c_float(kT), int(n_steps), nz,
+                                C.c_uint32(key[0]), C.c_uint32(key[1]), _p(stats, C.c_double))
+    if rc != 0:
+        raise RuntimeError("orc_langevin_run failed")
+    return x, v, dict(rebuilds=int(stats[0]), n_max=int(stats[1]), build_seconds=float(stats[2]))

@@ -197,3 +197,38 @@ def test_metropolis_and_reduced_potential():
     assert np.isclose(u, 101325.0 * 1000e-27 / (O.KB * 300.0))
     x, box, v0, v1 = O.barostat_propose(np.ones((4, 3)), np.diag([10.0, 10.0, 10.0]), 0.1, 0.75)
     assert np.isclose(v1 / v0, 1.05) and np.allclose(box[0, 0] ** 3, v1, rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------
+# the C restatement (cpu_baseline) agrees with the NumPy oracle
+# ---------------------------------------------------------------------------
+def test_c_oracle_matches_numpy_oracle():
+    from oracle import c_oracle as CO
+
+    x, box = O.lj_lattice(700, 0.5, 0.34, seed=3)
+    mask, nl, nnbr = CO.nl_build_fixed(x, box, 1.52, 150)
+    mask0, nl0, nnbr0 = O.neighborlist_build_fixed(x, box, 1.52, 150)
+    assert np.array_equal(nl, nl0) and np.array_equal(mask, mask0) and np.array_equal(nnbr, nnbr0)
+    e, f = CO.lj_nl(x, nl, mask, box, 0.34, 0.995792, 1.02)
+    e0 = O.lj_energy_nbrlist_f32(x, nl0, mask0, box, 0.34, 0.995792, 1.02)
+    f0 = O.lj_force_nbrlist_f32(x, nl0, mask0, box, 0.34, 0.995792, 1.02)
+    assert abs(e - float(e0)) <= 1e-5 * abs(float(e0)) and np.abs(f - f0).max() <= 1e-4 * max(1.0, np.abs(f0).max())
+    # trajectory with injected noise, including rebuilds
+    rng = np.random.default_rng(0)
+    n, steps, skin = 300, 25, 0.02
+    x, box = O.lj_lattice(n, 0.3, 0.34, seed=5)
+    noise = rng.normal(size=(steps, n, 3)).astype(f32)
+    mass = np.full(n, 39.948, f32)
+    kT, a, b = O.langevin_constants(300.0, 0.004, 1.0)
+    v0 = O.initial_velocities(mass, kT, rng.normal(size=(n, 3)).astype(f32))
+    xc, vc, st = CO.langevin_run(x, v0, box, mass, 0.34, 0.995792, 1.02, skin, 250, 0.004, a, b, kT, steps, noise)
+    xo, vo, rebuilds, (_, _, n_max) = O.langevin_run(x, v0, box, mass, 0.34, 0.995792, 1.02, skin, 250, 0.004, 1.0,
+                                                    300.0, steps, lambda s: noise[s])
+    assert st["rebuilds"] == rebuilds and rebuilds >= 1 and st["n_max"] == n_max
+    assert np.abs(xc - xo).max() < 1e-5 and np.abs(vc - vo).max() < 1e-3
+    # internal Philox stream == NumPy stream
+    kT, a, b = O.langevin_constants(300.0, 0.001, 1.0)
+    xc, vc, _ = CO.langevin_run(x, v0, box, mass, 0.34, 0.995792, 1.02, 0.5, 250, 0.001, a, b, kT, 3, None, (7, 9))
+    xo, vo, _, _ = O.langevin_run(x, v0, box, mass, 0.34, 0.995792, 1.02, 0.5, 250, 0.001, 1.0, 300.0, 3,
+                                  lambda s: O.philox_normals3(n, s, O.STREAM_LANGEVIN, (7, 9)))
+    assert np.abs(xc - xo).max() < 2e-6
