@@ -147,7 +147,9 @@ __device__ __forceinline__ float u32_to_uniform(uint32_t x) {
   return fmul(fadd((float)(x >> 9), 0.5f), 1.0f / 8388608.0f);
 }
 
-// three N(0,1) for (index, step) of `stream`: Box-Muller on one Philox block
+// three N(0,1) for (index, step) of `stream`: Box-Muller on one Philox block.
+// (z0, z1) = r01 (cos, sin)(2 pi u1), z2 = r23 cos(2 pi u3), r = sqrt(-2 ln u).
+// The hardware log2 / sin / cos (about 1e-6 absolute) are ample for a noise source.
 __device__ __forceinline__ void philox_normals3(uint32_t index, uint32_t step, uint32_t stream,
                                                 uint32_t k0, uint32_t k1, float& z0, float& z1,
                                                 float& z2) {
@@ -155,21 +157,33 @@ __device__ __forceinline__ void philox_normals3(uint32_t index, uint32_t step, u
   float u0 = u32_to_uniform(o.x), u1 = u32_to_uniform(o.y);
   float u2 = u32_to_uniform(o.z), u3 = u32_to_uniform(o.w);
   const float two_pi = 6.283185307179586f;
-  float r01 = fsqrt(fmul(-2.0f, logf(u0)));
-  float r23 = fsqrt(fmul(-2.0f, logf(u2)));
+  float r01 = fsqrt(fmul(-2.0f, __logf(u0)));
+  float r23 = fsqrt(fmul(-2.0f, __logf(u2)));
   float t1 = fmul(two_pi, u1), t3 = fmul(two_pi, u3);
-  z0 = fmul(r01, cosf(t1));
-  z1 = fmul(r01, sinf(t1));
-  z2 = fmul(r23, cosf(t3));
+  z0 = fmul(r01, __cosf(t1));
+  z1 = fmul(r01, __sinf(t1));
+  z2 = fmul(r23, __cosf(t3));
+}
+
+// component c (0..2) of the same draw, for kernels that give each lane one component
+__device__ __forceinline__ float philox_normal_c(uint32_t index, uint32_t step, uint32_t stream,
+                                                 uint32_t k0, uint32_t k1, int c) {
+  uint4 o = philox4x32(make_uint4(index, step, 0u, stream), k0, k1);
+  const float ua = u32_to_uniform(c == 2 ? o.z : o.x);
+  const float ub = u32_to_uniform(c == 2 ? o.w : o.y);
+  const float r = fsqrt(fmul(-2.0f, __logf(ua)));
+  const float t = fmul(6.283185307179586f, ub);
+  return fmul(r, c == 1 ? __sinf(t) : __cosf(t));
 }
 
 // LJ pair terms from r2 (within cutoff): e = 4 eps (s^12 - s^6), fs = 24 eps (2 s^12 - s^6) / r2
 __device__ __forceinline__ void lj_pair(float r2, float sig2, float eps4, float eps24, float& e,
                                         float& fs) {
-  float inv = 1.0f / r2;
+  // energies/forces are compared with a tolerance (not bit-for-bit), so the 1-ulp
+  // hardware reciprocal and explicit FMAs are fine here
+  float inv = __builtin_amdgcn_rcpf(r2);
   float s2 = sig2 * inv;
   float s6 = s2 * s2 * s2;
-  float s12 = s6 * s6;
-  e = eps4 * (s12 - s6);
-  fs = eps24 * (2.0f * s12 - s6) * inv;
+  e = (eps4 * s6) * (s6 - 1.0f);
+  fs = (eps24 * s6) * __builtin_fmaf(2.0f, s6, -1.0f) * inv;
 }

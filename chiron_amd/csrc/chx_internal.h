@@ -10,6 +10,10 @@
 int chx_launch_lj_fl(const float* x4, const uint32_t* fl, const int32_t* deg, int n, int g,
                      chx_box_t box, float sigma, float epsilon, float cutoff, float* f3,
                      float* energy, double* ws, int32_t* ctrl, hipStream_t st);
+// n_steps fused [force + BAOAB] launches on the force list (k_lj_step); launch i reads
+// (i even ? x_even : x_odd) and writes the other buffer.  do_aoa == 0: force + kicks only.
+int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, int64_t step0,
+                        int n_steps, int kicks_first, int do_aoa, hipStream_t st);
 int chx_launch_lj_allpairs(const float* x, int stride, int n, chx_box_t box, float sigma,
                            float epsilon, float cutoff, float* f3, float* energy, double* ws,
                            int32_t* ctrl, hipStream_t st);

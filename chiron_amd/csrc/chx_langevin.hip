@@ -207,6 +207,25 @@ extern "C" int chx_langevin_chunk(const chx_langevin_t* p, int64_t step0, int32_
   return chx_check_launch("chx_langevin_chunk");
 }
 
+extern "C" int chx_langevin_fused_chunk(const chx_langevin_t* p, float* x_even, float* x_odd,
+                                        int64_t step0, int32_t n_steps, int32_t kicks_first,
+                                        int32_t do_aoa, chx_stream_t stream) {
+  CHX_REQUIRE(p, "null params");
+  CHX_REQUIRE(p->n >= 1, "n < 1");
+  CHX_REQUIRE(x_even && x_odd && x_even != x_odd, "need two distinct position buffers");
+  CHX_REQUIRE(p->v && p->mass && p->ctrl && p->fl && p->deg, "null pointer");
+  CHX_REQUIRE(!p->box.periodic || (p->box.lx > 0 && p->box.ly > 0 && p->box.lz > 0),
+              "box lengths must be > 0");
+  CHX_REQUIRE(n_steps >= 0, "n_steps < 0");
+  CHX_REQUIRE(kicks_first >= 0 && kicks_first <= 2, "kicks_first must be 0, 1 or 2");
+  CHX_REQUIRE(step0 >= 0 && step0 + n_steps < (1ll << 31) - 1, "step index out of range");
+  CHX_REQUIRE(do_aoa || n_steps <= 1, "force-only mode takes a single launch");
+  int rc = chx_launch_lj_steps(p, x_even, x_odd, step0, n_steps, kicks_first, do_aoa,
+                               chx_stream(stream));
+  if (rc != CHX_OK) return rc;
+  return chx_check_launch("chx_langevin_fused_chunk");
+}
+
 extern "C" int chx_langevin_resume(const chx_langevin_t* p, chx_stream_t stream) {
   int rc = validate_langevin(p);
   if (rc != CHX_OK) return rc;

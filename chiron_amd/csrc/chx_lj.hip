@@ -173,6 +173,55 @@ struct LJParams {
   float eps24;  // 24 eps
 };
 
+#define CHX_FL_INVALID 0xFFFFFFFFu
+#define CHX_FL_UNROLL 4
+
+// One particle's share of its force-list row: lane q of the G cooperating lanes walks
+// entries q, q+G, ...  Index loads, position gathers and arithmetic are issued in
+// batches of CHX_FL_UNROLL so the two dependent memory round trips (entry -> xyz)
+// overlap across entries instead of serialising per entry.
+template <int G>
+__device__ __forceinline__ void lj_row(const float4* __restrict__ x4, const uint32_t* __restrict__ col,
+                                       size_t stride, int d, int q, const float4 xi, const Box3& box,
+                                       const LJParams& lj, float& fx, float& fy, float& fz, float& en) {
+  const int nt = (d + G - 1) / G;
+  for (int t0 = 0; t0 < nt; t0 += CHX_FL_UNROLL) {
+    uint32_t ent[CHX_FL_UNROLL];
+    float4 xj[CHX_FL_UNROLL];
+#pragma unroll
+    for (int u = 0; u < CHX_FL_UNROLL; ++u) {
+      const int k = (t0 + u) * G + q;
+      ent[u] = (k < d) ? col[(size_t)(t0 + u) * stride] : CHX_FL_INVALID;
+    }
+#pragma unroll
+    for (int u = 0; u < CHX_FL_UNROLL; ++u) {
+      xj[u] = xi;
+      if (ent[u] != CHX_FL_INVALID) xj[u] = x4[ent[u] & ~CHX_FL_HI];
+    }
+#pragma unroll
+    for (int u = 0; u < CHX_FL_UNROLL; ++u) {
+      if (ent[u] == CHX_FL_INVALID) continue;
+      const bool hi = (ent[u] & CHX_FL_HI) != 0u;
+      float rx, ry, rz;
+      if (hi) {
+        displacement(box, xi.x, xi.y, xi.z, xj[u].x, xj[u].y, xj[u].z, rx, ry, rz);
+      } else {
+        displacement(box, xj[u].x, xj[u].y, xj[u].z, xi.x, xi.y, xi.z, rx, ry, rz);
+      }
+      const float r2 = norm2(rx, ry, rz);
+      if (r2 <= lj.T) {
+        float e, fs;
+        lj_pair(r2, lj.sig2, lj.eps4, lj.eps24, e, fs);
+        if (!hi) fs = -fs;  // reaction on the higher-id particle
+        fx = __builtin_fmaf(fs, rx, fx);
+        fy = __builtin_fmaf(fs, ry, fy);
+        fz = __builtin_fmaf(fs, rz, fz);
+        en += e;
+      }
+    }
+  }
+}
+
 template <int G, bool WANT_F, bool WANT_E>
 __global__ __launch_bounds__(256) void k_lj_fl(const float4* __restrict__ x4,
                                                const uint32_t* __restrict__ fl,
@@ -190,39 +239,8 @@ __global__ __launch_bounds__(256) void k_lj_fl(const float4* __restrict__ x4,
   const int d = valid ? deg[p] : 0;
   float4 xi = make_float4(0.f, 0.f, 0.f, 0.f);
   if (valid) xi = x4[p];
-  const size_t stride = (size_t)n * G;
-  const uint32_t* col = fl + (size_t)p * G + q;
   float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
-  const int nt = (d + G - 1) / G;
-  uint32_t ent = (q < d) ? col[0] : 0u;
-  for (int t = 0; t < nt; ++t) {
-    const int k = t * G + q;
-    const int kn = k + G;
-    uint32_t ent_next = 0u;
-    if (kn < d) ent_next = col[(size_t)(t + 1) * stride];
-    if (k < d) {
-      const uint32_t j = ent & ~CHX_FL_HI;
-      const bool hi = (ent & CHX_FL_HI) != 0u;
-      const float4 xj = x4[j];
-      float rx, ry, rz;
-      if (hi) {
-        displacement(box, xi.x, xi.y, xi.z, xj.x, xj.y, xj.z, rx, ry, rz);
-      } else {
-        displacement(box, xj.x, xj.y, xj.z, xi.x, xi.y, xi.z, rx, ry, rz);
-      }
-      const float r2 = norm2(rx, ry, rz);
-      if (r2 <= lj.T) {
-        float e, fs;
-        lj_pair(r2, lj.sig2, lj.eps4, lj.eps24, e, fs);
-        if (!hi) fs = -fs;  // reaction on the higher-id particle
-        fx += fs * rx;
-        fy += fs * ry;
-        fz += fs * rz;
-        en += e;
-      }
-    }
-    ent = ent_next;
-  }
+  lj_row<G>(x4, fl + (size_t)p * G + q, (size_t)n * G, d, q, xi, box, lj, fx, fy, fz, en);
 #pragma unroll
   for (int o = G / 2; o > 0; o >>= 1) {
     if (WANT_F) {
@@ -242,6 +260,114 @@ __global__ __launch_bounds__(256) void k_lj_fl(const float4* __restrict__ x4,
     double mine = (valid && q == 0) ? 0.5 * (double)en : 0.0;
     mine = block_sum<256>(mine);
     if (threadIdx.x == 0) ws[blockIdx.x] = mine;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// fused MD step: pair force on x_cur, then (lanes 0..2 of the particle's lane
+// group, one Cartesian component each) the BAOAB update that consumes it:
+//   v += (dt/2) F/m   [x n_kicks: trailing kick of the previous step + leading kick]
+//   x += (dt/2) v ; v = a v + b sigma_v xi ; x += (dt/2) v ; wrap ; skin check
+// (chiron/integrators.py:181-195, :239-241).  Positions ping-pong between two
+// buffers so no launch reads what it writes.  ctrl[3] = first step that must NOT
+// run because the skin check fired (INT_MAX when clear): every later launch of the
+// chunk is a no-op and the host rebuilds the list at exactly the reference's step.
+// ---------------------------------------------------------------------------
+struct StepArgs {
+  int n;
+  const float4* x_cur;
+  float* x_next;  // (n,4)
+  float* v;       // (n,3)
+  const float4* ref4;
+  const float* mass;
+  const uint32_t* perm;
+  const uint32_t* fl;
+  const int32_t* deg;
+  Box3 box;
+  LJParams lj;
+  int wrap;
+  float T_half_skin;
+  float hdt, a, b, kT;
+  uint32_t k0, k1;
+  const float* noise;
+  long long noise_step0;
+  int32_t* ctrl;
+};
+
+template <int G>
+__global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int n_kicks, int do_aoa) {
+  constexpr int PPB = 256 / G;  // particles per block
+  __shared__ float sF[3 * PPB];
+  __shared__ float sS[3 * PPB];
+  if ((long long)a.ctrl[3] <= step) return;  // block-uniform
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  const int p = tid / G;
+  const int q = tid % G;
+  const bool valid = p < a.n;
+  const int d = valid ? a.deg[p] : 0;
+  float4 xi = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid) xi = a.x_cur[p];
+  float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
+  lj_row<G>(a.x_cur, a.fl + (size_t)p * G + q, (size_t)a.n * G, d, q, xi, a.box, a.lj, fx, fy, fz, en);
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) {
+    fx += __shfl_xor(fx, o, CHX_WAVE);
+    fy += __shfl_xor(fy, o, CHX_WAVE);
+    fz += __shfl_xor(fz, o, CHX_WAVE);
+  }
+  if (q == 0) {
+    const int pl = threadIdx.x / G;
+    sF[3 * pl] = fx;
+    sF[3 * pl + 1] = fy;
+    sF[3 * pl + 2] = fz;
+  }
+  __syncthreads();
+  // ---- integrate: one (particle, Cartesian component) task per thread, all lanes busy ----
+  const int p0 = blockIdx.x * PPB;
+  for (int task0 = 0; task0 < 3 * PPB; task0 += 256) {
+    const int task = task0 + threadIdx.x;
+    const int pl = task / 3;
+    const int c = task - 3 * pl;
+    const int pp = p0 + pl;
+    const bool live = task < 3 * PPB && pp < a.n;
+    float sq = 0.f;
+    if (live) {
+      const float m = a.mass[pp];
+      const float F = sF[task];
+      float vc = a.v[3 * (size_t)pp + c];
+      for (int k = 0; k < n_kicks; ++k) vc = fadd(vc, fdiv(fmul(a.hdt, F), m));  // B  :181 / :195
+      if (do_aoa) {
+        const float L = c == 0 ? a.box.lx : (c == 1 ? a.box.ly : a.box.lz);
+        float xc = reinterpret_cast<const float*>(a.x_cur)[4 * (size_t)pp + c];
+        xc = fadd(xc, fmul(a.hdt, vc));  // A  :183
+        const uint32_t o = a.perm ? a.perm[pp] : (uint32_t)pp;
+        float z;
+        if (a.noise) {
+          z = a.noise[((size_t)(step - a.noise_step0) * (size_t)a.n + o) * 3 + c];
+        } else {
+          z = philox_normal_c(o, (uint32_t)step, CHX_STREAM_LANGEVIN, a.k0, a.k1, c);
+        }
+        const float bs = fmul(a.b, fsqrt(fdiv(a.kT, m)));
+        vc = fadd(fmul(a.a, vc), fmul(bs, z));  // O  :186
+        xc = fadd(xc, fmul(a.hdt, vc));         // A  :188
+        if (a.wrap && a.box.periodic) xc = wrap1(xc, L);  // :239
+        a.x_next[4 * (size_t)pp + c] = xc;
+        if (a.ref4) {
+          float r = fsub(xc, reinterpret_cast<const float*>(a.ref4)[4 * (size_t)pp + c]);
+          if (a.box.periodic) r = min_image(r, L, fmul(L, 0.5f));
+          sq = fmul(r, r);
+        }
+      }
+      a.v[3 * (size_t)pp + c] = vc;
+    }
+    if (do_aoa && a.ref4) {  // skin check :241: (rx^2 + ry^2) + rz^2 in the reference's order
+      if (task < 3 * PPB) sS[task] = sq;
+      __syncthreads();
+      if (live && c == 0 && fadd(fadd(sS[task], sS[task + 1]), sS[task + 2]) > a.T_half_skin) {
+        atomicMin(&a.ctrl[3], (int)(step + 1));
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -292,6 +418,56 @@ int chx_launch_lj_fl(const float* x4, const uint32_t* fl, const int32_t* deg, in
   }
   chx_set_error("chx_launch_lj_fl: unsupported g = %d", g);
   return CHX_ERR_INVALID;
+}
+
+template <int G>
+static void launch_step_g(const StepArgs& a, long long step, int n_kicks, int do_aoa, hipStream_t st) {
+  const unsigned blocks = (unsigned)(((int64_t)a.n * G + 255) / 256);
+  hipLaunchKernelGGL((k_lj_step<G>), dim3(blocks), dim3(256), 0, st, a, step, n_kicks, do_aoa);
+}
+
+// launch i of the chunk reads (i even ? x_even : x_odd) and writes the other buffer
+int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, int64_t step0,
+                        int n_steps, int kicks_first, int do_aoa, hipStream_t st) {
+  StepArgs a;
+  a.n = p->n;
+  a.v = p->v;
+  a.ref4 = reinterpret_cast<const float4*>(p->ref4);
+  a.mass = p->mass;
+  a.perm = p->perm;
+  a.fl = p->fl;
+  a.deg = p->deg;
+  a.box = make_box3(p->box);
+  a.lj = make_lj(p->sigma, p->epsilon, p->cutoff);
+  a.wrap = p->wrap;
+  a.T_half_skin = chx_cutoff_threshold_h(p->skin * 0.5f);
+  a.hdt = p->half_dt;
+  a.a = p->a;
+  a.b = p->b;
+  a.kT = p->kT;
+  a.k0 = p->k0;
+  a.k1 = p->k1;
+  a.noise = p->noise;
+  a.noise_step0 = p->noise_step0;
+  a.ctrl = p->ctrl;
+  for (int i = 0; i < n_steps; ++i) {
+    a.x_cur = reinterpret_cast<const float4*>((i & 1) ? x_odd : x_even);
+    a.x_next = (i & 1) ? x_even : x_odd;
+    const int nk = i == 0 ? kicks_first : 2;
+    switch (p->g) {
+      case 1: launch_step_g<1>(a, step0 + i, nk, do_aoa, st); break;
+      case 2: launch_step_g<2>(a, step0 + i, nk, do_aoa, st); break;
+      case 4: launch_step_g<4>(a, step0 + i, nk, do_aoa, st); break;
+      case 8: launch_step_g<8>(a, step0 + i, nk, do_aoa, st); break;
+      case 16: launch_step_g<16>(a, step0 + i, nk, do_aoa, st); break;
+      case 32: launch_step_g<32>(a, step0 + i, nk, do_aoa, st); break;
+      case 64: launch_step_g<64>(a, step0 + i, nk, do_aoa, st); break;
+      default:
+        chx_set_error("chx_launch_lj_steps: unsupported g = %d", p->g);
+        return CHX_ERR_INVALID;
+    }
+  }
+  return CHX_OK;
 }
 
 extern "C" int chx_lj_fl_energy_force(const float* x4, const uint32_t* fl, const int32_t* deg,

@@ -1,17 +1,21 @@
 """BAOAB Langevin integrator behind the reference's ``LangevinIntegrator`` API.
 
 Reference: chiron/integrators.py:13-286.  The Python loop of the reference (one
-``jax.grad`` + ~12 XLA dispatches + one host sync per step, :174-205) becomes two
-HIP launches per step -- a fused B-B-A-O-A-wrap-skin-check kernel and the pair-force
-kernel -- enqueued in chunks from C (``chx_langevin_chunk``).  The skin check that the
-reference turns into a Python ``if`` every step (:241) sets a device flag instead;
-once it fires the rest of the chunk is a sequence of no-op launches, and the host
-rebuilds the neighbor list at exactly the step the reference would have and resumes.
+``jax.grad`` + ~12 XLA dispatches + one host sync per step, :174-205) becomes ONE HIP
+launch per step on the neighbor-list path: ``k_lj_step`` evaluates the pair force and,
+in the same kernel, applies the half-kicks that consume it followed by A-O-A, the
+periodic wrap and the skin check of the *next* step (the trailing kick :195 of step
+s-1 is merged with the leading kick :181 of step s; the arithmetic and its order are
+unchanged).  Steps are enqueued in chunks from C, two chunks ahead of the host.  The
+skin check that the reference turns into a Python ``if`` every step (:241) records the
+step at which it fires in device memory; later launches of the in-flight chunks turn
+into no-ops, and the host rebuilds the neighbor list from exactly the positions the
+reference would have rebuilt it from, then resumes.
 """
 from __future__ import annotations
 
+import collections
 import copy
-import ctypes as C
 import logging
 from typing import Optional, Tuple
 
@@ -25,6 +29,8 @@ from .rng import PRNGKey, fold_in
 from .states import SamplerState, ThermodynamicState
 
 log = logging.getLogger("chiron_amd")
+
+_INT_MAX = 2**31 - 1
 
 
 def langevin_constants(timestep, collision_rate):
@@ -41,7 +47,7 @@ class LangevinIntegrator:
     """Langevin dynamics with the BAOAB splitting (Leimkuhler & Matthews 2013).
 
     Same constructor and ``run`` signature as chiron/integrators.py:25-105.
-    ``chunk_size`` (steps enqueued per host round-trip) is the only addition.
+    ``chunk_size`` (steps enqueued per launch batch) is the only addition.
     """
 
     def __init__(
@@ -65,8 +71,8 @@ class LangevinIntegrator:
         self.traj = []
         self.refresh_velocities = refresh_velocities
         self._move_iteration = 0
-        self.chunk_size = int(chunk_size)
-        self.n_rebuilds = 0  # neighbor-list rebuilds triggered inside run()
+        self.chunk_size = max(1, int(chunk_size))
+        self.n_rebuilds = 0  # neighbor-list rebuilds triggered inside the last run()
 
     # ------------------------------------------------------------------
     def run(
@@ -79,9 +85,9 @@ class LangevinIntegrator:
         noise: Optional[torch.Tensor] = None,
     ) -> Tuple[SamplerState, object]:
         """chiron/integrators.py:75-218.  ``noise`` (number_of_steps, N, 3) optionally
-        replaces the device PRNG for the O step (deterministic parity tests)."""
-        from .potential import LJPotential
+        replaces the device PRNG in the O step (deterministic parity tests)."""
         from .neighbors import NeighborListNsqrd, PairListNsqrd
+        from .potential import LJPotential
         from .utils import get_list_of_mass, initialize_velocities
 
         potential = thermodynamic_state.potential
@@ -106,15 +112,17 @@ class LangevinIntegrator:
             sampler_state.velocities = initialize_velocities(temperature, potential.topology, key)
         v0 = sampler_state.velocities
 
-        n = x0.shape[0]
-        dev = x0.device
         if nbr_list is not None:
             nbr_list.build_from_state(sampler_state)  # :169
 
-        use_lj_kernels = isinstance(potential, LJPotential) and (
-            nbr_list is None or isinstance(nbr_list, (NeighborListNsqrd, PairListNsqrd))
-        )
-        if use_lj_kernels and nbr_list is not None:
+        is_lj = isinstance(potential, LJPotential)
+        if is_lj and isinstance(nbr_list, NeighborListNsqrd):
+            mode = "fused"
+        elif is_lj and (nbr_list is None or isinstance(nbr_list, PairListNsqrd)):
+            mode = "pairs"
+        else:
+            mode = "external"
+        if mode != "external" and nbr_list is not None:
             # same validation as compute_energy (chiron/potential.py:263-270)
             if not nbr_list.is_built:
                 raise ValueError("Neighborlist must be built before use")
@@ -124,46 +132,45 @@ class LangevinIntegrator:
                     f"Neighborlist cutoff ({nbr_list.cutoff}) must be the same as the potential cutoff ({potential.cutoff})"
                 )
 
-        st = _RunState(self, potential, nbr_list, x0, v0, mass_unitless, kbT_unitless, half_dt, a, b,
-                       key, noise, use_lj_kernels)
-        st.initial_force()
+        st = _RunState(self, potential, nbr_list, x0, v0, mass_unitless, kbT_unitless, half_dt, a, b, key, noise, mode)
 
-        step = 0
-        kicks_first = 1
-        steps_iter = None
+        bar = None
         if progress_bar:
             try:
                 from tqdm import tqdm
 
-                steps_iter = tqdm(total=number_of_steps)
+                bar = tqdm(total=number_of_steps)
             except Exception:  # pragma: no cover
-                steps_iter = None
-        wants_reports = (hasattr(self, "reporter") and self.reporter is not None) or self.save_traj_in_memory
-        while step < number_of_steps:
-            chunk = min(self.chunk_size, number_of_steps - step)
-            if not use_lj_kernels:
-                chunk = 1
-            if wants_reports:
-                # end the chunk on the next reporting step so the state can be read out there
-                base = self._move_iteration * number_of_steps
-                to_report = (-(step + base)) % self.report_interval
-                chunk = min(chunk, to_report + 1)
-            done = st.advance(step, chunk, kicks_first)
-            if steps_iter is not None:
-                steps_iter.update(done)
-            step += done
-            kicks_first = 2
-            last = step - 1
-            elapsed_step = last + self._move_iteration * number_of_steps
-            if elapsed_step % self.report_interval == 0:  # :197-205
-                if hasattr(self, "reporter") and self.reporter is not None:
+                bar = None
+        has_reporter = hasattr(self, "reporter") and self.reporter is not None
+        wants_reports = has_reporter or self.save_traj_in_memory
+        base = self._move_iteration * number_of_steps
+
+        def next_stop(step: int) -> int:
+            """First step count at which the host has to look at the state again."""
+            if not wants_reports:
+                return number_of_steps
+            to_report = (-(step + base)) % self.report_interval  # steps until the next reporting step
+            return min(number_of_steps, step + to_report + 1)
+
+        done = 0
+        while done < number_of_steps:
+            stop = next_stop(done)
+            before = done
+            done = st.advance_to(done, stop)
+            if bar is not None:
+                bar.update(done - before)
+            last = done - 1
+            elapsed_step = last + base
+            if done == stop and elapsed_step % self.report_interval == 0:  # :197-205
+                if has_reporter:
                     self._report(st.positions_user(), potential, st.nbr_list, last, self._move_iteration, elapsed_step)
                 if self.save_traj_in_memory:
                     self.traj.append(st.positions_user())
-        if steps_iter is not None:
-            steps_iter.close()
+        if bar is not None:
+            bar.close()
         if number_of_steps > 0:
-            st.final_kick()
+            st.final_kick(number_of_steps)
 
         updated_sampler_state = copy.deepcopy(sampler_state)  # :210-218
         updated_sampler_state.positions = st.positions_user()
@@ -193,11 +200,14 @@ class LangevinIntegrator:
         self.reporter.report(d)
 
 
+class _Pending:
+    __slots__ = ("s0", "n", "parity0", "host", "event")
+
+
 class _RunState:
     """Device-resident state of one ``run`` call in the kernels' internal layout."""
 
-    def __init__(self, integ, potential, nbr_list, x0, v0, mass, kT, half_dt, a, b, key: PRNGKey,
-                 noise, use_lj_kernels: bool):
+    def __init__(self, integ, potential, nbr_list, x0, v0, mass, kT, half_dt, a, b, key: PRNGKey, noise, mode: str):
         from .neighbors import NeighborListNsqrd, PairListNsqrd
 
         self.integ = integ
@@ -205,11 +215,11 @@ class _RunState:
         self.nbr_list = nbr_list
         self.kT, self.half_dt, self.a, self.b = kT, half_dt, a, b
         self.key = key
-        self.use_lj = use_lj_kernels
+        self.mode = mode
         self.n = x0.shape[0]
         self.dev = x0.device
         self.noise = None if noise is None else as_tensor(noise)
-        if self.noise is not None and (self.noise.dim() != 3 or self.noise.shape[1:] != (self.n, 3)):
+        if self.noise is not None and (self.noise.dim() != 3 or tuple(self.noise.shape[1:]) != (self.n, 3)):
             raise ValueError(f"noise must have shape (steps, {self.n}, 3), got {tuple(self.noise.shape)}")
         self.mass_user = mass
         self.ctrl = torch.zeros((4,), dtype=torch.int32, device=self.dev)
@@ -217,29 +227,36 @@ class _RunState:
         self.is_verlet = isinstance(nbr_list, NeighborListNsqrd)
         self.is_pairlist = isinstance(nbr_list, PairListNsqrd)
         self.n_rebuilds = 0
+        self.kicks_next = 1  # the first step of a run applies only its leading kick
+        self.depth = 2  # chunks kept in flight ahead of the host
         self._load(x0, v0)
+        if self.mode == "pairs":
+            ops.langevin_resume(self.params)  # F(x0), :171
+        elif self.mode == "external":
+            self._external_force()
 
     # -- layout ------------------------------------------------------------
+    def _pack(self, src, stride, perm):
+        out = torch.empty((self.n, stride), dtype=torch.float32, device=self.dev)
+        ops.check(
+            ops._lib.load().chx_permute_pack(ops._ptr(ops._f32(src)), ops._ptr(perm), self.n, ops._ptr(out), stride, ops._stream()),
+            "chx_permute_pack",
+        )
+        return out
+
     def _load(self, x_user: torch.Tensor, v_user: torch.Tensor):
         """(Re)pack user-order arrays into the internal order of the current force list."""
-        lib = ops._lib.load()
-        self.fl = self.nbr_list.force_list if (self.is_verlet and self.use_lj) else None
+        self.fl = self.nbr_list.force_list if self.mode == "fused" else None
         perm = self.fl.perm if self.fl is not None else None
         self.perm = perm
         n = self.n
-
-        def pack(src, stride):
-            out = torch.empty((n, stride), dtype=torch.float32, device=self.dev)
-            ops.check(lib.chx_permute_pack(ops._ptr(src), ops._ptr(perm), n, ops._ptr(out), stride, ops._stream()), "chx_permute_pack")
-            return out
-
-        self.x4 = pack(ops._f32(x_user), 4)
-        self.v = pack(ops._f32(v_user), 3)
+        self.x_a = self._pack(x_user, 4, perm)  # current positions live here when parity == 0
+        self.x_b = torch.zeros_like(self.x_a) if self.mode == "fused" else None
+        self.parity = 0
+        self.v = self._pack(v_user, 3, perm)
         self.mass = self.mass_user if perm is None else self.mass_user[perm.long()].contiguous()
-        self.f = torch.zeros((n, 3), dtype=torch.float32, device=self.dev)
-        self.ref4 = None
-        if self.is_verlet:
-            self.ref4 = pack(self.nbr_list.ref_positions, 4)
+        self.f = torch.zeros((n, 3), dtype=torch.float32, device=self.dev) if self.mode != "fused" else None
+        self.ref4 = self._pack(self.nbr_list.ref_positions, 4, perm) if self.is_verlet else None
         box = Box(0, 0.0, 0.0, 0.0)
         wrap = 0
         skin = 0.0
@@ -248,12 +265,14 @@ class _RunState:
             wrap = 1
             if self.is_verlet:
                 skin = float(self.nbr_list.skin.value_in_unit_system(unit.md_unit_system))
+        self.ctrl.zero_()
+        self.ctrl[3] = _INT_MAX
         p = LangevinParams()
         p.n = n
         p.g = self.fl.g if self.fl is not None else 1
-        p.x4 = self.x4.data_ptr()
+        p.x4 = self.x_a.data_ptr()
         p.v = self.v.data_ptr()
-        p.f = self.f.data_ptr()
+        p.f = self.f.data_ptr() if self.f is not None else None
         p.ref4 = self.ref4.data_ptr() if self.ref4 is not None else None
         p.mass = self.mass.data_ptr()
         p.perm = perm.data_ptr() if perm is not None else None
@@ -263,7 +282,7 @@ class _RunState:
         p.wrap = wrap
         p.skin = skin
         p.half_dt, p.a, p.b, p.kT = self.half_dt, self.a, self.b, self.kT
-        if self.use_lj:
+        if self.mode != "external":
             p.sigma, p.epsilon, p.cutoff = self.potential.sigma, self.potential.epsilon, self.potential.cutoff
             if self.is_pairlist and self.nbr_list.cutoff is None:
                 p.cutoff = -1.0
@@ -272,8 +291,11 @@ class _RunState:
         p.noise_step0 = 0
         p.ctrl = self.ctrl.data_ptr()
         p.ws = self.ws.data_ptr()
-        p.external_force = 0 if self.use_lj else 1
+        p.external_force = 1 if self.mode == "external" else 0
         self.params = p
+
+    def _x_cur(self) -> torch.Tensor:
+        return self.x_a if self.parity == 0 else self.x_b
 
     def _unpack(self, t: torch.Tensor) -> torch.Tensor:
         out = torch.empty((self.n, 3), dtype=torch.float32, device=self.dev)
@@ -284,12 +306,57 @@ class _RunState:
         return out
 
     def positions_user(self) -> torch.Tensor:
-        return self._unpack(self.x4)
+        return self._unpack(self._x_cur())
 
     def velocities_user(self) -> torch.Tensor:
         return self._unpack(self.v)
 
-    # -- dynamics ----------------------------------------------------------
+    def _rebuild(self):
+        """The host half of chiron/integrators.py:241-242 once the device check has fired."""
+        x_user, v_user = self.positions_user(), self.velocities_user()
+        self.nbr_list.build(x_user, self.nbr_list.box_vectors)
+        self._load(x_user, v_user)
+        self.n_rebuilds += 1
+
+    # -- fused neighbor-list path -------------------------------------------
+    def _enqueue_fused(self, s0: int, n: int, do_aoa: int = 1) -> _Pending:
+        even, odd = (self.x_a, self.x_b) if self.parity == 0 else (self.x_b, self.x_a)
+        ops.langevin_fused_chunk(self.params, even, odd, s0, n, self.kicks_next, do_aoa)
+        rec = _Pending()
+        rec.s0, rec.n, rec.parity0 = s0, n, self.parity
+        if do_aoa:
+            self.parity ^= n & 1
+            self.kicks_next = 2
+        rec.host = torch.empty((4,), dtype=torch.int32, pin_memory=True)
+        rec.host.copy_(self.ctrl, non_blocking=True)
+        rec.event = torch.cuda.Event()
+        rec.event.record()
+        return rec
+
+    def _advance_fused(self, done: int, stop: int) -> int:
+        chunk = self.integ.chunk_size
+        pending = collections.deque()
+        nxt = done
+        while done < stop:
+            while len(pending) < self.depth and nxt < stop:
+                c = min(chunk, stop - nxt)
+                pending.append(self._enqueue_fused(nxt, c))
+                nxt += c
+            rec = pending.popleft()
+            rec.event.synchronize()
+            halt = int(rec.host[3])
+            if halt <= rec.s0 + rec.n:
+                # skin check fired while producing x_halt: steps < halt ran, everything queued behind is a no-op
+                torch.cuda.synchronize()
+                pending.clear()
+                self.parity = rec.parity0 ^ ((halt - rec.s0) & 1)
+                self._rebuild()
+                done = nxt = halt
+            else:
+                done = rec.s0 + rec.n
+        return done
+
+    # -- other paths -------------------------------------------------------
     def _external_force(self):
         """Potentials without a fused kernel: ask the potential (reference integrators.py:171,193)."""
         F = self.potential.compute_force(self.positions_user(), self.nbr_list)
@@ -298,36 +365,34 @@ class _RunState:
         else:
             self.f.fill_(float(F))
 
-    def initial_force(self):
-        if self.use_lj:
-            ops.langevin_resume(self.params)
-        else:
-            self._external_force()
-
-    def _rebuild(self):
-        """The host half of chiron/integrators.py:241-242 after the device check fired."""
-        x_user, v_user = self.positions_user(), self.velocities_user()
-        self.nbr_list.build(x_user, self.nbr_list.box_vectors)
-        self.ctrl.zero_()
-        self._load(x_user, v_user)
-        self.n_rebuilds += 1
-
-    def advance(self, step0: int, n_steps: int, kicks_first: int) -> int:
-        """Run up to n_steps; returns how many completed (force included)."""
-        ops.langevin_chunk(self.params, step0, n_steps, kicks_first)
-        if self.use_lj:
-            ctrl = self.ctrl.cpu()  # one host sync per chunk
-            if int(ctrl[1]) != 0:
-                s = int(ctrl[2])
-                self._rebuild()
-                ops.langevin_resume(self.params)  # force of step s on the fresh list
-                return s - step0 + 1
-            return n_steps
+    def advance_to(self, done: int, stop: int) -> int:
+        """Run steps [done, stop); returns the new step count (== stop)."""
+        if self.mode == "fused":
+            return self._advance_fused(done, stop)
+        if self.mode == "pairs":
+            # all-pairs kernels: no skin check exists on this path (PairListNsqrd.check only looks at N)
+            chunk = self.integ.chunk_size
+            while done < stop:
+                c = min(chunk, stop - done)
+                ops.langevin_chunk(self.params, done, c, self.kicks_next)
+                self.kicks_next = 2
+                done += c
+            return done
         # external-force path: one step at a time, like the reference
-        if self.is_verlet and int(self.ctrl.cpu()[0]) != 0:
-            self._rebuild()
-        self._external_force()
-        return n_steps
+        while done < stop:
+            ops.langevin_chunk(self.params, done, 1, self.kicks_next)
+            self.kicks_next = 2
+            if self.is_verlet and int(self.ctrl.cpu()[0]) != 0:
+                self._rebuild()
+            self._external_force()
+            done += 1
+        return done
 
-    def final_kick(self):
-        ops.kick(self.v, self.f, self.mass, self.half_dt)
+    def final_kick(self, n_steps: int):
+        """Trailing half-kick of the last step (chiron/integrators.py:195)."""
+        if self.mode == "fused":
+            self.kicks_next = 1
+            rec = self._enqueue_fused(n_steps, 1, do_aoa=0)
+            rec.event.synchronize()
+        else:
+            ops.kick(self.v, self.f, self.mass, self.half_dt)

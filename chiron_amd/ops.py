@@ -308,6 +308,15 @@ def langevin_chunk(params: LangevinParams, step0: int, n_steps: int, kicks_first
     check(_lib.load().chx_langevin_chunk(C.byref(params), step0, n_steps, kicks_first, _stream()), "chx_langevin_chunk")
 
 
+def langevin_fused_chunk(params: LangevinParams, x_even: torch.Tensor, x_odd: torch.Tensor, step0: int,
+                         n_steps: int, kicks_first: int, do_aoa: int = 1) -> None:
+    _require_device(x_even, x_odd)
+    check(
+        _lib.load().chx_langevin_fused_chunk(C.byref(params), _ptr(x_even), _ptr(x_odd), step0, n_steps, kicks_first, do_aoa, _stream()),
+        "chx_langevin_fused_chunk",
+    )
+
+
 def langevin_resume(params: LangevinParams) -> None:
     check(_lib.load().chx_langevin_resume(C.byref(params), _stream()), "chx_langevin_resume")
 

@@ -83,6 +83,7 @@ class Topology:
         self._chains: List[Chain] = []
         self._atoms: List[Atom] = []
         self._n_residues = 0
+        self._masses_amu = None
 
     def addChain(self, id: Optional[str] = None) -> Chain:
         c = Chain(len(self._chains), self)
@@ -99,7 +100,24 @@ class Topology:
         a = Atom(name, element, len(self._atoms), residue)
         self._atoms.append(a)
         residue._atoms.append(a)
+        self._masses_amu = None
         return a
+
+    def masses_amu(self):
+        """Per-atom masses in amu as a cached float64 array (one unit conversion per element)."""
+        import numpy as np
+
+        if getattr(self, "_masses_amu", None) is None or len(self._masses_amu) != len(self._atoms):
+            per_element = {}
+            out = np.empty(len(self._atoms), dtype=np.float64)
+            for i, atom in enumerate(self._atoms):
+                el = atom.element
+                m = per_element.get(id(el))
+                if m is None:
+                    m = per_element[id(el)] = float(el.mass.value_in_unit(unit.amu))
+                out[i] = m
+            self._masses_amu = out
+        return self._masses_amu
 
     def atoms(self) -> Iterator[Atom]:
         return iter(self._atoms)

@@ -36,6 +36,8 @@ def get_nr_of_particles(topology) -> int:
 
 def get_list_of_mass(topology) -> unit.Quantity:
     """Masses (amu) from ``atom.element.mass`` (chiron/utils.py:106-113)."""
+    if hasattr(topology, "masses_amu"):
+        return topology.masses_amu() * unit.amu  # cached: the reference re-walks the atoms on every run()
     mass = [atom.element.mass.value_in_unit(unit.amu) for atom in topology.atoms()]
     return np.asarray(mass, dtype=np.float64) * unit.amu
 

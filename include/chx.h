@@ -208,6 +208,21 @@ int chx_langevin_chunk(const chx_langevin_t* p_h, int64_t step0, int32_t n_steps
 /* force evaluation that completes a halted step after the list was rebuilt */
 int chx_langevin_resume(const chx_langevin_t* p_h, chx_stream_t stream);
 
+/* Fused neighbor-list path: ONE launch per MD step.  Launch i (global step step0+i)
+ * reads positions from (i even ? x_even : x_odd), evaluates the pair force on the
+ * force list, applies the half-kicks that consume it (kicks_first for i = 0, else 2:
+ * trailing kick of the previous step + leading kick of this one), then A-O-A, wrap
+ * and the skin check, and writes the new positions to the other buffer
+ * (chiron/integrators.py:179-195 with :193-195 of step s-1 merged into step s).
+ * p_h->x4 / p_h->f are ignored.  ctrl[3] must hold INT32_MAX on entry; when the skin
+ * check fires while producing the positions of step s+1 the kernel stores s+1 there
+ * and every launch with step >= ctrl[3] is a no-op, so the state is exactly the one
+ * the reference rebuilds its list from.  do_aoa == 0: force + kicks only (the trailing
+ * kick that ends a run).  Asynchronous. */
+int chx_langevin_fused_chunk(const chx_langevin_t* p_h, float* x_even, float* x_odd, int64_t step0,
+                             int32_t n_steps, int32_t kicks_first, int32_t do_aoa,
+                             chx_stream_t stream);
+
 /* ------------------------------------------------------------ Monte Carlo */
 /* MonteCarloDisplacementMove proposal: x' = wrap(x + sigma_d * N(0,1) [* mask_i]),
  * chiron/mcmc.py:724-755.  Philox stream 2, counter word 1 = ctr. */
