@@ -360,13 +360,14 @@ __global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int
       }
       a.v[3 * (size_t)pp + c] = vc;
     }
-    if (do_aoa && a.ref4) {  // skin check :241: (rx^2 + ry^2) + rz^2 in the reference's order
-      if (task < 3 * PPB) sS[task] = sq;
-      __syncthreads();
-      if (live && c == 0 && fadd(fadd(sS[task], sS[task + 1]), sS[task + 2]) > a.T_half_skin) {
+    if (task < 3 * PPB) sS[task] = sq;
+  }
+  if (do_aoa && a.ref4) {  // skin check :241: (rx^2 + ry^2) + rz^2 in the reference's order
+    __syncthreads();
+    for (int pl = threadIdx.x; pl < PPB; pl += 256) {
+      if (p0 + pl < a.n && fadd(fadd(sS[3 * pl], sS[3 * pl + 1]), sS[3 * pl + 2]) > a.T_half_skin) {
         atomicMin(&a.ctrl[3], (int)(step + 1));
       }
-      __syncthreads();
     }
   }
 }

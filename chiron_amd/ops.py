@@ -199,13 +199,24 @@ def pl_calculate(xyz, box: Box, cutoff: Optional[float]):
 # ---------------------------------------------------------------------------
 # force list + LJ kernels
 # ---------------------------------------------------------------------------
-def _choose_g(maxdeg: int) -> int:
+def _choose_g(maxdeg: int, n: int) -> int:
+    """Lanes that cooperate on one particle in the list kernel.
+
+    Measured on MI355X (scripts/kernel_bench.py): the kernel wants >= ~5e5 lanes in flight to
+    fill 256 CUs, as few lanes per particle as that allows (less reduction / idle-lane overhead),
+    and no more than ~40 sequential entries per lane.
+    """
     env = os.environ.get("CHX_FL_G")
     if env:
         return int(env)
-    target = max(1.0, maxdeg / 6.0)
-    g = 1 << int(round(math.log2(target)))
-    return max(1, min(64, g))
+    g = 1
+    while g < 64 and n * g < (1 << 19):
+        g *= 2
+    while g < 64 and maxdeg > 40 * g:
+        g *= 2
+    while g > 1 and g > max(1, maxdeg):
+        g //= 2
+    return g
 
 
 class ForceList:
@@ -226,7 +237,7 @@ class ForceList:
         maxdeg_t = torch.empty((1,), dtype=torch.int32, device=dev)
         check(lib.chx_fl_count(_ptr(nl), _ptr(n_nbr), n, m, _ptr(self.inv), _ptr(self.deg), _ptr(maxdeg_t), _stream()), "chx_fl_count")
         self.maxdeg = int(maxdeg_t.item())  # build-time sync (the reference syncs here too, neighbors.py:709)
-        self.g = _choose_g(self.maxdeg)
+        self.g = _choose_g(self.maxdeg, n)
         chunks = max(1, -(-self.maxdeg // self.g))
         self.fl = torch.zeros((chunks, n, self.g), dtype=torch.int32, device=dev)
         cursor = torch.empty((n,), dtype=torch.int32, device=dev)

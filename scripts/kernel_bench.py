@@ -1,0 +1,61 @@
+"""Micro-benchmark of the pair-force / fused-step kernels (diagnostic, GPU box only).
+usage: python scripts/kernel_bench.py [workload ...]   env CHX_FL_G overrides lanes/particle"""
+import ctypes as C
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import bench
+from chiron_amd import _lib, ops
+from chiron_amd.integrators import _RunState, langevin_constants
+from chiron_amd import unit
+
+
+def ev_time(fn, reps=200, warm=20):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / reps  # us
+
+
+for wl in sys.argv[1:] or ["c3", "c4"]:
+    for g in os.environ.get("GS", "4,8,16").split(","):
+        os.environ["CHX_FL_G"] = g
+        fluid, pot, state, thermo, nbr, integ = bench.make_system(wl, 300.0, 32, "cell")
+        nbr.build_from_state(state)
+        fl = nbr.force_list
+        n = fl.n
+        p_nl = int(nbr.n_neighbors.sum())
+        alg = 24 * n + 16 * p_nl
+        x4 = fl.pack(state.positions, 4)
+        lib = _lib.load()
+        f3 = torch.empty((n, 3), dtype=torch.float32, device="cuda")
+        box = nbr._box_h
+        t_f = ev_time(lambda: lib.chx_lj_fl_energy_force(ops._ptr(x4), ops._ptr(fl.fl), ops._ptr(fl.deg), n, fl.g, box,
+                                                         C.c_float(pot.sigma), C.c_float(pot.epsilon), C.c_float(pot.cutoff),
+                                                         ops._ptr(f3), None, ops._ptr(fl.ws), ops._stream()))
+        # fused step kernel (skin check can never fire: huge skin)
+        half_dt, a, b = langevin_constants(1.0 * unit.femtoseconds, 1.0 / unit.picoseconds)
+        from chiron_amd.utils import get_list_of_mass
+        from chiron_amd._device import as_tensor
+        mass = as_tensor(get_list_of_mass(fluid.topology).value_in_unit_system(unit.md_unit_system))
+        v0 = torch.zeros((n, 3), device="cuda")
+        st = _RunState(integ, pot, nbr, state.positions, v0, mass, 2.494, half_dt, a, b, state.current_PRNG_key, None, "fused")
+        st.params.skin = 1e6
+        step = [0]
+
+        def one():
+            even, odd = (st.x_a, st.x_b) if (step[0] & 1) == 0 else (st.x_b, st.x_a)
+            ops.langevin_fused_chunk(st.params, even, odd, step[0], 1, 2, 1)
+            step[0] += 1
+        t_s = ev_time(one, reps=100, warm=10)
+        print(f"{wl} g={fl.g} maxdeg={fl.maxdeg} P_nl={p_nl} alg={alg/1e6:.2f}MB  force {t_f:7.2f} us ({alg/t_f/1e3:7.1f} GB/s, {alg/t_f/8e6*100:5.1f}%)   fused step {t_s:7.2f} us")
