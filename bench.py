@@ -83,39 +83,75 @@ def make_system(workload: str, temperature_K: float, chunk: int, build: str):
     return fluid, pot, state, thermo, nbr, integ
 
 
-def time_force_kernel(pot, state, nbr, reps: int):
-    """Average duration of the pair-force kernel alone (HIP events on the launch stream)."""
-    fl = nbr.force_list
-    x4 = fl.pack(state.positions, 4)
-    box = nbr._box_h
-    for _ in range(10):
-        fl.energy_force(x4, box, pot.sigma, pot.epsilon, pot.cutoff, True, False)
-    torch.cuda.synchronize()
-    start = torch.cuda.Event(enable_timing=True)
-    stop = torch.cuda.Event(enable_timing=True)
-    from chiron_amd import _lib, ops
+def time_kernels(fluid, pot, state, nbr, integ, reps: int):
+    """HIP-event timing (on the launch stream) of the two hot kernels on the current list:
+    k_lj_step (fused pair force + BAOAB, what the timed region launches once per step) and
+    k_lj_fl (the pair-force kernel alone, what compute_force() launches).
+    Returns (t_step_s, t_force_s, P_nl, force_list)."""
     import ctypes as C
 
+    from chiron_amd import _lib, ops, unit
+    from chiron_amd._device import as_tensor
+    from chiron_amd.integrators import _RunState, langevin_constants
+    from chiron_amd.utils import get_list_of_mass
+
     lib = _lib.load()
-    f3 = torch.empty((fl.n, 3), dtype=torch.float32, device=x4.device)
-    args = (ops._ptr(x4), ops._ptr(fl.fl), ops._ptr(fl.deg), fl.n, fl.g, box, C.c_float(pot.sigma),
+    fl = nbr.force_list
+    n = fl.n
+    box = nbr._box_h
+    x4 = fl.pack(state.positions, 4)
+    f3 = torch.empty((n, 3), dtype=torch.float32, device=x4.device)
+    args = (ops._ptr(x4), ops._ptr(fl.fl), ops._ptr(fl.deg), n, fl.g, box, C.c_float(pot.sigma),
             C.c_float(pot.epsilon), C.c_float(pot.cutoff), ops._ptr(f3), None, ops._ptr(fl.ws))
-    start.record()
-    for _ in range(reps):
-        lib.chx_lj_fl_energy_force(*args, ops._stream())
-    stop.record()
-    torch.cuda.synchronize()
-    t = start.elapsed_time(stop) * 1e-3 / reps
+
+    def timed(fn, count):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        start = torch.cuda.Event(enable_timing=True)
+        stop = torch.cuda.Event(enable_timing=True)
+        start.record()
+        for _ in range(count):
+            fn()
+        stop.record()
+        torch.cuda.synchronize()
+        return start.elapsed_time(stop) * 1e-3 / count
+
+    t_force = timed(lambda: lib.chx_lj_fl_energy_force(*args, ops._stream()), reps)
+
+    # the fused step kernel on the same state; a huge skin keeps the check from ever firing so that
+    # every launch does the full work (the comparison itself still runs)
+    half_dt, a, b = langevin_constants(integ.timestep, integ.collision_rate)
+    mass = as_tensor(get_list_of_mass(fluid.topology).value_in_unit_system(unit.md_unit_system))
+    v = state.velocities if state.velocities is not None else torch.zeros((n, 3), device=x4.device)
+    st = _RunState(integ, pot, nbr, state.positions, v, mass, 2.494, half_dt, a, b, state.current_PRNG_key, None, "fused")
+    st.params.skin = 1.0e6
+    step = [0]
+
+    def one_step():
+        even, odd = (st.x_a, st.x_b) if (step[0] & 1) == 0 else (st.x_b, st.x_a)
+        ops.langevin_fused_chunk(st.params, even, odd, step[0], 1, 2, 1)
+        step[0] += 1
+
+    t_step = timed(one_step, reps)
     p_nl = int(torch.minimum(nbr.n_neighbors, torch.tensor(nbr.n_max_neighbors, device=x4.device)).sum().item())
-    return t, p_nl, fl
+    return t_step, t_force, p_nl, fl
 
 
-def roofline_entry(n: int, p_nl: int, seconds: float, extra=None):
-    algorithmic = 24 * n + 16 * p_nl
+def roofline_entry(kind: str, n: int, p_nl: int, seconds: float, extra=None):
+    """Algorithmic bytes per launch: pair force 24 N + 16 P_nl; the fused step adds the
+    BAOAB traffic B_lang = 60 N (x, v, F in; x, v out) + 12 N (reference positions of the skin check)."""
+    force_bytes = 24 * n + 16 * p_nl
+    if kind == "step":
+        algorithmic = force_bytes + 72 * n
+        name = "k_lj_step (fused pair force + BAOAB + wrap + skin check; one launch per MD step)"
+    else:
+        algorithmic = force_bytes
+        name = "k_lj_fl (pair force over the neighbor list)"
     achieved = algorithmic / seconds / 1e9
     d = {
         "bound": "hbm",
-        "kernel": "k_lj_fl (pair force over the neighbor list)",
+        "kernel": name,
         "achieved": round(achieved, 2),
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
@@ -222,9 +258,11 @@ def main():
     value = world * args.steps / elapsed
 
     if rank == 0:
-        # dominant kernel, timed live on the same device / list state
-        t_k, p_nl, fl = time_force_kernel(pot, state, nbr, args.kernel_reps)
-        roof = roofline_entry(n, p_nl, t_k, {"lanes_per_particle": fl.g, "max_degree": fl.maxdeg})
+        # hot kernels, timed live on the same device / list state
+        t_step, t_force, p_nl, fl = time_kernels(fluid, pot, state, nbr, integ, args.kernel_reps)
+        info = {"lanes_per_particle": fl.g, "max_degree": fl.maxdeg}
+        roof = roofline_entry("step", n, p_nl, t_step, info)
+        roof_force = roofline_entry("force", n, p_nl, t_force, info)
         out = {
             "metric": "Langevin steps/sec + pair-force GB/s vs HBM roofline, LJ N=32k @1/8 GPU",
             "value": round(value, 2),
@@ -253,19 +291,22 @@ def main():
                 "swap_acceptance": (float(rex.n_accepted.sum() / max(1, rex.n_proposed.sum())) if world > 1 else None),
             },
             "roofline": roof,
+            "roofline_pair_force": roof_force,
         }
         if world == 1 and args.extra_c4 and args.workload != "c4":
             try:
                 fluid4, pot4, state4, thermo4, nbr4, integ4 = make_system("c4", 300.0, args.chunk, "cell")
                 nbr4.build_from_state(state4)
-                t4, p4, fl4 = time_force_kernel(pot4, state4, nbr4, args.kernel_reps)
-                out["roofline_262k"] = roofline_entry(fluid4.n_particles, p4, t4,
-                                                      {"lanes_per_particle": fl4.g, "max_degree": fl4.maxdeg})
+                ts4, tf4, p4, fl4 = time_kernels(fluid4, pot4, state4, nbr4, integ4, args.kernel_reps)
+                info4 = {"lanes_per_particle": fl4.g, "max_degree": fl4.maxdeg}
+                out["roofline_262k"] = roofline_entry("force", fluid4.n_particles, p4, tf4, info4)
+                out["roofline_262k_step"] = roofline_entry("step", fluid4.n_particles, p4, ts4, info4)
+                state4, nbr4 = integ4.run(state4, thermo4, number_of_steps=100, nbr_list=nbr4)  # warm-up
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                integ4.run(state4, thermo4, number_of_steps=300, nbr_list=nbr4)
+                integ4.run(state4, thermo4, number_of_steps=1000, nbr_list=nbr4)
                 torch.cuda.synchronize()
-                out["steps_per_s_262k"] = round(300 / (time.perf_counter() - t0), 2)
+                out["steps_per_s_262k"] = round(1000 / (time.perf_counter() - t0), 2)
                 del fluid4, pot4, state4, nbr4
             except Exception as exc:  # pragma: no cover - diagnostics only
                 out["roofline_262k"] = {"error": repr(exc)}
