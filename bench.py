@@ -206,8 +206,12 @@ def main():
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
 
-    if world > 1:
+    # under torchrun (RANK set) the process group is always created, also for one rank, so that the
+    # RCCL path (init, barrier, all-reduce, all-gather) can be exercised on a single-GPU box
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    exchange_on = world > 1 or (use_dist and os.environ.get("CHX_BENCH_EXCHANGE", "0") == "1")
 
     from chiron_amd import _lib, ops, unit
     from chiron_amd.multistate import ReplicaExchange
@@ -222,7 +226,7 @@ def main():
     rex = ReplicaExchange(ladder, PRNGKey(2024, 7), rank=rank, world_size=world)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -232,10 +236,10 @@ def main():
         done = 0
         exchanges = 0
         while done < n_steps:
-            seg = n_steps - done if world == 1 else min(args.exchange_interval, n_steps - done)
+            seg = min(args.exchange_interval, n_steps - done) if exchange_on else n_steps - done
             st, nb = integ.run(st, rex.my_state, number_of_steps=seg, nbr_list=nb)
             done += seg
-            if world > 1 and done < n_steps + 1:
+            if exchange_on:
                 energy = pot.compute_energy(st.positions, nb)
                 _, vscale = rex.exchange(energy)
                 if vscale != 1.0:
@@ -251,7 +255,7 @@ def main():
     state, exchanges = propagate(state, args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -317,7 +321,7 @@ def main():
             except Exception as exc:  # pragma: no cover
                 out["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

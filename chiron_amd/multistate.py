@@ -118,7 +118,7 @@ class ReplicaExchange:
         import torch.distributed as dist
 
         e = energy.detach().reshape(1).to(torch.float32)
-        if self.world_size == 1:
+        if self.world_size == 1 and not (dist.is_available() and dist.is_initialized()):
             return e.cpu().numpy().astype(np.float64)
         out = torch.empty(self.world_size, dtype=torch.float32, device=e.device)
         dist.all_gather_into_tensor(out, e)
