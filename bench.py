@@ -101,7 +101,7 @@ def time_kernels(fluid, pot, state, nbr, integ, reps: int):
     box = nbr._box_h
     x4 = fl.pack(state.positions, 4)
     f3 = torch.empty((n, 3), dtype=torch.float32, device=x4.device)
-    args = (ops._ptr(x4), ops._ptr(fl.fl), ops._ptr(fl.deg), n, fl.g, box, C.c_float(pot.sigma),
+    args = (ops._ptr(x4), ops._ptr(fl.fl), ops._ptr(fl.deg), n, fl.g, fl.chunks, box, C.c_float(pot.sigma),
             C.c_float(pot.epsilon), C.c_float(pot.cutoff), ops._ptr(f3), None, ops._ptr(fl.ws))
 
     def timed(fn, count):

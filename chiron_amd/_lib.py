@@ -47,6 +47,7 @@ class LangevinParams(C.Structure):
         ("ctrl", C.c_void_p),
         ("ws", C.c_void_p),
         ("external_force", C.c_int32),
+        ("fl_chunks", C.c_int32),
     ]
 
 
@@ -80,7 +81,7 @@ SIGNATURES = {
     "chx_permute_unpack": (C.c_int, [_P, _I32, _P, _I32, _P, _P]),
     "chx_invert_perm": (C.c_int, [_P, _I32, _P, _P]),
     "chx_lj_ws_count": (_I64, [_I32]),
-    "chx_lj_fl_energy_force": (C.c_int, [_P, _P, _P, _I32, _I32, Box, _F, _F, _F, _P, _P, _P, _P]),
+    "chx_lj_fl_energy_force": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, Box, _F, _F, _F, _P, _P, _P, _P]),
     "chx_lj_allpairs_energy_force": (C.c_int, [_P, _I32, Box, _F, _F, _F, _P, _P, _P, _P]),
     "chx_init_velocities": (C.c_int, [_P, _P, _I32, _F, _U32, _U32, _P, _P]),
     "chx_kick": (C.c_int, [_P, _P, _P, _I32, _F, _P]),

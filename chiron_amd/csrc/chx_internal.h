@@ -7,7 +7,7 @@
 
 // ctrl != NULL: the kernel is part of a Langevin chunk and turns into a no-op
 // (setting ctrl[1]) when ctrl[0] says the skin check fired.
-int chx_launch_lj_fl(const float* x4, const uint32_t* fl, const int32_t* deg, int n, int g,
+int chx_launch_lj_fl(const float* x4, const uint32_t* fl, const int32_t* deg, int n, int g, int chunks,
                      chx_box_t box, float sigma, float epsilon, float cutoff, float* f3,
                      float* energy, double* ws, int32_t* ctrl, hipStream_t st);
 // n_steps fused [force + BAOAB] launches on the force list (k_lj_step); launch i reads

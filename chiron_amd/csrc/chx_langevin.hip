@@ -153,15 +153,15 @@ static int validate_langevin(const chx_langevin_t* p) {
   CHX_REQUIRE(!p->fl || p->deg, "force list without degrees");
   CHX_REQUIRE(!p->box.periodic || (p->box.lx > 0 && p->box.ly > 0 && p->box.lz > 0),
               "box lengths must be > 0");
-  CHX_REQUIRE(!(p->fl) || p->g >= 1, "bad g");
+  CHX_REQUIRE(!(p->fl) || (p->g >= 1 && p->fl_chunks >= 1), "bad g / fl_chunks");
   return CHX_OK;
 }
 
 static int launch_force(const chx_langevin_t* p, int32_t* ctrl, hipStream_t st) {
   if (p->external_force) return CHX_OK;
   if (p->fl) {
-    return chx_launch_lj_fl(p->x4, p->fl, p->deg, p->n, p->g, p->box, p->sigma, p->epsilon, p->cutoff,
-                            p->f, nullptr, p->ws, ctrl, st);
+    return chx_launch_lj_fl(p->x4, p->fl, p->deg, p->n, p->g, p->fl_chunks, p->box, p->sigma, p->epsilon,
+                            p->cutoff, p->f, nullptr, p->ws, ctrl, st);
   }
   // no neighbor list: reference semantics are the no-PBC all-pairs branch when no list was
   // given (box.periodic == 0) and the PBC pair list otherwise
@@ -214,6 +214,7 @@ extern "C" int chx_langevin_fused_chunk(const chx_langevin_t* p, float* x_even, 
   CHX_REQUIRE(p->n >= 1, "n < 1");
   CHX_REQUIRE(x_even && x_odd && x_even != x_odd, "need two distinct position buffers");
   CHX_REQUIRE(p->v && p->mass && p->ctrl && p->fl && p->deg, "null pointer");
+  CHX_REQUIRE(p->fl_chunks >= 1, "fl_chunks < 1");
   CHX_REQUIRE(!p->box.periodic || (p->box.lx > 0 && p->box.ly > 0 && p->box.lz > 0),
               "box lengths must be > 0");
   CHX_REQUIRE(n_steps >= 0, "n_steps < 0");

@@ -173,34 +173,60 @@ struct LJParams {
   float eps24;  // 24 eps
 };
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one).  Give every
+// XCD a contiguous range of logical blocks: particles are in cell order, so each private 4 MB L2
+// then caches one spatial slab of positions instead of all of them.  Bijective for any grid size;
+// placement is a speed matter only.
+__device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nb) {
+#ifdef CHX_NO_XCD_REMAP
+  return b;
+#else
+  const unsigned q = nb / 8u, r = nb % 8u, x = b % 8u, i = b / 8u;
+  return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + i;
+#endif
+}
+
 #define CHX_FL_INVALID 0xFFFFFFFFu
 #define CHX_FL_UNROLL 4
 
 // One particle's share of its force-list row: lane q of the G cooperating lanes walks
-// entries q, q+G, ...  Index loads, position gathers and arithmetic are issued in
-// batches of CHX_FL_UNROLL so the two dependent memory round trips (entry -> xyz)
-// overlap across entries instead of serialising per entry.
+// entries q, q+G, ...  Index loads, position gathers and arithmetic are issued in batches
+// of CHX_FL_UNROLL so the dependent round trips (entry -> xyz) overlap across entries.  The
+// first batch is requested together with the particle's own position and degree -- it is
+// bounded by the (uniform) number of chunks, not by the degree, and filtered afterwards;
+// slots past a row's end hold 0 (a valid index), so the speculative gathers are harmless.
 template <int G>
-__device__ __forceinline__ void lj_row(const float4* __restrict__ x4, const uint32_t* __restrict__ col,
-                                       size_t stride, int d, int q, const float4 xi, const Box3& box,
-                                       const LJParams& lj, float& fx, float& fy, float& fz, float& en) {
+__device__ __forceinline__ void lj_row(const float4* __restrict__ x4, const uint32_t* __restrict__ fl,
+                                       const int32_t* __restrict__ deg, int n, int chunks, int p, int q,
+                                       bool valid, const Box3& box, const LJParams& lj, float4& xi_out,
+                                       float& fx, float& fy, float& fz, float& en) {
+  const int pc = valid ? p : 0;
+  const size_t stride = (size_t)n * G;
+  const uint32_t* col = fl + (size_t)pc * G + q;
+  uint32_t ent[CHX_FL_UNROLL];
+  float4 xj[CHX_FL_UNROLL];
+  const float4 xi = x4[pc];
+  int d = deg[pc];
+#pragma unroll
+  for (int u = 0; u < CHX_FL_UNROLL; ++u) ent[u] = (u < chunks) ? col[(size_t)u * stride] : 0u;
+#pragma unroll
+  for (int u = 0; u < CHX_FL_UNROLL; ++u) xj[u] = x4[ent[u] & ~CHX_FL_HI];
+  d = valid ? d : 0;
+  xi_out = xi;
   const int nt = (d + G - 1) / G;
   for (int t0 = 0; t0 < nt; t0 += CHX_FL_UNROLL) {
-    uint32_t ent[CHX_FL_UNROLL];
-    float4 xj[CHX_FL_UNROLL];
+    if (t0 > 0) {
 #pragma unroll
-    for (int u = 0; u < CHX_FL_UNROLL; ++u) {
-      const int k = (t0 + u) * G + q;
-      ent[u] = (k < d) ? col[(size_t)(t0 + u) * stride] : CHX_FL_INVALID;
+      for (int u = 0; u < CHX_FL_UNROLL; ++u) {
+        const int k = (t0 + u) * G + q;
+        ent[u] = (k < d) ? col[(size_t)(t0 + u) * stride] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < CHX_FL_UNROLL; ++u) xj[u] = x4[ent[u] & ~CHX_FL_HI];
     }
 #pragma unroll
     for (int u = 0; u < CHX_FL_UNROLL; ++u) {
-      xj[u] = xi;
-      if (ent[u] != CHX_FL_INVALID) xj[u] = x4[ent[u] & ~CHX_FL_HI];
-    }
-#pragma unroll
-    for (int u = 0; u < CHX_FL_UNROLL; ++u) {
-      if (ent[u] == CHX_FL_INVALID) continue;
+      if ((t0 + u) * G + q >= d) continue;
       const bool hi = (ent[u] & CHX_FL_HI) != 0u;
       float rx, ry, rz;
       if (hi) {
@@ -225,22 +251,21 @@ __device__ __forceinline__ void lj_row(const float4* __restrict__ x4, const uint
 template <int G, bool WANT_F, bool WANT_E>
 __global__ __launch_bounds__(256) void k_lj_fl(const float4* __restrict__ x4,
                                                const uint32_t* __restrict__ fl,
-                                               const int32_t* __restrict__ deg, int n, Box3 box,
-                                               LJParams lj, float* __restrict__ f3,
+                                               const int32_t* __restrict__ deg, int n, int chunks,
+                                               Box3 box, LJParams lj, float* __restrict__ f3,
                                                double* __restrict__ ws, int32_t* ctrl) {
   if (ctrl != nullptr && ctrl[0] != 0) {  // skin check fired in this step's integrate kernel
     if (blockIdx.x == 0 && threadIdx.x == 0) ctrl[1] = 1;
     return;
   }
-  const int tid = blockIdx.x * 256 + threadIdx.x;
+  const unsigned blk = xcd_block(blockIdx.x, gridDim.x);
+  const int tid = blk * 256 + threadIdx.x;
   const int p = tid / G;
   const int q = tid % G;
   const bool valid = p < n;
-  const int d = valid ? deg[p] : 0;
-  float4 xi = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (valid) xi = x4[p];
+  float4 xi;
   float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
-  lj_row<G>(x4, fl + (size_t)p * G + q, (size_t)n * G, d, q, xi, box, lj, fx, fy, fz, en);
+  lj_row<G>(x4, fl, deg, n, chunks, p, q, valid, box, lj, xi, fx, fy, fz, en);
 #pragma unroll
   for (int o = G / 2; o > 0; o >>= 1) {
     if (WANT_F) {
@@ -259,7 +284,7 @@ __global__ __launch_bounds__(256) void k_lj_fl(const float4* __restrict__ x4,
     // every pair is visited from both ends
     double mine = (valid && q == 0) ? 0.5 * (double)en : 0.0;
     mine = block_sum<256>(mine);
-    if (threadIdx.x == 0) ws[blockIdx.x] = mine;
+    if (threadIdx.x == 0) ws[blk] = mine;
   }
 }
 
@@ -283,6 +308,7 @@ struct StepArgs {
   const uint32_t* perm;
   const uint32_t* fl;
   const int32_t* deg;
+  int chunks;
   Box3 box;
   LJParams lj;
   int wrap;
@@ -294,21 +320,61 @@ struct StepArgs {
   int32_t* ctrl;
 };
 
+// operands of one (particle, component) integrate task
+struct StepTask {
+  bool live;
+  int pp, c;
+  float m, v, x, ref, z;
+};
+
+__device__ __forceinline__ StepTask load_step_task(const StepArgs& a, long long step, int do_aoa, int p0,
+                                                   int task, int ntask) {
+  StepTask t;
+  const int pl = task / 3;
+  t.c = task - 3 * pl;
+  t.pp = p0 + pl;
+  t.live = task < ntask && t.pp < a.n;
+  t.m = 1.f;
+  t.v = t.x = t.ref = t.z = 0.f;
+  if (t.live) {
+    t.m = a.mass[t.pp];
+    t.v = a.v[3 * (size_t)t.pp + t.c];
+    if (do_aoa) {
+      t.x = reinterpret_cast<const float*>(a.x_cur)[4 * (size_t)t.pp + t.c];
+      if (a.ref4) t.ref = reinterpret_cast<const float*>(a.ref4)[4 * (size_t)t.pp + t.c];
+      const uint32_t o = a.perm ? a.perm[t.pp] : (uint32_t)t.pp;
+      if (a.noise) {
+        t.z = a.noise[((size_t)(step - a.noise_step0) * (size_t)a.n + o) * 3 + t.c];
+      } else {
+        t.z = philox_normal_c(o, (uint32_t)step, CHX_STREAM_LANGEVIN, a.k0, a.k1, t.c);
+      }
+    }
+  }
+  return t;
+}
+
 template <int G>
 __global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int n_kicks, int do_aoa) {
   constexpr int PPB = 256 / G;  // particles per block
-  __shared__ float sF[3 * PPB];
-  __shared__ float sS[3 * PPB];
+  constexpr int NTASK = 3 * PPB;
+  __shared__ float sF[NTASK];
+  __shared__ float sS[NTASK];
   if ((long long)a.ctrl[3] <= step) return;  // block-uniform
-  const int tid = blockIdx.x * 256 + threadIdx.x;
+  const unsigned blk = xcd_block(blockIdx.x, gridDim.x);
+  const int p0 = blk * PPB;
+  // ---- operands of this thread's integrate task, requested before the force loop so their
+  //      latency (and the Philox arithmetic) hides under it ----
+  StepTask tk[(NTASK + 255) / 256];
+#pragma unroll
+  for (int it = 0; it < (NTASK + 255) / 256; ++it) tk[it] = load_step_task(a, step, do_aoa, p0, it * 256 + threadIdx.x, NTASK);
+
+  const int tid = blk * 256 + threadIdx.x;
   const int p = tid / G;
   const int q = tid % G;
   const bool valid = p < a.n;
-  const int d = valid ? a.deg[p] : 0;
-  float4 xi = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (valid) xi = a.x_cur[p];
+  float4 xi;
   float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
-  lj_row<G>(a.x_cur, a.fl + (size_t)p * G + q, (size_t)a.n * G, d, q, xi, a.box, a.lj, fx, fy, fz, en);
+  lj_row<G>(a.x_cur, a.fl, a.deg, a.n, a.chunks, p, q, valid, a.box, a.lj, xi, fx, fy, fz, en);
 #pragma unroll
   for (int o = G / 2; o > 0; o >>= 1) {
     fx += __shfl_xor(fx, o, CHX_WAVE);
@@ -323,44 +389,32 @@ __global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int
   }
   __syncthreads();
   // ---- integrate: one (particle, Cartesian component) task per thread, all lanes busy ----
-  const int p0 = blockIdx.x * PPB;
-  for (int task0 = 0; task0 < 3 * PPB; task0 += 256) {
-    const int task = task0 + threadIdx.x;
-    const int pl = task / 3;
-    const int c = task - 3 * pl;
-    const int pp = p0 + pl;
-    const bool live = task < 3 * PPB && pp < a.n;
+#pragma unroll
+  for (int it = 0; it < (NTASK + 255) / 256; ++it) {
+    const int task = it * 256 + threadIdx.x;
+    const StepTask& t = tk[it];
     float sq = 0.f;
-    if (live) {
-      const float m = a.mass[pp];
+    if (t.live) {
       const float F = sF[task];
-      float vc = a.v[3 * (size_t)pp + c];
-      for (int k = 0; k < n_kicks; ++k) vc = fadd(vc, fdiv(fmul(a.hdt, F), m));  // B  :181 / :195
+      float vc = t.v;
+      for (int k = 0; k < n_kicks; ++k) vc = fadd(vc, fdiv(fmul(a.hdt, F), t.m));  // B  :181 / :195
       if (do_aoa) {
-        const float L = c == 0 ? a.box.lx : (c == 1 ? a.box.ly : a.box.lz);
-        float xc = reinterpret_cast<const float*>(a.x_cur)[4 * (size_t)pp + c];
-        xc = fadd(xc, fmul(a.hdt, vc));  // A  :183
-        const uint32_t o = a.perm ? a.perm[pp] : (uint32_t)pp;
-        float z;
-        if (a.noise) {
-          z = a.noise[((size_t)(step - a.noise_step0) * (size_t)a.n + o) * 3 + c];
-        } else {
-          z = philox_normal_c(o, (uint32_t)step, CHX_STREAM_LANGEVIN, a.k0, a.k1, c);
-        }
-        const float bs = fmul(a.b, fsqrt(fdiv(a.kT, m)));
-        vc = fadd(fmul(a.a, vc), fmul(bs, z));  // O  :186
-        xc = fadd(xc, fmul(a.hdt, vc));         // A  :188
+        const float L = t.c == 0 ? a.box.lx : (t.c == 1 ? a.box.ly : a.box.lz);
+        float xc = fadd(t.x, fmul(a.hdt, vc));  // A  :183
+        const float bs = fmul(a.b, fsqrt(fdiv(a.kT, t.m)));
+        vc = fadd(fmul(a.a, vc), fmul(bs, t.z));  // O  :186
+        xc = fadd(xc, fmul(a.hdt, vc));           // A  :188
         if (a.wrap && a.box.periodic) xc = wrap1(xc, L);  // :239
-        a.x_next[4 * (size_t)pp + c] = xc;
+        a.x_next[4 * (size_t)t.pp + t.c] = xc;
         if (a.ref4) {
-          float r = fsub(xc, reinterpret_cast<const float*>(a.ref4)[4 * (size_t)pp + c]);
+          float r = fsub(xc, t.ref);
           if (a.box.periodic) r = min_image(r, L, fmul(L, 0.5f));
           sq = fmul(r, r);
         }
       }
-      a.v[3 * (size_t)pp + c] = vc;
+      a.v[3 * (size_t)t.pp + t.c] = vc;
     }
-    if (task < 3 * PPB) sS[task] = sq;
+    if (task < NTASK) sS[task] = sq;
   }
   if (do_aoa && a.ref4) {  // skin check :241: (rx^2 + ry^2) + rz^2 in the reference's order
     __syncthreads();
@@ -373,19 +427,19 @@ __global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int
 }
 
 template <int G>
-static int launch_lj_fl_g(const float4* x4, const uint32_t* fl, const int32_t* deg, int n, Box3 box,
-                          LJParams lj, float* f3, float* energy, double* ws, int32_t* ctrl,
+static int launch_lj_fl_g(const float4* x4, const uint32_t* fl, const int32_t* deg, int n, int chunks,
+                          Box3 box, LJParams lj, float* f3, float* energy, double* ws, int32_t* ctrl,
                           hipStream_t st) {
   const unsigned blocks = (unsigned)(((int64_t)n * G + 255) / 256);
   if (f3 && energy) {
-    hipLaunchKernelGGL((k_lj_fl<G, true, true>), dim3(blocks), dim3(256), 0, st, x4, fl, deg, n, box,
-                       lj, f3, ws, ctrl);
+    hipLaunchKernelGGL((k_lj_fl<G, true, true>), dim3(blocks), dim3(256), 0, st, x4, fl, deg, n, chunks,
+                       box, lj, f3, ws, ctrl);
   } else if (f3) {
-    hipLaunchKernelGGL((k_lj_fl<G, true, false>), dim3(blocks), dim3(256), 0, st, x4, fl, deg, n, box,
-                       lj, f3, ws, ctrl);
+    hipLaunchKernelGGL((k_lj_fl<G, true, false>), dim3(blocks), dim3(256), 0, st, x4, fl, deg, n, chunks,
+                       box, lj, f3, ws, ctrl);
   } else {
-    hipLaunchKernelGGL((k_lj_fl<G, false, true>), dim3(blocks), dim3(256), 0, st, x4, fl, deg, n, box,
-                       lj, f3, ws, ctrl);
+    hipLaunchKernelGGL((k_lj_fl<G, false, true>), dim3(blocks), dim3(256), 0, st, x4, fl, deg, n, chunks,
+                       box, lj, f3, ws, ctrl);
   }
   if (energy) {
     hipLaunchKernelGGL(k_sum_ws, dim3(1), dim3(256), 0, st, ws, (int)blocks, energy);
@@ -402,20 +456,20 @@ static LJParams make_lj(float sigma, float epsilon, float cutoff) {
   return lj;
 }
 
-int chx_launch_lj_fl(const float* x4, const uint32_t* fl, const int32_t* deg, int n, int g,
+int chx_launch_lj_fl(const float* x4, const uint32_t* fl, const int32_t* deg, int n, int g, int chunks,
                      chx_box_t box, float sigma, float epsilon, float cutoff, float* f3,
                      float* energy, double* ws, int32_t* ctrl, hipStream_t st) {
   const float4* xx = reinterpret_cast<const float4*>(x4);
   const Box3 b3 = make_box3(box);
   const LJParams lj = make_lj(sigma, epsilon, cutoff);
   switch (g) {
-    case 1: return launch_lj_fl_g<1>(xx, fl, deg, n, b3, lj, f3, energy, ws, ctrl, st);
-    case 2: return launch_lj_fl_g<2>(xx, fl, deg, n, b3, lj, f3, energy, ws, ctrl, st);
-    case 4: return launch_lj_fl_g<4>(xx, fl, deg, n, b3, lj, f3, energy, ws, ctrl, st);
-    case 8: return launch_lj_fl_g<8>(xx, fl, deg, n, b3, lj, f3, energy, ws, ctrl, st);
-    case 16: return launch_lj_fl_g<16>(xx, fl, deg, n, b3, lj, f3, energy, ws, ctrl, st);
-    case 32: return launch_lj_fl_g<32>(xx, fl, deg, n, b3, lj, f3, energy, ws, ctrl, st);
-    case 64: return launch_lj_fl_g<64>(xx, fl, deg, n, b3, lj, f3, energy, ws, ctrl, st);
+    case 1: return launch_lj_fl_g<1>(xx, fl, deg, n, chunks, b3, lj, f3, energy, ws, ctrl, st);
+    case 2: return launch_lj_fl_g<2>(xx, fl, deg, n, chunks, b3, lj, f3, energy, ws, ctrl, st);
+    case 4: return launch_lj_fl_g<4>(xx, fl, deg, n, chunks, b3, lj, f3, energy, ws, ctrl, st);
+    case 8: return launch_lj_fl_g<8>(xx, fl, deg, n, chunks, b3, lj, f3, energy, ws, ctrl, st);
+    case 16: return launch_lj_fl_g<16>(xx, fl, deg, n, chunks, b3, lj, f3, energy, ws, ctrl, st);
+    case 32: return launch_lj_fl_g<32>(xx, fl, deg, n, chunks, b3, lj, f3, energy, ws, ctrl, st);
+    case 64: return launch_lj_fl_g<64>(xx, fl, deg, n, chunks, b3, lj, f3, energy, ws, ctrl, st);
   }
   chx_set_error("chx_launch_lj_fl: unsupported g = %d", g);
   return CHX_ERR_INVALID;
@@ -438,6 +492,7 @@ int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, in
   a.perm = p->perm;
   a.fl = p->fl;
   a.deg = p->deg;
+  a.chunks = p->fl_chunks;
   a.box = make_box3(p->box);
   a.lj = make_lj(p->sigma, p->epsilon, p->cutoff);
   a.wrap = p->wrap;
@@ -472,7 +527,7 @@ int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, in
 }
 
 extern "C" int chx_lj_fl_energy_force(const float* x4, const uint32_t* fl, const int32_t* deg,
-                                      int32_t n, int32_t g, chx_box_t box, float sigma,
+                                      int32_t n, int32_t g, int32_t chunks, chx_box_t box, float sigma,
                                       float epsilon, float cutoff, float* force3_out,
                                       float* energy_out, double* ws, chx_stream_t stream) {
   CHX_REQUIRE(n >= 0, "n < 0");
@@ -483,9 +538,10 @@ extern "C" int chx_lj_fl_energy_force(const float* x4, const uint32_t* fl, const
     return CHX_OK;
   }
   CHX_REQUIRE(x4 && fl && deg, "null pointer");
+  CHX_REQUIRE(chunks >= 1, "chunks < 1");
   CHX_REQUIRE(!box.periodic || (box.lx > 0 && box.ly > 0 && box.lz > 0), "box lengths must be > 0");
-  int rc = chx_launch_lj_fl(x4, fl, deg, n, g, box, sigma, epsilon, cutoff, force3_out, energy_out,
-                            ws, nullptr, chx_stream(stream));
+  int rc = chx_launch_lj_fl(x4, fl, deg, n, g, chunks, box, sigma, epsilon, cutoff, force3_out,
+                            energy_out, ws, nullptr, chx_stream(stream));
   if (rc != CHX_OK) return rc;
   return chx_check_launch("chx_lj_fl_energy_force");
 }

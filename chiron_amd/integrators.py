@@ -270,6 +270,7 @@ class _RunState:
         p = LangevinParams()
         p.n = n
         p.g = self.fl.g if self.fl is not None else 1
+        p.fl_chunks = self.fl.chunks if self.fl is not None else 0
         p.x4 = self.x_a.data_ptr()
         p.v = self.v.data_ptr()
         p.f = self.f.data_ptr() if self.f is not None else None
@@ -313,10 +314,19 @@ class _RunState:
 
     def _rebuild(self):
         """The host half of chiron/integrators.py:241-242 once the device check has fired."""
+        import os, time
+
+        prof = os.environ.get("CHX_PROFILE_REBUILD") == "1"
+        if prof:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
         x_user, v_user = self.positions_user(), self.velocities_user()
         self.nbr_list.build(x_user, self.nbr_list.box_vectors)
         self._load(x_user, v_user)
         self.n_rebuilds += 1
+        if prof:
+            torch.cuda.synchronize()
+            self.integ.rebuild_seconds = getattr(self.integ, "rebuild_seconds", 0.0) + time.perf_counter() - t0
 
     # -- fused neighbor-list path -------------------------------------------
     def _enqueue_fused(self, s0: int, n: int, do_aoa: int = 1) -> _Pending:

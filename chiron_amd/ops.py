@@ -203,16 +203,16 @@ def _choose_g(maxdeg: int, n: int) -> int:
     """Lanes that cooperate on one particle in the list kernel.
 
     Measured on MI355X (scripts/kernel_bench.py): the kernel wants >= ~5e5 lanes in flight to
-    fill 256 CUs, as few lanes per particle as that allows (less reduction / idle-lane overhead),
-    and no more than ~40 sequential entries per lane.
+    fill 256 CUs (>= 2.6e5 lanes), as few lanes per particle as that allows (less reduction and
+    idle-lane overhead), and no more than ~24 sequential entries per lane.
     """
     env = os.environ.get("CHX_FL_G")
     if env:
         return int(env)
-    g = 1
-    while g < 64 and n * g < (1 << 19):
+    g = 4  # the fused step kernel wants <= 256 (particle, component) tasks per 256-thread block
+    while g < 64 and n * g < (1 << 18):
         g *= 2
-    while g < 64 and maxdeg > 40 * g:
+    while g < 64 and maxdeg > 24 * g:
         g *= 2
     while g > 1 and g > max(1, maxdeg):
         g //= 2
@@ -239,7 +239,8 @@ class ForceList:
         self.maxdeg = int(maxdeg_t.item())  # build-time sync (the reference syncs here too, neighbors.py:709)
         self.g = _choose_g(self.maxdeg, n)
         chunks = max(1, -(-self.maxdeg // self.g))
-        self.fl = torch.zeros((chunks, n, self.g), dtype=torch.int32, device=dev)
+        self.chunks = chunks
+        self.fl = torch.zeros((chunks, n, self.g), dtype=torch.int32, device=dev)  # zero = a valid index
         cursor = torch.empty((n,), dtype=torch.int32, device=dev)
         check(lib.chx_fl_fill(_ptr(nl), _ptr(n_nbr), n, m, _ptr(self.inv), self.g, _ptr(cursor), _ptr(self.fl), _stream()), "chx_fl_fill")
         rc = lib.chx_fl_sort(_ptr(self.fl), _ptr(self.deg), n, self.g, self.maxdeg, _stream())
@@ -272,7 +273,7 @@ class ForceList:
         e = torch.empty((1,), dtype=torch.float32, device=dev) if want_energy else None
         check(
             _lib.load().chx_lj_fl_energy_force(
-                _ptr(x4), _ptr(self.fl), _ptr(self.deg), self.n, self.g, box, C.c_float(sigma),
+                _ptr(x4), _ptr(self.fl), _ptr(self.deg), self.n, self.g, self.chunks, box, C.c_float(sigma),
                 C.c_float(epsilon), C.c_float(cutoff), _ptr(f3), _ptr(e), _ptr(self.ws), _stream(),
             ),
             "chx_lj_fl_energy_force",

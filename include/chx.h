@@ -144,10 +144,12 @@ int chx_invert_perm(const uint32_t* perm, int32_t n, uint32_t* inv_out, chx_stre
  * (chiron/potential.py:193-213, :260-279), F = -dE/dx (chiron/potential.py:21-24,
  * closed form :322-332).  x4 is (n,4) in internal order; force3_out (n,3) in
  * internal order (NULL = energy only); energy_out[1] (NULL = force only);
- * ws: >= chx_lj_ws_count(n) doubles. */
+ * chunks = allocated chunks of fl (fl holds chunks*n*g entries, slots past a row's
+ * end must hold a valid index, e.g. 0: the kernel loads the first entries of every
+ * row before it knows the row's length); ws: >= chx_lj_ws_count(n) doubles. */
 int64_t chx_lj_ws_count(int32_t n);
 int chx_lj_fl_energy_force(const float* x4, const uint32_t* fl, const int32_t* deg, int32_t n,
-                           int32_t g, chx_box_t box, float sigma, float epsilon, float cutoff,
+                           int32_t g, int32_t chunks, chx_box_t box, float sigma, float epsilon, float cutoff,
                            float* force3_out, float* energy_out, double* ws, chx_stream_t stream);
 
 /* All-pairs kernel: the nbr_list=None branch (no PBC, chiron/potential.py:26-63,
@@ -191,6 +193,7 @@ typedef struct {
   double* ws;            /* energy workspace, >= chx_lj_ws_count(n) */
   int32_t external_force; /* != 0: do not launch the LJ force kernel (the caller fills f
                              between single-step chunks: IdealGasPotential and other potentials) */
+  int32_t fl_chunks;      /* allocated chunks of the force list: fl holds fl_chunks * n * g entries */
 } chx_langevin_t;
 
 /* Enqueue n_steps BAOAB steps (chiron/integrators.py:179-195) starting at global

@@ -40,7 +40,7 @@ for wl in sys.argv[1:] or ["c3", "c4"]:
         lib = _lib.load()
         f3 = torch.empty((n, 3), dtype=torch.float32, device="cuda")
         box = nbr._box_h
-        t_f = ev_time(lambda: lib.chx_lj_fl_energy_force(ops._ptr(x4), ops._ptr(fl.fl), ops._ptr(fl.deg), n, fl.g, box,
+        t_f = ev_time(lambda: lib.chx_lj_fl_energy_force(ops._ptr(x4), ops._ptr(fl.fl), ops._ptr(fl.deg), n, fl.g, fl.chunks, box,
                                                          C.c_float(pot.sigma), C.c_float(pot.epsilon), C.c_float(pot.cutoff),
                                                          ops._ptr(f3), None, ops._ptr(fl.ws), ops._stream()))
         # fused step kernel (skin check can never fire: huge skin)

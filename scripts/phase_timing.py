@@ -28,7 +28,8 @@ for wl in sys.argv[1:] or ["c3", "c4"]:
     t("run 1 step", lambda: integ.run(state, thermo, number_of_steps=1, nbr_list=nbr))
     t("run 1 step again", lambda: integ.run(state, thermo, number_of_steps=1, nbr_list=nbr))
     out = t("run 200 steps", lambda: integ.run(state, thermo, number_of_steps=200, nbr_list=nbr))
-    print("   rebuilds:", integ.n_rebuilds)
+    print("   rebuilds:", integ.n_rebuilds, "rebuild wall ms:", 1e3 * getattr(integ, "rebuild_seconds", 0.0))
+    integ.rebuild_seconds = 0.0
     st2 = out[0]
     out = t("run 1000 steps (continued)", lambda: integ.run(st2, thermo, number_of_steps=1000, nbr_list=nbr))
-    print("   rebuilds:", integ.n_rebuilds)
+    print("   rebuilds:", integ.n_rebuilds, "rebuild wall ms:", 1e3 * getattr(integ, "rebuild_seconds", 0.0))
