@@ -204,6 +204,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs the MI355X: no CUDA/ROCm device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
+    # The host side of this path only launches kernels.  torch's intra-op CPU pool (one thread per
+    # visible core) must not wake up inside a CPU-quota'd container: the burst gets the whole
+    # process throttled for tens of milliseconds (seen as 40-70 ms holes in the launch stream).
+    torch.set_num_threads(1)
     import torch.distributed as dist
 
     # under torchrun (RANK set) the process group is always created, also for one rank, so that the
@@ -311,6 +315,7 @@ def main():
                 integ4.run(state4, thermo4, number_of_steps=1000, nbr_list=nbr4)
                 torch.cuda.synchronize()
                 out["steps_per_s_262k"] = round(1000 / (time.perf_counter() - t0), 2)
+                out["rebuilds_262k"] = integ4.n_rebuilds
                 del fluid4, pot4, state4, nbr4
             except Exception as exc:  # pragma: no cover - diagnostics only
                 out["roofline_262k"] = {"error": repr(exc)}

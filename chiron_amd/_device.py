@@ -2,6 +2,11 @@
 
 PyTorch-ROCm is used only for device memory, streams and ``torch.distributed``;
 every number on the hot path is produced by the HIP kernels in ``csrc/``.
+
+Host-side conversions are done with NumPy on purpose: a ``torch`` CPU op on a few
+hundred thousand elements wakes torch's whole intra-op thread pool (one thread per
+visible core), and in a CPU-quota'd container that burst gets the process throttled
+by the scheduler for tens of milliseconds -- long enough to starve the launch loop.
 """
 from __future__ import annotations
 
@@ -11,6 +16,15 @@ import numpy as np
 import torch
 
 _FORCED_DEVICE: Optional[torch.device] = None
+
+_NP_DTYPE = {
+    torch.float32: np.float32,
+    torch.float64: np.float64,
+    torch.int32: np.int32,
+    torch.int64: np.int64,
+    torch.uint8: np.uint8,
+    torch.bool: np.bool_,
+}
 
 
 def default_device() -> torch.device:
@@ -32,10 +46,11 @@ def as_tensor(x: Any, dtype=torch.float32, device=None) -> torch.Tensor:
     if device is None:
         device = x.device if isinstance(x, torch.Tensor) and _FORCED_DEVICE is None and x.is_cuda else default_device()
     if isinstance(x, torch.Tensor):
-        t = x.to(device=device, dtype=dtype)
-    else:
-        t = torch.as_tensor(np.asarray(x), dtype=dtype).to(device)
-    return t.contiguous()
+        if x.is_cuda or x.dtype == dtype or dtype not in _NP_DTYPE:
+            return x.to(device=device, dtype=dtype).contiguous()
+        x = x.detach().numpy()
+    arr = np.ascontiguousarray(np.asarray(x), dtype=_NP_DTYPE.get(dtype))
+    return torch.from_numpy(arr).to(device).contiguous()
 
 
 def is_array(x: Any) -> bool:

@@ -70,6 +70,12 @@ SIGNATURES = {
         C.c_int,
         [_P, _I32, _I32, Box, _F, C.POINTER(_I32), _P, _P, _P, _P, _P, _P, _P, _P, _P],
     ),
+    "chx_nl_build_cell_fl": (
+        C.c_int,
+        [_P, _I32, _I32, Box, _F, C.POINTER(_I32), _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P],
+    ),
+    "chx_nl_finish_padding": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),
+    "chx_pack_langevin": (C.c_int, [_P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P]),
     "chx_nl_calculate": (C.c_int, [_P, _P, _P, _I32, _I32, Box, _F, _P, _P, _P, _P, _P]),
     "chx_nl_check": (C.c_int, [_P, _P, _I32, Box, _F, _P, _P]),
     "chx_pl_build": (C.c_int, [_I32, _P, _P, _P]),
@@ -88,6 +94,8 @@ SIGNATURES = {
     "chx_langevin_chunk": (C.c_int, [C.POINTER(LangevinParams), _I64, _I32, _I32, _P]),
     "chx_langevin_resume": (C.c_int, [C.POINTER(LangevinParams), _P]),
     "chx_langevin_fused_chunk": (C.c_int, [C.POINTER(LangevinParams), _P, _P, _I64, _I32, _I32, _I32, _P]),
+    "chx_ctrl_reset": (C.c_int, [_P, _P]),
+    "chx_publish": (C.c_int, [_P, _P, _I32, _P]),
     "chx_mc_displace": (C.c_int, [_P, _P, _P, _I32, _F, Box, _U32, _U32, _U32, _P, _P]),
     "chx_scale": (C.c_int, [_P, _P, _I64, _F, _P]),
     "chx_metropolis_select": (

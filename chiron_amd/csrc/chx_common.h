@@ -68,8 +68,19 @@ __device__ __forceinline__ float mod_floor(float t, float L) {
 }
 
 // chiron/neighbors.py:79: mod(r + L/2, L) - L/2
+// Same value, bit for bit, for every input; the common case -L < t < 2L (always true for
+// wrapped coordinates) takes two compares and one add/sub instead of the general fmod path.
 __device__ __forceinline__ float min_image(float d, float L, float hL) {
-  return fsub(mod_floor(fadd(d, hL), L), hL);
+  const float t = fadd(d, hL);
+  float m;
+  if (__builtin_expect(!(t > -L && t < fmul(2.0f, L)), 0)) {
+    m = mod_floor(t, L);
+  } else {
+    m = t;
+    if (t >= L) m = fsub(t, L);  // fmod(t, L), exact by Sterbenz
+    if (t < 0.0f) m = fadd(t, L);  // fmod(t, L) = t, then the sign fix-up of jnp.mod
+  }
+  return fsub(m, hL);
 }
 
 // displacement r = a - b under the space's boundary conditions
@@ -78,6 +89,23 @@ __device__ __forceinline__ void displacement(const Box3& box, float ax, float ay
   rx = fsub(ax, bx);
   ry = fsub(ay, by);
   rz = fsub(az, bz);
+  if (box.periodic) {
+    rx = min_image(rx, box.lx, box.hx);
+    ry = min_image(ry, box.ly, box.hy);
+    rz = min_image(rz, box.lz, box.hz);
+  }
+}
+
+// r = (forward ? a - b : b - a) under the boundary conditions.  b - a is exactly -(a - b) in
+// IEEE arithmetic, so one subtraction plus a sign flip serves both orientations and the
+// (not antisymmetric) minimum-image rounding is applied once, to the correctly oriented value.
+__device__ __forceinline__ void displacement_oriented(const Box3& box, bool forward, float ax, float ay,
+                                                      float az, float bx, float by, float bz, float& rx,
+                                                      float& ry, float& rz) {
+  const uint32_t flip = forward ? 0u : 0x80000000u;
+  rx = __uint_as_float(__float_as_uint(fsub(ax, bx)) ^ flip);
+  ry = __uint_as_float(__float_as_uint(fsub(ay, by)) ^ flip);
+  rz = __uint_as_float(__float_as_uint(fsub(az, bz)) ^ flip);
   if (box.periodic) {
     rx = min_image(rx, box.lx, box.hx);
     ry = min_image(ry, box.ly, box.hy);

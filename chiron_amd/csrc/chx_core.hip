@@ -175,3 +175,32 @@ extern "C" int chx_scale(const float* in, float* out, int64_t count, float s, ch
                      count, s);
   return chx_check_launch("chx_scale");
 }
+
+// ---------------------------------------------------------------------------
+// control-block plumbing of the Langevin loop.  Both are ordinary kernels on the caller's
+// stream, so the hot loop never touches the runtime's copy engines / blit queues.
+// ---------------------------------------------------------------------------
+__global__ void k_ctrl_reset(int32_t* __restrict__ ctrl) {
+  if (threadIdx.x < 4) ctrl[threadIdx.x] = threadIdx.x == 3 ? 0x7FFFFFFF : 0;
+}
+
+extern "C" int chx_ctrl_reset(int32_t* ctrl, chx_stream_t stream) {
+  CHX_REQUIRE(ctrl, "null pointer");
+  hipLaunchKernelGGL(k_ctrl_reset, dim3(1), dim3(64), 0, chx_stream(stream), ctrl);
+  return chx_check_launch("chx_ctrl_reset");
+}
+
+// copy n <= 64 ints to host-mapped pinned memory with system-scope visibility
+__global__ void k_publish(const int32_t* __restrict__ src, int32_t* __restrict__ host_dst, int n) {
+  if ((int)threadIdx.x < n) {
+    __hip_atomic_store(&host_dst[threadIdx.x], src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __threadfence_system();
+}
+
+extern "C" int chx_publish(const int32_t* src, int32_t* host_mapped_dst, int32_t n, chx_stream_t stream) {
+  CHX_REQUIRE(src && host_mapped_dst, "null pointer");
+  CHX_REQUIRE(n >= 1 && n <= 64, "n must be in 1..64");
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, chx_stream(stream), src, host_mapped_dst, n);
+  return chx_check_launch("chx_publish");
+}

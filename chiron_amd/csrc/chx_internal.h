@@ -5,6 +5,17 @@
 
 #include "../../include/chx.h"
 
+struct CellGrid {
+  int ncx, ncy, ncz;
+  float sx, sy, sz;  // nc / L
+};
+
+// Bin particles into cells (chx_neighbors.hip): cell_of, cell_start, sorted_ids; zeroes status.
+int chx_cell_prepare(const float* xyz, int n, chx_box_t box, float cutoff_plus_skin,
+                     const int32_t* nc_h, int32_t* cell_of, int32_t* cell_count, int32_t* cell_start,
+                     uint32_t* sorted_ids, int32_t* status, int status_len, CellGrid* g_out,
+                     hipStream_t st);
+
 // ctrl != NULL: the kernel is part of a Langevin chunk and turns into a no-op
 // (setting ctrl[1]) when ctrl[0] says the skin check fired.
 int chx_launch_lj_fl(const float* x4, const uint32_t* fl, const int32_t* deg, int n, int g, int chunks,

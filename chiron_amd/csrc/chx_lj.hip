@@ -229,11 +229,7 @@ __device__ __forceinline__ void lj_row(const float4* __restrict__ x4, const uint
       if ((t0 + u) * G + q >= d) continue;
       const bool hi = (ent[u] & CHX_FL_HI) != 0u;
       float rx, ry, rz;
-      if (hi) {
-        displacement(box, xi.x, xi.y, xi.z, xj[u].x, xj[u].y, xj[u].z, rx, ry, rz);
-      } else {
-        displacement(box, xj[u].x, xj[u].y, xj[u].z, xi.x, xi.y, xi.z, rx, ry, rz);
-      }
+      displacement_oriented(box, hi, xi.x, xi.y, xi.z, xj[u].x, xj[u].y, xj[u].z, rx, ry, rz);
       const float r2 = norm2(rx, ry, rz);
       if (r2 <= lj.T) {
         float e, fs;
@@ -590,11 +586,7 @@ __global__ __launch_bounds__(256) void k_lj_allpairs(const float* __restrict__ x
         const float4 xj = tile[u];
         const bool hi = j > i;
         float rx, ry, rz;
-        if (hi) {
-          displacement(box, xi, yi, zi, xj.x, xj.y, xj.z, rx, ry, rz);
-        } else {
-          displacement(box, xj.x, xj.y, xj.z, xi, yi, zi, rx, ry, rz);
-        }
+        displacement_oriented(box, hi, xi, yi, zi, xj.x, xj.y, xj.z, rx, ry, rz);
         const float r2 = norm2(rx, ry, rz);
         if (!use_cutoff || r2 <= lj.T) {
           float e, fs;

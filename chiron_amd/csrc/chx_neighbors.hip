@@ -8,6 +8,7 @@
 #include <math.h>
 
 #include "chx_common.h"
+#include "chx_internal.h"
 
 // ---------------------------------------------------------------------------
 // shared row epilogue: padding (chiron/neighbors.py:603-620) and mask (:623)
@@ -104,11 +105,6 @@ extern "C" int64_t chx_cell_grid_h(chx_box_t box, float cs, int32_t n, int32_t* 
   }
   return total;
 }
-
-struct CellGrid {
-  int ncx, ncy, ncz;
-  float sx, sy, sz;  // nc / L
-};
 
 __device__ __forceinline__ int cell_coord(float x, float L, float s, int nc) {
   float w = wrap1(x, L);
@@ -266,15 +262,12 @@ __global__ __launch_bounds__(256) void k_nl_build_cell(
   if (lane == 0) n_nbr[i] = count;
 }
 
-extern "C" int chx_nl_build_cell(const float* xyz, int32_t n, int32_t m, chx_box_t box,
-                                 float cutoff_plus_skin, const int32_t* nc_h, int32_t* cell_of,
-                                 int32_t* cell_count, int32_t* cell_start, uint32_t* sorted_ids,
-                                 int32_t* status, uint32_t* nl_out, int32_t* nl_mask_out,
-                                 int32_t* n_nbr_out, chx_stream_t stream) {
-  CHX_REQUIRE(n >= 1 && m >= 1, "need n >= 1, m >= 1");
-  CHX_REQUIRE(xyz && nc_h && cell_of && cell_count && cell_start && sorted_ids && status &&
-                  nl_out && nl_mask_out && n_nbr_out,
-              "null pointer");
+// Bin the particles: cell_of, cell_start (exclusive scan) and sorted_ids (cell order, ascending id
+// inside a cell).  Shared by both cell-list builders.  status[0..7] is zeroed.
+int chx_cell_prepare(const float* xyz, int n, chx_box_t box, float cutoff_plus_skin,
+                     const int32_t* nc_h, int32_t* cell_of, int32_t* cell_count, int32_t* cell_start,
+                     uint32_t* sorted_ids, int32_t* status, int status_len, CellGrid* g_out,
+                     hipStream_t st) {
   CHX_REQUIRE(box.periodic && box.lx > 0 && box.ly > 0 && box.lz > 0, "periodic box required");
   CHX_REQUIRE(nc_h[0] >= 3 && nc_h[1] >= 3 && nc_h[2] >= 3, "need >= 3 cells per axis");
   const int64_t ncell64 = (int64_t)nc_h[0] * nc_h[1] * nc_h[2];
@@ -284,15 +277,14 @@ extern "C" int chx_nl_build_cell(const float* xyz, int32_t n, int32_t m, chx_box
                   box.lz / nc_h[2] >= cutoff_plus_skin,
               "cell edge smaller than cutoff + skin");
   const int ncell = (int)ncell64;
-  hipStream_t st = chx_stream(stream);
   const Box3 b3 = make_box3(box);
   CellGrid g;
   g.ncx = nc_h[0]; g.ncy = nc_h[1]; g.ncz = nc_h[2];
   g.sx = (float)nc_h[0] / box.lx; g.sy = (float)nc_h[1] / box.ly; g.sz = (float)nc_h[2] / box.lz;
-  const float T = chx_cutoff_threshold_h(cutoff_plus_skin);
+  *g_out = g;
   if (hipMemsetAsync(cell_count, 0, sizeof(int32_t) * ((size_t)ncell + 1), st) != hipSuccess ||
-      hipMemsetAsync(status, 0, sizeof(int32_t) * 4, st) != hipSuccess) {
-    chx_set_error("chx_nl_build_cell: hipMemsetAsync failed");
+      hipMemsetAsync(status, 0, sizeof(int32_t) * status_len, st) != hipSuccess) {
+    chx_set_error("chx_cell_prepare: hipMemsetAsync failed");
     return CHX_ERR_LAUNCH;
   }
   const unsigned pb = (unsigned)((n + 255) / 256);
@@ -302,6 +294,25 @@ extern "C" int chx_nl_build_cell(const float* xyz, int32_t n, int32_t m, chx_box
                      sorted_ids);
   hipLaunchKernelGGL(k_cell_sort, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, cell_start,
                      ncell, sorted_ids);
+  return CHX_OK;
+}
+
+extern "C" int chx_nl_build_cell(const float* xyz, int32_t n, int32_t m, chx_box_t box,
+                                 float cutoff_plus_skin, const int32_t* nc_h, int32_t* cell_of,
+                                 int32_t* cell_count, int32_t* cell_start, uint32_t* sorted_ids,
+                                 int32_t* status, uint32_t* nl_out, int32_t* nl_mask_out,
+                                 int32_t* n_nbr_out, chx_stream_t stream) {
+  CHX_REQUIRE(n >= 1 && m >= 1, "need n >= 1, m >= 1");
+  CHX_REQUIRE(xyz && nc_h && cell_of && cell_count && cell_start && sorted_ids && status &&
+                  nl_out && nl_mask_out && n_nbr_out,
+              "null pointer");
+  hipStream_t st = chx_stream(stream);
+  CellGrid g;
+  int rc = chx_cell_prepare(xyz, n, box, cutoff_plus_skin, nc_h, cell_of, cell_count, cell_start,
+                            sorted_ids, status, 4, &g, st);
+  if (rc != CHX_OK) return rc;
+  const Box3 b3 = make_box3(box);
+  const float T = chx_cutoff_threshold_h(cutoff_plus_skin);
   const unsigned wb = (unsigned)(((int64_t)n * CHX_WAVE + 255) / 256);
   hipLaunchKernelGGL(k_nl_build_cell, dim3(wb), dim3(256), 0, st, xyz, n, m, b3, T, g, cell_of,
                      cell_start, sorted_ids, nl_out, nl_mask_out, n_nbr_out, status);

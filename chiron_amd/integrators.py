@@ -31,6 +31,7 @@ from .states import SamplerState, ThermodynamicState
 log = logging.getLogger("chiron_amd")
 
 _INT_MAX = 2**31 - 1
+_TRACE_RUN = __import__("os").environ.get("CHX_TRACE_RUN") == "1"
 
 
 def langevin_constants(timestep, collision_rate):
@@ -223,6 +224,7 @@ class _RunState:
             raise ValueError(f"noise must have shape (steps, {self.n}, 3), got {tuple(self.noise.shape)}")
         self.mass_user = mass
         self.ctrl = torch.zeros((4,), dtype=torch.int32, device=self.dev)
+        self._ctrl_init = torch.tensor([0, 0, 0, _INT_MAX], dtype=torch.int32, device=self.dev)
         self.ws = torch.empty((int(ops._lib.load().chx_lj_ws_count(self.n)),), dtype=torch.float64, device=self.dev)
         self.is_verlet = isinstance(nbr_list, NeighborListNsqrd)
         self.is_pairlist = isinstance(nbr_list, PairListNsqrd)
@@ -250,13 +252,12 @@ class _RunState:
         perm = self.fl.perm if self.fl is not None else None
         self.perm = perm
         n = self.n
-        self.x_a = self._pack(x_user, 4, perm)  # current positions live here when parity == 0
-        self.x_b = torch.zeros_like(self.x_a) if self.mode == "fused" else None
+        # one launch: positions (current buffer when parity == 0), velocities, masses, reference positions
+        self.x_a, self.v, self.mass, self.ref4 = ops.pack_langevin(
+            x_user, v_user, self.mass_user, self.nbr_list.ref_positions if self.is_verlet else None, perm, self.is_verlet)
+        self.x_b = torch.empty_like(self.x_a) if self.mode == "fused" else None  # fully written before it is read
         self.parity = 0
-        self.v = self._pack(v_user, 3, perm)
-        self.mass = self.mass_user if perm is None else self.mass_user[perm.long()].contiguous()
         self.f = torch.zeros((n, 3), dtype=torch.float32, device=self.dev) if self.mode != "fused" else None
-        self.ref4 = self._pack(self.nbr_list.ref_positions, 4, perm) if self.is_verlet else None
         box = Box(0, 0.0, 0.0, 0.0)
         wrap = 0
         skin = 0.0
@@ -265,8 +266,7 @@ class _RunState:
             wrap = 1
             if self.is_verlet:
                 skin = float(self.nbr_list.skin.value_in_unit_system(unit.md_unit_system))
-        self.ctrl.zero_()
-        self.ctrl[3] = _INT_MAX
+        ops.ctrl_reset(self.ctrl)
         p = LangevinParams()
         p.n = n
         p.g = self.fl.g if self.fl is not None else 1
@@ -337,8 +337,16 @@ class _RunState:
         if do_aoa:
             self.parity ^= n & 1
             self.kicks_next = 2
-        rec.host = torch.empty((4,), dtype=torch.int32, pin_memory=True)
-        rec.host.copy_(self.ctrl, non_blocking=True)
+        # pinned read-back slots are allocated once per integrator (pinning memory can take milliseconds);
+        # a slot is reused only after the chunk that owned it has been waited for
+        ring = getattr(self.integ, "_pinned_ring", None)
+        if ring is None or len(ring) < self.depth + 2:
+            ring = self.integ._pinned_ring = [torch.empty((4,), dtype=torch.int32, pin_memory=True)
+                                              for _ in range(self.depth + 2)]
+            self.integ._ring_next = 0
+        rec.host = ring[self.integ._ring_next % len(ring)]
+        self.integ._ring_next += 1
+        ops.publish(self.ctrl, rec.host, 4)  # a kernel on this stream: no copy engine / blit queue in the loop
         rec.event = torch.cuda.Event()
         rec.event.record()
         return rec
@@ -353,7 +361,17 @@ class _RunState:
                 pending.append(self._enqueue_fused(nxt, c))
                 nxt += c
             rec = pending.popleft()
-            rec.event.synchronize()
+            if _TRACE_RUN:
+                import time as _t
+
+                t_w = _t.perf_counter()
+                rec.event.synchronize()
+                t_w = _t.perf_counter() - t_w
+                if t_w > 5e-3:
+                    print(f"[chx trace] waited {1e3*t_w:.1f} ms for chunk s0={rec.s0} n={rec.n} halt={int(rec.host[3])} "
+                          f"pending={len(pending)}", flush=True)
+            else:
+                rec.event.synchronize()
             halt = int(rec.host[3])
             if halt <= rec.s0 + rec.n:
                 # skin check fired while producing x_halt: steps < halt ran, everything queued behind is a no-op

@@ -11,6 +11,7 @@ All arithmetic runs in the HIP kernels of ``csrc/chx_neighbors.hip``.
 from __future__ import annotations
 
 import logging
+import os
 from abc import ABC, abstractmethod
 from typing import Optional, Tuple, Union
 
@@ -22,6 +23,7 @@ from ._device import as_tensor, is_array
 from .states import SamplerState
 
 log = logging.getLogger("chiron_amd")
+_DEBUG_BUILD = os.environ.get("CHX_DEBUG_BUILD") == "1"
 
 
 # ---------------------------------------------------------------------------
@@ -170,6 +172,7 @@ class NeighborListNsqrd(PairsBase):
         self.space = space
         self.is_built = False
         self._force_list = None
+        self._nl = self._nl_mask = self._first = None
         self.n_builds = 0
 
     @property
@@ -197,18 +200,52 @@ class NeighborListNsqrd(PairsBase):
         self.is_built = False  # chiron/neighbors.py:502
 
     # -- build -------------------------------------------------------------
-    def _build_pass(self, m: int):
-        """One fixed-width pass; returns (nl, mask, n_nbr, perm or None)."""
+    def _fl_geometry(self, n: int):
+        """(lanes per particle, chunks) of the force list the one-pass cell build writes into."""
+        geo = getattr(self, "_fl_geo", None)
+        if geo is not None and geo[0] == n:
+            # sticky: identical tensor sizes from rebuild to rebuild let the caching allocator hand the
+            # same blocks back (a changed size costs a hipMalloc, i.e. milliseconds of idle GPU)
+            return geo[1], geo[2]
+        # first build: expected number of neighbors inside cutoff+skin; capacity with head-room
+        b = self._box_h
+        rho = n / (b.lx * b.ly * b.lz)
+        expected = rho * 4.18879 * self._cutoff_and_skin ** 3
+        g = ops._choose_g(int(1.2 * expected) + 4, n)
+        chunks = max(1, -(-(int(1.6 * expected) + 24) // g))
+        self._fl_geo = (n, g, chunks)
+        return g, chunks
+
+    def _build_pass(self, m: int) -> dict:
+        """One fixed-width pass.  Returns the arrays plus ``max_n`` (largest row count) and ``n_eq``
+        (rows holding exactly m entries, the reference's growth trigger) from ONE host read-back."""
         cs = self._cutoff_and_skin
+        n = self.ref_positions.shape[0]
         if self._use_cell_list and self._box_h.periodic:
-            ncell, nc = ops.cell_grid(self._box_h, cs, self.ref_positions.shape[0])
+            ncell, nc = ops.cell_grid(self._box_h, cs, n)
             if ncell > 0:
-                nl, mask, n_nbr, sorted_ids, status = ops.nl_build_cell(self.ref_positions, self._box_h, cs, m, ncell, nc)
-                if int(status[0].item()) == 0:
-                    return nl, mask, n_nbr, sorted_ids
-                log.debug("cell build overflowed its on-chip candidate buffer; using the O(N^2) kernel")
+                g, chunks = self._fl_geometry(n)
+                for _ in range(4):
+                    nl, first, n_nbr, sorted_ids, fl, deg, status = ops.nl_build_cell_fl(
+                        self.ref_positions, self._box_h, cs, m, ncell, nc, g, chunks)
+                    st = status.cpu().tolist()  # the build's only host sync (the reference syncs at :709)
+                    if _DEBUG_BUILD:
+                        print(f"[chx build] n={n} m={m} g={g} chunks={chunks} status={st}", flush=True)
+                    if st[0]:
+                        log.debug("cell build overflowed its on-chip candidate buffer; using the O(N^2) kernel")
+                        break
+                    if st[4] > 0:  # some force-list row did not fit: grow the (sticky) capacity
+                        g = ops._choose_g(st[3], n)
+                        chunks = max(-(-st[3] // g) + 2, -(-(3 * chunks * g // 2) // g))
+                        self._fl_geo = (n, g, chunks)
+                        continue
+                    self._last_maxdeg = st[3]
+                    force_list = ops.ForceList.prebuilt(fl, deg, sorted_ids, g, chunks, st[3])
+                    return dict(nl=nl, first=first, mask=None, n_nbr=n_nbr, perm=sorted_ids, fl=force_list,
+                                max_n=st[1], n_eq=st[2])
         nl, mask, n_nbr = ops.nl_build_nsq(self.ref_positions, self._box_h, cs, m)
-        return nl, mask, n_nbr, None
+        summary = torch.stack([n_nbr.max(), (n_nbr == m).sum().to(n_nbr.dtype)]).cpu().tolist() if n > 0 else [0, 0]
+        return dict(nl=nl, first=None, mask=mask, n_nbr=n_nbr, perm=None, fl=None, max_n=summary[0], n_eq=summary[1])
 
     def build(self, positions, box_vectors):
         """chiron/neighbors.py:628-729"""
@@ -225,29 +262,56 @@ class NeighborListNsqrd(PairsBase):
         n = self.ref_positions.shape[0]
         self.particle_ids = torch.arange(n, dtype=torch.int32, device=self.ref_positions.device)
 
-        nl, mask, n_nbr, perm = self._build_pass(int(self.n_max_neighbors))
+        res = self._build_pass(int(self.n_max_neighbors))
         # growth loop, chiron/neighbors.py:709-727 (equality test, as in the reference)
-        while bool((n_nbr == self.n_max_neighbors).any().item()):
-            new_max = int(n_nbr.max().item()) + 10
+        while res["n_eq"] > 0:
+            new_max = int(res["max_n"]) + 10
             log.debug(f"Increasing n_max_neighbors from {self.n_max_neighbors} to at {new_max}")
             self.n_max_neighbors = new_max
-            nl, mask, n_nbr, perm = self._build_pass(int(self.n_max_neighbors))
-        if bool((n_nbr > self.n_max_neighbors).any().item()):
+            res = self._build_pass(int(self.n_max_neighbors))
+        truncated = res["max_n"] > self.n_max_neighbors
+        if truncated:
             log.warning(
                 "NeighborListNsqrd: some rows hold more than n_max_neighbors entries and none holds exactly "
                 "that many; like the reference (chiron/neighbors.py:709) the list is truncated silently."
             )
-        self.neighbor_mask, self.neighbor_list, self.n_neighbors = mask, nl, n_nbr
-        self._perm = perm
-        self._force_list = None
+        self._nl, self._nl_mask, self._first = res["nl"], res["mask"], res["first"]
+        self.n_neighbors = res["n_nbr"]
+        self._perm = res["perm"]
+        # a truncated public list interacts through its listed pairs only: derive the table from it
+        self._force_list = None if truncated else res["fl"]
         self.is_built = True
         self.n_builds += 1
 
+    def _finish_padding(self):
+        """Padding (:603-620) and mask (:623) are produced on first use: the MD loop never reads them."""
+        if self._nl_mask is None:
+            self._nl_mask = ops.nl_finish_padding(self._nl, self._first, self.n_neighbors)
+
+    @property
+    def neighbor_list(self) -> torch.Tensor:
+        """(N, n_max_neighbors) neighbor ids (uint32 payload in an int32 tensor), padded as the reference pads."""
+        self._finish_padding()
+        return self._nl
+
+    @neighbor_list.setter
+    def neighbor_list(self, value):
+        self._nl = value
+
+    @property
+    def neighbor_mask(self) -> torch.Tensor:
+        self._finish_padding()
+        return self._nl_mask
+
+    @neighbor_mask.setter
+    def neighbor_mask(self, value):
+        self._nl_mask = value
+
     @property
     def force_list(self) -> ops.ForceList:
-        """Internal full table for the force kernel, derived lazily from the half list."""
+        """Internal full table for the force kernel (from the one-pass build, else derived from the half list)."""
         if self._force_list is None:
-            self._force_list = ops.ForceList(self.neighbor_list, self.n_neighbors, self._perm)
+            self._force_list = ops.ForceList(self._nl, self.n_neighbors, self._perm)
         return self._force_list
 
     # -- calculate / check -------------------------------------------------

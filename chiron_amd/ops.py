@@ -146,6 +146,69 @@ def nl_build_cell(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: int, 
     return nl, mask, n_nbr, sorted_ids, status
 
 
+def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: int, ncell: int, nc, g: int, chunks: int):
+    """One-pass cell build (half-list rows without padding + force list).
+
+    Returns (nl_rows, first, n_nbr, sorted_ids, fl, deg, status8); nothing is synchronised here.
+    """
+    xyz = _f32(xyz)
+    _require_device(xyz)
+    n = xyz.shape[0]
+    dev = xyz.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    nl = torch.empty((n, m), **i32)
+    first = torch.empty((n,), **i32)
+    n_nbr = torch.empty((n,), **i32)
+    cell_of = torch.empty((n,), **i32)
+    cell_count = torch.empty((ncell + 1,), **i32)
+    cell_start = torch.empty((ncell + 1,), **i32)
+    sorted_ids = torch.empty((n,), **i32)
+    status = torch.empty((8,), **i32)
+    fl = torch.empty((chunks, n, g), **i32)
+    deg = torch.empty((n,), **i32)
+    xs4 = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    check(
+        _lib.load().chx_nl_build_cell_fl(
+            _ptr(xyz), n, m, box, C.c_float(cutoff_plus_skin), nc, _ptr(cell_of), _ptr(cell_count), _ptr(cell_start),
+            _ptr(sorted_ids), _ptr(status), _ptr(nl), _ptr(first), _ptr(n_nbr), g, chunks, _ptr(fl), _ptr(deg),
+            _ptr(xs4), _stream(),
+        ),
+        "chx_nl_build_cell_fl",
+    )
+    return nl, first, n_nbr, sorted_ids, fl, deg, status
+
+
+def nl_finish_padding(nl: torch.Tensor, first: torch.Tensor, n_nbr: torch.Tensor) -> torch.Tensor:
+    """Pad the rows in place (reference fill rule) and return the (N,M) list mask."""
+    _require_device(nl, first, n_nbr)
+    n, m = nl.shape
+    mask = torch.empty((n, m), dtype=torch.int32, device=nl.device)
+    check(_lib.load().chx_nl_finish_padding(_ptr(nl), _ptr(first), _ptr(n_nbr), n, m, _ptr(mask), _stream()), "chx_nl_finish_padding")
+    return mask
+
+
+def pack_langevin(x3, v3, mass, ref3, perm, want_ref: bool):
+    """User-order state -> internal order in one launch: (x4, v, mass_internal, ref4 or None)."""
+    x3, v3, mass = _f32(x3), _f32(v3), _f32(mass)
+    _require_device(x3, v3, mass, perm)
+    n = x3.shape[0]
+    dev = x3.device
+    x4 = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    v = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    m_int = torch.empty((n,), dtype=torch.float32, device=dev)
+    ref4 = None
+    if want_ref:
+        ref3 = _f32(ref3)
+        _require_device(ref3)
+        ref4 = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    check(
+        _lib.load().chx_pack_langevin(_ptr(x3), _ptr(v3), _ptr(mass), _ptr(ref3) if want_ref else None, _ptr(perm), n,
+                                      _ptr(x4), _ptr(v), _ptr(m_int), _ptr(ref4), _stream()),
+        "chx_pack_langevin",
+    )
+    return x4, v, m_int, ref4
+
+
 def nl_calculate(xyz, nl, nl_mask, box: Box, cutoff: float):
     xyz = _f32(xyz)
     _require_device(xyz, nl, nl_mask)
@@ -220,7 +283,21 @@ def _choose_g(maxdeg: int, n: int) -> int:
 
 
 class ForceList:
-    """Internal full neighbor table (see include/chx.h) built from the public half list."""
+    """Internal full neighbor table (see include/chx.h).
+
+    ``ForceList(nl, n_nbr, perm)`` derives it from a public half list (any builder, exactly the
+    listed pairs); ``ForceList.prebuilt(...)`` wraps the table the one-pass cell build emitted.
+    """
+
+    @classmethod
+    def prebuilt(cls, fl: torch.Tensor, deg: torch.Tensor, perm: torch.Tensor, g: int, chunks: int, maxdeg: int):
+        self = cls.__new__(cls)
+        self.n = deg.shape[0]
+        self.perm, self.inv = perm, None
+        self.fl, self.deg, self.g, self.chunks, self.maxdeg = fl, deg, g, chunks, maxdeg
+        self.sorted = True
+        self.ws = torch.empty((int(_lib.load().chx_lj_ws_count(self.n)),), dtype=torch.float64, device=deg.device)
+        return self
 
     def __init__(self, nl: torch.Tensor, n_nbr: torch.Tensor, perm: Optional[torch.Tensor] = None):
         _require_device(nl, n_nbr, perm)
@@ -327,6 +404,19 @@ def langevin_fused_chunk(params: LangevinParams, x_even: torch.Tensor, x_odd: to
         _lib.load().chx_langevin_fused_chunk(C.byref(params), _ptr(x_even), _ptr(x_odd), step0, n_steps, kicks_first, do_aoa, _stream()),
         "chx_langevin_fused_chunk",
     )
+
+
+def ctrl_reset(ctrl: torch.Tensor) -> None:
+    _require_device(ctrl)
+    check(_lib.load().chx_ctrl_reset(_ptr(ctrl), _stream()), "chx_ctrl_reset")
+
+
+def publish(src: torch.Tensor, pinned_dst: torch.Tensor, n: int) -> None:
+    """Device ints -> host-mapped pinned tensor by a kernel on the current stream (no copy engine)."""
+    _require_device(src)
+    if not pinned_dst.is_pinned():
+        raise _lib.ChxError("publish needs a pinned (host-mapped) destination tensor")
+    check(_lib.load().chx_publish(_ptr(src), C.c_void_p(pinned_dst.data_ptr()), n, _stream()), "chx_publish")
 
 
 def langevin_resume(params: LangevinParams) -> None:

@@ -81,7 +81,7 @@ class Chain:
 class Topology:
     def __init__(self):
         self._chains: List[Chain] = []
-        self._atoms: List[Atom] = []
+        self._segments: list = []  # lists of explicit Atom objects and (n, name, element, residue) runs
         self._n_residues = 0
         self._masses_amu = None
 
@@ -97,33 +97,62 @@ class Topology:
         return r
 
     def addAtom(self, name: str, element: Element, residue: Residue) -> Atom:
-        a = Atom(name, element, len(self._atoms), residue)
-        self._atoms.append(a)
+        a = Atom(name, element, self.getNumAtoms(), residue)
+        if not self._segments or not isinstance(self._segments[-1], list):
+            self._segments.append([])
+        self._segments[-1].append(a)
         residue._atoms.append(a)
         self._masses_amu = None
         return a
+
+    def addAtoms(self, n: int, name: str, element: Element, residue: Residue) -> None:
+        """``n`` identical atoms stored as ONE run instead of n Python objects.
+
+        A 262,144-atom topology made of individual ``Atom`` objects adds ~1e6 tracked objects to
+        the interpreter; every full garbage-collection pass then stalls the launch loop for tens of
+        milliseconds.  ``atoms()`` still yields (transient) ``Atom`` objects in index order.
+        """
+        if n > 0:
+            self._segments.append((int(n), name, element, residue))
+            self._masses_amu = None
 
     def masses_amu(self):
         """Per-atom masses in amu as a cached float64 array (one unit conversion per element)."""
         import numpy as np
 
-        if getattr(self, "_masses_amu", None) is None or len(self._masses_amu) != len(self._atoms):
+        if self._masses_amu is None:
             per_element = {}
-            out = np.empty(len(self._atoms), dtype=np.float64)
-            for i, atom in enumerate(self._atoms):
-                el = atom.element
+
+            def mass_of(el):
                 m = per_element.get(id(el))
                 if m is None:
                     m = per_element[id(el)] = float(el.mass.value_in_unit(unit.amu))
-                out[i] = m
-            self._masses_amu = out
+                return m
+
+            parts = []
+            for seg in self._segments:
+                if isinstance(seg, list):
+                    parts.append(np.array([mass_of(a.element) for a in seg], dtype=np.float64))
+                else:
+                    parts.append(np.full(seg[0], mass_of(seg[2]), dtype=np.float64))
+            self._masses_amu = np.concatenate(parts) if parts else np.zeros(0)
         return self._masses_amu
 
     def atoms(self) -> Iterator[Atom]:
-        return iter(self._atoms)
+        index = 0
+        for seg in self._segments:
+            if isinstance(seg, list):
+                for a in seg:
+                    yield a
+                index += len(seg)
+            else:
+                n, name, element, residue = seg
+                for k in range(n):
+                    yield Atom(name, element, index + k, residue)
+                index += n
 
     def getNumAtoms(self) -> int:
-        return len(self._atoms)
+        return sum(len(seg) if isinstance(seg, list) else seg[0] for seg in self._segments)
 
     @classmethod
     def homogeneous(cls, n: int, symbol: str = "Ar") -> "Topology":
@@ -132,6 +161,5 @@ class Topology:
         el = Element.getBySymbol(symbol)
         chain = top.addChain()
         res = top.addResidue("system", chain)
-        for _ in range(n):
-            top.addAtom(symbol, el, res)
+        top.addAtoms(n, symbol, el, res)
         return top

@@ -89,6 +89,27 @@ int chx_nl_build_cell(const float* xyz, int32_t n, int32_t m, chx_box_t box, flo
                       uint32_t* nl_out, int32_t* nl_mask_out, int32_t* n_nbr_out,
                       chx_stream_t stream);
 
+/* One-pass build for the hot loop: the same bins and the same predicate as
+ * chx_nl_build_cell, but (a) only the REAL entries of each half-list row are written
+ * (nl_rows_out[i, :min(n_nbr[i], m)]), with first_out[i] = smallest neighbor id (or
+ * 0xFFFFFFFF) so that chx_nl_finish_padding can later produce the reference's padding
+ * (chiron/neighbors.py:603-620) and mask (:623) if somebody reads them, and (b) the
+ * force list (layout above, internal order = sorted_ids, g lanes, capacity chunks*g
+ * entries per particle, unused slots = 0) and deg_out[n] are emitted directly, in scan
+ * order, without atomics.  status8 (out): [0] != 0 -> a half row overflowed the on-chip
+ * candidate buffer (nothing valid); [1] max n_nbr; [2] number of rows with n_nbr == m
+ * (the reference's growth trigger, :709); [3] max full degree; [4] rows whose full
+ * degree exceeded the capacity (force list invalid, retry with more chunks).
+ * xs4_out (n,4): the positions in internal (cell) order, x4[p] = xyz[sorted_ids[p]]. */
+int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_box_t box, float cutoff_plus_skin,
+                         const int32_t* nc_h, int32_t* cell_of, int32_t* cell_count,
+                         int32_t* cell_start, uint32_t* sorted_ids, int32_t* status8,
+                         uint32_t* nl_rows_out, uint32_t* first_out, int32_t* n_nbr_out, int32_t g,
+                         int32_t chunks, uint32_t* fl_out, int32_t* deg_out, float* xs4_out,
+                         chx_stream_t stream);
+int chx_nl_finish_padding(uint32_t* nl_inout, const uint32_t* first, const int32_t* n_nbr, int32_t n,
+                          int32_t m, int32_t* nl_mask_out, chx_stream_t stream);
+
 /* NeighborListNsqrd.calculate: chiron/neighbors.py:731-826.  For every slot
  * (i,k): r = disp(x_i, x_nl[i,k]); mask = (d < cutoff) & nl_mask; n_pairs = row sum. */
 int chx_nl_calculate(const float* xyz, const uint32_t* nl, const int32_t* nl_mask, int32_t n,
@@ -138,6 +159,11 @@ int chx_permute_pack(const float* src3, const uint32_t* perm, int32_t n, float* 
 int chx_permute_unpack(const float* src, int32_t src_stride, const uint32_t* perm, int32_t n,
                        float* dst3, chx_stream_t stream);
 int chx_invert_perm(const uint32_t* perm, int32_t n, uint32_t* inv_out, chx_stream_t stream);
+/* one launch: x4[p] = x3[perm[p]], v[p] = v3[perm[p]], mass_out[p] = mass[perm[p]],
+ * ref4[p] = ref3[perm[p]] (ref4_out may be NULL) */
+int chx_pack_langevin(const float* x3, const float* v3, const float* mass, const float* ref3,
+                      const uint32_t* perm, int32_t n, float* x4_out, float* v_out, float* mass_out,
+                      float* ref4_out, chx_stream_t stream);
 
 /* LJPotential.compute_energy / compute_force over the neighbor list:
  * E = sum over listed pairs with d < cutoff of 4 eps ((s/d)^12 - (s/d)^6)
@@ -225,6 +251,14 @@ int chx_langevin_resume(const chx_langevin_t* p_h, chx_stream_t stream);
 int chx_langevin_fused_chunk(const chx_langevin_t* p_h, float* x_even, float* x_odd, int64_t step0,
                              int32_t n_steps, int32_t kicks_first, int32_t do_aoa,
                              chx_stream_t stream);
+
+/* Control-block plumbing of the loop above, as ordinary kernels on the caller's stream:
+ * chx_ctrl_reset writes {0, 0, 0, INT32_MAX}; chx_publish copies n <= 64 ints into
+ * HOST-MAPPED pinned memory (host_mapped_dst is the device-visible address of a
+ * hipHostMalloc'ed block) with system-scope visibility, so the host can read the block
+ * after waiting for the stream without any copy-engine / blit work in the hot loop. */
+int chx_ctrl_reset(int32_t* ctrl, chx_stream_t stream);
+int chx_publish(const int32_t* src, int32_t* host_mapped_dst, int32_t n, chx_stream_t stream);
 
 /* ------------------------------------------------------------ Monte Carlo */
 /* MonteCarloDisplacementMove proposal: x' = wrap(x + sigma_d * N(0,1) [* mask_i]),

@@ -29,7 +29,10 @@ def ev_time(fn, reps=200, warm=20):
 
 for wl in sys.argv[1:] or ["c3", "c4"]:
     for g in os.environ.get("GS", "4,8,16").split(","):
-        os.environ["CHX_FL_G"] = g
+        if g == "auto":
+            os.environ.pop("CHX_FL_G", None)
+        else:
+            os.environ["CHX_FL_G"] = g
         fluid, pot, state, thermo, nbr, integ = bench.make_system(wl, 300.0, 32, "cell")
         nbr.build_from_state(state)
         fl = nbr.force_list
