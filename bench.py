@@ -164,6 +164,18 @@ def roofline_entry(kind: str, n: int, p_nl: int, seconds: float, extra=None):
     }
     if extra:
         d.update(extra)
+    # HBM traffic per launch from the committed PMC passes (profiles/pmc_traffic.json: separate
+    # rocprofv3 --pmc runs, 2 x FETCH_SIZE + WRITE_SIZE with the gfx950 correction); those passes
+    # profile the same kernel on the same box geometry at the lattice start state.
+    wl = {32768: "c3", 262144: "c4"}.get(n)
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            pmc = json.load(fh).get(f"{wl}:{'k_lj_step' if kind == 'step' else 'k_lj_fl'}")
+        if pmc:
+            d["traffic"] = int(pmc["traffic_bytes"])
+            d["traffic_source"] = "profiles/r01_pmc_hot_kernels.md (PMC passes at the lattice start state)"
+    except (OSError, ValueError):
+        pass
     return d
 
 

@@ -187,7 +187,9 @@ __device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nb) {
 }
 
 #define CHX_FL_INVALID 0xFFFFFFFFu
+#ifndef CHX_FL_UNROLL
 #define CHX_FL_UNROLL 4
+#endif
 
 // One particle's share of its force-list row: lane q of the G cooperating lanes walks
 // entries q, q+G, ...  Index loads, position gathers and arithmetic are issued in batches

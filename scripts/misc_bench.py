@@ -1,0 +1,33 @@
+"""Quick throughput probes for the secondary configurations (GPU box only)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+torch.set_num_threads(1)
+import bench
+from chiron_amd import unit
+from chiron_amd.neighbors import PairListNsqrd, OrthogonalPeriodicSpace, NeighborListCell
+from chiron_amd.mcmc import MonteCarloDisplacementMove
+
+def t(label, fn, n):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"{label:55s} {1e3*dt:9.2f} ms  ({n/dt:10.1f} /s)", flush=True)
+    return out
+
+# C2: N=512, all-pairs PBC (PairListNsqrd) Langevin
+fluid, pot, state, thermo, nbr, integ = bench.make_system("c2", 300.0, 32, "cell")
+pl = PairListNsqrd(OrthogonalPeriodicSpace(), cutoff=3 * 0.34 * unit.nanometer)
+out = integ.run(state, thermo, number_of_steps=100, nbr_list=pl)
+out = t("C2 N=512 PairListNsqrd Langevin, 2000 steps", lambda: integ.run(out[0], thermo, number_of_steps=2000, nbr_list=pl), 2000)
+out = t("C2 N=512 no list (no PBC) Langevin, 2000 steps", lambda: integ.run(out[0], thermo, number_of_steps=2000, nbr_list=None), 2000)
+out = integ.run(state, thermo, number_of_steps=100, nbr_list=nbr)
+out = t("C2 N=512 NeighborListCell Langevin, 2000 steps", lambda: integ.run(out[0], thermo, number_of_steps=2000, nbr_list=nbr), 2000)
+
+# MC displacement move on the C3 box
+fluid, pot, state, thermo, nbr, integ = bench.make_system("c3", 300.0, 32, "cell")
+nbr.build_from_state(state)
+move = MonteCarloDisplacementMove(displacement_sigma=0.0005 * unit.nanometer, number_of_moves=200, reporter=None)
+move.update(state, thermo, nbr)
+move = MonteCarloDisplacementMove(displacement_sigma=0.0005 * unit.nanometer, number_of_moves=500, reporter=None)
+t("C3 N=32768 MonteCarloDisplacementMove, 500 trial moves", lambda: move.update(state, thermo, nbr), 500)
+print("   acceptance", move.statistics)
