@@ -51,6 +51,40 @@ class LangevinParams(C.Structure):
     ]
 
 
+class McParams(C.Structure):
+    """``chx_mc_t`` (include/chx.h)."""
+
+    _fields_ = [
+        ("n", C.c_int32),
+        ("g", C.c_int32),
+        ("fl_chunks", C.c_int32),
+        ("reserved", C.c_int32),
+        ("x_a", C.c_void_p),
+        ("x_b", C.c_void_p),
+        ("ref4", C.c_void_p),
+        ("perm", C.c_void_p),
+        ("subset_mask", C.c_void_p),
+        ("fl", C.c_void_p),
+        ("deg", C.c_void_p),
+        ("box", Box),
+        ("skin", C.c_float),
+        ("sigma_d", C.c_float),
+        ("sigma", C.c_float),
+        ("epsilon", C.c_float),
+        ("cutoff", C.c_float),
+        ("reserved2", C.c_float),
+        ("beta", C.c_double),
+        ("state", C.c_void_p),
+        ("energy", C.c_void_p),
+        ("accept_log", C.c_void_p),
+        ("energy_log", C.c_void_p),
+        ("ws", C.c_void_p),
+    ]
+
+
+# indices into the chx_mc_t state block (include/chx.h)
+MC_CUR, MC_ACCEPTED, MC_PROPOSED, MC_HALT, MC_KEY0, MC_KEY1, MC_STATE_WORDS = 0, 1, 2, 3, 4, 5, 8
+
 _P = C.c_void_p
 _I32 = C.c_int32
 _I64 = C.c_int64
@@ -102,6 +136,7 @@ SIGNATURES = {
         C.c_int,
         [_P, _P, _I64, _P, _P, _P, _U32, _U32, _U32, _F, _P, _P, _P],
     ),
+    "chx_mc_displace_chunk": (C.c_int, [_P, _I64, _I32, _P]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -156,6 +156,7 @@ __device__ __forceinline__ double block_sum(double v) {
 #define CHX_STREAM_LANGEVIN 1u
 #define CHX_STREAM_MC_DISPLACE 2u
 #define CHX_STREAM_UNIFORM 3u
+#define CHX_STREAM_SPLIT 0x5EEDu  // key splitting (chiron_amd/rng.py: split)
 
 __device__ __forceinline__ uint4 philox4x32(uint4 c, uint32_t k0, uint32_t k1) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;

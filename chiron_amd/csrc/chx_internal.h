@@ -18,9 +18,22 @@ int chx_cell_prepare(const float* xyz, int n, chx_box_t box, float cutoff_plus_s
 
 // ctrl != NULL: the kernel is part of a Langevin chunk and turns into a no-op
 // (setting ctrl[1]) when ctrl[0] says the skin check fired.
+//
+// select != NULL (device-resident Monte Carlo): the positions are read from x4 or from
+// select->x4_alt, whichever state[CHX_MC_CUR] ^ flip names, and the launch is a no-op once
+// state[CHX_MC_HALT] <= trial; with energy == NULL the per-block partials stay in ws.
+struct chx_fl_select_t {
+  const int32_t* state;
+  const float* x4_alt;
+  int flip;
+  long long trial;
+};
 int chx_launch_lj_fl(const float* x4, const uint32_t* fl, const int32_t* deg, int n, int g, int chunks,
                      chx_box_t box, float sigma, float epsilon, float cutoff, float* f3,
-                     float* energy, double* ws, int32_t* ctrl, hipStream_t st);
+                     float* energy, double* ws, int32_t* ctrl, hipStream_t st,
+                     const chx_fl_select_t* select = nullptr);
+// number of per-block partials the list kernel leaves in ws for (n, g)
+static inline int chx_lj_fl_blocks(int n, int g) { return (int)(((int64_t)n * g + 255) / 256); }
 // n_steps fused [force + BAOAB] launches on the force list (k_lj_step); launch i reads
 // (i even ? x_even : x_odd) and writes the other buffer.  do_aoa == 0: force + kicks only.
 int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, int64_t step0,

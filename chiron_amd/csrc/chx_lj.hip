@@ -246,15 +246,30 @@ __device__ __forceinline__ void lj_row(const float4* __restrict__ x4, const uint
   }
 }
 
+// Optional run-time choice of the position buffer (device-resident Monte Carlo, chx_mc.hip):
+// state[CHX_MC_CUR] names the buffer holding the current configuration, flip = 1 selects the
+// other (proposed) one; the launch is a no-op once state[CHX_MC_HALT] <= trial.
+struct FlSelect {
+  const int32_t* state;
+  const float4* x4_alt;
+  int flip;
+  long long trial;
+};
+
 template <int G, bool WANT_F, bool WANT_E>
 __global__ __launch_bounds__(256) void k_lj_fl(const float4* __restrict__ x4,
                                                const uint32_t* __restrict__ fl,
                                                const int32_t* __restrict__ deg, int n, int chunks,
                                                Box3 box, LJParams lj, float* __restrict__ f3,
-                                               double* __restrict__ ws, int32_t* ctrl) {
+                                               double* __restrict__ ws, int32_t* ctrl,
+                                               FlSelect sel) {
   if (ctrl != nullptr && ctrl[0] != 0) {  // skin check fired in this step's integrate kernel
     if (blockIdx.x == 0 && threadIdx.x == 0) ctrl[1] = 1;
     return;
+  }
+  if (sel.state != nullptr) {  // Monte Carlo chunk: positions live in one of two buffers
+    if ((long long)sel.state[CHX_MC_HALT] <= sel.trial) return;
+    if (((sel.state[CHX_MC_CUR] ^ sel.flip) & 1) != 0) x4 = sel.x4_alt;
   }
   const unsigned blk = xcd_block(blockIdx.x, gridDim.x);
   const int tid = blk * 256 + threadIdx.x;
@@ -427,17 +442,17 @@ __global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int
 template <int G>
 static int launch_lj_fl_g(const float4* x4, const uint32_t* fl, const int32_t* deg, int n, int chunks,
                           Box3 box, LJParams lj, float* f3, float* energy, double* ws, int32_t* ctrl,
-                          hipStream_t st) {
+                          FlSelect sel, hipStream_t st) {
   const unsigned blocks = (unsigned)(((int64_t)n * G + 255) / 256);
   if (f3 && energy) {
     hipLaunchKernelGGL((k_lj_fl<G, true, true>), dim3(blocks), dim3(256), 0, st, x4, fl, deg, n, chunks,
-                       box, lj, f3, ws, ctrl);
+                       box, lj, f3, ws, ctrl, sel);
   } else if (f3) {
     hipLaunchKernelGGL((k_lj_fl<G, true, false>), dim3(blocks), dim3(256), 0, st, x4, fl, deg, n, chunks,
-                       box, lj, f3, ws, ctrl);
+                       box, lj, f3, ws, ctrl, sel);
   } else {
     hipLaunchKernelGGL((k_lj_fl<G, false, true>), dim3(blocks), dim3(256), 0, st, x4, fl, deg, n, chunks,
-                       box, lj, f3, ws, ctrl);
+                       box, lj, f3, ws, ctrl, sel);
   }
   if (energy) {
     hipLaunchKernelGGL(k_sum_ws, dim3(1), dim3(256), 0, st, ws, (int)blocks, energy);
@@ -456,18 +471,26 @@ static LJParams make_lj(float sigma, float epsilon, float cutoff) {
 
 int chx_launch_lj_fl(const float* x4, const uint32_t* fl, const int32_t* deg, int n, int g, int chunks,
                      chx_box_t box, float sigma, float epsilon, float cutoff, float* f3,
-                     float* energy, double* ws, int32_t* ctrl, hipStream_t st) {
+                     float* energy, double* ws, int32_t* ctrl, hipStream_t st,
+                     const chx_fl_select_t* select) {
   const float4* xx = reinterpret_cast<const float4*>(x4);
   const Box3 b3 = make_box3(box);
   const LJParams lj = make_lj(sigma, epsilon, cutoff);
+  FlSelect sel = {nullptr, nullptr, 0, 0};
+  if (select) {
+    sel.state = select->state;
+    sel.x4_alt = reinterpret_cast<const float4*>(select->x4_alt);
+    sel.flip = select->flip;
+    sel.trial = select->trial;
+  }
   switch (g) {
-    case 1: return launch_lj_fl_g<1>(xx, fl, deg, n, chunks, b3, lj, f3, energy, ws, ctrl, st);
-    case 2: return launch_lj_fl_g<2>(xx, fl, deg, n, chunks, b3, lj, f3, energy, ws, ctrl, st);
-    case 4: return launch_lj_fl_g<4>(xx, fl, deg, n, chunks, b3, lj, f3, energy, ws, ctrl, st);
-    case 8: return launch_lj_fl_g<8>(xx, fl, deg, n, chunks, b3, lj, f3, energy, ws, ctrl, st);
-    case 16: return launch_lj_fl_g<16>(xx, fl, deg, n, chunks, b3, lj, f3, energy, ws, ctrl, st);
-    case 32: return launch_lj_fl_g<32>(xx, fl, deg, n, chunks, b3, lj, f3, energy, ws, ctrl, st);
-    case 64: return launch_lj_fl_g<64>(xx, fl, deg, n, chunks, b3, lj, f3, energy, ws, ctrl, st);
+    case 1: return launch_lj_fl_g<1>(xx, fl, deg, n, chunks, b3, lj, f3, energy, ws, ctrl, sel, st);
+    case 2: return launch_lj_fl_g<2>(xx, fl, deg, n, chunks, b3, lj, f3, energy, ws, ctrl, sel, st);
+    case 4: return launch_lj_fl_g<4>(xx, fl, deg, n, chunks, b3, lj, f3, energy, ws, ctrl, sel, st);
+    case 8: return launch_lj_fl_g<8>(xx, fl, deg, n, chunks, b3, lj, f3, energy, ws, ctrl, sel, st);
+    case 16: return launch_lj_fl_g<16>(xx, fl, deg, n, chunks, b3, lj, f3, energy, ws, ctrl, sel, st);
+    case 32: return launch_lj_fl_g<32>(xx, fl, deg, n, chunks, b3, lj, f3, energy, ws, ctrl, sel, st);
+    case 64: return launch_lj_fl_g<64>(xx, fl, deg, n, chunks, b3, lj, f3, energy, ws, ctrl, sel, st);
   }
   chx_set_error("chx_launch_lj_fl: unsupported g = %d", g);
   return CHX_ERR_INVALID;

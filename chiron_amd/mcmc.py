@@ -9,13 +9,16 @@ decision and the statistics are host logic exactly as in the reference.
 from __future__ import annotations
 
 import copy
+import ctypes as C
 import math
+import os
 from typing import List, Optional, Tuple
 
 import numpy as np
 import torch
 
-from . import ops, unit
+from . import _lib, ops, unit
+from .rng import PRNGKey
 from .rng import uniform as host_uniform
 from .states import SamplerState, ThermodynamicState
 
@@ -230,6 +233,161 @@ class MonteCarloDisplacementMove(MCMove):
         self.atom_subset = atom_subset
         self.atom_subset_mask = None
 
+    # trials enqueued per host round trip of the device-resident loop
+    _DEVICE_CHUNK = 256
+
+    def update(self, sampler_state, thermodynamic_state, nbr_list=None):
+        """chiron/mcmc.py:243-306.  With an LJ potential on a built Verlet list the whole trial
+        loop runs on the device (``_update_device``); every other combination takes the
+        reference-shaped host loop of ``MCMove.update`` (one kernel sequence per trial)."""
+        if self._device_loop_applies(sampler_state, thermodynamic_state, nbr_list):
+            return self._update_device(sampler_state, thermodynamic_state, nbr_list)
+        return super().update(sampler_state, thermodynamic_state, nbr_list)
+
+    def _device_loop_applies(self, sampler_state, thermodynamic_state, nbr_list) -> bool:
+        from .neighbors import NeighborListNsqrd
+        from .potential import LJPotential
+
+        if os.environ.get("CHX_MC_HOST_LOOP", "0") == "1":
+            return False
+        cls = type(self)
+        if (cls._propose is not MonteCarloDisplacementMove._propose or cls._step is not MCMove._step
+                or cls._accept_or_reject is not MCMove._accept_or_reject):
+            return False  # a subclass changed the trial: honour it
+        if self.acceptance_method != "Metropolis-Hastings" or self.number_of_moves <= 0:
+            return False
+        pot = getattr(thermodynamic_state, "potential", None)
+        if type(pot) is not LJPotential or not isinstance(nbr_list, NeighborListNsqrd) or not nbr_list.is_built:
+            return False
+        if not sampler_state.positions.is_cuda or sampler_state.number_of_particles != nbr_list.ref_positions.shape[0]:
+            return False
+        if nbr_list.cutoff.value_in_unit_system(unit.md_unit_system) != pot.cutoff:
+            return False  # the host loop raises the reference's error
+        # the proposal wraps in the sampler state's box, the energy uses the list's: they must agree
+        if nbr_list.space.periodic and sampler_state.box_vectors is None:
+            return False
+        b0, b1 = ops.make_box(sampler_state.box_vectors, nbr_list.space.periodic), nbr_list._box_h
+        return (b0.periodic, b0.lx, b0.ly, b0.lz) == (b1.periodic, b1.lx, b1.ly, b1.lz)
+
+    def _subset_mask(self, sampler_state):
+        if self.atom_subset is not None and self.atom_subset_mask is None:
+            # per-particle 0/1 mask (the reference's (N,3)*(N,) product only broadcasts for N in {1,3}; :717-722, :743)
+            mask = np.zeros(sampler_state.number_of_particles, dtype=np.float32)
+            for atom in self.atom_subset:
+                mask[atom] = 1.0
+            self.atom_subset_mask = torch.as_tensor(mask, device=sampler_state.positions.device)
+        return self.atom_subset_mask if self.atom_subset is not None else None
+
+    def _device_context(self, sampler_state, thermodynamic_state, nbr_list, energy: float):
+        """Pack the configuration into the force list's internal order and fill ``chx_mc_t``."""
+        pot = thermodynamic_state.potential
+        fl = nbr_list.force_list
+        dev = sampler_state.positions.device
+        n = sampler_state.number_of_particles
+        key = sampler_state._current_PRNG_key
+        ctx = {"fl": fl, "nbr_list": nbr_list}
+        ctx["x_a"] = fl.pack(sampler_state.positions, 4)
+        ctx["x_b"] = torch.empty_like(ctx["x_a"])
+        ctx["ref4"] = fl.pack(nbr_list.ref_positions, 4)
+        st = np.zeros(_lib.MC_STATE_WORDS, dtype=np.uint32)
+        st[_lib.MC_HALT] = 0x7FFFFFFF
+        st[_lib.MC_KEY0], st[_lib.MC_KEY1] = key[0], key[1]
+        ctx["state"] = torch.from_numpy(st.view(np.int32)).to(dev)
+        ctx["energy"] = torch.from_numpy(np.array([energy, energy], dtype=np.float64)).to(dev)
+        ctx["accept_log"] = torch.zeros((self._DEVICE_CHUNK,), dtype=torch.int32, device=dev)
+        ctx["energy_log"] = torch.zeros((self._DEVICE_CHUNK,), dtype=torch.float32, device=dev)
+        mask = self._subset_mask(sampler_state)
+        if thermodynamic_state.beta is None:
+            thermodynamic_state.beta = 1.0 / (unit.BOLTZMANN_CONSTANT_kB * (thermodynamic_state.temperature * unit.kelvin))
+        beta = float(thermodynamic_state.beta * (unit.Quantity(1.0, unit.kilojoule_per_mole) / unit.AVOGADRO_CONSTANT_NA))
+        p = _lib.McParams()
+        p.n, p.g, p.fl_chunks = n, fl.g, fl.chunks
+        p.x_a, p.x_b, p.ref4 = ctx["x_a"].data_ptr(), ctx["x_b"].data_ptr(), ctx["ref4"].data_ptr()
+        p.perm = None if fl.perm is None else fl.perm.data_ptr()
+        p.subset_mask = None if mask is None else mask.data_ptr()
+        p.fl, p.deg = fl.fl.data_ptr(), fl.deg.data_ptr()
+        p.box = nbr_list._box_h
+        p.skin = float(nbr_list.skin.value_in_unit_system(unit.md_unit_system))
+        p.sigma, p.epsilon, p.cutoff = pot.sigma, pot.epsilon, pot.cutoff
+        p.beta = beta
+        p.state, p.energy = ctx["state"].data_ptr(), ctx["energy"].data_ptr()
+        p.accept_log, p.energy_log = ctx["accept_log"].data_ptr(), ctx["energy_log"].data_ptr()
+        p.ws = fl.ws.data_ptr()
+        ctx["params"] = p
+        return ctx
+
+    def _after_attempt(self, i, energy, sigma_md):
+        """Bookkeeping of one finished trial (chiron/mcmc.py:281-303): report, then autotune."""
+        self._number_of_attempts_made += 1
+        if self.reporter is not None and self._number_of_attempts_made % self.report_interval == 0:
+            self.reporter.report(
+                {
+                    "step": i,
+                    "iteration": self._move_iteration,
+                    "number_of_attempts_made": self._number_of_attempts_made,
+                    "potential_energy": np.float32(energy),
+                    "displacement_sigma": sigma_md,
+                    "acceptance_probability": self.n_accepted / self.n_proposed,
+                }
+            )
+        if self.autotune and self._number_of_attempts_made % self.autotune_interval == 0 and self._number_of_attempts_made > 0:
+            self._autotune()
+
+    def _update_device(self, sampler_state, thermodynamic_state, nbr_list):
+        """The loop of ``MCMove.update`` with the trials enqueued in chunks (chx_mc_displace_chunk).
+
+        Same proposal numbers, energies, decisions, statistics, reports and PRNG chain as the
+        host loop; a trial whose proposal violates the list's skin runs through ``_step`` (the
+        reference's deepcopy-and-rebuild branch) and the device loop resumes after it.
+        """
+        sampler_state = copy.deepcopy(sampler_state)  # the caller's object keeps its positions
+        pot = thermodynamic_state.potential
+        energy = float(pot.compute_energy(sampler_state.positions, nbr_list))  # :392-399
+        ctx = self._device_context(sampler_state, thermodynamic_state, nbr_list, energy)
+        total = self.number_of_moves
+        i = 0
+        while i < total:
+            m = min(total - i, self._DEVICE_CHUNK)
+            if self.autotune:  # sigma is a launch constant: a chunk ends where autotune may change it
+                m = min(m, self.autotune_interval - self._number_of_attempts_made % self.autotune_interval)
+            sigma_md = float(self.displacement_sigma.value_in_unit_system(unit.md_unit_system))
+            ctx["params"].sigma_d = sigma_md
+            ops.mc_displace_chunk(ctx["params"], i, m)
+            st = ctx["state"].cpu().numpy()  # waits for the chunk
+            halt = int(st[_lib.MC_HALT])
+            halted = halt < i + m
+            done = (halt if halted else i + m) - i
+            if done > 0:
+                acc = ctx["accept_log"][:done].cpu().numpy()
+                elog = ctx["energy_log"][:done].cpu().numpy()
+                for k in range(done):
+                    self._update_statistics(bool(acc[k]))
+                    self._after_attempt(i + k, elog[k], sigma_md)
+                energy = float(elog[done - 1])
+                i += done
+            if halted:
+                # trial `halt` trips the skin check: run it on the reference's rebuild branch
+                cur = ctx["x_b"] if (int(st[_lib.MC_CUR]) & 1) else ctx["x_a"]
+                sampler_state.positions = ctx["fl"].unpack(cur)
+                sampler_state._current_PRNG_key = PRNGKey(int(st[_lib.MC_KEY0]) & 0xFFFFFFFF, int(st[_lib.MC_KEY1]) & 0xFFFFFFFF)
+                self._current_reduced_potential = thermodynamic_state.reduced_potential_from_energy(energy, sampler_state)
+                sampler_state, thermodynamic_state, nbr_list = self._step(sampler_state, thermodynamic_state, nbr_list)
+                energy = float(pot.compute_energy(sampler_state.positions, nbr_list))
+                self._after_attempt(i, energy, sigma_md)
+                i += 1
+                if i < total:
+                    ctx = self._device_context(sampler_state, thermodynamic_state, nbr_list, energy)
+                else:
+                    ctx = None
+        if ctx is not None:
+            st = ctx["state"].cpu().numpy()
+            cur = ctx["x_b"] if (int(st[_lib.MC_CUR]) & 1) else ctx["x_a"]
+            sampler_state.positions = ctx["fl"].unpack(cur)
+            sampler_state._current_PRNG_key = PRNGKey(int(st[_lib.MC_KEY0]) & 0xFFFFFFFF, int(st[_lib.MC_KEY1]) & 0xFFFFFFFF)
+        self._current_reduced_potential = thermodynamic_state.reduced_potential_from_energy(energy, sampler_state)
+        self._move_iteration += 1
+        return sampler_state, thermodynamic_state, nbr_list
+
     def _report(self, step, iteration, number_of_attempts_made, acceptance_probability, sampler_state,
                 thermodynamic_state, nbr_list=None):
         potential = thermodynamic_state.potential.compute_energy(sampler_state.positions, nbr_list)
@@ -254,14 +412,7 @@ class MonteCarloDisplacementMove(MCMove):
     def _propose(self, current_sampler_state, current_thermodynamic_state, current_reduced_potential,
                  current_nbr_list=None):
         """chiron/mcmc.py:680-787"""
-        n = current_sampler_state.number_of_particles
-        if self.atom_subset is not None and self.atom_subset_mask is None:
-            # per-particle 0/1 mask (the reference's (N,3)*(N,) product only broadcasts for N in {1,3}; :717-722, :743)
-            mask = np.zeros(n, dtype=np.float32)
-            for atom in self.atom_subset:
-                mask[atom] = 1.0
-            self.atom_subset_mask = torch.as_tensor(mask, device=current_sampler_state.positions.device)
-
+        self._subset_mask(current_sampler_state)
         key = current_sampler_state.new_PRNG_key
         unitless_displacement_sigma = float(self.displacement_sigma.value_in_unit_system(unit.md_unit_system))
         proposed_sampler_state = copy.deepcopy(current_sampler_state)

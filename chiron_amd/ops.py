@@ -438,6 +438,11 @@ def mc_displace(x: torch.Tensor, sigma_d: float, box: Box, key: PRNGKey, ctr: in
     return out
 
 
+def mc_displace_chunk(params: "_lib.McParams", trial0: int, n_trials: int) -> None:
+    """Enqueue ``n_trials`` device-resident displacement trials (include/chx.h: chx_mc_displace_chunk)."""
+    check(_lib.load().chx_mc_displace_chunk(C.byref(params), trial0, n_trials, _stream()), "chx_mc_displace_chunk")
+
+
 def metropolis_select(x_cur, x_prop, log_ratio, u_cur, u_prop, key: PRNGKey, ctr: int, accepted, counters, uniform: float = -1.0) -> None:
     _require_device(x_cur, x_prop, log_ratio, u_cur, u_prop, accepted, counters)
     check(

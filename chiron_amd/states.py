@@ -222,8 +222,13 @@ class ThermodynamicState:
         if self.beta is None:
             self.beta = 1.0 / (unit.BOLTZMANN_CONSTANT_kB * (self.temperature * unit.kelvin))
         energy = self.potential.compute_energy(sampler_state.positions, nbr_list)
-        energy = float(energy)
-        reduced_potential = unit.Quantity(energy, unit.kilojoule_per_mole) / unit.AVOGADRO_CONSTANT_NA
+        return self.reduced_potential_from_energy(float(energy), sampler_state)
+
+    def reduced_potential_from_energy(self, energy: float, sampler_state: SamplerState):
+        """The arithmetic of ``get_reduced_potential`` for an already known potential energy (kJ/mol)."""
+        if self.beta is None:
+            self.beta = 1.0 / (unit.BOLTZMANN_CONSTANT_kB * (self.temperature * unit.kelvin))
+        reduced_potential = unit.Quantity(float(energy), unit.kilojoule_per_mole) / unit.AVOGADRO_CONSTANT_NA
         if self.pressure is not None:
             box = sampler_state.box_vectors
             if isinstance(box, torch.Tensor):

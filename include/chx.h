@@ -280,6 +280,58 @@ int chx_metropolis_select(float* x_cur, const float* x_prop, int64_t count,
                           uint32_t k0, uint32_t k1, uint32_t ctr, float uniform_h,
                           int32_t* accepted_out, int32_t* counters, chx_stream_t stream);
 
+/* Device-resident MonteCarloDisplacementMove loop on the force list: n_trials
+ * consecutive propose / energy / Metropolis trials (chiron/mcmc.py:243-306, :357-463,
+ * :680-787) enqueued back to back, three launches per trial and no host round trip:
+ *   propose  x' = wrap(x + sigma_d N(0,1) [* mask]) into the spare buffer + skin check
+ *            against ref4 (chiron/neighbors.py:868); the proposal key is the subkey of
+ *            split(chain key) -- what SamplerState.new_PRNG_key would hand out
+ *   energy   list kernel on x' (per-block fp64 partials, fixed order)
+ *   decide   U' = fp32(sum partials); accept iff !isnan(beta U') and
+ *            (beta U' - beta U <= 0 or uniform < exp(-(beta U' - beta U))) with the uniform
+ *            drawn from the next subkey of the chain (:428-436, :531-548); on accept the
+ *            buffers swap roles (state[CHX_MC_CUR] ^= 1) and U <- U'.  The chain key
+ *            advances by two splits per trial, exactly like the host path.
+ * When the skin check fires in trial t the kernels store t in state[CHX_MC_HALT] and every
+ * launch of trial >= t is a no-op: the caller runs that trial through the rebuild path and
+ * resumes.  state is CHX_MC_STATE_WORDS ints (indices below); energy[0] = current
+ * potential energy (kJ/mol), energy[1] = last proposed.  accept_log / energy_log
+ * (n_trials entries each, may be NULL) record the decision and the current energy after
+ * every trial, indexed by trial - trial0.  Asynchronous. */
+#define CHX_MC_CUR 0       /* which buffer (0: x_a, 1: x_b) holds the current configuration */
+#define CHX_MC_ACCEPTED 1  /* running counters */
+#define CHX_MC_PROPOSED 2
+#define CHX_MC_HALT 3      /* first trial that did not run; INT32_MAX when clear */
+#define CHX_MC_KEY0 4      /* PRNG chain key */
+#define CHX_MC_KEY1 5
+#define CHX_MC_STATE_WORDS 8
+typedef struct chx_mc_t {
+  int32_t n;
+  int32_t g;               /* lanes per particle of the force list */
+  int32_t fl_chunks;
+  int32_t reserved;
+  float* x_a;              /* (n,4) internal order */
+  float* x_b;              /* (n,4) internal order */
+  const float* ref4;       /* (n,4) positions the list was built from, internal order */
+  const uint32_t* perm;    /* internal -> original id */
+  const float* subset_mask;/* per ORIGINAL id 0/1 factors, or NULL */
+  const uint32_t* fl;
+  const int32_t* deg;
+  chx_box_t box;
+  float skin;
+  float sigma_d;           /* displacement sigma (nm) */
+  float sigma, epsilon, cutoff;
+  float reserved2;
+  double beta;             /* mol/kJ */
+  int32_t* state;          /* CHX_MC_STATE_WORDS ints */
+  double* energy;          /* [0] current, [1] proposed */
+  int32_t* accept_log;
+  float* energy_log;
+  double* ws;              /* chx_lj_ws_count(n) doubles */
+} chx_mc_t;
+int chx_mc_displace_chunk(const chx_mc_t* p_h, int64_t trial0, int32_t n_trials,
+                          chx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,8 @@ fluid, pot, state, thermo, nbr, integ = bench.make_system("c3", 300.0, 32, "cell
 nbr.build_from_state(state)
 move = MonteCarloDisplacementMove(displacement_sigma=0.0005 * unit.nanometer, number_of_moves=200, reporter=None)
 move.update(state, thermo, nbr)
-move = MonteCarloDisplacementMove(displacement_sigma=0.0005 * unit.nanometer, number_of_moves=500, reporter=None)
-t("C3 N=32768 MonteCarloDisplacementMove, 500 trial moves", lambda: move.update(state, thermo, nbr), 500)
-print("   acceptance", move.statistics)
+for label, env, moves in (("device-resident loop", "0", 4000), ("host loop (reference-shaped)", "1", 500)):
+    os.environ["CHX_MC_HOST_LOOP"] = env
+    move = MonteCarloDisplacementMove(displacement_sigma=0.0005 * unit.nanometer, number_of_moves=moves, reporter=None)
+    t(f"C3 N=32768 MonteCarloDisplacementMove, {moves} trials, {label}", lambda: move.update(state, thermo, nbr), moves)
+    print("   acceptance", move.statistics)

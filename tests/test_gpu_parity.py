@@ -676,6 +676,65 @@ def test_mc_displacement_move_lj(ca, O):
         ca.mcmc.MoveSchedule([("bad", 123)])
 
 
+def _mc_run(ca, O, host_loop, monkeypatch, *, n=500, skin=SKIN, sigma_d=0.002, moves=60, subset=None, autotune=False,
+            nbr_cls="NeighborListCell", iterations=1, pressure=None):
+    u = ca.unit
+    monkeypatch.setenv("CHX_MC_HOST_LOOP", "1" if host_loop else "0")
+    x, box = O.lj_lattice(n, 0.1, SIGMA, seed=71)
+    pot = lj_pot(ca, n)
+    state = make_state(ca, x, box)
+    thermo = ca.states.ThermodynamicState(pot, temperature=300 * u.kelvin, pressure=pressure)
+    nbr = getattr(ca.neighbors, nbr_cls)(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+                                         skin=skin * u.nanometer, n_max_neighbors=180)
+    nbr.build_from_state(state)
+    rep = ca_reporter(ca)
+    move = ca.mcmc.MonteCarloDisplacementMove(displacement_sigma=sigma_d * u.nanometer, number_of_moves=moves,
+                                              atom_subset=subset, reporter=rep, report_interval=3,
+                                              autotune=autotune, autotune_interval=16)
+    assert move._device_loop_applies(state, thermo, nbr) == (not host_loop)
+    for _ in range(iterations):
+        state, thermo, nbr = move.update(state, thermo, nbr)
+    return dict(
+        x=state.positions.cpu().numpy(), key=tuple(state._current_PRNG_key), stats=move.statistics,
+        attempts=move.number_of_attemps_made, u=float(move._current_reduced_potential),
+        sigma=move.displacement_sigma.value_in_unit_system(u.md_unit_system),
+        ref=nbr.ref_positions.cpu().numpy(), n_nbr=nbr.n_neighbors.cpu().numpy(),
+        reports={k: rep.get_property(k) for k in ("step", "iteration", "number_of_attempts_made", "potential_energy",
+                                                  "displacement_sigma", "acceptance_probability")},
+    )
+
+
+@pytest.mark.parametrize(
+    "kw",
+    [
+        dict(sigma_d=0.03, moves=30),                             # mixed accept/reject on one list
+        dict(skin=0.05, sigma_d=0.01, moves=80),                  # several skin violations -> rebuild branch
+        dict(skin=0.05, sigma_d=0.01, moves=50, autotune=True, iterations=2),
+        dict(subset=[0, 3, 17, 499], sigma_d=0.05, moves=40),
+        dict(nbr_cls="NeighborListNsqrd", sigma_d=0.02, moves=30, pressure=1.0),
+    ],
+    ids=["plain", "rebuilds", "autotune", "subset", "nsq-npt"],
+)
+def test_mc_device_loop_equals_host_loop(ca, O, monkeypatch, kw):
+    """The chunked device-resident trial loop reproduces the reference-shaped host loop exactly:
+    same proposals, energies, decisions, statistics, reports, PRNG chain and list rebuilds."""
+    if "pressure" in kw and kw["pressure"] is not None:
+        kw = dict(kw, pressure=kw["pressure"] * ca.unit.atmosphere)
+    host = _mc_run(ca, O, True, monkeypatch, **kw)
+    devr = _mc_run(ca, O, False, monkeypatch, **kw)
+    assert devr["stats"] == host["stats"] and devr["attempts"] == host["attempts"]
+    assert 0 < host["stats"]["n_accepted"] < host["stats"]["n_proposed"] or kw.get("subset")
+    assert devr["key"] == host["key"]
+    assert np.array_equal(devr["x"], host["x"])
+    assert np.array_equal(devr["ref"], host["ref"]) and np.array_equal(devr["n_nbr"], host["n_nbr"])
+    assert devr["sigma"] == host["sigma"]
+    assert np.isclose(devr["u"], host["u"], rtol=1e-12)
+    for k, v in host["reports"].items():
+        assert np.array_equal(np.asarray(devr["reports"][k], dtype=np.float64), np.asarray(v, dtype=np.float64)), k
+    if kw.get("skin") == 0.05:
+        assert not np.array_equal(host["ref"], O.lj_lattice(500, 0.1, SIGMA, seed=71)[0])  # the list was rebuilt
+
+
 def ca_reporter(ca):
     from chiron_amd.reporters import MCReporter
 

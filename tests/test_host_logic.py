@@ -285,6 +285,8 @@ def test_library_exports_every_declared_symbol():
     # struct layouts agree with the header (x86-64 SysV)
     assert ctypes.sizeof(_lib.Box) == 16
     assert ctypes.sizeof(_lib.LangevinParams) == 176
+    assert ctypes.sizeof(_lib.McParams) == 160
+    assert _lib.McParams.beta.offset == 112 and _lib.McParams.ws.offset == 152
 
 
 def test_cutoff_threshold_helper_is_exact():
