@@ -197,11 +197,45 @@ __device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nb) {
 // first batch is requested together with the particle's own position and degree -- it is
 // bounded by the (uniform) number of chunks, not by the degree, and filtered afterwards;
 // slots past a row's end hold 0 (a valid index), so the speculative gathers are harmless.
+// ---------------------------------------------------------------------------
+// Two list entries per lane at a time, in packed fp32 (v_pk_add/mul/fma_f32: two IEEE
+// operations per issue slot, each rounded exactly like its scalar twin).
+// ---------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 f2_splat(float v) { return (f2){v, v}; }
+
+// chiron/neighbors.py:79 for both halves: mod(d + L/2, L) - L/2, valid for |d| < L (the caller
+// checks that and falls back to the general path otherwise).  With t = d + L/2 in (-L/2, 3L/2)
+// jnp.mod picks, of {t - L, t, t + L}, the one in [0, L]: exactly the SMALLEST NON-NEGATIVE of
+// the three, i.e. their minimum as unsigned bit patterns (negative floats have the top bit set).
+// Same roundings as min_image(): t - L is exact (Sterbenz) and t + L rounds once.
+__device__ __forceinline__ f2 min_image2(f2 d, float L, float hL) {
+  const f2 t = d + hL;
+  const f2 a = t - L;
+  const f2 c = t + L;
+  f2 m;
+  m.x = __uint_as_float(min(min(__float_as_uint(a.x), __float_as_uint(t.x)), __float_as_uint(c.x)));
+  m.y = __uint_as_float(min(min(__float_as_uint(a.y), __float_as_uint(t.y)), __float_as_uint(c.y)));
+  return m - hL;
+}
+
+// One particle's share of its force-list row: lane q of the G cooperating lanes walks
+// entries q, q+G, ...  Index loads, position gathers and arithmetic are issued in batches
+// of CHX_FL_UNROLL so the dependent round trips (entry -> xyz) overlap across entries.  The
+// first batch is requested together with the particle's own position and degree -- it is
+// bounded by the (uniform) number of chunks, not by the degree, and filtered afterwards;
+// slots past a row's end hold 0 (a valid index), so the speculative gathers are harmless.
+//
+// The kernel is VALU-bound at large N (a wave64 op takes 4 cycles on a SIMD16), so the pair
+// arithmetic is branch-free and packed two entries wide; a lane that meets |d| >= L on some
+// axis (unwrapped input coordinates) redoes its share through the general min_image().
 template <int G>
 __device__ __forceinline__ void lj_row(const float4* __restrict__ x4, const uint32_t* __restrict__ fl,
                                        const int32_t* __restrict__ deg, int n, int chunks, int p, int q,
                                        bool valid, const Box3& box, const LJParams& lj, float4& xi_out,
                                        float& fx, float& fy, float& fz, float& en) {
+  static_assert(CHX_FL_UNROLL % 2 == 0, "entries are processed in pairs");
   const int pc = valid ? p : 0;
   const size_t stride = (size_t)n * G;
   const uint32_t* col = fl + (size_t)pc * G + q;
@@ -216,6 +250,8 @@ __device__ __forceinline__ void lj_row(const float4* __restrict__ x4, const uint
   d = valid ? d : 0;
   xi_out = xi;
   const int nt = (d + G - 1) / G;
+  f2 ax = f2_splat(0.f), ay = f2_splat(0.f), az = f2_splat(0.f), ae = f2_splat(0.f);
+  bool bad = false;
   for (int t0 = 0; t0 < nt; t0 += CHX_FL_UNROLL) {
     if (t0 > 0) {
 #pragma unroll
@@ -227,23 +263,68 @@ __device__ __forceinline__ void lj_row(const float4* __restrict__ x4, const uint
       for (int u = 0; u < CHX_FL_UNROLL; ++u) xj[u] = x4[ent[u] & ~CHX_FL_HI];
     }
 #pragma unroll
-    for (int u = 0; u < CHX_FL_UNROLL; ++u) {
-      if ((t0 + u) * G + q >= d) continue;
-      const bool hi = (ent[u] & CHX_FL_HI) != 0u;
-      float rx, ry, rz;
-      displacement_oriented(box, hi, xi.x, xi.y, xi.z, xj[u].x, xj[u].y, xj[u].z, rx, ry, rz);
-      const float r2 = norm2(rx, ry, rz);
-      if (r2 <= lj.T) {
+    for (int u = 0; u < CHX_FL_UNROLL; u += 2) {
+      const bool act0 = (t0 + u) * G + q < d;
+      const bool act1 = (t0 + u + 1) * G + q < d;
+      if (!act0) continue;  // act1 implies act0
+      // orientation: r = x_lo - x_hi by ORIGINAL id = +-(xi - xj); multiplying by +-1 is exact
+      const f2 sgn = {(ent[u] & CHX_FL_HI) ? 1.0f : -1.0f, (ent[u + 1] & CHX_FL_HI) ? 1.0f : -1.0f};
+      f2 rx = (xi.x - (f2){xj[u].x, xj[u + 1].x}) * sgn;
+      f2 ry = (xi.y - (f2){xj[u].y, xj[u + 1].y}) * sgn;
+      f2 rz = (xi.z - (f2){xj[u].z, xj[u + 1].z}) * sgn;
+      if (box.periodic) {
+        bad |= !(fabsf(rx.x) < box.lx) | !(fabsf(ry.x) < box.ly) | !(fabsf(rz.x) < box.lz);
+        bad |= !(fabsf(rx.y) < box.lx) | !(fabsf(ry.y) < box.ly) | !(fabsf(rz.y) < box.lz);
+        rx = min_image2(rx, box.lx, box.hx);
+        ry = min_image2(ry, box.ly, box.hy);
+        rz = min_image2(rz, box.lz, box.hz);
+      }
+      const f2 r2 = (rx * rx + ry * ry) + rz * rz;  // norm2() in both halves
+      const bool in0 = r2.x <= lj.T;
+      const bool in1 = act1 && r2.y <= lj.T;
+      const f2 inv = {__builtin_amdgcn_rcpf(r2.x), __builtin_amdgcn_rcpf(r2.y)};
+      const f2 s2 = inv * lj.sig2;
+      const f2 s6 = s2 * s2 * s2;
+      f2 e = (s6 * lj.eps4) * (s6 - 1.0f);
+      f2 fs = (s6 * lj.eps24) * __builtin_elementwise_fma(f2_splat(2.0f), s6, f2_splat(-1.0f)) * inv;
+      fs.x = in0 ? fs.x : 0.0f;
+      fs.y = in1 ? fs.y : 0.0f;
+      e.x = in0 ? e.x : 0.0f;
+      e.y = in1 ? e.y : 0.0f;
+      fs *= sgn;  // action on the lower id, reaction on the higher
+      ax = __builtin_elementwise_fma(fs, rx, ax);
+      ay = __builtin_elementwise_fma(fs, ry, ay);
+      az = __builtin_elementwise_fma(fs, rz, az);
+      ae += e;
+    }
+  }
+  if (__builtin_expect(bad, 0)) {
+    // general path, one entry at a time (bit-identical to the fast path wherever that is valid)
+    ax = ay = az = ae = f2_splat(0.f);
+    for (int t = 0; t < nt; ++t) {
+      if (t * G + q >= d) break;
+      const uint32_t en_t = col[(size_t)t * stride];
+      const float4 xo = x4[en_t & ~CHX_FL_HI];
+      const bool hi = (en_t & CHX_FL_HI) != 0u;
+      float gx, gy, gz;
+      displacement_oriented(box, hi, xi.x, xi.y, xi.z, xo.x, xo.y, xo.z, gx, gy, gz);
+      const float g2 = norm2(gx, gy, gz);
+      if (g2 <= lj.T) {
         float e, fs;
-        lj_pair(r2, lj.sig2, lj.eps4, lj.eps24, e, fs);
-        if (!hi) fs = -fs;  // reaction on the higher-id particle
-        fx = __builtin_fmaf(fs, rx, fx);
-        fy = __builtin_fmaf(fs, ry, fy);
-        fz = __builtin_fmaf(fs, rz, fz);
-        en += e;
+        lj_pair(g2, lj.sig2, lj.eps4, lj.eps24, e, fs);
+        if (!hi) fs = -fs;
+        const int h = t & 1;  // same accumulator parity as the fast path
+        ax[h] = __builtin_fmaf(fs, gx, ax[h]);
+        ay[h] = __builtin_fmaf(fs, gy, ay[h]);
+        az[h] = __builtin_fmaf(fs, gz, az[h]);
+        ae[h] += e;
       }
     }
   }
+  fx += ax.x + ax.y;
+  fy += ay.x + ay.y;
+  fz += az.x + az.y;
+  en += ae.x + ae.y;
 }
 
 // Optional run-time choice of the position buffer (device-resident Monte Carlo, chx_mc.hip):
