@@ -14,9 +14,6 @@
 
 #define CHX_CELL_CAP 1024  // half-row candidates kept on chip per row
 
-__device__ __forceinline__ size_t fl_slot(int p, int k, int n, int g) {
-  return ((size_t)(k / g) * (size_t)n + (size_t)p) * (size_t)g + (size_t)(k % g);
-}
 
 __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
     const float4* __restrict__ xs4, int n, int m, Box3 box, float T, CellGrid g,
@@ -98,7 +95,7 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
     const unsigned long long b = __ballot(ok);
     if (b) {
       const int slot = count_f + __popcll(b & lt);
-      if (ok && slot < fcap) fl[fl_slot(w, slot, n, fg)] = (uint32_t)k | (hi ? CHX_FL_HI : 0u);
+      if (ok && slot < fcap) fl[chx_fl_addr(w, slot, n, fg)] = (uint32_t)k | (hi ? CHX_FL_HI : 0u);
       count_f += __popcll(b);
     }
     const bool okh = ok && hi;
@@ -110,7 +107,7 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
     }
   }
   // force-list row: unused slots must hold a valid index (the force kernel gathers speculatively)
-  for (int sl = (count_f < fcap ? count_f : fcap) + lane; sl < fcap; sl += CHX_WAVE) fl[fl_slot(w, sl, n, fg)] = 0u;
+  for (int sl = (count_f < fcap ? count_f : fcap) + lane; sl < fcap; sl += CHX_WAVE) fl[chx_fl_addr(w, sl, n, fg)] = 0u;
   const int kept = count_h < CHX_CELL_CAP - 40 ? count_h : CHX_CELL_CAP - 40;
   __threadfence_block();
   // half row: rank sort -> ascending ids, as jnp.where(mask, size=M) returns them
@@ -201,7 +198,7 @@ extern "C" int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_
               "null pointer");
   CHX_REQUIRE(g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64,
               "g must be a power of two <= 64");
-  CHX_REQUIRE(chunks >= 1 && (int64_t)chunks * g < (1 << 20), "bad force-list capacity");
+  CHX_REQUIRE(chunks >= 1 && (int64_t)chunks * CHX_FL_QUAD * g < (1 << 20), "bad force-list capacity");
   hipStream_t st = chx_stream(stream);
   CellGrid grid;
   int rc = chx_cell_prepare(xyz, n, box, cutoff_plus_skin, nc_h, cell_of, cell_count, cell_start,
@@ -212,7 +209,7 @@ extern "C" int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_
   float4* xs4 = reinterpret_cast<float4*>(xs4_out);
   hipLaunchKernelGGL(k_gather_sorted, dim3((n + 255) / 256), dim3(256), 0, st, xyz, sorted_ids, n, xs4);
   hipLaunchKernelGGL(k_nl_build_cell_fl, dim3(wb), dim3(256), 0, st, xs4, n, m, make_box3(box), T, grid,
-                     cell_of, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, chunks * g,
+                     cell_of, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, chunks * CHX_FL_QUAD * g,
                      fl_out, deg_out, status8);
   const unsigned sb = (unsigned)((n + 255) / 256 < 64 ? (n + 255) / 256 : 64);
   hipLaunchKernelGGL(k_nl_summary, dim3(sb), dim3(256), 0, st, n_nbr_out, deg_out, n, m, status8);

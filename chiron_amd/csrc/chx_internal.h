@@ -32,6 +32,14 @@ int chx_launch_lj_fl(const float* x4, const uint32_t* fl, const int32_t* deg, in
                      chx_box_t box, float sigma, float epsilon, float cutoff, float* f3,
                      float* energy, double* ws, int32_t* ctrl, hipStream_t st,
                      const chx_fl_select_t* select = nullptr);
+// Force-list addressing: a row is stored in chunks of W = CHX_FL_QUAD * g entries,
+// fl[chunk][particle][W], so lane q of the g lanes that own a particle reads its four
+// entries 4q..4q+3 of a chunk with one 16-byte load.
+#define CHX_FL_QUAD 4
+__device__ __forceinline__ size_t chx_fl_addr(int p, int k, int n, int g) {
+  const int w = CHX_FL_QUAD * g;
+  return ((size_t)(k / w) * (size_t)n + (size_t)p) * (size_t)w + (size_t)(k % w);
+}
 // number of per-block partials the list kernel leaves in ws for (n, g)
 static inline int chx_lj_fl_blocks(int n, int g) { return (int)(((int64_t)n * g + 255) / 256); }
 // n_steps fused [force + BAOAB] launches on the force list (k_lj_step); launch i reads

@@ -15,9 +15,6 @@
 // ---------------------------------------------------------------------------
 // force list construction
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ size_t fl_addr(int p, int k, int n, int g) {
-  return ((size_t)(k / g) * (size_t)n + (size_t)p) * (size_t)g + (size_t)(k % g);
-}
 
 __global__ __launch_bounds__(256) void k_fl_count(const uint32_t* __restrict__ nl,
                                                   const int32_t* __restrict__ n_nbr, int n, int m,
@@ -86,9 +83,9 @@ __global__ __launch_bounds__(256) void k_fl_fill(const uint32_t* __restrict__ nl
   for (int k = lane; k < cnt; k += CHX_WAVE) {
     const uint32_t j = nl[(size_t)i * m + k];  // j > i in original ids
     const uint32_t sj = inv ? inv[j] : j;
-    fl[fl_addr((int)si, base + k, n, g)] = sj | CHX_FL_HI;
+    fl[chx_fl_addr((int)si, base + k, n, g)] = sj | CHX_FL_HI;
     const int slot = atomicAdd(&cursor[sj], 1);
-    fl[fl_addr((int)sj, slot, n, g)] = si;
+    fl[chx_fl_addr((int)sj, slot, n, g)] = si;
   }
 }
 
@@ -119,7 +116,7 @@ __global__ __launch_bounds__(64) void k_fl_sort(uint32_t* __restrict__ fl,
   const int p = blockIdx.x * 64 + t;
   if (p >= n) return;
   const int d = deg[p];
-  for (int k = 0; k < d; ++k) tile[k * 64 + t] = fl[fl_addr(p, k, n, g)];
+  for (int k = 0; k < d; ++k) tile[k * 64 + t] = fl[chx_fl_addr(p, k, n, g)];
   for (int a = 1; a < d; ++a) {
     const uint32_t v = tile[a * 64 + t];
     const uint32_t key = v & ~CHX_FL_HI;
@@ -130,7 +127,7 @@ __global__ __launch_bounds__(64) void k_fl_sort(uint32_t* __restrict__ fl,
     }
     tile[(b + 1) * 64 + t] = v;
   }
-  for (int k = 0; k < d; ++k) fl[fl_addr(p, k, n, g)] = tile[k * 64 + t];
+  for (int k = 0; k < d; ++k) fl[chx_fl_addr(p, k, n, g)] = tile[k * 64 + t];
 }
 
 extern "C" int chx_fl_sort(uint32_t* fl, const int32_t* deg, int32_t n, int32_t g, int32_t maxdeg,
@@ -187,16 +184,7 @@ __device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nb) {
 }
 
 #define CHX_FL_INVALID 0xFFFFFFFFu
-#ifndef CHX_FL_UNROLL
-#define CHX_FL_UNROLL 4
-#endif
 
-// One particle's share of its force-list row: lane q of the G cooperating lanes walks
-// entries q, q+G, ...  Index loads, position gathers and arithmetic are issued in batches
-// of CHX_FL_UNROLL so the dependent round trips (entry -> xyz) overlap across entries.  The
-// first batch is requested together with the particle's own position and degree -- it is
-// bounded by the (uniform) number of chunks, not by the degree, and filtered afterwards;
-// slots past a row's end hold 0 (a valid index), so the speculative gathers are harmless.
 // ---------------------------------------------------------------------------
 // Two list entries per lane at a time, in packed fp32 (v_pk_add/mul/fma_f32: two IEEE
 // operations per issue slot, each rounded exactly like its scalar twin).
@@ -220,12 +208,13 @@ __device__ __forceinline__ f2 min_image2(f2 d, float L, float hL) {
   return m - hL;
 }
 
-// One particle's share of its force-list row: lane q of the G cooperating lanes walks
-// entries q, q+G, ...  Index loads, position gathers and arithmetic are issued in batches
-// of CHX_FL_UNROLL so the dependent round trips (entry -> xyz) overlap across entries.  The
-// first batch is requested together with the particle's own position and degree -- it is
-// bounded by the (uniform) number of chunks, not by the degree, and filtered afterwards;
-// slots past a row's end hold 0 (a valid index), so the speculative gathers are harmless.
+// One particle's share of its force-list row.  A row is stored in chunks of W = 4 G entries
+// (fl[chunk][particle][W]); lane q of the G cooperating lanes owns entries 4q..4q+3 of every
+// chunk and fetches them with ONE 16-byte load, so a wavefront reads 1 KB of contiguous index
+// data per instruction.  The first chunk is requested together with the particle's own
+// position and degree (slots past a row's end hold 0, a valid index, so the speculative
+// gathers are harmless); the index quad of chunk c+1 is requested before the arithmetic of
+// chunk c, so only the position gathers sit on the dependent-latency chain.
 //
 // The kernel is VALU-bound at large N (a wave64 op takes 4 cycles on a SIMD16), so the pair
 // arithmetic is branch-free and packed two entries wide; a lane that meets |d| >= L on some
@@ -235,37 +224,30 @@ __device__ __forceinline__ void lj_row(const float4* __restrict__ x4, const uint
                                        const int32_t* __restrict__ deg, int n, int chunks, int p, int q,
                                        bool valid, const Box3& box, const LJParams& lj, float4& xi_out,
                                        float& fx, float& fy, float& fz, float& en) {
-  static_assert(CHX_FL_UNROLL % 2 == 0, "entries are processed in pairs");
+  constexpr int W = 4 * G;
   const int pc = valid ? p : 0;
-  const size_t stride = (size_t)n * G;
-  const uint32_t* col = fl + (size_t)pc * G + q;
-  uint32_t ent[CHX_FL_UNROLL];
-  float4 xj[CHX_FL_UNROLL];
+  const size_t stride = (size_t)n * G;  // uint4 units between consecutive chunks
+  const uint4* col = reinterpret_cast<const uint4*>(fl) + (size_t)pc * G + q;
   const float4 xi = x4[pc];
   int d = deg[pc];
+  uint4 e4 = col[0];
+  uint32_t ent[4] = {e4.x, e4.y, e4.z, e4.w};
+  float4 xj[4];
 #pragma unroll
-  for (int u = 0; u < CHX_FL_UNROLL; ++u) ent[u] = (u < chunks) ? col[(size_t)u * stride] : 0u;
-#pragma unroll
-  for (int u = 0; u < CHX_FL_UNROLL; ++u) xj[u] = x4[ent[u] & ~CHX_FL_HI];
+  for (int u = 0; u < 4; ++u) xj[u] = x4[ent[u] & ~CHX_FL_HI];
   d = valid ? d : 0;
   xi_out = xi;
-  const int nt = (d + G - 1) / G;
+  const int nc = (d + W - 1) / W;
   f2 ax = f2_splat(0.f), ay = f2_splat(0.f), az = f2_splat(0.f), ae = f2_splat(0.f);
   bool bad = false;
-  for (int t0 = 0; t0 < nt; t0 += CHX_FL_UNROLL) {
-    if (t0 > 0) {
+  for (int c = 0; c < nc; ++c) {
+    const int k0 = c * W + 4 * q;  // this lane's first entry of the chunk
+    uint4 nx = make_uint4(0u, 0u, 0u, 0u);
+    if (c + 1 < nc) nx = col[(size_t)(c + 1) * stride];
 #pragma unroll
-      for (int u = 0; u < CHX_FL_UNROLL; ++u) {
-        const int k = (t0 + u) * G + q;
-        ent[u] = (k < d) ? col[(size_t)(t0 + u) * stride] : 0u;
-      }
-#pragma unroll
-      for (int u = 0; u < CHX_FL_UNROLL; ++u) xj[u] = x4[ent[u] & ~CHX_FL_HI];
-    }
-#pragma unroll
-    for (int u = 0; u < CHX_FL_UNROLL; u += 2) {
-      const bool act0 = (t0 + u) * G + q < d;
-      const bool act1 = (t0 + u + 1) * G + q < d;
+    for (int u = 0; u < 4; u += 2) {
+      const bool act0 = k0 + u < d;
+      const bool act1 = k0 + u + 1 < d;
       if (!act0) continue;  // act1 implies act0
       // orientation: r = x_lo - x_hi by ORIGINAL id = +-(xi - xj); multiplying by +-1 is exact
       const f2 sgn = {(ent[u] & CHX_FL_HI) ? 1.0f : -1.0f, (ent[u + 1] & CHX_FL_HI) ? 1.0f : -1.0f};
@@ -297,27 +279,35 @@ __device__ __forceinline__ void lj_row(const float4* __restrict__ x4, const uint
       az = __builtin_elementwise_fma(fs, rz, az);
       ae += e;
     }
+    if (c + 1 < nc) {
+      ent[0] = nx.x, ent[1] = nx.y, ent[2] = nx.z, ent[3] = nx.w;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xj[u] = x4[ent[u] & ~CHX_FL_HI];
+    }
   }
   if (__builtin_expect(bad, 0)) {
     // general path, one entry at a time (bit-identical to the fast path wherever that is valid)
     ax = ay = az = ae = f2_splat(0.f);
-    for (int t = 0; t < nt; ++t) {
-      if (t * G + q >= d) break;
-      const uint32_t en_t = col[(size_t)t * stride];
-      const float4 xo = x4[en_t & ~CHX_FL_HI];
-      const bool hi = (en_t & CHX_FL_HI) != 0u;
-      float gx, gy, gz;
-      displacement_oriented(box, hi, xi.x, xi.y, xi.z, xo.x, xo.y, xo.z, gx, gy, gz);
-      const float g2 = norm2(gx, gy, gz);
-      if (g2 <= lj.T) {
-        float e, fs;
-        lj_pair(g2, lj.sig2, lj.eps4, lj.eps24, e, fs);
-        if (!hi) fs = -fs;
-        const int h = t & 1;  // same accumulator parity as the fast path
-        ax[h] = __builtin_fmaf(fs, gx, ax[h]);
-        ay[h] = __builtin_fmaf(fs, gy, ay[h]);
-        az[h] = __builtin_fmaf(fs, gz, az[h]);
-        ae[h] += e;
+    const uint32_t* row = fl + ((size_t)pc * G + q) * 4;
+    for (int c = 0; c < nc; ++c) {
+      for (int u = 0; u < 4; ++u) {
+        if (c * W + 4 * q + u >= d) break;
+        const uint32_t en_t = row[(size_t)c * stride * 4 + u];
+        const float4 xo = x4[en_t & ~CHX_FL_HI];
+        const bool hi = (en_t & CHX_FL_HI) != 0u;
+        float gx, gy, gz;
+        displacement_oriented(box, hi, xi.x, xi.y, xi.z, xo.x, xo.y, xo.z, gx, gy, gz);
+        const float g2 = norm2(gx, gy, gz);
+        if (g2 <= lj.T) {
+          float e, fs;
+          lj_pair(g2, lj.sig2, lj.eps4, lj.eps24, e, fs);
+          if (!hi) fs = -fs;
+          const int h = u & 1;  // same accumulator parity as the fast path
+          ax[h] = __builtin_fmaf(fs, gx, ax[h]);
+          ay[h] = __builtin_fmaf(fs, gy, ay[h]);
+          az[h] = __builtin_fmaf(fs, gz, az[h]);
+          ae[h] += e;
+        }
       }
     }
   }

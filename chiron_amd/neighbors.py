@@ -212,7 +212,7 @@ class NeighborListNsqrd(PairsBase):
         rho = n / (b.lx * b.ly * b.lz)
         expected = rho * 4.18879 * self._cutoff_and_skin ** 3
         g = ops._choose_g(int(1.2 * expected) + 4, n)
-        chunks = max(1, -(-(int(1.6 * expected) + 24) // g))
+        chunks = ops.fl_chunks_for(int(1.6 * expected) + 24, g)
         self._fl_geo = (n, g, chunks)
         return g, chunks
 
@@ -236,7 +236,7 @@ class NeighborListNsqrd(PairsBase):
                         break
                     if st[4] > 0:  # some force-list row did not fit: grow the (sticky) capacity
                         g = ops._choose_g(st[3], n)
-                        chunks = max(-(-st[3] // g) + 2, -(-(3 * chunks * g // 2) // g))
+                        chunks = max(ops.fl_chunks_for(st[3] + 8, g), -(-3 * chunks // 2))
                         self._fl_geo = (n, g, chunks)
                         continue
                     self._last_maxdeg = st[3]

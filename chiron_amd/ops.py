@@ -164,7 +164,7 @@ def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: in
     cell_start = torch.empty((ncell + 1,), **i32)
     sorted_ids = torch.empty((n,), **i32)
     status = torch.empty((8,), **i32)
-    fl = torch.empty((chunks, n, g), **i32)
+    fl = torch.empty((chunks, n, FL_QUAD * g), **i32)
     deg = torch.empty((n,), **i32)
     xs4 = torch.empty((n, 4), dtype=torch.float32, device=dev)
     check(
@@ -262,6 +262,13 @@ def pl_calculate(xyz, box: Box, cutoff: Optional[float]):
 # ---------------------------------------------------------------------------
 # force list + LJ kernels
 # ---------------------------------------------------------------------------
+FL_QUAD = 4  # entries per lane per chunk: a force-list row is stored in chunks of FL_QUAD * g entries
+
+
+def fl_chunks_for(maxdeg: int, g: int) -> int:
+    return max(1, -(-int(maxdeg) // (FL_QUAD * g)))
+
+
 def _choose_g(maxdeg: int, n: int) -> int:
     """Lanes that cooperate on one particle in the list kernel.
 
@@ -315,9 +322,9 @@ class ForceList:
         check(lib.chx_fl_count(_ptr(nl), _ptr(n_nbr), n, m, _ptr(self.inv), _ptr(self.deg), _ptr(maxdeg_t), _stream()), "chx_fl_count")
         self.maxdeg = int(maxdeg_t.item())  # build-time sync (the reference syncs here too, neighbors.py:709)
         self.g = _choose_g(self.maxdeg, n)
-        chunks = max(1, -(-self.maxdeg // self.g))
+        chunks = fl_chunks_for(self.maxdeg, self.g)
         self.chunks = chunks
-        self.fl = torch.zeros((chunks, n, self.g), dtype=torch.int32, device=dev)  # zero = a valid index
+        self.fl = torch.zeros((chunks, n, FL_QUAD * self.g), dtype=torch.int32, device=dev)  # zero = a valid index
         cursor = torch.empty((n,), dtype=torch.int32, device=dev)
         check(lib.chx_fl_fill(_ptr(nl), _ptr(n_nbr), n, m, _ptr(self.inv), self.g, _ptr(cursor), _ptr(self.fl), _stream()), "chx_fl_fill")
         rc = lib.chx_fl_sort(_ptr(self.fl), _ptr(self.deg), n, self.g, self.maxdeg, _stream())

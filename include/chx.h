@@ -94,7 +94,7 @@ int chx_nl_build_cell(const float* xyz, int32_t n, int32_t m, chx_box_t box, flo
  * (nl_rows_out[i, :min(n_nbr[i], m)]), with first_out[i] = smallest neighbor id (or
  * 0xFFFFFFFF) so that chx_nl_finish_padding can later produce the reference's padding
  * (chiron/neighbors.py:603-620) and mask (:623) if somebody reads them, and (b) the
- * force list (layout above, internal order = sorted_ids, g lanes, capacity chunks*g
+ * force list (layout above, internal order = sorted_ids, g lanes, capacity chunks*4*g
  * entries per particle, unused slots = 0) and deg_out[n] are emitted directly, in scan
  * order, without atomics.  status8 (out): [0] != 0 -> a half row overflowed the on-chip
  * candidate buffer (nothing valid); [1] max n_nbr; [2] number of rows with n_nbr == m
@@ -136,9 +136,11 @@ int chx_pl_calculate(const float* xyz, int32_t n, chx_box_t box, float cutoff,
 /* ----------------------------------------------------- LJ energy and force */
 /* Force list: an internal FULL neighbor table derived from the public half
  * list, laid out for the force kernel: particle p (internal order, p =
- * inv[original id], inv may be NULL = identity) owns deg[p] entries; entry k
- * lives at fl[((k / g) * n + p) * g + (k % g)], g lanes cooperate on one
- * particle.  Entry = internal index of the neighbor | CHX_FL_HI when the
+ * inv[original id], inv may be NULL = identity) owns deg[p] entries; g lanes
+ * cooperate on one particle and a row is stored in chunks of W = 4 g entries:
+ * entry k lives at fl[((k / W) * n + p) * W + (k % W)], so lane q reads its
+ * entries 4q..4q+3 of a chunk with one 16-byte load (fl must be 16-byte
+ * aligned).  Entry = internal index of the neighbor | CHX_FL_HI when the
  * neighbor's ORIGINAL id is the larger one (the pair is then stored in this
  * particle's row of the reference half list and r_ij = x_p - x_q as in
  * chiron/neighbors.py:777-779; otherwise r_ij = x_q - x_p and the force on p
@@ -170,7 +172,7 @@ int chx_pack_langevin(const float* x3, const float* v3, const float* mass, const
  * (chiron/potential.py:193-213, :260-279), F = -dE/dx (chiron/potential.py:21-24,
  * closed form :322-332).  x4 is (n,4) in internal order; force3_out (n,3) in
  * internal order (NULL = energy only); energy_out[1] (NULL = force only);
- * chunks = allocated chunks of fl (fl holds chunks*n*g entries, slots past a row's
+ * chunks = allocated chunks of fl (fl holds chunks*n*4*g entries, slots past a row's
  * end must hold a valid index, e.g. 0: the kernel loads the first entries of every
  * row before it knows the row's length); ws: >= chx_lj_ws_count(n) doubles. */
 int64_t chx_lj_ws_count(int32_t n);
@@ -219,7 +221,7 @@ typedef struct {
   double* ws;            /* energy workspace, >= chx_lj_ws_count(n) */
   int32_t external_force; /* != 0: do not launch the LJ force kernel (the caller fills f
                              between single-step chunks: IdealGasPotential and other potentials) */
-  int32_t fl_chunks;      /* allocated chunks of the force list: fl holds fl_chunks * n * g entries */
+  int32_t fl_chunks;      /* allocated chunks of the force list: fl holds fl_chunks * n * 4 * g entries */
 } chx_langevin_t;
 
 /* Enqueue n_steps BAOAB steps (chiron/integrators.py:179-195) starting at global
