@@ -137,6 +137,11 @@ SIGNATURES = {
         [_P, _P, _I64, _P, _P, _P, _U32, _U32, _U32, _F, _P, _P, _P],
     ),
     "chx_mc_displace_chunk": (C.c_int, [_P, _I64, _I32, _P]),
+    "chx_lj_nl_energy_force": (C.c_int, [_P, _P, _P, _I32, _I32, Box, _F, _F, _F, _P, _P, _P, _P]),
+    "chx_baoab_step": (
+        C.c_int,
+        [_P, _P, _P, _P, _I32, Box, _I32, _F, _F, _F, _F, _P, _F, _U32, _U32, _U32, _P, _P, _P],
+    ),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -146,6 +146,65 @@ __global__ __launch_bounds__(256) void k_baoab(BaoabArgs p, long long step, int 
   }
 }
 
+// One BAOAB update on plain user-order (n,3) arrays: the body of the reference's loop
+// (chiron/integrators.py:181-188, wrap :239, skin check :241) for callers that drive the loop
+// themselves and evaluate the force in between.
+__global__ __launch_bounds__(256) void k_baoab3(float* __restrict__ x, float* __restrict__ v,
+                                                const float* __restrict__ f, const float* __restrict__ mass,
+                                                int n, float hdt, float a, float b, float kT, Box3 box,
+                                                int wrap, const float* __restrict__ ref, float T_half_skin,
+                                                uint32_t k0, uint32_t k1, uint32_t step,
+                                                const float* __restrict__ noise, int32_t* __restrict__ flag) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= n) return;
+  const float m = mass[s];
+  float z[3];
+  if (noise) {
+    z[0] = noise[3 * (size_t)s], z[1] = noise[3 * (size_t)s + 1], z[2] = noise[3 * (size_t)s + 2];
+  } else {
+    philox_normals3((uint32_t)s, step, CHX_STREAM_LANGEVIN, k0, k1, z[0], z[1], z[2]);
+  }
+  const float bs = fmul(b, fsqrt(fdiv(kT, m)));
+  const float L[3] = {box.lx, box.ly, box.lz};
+  float xn[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float vc = fadd(v[3 * (size_t)s + c], fdiv(fmul(hdt, f[3 * (size_t)s + c]), m));  // B  :181
+    float xc = fadd(x[3 * (size_t)s + c], fmul(hdt, vc));                              // A  :183
+    vc = fadd(fmul(a, vc), fmul(bs, z[c]));                                           // O  :186
+    xc = fadd(xc, fmul(hdt, vc));                                                      // A  :188
+    if (wrap && box.periodic) xc = wrap1(xc, L[c]);                                   // :239
+    x[3 * (size_t)s + c] = xc;
+    v[3 * (size_t)s + c] = vc;
+    xn[c] = xc;
+  }
+  if (ref && flag) {
+    float rx, ry, rz;
+    displacement(box, xn[0], xn[1], xn[2], ref[3 * (size_t)s], ref[3 * (size_t)s + 1], ref[3 * (size_t)s + 2],
+                 rx, ry, rz);
+    if (norm2(rx, ry, rz) > T_half_skin) flag[0] = 1;  // :241, chiron/neighbors.py:868
+  }
+}
+
+extern "C" int chx_baoab_step(float* x, float* v, const float* f, const float* mass, int32_t n,
+                              chx_box_t box, int32_t wrap, float half_dt, float a, float b, float kT,
+                              const float* ref_xyz, float skin, uint32_t k0, uint32_t k1, uint32_t step,
+                              const float* noise, int32_t* rebuild_flag_out, chx_stream_t stream) {
+  CHX_REQUIRE(n >= 0, "n < 0");
+  hipStream_t st = chx_stream(stream);
+  if (rebuild_flag_out && hipMemsetAsync(rebuild_flag_out, 0, sizeof(int32_t), st) != hipSuccess) {
+    chx_set_error("chx_baoab_step: hipMemsetAsync failed");
+    return CHX_ERR_LAUNCH;
+  }
+  if (n == 0) return CHX_OK;
+  CHX_REQUIRE(x && v && f && mass, "null pointer");
+  CHX_REQUIRE(!box.periodic || (box.lx > 0 && box.ly > 0 && box.lz > 0), "box lengths must be > 0");
+  hipLaunchKernelGGL(k_baoab3, dim3((n + 255) / 256), dim3(256), 0, st, x, v, f, mass, n, half_dt, a, b, kT,
+                     make_box3(box), wrap, ref_xyz, chx_cutoff_threshold_h(skin * 0.5f), k0, k1, step, noise,
+                     rebuild_flag_out);
+  return chx_check_launch("chx_baoab_step");
+}
+
 static int validate_langevin(const chx_langevin_t* p) {
   CHX_REQUIRE(p, "null params");
   CHX_REQUIRE(p->n >= 1, "n < 1");

@@ -639,6 +639,95 @@ extern "C" int chx_lj_fl_energy_force(const float* x4, const uint32_t* fl, const
 }
 
 // ---------------------------------------------------------------------------
+// Direct evaluation on the PUBLIC half list (chiron/potential.py:260-279 on the arrays of
+// chiron/neighbors.py:617-626), for callers that hold only (neighbor_list, n_neighbors):
+// one wavefront per row, the row's own force reduced in registers, the reaction scattered
+// with float atomics (summation order of the forces is therefore not reproducible; the
+// energy is).  The hot loops never use this: they run on the force list above.
+// ---------------------------------------------------------------------------
+template <bool WANT_F, bool WANT_E>
+__global__ __launch_bounds__(256) void k_lj_nl(const float* __restrict__ x, const uint32_t* __restrict__ nl,
+                                               const int32_t* __restrict__ n_nbr, int n, int m, Box3 box,
+                                               LJParams lj, float* __restrict__ f3, double* __restrict__ ws) {
+  const int lane = lane_id();
+  const int i = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
+  if (i < n) {
+    int cnt = n_nbr[i];
+    cnt = cnt < m ? cnt : m;
+    const float xi = x[3 * (size_t)i], yi = x[3 * (size_t)i + 1], zi = x[3 * (size_t)i + 2];
+    for (int k = lane; k < cnt; k += CHX_WAVE) {
+      const uint32_t j = nl[(size_t)i * m + k];
+      float rx, ry, rz;  // r_ij = x_i - x_j with i < j, as chiron/neighbors.py:777-779
+      displacement(box, xi, yi, zi, x[3 * (size_t)j], x[3 * (size_t)j + 1], x[3 * (size_t)j + 2], rx, ry, rz);
+      const float r2 = norm2(rx, ry, rz);
+      if (r2 <= lj.T) {
+        float e, fs;
+        lj_pair(r2, lj.sig2, lj.eps4, lj.eps24, e, fs);
+        en += e;
+        if (WANT_F) {
+          fx = __builtin_fmaf(fs, rx, fx);
+          fy = __builtin_fmaf(fs, ry, fy);
+          fz = __builtin_fmaf(fs, rz, fz);
+          atomicAdd(&f3[3 * (size_t)j], -fs * rx);
+          atomicAdd(&f3[3 * (size_t)j + 1], -fs * ry);
+          atomicAdd(&f3[3 * (size_t)j + 2], -fs * rz);
+        }
+      }
+    }
+    if (WANT_F) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        fx += __shfl_xor(fx, o, CHX_WAVE);
+        fy += __shfl_xor(fy, o, CHX_WAVE);
+        fz += __shfl_xor(fz, o, CHX_WAVE);
+      }
+      if (lane == 0 && cnt > 0) {
+        atomicAdd(&f3[3 * (size_t)i], fx);
+        atomicAdd(&f3[3 * (size_t)i + 1], fy);
+        atomicAdd(&f3[3 * (size_t)i + 2], fz);
+      }
+    }
+  }
+  if (WANT_E) {
+    double mine = block_sum<256>((double)en);
+    if (threadIdx.x == 0) ws[blockIdx.x] = mine;
+  }
+}
+
+extern "C" int chx_lj_nl_energy_force(const float* xyz, const uint32_t* nl, const int32_t* n_nbr,
+                                      int32_t n, int32_t m, chx_box_t box, float sigma, float epsilon,
+                                      float cutoff, float* energy_out, float* force_out, double* ws,
+                                      chx_stream_t stream) {
+  CHX_REQUIRE(n >= 0 && m >= 1, "need n >= 0, m >= 1");
+  CHX_REQUIRE(force_out || energy_out, "nothing to compute");
+  CHX_REQUIRE(!energy_out || ws, "energy needs a workspace");
+  hipStream_t st = chx_stream(stream);
+  if (n == 0) {
+    if (energy_out) (void)hipMemsetAsync(energy_out, 0, sizeof(float), st);
+    return CHX_OK;
+  }
+  CHX_REQUIRE(xyz && nl && n_nbr, "null pointer");
+  CHX_REQUIRE(!box.periodic || (box.lx > 0 && box.ly > 0 && box.lz > 0), "box lengths must be > 0");
+  if (force_out && hipMemsetAsync(force_out, 0, sizeof(float) * 3 * (size_t)n, st) != hipSuccess) {
+    chx_set_error("chx_lj_nl_energy_force: hipMemsetAsync failed");
+    return CHX_ERR_LAUNCH;
+  }
+  const Box3 b3 = make_box3(box);
+  const LJParams lj = make_lj(sigma, epsilon, cutoff);
+  const unsigned blocks = (unsigned)(((int64_t)n * CHX_WAVE + 255) / 256);  // <= chx_lj_ws_count(n)
+  if (force_out && energy_out) {
+    hipLaunchKernelGGL((k_lj_nl<true, true>), dim3(blocks), dim3(256), 0, st, xyz, nl, n_nbr, n, m, b3, lj, force_out, ws);
+  } else if (force_out) {
+    hipLaunchKernelGGL((k_lj_nl<true, false>), dim3(blocks), dim3(256), 0, st, xyz, nl, n_nbr, n, m, b3, lj, force_out, ws);
+  } else {
+    hipLaunchKernelGGL((k_lj_nl<false, true>), dim3(blocks), dim3(256), 0, st, xyz, nl, n_nbr, n, m, b3, lj, force_out, ws);
+  }
+  if (energy_out) hipLaunchKernelGGL(k_sum_ws, dim3(1), dim3(256), 0, st, ws, (int)blocks, energy_out);
+  return chx_check_launch("chx_lj_nl_energy_force");
+}
+
+// ---------------------------------------------------------------------------
 // all-pairs kernel: 16 lanes per particle (4 particles per wavefront, 16 per
 // block), j-tiles of 256 particles staged through LDS
 // ---------------------------------------------------------------------------

@@ -365,6 +365,40 @@ class ForceList:
         return f3, e
 
 
+def lj_nl_energy_force(xyz: torch.Tensor, nl: torch.Tensor, n_nbr: torch.Tensor, box: Box, sigma: float,
+                       epsilon: float, cutoff: float, want_force: bool = True, want_energy: bool = True):
+    """Energy/force straight from the public half list (no force list; atomics for the reaction)."""
+    xyz = _f32(xyz)
+    _require_device(xyz, nl, n_nbr)
+    lib = _lib.load()
+    n, m = nl.shape
+    dev = xyz.device
+    f = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_force else None
+    e = torch.empty((1,), dtype=torch.float32, device=dev) if want_energy else None
+    ws = torch.empty((int(lib.chx_lj_ws_count(n)),), dtype=torch.float64, device=dev)
+    check(
+        lib.chx_lj_nl_energy_force(_ptr(xyz), _ptr(nl), _ptr(n_nbr), n, m, box, C.c_float(sigma), C.c_float(epsilon),
+                                   C.c_float(cutoff), _ptr(e), _ptr(f), _ptr(ws), _stream()),
+        "chx_lj_nl_energy_force",
+    )
+    return f, e
+
+
+def baoab_step(x: torch.Tensor, v: torch.Tensor, f: torch.Tensor, mass: torch.Tensor, half_dt: float, a: float,
+               b: float, kT: float, box: Box, wrap: bool, ref: Optional[torch.Tensor], skin: float, key: PRNGKey,
+               step: int, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One in-place BAOAB update on user-order arrays; returns the device rebuild flag (int32[1])."""
+    _require_device(x, v, f, mass, ref, noise)
+    flag = torch.empty((1,), dtype=torch.int32, device=x.device)
+    check(
+        _lib.load().chx_baoab_step(_ptr(x), _ptr(v), _ptr(f), _ptr(mass), x.shape[0], box, int(bool(wrap)),
+                                   C.c_float(half_dt), C.c_float(a), C.c_float(b), C.c_float(kT), _ptr(ref), C.c_float(skin),
+                                   key[0], key[1], int(step) & 0xFFFFFFFF, _ptr(noise), _ptr(flag), _stream()),
+        "chx_baoab_step",
+    )
+    return flag
+
+
 def lj_allpairs(xyz: torch.Tensor, box: Box, sigma: float, epsilon: float, cutoff: Optional[float],
                 want_force: bool = True, want_energy: bool = True):
     xyz = _f32(xyz)

@@ -14,7 +14,11 @@
  *     are asynchronous; no entry point allocates or synchronises unless it says so.
  *   - return value: 0 = CHX_OK, negative = error (chx_last_error() has text).
  *   - arrays are C-contiguous fp32 / int32 / uint32; xyz arrays are (n,3).
- *   - boxes are orthorhombic: chx_box_t{periodic, lx, ly, lz} by value.
+ *   - boxes are orthorhombic: chx_box_t{periodic, lx, ly, lz} by value.  In every
+ *     signature the box comes BEFORE any scalar float argument unless fewer than five
+ *     integer/pointer arguments precede it: some libffi builds (ctypes, cgo-less FFIs)
+ *     mis-marshal a mixed int/float struct that takes the last integer register after
+ *     float registers are already in use.
  */
 #ifndef CHX_H
 #define CHX_H
@@ -180,6 +184,15 @@ int chx_lj_fl_energy_force(const float* x4, const uint32_t* fl, const int32_t* d
                            int32_t g, int32_t chunks, chx_box_t box, float sigma, float epsilon, float cutoff,
                            float* force3_out, float* energy_out, double* ws, chx_stream_t stream);
 
+/* The same energy / force evaluated directly on the PUBLIC half list (neighbor_list (n,m),
+ * n_neighbors (n), user order, xyz (n,3)) -- chiron/potential.py:260-279 on the arrays of
+ * chiron/neighbors.py:617-626 -- for callers that do not keep a force list.  One wavefront
+ * per row; reaction forces are scattered with float atomics, so the force summation order
+ * is not reproducible (the energy is).  force_out (n,3) or NULL, energy_out[1] or NULL. */
+int chx_lj_nl_energy_force(const float* xyz, const uint32_t* nl, const int32_t* n_nbr, int32_t n,
+                           int32_t m, chx_box_t box, float sigma, float epsilon, float cutoff,
+                           float* energy_out, float* force_out, double* ws, chx_stream_t stream);
+
 /* All-pairs kernel: the nbr_list=None branch (no PBC, chiron/potential.py:26-63,
  * :235-258) and the PairListNsqrd branch (PBC, chiron/neighbors.py:1106-1216).
  * cutoff < 0: no cutoff.  xyz/force are (n,3) in user order. */
@@ -223,6 +236,16 @@ typedef struct {
                              between single-step chunks: IdealGasPotential and other potentials) */
   int32_t fl_chunks;      /* allocated chunks of the force list: fl holds fl_chunks * n * 4 * g entries */
 } chx_langevin_t;
+
+/* One BAOAB update on user-order (n,3) arrays, in place: v += half_dt F/m; x += half_dt v;
+ * v = a v + b sqrt(kT/m) xi; x += half_dt v; [wrap]; rebuild_flag_out[0] = any particle moved
+ * >= skin/2 from ref_xyz (chiron/integrators.py:181-188, :239-241).  xi = noise (n,3) if
+ * given, else Philox stream 1 at counter (particle, step).  The caller evaluates the force
+ * and applies the trailing chx_kick (:193-195).  ref_xyz / rebuild_flag_out may be NULL. */
+int chx_baoab_step(float* x, float* v, const float* f, const float* mass, int32_t n, chx_box_t box,
+                   int32_t wrap, float half_dt, float a, float b, float kT, const float* ref_xyz,
+                   float skin, uint32_t k0, uint32_t k1, uint32_t step, const float* noise,
+                   int32_t* rebuild_flag_out, chx_stream_t stream);
 
 /* Enqueue n_steps BAOAB steps (chiron/integrators.py:179-195) starting at global
  * step index step0: per step one fused integrate kernel [n_kicks x B, A, O, A,

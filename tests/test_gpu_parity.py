@@ -479,6 +479,60 @@ def test_lj_pairlist_and_nolist(ca, O, methane_coords, golden):
     assert abs(float(e) - g["build_crosscheck_energy_kj_mol"]) < 0.2
 
 
+def test_lj_nl_direct_half_list_kernel(ca, O):
+    """chx_lj_nl_energy_force: energy/force straight from (neighbor_list, n_neighbors) -- the arrays the
+    reference itself would hand over -- agree with the fp64 brute force and with the force-list path."""
+    u = ca.unit
+    for seed, n, rho in ((5, 700, 0.3), (6, 1500, 0.05)):
+        x, box = O.lj_lattice(n, rho, SIGMA, seed=seed)
+        for cls_name in ("NeighborListNsqrd", "NeighborListCell"):
+            nbr = getattr(ca.neighbors, cls_name)(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+                                                  skin=SKIN * u.nanometer, n_max_neighbors=180)
+            nbr.build(x, box)
+            x2 = (x + np.random.default_rng(seed).normal(0, 0.03, size=x.shape)).astype(f32)
+            f, e = ca.ops.lj_nl_energy_force(dev(x2), nbr.neighbor_list, nbr.n_neighbors, nbr._box_h, SIGMA, EPS, CUTOFF)
+            _check_vs_f64(O, e[0], f.cpu().numpy(), x2, box, SIGMA, EPS, CUTOFF)
+            pot = lj_pot(ca, n)
+            e_fl, f_fl = pot.compute_energy_and_force(x2, nbr)
+            assert np.isclose(float(e[0]), float(e_fl), rtol=2e-6)
+            assert np.abs(f.cpu().numpy() - f_fl.cpu().numpy()).max() < 1e-4 * max(1.0, np.abs(f_fl.cpu().numpy()).max())
+            f_only, none = ca.ops.lj_nl_energy_force(dev(x2), nbr.neighbor_list, nbr.n_neighbors, nbr._box_h, SIGMA, EPS,
+                                                     CUTOFF, want_energy=False)
+            assert none is None and np.allclose(f_only.cpu().numpy(), f.cpu().numpy(), atol=1e-3)
+
+
+def test_baoab_step_entry_point_bitexact(ca, O):
+    """chx_baoab_step on user-order arrays: B-A-O-A, wrap and the skin flag, bit for bit against the fp32
+    restatement of chiron/integrators.py:181-188, :239-241 with injected noise."""
+    from chiron_amd.rng import PRNGKey
+
+    n = 777
+    x, box = O.lj_lattice(n, 0.4, SIGMA, seed=12)
+    rng = np.random.default_rng(8)
+    mass = rng.uniform(1.0, 40.0, n).astype(f32)
+    kT, a, b = O.langevin_constants(300.0, 0.002, 1.0)
+    v = O.initial_velocities(mass, kT, rng.normal(size=(n, 3)).astype(f32))
+    F = rng.normal(0, 300.0, size=(n, 3)).astype(f32)
+    noise = rng.normal(size=(n, 3)).astype(f32)
+    xo, vo = O.baoa_half(x, v, F, mass, 0.002, a, b, kT, noise)
+    xo = O.periodic_wrap(xo, box)
+    bx = ca.ops.make_box(box, True)
+    key = PRNGKey(3, 4)
+    for skin in (10.0, 1e-4):
+        xd, vd = dev(x).clone(), dev(v).clone()
+        flag = ca.ops.baoab_step(xd, vd, dev(F), dev(mass), 0.001, float(a), float(b), float(np.float32(kT)), bx, True,
+                                 dev(x), skin, key, 0, dev(noise))
+        assert np.array_equal(xd.cpu().numpy(), xo) and np.array_equal(vd.cpu().numpy(), vo)
+        assert bool(flag.item()) == O.neighborlist_check(xo, x, box, skin)
+    # device noise: same stream as the integrator (Philox stream 1 at counter (particle, step))
+    xd, vd = dev(x).clone(), dev(v).clone()
+    ca.ops.baoab_step(xd, vd, dev(F), dev(mass), 0.001, float(a), float(b), float(np.float32(kT)), bx, True, None, 1.0, key, 7)
+    z = O.philox_normals3(n, 7, O.STREAM_LANGEVIN, key)
+    x1, v1 = O.baoa_half(x, v, F, mass, 0.002, a, b, kT, z)
+    assert np.allclose(vd.cpu().numpy(), v1, rtol=1e-4, atol=1e-5)
+    assert np.allclose(xd.cpu().numpy(), O.periodic_wrap(x1, box), atol=1e-5)
+
+
 def test_lj_empty_and_tiny(ca):
     u = ca.unit
     pot = lj_pot(ca, 2)
@@ -765,6 +819,137 @@ def test_ideal_gas_barostat(ca):
     assert 5 <= move.statistics["n_accepted"] <= 10  # the reference's 8/10 depends on the JAX stream
     # positions scaled with the box
     assert np.isclose(float(state.box_vectors[0][0]) ** 3, vol[-1], rtol=1e-4)
+
+
+def _methane_system(ca, golden, methane_coords, nbr_kind):
+    """Examples/LJ_MCMC.py:10-93: united-atom methane, 1100 beads, NPT state at 140 K / 13 atm."""
+    u = ca.unit
+    from chiron_amd.topology import Element, Topology
+
+    g = golden["methane"]
+    top = Topology()
+    element = Element(1000, "CH4", "CH4", u.Quantity(16.04, u.gram / u.mole))
+    chain = top.addChain()
+    for _ in range(1100):
+        residue = top.addResidue("CH4", chain)
+        top.addAtom("CH4", element, residue)
+    pot = ca.potential.LJPotential(top, sigma=g["sigma"] * u.nanometer,
+                                   epsilon=g["epsilon_kcal_mol"] * u.kilocalories_per_mole,
+                                   cutoff=g["cutoff"] * u.nanometer)
+    thermo = ca.states.ThermodynamicState(potential=pot, temperature=140 * u.kelvin, pressure=13.00765 * u.atmosphere)
+    L = g["box_edge"]
+    ca.utils.PRNG.set_seed(1234)
+    state = ca.states.SamplerState(positions=nm(methane_coords.astype(f32), ca), current_PRNG_key=ca.utils.PRNG.get_random_key(),
+                                   box_vectors=nm(np.diag([L, L, L]).astype(f32), ca))
+    space = ca.neighbors.OrthogonalPeriodicSpace()
+    if nbr_kind == "pairlist":
+        nbr = ca.neighbors.PairListNsqrd(space, cutoff=g["cutoff"] * u.nanometer)
+    else:
+        nbr = ca.neighbors.NeighborListCell(space, cutoff=g["cutoff"] * u.nanometer, skin=0.3 * u.nanometer, n_max_neighbors=250)
+    nbr.build_from_state(state)
+    return pot, thermo, state, nbr, g
+
+
+def test_lj_barostat_proposal_matches_oracle(ca, O, golden, methane_coords):
+    """One MonteCarloBarostatMove proposal on the LJ_MCMC system: scaled coordinates/box, forced list
+    rebuild and log_proposal_ratio = -(u' - u) + N ln(V'/V) (chiron/mcmc.py:913-1009) vs the fp64 oracle."""
+    u = ca.unit
+    from chiron_amd.rng import split, uniform
+
+    pot, thermo, state, nbr, g = _methane_system(ca, golden, methane_coords, "cell")
+    move = ca.mcmc.MonteCarloBarostatMove(volume_max_scale=0.02, number_of_moves=1)
+    key_before = state._current_PRNG_key
+    u_cur = thermo.get_reduced_potential(state, nbr)
+    prop, _, u_prop, lpr, nbr_prop = move._propose(state, thermo, u_cur, nbr)
+    # the proposal the host logic must have made from the key chain
+    _, sub = split(key_before)
+    L = g["box_edge"]
+    v0 = float(np.float32(L)) ** 3
+    dv = (2.0 * uniform(sub) - 1.0) * 0.02 * v0
+    scale = ((v0 + dv) / v0) ** (1.0 / 3.0)
+    x0 = methane_coords.astype(f32)
+    assert np.array_equal(prop.positions.cpu().numpy(), x0 * np.float32(scale))
+    assert np.allclose(prop.box_vectors.cpu().numpy(), np.diag([L, L, L]).astype(f32) * np.float32(scale), rtol=1e-7)
+    assert nbr_prop is not nbr and np.array_equal(nbr_prop.ref_positions.cpu().numpy(), prop.positions.cpu().numpy())
+    # energies against the fp64 brute force at both volumes
+    eps = g["epsilon_kcal_mol"] * 4.184
+    e0 = O.lj_bruteforce_f64(x0, np.diag([L, L, L]).astype(f32), g["sigma"], eps, g["cutoff"])[0]
+    bx1 = prop.box_vectors.cpu().numpy()
+    e1 = O.lj_bruteforce_f64(prop.positions.cpu().numpy(), bx1, g["sigma"], eps, g["cutoff"])[0]
+    v1 = float(np.float64(bx1[0, 0]) * np.float64(bx1[1, 1]) * np.float64(bx1[2, 2]))
+    u0 = O.reduced_potential(e0, 140.0, 13.00765, v0)
+    u1 = O.reduced_potential(e1, 140.0, 13.00765, v1)
+    assert np.isclose(float(u_cur), u0, rtol=2e-5) and np.isclose(float(u_prop), u1, rtol=2e-5)
+    expect = -(u1 - u0) + 1100 * np.log(v1 / v0)
+    assert abs(float(lpr) - expect) < 2e-4 * max(1.0, abs(u0))
+
+
+@pytest.mark.parametrize("nbr_kind", ["pairlist", "cell"])
+def test_lj_mcmc_three_move_schedule(ca, O, golden, methane_coords, nbr_kind):
+    """Examples/LJ_MCMC.py:95-170 (shortened): Langevin + displacement + barostat moves on NPT methane."""
+    u = ca.unit
+    from chiron_amd.reporters import LangevinDynamicsReporter, MCReporter
+
+    pot, thermo, state, nbr, g = _methane_system(ca, golden, methane_coords, nbr_kind)
+    rep_d, rep_b, rep_l = MCReporter("disp", 10), MCReporter("baro", 1), LangevinDynamicsReporter("lang", 10)
+    disp = ca.mcmc.MonteCarloDisplacementMove(displacement_sigma=0.001 * u.nanometer, number_of_moves=30, reporter=rep_d,
+                                              report_interval=10, autotune=True, autotune_interval=100)
+    baro = ca.mcmc.MonteCarloBarostatMove(volume_max_scale=0.01, number_of_moves=6, reporter=rep_b, report_interval=1,
+                                          autotune=True, autotune_interval=50)
+    lang = ca.mcmc.LangevinDynamicsMove(timestep=1.0 * u.femtoseconds, collision_rate=1.0 / u.picoseconds,
+                                        number_of_steps=40, reporter=rep_l, report_interval=10)
+    sampler = ca.mcmc.MCMCSampler(ca.mcmc.MoveSchedule([("LangevinDynamicsMove", lang),
+                                                        ("MonteCarloDisplacementMove", disp),
+                                                        ("MonteCarloBarostatMove", baro)]))
+    s2, t2, n2 = sampler.run(state, thermo, n_iterations=2, nbr_list=nbr)
+    assert disp.statistics["n_proposed"] == 60 and baro.statistics["n_proposed"] == 12
+    assert disp.statistics["n_accepted"] > 0
+    vol = rep_b.get_property("volume")
+    assert vol.shape == (12,) and np.all(np.isfinite(vol))
+    bx = s2.box_vectors.cpu().numpy()
+    assert np.isclose(bx[0, 0] * bx[1, 1] * bx[2, 2], vol[-1], rtol=1e-5)
+    if baro.statistics["n_accepted"] > 0:
+        assert not np.isclose(vol[-1], g["box_edge"] ** 3, rtol=1e-9)
+    # the final configuration sits inside the final box and its energy is what the fp64 oracle says
+    x = s2.positions.cpu().numpy()
+    assert x.min() >= 0.0 and x.max() <= bx[0, 0] * (1 + 1e-6)
+    e = float(pot.compute_energy(s2.positions, n2))
+    e64, _, eabs, _ = O.lj_bruteforce_f64(x, bx, g["sigma"], g["epsilon_kcal_mol"] * 4.184, g["cutoff"])
+    assert abs(e - e64) <= 1e-5 * eabs
+    assert np.isclose(float(baro._current_reduced_potential), float(t2.get_reduced_potential(s2, n2)), rtol=1e-5)
+    assert rep_l.get_property("potential_energy") is not None
+
+
+def test_minimize_energy(ca, O, golden):
+    """chiron/tests/test_minization.py: 0 iterations keep the energy, 100 iterations lower it on an
+    LJ fluid (:30-80); two particles relax to the LJ minimum E = -1, r = 2^(1/6) (:83-128)."""
+    u = ca.unit
+    from chiron_amd.minimze import minimize_energy
+
+    n = 600
+    x, box = O.lj_lattice(n, 0.6, SIGMA, seed=3, jitter=0.25)
+    pot = lj_pot(ca, n)
+    nbr = ca.neighbors.NeighborListNsqrd(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+                                         skin=SKIN * u.nanometer, n_max_neighbors=180)
+    nbr.build(x, box)
+    e0 = float(pot.compute_energy(x, nbr))
+    r0 = minimize_energy(dev(x), pot.compute_energy, nbr, maxiter=0)
+    assert np.isclose(float(pot.compute_energy(r0.params, nbr)), e0)
+    r = minimize_energy(dev(x), pot.compute_energy, nbr, maxiter=100)
+    e_min = float(pot.compute_energy(r.params, nbr))
+    assert e_min < e0 and np.isfinite(e_min) and r.state.iter_num <= 100
+    # two particles (sigma = 1 nm, eps = 1 kJ/mol, pair list, 10 nm box)
+    g = golden["minimized_pair"]
+    pot2 = ca.potential.LJPotential(None, sigma=1.0 * u.nanometer, epsilon=1.0 * u.kilojoules_per_mole, cutoff=3.0 * u.nanometer)
+    coords = np.array([[0.0, 0.0, 0.0], [0.9, 0.0, 0.0]], f32)
+    pl = ca.neighbors.PairListNsqrd(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=3.0 * u.nanometer)
+    pl.build(coords, np.diag([10.0, 10.0, 10.0]).astype(f32))
+    res = minimize_energy(dev(coords), pot2.compute_energy, pl, maxiter=10_000)
+    mx = res.params.cpu().numpy()
+    assert np.isclose(float(pot2.compute_energy(res.params, pl)), g["energy"], atol=1e-3)
+    assert np.isclose(np.linalg.norm(mx[1] - mx[0]), g["separation"], atol=1e-3)
+    with pytest.raises(TypeError):
+        minimize_energy(dev(coords), lambda x_: 0.0, None, maxiter=3)
 
 
 def test_metropolis_select_kernel(ca):

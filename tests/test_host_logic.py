@@ -285,6 +285,14 @@ def test_library_exports_every_declared_symbol():
     # struct layouts agree with the header (x86-64 SysV)
     assert ctypes.sizeof(_lib.Box) == 16
     assert ctypes.sizeof(_lib.LangevinParams) == 176
+    # struct-by-value marshalling rule of include/chx.h: no float scalars before a box that follows
+    # five or more integer/pointer arguments (mis-marshalled by this image's libffi)
+    for name, (_, args) in _lib.SIGNATURES.items():
+        if _lib.Box in args:
+            i = args.index(_lib.Box)
+            ints = sum(1 for a in args[:i] if a not in (ctypes.c_float, ctypes.c_double))
+            floats = i - ints
+            assert floats == 0 or ints < 5, name
     assert ctypes.sizeof(_lib.McParams) == 160
     assert _lib.McParams.beta.offset == 112 and _lib.McParams.ws.offset == 152
 
