@@ -72,24 +72,23 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
   }
   __threadfence_block();
   int count_h = 0, count_f = 0;
+  int r = 0;  // range holding this lane's candidate; candidates only move forward
   for (int t0 = 0; t0 < total; t0 += CHX_WAVE) {
     const int t = t0 + lane;
     bool ok = false, hi = false;
     uint32_t j = 0;
     int k = 0;
     if (t < total) {
-      int r = 0;
-#pragma unroll
-      for (int q = 1; q < 18; ++q) r += rng_o[q] <= t ? 1 : 0;
+      while (r < 17 && rng_o[r + 1] <= t) ++r;
       k = rng_s[r] + (t - rng_o[r]);
       j = sorted_ids[k];
       const float4 xk = xs4[k];
-      if (j != i) {
-        hi = j > i;
-        float rx, ry, rz;  // x_i - x_j for row i of the half list, x_j - x_i for row j
-        displacement_oriented(box, hi, xi, yi, zi, xk.x, xk.y, xk.z, rx, ry, rz);
-        ok = norm2(rx, ry, rz) <= T;
-      }
+      hi = j > i;
+      float rx, ry, rz;  // x_i - x_j for row i of the half list, x_j - x_i for row j
+      bool bad;
+      displacement_oriented_fast(box, hi, xi, yi, zi, xk.x, xk.y, xk.z, rx, ry, rz, bad);
+      if (__builtin_expect(bad, 0)) displacement_oriented(box, hi, xi, yi, zi, xk.x, xk.y, xk.z, rx, ry, rz);
+      ok = (j != i) & (norm2(rx, ry, rz) <= T);
     }
     const unsigned long long lt = (1ull << lane) - 1ull;
     const unsigned long long b = __ballot(ok);
@@ -106,8 +105,16 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
       count_h += __popcll(bh);
     }
   }
-  // force-list row: unused slots must hold a valid index (the force kernel gathers speculatively)
-  for (int sl = (count_f < fcap ? count_f : fcap) + lane; sl < fcap; sl += CHX_WAVE) fl[chx_fl_addr(w, sl, n, fg)] = 0u;
+  // force-list row: the force kernel gathers whole chunks (and chunk 0 speculatively), so the
+  // unused slots of the chunks it can touch must hold a valid index; later chunks are never read
+  {
+    const int wd = CHX_FL_QUAD * fg;
+    const int used = count_f < fcap ? count_f : fcap;
+    int end = (used + wd - 1) / wd * wd;
+    end = end < wd ? wd : end;
+    end = end < fcap ? end : fcap;
+    for (int sl = used + lane; sl < end; sl += CHX_WAVE) fl[chx_fl_addr(w, sl, n, fg)] = 0u;
+  }
   const int kept = count_h < CHX_CELL_CAP - 40 ? count_h : CHX_CELL_CAP - 40;
   __threadfence_block();
   // half row: rank sort -> ascending ids, as jnp.where(mask, size=M) returns them

@@ -113,6 +113,35 @@ __device__ __forceinline__ void displacement_oriented(const Box3& box, bool forw
   }
 }
 
+// Branch-free minimum image for |d| < L (same value, bit for bit, as min_image()).  With
+// t = d + L/2 in (-L/2, 3L/2) jnp.mod picks, of {t - L, t, t + L}, the one in [0, L]: exactly
+// the SMALLEST NON-NEGATIVE of the three, i.e. their minimum as unsigned bit patterns
+// (negative floats have the top bit set).  t - L is exact (Sterbenz), t + L rounds once.
+__device__ __forceinline__ float min_image_fast(float d, float L, float hL) {
+  const float t = fadd(d, hL);
+  const uint32_t a = __float_as_uint(fsub(t, L)), b = __float_as_uint(t), c = __float_as_uint(fadd(t, L));
+  return fsub(__uint_as_float(min(min(a, b), c)), hL);
+}
+
+// displacement_oriented() for the common case; `bad` is raised when some |component| >= L
+// (unwrapped coordinates) and the caller must redo the pair through displacement_oriented().
+__device__ __forceinline__ void displacement_oriented_fast(const Box3& box, bool forward, float ax, float ay,
+                                                           float az, float bx, float by, float bz,
+                                                           float& rx, float& ry, float& rz, bool& bad) {
+  const uint32_t flip = forward ? 0u : 0x80000000u;
+  rx = __uint_as_float(__float_as_uint(fsub(ax, bx)) ^ flip);
+  ry = __uint_as_float(__float_as_uint(fsub(ay, by)) ^ flip);
+  rz = __uint_as_float(__float_as_uint(fsub(az, bz)) ^ flip);
+  if (box.periodic) {
+    bad = !(fabsf(rx) < box.lx) | !(fabsf(ry) < box.ly) | !(fabsf(rz) < box.lz);
+    rx = min_image_fast(rx, box.lx, box.hx);
+    ry = min_image_fast(ry, box.ly, box.hy);
+    rz = min_image_fast(rz, box.lz, box.hz);
+  } else {
+    bad = false;
+  }
+}
+
 // jnp.linalg.norm squared: (x*x + y*y) + z*z
 __device__ __forceinline__ float norm2(float rx, float ry, float rz) {
   return fadd(fadd(fmul(rx, rx), fmul(ry, ry)), fmul(rz, rz));

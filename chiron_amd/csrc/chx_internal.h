@@ -37,8 +37,8 @@ int chx_launch_lj_fl(const float* x4, const uint32_t* fl, const int32_t* deg, in
 // entries 4q..4q+3 of a chunk with one 16-byte load.
 #define CHX_FL_QUAD 4
 __device__ __forceinline__ size_t chx_fl_addr(int p, int k, int n, int g) {
-  const int w = CHX_FL_QUAD * g;
-  return ((size_t)(k / w) * (size_t)n + (size_t)p) * (size_t)w + (size_t)(k % w);
+  const int sh = 31 - __clz(CHX_FL_QUAD * g);  // g is a power of two
+  return ((((size_t)(k >> sh)) * (size_t)n + (size_t)p) << sh) + (size_t)(k & ((1 << sh) - 1));
 }
 // number of per-block partials the list kernel leaves in ws for (n, g)
 static inline int chx_lj_fl_blocks(int n, int g) { return (int)(((int64_t)n * g + 255) / 256); }

@@ -133,6 +133,8 @@ __global__ __launch_bounds__(64) void k_fl_sort(uint32_t* __restrict__ fl,
 extern "C" int chx_fl_sort(uint32_t* fl, const int32_t* deg, int32_t n, int32_t g, int32_t maxdeg,
                            chx_stream_t stream) {
   CHX_REQUIRE(n >= 0 && maxdeg >= 0, "need n >= 0, maxdeg >= 0");
+  CHX_REQUIRE(g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64,
+              "g must be a power of two <= 64");
   if (n == 0 || maxdeg <= 1) return CHX_OK;
   CHX_REQUIRE(fl && deg, "null pointer");
   const size_t lds = (size_t)maxdeg * 64 * sizeof(uint32_t);
