@@ -1,0 +1,204 @@
+"""GPU parity at BASELINE.json's full sizes (C4: N = 262,144; C3: N = 32,768).
+
+The NumPy oracle cannot sweep these sizes, so parity is pinned through (a) oracle results on
+random SAMPLES of rows/particles (bit-exact for neighbor rows, fp64 tolerance for forces) and
+(b) size-independent properties: pair-count symmetry, Newton's third law, agreement of two
+independent kernels/layouts, permutation and translation invariance, independence of the
+trajectory from how steps are batched into launches.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+f32 = np.float32
+SIGMA, EPS = 0.34, 0.238 * 4.184
+CUTOFF, SKIN = 3 * SIGMA, 0.5
+N4, N3 = 262144, 32768
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import chiron_oracle
+
+    return chiron_oracle
+
+
+@pytest.fixture(scope="module")
+def ca():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from chiron_amd import _lib, integrators, mcmc, neighbors, ops, potential, states, unit, utils
+
+    _lib.load()
+    return type("NS", (), dict(unit=unit, neighbors=neighbors, potential=potential, states=states, ops=ops,
+                               utils=utils, integrators=integrators, mcmc=mcmc))
+
+
+def dev(a):
+    return torch.as_tensor(np.asarray(a, dtype=f32)).cuda()
+
+
+def _pot(ca, n):
+    from chiron_amd.topology import Topology
+
+    u = ca.unit
+    return ca.potential.LJPotential(Topology.homogeneous(n), sigma=SIGMA * u.nanometer,
+                                    epsilon=EPS * u.kilojoule_per_mole, cutoff=CUTOFF * u.nanometer)
+
+
+def _nbr(ca, m=180, skin=SKIN):
+    u = ca.unit
+    return ca.neighbors.NeighborListCell(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+                                         skin=skin * u.nanometer, n_max_neighbors=m)
+
+
+@pytest.fixture(scope="module")
+def c4(ca, O):
+    x, box = O.lj_lattice(N4, 0.1, SIGMA, seed=1234)
+    nbr = _nbr(ca)
+    nbr.build(x, box)
+    assert nbr._perm is not None, "cell path was not taken"
+    return x, box, nbr
+
+
+def _oracle_row(O, x, box, i, cutoff_skin):
+    """Row i of the reference half list: ascending j > i with d < cutoff + skin (chiron/neighbors.py:548-626)."""
+    n = x.shape[0]
+    xi = np.broadcast_to(x[i], (n, 3))
+    _, d = O.periodic_displacement(xi, x, box)
+    mask = (d < f32(cutoff_skin)) & (np.arange(n) > i)
+    return np.nonzero(mask)[0].astype(np.uint32)
+
+
+def test_c4_neighbor_rows_match_oracle_on_a_sample(ca, O, c4):
+    x, box, nbr = c4
+    nl = nbr.neighbor_list.cpu().numpy().view(np.uint32)
+    n_nbr = nbr.n_neighbors.cpu().numpy()
+    mask = nbr.neighbor_mask.cpu().numpy()
+    m = nl.shape[1]
+    rng = np.random.default_rng(2024)
+    rows = np.concatenate([rng.integers(0, N4, 60), [0, 1, N4 - 2, N4 - 1]])
+    for i in rows:
+        row = _oracle_row(O, x, box, int(i), CUTOFF + SKIN)
+        k = len(row)
+        assert n_nbr[i] == k
+        assert np.array_equal(nl[i, :k], row)
+        # padding rule (:603-623): fill = first neighbor (0 if none), +1 if that is i itself
+        fill = row[0] if k else 0
+        fill = fill + 1 if fill == i else fill
+        assert np.all(nl[i, k:] == fill)
+        assert np.array_equal(mask[i], (np.arange(m) < k).astype(np.int32))
+    # global structure: every listed id is larger than its row, rows ascend, counts are symmetric
+    real = np.arange(m)[None, :] < n_nbr[:, None]
+    assert np.all(nl[real] > np.repeat(np.arange(N4, dtype=np.uint32), n_nbr))
+    asc = (np.diff(nl.astype(np.int64), axis=1) > 0) | ~real[:, 1:]
+    assert asc.all()
+    p_nl = int(n_nbr.sum())
+    assert 3.5e6 < p_nl < 6e6  # ~4.9e6 list pairs at rho* = 0.1
+    fl = nbr.force_list
+    assert int(fl.deg.sum()) == 2 * p_nl
+    # full degree of particle i = own row + appearances in other rows
+    appear = np.bincount(nl[real], minlength=N4)
+    deg_user = np.empty(N4, np.int64)
+    deg_user[fl.perm.cpu().numpy().view(np.uint32)] = fl.deg.cpu().numpy()
+    assert np.array_equal(deg_user, n_nbr + appear)
+
+
+def test_c4_force_energy_properties(ca, O, c4):
+    x, box, nbr = c4
+    pot = _pot(ca, N4)
+    rng = np.random.default_rng(7)
+    x2 = (x + rng.normal(0, 0.04, size=x.shape)).astype(f32)  # inside the skin guarantee
+    e, f = pot.compute_energy_and_force(x2, nbr)
+    e, f = float(e), f.cpu().numpy()
+    fmax = np.abs(f).max()
+    # Newton's third law: the net force vanishes up to fp32 summation noise
+    assert np.abs(f.astype(np.float64).sum(axis=0)).max() < 1e-5 * fmax * np.sqrt(N4) + 1e-3
+    # two independent kernels and data layouts (force list in cell order vs. the public half list)
+    f_h, e_h = ca.ops.lj_nl_energy_force(dev(x2), nbr.neighbor_list, nbr.n_neighbors, nbr._box_h, SIGMA, EPS, CUTOFF)
+    assert abs(e - float(e_h[0])) <= 2e-6 * abs(e)
+    assert np.abs(f - f_h.cpu().numpy()).max() <= 2e-5 * max(1.0, fmax)
+    # fp64 brute force over all N for a sample of particles
+    L = np.diag(box).astype(np.float64)
+    x64 = x2.astype(np.float64)
+    for i in rng.integers(0, N4, 48):
+        r = x64[i] - x64
+        r -= L * np.round(r / L)
+        d2 = (r * r).sum(axis=1)
+        sel = (d2 < CUTOFF ** 2) & (d2 > 0)
+        s6 = (SIGMA ** 2 / d2[sel]) ** 3
+        fi = ((24 * EPS * (2 * s6 * s6 - s6) / d2[sel])[:, None] * r[sel])
+        ref = fi.sum(axis=0)
+        assert np.abs(f[i] - ref).max() <= 1e-5 * max(1.0, np.abs(fi).sum(axis=0).max())
+    # permutation invariance: the same configuration with shuffled particle ids
+    perm = rng.permutation(N4)
+    nbr_p = _nbr(ca)
+    nbr_p.build(x[perm], box)
+    e_p, f_p = pot.compute_energy_and_force(x2[perm], nbr_p)
+    assert abs(float(e_p) - e) <= 2e-6 * abs(e)
+    assert np.abs(f_p.cpu().numpy() - f[perm]).max() <= 2e-5 * max(1.0, fmax)
+    assert int(nbr_p.n_neighbors.sum()) == int(nbr.n_neighbors.sum())
+    # translation invariance under the periodic boundary conditions
+    shift = np.array([3.7, -11.2, 20.05], f32)
+    xs = O.periodic_wrap((x + shift).astype(f32), box)
+    nbr_s = _nbr(ca)
+    nbr_s.build(xs, box)
+    e0 = float(pot.compute_energy(x, nbr))
+    e_s = float(pot.compute_energy(xs, nbr_s))
+    assert abs(e_s - e0) <= 1e-5 * abs(e0)
+
+
+def _run_langevin(ca, O, n, chunk, steps, skin, seed=1234):
+    u = ca.unit
+    x, box = O.lj_lattice(n, 0.1, SIGMA, seed=seed)
+    pot = _pot(ca, n)
+    ca.utils.PRNG.set_seed(1234)
+    state = ca.states.SamplerState(u.Quantity(x, u.nanometer), ca.utils.PRNG.get_random_key(),
+                                   box_vectors=u.Quantity(box, u.nanometer))
+    thermo = ca.states.ThermodynamicState(pot, temperature=300 * u.kelvin)
+    nbr = _nbr(ca, skin=skin)
+    integ = ca.integrators.LangevinIntegrator(timestep=2.0 * u.femtoseconds, collision_rate=1.0 / u.picoseconds,
+                                              chunk_size=chunk)
+    out, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr)
+    return out, nbr, integ
+
+
+def test_c4_langevin_is_independent_of_launch_batching(ca, O):
+    """N = 262,144, fused step kernel, device RNG: chunk sizes 5 and 32 give the same trajectory bit for
+    bit, rebuild at the same steps, and keep the kinetic temperature (chiron/integrators.py:179-195)."""
+    a, nbr_a, integ_a = _run_langevin(ca, O, N4, 5, 96, 0.06)
+    b, nbr_b, integ_b = _run_langevin(ca, O, N4, 32, 96, 0.06)
+    assert integ_a.n_rebuilds == integ_b.n_rebuilds and integ_a.n_rebuilds >= 1
+    assert torch.equal(a.positions, b.positions) and torch.equal(a.velocities, b.velocities)
+    assert torch.equal(nbr_a.ref_positions, nbr_b.ref_positions)
+    assert torch.equal(nbr_a.n_neighbors, nbr_b.n_neighbors)
+    v = a.velocities.cpu().numpy().astype(np.float64)
+    kT = O.R_KJ * 300.0
+    assert abs((39.948 * v ** 2).mean() / kT - 1.0) < 0.02
+    x = a.positions.cpu().numpy()
+    L = float(a.box_vectors[0][0])
+    assert x.min() >= 0.0 and x.max() < L * (1 + 1e-6)
+
+
+def test_c3_mc_device_loop_equals_host_loop(ca, O, monkeypatch):
+    """MonteCarloDisplacementMove at N = 32,768: device-resident loop == reference-shaped host loop."""
+    u = ca.unit
+    res = []
+    for host in ("1", "0"):
+        monkeypatch.setenv("CHX_MC_HOST_LOOP", host)
+        x, box = O.lj_lattice(N3, 0.1, SIGMA, seed=1234)
+        pot = _pot(ca, N3)
+        ca.utils.PRNG.set_seed(1234)
+        state = ca.states.SamplerState(u.Quantity(x, u.nanometer), ca.utils.PRNG.get_random_key(),
+                                       box_vectors=u.Quantity(box, u.nanometer))
+        thermo = ca.states.ThermodynamicState(pot, temperature=300 * u.kelvin)
+        nbr = _nbr(ca, skin=0.02)
+        nbr.build_from_state(state)
+        move = ca.mcmc.MonteCarloDisplacementMove(displacement_sigma=0.0012 * u.nanometer, number_of_moves=40)
+        s2, _, n2 = move.update(state, thermo, nbr)
+        res.append((s2.positions.cpu().numpy(), tuple(s2._current_PRNG_key), move.statistics, n2.ref_positions.cpu().numpy()))
+    assert res[0][2] == res[1][2] and 0 < res[0][2]["n_accepted"]
+    assert res[0][1] == res[1][1]
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][3], res[1][3])
+    assert not np.array_equal(res[0][3], O.lj_lattice(N3, 0.1, SIGMA, seed=1234)[0])  # at least one rebuild happened
