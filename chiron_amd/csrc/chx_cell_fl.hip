@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
   const uint32_t i = sorted_ids[w];
   const float4 xw = xs4[w];  // positions in cell order: candidate loads below are coalesced
   const float xi = xw.x, yi = xw.y, zi = xw.z;
-  const int c = cell_of[i];
+  const int c = __float_as_int(xw.w);
   const int cx = c % g.ncx, cy = (c / g.ncx) % g.ncy, cz = c / (g.ncx * g.ncy);
   // The 27 surrounding cells are at most 18 contiguous index ranges of the cell-ordered arrays
   // (the three x-neighbours of a (y,z) row are adjacent except across the periodic seam).  Lane r
@@ -73,16 +73,31 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
   __threadfence_block();
   int count_h = 0, count_f = 0;
   int r = 0;  // range holding this lane's candidate; candidates only move forward
+  // candidate of the NEXT iteration is requested before the current one is processed, so the
+  // loop's global loads overlap instead of forming a chain of dependent round trips
+  int k_n = 0;
+  uint32_t j_n = 0;
+  float4 x_n = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (lane < total) {
+    while (r < 17 && rng_o[r + 1] <= lane) ++r;
+    k_n = rng_s[r] + (lane - rng_o[r]);
+    j_n = sorted_ids[k_n];
+    x_n = xs4[k_n];
+  }
   for (int t0 = 0; t0 < total; t0 += CHX_WAVE) {
     const int t = t0 + lane;
     bool ok = false, hi = false;
-    uint32_t j = 0;
-    int k = 0;
+    const uint32_t j = j_n;
+    const int k = k_n;
+    const float4 xk = x_n;
+    if (t + CHX_WAVE < total) {
+      const int tn = t + CHX_WAVE;
+      while (r < 17 && rng_o[r + 1] <= tn) ++r;
+      k_n = rng_s[r] + (tn - rng_o[r]);
+      j_n = sorted_ids[k_n];
+      x_n = xs4[k_n];
+    }
     if (t < total) {
-      while (r < 17 && rng_o[r + 1] <= t) ++r;
-      k = rng_s[r] + (t - rng_o[r]);
-      j = sorted_ids[k];
-      const float4 xk = xs4[k];
       hi = j > i;
       float rx, ry, rz;  // x_i - x_j for row i of the half list, x_j - x_i for row j
       bool bad;
@@ -146,12 +161,14 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
   }
 }
 
-__global__ void k_gather_sorted(const float* __restrict__ xyz, const uint32_t* __restrict__ sorted_ids, int n,
-                                float4* __restrict__ xs4) {
+// positions in cell order; .w carries the particle's cell index (as int bits) so the build kernel
+// needs no dependent cell_of[sorted_ids[w]] round trip
+__global__ void k_gather_sorted(const float* __restrict__ xyz, const uint32_t* __restrict__ sorted_ids,
+                                const int32_t* __restrict__ cell_of, int n, float4* __restrict__ xs4) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const size_t j = sorted_ids[k];
-  xs4[k] = make_float4(xyz[3 * j], xyz[3 * j + 1], xyz[3 * j + 2], 0.f);
+  xs4[k] = make_float4(xyz[3 * j], xyz[3 * j + 1], xyz[3 * j + 2], __int_as_float(cell_of[j]));
 }
 
 // status[1] = max n_nbr, status[2] = #rows with n_nbr == m, status[3] = max full degree
@@ -214,7 +231,7 @@ extern "C" int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_
   const float T = chx_cutoff_threshold_h(cutoff_plus_skin);
   const unsigned wb = (unsigned)(((int64_t)n * CHX_WAVE + 255) / 256);
   float4* xs4 = reinterpret_cast<float4*>(xs4_out);
-  hipLaunchKernelGGL(k_gather_sorted, dim3((n + 255) / 256), dim3(256), 0, st, xyz, sorted_ids, n, xs4);
+  hipLaunchKernelGGL(k_gather_sorted, dim3((n + 255) / 256), dim3(256), 0, st, xyz, sorted_ids, cell_of, n, xs4);
   hipLaunchKernelGGL(k_nl_build_cell_fl, dim3(wb), dim3(256), 0, st, xs4, n, m, make_box3(box), T, grid,
                      cell_of, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, chunks * CHX_FL_QUAD * g,
                      fl_out, deg_out, status8);

@@ -125,33 +125,37 @@ __global__ void k_cell_assign(const float* __restrict__ xyz, int n, Box3 box, Ce
   atomicAdd(&cell_count[c], 1);
 }
 
-// single-block exclusive scan: cell_start[0..ncell] from cell_count; zeroes cell_count (reused as cursor)
+// single-block exclusive scan: cell_start[0..ncell] from cell_count; zeroes cell_count (reused as
+// cursor).  Tiles of 1024 cells, coalesced loads, wave-shuffle scans (two barriers per tile).
 __global__ __launch_bounds__(1024) void k_cell_scan(int32_t* __restrict__ cell_count,
                                                     int32_t* __restrict__ cell_start, int ncell) {
-  __shared__ int32_t part[1024];
-  const int t = threadIdx.x;
-  const int chunk = (ncell + 1023) / 1024;
-  const int lo = t * chunk;
-  const int hi = lo + chunk < ncell ? lo + chunk : ncell;
-  int32_t s = 0;
-  for (int c = lo; c < hi; ++c) s += cell_count[c];
-  part[t] = s;
+  __shared__ int32_t wsum[16];
+  __shared__ int32_t carry_s;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (t == 0) carry_s = 0;
   __syncthreads();
-  // Hillis-Steele inclusive scan over the 1024 partials
-  for (int o = 1; o < 1024; o <<= 1) {
-    int32_t v = t >= o ? part[t - o] : 0;
+  for (int base = 0; base < ncell; base += 1024) {
+    const int c = base + t;
+    const int32_t v = c < ncell ? cell_count[c] : 0;
+    int32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t u = __shfl_up(incl, o, CHX_WAVE);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) wsum[wv] = incl;
     __syncthreads();
-    part[t] += v;
+    int32_t before = carry_s;
+    for (int k = 0; k < wv; ++k) before += wsum[k];
+    if (c < ncell) {
+      cell_start[c] = before + incl - v;
+      cell_count[c] = 0;
+    }
+    __syncthreads();
+    if (t == 1023) carry_s = before + incl;
     __syncthreads();
   }
-  int32_t run = t > 0 ? part[t - 1] : 0;
-  for (int c = lo; c < hi; ++c) {
-    int32_t k = cell_count[c];
-    cell_start[c] = run;
-    run += k;
-    cell_count[c] = 0;
-  }
-  if (t == 1023) cell_start[ncell] = part[1023];
+  if (t == 0) cell_start[ncell] = carry_s;
 }
 
 __global__ void k_cell_scatter(const int32_t* __restrict__ cell_of, int n,
