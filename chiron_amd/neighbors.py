@@ -144,14 +144,19 @@ class PairsBase(ABC):
 class NeighborListNsqrd(PairsBase):
     """Half (unique-pair) Verlet list with skin, padded to ``n_max_neighbors``.
 
-    Reference: chiron/neighbors.py:378-907.  ``build`` here runs the O(N^2)
-    wave-per-row HIP kernel; outputs (``neighbor_list`` (N,M), ``neighbor_mask``
-    (N,M) int32, ``n_neighbors`` (N,) int32) are bit-identical to the reference's
-    ``vmap(_build_neighborlist)`` including padding and the growth loop.
+    Reference: chiron/neighbors.py:378-907.  The outputs (``neighbor_list`` (N,M),
+    ``neighbor_mask`` (N,M) int32, ``n_neighbors`` (N,) int32) are bit-identical to the
+    reference's ``vmap(_build_neighborlist)`` including padding and the growth loop.
     Neighbor ids are stored in an int32 tensor holding the uint32 payload.
+
+    ``algorithm`` (not in the reference) picks the build kernel: ``"nsq"`` is the O(N^2)
+    wave-per-row kernel that follows the reference's own loop structure, ``"cell"`` the O(N)
+    cell-list kernel; both produce the same bits, so the default ``"auto"`` takes the cell
+    kernel whenever the periodic box holds at least 3 cells per axis and the O(N^2) kernel
+    otherwise (non-periodic spaces, small boxes).
     """
 
-    _use_cell_list = False
+    _algorithm = "auto"
 
     def __init__(
         self,
@@ -159,7 +164,13 @@ class NeighborListNsqrd(PairsBase):
         cutoff: unit.Quantity = unit.Quantity(1.2, unit.nanometer),
         skin: unit.Quantity = unit.Quantity(0.4, unit.nanometer),
         n_max_neighbors: int = 200,
+        *,
+        algorithm: Optional[str] = None,
     ):
+        algorithm = self._algorithm if algorithm is None else algorithm
+        if algorithm not in ("auto", "nsq", "cell"):
+            raise ValueError(f"algorithm must be 'auto', 'nsq' or 'cell', got {algorithm!r}")
+        self._use_cell_list = algorithm != "nsq"
         if not isinstance(space, Space):
             raise TypeError(f"space must be of type Space, found {type(space)}")
         if not skin.unit.is_compatible(unit.angstrom):
@@ -360,10 +371,11 @@ class NeighborListCell(NeighborListNsqrd):
     fp32 predicate, and emits each row in ascending-id order with the same
     padding, so ``neighbor_list`` / ``neighbor_mask`` / ``n_neighbors`` are
     bit-identical to ``NeighborListNsqrd`` on the same input.  Falls back to the
-    O(N^2) kernel when the box holds fewer than 3 cells per axis.
+    O(N^2) kernel when the box holds fewer than 3 cells per axis.  (Kept as an explicit name;
+    ``NeighborListNsqrd`` with its default ``algorithm="auto"`` takes the same kernels.)
     """
 
-    _use_cell_list = True
+    _algorithm = "cell"
 
 
 # ---------------------------------------------------------------------------

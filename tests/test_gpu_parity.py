@@ -56,6 +56,18 @@ def make_state(ca, x, box):
                                   box_vectors=None if box is None else nm(np.asarray(box, dtype=f32), ca))
 
 
+def nbr_class(ca, name):
+    """'NeighborListNsqrd' here means the O(N^2) kernel explicitly (the class's default 'auto'
+    algorithm would take the cell kernel on most boxes); 'NeighborListAuto' is the plain default."""
+    import functools
+
+    if name == "NeighborListNsqrd":
+        return functools.partial(ca.neighbors.NeighborListNsqrd, algorithm="nsq")
+    if name == "NeighborListAuto":
+        return ca.neighbors.NeighborListNsqrd
+    return getattr(ca.neighbors, name)
+
+
 def lj_pot(ca, n, sigma=SIGMA, eps_kj=EPS, cutoff=CUTOFF):
     u = ca.unit
     from chiron_amd.topology import Topology
@@ -106,7 +118,7 @@ def test_spaces_random_bitexact(ca, O):
 def test_neighborlist_pair_golden(ca, golden, cls_name):
     g = golden["neighborlist_pair"]
     u = ca.unit
-    cls = getattr(ca.neighbors, cls_name)
+    cls = nbr_class(ca, cls_name)
     x = np.array(g["coordinates"], f32)
     state = make_state(ca, x, g["box"])
     nbr = cls(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=g["cutoff"] * u.nanometer, skin=g["skin"] * u.nanometer,
@@ -134,7 +146,7 @@ def test_neighborlist_pair_golden(ca, golden, cls_name):
 def test_neighborlist_cube_golden(ca, golden, cls_name):
     g = golden["neighborlist_cube"]
     u = ca.unit
-    cls = getattr(ca.neighbors, cls_name)
+    cls = nbr_class(ca, cls_name)
     x = cube_coordinates(g["n_xyz"], g["scale_factor"])
     state = make_state(ca, x, g["box"])
     c = g["case_all"]
@@ -205,7 +217,7 @@ def _systems(O):
 @pytest.mark.parametrize("cls_name", ["NeighborListNsqrd", "NeighborListCell"])
 def test_neighborlist_random_bitexact(ca, O, cls_name):
     u = ca.unit
-    cls = getattr(ca.neighbors, cls_name)
+    cls = nbr_class(ca, cls_name)
     for name, x, box in _systems(O):
         for m0 in (180, 12):  # 12 forces the growth loop
             nbr = cls(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer, skin=SKIN * u.nanometer,
@@ -249,12 +261,19 @@ def test_cell_equals_nsq_medium(ca, O):
     u = ca.unit
     x, box = O.lj_lattice(32768, 0.1, SIGMA, seed=1234)
     a = ca.neighbors.NeighborListNsqrd(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
-                                       skin=SKIN * u.nanometer, n_max_neighbors=180)
+                                       skin=SKIN * u.nanometer, n_max_neighbors=180, algorithm="nsq")
     b = ca.neighbors.NeighborListCell(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
                                       skin=SKIN * u.nanometer, n_max_neighbors=180)
     a.build(x, box)
     b.build(x, box)
     assert b._perm is not None, "cell path was not taken"
+    assert a._perm is None, "the O(N^2) kernel was not taken"
+    c = ca.neighbors.NeighborListNsqrd(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+                                       skin=SKIN * u.nanometer, n_max_neighbors=180)  # default: auto -> cell kernel
+    c.build(x, box)
+    assert c._perm is not None and torch.equal(c.neighbor_list, a.neighbor_list)
+    with pytest.raises(ValueError):
+        ca.neighbors.NeighborListNsqrd(ca.neighbors.OrthogonalPeriodicSpace(), algorithm="octree")
     assert torch.equal(a.neighbor_list, b.neighbor_list)
     assert torch.equal(a.n_neighbors, b.n_neighbors) and torch.equal(a.neighbor_mask, b.neighbor_mask)
     assert 4.5e5 < int(a.n_neighbors.sum()) < 7.5e5  # ~6e5 list pairs at rho*=0.1
@@ -403,7 +422,7 @@ def _check_vs_f64(O, e, f, x, box, sigma, eps, cutoff, periodic=True, pair_filte
 @pytest.mark.parametrize("cls_name", ["NeighborListNsqrd", "NeighborListCell"])
 def test_lj_nbrlist_energy_force(ca, O, cls_name):
     u = ca.unit
-    cls = getattr(ca.neighbors, cls_name)
+    cls = nbr_class(ca, cls_name)
     for name, x, box in _systems(O):
         n = x.shape[0]
         pot = lj_pot(ca, n)
@@ -486,7 +505,7 @@ def test_lj_nl_direct_half_list_kernel(ca, O):
     for seed, n, rho in ((5, 700, 0.3), (6, 1500, 0.05)):
         x, box = O.lj_lattice(n, rho, SIGMA, seed=seed)
         for cls_name in ("NeighborListNsqrd", "NeighborListCell"):
-            nbr = getattr(ca.neighbors, cls_name)(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+            nbr = nbr_class(ca, cls_name)(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
                                                   skin=SKIN * u.nanometer, n_max_neighbors=180)
             nbr.build(x, box)
             x2 = (x + np.random.default_rng(seed).normal(0, 0.03, size=x.shape)).astype(f32)
@@ -573,7 +592,7 @@ def _langevin_setup(ca, O, n, rho, seed, skin, dt_fs, nbr_cls="NeighborListCell"
     pot = lj_pot(ca, n)
     state = make_state(ca, x, box)
     thermo = ca.states.ThermodynamicState(pot, temperature=300 * u.kelvin)
-    nbr = getattr(ca.neighbors, nbr_cls)(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+    nbr = nbr_class(ca, nbr_cls)(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
                                          skin=skin * u.nanometer, n_max_neighbors=m)
     integ = ca.integrators.LangevinIntegrator(timestep=dt_fs * u.femtoseconds, collision_rate=1.0 / u.picoseconds,
                                               chunk_size=7)
@@ -738,7 +757,7 @@ def _mc_run(ca, O, host_loop, monkeypatch, *, n=500, skin=SKIN, sigma_d=0.002, m
     pot = lj_pot(ca, n)
     state = make_state(ca, x, box)
     thermo = ca.states.ThermodynamicState(pot, temperature=300 * u.kelvin, pressure=pressure)
-    nbr = getattr(ca.neighbors, nbr_cls)(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+    nbr = nbr_class(ca, nbr_cls)(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
                                          skin=skin * u.nanometer, n_max_neighbors=180)
     nbr.build_from_state(state)
     rep = ca_reporter(ca)
