@@ -318,3 +318,29 @@ def test_cell_grid_helper():
     assert total == 0  # fewer than 3 cells per axis -> O(N^2) kernel
     total, nc = ops.cell_grid(ops.make_box(None, False), 1.52, 100)
     assert total == 0
+
+
+def test_branch_free_minimum_image_formula_is_exact():
+    """The hot kernels evaluate mod(d + L/2, L) - L/2 (chiron/neighbors.py:79) for |d| < L as the
+    unsigned-integer minimum of {t - L, t, t + L}, t = d + L/2 (csrc/chx_common.h: min_image_fast,
+    csrc/chx_lj.hip: min_image2).  Same arithmetic restated in NumPy fp32: bit-identical to the
+    reference formula on random and adversarial inputs."""
+    f32 = np.float32
+    rng = np.random.default_rng(0)
+    for L in (1.0, 4.275021399280942, 5.8601, 23.4402, 46.8805, 1e-3, 977.0, 3.0000002):
+        L = f32(L)
+        hL = f32(L * f32(0.5))
+        d = rng.uniform(-1.0, 1.0, 2_000_000).astype(f32) * L
+        edge = [0.0, -0.0, hL, -hL, np.nextafter(hL, f32(0)), np.nextafter(-hL, f32(0)), np.nextafter(hL, L),
+                np.nextafter(-hL, -L), np.nextafter(L, f32(0)), -np.nextafter(L, f32(0)), 1e-30, -1e-30, 1e-45, -1e-45,
+                np.nextafter(f32(0), f32(1)) * 3, L * f32(0.75), -L * f32(0.75)]
+        tiny = (rng.uniform(-1, 1, 1000) * 1e-6).astype(f32)
+        near = np.concatenate([hL + tiny * L, -hL + tiny * L, L * (1 - np.abs(tiny)), -L * (1 - np.abs(tiny))]).astype(f32)
+        d = np.concatenate([d, np.array(edge, dtype=f32), near])
+        d = d[np.abs(d) < L]
+        ref = (np.mod(d + hL, L) - hL).astype(f32)
+        t = (d + hL).astype(f32)
+        a, c = (t - L).astype(f32), (t + L).astype(f32)
+        m = np.minimum(np.minimum(a.view(np.uint32), t.view(np.uint32)), c.view(np.uint32)).view(f32)
+        fast = (m - hL).astype(f32)
+        assert np.array_equal(fast.view(np.uint32), ref.view(np.uint32)), float(L)
