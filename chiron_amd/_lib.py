@@ -48,6 +48,12 @@ class LangevinParams(C.Structure):
         ("ws", C.c_void_p),
         ("external_force", C.c_int32),
         ("fl_chunks", C.c_int32),
+        ("fl_inner", C.c_void_p),
+        ("deg_inner", C.c_void_p),
+        ("ref_inner4", C.c_void_p),
+        ("inner_skin", C.c_float),
+        ("prune_every", C.c_int32),
+        ("prune_phase", C.c_int64),
     ]
 
 

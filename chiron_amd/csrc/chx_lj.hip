@@ -9,6 +9,9 @@
 // particle id, chiron/neighbors.py:773-779), min-imaged as in :79, and the cutoff
 // mask is the exact `d < cutoff` of :782, so the set of interacting pairs is
 // bit-identical to the reference's; only the summation order differs.
+#include <cstdio>
+#include <cstdlib>
+
 #include "chx_common.h"
 #include "chx_internal.h"
 
@@ -404,13 +407,19 @@ struct StepArgs {
   const float* noise;
   long long noise_step0;
   int32_t* ctrl;
+  // dynamically pruned inner list (NULL: always run on the full force list)
+  uint32_t* fli;
+  int32_t* degi;
+  float4* refi4;        // positions at the last pruning pass
+  float T_inner;        // r2 <= T_inner: kept by the pruning pass  ((cutoff + inner skin)^2, padded up)
+  float T_half_inner;   // a particle that moved r2 > T_half_inner since the pass invalidates the inner list
 };
 
 // operands of one (particle, component) integrate task
 struct StepTask {
   bool live;
   int pp, c;
-  float m, v, x, ref, z;
+  float m, v, x, ref, refi, z;
 };
 
 __device__ __forceinline__ StepTask load_step_task(const StepArgs& a, long long step, int do_aoa, int p0,
@@ -421,13 +430,14 @@ __device__ __forceinline__ StepTask load_step_task(const StepArgs& a, long long 
   t.pp = p0 + pl;
   t.live = task < ntask && t.pp < a.n;
   t.m = 1.f;
-  t.v = t.x = t.ref = t.z = 0.f;
+  t.v = t.x = t.ref = t.refi = t.z = 0.f;
   if (t.live) {
     t.m = a.mass[t.pp];
     t.v = a.v[3 * (size_t)t.pp + t.c];
     if (do_aoa) {
       t.x = reinterpret_cast<const float*>(a.x_cur)[4 * (size_t)t.pp + t.c];
       if (a.ref4) t.ref = reinterpret_cast<const float*>(a.ref4)[4 * (size_t)t.pp + t.c];
+      if (a.fli) t.refi = reinterpret_cast<const float*>(a.refi4)[4 * (size_t)t.pp + t.c];
       const uint32_t o = a.perm ? a.perm[t.pp] : (uint32_t)t.pp;
       if (a.noise) {
         t.z = a.noise[((size_t)(step - a.noise_step0) * (size_t)a.n + o) * 3 + t.c];
@@ -445,7 +455,14 @@ __global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int
   constexpr int NTASK = 3 * PPB;
   __shared__ float sF[NTASK];
   __shared__ float sS[NTASK];
+  __shared__ float sI[NTASK];
   if ((long long)a.ctrl[3] <= step) return;  // block-uniform
+  // Which table this launch walks: the pruned inner list, unless some particle has moved too far
+  // since the last pruning pass (flag raised by an EARLIER launch; the two flag words alternate
+  // with the step parity so that no launch reads a word its own blocks may be writing).
+  const bool inner = a.fli != nullptr && a.ctrl[4 + (int)(step & 1)] == 0;
+  const uint32_t* fl_use = inner ? a.fli : a.fl;
+  const int32_t* deg_use = inner ? a.degi : a.deg;
   const unsigned blk = xcd_block(blockIdx.x, gridDim.x);
   const int p0 = blk * PPB;
   // ---- operands of this thread's integrate task, requested before the force loop so their
@@ -460,7 +477,7 @@ __global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int
   const bool valid = p < a.n;
   float4 xi;
   float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
-  lj_row<G>(a.x_cur, a.fl, a.deg, a.n, a.chunks, p, q, valid, a.box, a.lj, xi, fx, fy, fz, en);
+  lj_row<G>(a.x_cur, fl_use, deg_use, a.n, a.chunks, p, q, valid, a.box, a.lj, xi, fx, fy, fz, en);
 #pragma unroll
   for (int o = G / 2; o > 0; o >>= 1) {
     fx += __shfl_xor(fx, o, CHX_WAVE);
@@ -479,7 +496,7 @@ __global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int
   for (int it = 0; it < (NTASK + 255) / 256; ++it) {
     const int task = it * 256 + threadIdx.x;
     const StepTask& t = tk[it];
-    float sq = 0.f;
+    float sq = 0.f, sqi = 0.f;
     if (t.live) {
       const float F = sF[task];
       float vc = t.v;
@@ -497,18 +514,113 @@ __global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int
           if (a.box.periodic) r = min_image(r, L, fmul(L, 0.5f));
           sq = fmul(r, r);
         }
+        if (a.fli) {
+          float r = fsub(xc, t.refi);
+          if (a.box.periodic) r = min_image(r, L, fmul(L, 0.5f));
+          sqi = fmul(r, r);
+        }
       }
       a.v[3 * (size_t)t.pp + t.c] = vc;
     }
-    if (task < NTASK) sS[task] = sq;
+    if (task < NTASK) {
+      sS[task] = sq;
+      sI[task] = sqi;
+    }
   }
-  if (do_aoa && a.ref4) {  // skin check :241: (rx^2 + ry^2) + rz^2 in the reference's order
+  if (do_aoa && (a.ref4 || a.fli)) {
     __syncthreads();
+    bool stale = false;
     for (int pl = threadIdx.x; pl < PPB; pl += 256) {
-      if (p0 + pl < a.n && fadd(fadd(sS[3 * pl], sS[3 * pl + 1]), sS[3 * pl + 2]) > a.T_half_skin) {
+      if (p0 + pl >= a.n) continue;
+      // skin check :241: (rx^2 + ry^2) + rz^2 in the reference's order
+      if (a.ref4 && fadd(fadd(sS[3 * pl], sS[3 * pl + 1]), sS[3 * pl + 2]) > a.T_half_skin) {
         atomicMin(&a.ctrl[3], (int)(step + 1));
       }
+      if (a.fli && (sI[3 * pl] + sI[3 * pl + 1]) + sI[3 * pl + 2] > a.T_half_inner) stale = true;
     }
+    // the inner list stays off until the next pruning pass clears both words
+    if (a.fli && (stale || (!inner && threadIdx.x == 0))) a.ctrl[4 + (int)((step + 1) & 1)] = 1;
+  }
+  if (a.fli && !inner && blockIdx.x == 0 && threadIdx.x == 0) a.ctrl[6] += 1;  // launches on the full list
+}
+
+// ---------------------------------------------------------------------------
+// Dynamic pruning: the reference's list keeps every pair within cutoff + skin of the last build
+// (skin = 0.5 nm in its examples: 3.3x the volume of the cutoff sphere), but a pair can only
+// interact while |r| < cutoff.  Every few steps this pass copies, in order, the entries with
+// |r_now| < cutoff + inner_skin into a second table of the same layout and records the positions
+// it saw; the step kernel walks that table for as long as no particle has moved more than
+// inner_skin / 2 since (checked next to the reference's own skin check) and falls back to the
+// full table otherwise, until the next pass.  A dropped pair was farther than cutoff + inner_skin
+// and each partner moved less than inner_skin / 2, so it is still outside the cutoff: the set of
+// interacting pairs -- the reference's set -- is unchanged; only the summation order differs.
+// ---------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256) void k_fl_prune(StepArgs a, long long step) {
+  if ((long long)a.ctrl[3] <= step) return;
+  constexpr int W = 4 * G;
+  const unsigned blk = xcd_block(blockIdx.x, gridDim.x);
+  const int tid = blk * 256 + threadIdx.x;
+  const int p = tid / G;
+  const int q = tid % G;
+  const bool valid = p < a.n;
+  const int pc = valid ? p : 0;
+  const size_t stride = (size_t)a.n * G;
+  const uint4* col = reinterpret_cast<const uint4*>(a.fl) + (size_t)pc * G + q;
+  const float4 xi = a.x_cur[pc];
+  const int d = valid ? a.deg[pc] : 0;
+  const int nc = (d + W - 1) / W;
+  int base = 0;  // entries kept so far in this row (uniform over the G lanes)
+  for (int c = 0; c < nc; ++c) {
+    const uint4 e4 = col[(size_t)c * stride];
+    const uint32_t ent[4] = {e4.x, e4.y, e4.z, e4.w};
+    float4 xj[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xj[u] = a.x_cur[ent[u] & ~CHX_FL_HI];
+    bool keep[4];
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float rx = xi.x - xj[u].x, ry = xi.y - xj[u].y, rz = xi.z - xj[u].z;
+      bool far = false;
+      if (a.box.periodic) {
+        far = !(fabsf(rx) < a.box.lx) | !(fabsf(ry) < a.box.ly) | !(fabsf(rz) < a.box.lz);
+        rx = min_image_fast(rx, a.box.lx, a.box.hx);
+        ry = min_image_fast(ry, a.box.ly, a.box.hy);
+        rz = min_image_fast(rz, a.box.lz, a.box.hz);
+      }
+      // unwrapped coordinates (far): keep the entry, the force kernel sorts it out
+      keep[u] = (c * W + 4 * q + u < d) && (far || (rx * rx + ry * ry) + rz * rz <= a.T_inner);
+      cnt += keep[u] ? 1 : 0;
+    }
+    // ordered compaction over the G lanes that share the row
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) {
+      const int v = __shfl_up(incl, o, G);
+      if (q >= o) incl += v;
+    }
+    int slot = base + incl - cnt;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (keep[u]) a.fli[chx_fl_addr(pc, slot++, a.n, G)] = ent[u];
+    }
+    base += __shfl(incl, G - 1, G);
+  }
+  if (valid) {
+    // the force kernel gathers whole chunks (chunk 0 speculatively): pad the last touched chunk
+    int end = (base + W - 1) / W * W;
+    end = end < W ? W : end;
+    for (int sl = base + q; sl < end; sl += G) a.fli[chx_fl_addr(p, sl, a.n, G)] = 0u;
+    if (q == 0) {
+      a.degi[p] = base;
+      a.refi4[p] = xi;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.ctrl[4] = 0;
+    a.ctrl[5] = 0;
+    a.ctrl[7] += 1;
   }
 }
 
@@ -570,9 +682,18 @@ int chx_launch_lj_fl(const float* x4, const uint32_t* fl, const int32_t* deg, in
 }
 
 template <int G>
-static void launch_step_g(const StepArgs& a, long long step, int n_kicks, int do_aoa, hipStream_t st) {
+static void launch_step_g(const StepArgs& a, long long step, int n_kicks, int do_aoa, bool prune,
+                          hipStream_t st) {
   const unsigned blocks = (unsigned)(((int64_t)a.n * G + 255) / 256);
+  static const bool dbg = getenv("CHX_DEBUG_SYNC") != nullptr;  // serialise + narrate (fault hunting)
+  if (prune) {
+    if (dbg) fprintf(stderr, "[chx] k_fl_prune<%d> step %lld\n", G, step);
+    hipLaunchKernelGGL((k_fl_prune<G>), dim3(blocks), dim3(256), 0, st, a, step);
+    if (dbg) (void)hipStreamSynchronize(st);
+  }
+  if (dbg) fprintf(stderr, "[chx] k_lj_step<%d> step %lld kicks %d aoa %d\n", G, step, n_kicks, do_aoa);
   hipLaunchKernelGGL((k_lj_step<G>), dim3(blocks), dim3(256), 0, st, a, step, n_kicks, do_aoa);
+  if (dbg) (void)hipStreamSynchronize(st);
 }
 
 // launch i of the chunk reads (i even ? x_even : x_odd) and writes the other buffer
@@ -600,18 +721,35 @@ int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, in
   a.noise = p->noise;
   a.noise_step0 = p->noise_step0;
   a.ctrl = p->ctrl;
+  const bool use_inner = p->fl_inner && p->deg_inner && p->ref_inner4 && p->prune_every > 0 && p->inner_skin > 0.f;
+  a.fli = use_inner ? p->fl_inner : nullptr;
+  a.degi = use_inner ? p->deg_inner : nullptr;
+  a.refi4 = use_inner ? reinterpret_cast<float4*>(p->ref_inner4) : nullptr;
+  {
+    // keep |r| < cutoff + inner_skin (padded up), distrust the table once a particle has moved
+    // inner_skin / 2 (padded down): the paddings dwarf fp32 rounding
+    const float rk = (p->cutoff + p->inner_skin) * 1.00001f;
+    const float hm = 0.5f * p->inner_skin * 0.9999f;
+    a.T_inner = rk * rk;
+    a.T_half_inner = hm * hm;
+  }
   for (int i = 0; i < n_steps; ++i) {
     a.x_cur = reinterpret_cast<const float4*>((i & 1) ? x_odd : x_even);
     a.x_next = (i & 1) ? x_even : x_odd;
     const int nk = i == 0 ? kicks_first : 2;
+    // pruning passes sit at fixed step indices (counted from prune_phase), not at chunk
+    // boundaries: a trajectory does not depend on how its steps are batched into calls
+    // (the force-only launch that ends a run is included: it may be the first one after a rebuild)
+    const bool prune = use_inner && (step0 + i >= p->prune_phase) &&
+                       ((step0 + i - p->prune_phase) % p->prune_every == 0);
     switch (p->g) {
-      case 1: launch_step_g<1>(a, step0 + i, nk, do_aoa, st); break;
-      case 2: launch_step_g<2>(a, step0 + i, nk, do_aoa, st); break;
-      case 4: launch_step_g<4>(a, step0 + i, nk, do_aoa, st); break;
-      case 8: launch_step_g<8>(a, step0 + i, nk, do_aoa, st); break;
-      case 16: launch_step_g<16>(a, step0 + i, nk, do_aoa, st); break;
-      case 32: launch_step_g<32>(a, step0 + i, nk, do_aoa, st); break;
-      case 64: launch_step_g<64>(a, step0 + i, nk, do_aoa, st); break;
+      case 1: launch_step_g<1>(a, step0 + i, nk, do_aoa, prune, st); break;
+      case 2: launch_step_g<2>(a, step0 + i, nk, do_aoa, prune, st); break;
+      case 4: launch_step_g<4>(a, step0 + i, nk, do_aoa, prune, st); break;
+      case 8: launch_step_g<8>(a, step0 + i, nk, do_aoa, prune, st); break;
+      case 16: launch_step_g<16>(a, step0 + i, nk, do_aoa, prune, st); break;
+      case 32: launch_step_g<32>(a, step0 + i, nk, do_aoa, prune, st); break;
+      case 64: launch_step_g<64>(a, step0 + i, nk, do_aoa, prune, st); break;
       default:
         chx_set_error("chx_launch_lj_steps: unsupported g = %d", p->g);
         return CHX_ERR_INVALID;

@@ -17,6 +17,7 @@ from __future__ import annotations
 import collections
 import copy
 import logging
+import os
 from typing import Optional, Tuple
 
 import numpy as np
@@ -223,7 +224,7 @@ class _RunState:
         if self.noise is not None and (self.noise.dim() != 3 or tuple(self.noise.shape[1:]) != (self.n, 3)):
             raise ValueError(f"noise must have shape (steps, {self.n}, 3), got {tuple(self.noise.shape)}")
         self.mass_user = mass
-        self.ctrl = torch.zeros((4,), dtype=torch.int32, device=self.dev)
+        self.ctrl = torch.zeros((8,), dtype=torch.int32, device=self.dev)
         self._ctrl_init = torch.tensor([0, 0, 0, _INT_MAX], dtype=torch.int32, device=self.dev)
         self.ws = torch.empty((int(ops._lib.load().chx_lj_ws_count(self.n)),), dtype=torch.float64, device=self.dev)
         self.is_verlet = isinstance(nbr_list, NeighborListNsqrd)
@@ -246,7 +247,25 @@ class _RunState:
         )
         return out
 
-    def _load(self, x_user: torch.Tensor, v_user: torch.Tensor):
+    def _inner_list_settings(self, skin: float):
+        """(inner_skin [nm], prune_every [steps]) of the dynamically pruned list, (0, 0) = off.
+
+        The reference's skin (0.5 nm in its examples) keeps ~3x more pairs listed than can
+        interact; between rebuilds the step kernel walks a copy pruned to cutoff + inner_skin
+        that is refreshed every ``prune_every`` steps (include/chx.h: chx_langevin_t).  Pure
+        speed knobs: the interacting pairs are the reference's in every case.
+        """
+        env_skin, env_every = os.environ.get("CHX_INNER_SKIN"), os.environ.get("CHX_PRUNE_EVERY")
+        inner = float(env_skin) if env_skin is not None else getattr(self.integ, "inner_skin_nm", None)
+        every = int(env_every) if env_every is not None else getattr(self.integ, "prune_every", 32)
+        if inner is None:
+            # little to prune under a thin skin; tiny systems are pure launch latency
+            inner = 0.12 if (skin >= 0.3 and self.n >= 2048) else 0.0
+        if inner <= 0.0 or every <= 0 or inner >= skin:
+            return 0.0, 0
+        return inner, every
+
+    def _load(self, x_user: torch.Tensor, v_user: torch.Tensor, step: int = 0):
         """(Re)pack user-order arrays into the internal order of the current force list."""
         self.fl = self.nbr_list.force_list if self.mode == "fused" else None
         perm = self.fl.perm if self.fl is not None else None
@@ -293,6 +312,15 @@ class _RunState:
         p.ctrl = self.ctrl.data_ptr()
         p.ws = self.ws.data_ptr()
         p.external_force = 1 if self.mode == "external" else 0
+        if self.fl is not None and self.is_verlet:
+            inner, every = self._inner_list_settings(skin)
+            if every > 0:
+                self.fl_inner = torch.empty_like(self.fl.fl)
+                self.deg_inner = torch.empty_like(self.fl.deg)
+                self.ref_inner4 = torch.empty_like(self.x_a)
+                p.fl_inner, p.deg_inner = self.fl_inner.data_ptr(), self.deg_inner.data_ptr()
+                p.ref_inner4 = self.ref_inner4.data_ptr()
+                p.inner_skin, p.prune_every, p.prune_phase = inner, every, step
         self.params = p
 
     def _x_cur(self) -> torch.Tensor:
@@ -312,7 +340,7 @@ class _RunState:
     def velocities_user(self) -> torch.Tensor:
         return self._unpack(self.v)
 
-    def _rebuild(self):
+    def _rebuild(self, step: int = 0):
         """The host half of chiron/integrators.py:241-242 once the device check has fired."""
         import os, time
 
@@ -322,7 +350,7 @@ class _RunState:
             t0 = time.perf_counter()
         x_user, v_user = self.positions_user(), self.velocities_user()
         self.nbr_list.build(x_user, self.nbr_list.box_vectors)
-        self._load(x_user, v_user)
+        self._load(x_user, v_user, step)
         self.n_rebuilds += 1
         if prof:
             torch.cuda.synchronize()
@@ -341,15 +369,21 @@ class _RunState:
         # a slot is reused only after the chunk that owned it has been waited for
         ring = getattr(self.integ, "_pinned_ring", None)
         if ring is None or len(ring) < self.depth + 2:
-            ring = self.integ._pinned_ring = [torch.empty((4,), dtype=torch.int32, pin_memory=True)
+            ring = self.integ._pinned_ring = [torch.empty((8,), dtype=torch.int32, pin_memory=True)
                                               for _ in range(self.depth + 2)]
             self.integ._ring_next = 0
         rec.host = ring[self.integ._ring_next % len(ring)]
         self.integ._ring_next += 1
-        ops.publish(self.ctrl, rec.host, 4)  # a kernel on this stream: no copy engine / blit queue in the loop
+        ops.publish(self.ctrl, rec.host, 8)  # a kernel on this stream: no copy engine / blit queue in the loop
         rec.event = torch.cuda.Event()
         rec.event.record()
         return rec
+
+    def _bank_inner_stats(self):
+        """Fold the device counters (reset with every load) into the integrator's totals."""
+        self.integ.full_list_launches = getattr(self.integ, "full_list_launches", 0) + getattr(self, "_seen_full", 0)
+        self.integ.prune_passes = getattr(self.integ, "prune_passes", 0) + getattr(self, "_seen_prune", 0)
+        self._seen_full = self._seen_prune = 0
 
     def _advance_fused(self, done: int, stop: int) -> int:
         chunk = self.integ.chunk_size
@@ -373,12 +407,14 @@ class _RunState:
             else:
                 rec.event.synchronize()
             halt = int(rec.host[3])
+            self._seen_full, self._seen_prune = int(rec.host[6]), int(rec.host[7])  # counters since the last load
             if halt <= rec.s0 + rec.n:
                 # skin check fired while producing x_halt: steps < halt ran, everything queued behind is a no-op
                 torch.cuda.synchronize()
                 pending.clear()
                 self.parity = rec.parity0 ^ ((halt - rec.s0) & 1)
-                self._rebuild()
+                self._bank_inner_stats()
+                self._rebuild(halt)
                 done = nxt = halt
             else:
                 done = rec.s0 + rec.n
@@ -422,5 +458,7 @@ class _RunState:
             self.kicks_next = 1
             rec = self._enqueue_fused(n_steps, 1, do_aoa=0)
             rec.event.synchronize()
+            self._seen_full, self._seen_prune = int(rec.host[6]), int(rec.host[7])
+            self._bank_inner_stats()
         else:
             ops.kick(self.v, self.f, self.mass, self.half_dt)

@@ -270,19 +270,20 @@ def fl_chunks_for(maxdeg: int, g: int) -> int:
 
 
 def _choose_g(maxdeg: int, n: int) -> int:
-    """Lanes that cooperate on one particle in the list kernel.
+    """Lanes that cooperate on one particle in the list kernels.
 
-    Measured on MI355X (scripts/kernel_bench.py): the kernel wants >= ~5e5 lanes in flight to
-    fill 256 CUs (>= 2.6e5 lanes), as few lanes per particle as that allows (less reduction and
-    idle-lane overhead), and no more than ~24 sequential entries per lane.
+    Measured on MI355X (scripts/exp_prune.sh, scripts/kernel_bench.py): the kernels want
+    >= 2^18 lanes in flight to fill 256 CUs, as few lanes per particle as that allows (less
+    reduction, fewer idle lanes, all workgroups resident at once), and no more than ~48 listed
+    entries per lane (the step kernel mostly walks the pruned list, about half of that).
     """
     env = os.environ.get("CHX_FL_G")
     if env:
         return int(env)
-    g = 4  # the fused step kernel wants <= 256 (particle, component) tasks per 256-thread block
+    g = 2
     while g < 64 and n * g < (1 << 18):
         g *= 2
-    while g < 64 and maxdeg > 24 * g:
+    while g < 64 and maxdeg > 48 * g:
         g *= 2
     while g > 1 and g > max(1, maxdeg):
         g //= 2

@@ -15,13 +15,13 @@ T = {"drain": 0.0, "unpack": 0.0, "build": 0.0, "load": 0.0, "n": 0}
 RS = integrators._RunState
 orig_rebuild = RS._rebuild
 
-def timed_rebuild(self):
+def timed_rebuild(self, step=0):
     t0 = time.perf_counter()
     x_user, v_user = self.positions_user(), self.velocities_user()
     torch.cuda.synchronize(); t1 = time.perf_counter()
     self.nbr_list.build(x_user, self.nbr_list.box_vectors)
     torch.cuda.synchronize(); t2 = time.perf_counter()
-    self._load(x_user, v_user)
+    self._load(x_user, v_user, step)
     torch.cuda.synchronize(); t3 = time.perf_counter()
     self.n_rebuilds += 1
     T["unpack"] += t1 - t0; T["build"] += t2 - t1; T["load"] += t3 - t2; T["n"] += 1
@@ -35,3 +35,4 @@ n = max(T["n"], 1)
 print(f"{wl}: {steps} steps in {1e3*dt:.2f} ms ({steps/dt:.0f} steps/s), rebuilds {T['n']}")
 print(f"  per rebuild: unpack {1e6*T['unpack']/n:.0f} us, build {1e6*T['build']/n:.0f} us, load {1e6*T['load']/n:.0f} us"
       f"  -> {1e6*(T['unpack']+T['build']+T['load'])/n:.0f} us; all rebuilds = {100*(T['unpack']+T['build']+T['load'])/dt:.1f}% of the run")
+print(f"  inner list: {getattr(integ, 'prune_passes', 0)} pruning passes, {getattr(integ, 'full_list_launches', 0)} launches on the full list")

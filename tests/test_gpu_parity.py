@@ -616,6 +616,41 @@ def test_langevin_injected_noise_matches_oracle(ca, O):
     assert np.abs(out.velocities.cpu().numpy() - vo).max() < 2e-4 * max(1.0, np.abs(vo).max())
 
 
+@pytest.mark.parametrize("inner,every", [(0.03, 4), (0.002, 8), (0.01, 1000)], ids=["pruned", "mostly-stale", "never-refreshed"])
+def test_langevin_pruned_inner_list_keeps_the_reference_pairs(ca, O, monkeypatch, inner, every):
+    """The dynamically pruned inner list is a speed device only: with it on -- including when it
+    goes stale and the kernel falls back to the full list -- the trajectory follows the oracle
+    (injected noise) and the list rebuilds happen at the reference's steps."""
+    n, steps, skin = 2500, 40, 0.05
+    monkeypatch.setenv("CHX_INNER_SKIN", str(inner))
+    monkeypatch.setenv("CHX_PRUNE_EVERY", str(every))
+    x, box, pot, state, thermo, nbr, integ = _langevin_setup(ca, O, n, 0.3, 43, skin, 4.0)
+    rng = np.random.default_rng(5)
+    noise = rng.normal(size=(steps, n, 3)).astype(f32)
+    mass = np.full(n, 39.948, f32)
+    kT = O.R_KJ * 300.0
+    v0 = O.initial_velocities(mass, kT, rng.normal(size=(n, 3)).astype(f32))
+    state.velocities = v0
+    out, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr, noise=noise)
+    xo, vo, rebuilds, _ = O.langevin_run(x, v0, box, mass, SIGMA, EPS, CUTOFF, skin, 180, 0.004, 1.0, 300.0, steps,
+                                         lambda s_: noise[s_])
+    assert integ.n_rebuilds == rebuilds and rebuilds >= 1
+    assert integ.prune_passes >= 1
+    if inner < 0.005 or every > steps:
+        assert integ.full_list_launches > 0  # the stale-list fallback really ran
+    else:
+        assert integ.full_list_launches <= steps // 4  # the pruned table carried (nearly) every launch
+    assert np.abs(out.positions.cpu().numpy() - xo).max() < 5e-6
+    assert np.abs(out.velocities.cpu().numpy() - vo).max() < 5e-4 * max(1.0, np.abs(vo).max())
+    # and the run is still independent of how the steps are batched into launches
+    x2, box2, pot2, state2, thermo2, nbr2, integ2 = _langevin_setup(ca, O, n, 0.3, 43, skin, 4.0)
+    integ2.chunk_size = 32
+    state2.velocities = v0
+    out2, _ = integ2.run(state2, thermo2, number_of_steps=steps, nbr_list=nbr2, noise=noise)
+    assert torch.equal(out.positions, out2.positions) and torch.equal(out.velocities, out2.velocities)
+    assert (integ2.prune_passes, integ2.full_list_launches) == (integ.prune_passes, integ.full_list_launches)
+
+
 def test_langevin_rebuild_step_matches_oracle(ca, O):
     """Tiny skin + large timestep: the device flag must stop the chunk at the reference's rebuild step."""
     n, steps = 400, 30
