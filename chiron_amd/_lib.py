@@ -157,6 +157,28 @@ class ChxError(RuntimeError):
     pass
 
 
+def _share_torch_hip_runtime() -> None:
+    """libchx must drive the SAME HIP runtime instance that owns torch's streams and allocations.
+
+    The PyTorch-ROCm wheel bundles its own libamdhip64.so while libchx.so is linked against the
+    system one (/opt/rocm): with both in the process, libchx's HIP calls have to bind to the copy
+    torch uses, or the stream handles it is given belong to another runtime.  Putting torch's
+    copy in the global symbol scope and initialising torch's device context BEFORE libchx (and its
+    registration of the gfx950 code objects) is loaded guarantees that, whatever the import order
+    of the caller (found with build()+smoke() in one process: hipMemsetAsync failed).
+    """
+    try:
+        import torch
+    except ImportError:  # pragma: no cover - torch is the memory/stream provider of this package
+        return
+    if getattr(torch.version, "hip", None):
+        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(bundled):
+            C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+    if torch.cuda.is_available():
+        torch.cuda.init()
+
+
 def load() -> C.CDLL:
     """Load libchx.so and bind every symbol; raises if anything is missing."""
     global _lib
@@ -167,6 +189,7 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: the HIP extension has not been built "
             "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
         )
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
