@@ -169,20 +169,59 @@ __global__ void k_cell_scatter(const int32_t* __restrict__ cell_of, int n,
 }
 
 // ascending particle id inside each cell: makes the internal order (and with it
-// every floating-point summation order downstream) reproducible run to run
-__global__ void k_cell_sort(const int32_t* __restrict__ cell_start, int ncell,
-                            uint32_t* __restrict__ sorted_ids) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
+// every floating-point summation order downstream) reproducible run to run.
+// One wavefront per cell: every lane holds up to CHX_SORT_PER_LANE ids in registers, ranks
+// them against the whole cell through wave shuffles and writes them back in place by rank.
+// Cells with more particles than that (reduced densities far above a liquid's) fall back
+// to a serial insertion sort by lane 0.
+#define CHX_SORT_PER_LANE 4
+__global__ __launch_bounds__(256) void k_cell_sort(const int32_t* __restrict__ cell_start, int ncell,
+                                                   uint32_t* __restrict__ sorted_ids) {
+  const int lane = lane_id();
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (c >= ncell) return;
   const int s = cell_start[c], e = cell_start[c + 1];
-  for (int a = s + 1; a < e; ++a) {
-    uint32_t v = sorted_ids[a];
-    int b = a - 1;
-    while (b >= s && sorted_ids[b] > v) {
-      sorted_ids[b + 1] = sorted_ids[b];
-      --b;
+  const int np = e - s;
+  if (np <= 1) return;
+  if (np > CHX_WAVE * CHX_SORT_PER_LANE) {
+    if (lane == 0) {
+      for (int a = s + 1; a < e; ++a) {
+        const uint32_t v = sorted_ids[a];
+        int b = a - 1;
+        while (b >= s && sorted_ids[b] > v) {
+          sorted_ids[b + 1] = sorted_ids[b];
+          --b;
+        }
+        sorted_ids[b + 1] = v;
+      }
     }
-    sorted_ids[b + 1] = v;
+    return;
+  }
+  uint32_t mine[CHX_SORT_PER_LANE];
+  int rank[CHX_SORT_PER_LANE];
+#pragma unroll
+  for (int k = 0; k < CHX_SORT_PER_LANE; ++k) {
+    const int t = k * CHX_WAVE + lane;
+    mine[k] = t < np ? sorted_ids[s + t] : 0xFFFFFFFFu;  // ids are distinct and < 2^32 - 1
+    rank[k] = 0;
+  }
+  const int rounds = (np + CHX_WAVE - 1) / CHX_WAVE;
+  for (int kb = 0; kb < rounds; ++kb) {
+    // lane-uniform choice of the register that is broadcast this round
+    uint32_t src = mine[0];
+#pragma unroll
+    for (int k = 1; k < CHX_SORT_PER_LANE; ++k) src = kb == k ? mine[k] : src;
+    const int count = np - kb * CHX_WAVE < CHX_WAVE ? np - kb * CHX_WAVE : CHX_WAVE;
+    for (int l = 0; l < count; ++l) {
+      const uint32_t other = __shfl(src, l, CHX_WAVE);
+#pragma unroll
+      for (int k = 0; k < CHX_SORT_PER_LANE; ++k) rank[k] += other < mine[k] ? 1 : 0;
+    }
+  }
+  // every id was read into registers above before any lane writes
+#pragma unroll
+  for (int k = 0; k < CHX_SORT_PER_LANE; ++k) {
+    if (k * CHX_WAVE + lane < np) sorted_ids[s + rank[k]] = mine[k];
   }
 }
 
@@ -296,8 +335,8 @@ int chx_cell_prepare(const float* xyz, int n, chx_box_t box, float cutoff_plus_s
   hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, st, cell_count, cell_start, ncell);
   hipLaunchKernelGGL(k_cell_scatter, dim3(pb), dim3(256), 0, st, cell_of, n, cell_start, cell_count,
                      sorted_ids);
-  hipLaunchKernelGGL(k_cell_sort, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, cell_start,
-                     ncell, sorted_ids);
+  hipLaunchKernelGGL(k_cell_sort, dim3((unsigned)(((int64_t)ncell * CHX_WAVE + 255) / 256)), dim3(256), 0, st,
+                     cell_start, ncell, sorted_ids);
   return CHX_OK;
 }
 

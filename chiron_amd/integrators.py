@@ -272,11 +272,20 @@ class _RunState:
         self.perm = perm
         n = self.n
         # one launch: positions (current buffer when parity == 0), velocities, masses, reference positions
+        prev = (self.x_a, self.v, self.mass, self.ref4) if getattr(self, "x_a", None) is not None else None
         self.x_a, self.v, self.mass, self.ref4 = ops.pack_langevin(
-            x_user, v_user, self.mass_user, self.nbr_list.ref_positions if self.is_verlet else None, perm, self.is_verlet)
-        self.x_b = torch.empty_like(self.x_a) if self.mode == "fused" else None  # fully written before it is read
+            x_user, v_user, self.mass_user, self.nbr_list.ref_positions if self.is_verlet else None, perm, self.is_verlet,
+            out=prev)  # a rebuild writes into the buffers of the previous load (the state was copied out first)
+        if self.mode == "fused":
+            if getattr(self, "x_b", None) is None:
+                self.x_b = torch.empty_like(self.x_a)  # fully written before it is read
+        else:
+            self.x_b = None
         self.parity = 0
-        self.f = torch.zeros((n, 3), dtype=torch.float32, device=self.dev) if self.mode != "fused" else None
+        if self.mode != "fused":
+            self.f = torch.zeros((n, 3), dtype=torch.float32, device=self.dev)
+        else:
+            self.f = None
         box = Box(0, 0.0, 0.0, 0.0)
         wrap = 0
         skin = 0.0
@@ -315,9 +324,10 @@ class _RunState:
         if self.fl is not None and self.is_verlet:
             inner, every = self._inner_list_settings(skin)
             if every > 0:
-                self.fl_inner = torch.empty_like(self.fl.fl)
-                self.deg_inner = torch.empty_like(self.fl.deg)
-                self.ref_inner4 = torch.empty_like(self.x_a)
+                if getattr(self, "fl_inner", None) is None or self.fl_inner.shape != self.fl.fl.shape:
+                    self.fl_inner = torch.empty_like(self.fl.fl)
+                    self.deg_inner = torch.empty_like(self.fl.deg)
+                    self.ref_inner4 = torch.empty_like(self.x_a)
                 p.fl_inner, p.deg_inner = self.fl_inner.data_ptr(), self.deg_inner.data_ptr()
                 p.ref_inner4 = self.ref_inner4.data_ptr()
                 p.inner_skin, p.prune_every, p.prune_phase = inner, every, step
@@ -349,7 +359,11 @@ class _RunState:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
         x_user, v_user = self.positions_user(), self.velocities_user()
-        self.nbr_list.build(x_user, self.nbr_list.box_vectors)
+        self.nbr_list._adopt_positions = True  # x_user is a fresh tensor nobody else holds
+        try:
+            self.nbr_list.build(x_user, self.nbr_list.box_vectors)
+        finally:
+            self.nbr_list._adopt_positions = False
         self._load(x_user, v_user, step)
         self.n_rebuilds += 1
         if prof:

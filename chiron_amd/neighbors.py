@@ -197,6 +197,7 @@ class NeighborListNsqrd(PairsBase):
                 f"cutoff must be a unit.Quantity with units of distance, cutoff.unit = {cutoff.unit}"
             )
         self._cutoff = cutoff
+        self._cs_md = None
         self.is_built = False  # chiron/neighbors.py:485
 
     @property
@@ -208,6 +209,7 @@ class NeighborListNsqrd(PairsBase):
         if not skin.unit.is_compatible(unit.nanometer):
             raise ValueError(f"skin must be a unit.Quantity with units of distance, skin.unit = {skin.unit}")
         self._skin = skin
+        self._cs_md = None
         self.is_built = False  # chiron/neighbors.py:502
 
     # -- build -------------------------------------------------------------
@@ -237,8 +239,10 @@ class NeighborListNsqrd(PairsBase):
             if ncell > 0:
                 g, chunks = self._fl_geometry(n)
                 for _ in range(4):
+                    if getattr(self, "_scratch", None) is None:
+                        self._scratch = {}
                     nl, first, n_nbr, sorted_ids, fl, deg, status = ops.nl_build_cell_fl(
-                        self.ref_positions, self._box_h, cs, m, ncell, nc, g, chunks)
+                        self.ref_positions, self._box_h, cs, m, ncell, nc, g, chunks, self._scratch)
                     st = status.cpu().tolist()  # the build's only host sync (the reference syncs at :709)
                     if _DEBUG_BUILD:
                         print(f"[chx build] n={n} m={m} g={g} chunks={chunks} status={st}", flush=True)
@@ -261,17 +265,25 @@ class NeighborListNsqrd(PairsBase):
     def build(self, positions, box_vectors):
         """chiron/neighbors.py:628-729"""
         positions = _strip_positions(positions)
-        box_vectors = _strip_box(box_vectors)
-        self.ref_positions = as_tensor(positions).clone()
-        self.box_vectors = None if box_vectors is None else as_tensor(box_vectors)
-        if self.space.periodic and self.box_vectors is None:
-            # the reference raises from Space.displacement (chiron/neighbors.py:71-72)
-            raise ValueError("box_vectors must be provided for a periodic system")
-        self._box_h = ops.make_box(self.box_vectors, self.space.periodic)
-        cutoff_and_skin = self.cutoff + self.skin
-        self._cutoff_and_skin = float(cutoff_and_skin.value_in_unit_system(unit.md_unit_system))
+        if box_vectors is not None and box_vectors is getattr(self, "box_vectors", None) and getattr(self, "_box_h", None) is not None:
+            pass  # the very tensor this list already holds (integrator rebuilds): host copy is current
+        else:
+            box_vectors = _strip_box(box_vectors)
+            self.box_vectors = None if box_vectors is None else as_tensor(box_vectors)
+            if self.space.periodic and self.box_vectors is None:
+                # the reference raises from Space.displacement (chiron/neighbors.py:71-72)
+                raise ValueError("box_vectors must be provided for a periodic system")
+            self._box_h = ops.make_box(self.box_vectors, self.space.periodic)  # reads the box on the host
+        pos = as_tensor(positions)
+        # ``_adopt_positions``: the integrator hands over a tensor nobody else holds (no copy needed)
+        self.ref_positions = pos if getattr(self, "_adopt_positions", False) and pos is positions else pos.clone()
+        if self._cs_md is None:  # unit arithmetic is slow Python: once per (cutoff, skin)
+            self._cs_md = float((self.cutoff + self.skin).value_in_unit_system(unit.md_unit_system))
+        self._cutoff_and_skin = self._cs_md
         n = self.ref_positions.shape[0]
-        self.particle_ids = torch.arange(n, dtype=torch.int32, device=self.ref_positions.device)
+        ids = getattr(self, "particle_ids", None)
+        if ids is None or ids.shape[0] != n or ids.device != self.ref_positions.device:
+            self.particle_ids = torch.arange(n, dtype=torch.int32, device=self.ref_positions.device)
 
         res = self._build_pass(int(self.n_max_neighbors))
         # growth loop, chiron/neighbors.py:709-727 (equality test, as in the reference)
@@ -356,6 +368,8 @@ class NeighborListNsqrd(PairsBase):
         for k, v in self.__dict__.items():
             if k == "_force_list":
                 new._force_list = None  # rebuilt lazily; it is a pure function of the list
+            elif k == "_scratch":
+                new._scratch = None  # kernel work arrays are not part of the list
             elif isinstance(v, torch.Tensor):
                 setattr(new, k, v.clone())
             else:

@@ -146,10 +146,13 @@ def nl_build_cell(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: int, 
     return nl, mask, n_nbr, sorted_ids, status
 
 
-def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: int, ncell: int, nc, g: int, chunks: int):
+def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: int, ncell: int, nc, g: int, chunks: int,
+                     scratch: Optional[dict] = None):
     """One-pass cell build (half-list rows without padding + force list).
 
     Returns (nl_rows, first, n_nbr, sorted_ids, fl, deg, status8); nothing is synchronised here.
+    ``scratch`` (a dict the caller keeps between builds) lets the kernel-internal work arrays be
+    reused: the arrays that become part of the list are always fresh.
     """
     xyz = _f32(xyz)
     _require_device(xyz)
@@ -159,14 +162,20 @@ def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: in
     nl = torch.empty((n, m), **i32)
     first = torch.empty((n,), **i32)
     n_nbr = torch.empty((n,), **i32)
-    cell_of = torch.empty((n,), **i32)
-    cell_count = torch.empty((ncell + 1,), **i32)
-    cell_start = torch.empty((ncell + 1,), **i32)
     sorted_ids = torch.empty((n,), **i32)
-    status = torch.empty((8,), **i32)
     fl = torch.empty((chunks, n, FL_QUAD * g), **i32)
     deg = torch.empty((n,), **i32)
-    xs4 = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    key = (n, ncell, str(dev))
+    if scratch is not None and scratch.get("key") == key:
+        cell_of, cell_count, cell_start, status, xs4 = scratch["arrays"]
+    else:
+        cell_of = torch.empty((n,), **i32)
+        cell_count = torch.empty((ncell + 1,), **i32)
+        cell_start = torch.empty((ncell + 1,), **i32)
+        status = torch.empty((8,), **i32)
+        xs4 = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        if scratch is not None:
+            scratch["key"], scratch["arrays"] = key, (cell_of, cell_count, cell_start, status, xs4)
     check(
         _lib.load().chx_nl_build_cell_fl(
             _ptr(xyz), n, m, box, C.c_float(cutoff_plus_skin), nc, _ptr(cell_of), _ptr(cell_count), _ptr(cell_start),
@@ -187,20 +196,23 @@ def nl_finish_padding(nl: torch.Tensor, first: torch.Tensor, n_nbr: torch.Tensor
     return mask
 
 
-def pack_langevin(x3, v3, mass, ref3, perm, want_ref: bool):
-    """User-order state -> internal order in one launch: (x4, v, mass_internal, ref4 or None)."""
+def pack_langevin(x3, v3, mass, ref3, perm, want_ref: bool, out=None):
+    """User-order state -> internal order in one launch: (x4, v, mass_internal, ref4 or None).
+    ``out`` = a previous result of the same shapes to write into."""
     x3, v3, mass = _f32(x3), _f32(v3), _f32(mass)
     _require_device(x3, v3, mass, perm)
     n = x3.shape[0]
     dev = x3.device
-    x4 = torch.empty((n, 4), dtype=torch.float32, device=dev)
-    v = torch.empty((n, 3), dtype=torch.float32, device=dev)
-    m_int = torch.empty((n,), dtype=torch.float32, device=dev)
-    ref4 = None
+    if out is not None and out[0].shape[0] == n and (out[3] is not None) == bool(want_ref):
+        x4, v, m_int, ref4 = out
+    else:
+        x4 = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        v = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        m_int = torch.empty((n,), dtype=torch.float32, device=dev)
+        ref4 = torch.empty((n, 4), dtype=torch.float32, device=dev) if want_ref else None
     if want_ref:
         ref3 = _f32(ref3)
         _require_device(ref3)
-        ref4 = torch.empty((n, 4), dtype=torch.float32, device=dev)
     check(
         _lib.load().chx_pack_langevin(_ptr(x3), _ptr(v3), _ptr(mass), _ptr(ref3) if want_ref else None, _ptr(perm), n,
                                       _ptr(x4), _ptr(v), _ptr(m_int), _ptr(ref4), _stream()),

@@ -19,7 +19,9 @@ def timed_rebuild(self, step=0):
     t0 = time.perf_counter()
     x_user, v_user = self.positions_user(), self.velocities_user()
     torch.cuda.synchronize(); t1 = time.perf_counter()
+    self.nbr_list._adopt_positions = True
     self.nbr_list.build(x_user, self.nbr_list.box_vectors)
+    self.nbr_list._adopt_positions = False
     torch.cuda.synchronize(); t2 = time.perf_counter()
     self._load(x_user, v_user, step)
     torch.cuda.synchronize(); t3 = time.perf_counter()
