@@ -78,6 +78,22 @@ class SamplerState:
         self._box_vectors = None if box_vectors is None else self._to_md(box_vectors)
         self._current_PRNG_key = current_PRNG_key
 
+    def __deepcopy__(self, memo):
+        """Same result as the generic deep copy (every caller of the reference copies states
+        freely, chiron/integrators.py:210, chiron/mcmc.py:726), without walking the object graph:
+        three tensor clones."""
+        new = SamplerState.__new__(SamplerState)
+        memo[id(self)] = new
+        for name, value in self.__dict__.items():
+            if isinstance(value, unit.Quantity) and isinstance(value._value, torch.Tensor):
+                value = unit.Quantity(value._value.clone(), value.unit)
+            elif name not in ("_distance_unit", "_time_unit", "_current_PRNG_key"):
+                import copy
+
+                value = copy.deepcopy(value, memo)
+            setattr(new, name, value)
+        return new
+
     def _to_md(self, q: unit.Quantity) -> unit.Quantity:
         value = q.value_in_unit_system(unit.md_unit_system)
         target = self._distance_unit

@@ -43,13 +43,14 @@ class Unit:
     __array_ufunc__ = None  # make numpy defer to __rmul__/__rtruediv__
     __array_priority__ = 1000
 
-    __slots__ = ("dims", "scale", "name")
+    __slots__ = ("dims", "scale", "name", "_sys_factor")
 
     def __init__(self, dims, scale, name: str):
         self.dims = tuple(Fraction(d) for d in dims)
         # exact rational scale whenever possible so that e.g. 10 angstrom == 1 nm exactly
         self.scale = _exact(scale)
         self.name = name
+        self._sys_factor = None  # (unit system id, float factor): exact-rational arithmetic is slow
 
     # -- algebra -----------------------------------------------------------
     def is_compatible(self, other: "Unit") -> bool:
@@ -149,8 +150,17 @@ class UnitSystem:
         # SI scale of the system's base unit for each dimension, where the mass
         # slot holds the scale of dalton (= gram/mole, mass*amount^-1).
         self.base_scales = base_scales
+        self._scale_cache = {}
 
-    def scale_for(self, dims) -> float:
+    def scale_for(self, dims):
+        """SI scale of this system's unit for ``dims`` (memoised: the hot callers convert the same
+        handful of dimensions -- length, velocity, energy -- thousands of times)."""
+        hit = self._scale_cache.get(dims)
+        if hit is None:
+            hit = self._scale_cache[dims] = self._scale_for(dims)
+        return hit
+
+    def _scale_for(self, dims):
         l, m, t, th, n, a, q = dims
         s = self.base_scales
         # mass^m is expressed as dalton^m * mole^m (dalton = mass/amount)
@@ -201,7 +211,13 @@ class Quantity:
         return _scale_value(self._value, self.unit.conversion_factor_to(unit))
 
     def value_in_unit_system(self, system: UnitSystem):
-        return _scale_value(self._value, float(self.unit.scale / system.scale_for(self.unit.dims)))
+        u = self.unit
+        cached = u._sys_factor
+        if cached is not None and cached[0] == id(system):
+            return _scale_value(self._value, cached[1])
+        factor = float(u.scale / system.scale_for(u.dims))
+        u._sys_factor = (id(system), factor)
+        return _scale_value(self._value, factor)
 
     def in_units_of(self, unit: Unit) -> "Quantity":
         return Quantity(self.value_in_unit(unit), unit)
