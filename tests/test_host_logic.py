@@ -345,3 +345,42 @@ def test_branch_free_minimum_image_formula_is_exact():
         m = np.minimum(np.minimum(a.view(np.uint32), t.view(np.uint32)), c.view(np.uint32)).view(f32)
         fast = (m - hL).astype(f32)
         assert np.array_equal(fast.view(np.uint32), ref.view(np.uint32)), float(L)
+
+
+def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
+    """Error convention of include/chx.h: a negative status plus a message, never an exception or a
+    launch, when the arguments cannot be right (these paths return before any HIP call)."""
+    import ctypes
+
+    from chiron_amd import _lib
+
+    lib = _lib.load()
+    box = _lib.Box(1, 10.0, 10.0, 10.0)
+    f = ctypes.c_float
+
+    def failed(rc, needle):
+        assert rc < 0
+        msg = lib.chx_last_error().decode()
+        assert needle in msg, msg
+
+    failed(lib.chx_nl_build_nsq(None, -1, 8, box, f(1.0), None, None, None, None), "chx_nl_build_nsq")
+    failed(lib.chx_nl_build_nsq(None, 4, 8, box, f(1.0), None, None, None, None), "null pointer")
+    failed(lib.chx_nl_build_nsq(ctypes.c_void_p(64), 4, 8, _lib.Box(1, 0.0, 1.0, 1.0), f(1.0), ctypes.c_void_p(64),
+                                ctypes.c_void_p(64), ctypes.c_void_p(64), None), "box lengths")
+    failed(lib.chx_lj_fl_energy_force(None, None, None, 8, 4, 1, box, f(1), f(1), f(1), None, None, None, None),
+           "nothing to compute")
+    failed(lib.chx_lj_fl_energy_force(None, None, None, 8, 4, 0, box, f(1), f(1), f(1), ctypes.c_void_p(64), None,
+                                      None, None), "null pointer")
+    failed(lib.chx_fl_fill(ctypes.c_void_p(64), ctypes.c_void_p(64), 8, 4, None, 3, ctypes.c_void_p(64),
+                           ctypes.c_void_p(64), None), "power of two")
+    failed(lib.chx_langevin_fused_chunk(None, None, None, 0, 1, 1, 1, None), "null params")
+    failed(lib.chx_mc_displace_chunk(None, 0, 1, None), "null parameter block")
+    failed(lib.chx_lj_nl_energy_force(None, None, None, 8, 0, box, f(1), f(1), f(1), None, None, None, None), "m >= 1")
+    failed(lib.chx_baoab_step(None, None, None, None, -3, box, 1, f(1), f(1), f(1), f(1), None, f(1), 0, 0, 0, None,
+                              None, None), "n < 0")
+    failed(lib.chx_kick(None, None, None, 5, f(0.1), None), "null pointer")
+    p = _lib.McParams()
+    p.n = 0
+    failed(lib.chx_mc_displace_chunk(ctypes.byref(p), 0, 1, None), "n <= 0")
+    # the threshold helper and the grid helper are pure host functions
+    assert lib.chx_version() == 1
