@@ -14,6 +14,7 @@ reference evaluates to, reference :21-24 and :322-332); no autodiff is involved.
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from . import ops, unit
@@ -66,6 +67,62 @@ class IdealGasPotential(NeuralNetworkPotential):
 
     def compute_force(self, positions, nbr_list=None):
         return 0.0
+
+
+class HarmonicOscillatorPotential(NeuralNetworkPotential):
+    """U(x) = (k/2) sum (x - x0)^2 + U0 (chiron/potential.py:335-430).
+
+    Not a pair path: kept so that the reference's integrator tests (a Harmonic oscillator
+    propagated with LangevinIntegrator, chiron/tests/test_mcmc.py:12-84) run on the BAOAB kernels
+    through the integrator's generic-potential branch.  Energy and the analytic force are plain
+    device tensor expressions, not hand-written kernels.
+    """
+
+    def __init__(
+        self,
+        topology,
+        k: unit.Quantity = 1.0 * unit.kilocalories_per_mole / unit.angstrom**2,
+        x0: unit.Quantity = None,
+        U0: unit.Quantity = 0.0 * unit.kilocalories_per_mole,
+    ):
+        if x0 is None:
+            x0 = unit.Quantity(np.array([[0.0, 0.0, 0.0]]), unit.angstrom)
+        # validation order and messages follow chiron/potential.py:358-389
+        if not isinstance(topology, Topology):
+            if not isinstance(topology, property):
+                if topology is not None:
+                    raise TypeError(
+                        f"Topology must be a Topology object or None, type(topology) = {type(topology)}"
+                    )
+        if not isinstance(k, unit.Quantity):
+            raise TypeError(f"k must be a unit.Quantity, type(k) = {type(k)}")
+        if not isinstance(x0, unit.Quantity):
+            raise TypeError(f"positions must be a unit.Quantity, type(positions) = {type(x0)}")
+        if not isinstance(U0, unit.Quantity):
+            raise TypeError(f"U0 must be a unit.Quantity, type(U0) = {type(U0)}")
+        if not k.unit.is_compatible(unit.kilocalories_per_mole / unit.angstrom**2):
+            raise ValueError(
+                f"k must be a unit.Quantity with units of energy per distance squared, k.unit = {k.unit}"
+            )
+        if not x0.unit.is_compatible(unit.angstrom):
+            raise ValueError(
+                f"positions must be a unit.Quantity with units of distance, positions.unit = {x0.unit}"
+            )
+        assert x0.shape[1] == 3, f"positions must be a NX3 vector, positions.shape = {x0.shape}"
+        if not U0.unit.is_compatible(unit.kilocalories_per_mole):
+            raise ValueError(f"U0 must be a unit.Quantity with units of energy, U0.unit = {U0.unit}")
+        self.k = float(k.value_in_unit_system(unit.md_unit_system))
+        self.x0 = as_tensor(x0.value_in_unit_system(unit.md_unit_system))
+        self.U0 = float(U0.value_in_unit_system(unit.md_unit_system))
+        self.topology = topology
+
+    def compute_energy(self, positions, nbr_list=None, debug_mode=False):
+        d = as_tensor(positions) - self.x0.to(as_tensor(positions).device)
+        return 0.5 * self.k * (d * d).sum() + self.U0  # :413-418
+
+    def compute_force(self, positions, nbr_list=None):
+        d = as_tensor(positions) - self.x0.to(as_tensor(positions).device)
+        return -self.k * d  # -grad U (the reference differentiates :413-418 with jax.grad)
 
 
 class LJPotential(NeuralNetworkPotential):

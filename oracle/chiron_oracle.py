@@ -19,9 +19,16 @@ test_pairs.py:26-57,102-160,275-318,348-405,441-485 (bit-exact indices/masks/
 distances), test_potential.py:33-55,177-230 and test_testsystems.py:144-165
 (energies/forces).  Whether XLA-CPU contracts x*x+y*y into an FMA in
 ``jnp.linalg.norm`` cannot be checked here, so agreement with a live JAX run at
-1-ulp cutoff-boundary pairs is UNPINNED (expected <~1 flip per 1e7 pairs), and
-anything that depends on JAX's threefry stream (test_mcmc.py:81-84, :451-452)
-is UNPINNED as well.
+1-ulp cutoff-boundary pairs is UNPINNED (expected <~1 flip per 1e7 pairs).
+The two literals that depend on JAX's threefry stream ARE pinned: with the stream
+restated in ``oracle/jax_prng.py`` (Threefry-2x32 + jax.random's split / uniform /
+normal), ``baoa_half`` / ``kick`` / ``initial_velocities`` reproduce the five
+Langevin energies of test_mcmc.py:81-84 to the reference's own tolerance (rtol
+1e-5; observed 3e-6, a constant-factor offset consistent with an element-mass or
+gas-constant digit in the reference's unpinned openmm) and ``barostat_propose`` /
+``barostat_log_ratio`` / ``metropolis_accept`` reproduce the 8-of-10 acceptance of
+test_mcmc.py:451-452 (tests/test_oracle_golden.py).  What stays UNPINNED is the
+product's own Philox stream (a different generator by design).
 """
 from __future__ import annotations
 

@@ -1006,6 +1006,76 @@ def test_minimize_energy(ca, O, golden):
         minimize_energy(dev(coords), lambda x_: 0.0, None, maxiter=3)
 
 
+def test_langevin_reference_literal_on_the_hip_integrator(ca, golden):
+    """chiron/tests/test_mcmc.py:12-84 end to end on the product: a Harmonic oscillator propagated by
+    LangevinIntegrator (BAOAB kernels, generic-potential branch) with the velocities and O-step
+    noise of the reference's own JAX stream (restated in oracle/jax_prng.py) reports the five
+    energies the reference asserts, to the reference's tolerance."""
+    from test_oracle_golden import jax_stream_langevin_ho
+
+    from chiron_amd.potential import HarmonicOscillatorPotential
+    from chiron_amd.reporters import LangevinDynamicsReporter
+    from chiron_amd.topology import Topology
+
+    u = ca.unit
+    g = golden["langevin_ho_jax_prng"]
+    e_oracle, x0, v0, noise, k_md = jax_stream_langevin_ho(g)
+    pot = HarmonicOscillatorPotential(Topology.homogeneous(1, "Ar"), g["k_kcal_mol_A2"] * u.kilocalories_per_mole / u.angstrom**2)
+    assert pot.k == k_md
+    thermo = ca.states.ThermodynamicState(potential=pot, temperature=g["temperature_K"] * u.kelvin)
+    ca.utils.PRNG.set_seed(g["seed"])
+    state = ca.states.SamplerState(positions=nm(x0, ca), current_PRNG_key=ca.utils.PRNG.get_random_key())
+    state.velocities = v0
+    reporter = LangevinDynamicsReporter()
+    integ = ca.integrators.LangevinIntegrator(timestep=g["timestep_fs"] * u.femtosecond, reporter=reporter, report_interval=1,
+                                              refresh_velocities=False)
+    integ.run(state, thermo, number_of_steps=5, noise=noise)
+    reporter.flush_buffer()
+    energy = np.asarray(reporter.get_property("potential_energy"), dtype=np.float64).ravel()
+    assert energy.shape == (5,)
+    assert np.allclose(energy, np.array(g["potential_energy"]), rtol=g["rtol"], atol=1e-8)
+    assert np.allclose(energy, e_oracle, rtol=2e-6)
+
+
+def test_barostat_reference_literal_on_the_product_move(ca, golden, monkeypatch):
+    """chiron/tests/test_mcmc.py:340-452 on the product's MonteCarloBarostatMove with its two random
+    draws (key split, uniform) switched to the reference's JAX stream: 8 of 10 moves accepted, the
+    same decisions as the oracle."""
+    from test_oracle_golden import jax_stream_barostat_decisions
+
+    from oracle import jax_prng as JX
+    from chiron_amd import mcmc as mcmc_mod, states as states_mod
+    from chiron_amd.rng import PRNGKey
+    from chiron_amd.topology import Topology
+
+    u = ca.unit
+    g = golden["barostat_ideal_gas_jax_prng"]
+
+    def jax_split(key):
+        a, b = JX.split((key[0], key[1]))
+        return PRNGKey(*a), PRNGKey(*b)
+
+    monkeypatch.setattr(states_mod, "split", jax_split)
+    monkeypatch.setattr(mcmc_mod, "host_uniform", lambda key, counter=0: float(JX.uniform((key[0], key[1]))))
+    positions = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 0], [1, 0, 1], [0, 1, 1], [1, 1, 1]], f32)
+    L = g["box_nm"]
+    pot = ca.potential.IdealGasPotential(Topology.homogeneous(g["n_particles"]))
+    _, first = JX.split(JX.PRNGKey(g["seed"]))  # PRNG.get_random_key() of the reference
+    state = ca.states.SamplerState(nm(positions, ca), PRNGKey(*first), box_vectors=nm(np.diag([L, L, L]).astype(f32), ca))
+    thermo = ca.states.ThermodynamicState(pot, temperature=g["temperature_K"] * u.kelvin, pressure=g["pressure_atm"] * u.atmosphere)
+    rep = ca_reporter(ca)
+    move = ca.mcmc.MonteCarloBarostatMove(volume_max_scale=g["volume_max_scale"], number_of_moves=g["n_proposed"],
+                                          reporter=rep, report_interval=1)
+    nbr = ca.neighbors.PairListNsqrd(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=0 * u.nanometer)
+    state, thermo, nbr = move.update(state, thermo, nbr)
+    assert move.statistics == {"n_accepted": g["n_accepted"], "n_proposed": g["n_proposed"]}
+    decisions, final_volume = jax_stream_barostat_decisions(g)
+    vol = rep.get_property("volume")
+    assert np.isclose(vol[-1], final_volume, rtol=1e-5)
+    accepted = np.concatenate([[vol[0] != L ** 3], np.diff(vol) != 0])
+    assert list(accepted) == decisions
+
+
 def test_metropolis_select_kernel(ca):
     from chiron_amd.rng import PRNGKey
 

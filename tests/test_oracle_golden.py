@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import chiron_oracle as O
+from oracle import jax_prng as JX
 from conftest import cube_coordinates
 
 f32 = np.float32
@@ -232,3 +233,83 @@ def test_c_oracle_matches_numpy_oracle():
     xo, vo, _, _ = O.langevin_run(x, v0, box, mass, 0.34, 0.995792, 1.02, 0.5, 250, 0.001, 1.0, 300.0, 3,
                                   lambda s: O.philox_normals3(n, s, O.STREAM_LANGEVIN, (7, 9)))
     assert np.abs(xc - xo).max() < 2e-6
+
+
+def jax_stream_langevin_ho(g, steps=5):
+    """The reference's HO Langevin test (chiron/tests/test_mcmc.py:12-84) on the oracle's BAOAB
+    functions, with the draws of chiron/utils.py:27-38,142, chiron/states.py:150-154 and
+    chiron/integrators.py:124,179,185 taken from the restated JAX stream.
+    Returns (energies, x0, v0, noise[steps,1,3], k_md)."""
+    f32 = np.float32
+    _, state_key = JX.split(JX.PRNGKey(g["seed"]))  # PRNG.get_random_key()
+    _, key = JX.split(state_key)                     # sampler_state.new_PRNG_key
+    kT, a, b = O.langevin_constants(g["temperature_K"], g["timestep_fs"] * 1e-3, g["collision_rate_per_ps"])
+    mass = np.array([g["mass_amu"]], f32)
+    k_md = f32(g["k_kcal_mol_A2"] * 4.184 / 0.01)    # kJ/mol/nm^2
+    x = np.zeros((1, 3), f32)
+    v0 = O.initial_velocities(mass, kT, JX.normal(key, (1, 3)))  # refresh_velocities=True: the run key itself
+    v = v0.copy()
+    force = lambda xx: (-k_md * xx).astype(f32)      # -grad of (k/2) sum (x - x0)^2, chiron/potential.py:413-418
+    F = force(x)
+    energies, noise = [], []
+    dt = g["timestep_fs"] * 1e-3
+    for _ in range(steps):
+        key, sub = JX.split(key)
+        z = JX.normal(sub, (1, 3))
+        noise.append(z)
+        x, v = O.baoa_half(x, v, F, mass, dt, a, b, kT, z)
+        F = force(x)
+        v = O.kick(v, F, mass, dt)
+        energies.append(float(f32(0.5) * k_md * np.sum((x * x).astype(f32), dtype=f32)))
+    return np.array(energies), np.zeros((1, 3), f32), v0, np.stack(noise), float(k_md)
+
+
+def test_langevin_literal_that_depends_on_the_jax_stream(golden):
+    """chiron/tests/test_mcmc.py:81-84: the five Harmonic-oscillator energies, to the reference's own
+    tolerance -- pins the oracle's BAOAB / velocity-initialisation arithmetic and the key handling
+    against a real output of the reference."""
+    g = golden["langevin_ho_jax_prng"]
+    e, *_ = jax_stream_langevin_ho(g)
+    assert np.allclose(e, np.array(g["potential_energy"]), rtol=g["rtol"], atol=1e-8)
+
+
+def jax_stream_barostat_decisions(g, split=JX.split, uniform=JX.uniform):
+    """The reference's ideal-gas barostat test (chiron/tests/test_mcmc.py:340-452) on the oracle's
+    propose / log-ratio / accept functions with the restated JAX draws (chiron/mcmc.py:953,967,437)."""
+    _, state_key = split(JX.PRNGKey(g["seed"]))
+    L = g["box_nm"]
+    x = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 0], [1, 0, 1], [0, 1, 1], [1, 1, 1]], np.float32)
+    box = np.diag([L, L, L]).astype(np.float32)
+    vol = lambda b: float(b[0, 0]) * float(b[1, 1]) * float(b[2, 2])
+    u_cur = O.reduced_potential(0.0, g["temperature_K"], g["pressure_atm"], vol(box))
+    decisions = []
+    for _ in range(g["n_proposed"]):
+        state_key, key = split(state_key)
+        u01 = (float(uniform(key, (), -1.0, 1.0)) + 1.0) / 2.0  # barostat_propose maps u01 -> uniform(-1, 1)
+        x_new, box_new, v0, v1 = O.barostat_propose(x, box, g["volume_max_scale"], u01)
+        u_new = O.reduced_potential(0.0, g["temperature_K"], g["pressure_atm"], v1)
+        lpr = O.barostat_log_ratio(u_new, u_cur, g["n_particles"], v1, v0)
+        state_key, akey = split(state_key)
+        ok = O.metropolis_accept(lpr, float(uniform(akey)))
+        decisions.append(ok)
+        if ok:
+            x, box, u_cur = x_new, box_new, u_new
+    return decisions, vol(box)
+
+
+def test_barostat_literal_that_depends_on_the_jax_stream(golden):
+    """chiron/tests/test_mcmc.py:451-452: 8 of the 10 volume moves are accepted."""
+    g = golden["barostat_ideal_gas_jax_prng"]
+    decisions, _ = jax_stream_barostat_decisions(g)
+    assert len(decisions) == g["n_proposed"] and sum(decisions) == g["n_accepted"]
+
+
+def test_threefry_known_answers():
+    """Random123 known-answer vectors for Threefry-2x32-20 (kat_vectors: zero, all-ones, pi digits)."""
+    u = np.uint32
+    x0, x1 = JX.threefry2x32((0, 0), np.array([0], u), np.array([0], u))
+    assert (int(x0[0]), int(x1[0])) == (0x6B200159, 0x99BA4EFE)
+    x0, x1 = JX.threefry2x32((0xFFFFFFFF, 0xFFFFFFFF), np.array([0xFFFFFFFF], u), np.array([0xFFFFFFFF], u))
+    assert (int(x0[0]), int(x1[0])) == (0x1CB996FC, 0xBB002BE7)
+    x0, x1 = JX.threefry2x32((0x13198A2E, 0x03707344), np.array([0x243F6A88], u), np.array([0x85A308D3], u))
+    assert (int(x0[0]), int(x1[0])) == (0xC4923A9C, 0x483DF7A0)
