@@ -415,34 +415,40 @@ struct StepArgs {
   float T_half_inner;   // a particle that moved r2 > T_half_inner since the pass invalidates the inner list
 };
 
-// operands of one (particle, component) integrate task
-struct StepTask {
+// operands of one particle's integrate work
+struct StepParticle {
   bool live;
-  int pp, c;
-  float m, v, x, ref, refi, z;
+  int pp;
+  float m;
+  float v[3];
+  float4 x, ref, refi;
+  float z[3];
 };
 
-__device__ __forceinline__ StepTask load_step_task(const StepArgs& a, long long step, int do_aoa, int p0,
-                                                   int task, int ntask) {
-  StepTask t;
-  const int pl = task / 3;
-  t.c = task - 3 * pl;
+__device__ __forceinline__ StepParticle load_step_particle(const StepArgs& a, long long step, int do_aoa, int p0,
+                                                           int pl, int ppb) {
+  StepParticle t;
   t.pp = p0 + pl;
-  t.live = task < ntask && t.pp < a.n;
+  t.live = pl < ppb && t.pp < a.n;
   t.m = 1.f;
-  t.v = t.x = t.ref = t.refi = t.z = 0.f;
+  t.v[0] = t.v[1] = t.v[2] = 0.f;
+  t.z[0] = t.z[1] = t.z[2] = 0.f;
+  t.x = t.ref = t.refi = make_float4(0.f, 0.f, 0.f, 0.f);
   if (t.live) {
     t.m = a.mass[t.pp];
-    t.v = a.v[3 * (size_t)t.pp + t.c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) t.v[c] = a.v[3 * (size_t)t.pp + c];
     if (do_aoa) {
-      t.x = reinterpret_cast<const float*>(a.x_cur)[4 * (size_t)t.pp + t.c];
-      if (a.ref4) t.ref = reinterpret_cast<const float*>(a.ref4)[4 * (size_t)t.pp + t.c];
-      if (a.fli) t.refi = reinterpret_cast<const float*>(a.refi4)[4 * (size_t)t.pp + t.c];
+      t.x = a.x_cur[t.pp];
+      if (a.ref4) t.ref = a.ref4[t.pp];
+      if (a.fli) t.refi = a.refi4[t.pp];
       const uint32_t o = a.perm ? a.perm[t.pp] : (uint32_t)t.pp;
       if (a.noise) {
-        t.z = a.noise[((size_t)(step - a.noise_step0) * (size_t)a.n + o) * 3 + t.c];
+        const float* row = a.noise + ((size_t)(step - a.noise_step0) * (size_t)a.n + o) * 3;
+        t.z[0] = row[0], t.z[1] = row[1], t.z[2] = row[2];
       } else {
-        t.z = philox_normal_c(o, (uint32_t)step, CHX_STREAM_LANGEVIN, a.k0, a.k1, t.c);
+        // one Philox block serves the three components of the particle
+        philox_normals3(o, (uint32_t)step, CHX_STREAM_LANGEVIN, a.k0, a.k1, t.z[0], t.z[1], t.z[2]);
       }
     }
   }
@@ -451,11 +457,8 @@ __device__ __forceinline__ StepTask load_step_task(const StepArgs& a, long long 
 
 template <int G>
 __global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int n_kicks, int do_aoa) {
-  constexpr int PPB = 256 / G;  // particles per block
-  constexpr int NTASK = 3 * PPB;
-  __shared__ float sF[NTASK];
-  __shared__ float sS[NTASK];
-  __shared__ float sI[NTASK];
+  constexpr int PPB = 256 / G;  // particles per block (<= 256)
+  __shared__ float sF[3 * PPB];
   if ((long long)a.ctrl[3] <= step) return;  // block-uniform
   // Which table this launch walks: the pruned inner list, unless some particle has moved too far
   // since the last pruning pass (flag raised by an EARLIER launch; the two flag words alternate
@@ -465,11 +468,10 @@ __global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int
   const int32_t* deg_use = inner ? a.degi : a.deg;
   const unsigned blk = xcd_block(blockIdx.x, gridDim.x);
   const int p0 = blk * PPB;
-  // ---- operands of this thread's integrate task, requested before the force loop so their
-  //      latency (and the Philox arithmetic) hides under it ----
-  StepTask tk[(NTASK + 255) / 256];
-#pragma unroll
-  for (int it = 0; it < (NTASK + 255) / 256; ++it) tk[it] = load_step_task(a, step, do_aoa, p0, it * 256 + threadIdx.x, NTASK);
+  // ---- operands of this thread's integrate work (threads 0..PPB-1 own one particle each: the
+  //      first wavefronts of the block), requested before the force loop so their latency and the
+  //      Philox arithmetic hide under it ----
+  const StepParticle tk = load_step_particle(a, step, do_aoa, p0, threadIdx.x, PPB);
 
   const int tid = blk * 256 + threadIdx.x;
   const int p = tid / G;
@@ -491,56 +493,49 @@ __global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int
     sF[3 * pl + 2] = fz;
   }
   __syncthreads();
-  // ---- integrate: one (particle, Cartesian component) task per thread, all lanes busy ----
+  // ---- integrate: one particle per thread, packed into the first PPB threads of the block ----
+  bool stale = false;
+  if (tk.live) {
+    const float L[3] = {a.box.lx, a.box.ly, a.box.lz};
+    const float xo[3] = {tk.x.x, tk.x.y, tk.x.z};
+    const float rf[3] = {tk.ref.x, tk.ref.y, tk.ref.z};
+    const float ri[3] = {tk.refi.x, tk.refi.y, tk.refi.z};
+    const float bs = fmul(a.b, fsqrt(fdiv(a.kT, tk.m)));
+    float xn[3], sq[3], sqi[3];
 #pragma unroll
-  for (int it = 0; it < (NTASK + 255) / 256; ++it) {
-    const int task = it * 256 + threadIdx.x;
-    const StepTask& t = tk[it];
-    float sq = 0.f, sqi = 0.f;
-    if (t.live) {
-      const float F = sF[task];
-      float vc = t.v;
-      for (int k = 0; k < n_kicks; ++k) vc = fadd(vc, fdiv(fmul(a.hdt, F), t.m));  // B  :181 / :195
+    for (int c = 0; c < 3; ++c) {
+      const float F = sF[3 * threadIdx.x + c];
+      float vc = tk.v[c];
+      for (int k = 0; k < n_kicks; ++k) vc = fadd(vc, fdiv(fmul(a.hdt, F), tk.m));  // B  :181 / :195
+      xn[c] = 0.f, sq[c] = 0.f, sqi[c] = 0.f;
       if (do_aoa) {
-        const float L = t.c == 0 ? a.box.lx : (t.c == 1 ? a.box.ly : a.box.lz);
-        float xc = fadd(t.x, fmul(a.hdt, vc));  // A  :183
-        const float bs = fmul(a.b, fsqrt(fdiv(a.kT, t.m)));
-        vc = fadd(fmul(a.a, vc), fmul(bs, t.z));  // O  :186
-        xc = fadd(xc, fmul(a.hdt, vc));           // A  :188
-        if (a.wrap && a.box.periodic) xc = wrap1(xc, L);  // :239
-        a.x_next[4 * (size_t)t.pp + t.c] = xc;
+        float xc = fadd(xo[c], fmul(a.hdt, vc));        // A  :183
+        vc = fadd(fmul(a.a, vc), fmul(bs, tk.z[c]));    // O  :186
+        xc = fadd(xc, fmul(a.hdt, vc));                 // A  :188
+        if (a.wrap && a.box.periodic) xc = wrap1(xc, L[c]);  // :239
+        xn[c] = xc;
         if (a.ref4) {
-          float r = fsub(xc, t.ref);
-          if (a.box.periodic) r = min_image(r, L, fmul(L, 0.5f));
-          sq = fmul(r, r);
+          float r = fsub(xc, rf[c]);
+          if (a.box.periodic) r = min_image(r, L[c], fmul(L[c], 0.5f));
+          sq[c] = fmul(r, r);
         }
         if (a.fli) {
-          float r = fsub(xc, t.refi);
-          if (a.box.periodic) r = min_image(r, L, fmul(L, 0.5f));
-          sqi = fmul(r, r);
+          float r = fsub(xc, ri[c]);
+          if (a.box.periodic) r = min_image(r, L[c], fmul(L[c], 0.5f));
+          sqi[c] = fmul(r, r);
         }
       }
-      a.v[3 * (size_t)t.pp + t.c] = vc;
+      a.v[3 * (size_t)tk.pp + c] = vc;
     }
-    if (task < NTASK) {
-      sS[task] = sq;
-      sI[task] = sqi;
-    }
-  }
-  if (do_aoa && (a.ref4 || a.fli)) {
-    __syncthreads();
-    bool stale = false;
-    for (int pl = threadIdx.x; pl < PPB; pl += 256) {
-      if (p0 + pl >= a.n) continue;
+    if (do_aoa) {
+      reinterpret_cast<float4*>(a.x_next)[tk.pp] = make_float4(xn[0], xn[1], xn[2], 0.f);
       // skin check :241: (rx^2 + ry^2) + rz^2 in the reference's order
-      if (a.ref4 && fadd(fadd(sS[3 * pl], sS[3 * pl + 1]), sS[3 * pl + 2]) > a.T_half_skin) {
-        atomicMin(&a.ctrl[3], (int)(step + 1));
-      }
-      if (a.fli && (sI[3 * pl] + sI[3 * pl + 1]) + sI[3 * pl + 2] > a.T_half_inner) stale = true;
+      if (a.ref4 && fadd(fadd(sq[0], sq[1]), sq[2]) > a.T_half_skin) atomicMin(&a.ctrl[3], (int)(step + 1));
+      if (a.fli && (sqi[0] + sqi[1]) + sqi[2] > a.T_half_inner) stale = true;
     }
-    // the inner list stays off until the next pruning pass clears both words
-    if (a.fli && (stale || (!inner && threadIdx.x == 0))) a.ctrl[4 + (int)((step + 1) & 1)] = 1;
   }
+  // the inner list stays off until the next pruning pass clears both words
+  if (do_aoa && a.fli && (stale || (!inner && threadIdx.x == 0))) a.ctrl[4 + (int)((step + 1) & 1)] = 1;
   if (a.fli && !inner && blockIdx.x == 0 && threadIdx.x == 0) a.ctrl[6] += 1;  // launches on the full list
 }
 
