@@ -420,17 +420,86 @@ struct StepParticle {
   bool live;
   int pp;
   float m;
+  float bs;  // b sigma_v = b sqrt(kT / m), chiron/integrators.py:131,186
   float v[3];
   float4 x, ref, refi;
   float z[3];
 };
 
+// One Cartesian component of the BAOAB update (chiron/integrators.py:181-195) with the wrap (:239),
+// the squared displacement from the list's reference positions (skin check, :241) and from the
+// positions of the last pruning pass.  FAST assumes 0 <= x_new < L and |x_new - ref| < L and
+// returns true when the assumption fails (the caller then takes the general instantiation):
+//   * x - floor(x / L) L == x bit for bit when +0 <= x < L (x / L rounds below 1: the spacing of
+//     floats under L is at least 2^-24 L), tested on the bit patterns so that -0.0 takes the
+//     general path (it wraps to +0.0);
+//   * min_image_fast == min_image for |d| < L (tests/test_host_logic.py, exhaustive on the CPU).
+template <bool FAST, bool HOT>
+__device__ __forceinline__ bool integrate_component(const StepArgs& a, int n_kicks, int do_aoa, float F, float m,
+                                                    float bs, float z, float v, float xo, float rf, float ri, float L,
+                                                    float hL, float& vn, float& xn, float& sq, float& sqi) {
+  // HOT: the steady-state launch (both kicks, A-O-A, periodic wrap, skin check, inner list), with
+  // the launch-uniform switches folded at compile time
+  const bool periodic = HOT || a.box.periodic;
+  const bool has_ref = HOT || a.ref4 != nullptr;
+  const bool has_inner = HOT || a.fli != nullptr;
+  const bool do_wrap = HOT || (a.wrap && a.box.periodic);
+  if (HOT) n_kicks = 2, do_aoa = 1;
+  bool rare = false;
+  const float kick = fdiv(fmul(a.hdt, F), m);
+  float vc = v;
+  for (int k = 0; k < n_kicks; ++k) vc = fadd(vc, kick);  // B  :181 / :195
+  xn = 0.f, sq = 0.f, sqi = 0.f;
+  if (do_aoa) {
+    float xc = fadd(xo, fmul(a.hdt, vc));      // A  :183
+    vc = fadd(fmul(a.a, vc), fmul(bs, z));     // O  :186
+    xc = fadd(xc, fmul(a.hdt, vc));            // A  :188
+    if (do_wrap) {                             // :239
+      if (FAST) {
+        rare |= !(__float_as_uint(xc) < __float_as_uint(L));
+      } else {
+        xc = wrap1(xc, L);
+      }
+    }
+    xn = xc;
+    if (has_ref) {
+      float r = fsub(xc, rf);
+      if (periodic) {
+        if (FAST) {
+          rare |= !(fabsf(r) < L);
+          r = min_image_fast(r, L, hL);
+        } else {
+          r = min_image(r, L, hL);
+        }
+      }
+      sq = fmul(r, r);
+    }
+    if (has_inner) {
+      // speed-only bookkeeping: anything the fast formula cannot vouch for counts as "moved too far"
+      float r = fsub(xc, ri);
+      if (periodic) {
+        if (FAST) {
+          const bool far = !(fabsf(r) < L);
+          r = far ? __builtin_inff() : min_image_fast(r, L, hL);
+        } else {
+          r = min_image(r, L, hL);
+        }
+      }
+      sqi = r * r;
+    }
+  }
+  vn = vc;
+  return rare;
+}
+
+template <bool HOT>
 __device__ __forceinline__ StepParticle load_step_particle(const StepArgs& a, long long step, int do_aoa, int p0,
                                                            int pl, int ppb) {
   StepParticle t;
   t.pp = p0 + pl;
   t.live = pl < ppb && t.pp < a.n;
   t.m = 1.f;
+  t.bs = 0.f;
   t.v[0] = t.v[1] = t.v[2] = 0.f;
   t.z[0] = t.z[1] = t.z[2] = 0.f;
   t.x = t.ref = t.refi = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -439,11 +508,12 @@ __device__ __forceinline__ StepParticle load_step_particle(const StepArgs& a, lo
 #pragma unroll
     for (int c = 0; c < 3; ++c) t.v[c] = a.v[3 * (size_t)t.pp + c];
     if (do_aoa) {
+      t.bs = fmul(a.b, fsqrt(fdiv(a.kT, t.m)));
       t.x = a.x_cur[t.pp];
-      if (a.ref4) t.ref = a.ref4[t.pp];
-      if (a.fli) t.refi = a.refi4[t.pp];
-      const uint32_t o = a.perm ? a.perm[t.pp] : (uint32_t)t.pp;
-      if (a.noise) {
+      if (HOT || a.ref4) t.ref = a.ref4[t.pp];
+      if (HOT || a.fli) t.refi = a.refi4[t.pp];
+      const uint32_t o = (HOT || a.perm) ? a.perm[t.pp] : (uint32_t)t.pp;
+      if (!HOT && a.noise) {
         const float* row = a.noise + ((size_t)(step - a.noise_step0) * (size_t)a.n + o) * 3;
         t.z[0] = row[0], t.z[1] = row[1], t.z[2] = row[2];
       } else {
@@ -455,15 +525,20 @@ __device__ __forceinline__ StepParticle load_step_particle(const StepArgs& a, lo
   return t;
 }
 
-template <int G>
+template <int G, bool HOT>
 __global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int n_kicks, int do_aoa) {
   constexpr int PPB = 256 / G;  // particles per block (<= 256)
+  if (HOT) {  // what the launcher checked (launch_step_g), restated for the optimiser
+    n_kicks = 2, do_aoa = 1;
+    a.box.periodic = 1, a.wrap = 1;
+    a.noise = nullptr;
+  }
   __shared__ float sF[3 * PPB];
   if ((long long)a.ctrl[3] <= step) return;  // block-uniform
   // Which table this launch walks: the pruned inner list, unless some particle has moved too far
   // since the last pruning pass (flag raised by an EARLIER launch; the two flag words alternate
   // with the step parity so that no launch reads a word its own blocks may be writing).
-  const bool inner = a.fli != nullptr && a.ctrl[4 + (int)(step & 1)] == 0;
+  const bool inner = (HOT || a.fli != nullptr) && a.ctrl[4 + (int)(step & 1)] == 0;
   const uint32_t* fl_use = inner ? a.fli : a.fl;
   const int32_t* deg_use = inner ? a.degi : a.deg;
   const unsigned blk = xcd_block(blockIdx.x, gridDim.x);
@@ -471,7 +546,7 @@ __global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int
   // ---- operands of this thread's integrate work (threads 0..PPB-1 own one particle each: the
   //      first wavefronts of the block), requested before the force loop so their latency and the
   //      Philox arithmetic hide under it ----
-  const StepParticle tk = load_step_particle(a, step, do_aoa, p0, threadIdx.x, PPB);
+  const StepParticle tk = load_step_particle<HOT>(a, step, do_aoa, p0, threadIdx.x, PPB);
 
   const int tid = blk * 256 + threadIdx.x;
   const int p = tid / G;
@@ -493,50 +568,41 @@ __global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int
     sF[3 * pl + 2] = fz;
   }
   __syncthreads();
-  // ---- integrate: one particle per thread, packed into the first PPB threads of the block ----
+  // ---- integrate: one particle per thread, packed into the first PPB threads of the block.
+  //      These few wavefronts are the tail of the launch, so the common case (coordinates inside
+  //      the box, |x - ref| < L) runs branch-free; a particle that falls outside it is redone
+  //      through the general formulas, which give the same bits wherever both apply. ----
   bool stale = false;
   if (tk.live) {
     const float L[3] = {a.box.lx, a.box.ly, a.box.lz};
+    const float hL[3] = {a.box.hx, a.box.hy, a.box.hz};
     const float xo[3] = {tk.x.x, tk.x.y, tk.x.z};
     const float rf[3] = {tk.ref.x, tk.ref.y, tk.ref.z};
     const float ri[3] = {tk.refi.x, tk.refi.y, tk.refi.z};
-    const float bs = fmul(a.b, fsqrt(fdiv(a.kT, tk.m)));
-    float xn[3], sq[3], sqi[3];
+    float vn[3], xn[3], sq[3], sqi[3];
+    bool rare = false;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float F = sF[3 * threadIdx.x + c];
-      float vc = tk.v[c];
-      for (int k = 0; k < n_kicks; ++k) vc = fadd(vc, fdiv(fmul(a.hdt, F), tk.m));  // B  :181 / :195
-      xn[c] = 0.f, sq[c] = 0.f, sqi[c] = 0.f;
-      if (do_aoa) {
-        float xc = fadd(xo[c], fmul(a.hdt, vc));        // A  :183
-        vc = fadd(fmul(a.a, vc), fmul(bs, tk.z[c]));    // O  :186
-        xc = fadd(xc, fmul(a.hdt, vc));                 // A  :188
-        if (a.wrap && a.box.periodic) xc = wrap1(xc, L[c]);  // :239
-        xn[c] = xc;
-        if (a.ref4) {
-          float r = fsub(xc, rf[c]);
-          if (a.box.periodic) r = min_image(r, L[c], fmul(L[c], 0.5f));
-          sq[c] = fmul(r, r);
-        }
-        if (a.fli) {
-          float r = fsub(xc, ri[c]);
-          if (a.box.periodic) r = min_image(r, L[c], fmul(L[c], 0.5f));
-          sqi[c] = fmul(r, r);
-        }
-      }
-      a.v[3 * (size_t)tk.pp + c] = vc;
+    for (int c = 0; c < 3; ++c)
+      rare |= integrate_component<true, HOT>(a, n_kicks, do_aoa, sF[3 * threadIdx.x + c], tk.m, tk.bs, tk.z[c], tk.v[c],
+                                        xo[c], rf[c], ri[c], L[c], hL[c], vn[c], xn[c], sq[c], sqi[c]);
+    if (__builtin_expect(rare, 0)) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        (void)integrate_component<false, HOT>(a, n_kicks, do_aoa, sF[3 * threadIdx.x + c], tk.m, tk.bs, tk.z[c], tk.v[c],
+                                         xo[c], rf[c], ri[c], L[c], hL[c], vn[c], xn[c], sq[c], sqi[c]);
     }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.v[3 * (size_t)tk.pp + c] = vn[c];
     if (do_aoa) {
       reinterpret_cast<float4*>(a.x_next)[tk.pp] = make_float4(xn[0], xn[1], xn[2], 0.f);
       // skin check :241: (rx^2 + ry^2) + rz^2 in the reference's order
-      if (a.ref4 && fadd(fadd(sq[0], sq[1]), sq[2]) > a.T_half_skin) atomicMin(&a.ctrl[3], (int)(step + 1));
-      if (a.fli && (sqi[0] + sqi[1]) + sqi[2] > a.T_half_inner) stale = true;
+      if ((HOT || a.ref4) && fadd(fadd(sq[0], sq[1]), sq[2]) > a.T_half_skin) atomicMin(&a.ctrl[3], (int)(step + 1));
+      if ((HOT || a.fli) && (sqi[0] + sqi[1]) + sqi[2] > a.T_half_inner) stale = true;
     }
   }
   // the inner list stays off until the next pruning pass clears both words
-  if (do_aoa && a.fli && (stale || (!inner && threadIdx.x == 0))) a.ctrl[4 + (int)((step + 1) & 1)] = 1;
-  if (a.fli && !inner && blockIdx.x == 0 && threadIdx.x == 0) a.ctrl[6] += 1;  // launches on the full list
+  if (do_aoa && (HOT || a.fli) && (stale || (!inner && threadIdx.x == 0))) a.ctrl[4 + (int)((step + 1) & 1)] = 1;
+  if ((HOT || a.fli) && !inner && blockIdx.x == 0 && threadIdx.x == 0) a.ctrl[6] += 1;  // launches on the full list
 }
 
 // ---------------------------------------------------------------------------
@@ -687,7 +753,13 @@ static void launch_step_g(const StepArgs& a, long long step, int n_kicks, int do
     if (dbg) (void)hipStreamSynchronize(st);
   }
   if (dbg) fprintf(stderr, "[chx] k_lj_step<%d> step %lld kicks %d aoa %d\n", G, step, n_kicks, do_aoa);
-  hipLaunchKernelGGL((k_lj_step<G>), dim3(blocks), dim3(256), 0, st, a, step, n_kicks, do_aoa);
+  // steady-state launches take the instantiation with the launch-uniform switches folded
+  const bool hot = n_kicks == 2 && do_aoa && a.wrap && a.box.periodic && a.ref4 && a.fli && a.perm && !a.noise;
+  if (hot) {
+    hipLaunchKernelGGL((k_lj_step<G, true>), dim3(blocks), dim3(256), 0, st, a, step, n_kicks, do_aoa);
+  } else {
+    hipLaunchKernelGGL((k_lj_step<G, false>), dim3(blocks), dim3(256), 0, st, a, step, n_kicks, do_aoa);
+  }
   if (dbg) (void)hipStreamSynchronize(st);
 }
 

@@ -58,7 +58,10 @@ for wl in sys.argv[1:] or ["c3", "c4"]:
 
         def one():
             even, odd = (st.x_a, st.x_b) if (step[0] & 1) == 0 else (st.x_b, st.x_a)
-            ops.langevin_fused_chunk(st.params, even, odd, step[0], 1, 2, 1)
-            step[0] += 1
-        t_s = ev_time(one, reps=100, warm=10)
+            ops.langevin_fused_chunk(st.params, even, odd, step[0], CH, 2, 1)
+            step[0] += CH
+        CH = 64  # launches per C call: a single launch per ctypes call is host-bound at ~5 us
+        if os.environ.get("KB_FULL_LIST"):
+            st.params.prune_every = 0  # walk the full list (default: production pruning, a pass every 32 steps included)
+        t_s = ev_time(one, reps=20, warm=3) / CH
         print(f"{wl} g={fl.g} maxdeg={fl.maxdeg} P_nl={p_nl} alg={alg/1e6:.2f}MB  force {t_f:7.2f} us ({alg/t_f/1e3:7.1f} GB/s, {alg/t_f/8e6*100:5.1f}%)   fused step {t_s:7.2f} us")
