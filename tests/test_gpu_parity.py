@@ -616,6 +616,35 @@ def test_langevin_injected_noise_matches_oracle(ca, O):
     assert np.abs(out.velocities.cpu().numpy() - vo).max() < 2e-4 * max(1.0, np.abs(vo).max())
 
 
+def test_langevin_box_crossings_and_unwrapped_input_match_oracle(ca, O):
+    """The step kernel's epilogue runs a branch-free form for 0 <= x < L, |x - ref| < L and redoes a
+    particle through the general wrap / minimum-image formulas otherwise: start from UNWRAPPED
+    coordinates (images up to +-3 boxes away, so |x - ref| >= L after the first wrap) with a hot, fast
+    system whose particles cross the box faces, and follow the oracle through both branches."""
+    n, steps, skin = 700, 25, 0.3
+    x, box, pot, state, thermo, nbr, integ = _langevin_setup(ca, O, n, 0.5, 45, skin, 4.0)
+    rng = np.random.default_rng(17)
+    L = np.diag(box).astype(f32)
+    x = (x + rng.integers(-3, 4, size=(n, 3)).astype(f32) * L).astype(f32)
+    state = make_state(ca, x, box)
+    noise = rng.normal(size=(steps, n, 3)).astype(f32)
+    mass = np.full(n, 39.948, f32)
+    kT = O.R_KJ * 300.0
+    v0 = (3.0 * O.initial_velocities(mass, kT, rng.normal(size=(n, 3)).astype(f32))).astype(f32)
+    state.velocities = v0
+    out, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr, noise=noise)
+    xo, vo, rebuilds, _ = O.langevin_run(x, v0, box, mass, SIGMA, EPS, CUTOFF, skin, 180, 0.004, 1.0, 300.0, steps,
+                                         lambda s: noise[s])
+    assert integ.n_rebuilds == rebuilds
+    got = out.positions.cpu().numpy()
+    assert (got >= 0).all() and (got <= L).all()
+    # particles that left through a face came back in through the opposite one
+    x_w = x - np.floor(x / L) * L
+    assert (np.abs(xo - x_w) > 0.5 * L).any(), "test needs box crossings to be meaningful"
+    assert np.abs(got - xo).max() < 5e-6
+    assert np.abs(out.velocities.cpu().numpy() - vo).max() < 5e-4 * max(1.0, np.abs(vo).max())
+
+
 @pytest.mark.parametrize("inner,every", [(0.03, 4), (0.002, 8), (0.01, 1000)], ids=["pruned", "mostly-stale", "never-refreshed"])
 def test_langevin_pruned_inner_list_keeps_the_reference_pairs(ca, O, monkeypatch, inner, every):
     """The dynamically pruned inner list is a speed device only: with it on -- including when it
