@@ -11,7 +11,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libchx.so")
+LIB_PATH = os.environ.get("CHX_LIB") or os.path.join(_HERE, "libchx.so")  # CHX_LIB: A/B experiments against another build
 
 
 class Box(C.Structure):

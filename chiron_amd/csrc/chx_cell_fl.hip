@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
     int end = (used + wd - 1) / wd * wd;
     end = end < wd ? wd : end;
     end = end < fcap ? end : fcap;
-    for (int sl = used + lane; sl < end; sl += CHX_WAVE) fl[chx_fl_addr(w, sl, n, fg)] = 0u;
+    // (the row's own index: a zero-length pair keeps the force kernel on its fast path)
+    for (int sl = used + lane; sl < end; sl += CHX_WAVE) fl[chx_fl_addr(w, sl, n, fg)] = (uint32_t)w;
   }
   const int kept = count_h < CHX_CELL_CAP - 40 ? count_h : CHX_CELL_CAP - 40;
   __threadfence_block();

@@ -92,6 +92,19 @@ __global__ __launch_bounds__(256) void k_fl_fill(const uint32_t* __restrict__ nl
   }
 }
 
+// slots between a row's end and the end of its last touched chunk (at least chunk 0): the row's
+// own index, a valid gather target whose zero-length pair keeps lj_row on its fast path
+__global__ __launch_bounds__(256) void k_fl_pad(const int32_t* __restrict__ deg, int n, int g,
+                                                uint32_t* __restrict__ fl) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int w = CHX_FL_QUAD * g;
+  const int d = deg[p];
+  int end = (d + w - 1) / w * w;
+  end = end < w ? w : end;
+  for (int sl = d; sl < end; ++sl) fl[chx_fl_addr(p, sl, n, g)] = (uint32_t)p;
+}
+
 extern "C" int chx_fl_fill(const uint32_t* nl, const int32_t* n_nbr, int32_t n, int32_t m,
                            const uint32_t* inv, int32_t g, int32_t* cursor_ws, uint32_t* fl_out,
                            chx_stream_t stream) {
@@ -108,6 +121,8 @@ extern "C" int chx_fl_fill(const uint32_t* nl, const int32_t* n_nbr, int32_t n, 
   const unsigned wb = (unsigned)(((int64_t)n * CHX_WAVE + 255) / 256);
   hipLaunchKernelGGL(k_fl_fill, dim3(wb), dim3(256), 0, st, nl, n_nbr, n, m, inv, g, cursor_ws,
                      fl_out);
+  // the cursors now hold the row lengths
+  hipLaunchKernelGGL(k_fl_pad, dim3((n + 255) / 256), dim3(256), 0, st, cursor_ws, n, g, fl_out);
   return chx_check_launch("chx_fl_fill");
 }
 
@@ -203,8 +218,7 @@ __device__ __forceinline__ f2 f2_splat(float v) { return (f2){v, v}; }
 // jnp.mod picks, of {t - L, t, t + L}, the one in [0, L]: exactly the SMALLEST NON-NEGATIVE of
 // the three, i.e. their minimum as unsigned bit patterns (negative floats have the top bit set).
 // Same roundings as min_image(): t - L is exact (Sterbenz) and t + L rounds once.
-__device__ __forceinline__ f2 min_image2(f2 d, float L, float hL) {
-  const f2 t = d + hL;
+__device__ __forceinline__ f2 min_image2_t(f2 t, float L, float hL) {  // t = d + L/2, already rounded
   const f2 a = t - L;
   const f2 c = t + L;
   f2 m;
@@ -213,17 +227,126 @@ __device__ __forceinline__ f2 min_image2(f2 d, float L, float hL) {
   return m - hL;
 }
 
+// {a.x, b.x} and {a.y, b.y} in one instruction each (v_pk_mov_b32: D.lo = S0[op_sel[0]],
+// D.hi = S1[op_sel[1]]; probed on the hardware, scripts/ub/pk_mov_probe.hip).  The gathers land
+// as (x, y, z, w) per neighbor; the packed arithmetic wants (x_u, x_u+1): without this the
+// compiler shuffles single registers, ~10 v_mov per pair of entries.
+__device__ __forceinline__ f2 pk_xx(f2 a, f2 b) {
+  f2 r;
+  asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f2 pk_yy(f2 a, f2 b) {
+  f2 r;
+  asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// Minimum image of a wavefront's pairs (launch-uniform):
+//   LJ_OPEN   non-periodic space, r = x_lo - x_hi;
+//   LJ_SHIFT  periodic: min_image2_t (the three candidates), |d| < L checked per pair.
+// (A third form for particles far from every box face -- t = d + L/2 lies in [0, L), so
+// r = t - L/2 with a range check on t -- saves a quarter of the arithmetic and was measured to
+// change nothing: at N = 262144 the kernel waits on the L1's gather rate, scripts/exp_gather.sh.)
+#define LJ_OPEN 0
+#define LJ_SHIFT 2
+
+struct RowAcc {
+  f2 ax, ay, az, ae;
+  bool bad;
+};
+
+// two list entries (u, u+1) of one lane; xj*: the gathered neighbor positions as (x,y) and (z,w)
+template <int MODE>
+__device__ __forceinline__ void lj_pair2(const float4& xi, f2 xy0, f2 zw0, f2 xy1, f2 zw1, uint32_t e0, uint32_t e1,
+                                         bool act1, const Box3& box, const LJParams& lj, RowAcc& A) {
+  // orientation: r = x_lo - x_hi by ORIGINAL id = +-(xi - xj); multiplying by +-1 is exact
+  const f2 sgn = {(e0 & CHX_FL_HI) ? 1.0f : -1.0f, (e1 & CHX_FL_HI) ? 1.0f : -1.0f};
+  const f2 dx = xi.x - pk_xx(xy0, xy1);
+  const f2 dy = xi.y - pk_yy(xy0, xy1);
+  const f2 dz = xi.z - pk_xx(zw0, zw1);
+  f2 rx, ry, rz;
+  if (MODE == LJ_OPEN) {
+    rx = dx * sgn, ry = dy * sgn, rz = dz * sgn;
+  } else {
+    // t = (+-d) + L/2 with ONE rounding: +-d is exact, so the fma equals the reference's add
+    const f2 tx = __builtin_elementwise_fma(dx, sgn, f2_splat(box.hx));
+    const f2 ty = __builtin_elementwise_fma(dy, sgn, f2_splat(box.hy));
+    const f2 tz = __builtin_elementwise_fma(dz, sgn, f2_splat(box.hz));
+    A.bad |= !(fabsf(dx.x) < box.lx) | !(fabsf(dy.x) < box.ly) | !(fabsf(dz.x) < box.lz);
+    A.bad |= !(fabsf(dx.y) < box.lx) | !(fabsf(dy.y) < box.ly) | !(fabsf(dz.y) < box.lz);
+    rx = min_image2_t(tx, box.lx, box.hx);
+    ry = min_image2_t(ty, box.ly, box.hy);
+    rz = min_image2_t(tz, box.lz, box.hz);
+  }
+  const f2 r2 = (rx * rx + ry * ry) + rz * rz;  // norm2() in both halves
+  const bool in0 = r2.x <= lj.T;
+  const bool in1 = act1 && r2.y <= lj.T;
+  const f2 inv = {__builtin_amdgcn_rcpf(r2.x), __builtin_amdgcn_rcpf(r2.y)};
+  const f2 s2 = inv * lj.sig2;
+  const f2 s6 = s2 * s2 * s2;
+  f2 e = (s6 * lj.eps4) * (s6 - 1.0f);
+  f2 fs = (s6 * lj.eps24) * __builtin_elementwise_fma(f2_splat(2.0f), s6, f2_splat(-1.0f)) * inv;
+  fs.x = in0 ? fs.x : 0.0f;
+  fs.y = in1 ? fs.y : 0.0f;
+  e.x = in0 ? e.x : 0.0f;
+  e.y = in1 ? e.y : 0.0f;
+  fs *= sgn;  // action on the lower id, reaction on the higher
+  A.ax = __builtin_elementwise_fma(fs, rx, A.ax);
+  A.ay = __builtin_elementwise_fma(fs, ry, A.ay);
+  A.az = __builtin_elementwise_fma(fs, rz, A.az);
+  A.ae += e;
+}
+
+// the chunk loop of one lane: chunk 0 (index quad e4, its four gathers) is already in flight
+template <int G, int MODE>
+__device__ __forceinline__ void lj_row_loop(const float4* __restrict__ x4, const uint4* __restrict__ col,
+                                            size_t stride, int d, int nc, int q, const float4& xi, uint4 e4,
+                                            float4 (&xj)[4], const Box3& box, const LJParams& lj, RowAcc& A) {
+  constexpr int W = 4 * G;
+  for (int c = 0; c < nc; ++c) {
+    const int k0 = c * W + 4 * q;  // this lane's first entry of the chunk
+    uint4 nx = make_uint4(0u, 0u, 0u, 0u);
+    if (c + 1 < nc) nx = col[(size_t)(c + 1) * stride];
+#ifdef CHX_EXP_NO_MATH
+    if (k0 < d) { A.ax += (f2){xj[0].x + xj[1].y, xj[2].z + xj[3].x}; }
+#else
+    if (k0 < d) {
+      lj_pair2<MODE>(xi, (f2){xj[0].x, xj[0].y}, (f2){xj[0].z, xj[0].w}, (f2){xj[1].x, xj[1].y},
+                     (f2){xj[1].z, xj[1].w}, e4.x, e4.y, k0 + 1 < d, box, lj, A);
+    }
+    if (k0 + 2 < d) {
+      lj_pair2<MODE>(xi, (f2){xj[2].x, xj[2].y}, (f2){xj[2].z, xj[2].w}, (f2){xj[3].x, xj[3].y},
+                     (f2){xj[3].z, xj[3].w}, e4.z, e4.w, k0 + 3 < d, box, lj, A);
+    }
+#endif
+    if (c + 1 < nc) {
+      e4 = nx;
+#ifdef CHX_EXP_NO_GATHER
+      xj[0].x += 0.01f; xj[1].y += 0.01f; xj[2].z += 0.01f; xj[3].x += 0.01f;
+#else
+      xj[0] = x4[e4.x & ~CHX_FL_HI];
+      xj[1] = x4[e4.y & ~CHX_FL_HI];
+      xj[2] = x4[e4.z & ~CHX_FL_HI];
+      xj[3] = x4[e4.w & ~CHX_FL_HI];
+#endif
+    }
+  }
+}
+
 // One particle's share of its force-list row.  A row is stored in chunks of W = 4 G entries
 // (fl[chunk][particle][W]); lane q of the G cooperating lanes owns entries 4q..4q+3 of every
 // chunk and fetches them with ONE 16-byte load, so a wavefront reads 1 KB of contiguous index
 // data per instruction.  The first chunk is requested together with the particle's own
-// position and degree (slots past a row's end hold 0, a valid index, so the speculative
+// position and degree (slots past a row's end hold a valid index -- the builders write the row's
+// own index there, a zero-length pair that stays on the fast path -- so the speculative
 // gathers are harmless); the index quad of chunk c+1 is requested before the arithmetic of
 // chunk c, so only the position gathers sit on the dependent-latency chain.
 //
 // The kernel is VALU-bound at large N (a wave64 op takes 4 cycles on a SIMD16), so the pair
-// arithmetic is branch-free and packed two entries wide; a lane that meets |d| >= L on some
-// axis (unwrapped input coordinates) redoes its share through the general min_image().
+// arithmetic is branch-free and packed two entries wide; a lane whose fast form does not apply
+// (unwrapped input coordinates, a list that does not match the positions) redoes its share
+// through the general min_image().
 template <int G>
 __device__ __forceinline__ void lj_row(const float4* __restrict__ x4, const uint32_t* __restrict__ fl,
                                        const int32_t* __restrict__ deg, int n, int chunks, int p, int q,
@@ -235,64 +358,26 @@ __device__ __forceinline__ void lj_row(const float4* __restrict__ x4, const uint
   const uint4* col = reinterpret_cast<const uint4*>(fl) + (size_t)pc * G + q;
   const float4 xi = x4[pc];
   int d = deg[pc];
-  uint4 e4 = col[0];
-  uint32_t ent[4] = {e4.x, e4.y, e4.z, e4.w};
+  const uint4 e4 = col[0];
   float4 xj[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) xj[u] = x4[ent[u] & ~CHX_FL_HI];
+  xj[0] = x4[e4.x & ~CHX_FL_HI];
+  xj[1] = x4[e4.y & ~CHX_FL_HI];
+  xj[2] = x4[e4.z & ~CHX_FL_HI];
+  xj[3] = x4[e4.w & ~CHX_FL_HI];
   d = valid ? d : 0;
   xi_out = xi;
   const int nc = (d + W - 1) / W;
-  f2 ax = f2_splat(0.f), ay = f2_splat(0.f), az = f2_splat(0.f), ae = f2_splat(0.f);
-  bool bad = false;
-  for (int c = 0; c < nc; ++c) {
-    const int k0 = c * W + 4 * q;  // this lane's first entry of the chunk
-    uint4 nx = make_uint4(0u, 0u, 0u, 0u);
-    if (c + 1 < nc) nx = col[(size_t)(c + 1) * stride];
-#pragma unroll
-    for (int u = 0; u < 4; u += 2) {
-      const bool act0 = k0 + u < d;
-      const bool act1 = k0 + u + 1 < d;
-      if (!act0) continue;  // act1 implies act0
-      // orientation: r = x_lo - x_hi by ORIGINAL id = +-(xi - xj); multiplying by +-1 is exact
-      const f2 sgn = {(ent[u] & CHX_FL_HI) ? 1.0f : -1.0f, (ent[u + 1] & CHX_FL_HI) ? 1.0f : -1.0f};
-      f2 rx = (xi.x - (f2){xj[u].x, xj[u + 1].x}) * sgn;
-      f2 ry = (xi.y - (f2){xj[u].y, xj[u + 1].y}) * sgn;
-      f2 rz = (xi.z - (f2){xj[u].z, xj[u + 1].z}) * sgn;
-      if (box.periodic) {
-        bad |= !(fabsf(rx.x) < box.lx) | !(fabsf(ry.x) < box.ly) | !(fabsf(rz.x) < box.lz);
-        bad |= !(fabsf(rx.y) < box.lx) | !(fabsf(ry.y) < box.ly) | !(fabsf(rz.y) < box.lz);
-        rx = min_image2(rx, box.lx, box.hx);
-        ry = min_image2(ry, box.ly, box.hy);
-        rz = min_image2(rz, box.lz, box.hz);
-      }
-      const f2 r2 = (rx * rx + ry * ry) + rz * rz;  // norm2() in both halves
-      const bool in0 = r2.x <= lj.T;
-      const bool in1 = act1 && r2.y <= lj.T;
-      const f2 inv = {__builtin_amdgcn_rcpf(r2.x), __builtin_amdgcn_rcpf(r2.y)};
-      const f2 s2 = inv * lj.sig2;
-      const f2 s6 = s2 * s2 * s2;
-      f2 e = (s6 * lj.eps4) * (s6 - 1.0f);
-      f2 fs = (s6 * lj.eps24) * __builtin_elementwise_fma(f2_splat(2.0f), s6, f2_splat(-1.0f)) * inv;
-      fs.x = in0 ? fs.x : 0.0f;
-      fs.y = in1 ? fs.y : 0.0f;
-      e.x = in0 ? e.x : 0.0f;
-      e.y = in1 ? e.y : 0.0f;
-      fs *= sgn;  // action on the lower id, reaction on the higher
-      ax = __builtin_elementwise_fma(fs, rx, ax);
-      ay = __builtin_elementwise_fma(fs, ry, ay);
-      az = __builtin_elementwise_fma(fs, rz, az);
-      ae += e;
-    }
-    if (c + 1 < nc) {
-      ent[0] = nx.x, ent[1] = nx.y, ent[2] = nx.z, ent[3] = nx.w;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) xj[u] = x4[ent[u] & ~CHX_FL_HI];
-    }
+  RowAcc A;
+  A.ax = A.ay = A.az = A.ae = f2_splat(0.f);
+  A.bad = false;
+  if (!box.periodic) {
+    lj_row_loop<G, LJ_OPEN>(x4, col, stride, d, nc, q, xi, e4, xj, box, lj, A);
+  } else {
+    lj_row_loop<G, LJ_SHIFT>(x4, col, stride, d, nc, q, xi, e4, xj, box, lj, A);
   }
-  if (__builtin_expect(bad, 0)) {
-    // general path, one entry at a time (bit-identical to the fast path wherever that is valid)
-    ax = ay = az = ae = f2_splat(0.f);
+  if (__builtin_expect(A.bad, 0)) {
+    // general path, one entry at a time (bit-identical to the fast paths wherever those are valid)
+    A.ax = A.ay = A.az = A.ae = f2_splat(0.f);
     const uint32_t* row = fl + ((size_t)pc * G + q) * 4;
     for (int c = 0; c < nc; ++c) {
       for (int u = 0; u < 4; ++u) {
@@ -308,18 +393,18 @@ __device__ __forceinline__ void lj_row(const float4* __restrict__ x4, const uint
           lj_pair(g2, lj.sig2, lj.eps4, lj.eps24, e, fs);
           if (!hi) fs = -fs;
           const int h = u & 1;  // same accumulator parity as the fast path
-          ax[h] = __builtin_fmaf(fs, gx, ax[h]);
-          ay[h] = __builtin_fmaf(fs, gy, ay[h]);
-          az[h] = __builtin_fmaf(fs, gz, az[h]);
-          ae[h] += e;
+          A.ax[h] = __builtin_fmaf(fs, gx, A.ax[h]);
+          A.ay[h] = __builtin_fmaf(fs, gy, A.ay[h]);
+          A.az[h] = __builtin_fmaf(fs, gz, A.az[h]);
+          A.ae[h] += e;
         }
       }
     }
   }
-  fx += ax.x + ax.y;
-  fy += ay.x + ay.y;
-  fz += az.x + az.y;
-  en += ae.x + ae.y;
+  fx += A.ax.x + A.ax.y;
+  fy += A.ay.x + A.ay.y;
+  fz += A.az.x + A.az.y;
+  en += A.ae.x + A.ae.y;
 }
 
 // Optional run-time choice of the position buffer (device-resident Monte Carlo, chx_mc.hip):
@@ -672,7 +757,7 @@ __global__ __launch_bounds__(256) void k_fl_prune(StepArgs a, long long step) {
     // the force kernel gathers whole chunks (chunk 0 speculatively): pad the last touched chunk
     int end = (base + W - 1) / W * W;
     end = end < W ? W : end;
-    for (int sl = base + q; sl < end; sl += G) a.fli[chx_fl_addr(p, sl, a.n, G)] = 0u;
+    for (int sl = base + q; sl < end; sl += G) a.fli[chx_fl_addr(p, sl, a.n, G)] = (uint32_t)p;
     if (q == 0) {
       a.degi[p] = base;
       a.refi4[p] = xi;

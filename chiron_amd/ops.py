@@ -300,7 +300,7 @@ def _choose_g(maxdeg: int, n: int) -> int:
     env = os.environ.get("CHX_FL_G")
     if env:
         return int(env)
-    g = 2
+    g = 1  # one lane per particle once that alone fills the chip (N >= 2^18: no reduction, no idle partner lanes)
     while g < 64 and n * g < (1 << 18):
         g *= 2
     while g < 64 and maxdeg > 48 * g:

@@ -1,7 +1,9 @@
+# what bounds the list kernels: variants without the pair arithmetic / without the position gathers (GPU box)
 set -e
 cd $GRAFT_REPO_ROOT
-for v in "-DCHX_EXP_NO_MATH" "-DCHX_EXP_NO_INDEX" "-DCHX_EXP_NO_INDEX -DCHX_EXP_SAME_LINE_GATHER" "-DCHX_EXP_NO_MATH -DCHX_EXP_SAME_LINE_GATHER"; do
+for v in "" "-DCHX_EXP_NO_MATH" "-DCHX_EXP_NO_GATHER" "-DCHX_EXP_NO_MATH -DCHX_EXP_NO_GATHER"; do
   echo "== variant: $v"
   bash scripts/build_variant.sh $v
   GS=auto python scripts/kernel_bench.py c3 c4 2>&1 | grep -v amdgpu.ids
+  GS=1,4 python scripts/kernel_bench.py c4 2>&1 | grep -v amdgpu.ids
 done
