@@ -128,14 +128,16 @@ def time_kernels(fluid, pot, state, nbr, integ, reps: int):
     st.params.skin = 1.0e6
     step = [0]
 
-    def eight_steps():
-        # 8 launches per C call (as the integrator enqueues them), so the Python call rate does not
-        # bound the measurement; the pruning pass every 32 steps is part of the per-step figure
-        even, odd = (st.x_a, st.x_b) if (step[0] & 1) == 0 else (st.x_b, st.x_a)
-        ops.langevin_fused_chunk(st.params, even, odd, step[0], 8, 2, 1)
-        step[0] += 8
+    per_call = 32
 
-    t_step = timed(eight_steps, max(1, reps // 8)) / 8
+    def one_chunk():
+        # 32 launches per C call (exactly how the integrator enqueues them), so the Python call rate
+        # does not bound the measurement; the pruning pass every 32 steps is part of the per-step figure
+        even, odd = (st.x_a, st.x_b) if (step[0] & 1) == 0 else (st.x_b, st.x_a)
+        ops.langevin_fused_chunk(st.params, even, odd, step[0], per_call, 2, 1)
+        step[0] += per_call
+
+    t_step = timed(one_chunk, max(2, reps // per_call)) / per_call
     p_nl = int(torch.minimum(nbr.n_neighbors, torch.tensor(nbr.n_max_neighbors, device=x4.device)).sum().item())
     return t_step, t_force, p_nl, fl
 

@@ -33,6 +33,7 @@ log = logging.getLogger("chiron_amd")
 
 _INT_MAX = 2**31 - 1
 _TRACE_RUN = __import__("os").environ.get("CHX_TRACE_RUN") == "1"
+_SPECULATIVE_REBUILD = __import__("os").environ.get("CHX_SYNC_REBUILD") != "1"
 
 
 def langevin_constants(timestep, collision_rate):
@@ -350,8 +351,12 @@ class _RunState:
     def velocities_user(self) -> torch.Tensor:
         return self._unpack(self.v)
 
-    def _rebuild(self, step: int = 0):
-        """The host half of chiron/integrators.py:241-242 once the device check has fired."""
+    def _rebuild(self, step: int = 0, speculative: bool = False):
+        """The host half of chiron/integrators.py:241-242 once the device check has fired.
+
+        ``speculative``: do not wait for the build's status block (the reference's sync at
+        chiron/neighbors.py:709); the caller keeps enqueuing steps on the new list and calls
+        ``_settle`` before it trusts anything computed with it."""
         import os, time
 
         prof = os.environ.get("CHX_PROFILE_REBUILD") == "1"
@@ -359,16 +364,35 @@ class _RunState:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
         x_user, v_user = self.positions_user(), self.velocities_user()
-        self.nbr_list._adopt_positions = True  # x_user is a fresh tensor nobody else holds
-        try:
-            self.nbr_list.build(x_user, self.nbr_list.box_vectors)
-        finally:
-            self.nbr_list._adopt_positions = False
+        spec = speculative and _SPECULATIVE_REBUILD and self.nbr_list._build_speculative(x_user)
+        if not spec:
+            self.nbr_list._adopt_positions = True  # x_user is a fresh tensor nobody else holds
+            try:
+                self.nbr_list.build(x_user, self.nbr_list.box_vectors)
+            finally:
+                self.nbr_list._adopt_positions = False
         self._load(x_user, v_user, step)
+        self._unsettled = (x_user, v_user, step) if spec else None
         self.n_rebuilds += 1
         if prof:
             torch.cuda.synchronize()
             self.integ.rebuild_seconds = getattr(self.integ, "rebuild_seconds", 0.0) + time.perf_counter() - t0
+
+    def _settle(self) -> bool:
+        """Validate the last speculative rebuild.  False: its capacity assumptions did not hold; the
+        list has been rebuilt the synchronous way and the state reloaded at the rebuild step, and
+        whatever was enqueued since must be redone from there (``self._unsettled_step``)."""
+        pend = getattr(self, "_unsettled", None)
+        if pend is None:
+            return True
+        self._unsettled = None
+        if self.nbr_list._confirm_build():
+            return True
+        x_user, v_user, step = pend
+        torch.cuda.synchronize()
+        self._load(x_user, v_user, step)
+        self._unsettled_step = step
+        return False
 
     # -- fused neighbor-list path -------------------------------------------
     def _enqueue_fused(self, s0: int, n: int, do_aoa: int = 1) -> _Pending:
@@ -420,18 +444,24 @@ class _RunState:
                           f"pending={len(pending)}", flush=True)
             else:
                 rec.event.synchronize()
+            if not self._settle():
+                # the speculative rebuild before this chunk overflowed a capacity: redo from its step
+                pending.clear()
+                done = nxt = self._unsettled_step
+                continue
             halt = int(rec.host[3])
             self._seen_full, self._seen_prune = int(rec.host[6]), int(rec.host[7])  # counters since the last load
             if halt <= rec.s0 + rec.n:
-                # skin check fired while producing x_halt: steps < halt ran, everything queued behind is a no-op
-                torch.cuda.synchronize()
+                # skin check fired while producing x_halt: steps < halt ran, everything queued behind is a
+                # no-op; the rebuild is enqueued behind those launches, nothing waits for them
                 pending.clear()
                 self.parity = rec.parity0 ^ ((halt - rec.s0) & 1)
                 self._bank_inner_stats()
-                self._rebuild(halt)
+                self._rebuild(halt, speculative=True)
                 done = nxt = halt
             else:
                 done = rec.s0 + rec.n
+        self._settle()  # a rebuild at the very last step: nothing ran on its list yet
         return done
 
     # -- other paths -------------------------------------------------------

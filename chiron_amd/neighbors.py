@@ -306,6 +306,77 @@ class NeighborListNsqrd(PairsBase):
         self.is_built = True
         self.n_builds += 1
 
+    # -- unsynchronised rebuild (integrator only) ---------------------------------------------
+    def _build_speculative(self, positions: torch.Tensor) -> bool:
+        """Rebuild from ``positions`` WITHOUT waiting for the build's status block.
+
+        The reference synchronises inside every build (chiron/neighbors.py:709) to decide whether
+        ``n_max_neighbors`` has to grow.  Between two rebuilds of one trajectory it almost never does,
+        so the integrator enqueues the build, publishes the status block to pinned host memory and
+        carries on with the arrays it got; ``_confirm_build`` reads the block later (by then it has
+        long arrived) and, if a capacity did overflow, redoes the build through ``build()`` -- the
+        caller then discards whatever it ran on the speculative list.  The overflowing kernel bounds
+        its writes, so a speculative list is always safe to walk.  Returns False (nothing enqueued)
+        when this fast path does not apply.
+        """
+        if not (self.is_built and self._use_cell_list and getattr(self, "_box_h", None) is not None
+                and self._box_h.periodic and getattr(self, "_fl_geo", None) is not None and self._cs_md is not None):
+            return False
+        n = positions.shape[0]
+        if self._fl_geo[0] != n or positions.dtype != torch.float32 or not positions.is_cuda:
+            return False
+        cs = self._cs_md
+        ncell, nc = ops.cell_grid(self._box_h, cs, n)
+        if ncell <= 0:
+            return False
+        m = int(self.n_max_neighbors)
+        g, chunks = self._fl_geometry(n)
+        if getattr(self, "_scratch", None) is None:
+            self._scratch = {}
+        self.ref_positions = positions  # a fresh tensor nobody else holds
+        self._cutoff_and_skin = cs
+        nl, first, n_nbr, sorted_ids, fl, deg, status = ops.nl_build_cell_fl(
+            positions, self._box_h, cs, m, ncell, nc, g, chunks, self._scratch)
+        host = getattr(self, "_status_host", None)
+        if host is None:
+            host = self._status_host = torch.empty((8,), dtype=torch.int32, pin_memory=True)
+        ops.publish(status, host, 8)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._spec = (ev, m, g, chunks)
+        self._nl, self._nl_mask, self._first = nl, None, first
+        self.n_neighbors = n_nbr
+        self._perm = sorted_ids
+        self._force_list = ops.ForceList.prebuilt(fl, deg, sorted_ids, g, chunks, getattr(self, "_last_maxdeg", 0))
+        self.n_builds += 1
+        return True
+
+    def _confirm_build(self) -> bool:
+        """True if the last ``_build_speculative`` produced the list ``build()`` would have; otherwise
+        the list has been rebuilt synchronously from the same positions and False is returned."""
+        spec = getattr(self, "_spec", None)
+        if spec is None:
+            return True
+        self._spec = None
+        ev, m, g, chunks = spec
+        ev.synchronize()
+        st = self._status_host.tolist()
+        # [0] on-chip candidate overflow, [1] max n_neighbors, [2] rows with exactly m entries (the
+        # reference's growth trigger), [3] max force-list degree, [4] force-list rows that did not fit
+        if st[0] == 0 and st[2] == 0 and st[4] == 0 and st[1] <= m:
+            self._last_maxdeg = st[3]
+            self._force_list.maxdeg = st[3]
+            return True
+        if _DEBUG_BUILD:
+            print(f"[chx build] speculative rebuild rejected, status={st}", flush=True)
+        self.n_builds -= 1
+        self._adopt_positions = True
+        try:
+            self.build(self.ref_positions, self.box_vectors)
+        finally:
+            self._adopt_positions = False
+        return False
+
     def _finish_padding(self):
         """Padding (:603-620) and mask (:623) are produced on first use: the MD loop never reads them."""
         if self._nl_mask is None:
@@ -363,6 +434,7 @@ class NeighborListNsqrd(PairsBase):
     def __deepcopy__(self, memo):
         import copy
 
+        self._confirm_build()
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
@@ -370,6 +442,8 @@ class NeighborListNsqrd(PairsBase):
                 new._force_list = None  # rebuilt lazily; it is a pure function of the list
             elif k == "_scratch":
                 new._scratch = None  # kernel work arrays are not part of the list
+            elif k in ("_spec", "_status_host"):
+                setattr(new, k, None)
             elif isinstance(v, torch.Tensor):
                 setattr(new, k, v.clone())
             else:

@@ -680,6 +680,55 @@ def test_langevin_pruned_inner_list_keeps_the_reference_pairs(ca, O, monkeypatch
     assert (integ2.prune_passes, integ2.full_list_launches) == (integ.prune_passes, integ.full_list_launches)
 
 
+@pytest.mark.parametrize("sabotage", [False, True], ids=["accepted", "rejected"])
+def test_langevin_speculative_rebuild(ca, O, monkeypatch, sabotage):
+    """Rebuilds inside run() do not wait for the build's status block (the reference's sync,
+    chiron/neighbors.py:709): steps are enqueued on the new list at once and the block is read a
+    chunk later.  With the block clean the trajectory is the oracle's; when a capacity overflowed
+    (here: the first rebuild is handed a four-entry force list) the speculative list and everything run
+    on it are thrown away, the list is rebuilt the synchronous way and the trajectory is still the
+    oracle's."""
+    n, steps, skin = 2500, 40, 0.05
+    x, box, pot, state, thermo, nbr, integ = _langevin_setup(ca, O, n, 0.3, 43, skin, 4.0)
+    rng = np.random.default_rng(5)
+    noise = rng.normal(size=(steps, n, 3)).astype(f32)
+    mass = np.full(n, 39.948, f32)
+    v0 = O.initial_velocities(mass, O.R_KJ * 300.0, rng.normal(size=(n, 3)).astype(f32))
+    state.velocities = v0
+    calls = {"spec": 0, "rejected": 0}
+    cls = type(nbr)
+    orig_spec, orig_confirm, orig_geo = cls._build_speculative, cls._confirm_build, cls._fl_geometry
+
+    def spec(self, positions):
+        calls["spec"] += 1
+        if sabotage and calls["spec"] == 1:
+            monkeypatch.setattr(cls, "_fl_geometry", lambda s, n_: (1, 1))  # room for four entries per row
+            try:
+                return orig_spec(self, positions)
+            finally:
+                monkeypatch.setattr(cls, "_fl_geometry", orig_geo)
+        return orig_spec(self, positions)
+
+    def confirm(self):
+        pending = getattr(self, "_spec", None) is not None
+        ok = orig_confirm(self)
+        if pending and not ok:
+            calls["rejected"] += 1
+        return ok
+
+    monkeypatch.setattr(cls, "_build_speculative", spec)
+    monkeypatch.setattr(cls, "_confirm_build", confirm)
+    out, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr, noise=noise)
+    xo, vo, rebuilds, (nl_mask, nl, n_max) = O.langevin_run(x, v0, box, mass, SIGMA, EPS, CUTOFF, skin, 180, 0.004, 1.0,
+                                                            300.0, steps, lambda s_: noise[s_])
+    assert rebuilds >= 1 and integ.n_rebuilds == rebuilds
+    assert calls["spec"] == rebuilds and calls["rejected"] == (1 if sabotage else 0)
+    assert np.abs(out.positions.cpu().numpy() - xo).max() < 5e-6
+    assert np.abs(out.velocities.cpu().numpy() - vo).max() < 5e-4 * max(1.0, np.abs(vo).max())
+    assert nbr.n_max_neighbors == n_max
+    assert np.array_equal(u32(nbr.neighbor_list)[:, :nl.shape[1]], nl)
+
+
 def test_langevin_rebuild_step_matches_oracle(ca, O):
     """Tiny skin + large timestep: the device flag must stop the chunk at the reference's rebuild step."""
     n, steps = 400, 30
