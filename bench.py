@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--build", default="cell", choices=["cell", "nsq"], help="neighbor-list build kernel")
     ap.add_argument("--chunk", type=int, default=32, help="steps enqueued per host round trip")
-    ap.add_argument("--exchange-interval", type=int, default=500)
+    ap.add_argument("--exchange-interval", type=int, default=1000, help="steps between replica-exchange attempts (1 ps at dt = 1 fs)")
     ap.add_argument("--kernel-reps", type=int, default=200)
     ap.add_argument("--cpu-steps", type=int, default=-1, help="steps of the CPU baseline (-1 = auto, 0 = skip)")
     ap.add_argument("--extra-c4", type=int, default=1, help="also report the N=262,144 pair-force roofline (1 GPU runs)")

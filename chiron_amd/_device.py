@@ -43,6 +43,9 @@ def set_default_device(device) -> None:
 
 def as_tensor(x: Any, dtype=torch.float32, device=None) -> torch.Tensor:
     """Convert lists / numpy arrays / tensors to a contiguous tensor on the device."""
+    if (device is None and _FORCED_DEVICE is None and isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == dtype
+            and x.is_contiguous()):
+        return x  # already what the kernels take (the common case on the hot path)
     if device is None:
         device = x.device if isinstance(x, torch.Tensor) and _FORCED_DEVICE is None and x.is_cuda else default_device()
     if isinstance(x, torch.Tensor):

@@ -102,9 +102,22 @@ class LangevinIntegrator:
 
         key = sampler_state.new_PRNG_key  # :124
 
-        kbT_unitless = float((self.kB * temperature).value_in_unit_system(unit.md_unit_system))
-        mass_unitless = as_tensor(mass.value_in_unit_system(unit.md_unit_system))
-        half_dt, a, b = langevin_constants(self.timestep, self.collision_rate)
+        # unit arithmetic is slow Python (exact rationals) and the mass upload a host->device copy:
+        # both are functions of objects that rarely change between run() calls
+        cache = self.__dict__.setdefault("_run_cache", {})
+        kT_key = ("kT", id(temperature))
+        if cache.get(kT_key, (None,))[0] is not temperature:
+            cache[kT_key] = (temperature, float((self.kB * temperature).value_in_unit_system(unit.md_unit_system)))
+        kbT_unitless = cache[kT_key][1]
+        m_key = ("mass", id(potential.topology), str(x0.device))
+        if cache.get(m_key, (None,))[0] is not mass._value:
+            cache[m_key] = (mass._value, as_tensor(mass.value_in_unit_system(unit.md_unit_system)))
+        mass_unitless = cache[m_key][1]
+        c_key = ("dt",)
+        if cache.get(c_key, (None, None))[:2] != (id(self.timestep), id(self.collision_rate)):
+            cache[c_key] = (id(self.timestep), id(self.collision_rate), langevin_constants(self.timestep, self.collision_rate),
+                            self.timestep, self.collision_rate)
+        half_dt, a, b = cache[c_key][2]
 
         # velocity (re)initialisation rules, :140-160
         if (
@@ -115,10 +128,18 @@ class LangevinIntegrator:
             sampler_state.velocities = initialize_velocities(temperature, potential.topology, key)
         v0 = sampler_state.velocities
 
-        if nbr_list is not None:
-            nbr_list.build_from_state(sampler_state)  # :169
-
         is_lj = isinstance(potential, LJPotential)
+        spec0 = False
+        if nbr_list is not None:  # :169
+            # a list this integrator has built before for the same box: enqueue the build without
+            # waiting for its status block (validated after the first chunk, see _RunState._settle)
+            if (is_lj and _SPECULATIVE_REBUILD and isinstance(nbr_list, NeighborListNsqrd)
+                    and getattr(nbr_list, "_box_token", None) is not None
+                    and nbr_list._box_token is getattr(sampler_state, "_box_token", None)
+                    and isinstance(x0, torch.Tensor) and x0.is_cuda and x0.dtype == torch.float32):
+                spec0 = nbr_list._build_speculative(x0.clone())
+            if not spec0:
+                nbr_list.build_from_state(sampler_state)
         if is_lj and isinstance(nbr_list, NeighborListNsqrd):
             mode = "fused"
         elif is_lj and (nbr_list is None or isinstance(nbr_list, PairListNsqrd)):
@@ -136,6 +157,8 @@ class LangevinIntegrator:
                 )
 
         st = _RunState(self, potential, nbr_list, x0, v0, mass_unitless, kbT_unitless, half_dt, a, b, key, noise, mode)
+        if spec0:
+            st._unsettled = (nbr_list.ref_positions, v0, 0, 1)
 
         bar = None
         if progress_bar:
@@ -174,10 +197,10 @@ class LangevinIntegrator:
             bar.close()
         if number_of_steps > 0:
             st.final_kick(number_of_steps)
+        elif mode == "fused":
+            st._settle()
 
-        updated_sampler_state = copy.deepcopy(sampler_state)  # :210-218
-        updated_sampler_state.positions = st.positions_user()
-        updated_sampler_state.velocities = st.velocities_user()
+        updated_sampler_state = sampler_state._copy_with(st.positions_user(), st.velocities_user())  # :210-218
         updated_sampler_state.current_PRNG_key = fold_in(key, number_of_steps)
         self.n_rebuilds = st.n_rebuilds
         return updated_sampler_state, st.nbr_list
@@ -225,9 +248,16 @@ class _RunState:
         if self.noise is not None and (self.noise.dim() != 3 or tuple(self.noise.shape[1:]) != (self.n, 3)):
             raise ValueError(f"noise must have shape (steps, {self.n}, 3), got {tuple(self.noise.shape)}")
         self.mass_user = mass
-        self.ctrl = torch.zeros((8,), dtype=torch.int32, device=self.dev)
-        self._ctrl_init = torch.tensor([0, 0, 0, _INT_MAX], dtype=torch.int32, device=self.dev)
-        self.ws = torch.empty((int(ops._lib.load().chx_lj_ws_count(self.n)),), dtype=torch.float64, device=self.dev)
+        # small device scratch kept on the integrator between run() calls (every launch of a run is
+        # enqueued behind the previous run's on the same stream; _load resets the control block)
+        keep = integ.__dict__.setdefault("_dev_scratch", {})
+        sk = (self.n, str(self.dev))
+        if keep.get("key") != sk:
+            keep.clear()
+            keep["key"] = sk
+            keep["ctrl"] = torch.zeros((8,), dtype=torch.int32, device=self.dev)
+            keep["ws"] = torch.empty((int(ops._lib.load().chx_lj_ws_count(self.n)),), dtype=torch.float64, device=self.dev)
+        self.ctrl, self.ws = keep["ctrl"], keep["ws"]
         self.is_verlet = isinstance(nbr_list, NeighborListNsqrd)
         self.is_pairlist = isinstance(nbr_list, PairListNsqrd)
         self.n_rebuilds = 0
@@ -372,7 +402,7 @@ class _RunState:
             finally:
                 self.nbr_list._adopt_positions = False
         self._load(x_user, v_user, step)
-        self._unsettled = (x_user, v_user, step) if spec else None
+        self._unsettled = (x_user, v_user, step, self.kicks_next) if spec else None
         self.n_rebuilds += 1
         if prof:
             torch.cuda.synchronize()
@@ -388,9 +418,10 @@ class _RunState:
         self._unsettled = None
         if self.nbr_list._confirm_build():
             return True
-        x_user, v_user, step = pend
+        x_user, v_user, step, kicks = pend
         torch.cuda.synchronize()
         self._load(x_user, v_user, step)
+        self.kicks_next = kicks
         self._unsettled_step = step
         return False
 

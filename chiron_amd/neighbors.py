@@ -124,7 +124,10 @@ class PairsBase(ABC):
         # chiron/neighbors.py:310-331
         if not isinstance(sampler_state, SamplerState):
             raise TypeError(f"Expected SamplerState, got {type(sampler_state)} instead")
+        self._box_token = None
         self.build(sampler_state.positions, sampler_state.box_vectors)
+        # lets the integrator recognise "same box as at the last build" without reading the device
+        self._box_token = getattr(sampler_state, "_box_token", None)
 
     @abstractmethod
     def calculate(self, positions):

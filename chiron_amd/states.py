@@ -76,6 +76,7 @@ class SamplerState:
         self._positions = self._to_md(positions)
         self._velocities = None if velocities is None else self._to_md(velocities)
         self._box_vectors = None if box_vectors is None else self._to_md(box_vectors)
+        self._box_token = object()  # identity of the box VALUES: copies share it, assigning a box renews it
         self._current_PRNG_key = current_PRNG_key
 
     def __deepcopy__(self, memo):
@@ -87,11 +88,22 @@ class SamplerState:
         for name, value in self.__dict__.items():
             if isinstance(value, unit.Quantity) and isinstance(value._value, torch.Tensor):
                 value = unit.Quantity(value._value.clone(), value.unit)
-            elif name not in ("_distance_unit", "_time_unit", "_current_PRNG_key"):
+            elif name not in ("_distance_unit", "_time_unit", "_current_PRNG_key", "_box_token"):
                 import copy
 
                 value = copy.deepcopy(value, memo)
             setattr(new, name, value)
+        return new
+
+    def _copy_with(self, positions: torch.Tensor, velocities: torch.Tensor) -> "SamplerState":
+        """``deepcopy(self)`` followed by assigning fresh md-unit fp32 device arrays (what
+        chiron/integrators.py:210-214 does), without cloning the two arrays that are replaced."""
+        new = SamplerState.__new__(SamplerState)
+        new.__dict__.update(self.__dict__)
+        if self._box_vectors is not None:
+            new._box_vectors = unit.Quantity(self._box_vectors._value.clone(), self._box_vectors.unit)
+        new._positions = unit.Quantity(positions, self._distance_unit)
+        new._velocities = unit.Quantity(velocities, self._distance_unit / self._time_unit)
         return new
 
     def _to_md(self, q: unit.Quantity) -> unit.Quantity:
@@ -132,6 +144,7 @@ class SamplerState:
 
     @box_vectors.setter
     def box_vectors(self, box_vectors) -> None:
+        self._box_token = object()
         if isinstance(box_vectors, unit.Quantity):
             self._box_vectors = self._to_md(box_vectors)
         else:
