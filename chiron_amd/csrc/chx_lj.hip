@@ -619,11 +619,20 @@ __global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int
     a.noise = nullptr;
   }
   __shared__ float sF[3 * PPB];
+  // (CHX_EXP_*: timing decomposition of scripts/exp_step.sh, never defined in the product build)
+#ifndef CHX_EXP_NOCTRL
   if ((long long)a.ctrl[3] <= step) return;  // block-uniform
+#endif
   // Which table this launch walks: the pruned inner list, unless some particle has moved too far
   // since the last pruning pass (flag raised by an EARLIER launch; the two flag words alternate
   // with the step parity so that no launch reads a word its own blocks may be writing).
+  // (Requesting both control words together ahead of the branch -- two s_load_dwordx4 in one asm
+  // block, since the compiler narrows and sinks plain reads -- measured 3 % SLOWER at N = 32768.)
+#ifndef CHX_EXP_NOCTRL
   const bool inner = (HOT || a.fli != nullptr) && a.ctrl[4 + (int)(step & 1)] == 0;
+#else
+  const bool inner = HOT || a.fli != nullptr;
+#endif
   const uint32_t* fl_use = inner ? a.fli : a.fl;
   const int32_t* deg_use = inner ? a.degi : a.deg;
   const unsigned blk = xcd_block(blockIdx.x, gridDim.x);
@@ -639,7 +648,9 @@ __global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int
   const bool valid = p < a.n;
   float4 xi;
   float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
+#ifndef CHX_EXP_NOFORCE
   lj_row<G>(a.x_cur, fl_use, deg_use, a.n, a.chunks, p, q, valid, a.box, a.lj, xi, fx, fy, fz, en);
+#endif
 #pragma unroll
   for (int o = G / 2; o > 0; o >>= 1) {
     fx += __shfl_xor(fx, o, CHX_WAVE);
@@ -658,7 +669,15 @@ __global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int
   //      the box, |x - ref| < L) runs branch-free; a particle that falls outside it is redone
   //      through the general formulas, which give the same bits wherever both apply. ----
   bool stale = false;
+#ifdef CHX_EXP_NOEPI
+  if (tk.live) {  // positions pass through (wrapped input stays wrapped), every operand is consumed
+    reinterpret_cast<float4*>(a.x_next)[tk.pp] = make_float4(
+        tk.x.x, tk.x.y, tk.x.z, sF[3 * threadIdx.x] + tk.z[0] + tk.v[0] + tk.m + tk.bs + tk.ref.x + tk.refi.x);
+  }
+  if (false) {
+#else
   if (tk.live) {
+#endif
     const float L[3] = {a.box.lx, a.box.ly, a.box.lz};
     const float hL[3] = {a.box.hx, a.box.hy, a.box.hz};
     const float xo[3] = {tk.x.x, tk.x.y, tk.x.z};

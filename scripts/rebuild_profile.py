@@ -8,7 +8,7 @@ from chiron_amd import integrators
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
-fluid, pot, state, thermo, nbr, integ = bench.make_system(wl, 300.0, 32, "cell")
+fluid, pot, state, thermo, nbr, integ = bench.make_system(wl, 300.0, int(os.environ.get("CHUNK", "32")), "cell")
 out = integ.run(state, thermo, number_of_steps=300, nbr_list=nbr)
 
 T = {"drain": 0.0, "unpack": 0.0, "build": 0.0, "load": 0.0, "n": 0}
