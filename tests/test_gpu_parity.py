@@ -815,6 +815,72 @@ def test_langevin_kinetic_temperature(ca, O):
     assert integ.n_rebuilds >= 1
 
 
+def test_reference_workflow_langevin_lj_fluid(ca, O, tmp_path):
+    """chiron/tests/test_convergence_tests.py:128-184 (skipped upstream as too slow for JAX-CPU) in the
+    reference's own shape: LennardJonesFluid(reduced_density=0.1, nparticles=5000), NeighborListNsqrd
+    (cutoff 3 sigma, skin 0.5 nm, M = 180) built from the state, LangevinIntegrator with a
+    LangevinDynamicsReporter every 100 steps, 1000 steps with the progress bar on.  Checked here:
+    the reporter's frames, the box, the thermostat, that the input state is not advanced (only its PRNG
+    key, as in the reference), and that the same key reproduces the run bit for bit."""
+    from chiron_amd.reporters import BaseReporter, LangevinDynamicsReporter
+    from chiron_amd.testsystems import LennardJonesFluid
+
+    u = ca.unit
+    fluid = LennardJonesFluid(reduced_density=0.1, nparticles=5000)
+    cutoff, skin = 3 * 0.34 * u.nanometer, 0.5 * u.nanometer
+    pot = ca.potential.LJPotential(fluid.topology, sigma=0.34 * u.nanometer, cutoff=cutoff)
+    thermo = ca.states.ThermodynamicState(potential=pot, temperature=300 * u.kelvin)
+    BaseReporter.set_directory(str(tmp_path))
+
+    def run_once():
+        ca.utils.PRNG.set_seed(1234)
+        state = ca.states.SamplerState(positions=fluid.positions, box_vectors=fluid.system.getDefaultPeriodicBoxVectors(),
+                                       current_PRNG_key=ca.utils.PRNG.get_random_key())
+        nbr = ca.neighbors.NeighborListNsqrd(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=cutoff, skin=skin,
+                                             n_max_neighbors=180)
+        nbr.build_from_state(state)
+        reporter = LangevinDynamicsReporter("lj_fluid_workflow")
+        integ = ca.integrators.LangevinIntegrator(reporter=reporter, report_interval=100)
+        x_before, key_before = state.positions.clone(), state.current_PRNG_key
+        out, nbr_out = integ.run(state, thermo, number_of_steps=1000, nbr_list=nbr, progress_bar=True)
+        assert torch.equal(state.positions, x_before) and state.current_PRNG_key != key_before
+        reporter.flush_buffer()
+        return out, nbr_out, reporter, integ
+
+    out, nbr, reporter, integ = run_once()
+    steps = np.asarray(reporter.get_property("step")).ravel()
+    assert steps.tolist() == list(range(0, 1000, 100))
+    energy = np.asarray(reporter.get_property("potential_energy"), dtype=np.float64).ravel()
+    frames = np.asarray(reporter.get_property("positions"))
+    assert energy.shape == (10,) and np.isfinite(energy).all() and frames.shape == (10, 5000, 3)
+    L = float(out.box_vectors[0, 0])
+    x = out.positions.cpu().numpy()
+    assert (x >= 0).all() and (x <= L).all()
+    # the reported energy of a frame is the potential's energy of that frame (fresh list, fp64 oracle)
+    nbr9 = ca.neighbors.NeighborListNsqrd(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=cutoff, skin=skin, n_max_neighbors=180)
+    nbr9.build(frames[-1], out.box_vectors)
+    e_again = float(pot.compute_energy(torch.as_tensor(frames[-1], device=out.positions.device), nbr9))
+    assert abs(e_again - energy[-1]) <= 2e-5 * abs(energy[-1]) + 1e-3
+    assert pot.epsilon == pytest.approx(4.184)  # the reference's default: 1 kcal/mol (chiron/potential.py:136)
+    e64, _, abs_e, _ = O.lj_bruteforce_f64(frames[-1], out.box_vectors.cpu().numpy(), SIGMA, pot.epsilon, CUTOFF)
+    assert abs(energy[-1] - e64) <= 1e-5 * max(abs_e, 1.0)
+    # eps = 1 kcal/mol puts 300 K below the LJ critical point (T* = 0.6): the lattice gas condenses, the
+    # potential energy falls and the 1/ps thermostat has not yet carried the heat away after 1 ps (the
+    # equilibrium <m v^2> = kT is pinned by test_langevin_kinetic_temperature)
+    v = out.velocities.cpu().numpy()
+    assert 0.9 < (39.948 * v ** 2).mean() / (O.R_KJ * 300.0) < 1.6
+    assert energy[-1] < energy[0]
+    assert nbr.is_built and integ.n_rebuilds >= 2
+    # the list handed back is the reference's list of its last rebuild: ascending ids, padding rule, mask
+    nl_mask, nl, n_nbr, n_max = O.neighborlist_build(nbr.ref_positions.cpu().numpy(), out.box_vectors.cpu().numpy(),
+                                                     1.02, 0.5, nbr.n_max_neighbors)
+    assert n_max == nbr.n_max_neighbors and np.array_equal(u32(nbr.neighbor_list), nl)
+    assert np.array_equal(nbr.neighbor_mask.cpu().numpy(), nl_mask)
+    out2, _, reporter2, _ = run_once()
+    assert torch.equal(out.positions, out2.positions) and torch.equal(out.velocities, out2.velocities)
+    assert np.array_equal(np.asarray(reporter2.get_property("potential_energy")), np.asarray(reporter.get_property("potential_energy")))
+
+
 # ---------------------------------------------------------------------------
 # Monte Carlo
 # ---------------------------------------------------------------------------
