@@ -345,7 +345,7 @@ class ForceList:
         self.g = _choose_g(self.maxdeg, n)
         chunks = fl_chunks_for(self.maxdeg, self.g)
         self.chunks = chunks
-        self.fl = torch.zeros((chunks, n, FL_QUAD * self.g), dtype=torch.int32, device=dev)  # zero = a valid index
+        self.fl = torch.zeros((chunks, n, FL_QUAD * self.g), dtype=torch.int32, device=dev)  # a valid index everywhere; chx_fl_fill pads rows with their own index
         cursor = torch.empty((n,), dtype=torch.int32, device=dev)
         check(lib.chx_fl_fill(_ptr(nl), _ptr(n_nbr), n, m, _ptr(self.inv), self.g, _ptr(cursor), _ptr(self.fl), _stream()), "chx_fl_fill")
         rc = lib.chx_fl_sort(_ptr(self.fl), _ptr(self.deg), n, self.g, self.maxdeg, _stream())

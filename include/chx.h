@@ -176,9 +176,12 @@ int chx_pack_langevin(const float* x3, const float* v3, const float* mass, const
  * (chiron/potential.py:193-213, :260-279), F = -dE/dx (chiron/potential.py:21-24,
  * closed form :322-332).  x4 is (n,4) in internal order; force3_out (n,3) in
  * internal order (NULL = energy only); energy_out[1] (NULL = force only);
- * chunks = allocated chunks of fl (fl holds chunks*n*4*g entries, slots past a row's
- * end must hold a valid index, e.g. 0: the kernel loads the first entries of every
- * row before it knows the row's length); ws: >= chx_lj_ws_count(n) doubles. */
+ * chunks = allocated chunks of fl (fl holds chunks*n*4*g entries; the slots between a
+ * row's end and the end of its last touched chunk -- at least chunk 0 -- must hold a
+ * valid index: the kernel loads the first entries of every row before it knows the
+ * row's length and gathers whole chunks.  chx_fl_fill and the cell build write the
+ * row's own index there, a zero-length pair that keeps the kernel on its fast path);
+ * ws: >= chx_lj_ws_count(n) doubles. */
 int64_t chx_lj_ws_count(int32_t n);
 int chx_lj_fl_energy_force(const float* x4, const uint32_t* fl, const int32_t* deg, int32_t n,
                            int32_t g, int32_t chunks, chx_box_t box, float sigma, float epsilon, float cutoff,
