@@ -254,12 +254,19 @@ __device__ __forceinline__ f2 pk_yy(f2 a, f2 b) {
 struct RowAcc {
   f2 ax, ay, az, ae;
   bool bad;
+  bool keep0, keep1;  // PRUNE: entries u / u+1 of the last lj_pair2 call stay in the inner list
+};
+
+// what the pruning variant of the step kernel needs besides the list it walks (see k_lj_step)
+struct PruneOut {
+  uint32_t* fli;   // inner list, same geometry as the force list
+  float T_inner;   // r2 <= T_inner: kept
 };
 
 // two list entries (u, u+1) of one lane; xj*: the gathered neighbor positions as (x,y) and (z,w)
-template <int MODE>
+template <int MODE, bool PRUNE>
 __device__ __forceinline__ void lj_pair2(const float4& xi, f2 xy0, f2 zw0, f2 xy1, f2 zw1, uint32_t e0, uint32_t e1,
-                                         bool act1, const Box3& box, const LJParams& lj, RowAcc& A) {
+                                         bool act1, const Box3& box, const LJParams& lj, float T_inner, RowAcc& A) {
   // orientation: r = x_lo - x_hi by ORIGINAL id = +-(xi - xj); multiplying by +-1 is exact
   const f2 sgn = {(e0 & CHX_FL_HI) ? 1.0f : -1.0f, (e1 & CHX_FL_HI) ? 1.0f : -1.0f};
   const f2 dx = xi.x - pk_xx(xy0, xy1);
@@ -273,13 +280,21 @@ __device__ __forceinline__ void lj_pair2(const float4& xi, f2 xy0, f2 zw0, f2 xy
     const f2 tx = __builtin_elementwise_fma(dx, sgn, f2_splat(box.hx));
     const f2 ty = __builtin_elementwise_fma(dy, sgn, f2_splat(box.hy));
     const f2 tz = __builtin_elementwise_fma(dz, sgn, f2_splat(box.hz));
-    A.bad |= !(fabsf(dx.x) < box.lx) | !(fabsf(dy.x) < box.ly) | !(fabsf(dz.x) < box.lz);
-    A.bad |= !(fabsf(dx.y) < box.lx) | !(fabsf(dy.y) < box.ly) | !(fabsf(dz.y) < box.lz);
+    const bool bad0 = !(fabsf(dx.x) < box.lx) | !(fabsf(dy.x) < box.ly) | !(fabsf(dz.x) < box.lz);
+    const bool bad1 = !(fabsf(dx.y) < box.lx) | !(fabsf(dy.y) < box.ly) | !(fabsf(dz.y) < box.lz);
+    A.bad |= bad0 | bad1;
+    // unwrapped coordinates: the fast minimum image says nothing about such a pair, keep it listed
+    if (PRUNE) A.keep0 = bad0, A.keep1 = bad1;
     rx = min_image2_t(tx, box.lx, box.hx);
     ry = min_image2_t(ty, box.ly, box.hy);
     rz = min_image2_t(tz, box.lz, box.hz);
   }
   const f2 r2 = (rx * rx + ry * ry) + rz * rz;  // norm2() in both halves
+  if (PRUNE) {
+    if (MODE == LJ_OPEN) A.keep0 = A.keep1 = false;
+    A.keep0 |= r2.x <= T_inner;
+    A.keep1 = act1 && (A.keep1 || r2.y <= T_inner);
+  }
   const bool in0 = r2.x <= lj.T;
   const bool in1 = act1 && r2.y <= lj.T;
   const f2 inv = {__builtin_amdgcn_rcpf(r2.x), __builtin_amdgcn_rcpf(r2.y)};
@@ -298,28 +313,52 @@ __device__ __forceinline__ void lj_pair2(const float4& xi, f2 xy0, f2 zw0, f2 xy
   A.ae += e;
 }
 
-// the chunk loop of one lane: chunk 0 (index quad e4, its four gathers) is already in flight
-template <int G, int MODE>
+// the chunk loop of one lane: chunk 0 (index quad e4, its four gathers) is already in flight.
+// PRUNE: the entries with r2 <= T_inner are also copied, in order, into row p of the inner list
+// (ordered compaction over the G lanes that share the row); `kept` returns the row's new length.
+template <int G, int MODE, bool PRUNE>
 __device__ __forceinline__ void lj_row_loop(const float4* __restrict__ x4, const uint4* __restrict__ col,
                                             size_t stride, int d, int nc, int q, const float4& xi, uint4 e4,
-                                            float4 (&xj)[4], const Box3& box, const LJParams& lj, RowAcc& A) {
+                                            float4 (&xj)[4], const Box3& box, const LJParams& lj, RowAcc& A,
+                                            const PruneOut& po, int p, int n, int& kept) {
   constexpr int W = 4 * G;
+  int base = 0;  // PRUNE: entries kept so far in this row (uniform over the G lanes)
   for (int c = 0; c < nc; ++c) {
     const int k0 = c * W + 4 * q;  // this lane's first entry of the chunk
     uint4 nx = make_uint4(0u, 0u, 0u, 0u);
     if (c + 1 < nc) nx = col[(size_t)(c + 1) * stride];
+    bool kp[4] = {false, false, false, false};
 #ifdef CHX_EXP_NO_MATH
     if (k0 < d) { A.ax += (f2){xj[0].x + xj[1].y, xj[2].z + xj[3].x}; }
 #else
     if (k0 < d) {
-      lj_pair2<MODE>(xi, (f2){xj[0].x, xj[0].y}, (f2){xj[0].z, xj[0].w}, (f2){xj[1].x, xj[1].y},
-                     (f2){xj[1].z, xj[1].w}, e4.x, e4.y, k0 + 1 < d, box, lj, A);
+      lj_pair2<MODE, PRUNE>(xi, (f2){xj[0].x, xj[0].y}, (f2){xj[0].z, xj[0].w}, (f2){xj[1].x, xj[1].y},
+                            (f2){xj[1].z, xj[1].w}, e4.x, e4.y, k0 + 1 < d, box, lj, po.T_inner, A);
+      if (PRUNE) kp[0] = A.keep0, kp[1] = A.keep1;
     }
     if (k0 + 2 < d) {
-      lj_pair2<MODE>(xi, (f2){xj[2].x, xj[2].y}, (f2){xj[2].z, xj[2].w}, (f2){xj[3].x, xj[3].y},
-                     (f2){xj[3].z, xj[3].w}, e4.z, e4.w, k0 + 3 < d, box, lj, A);
+      lj_pair2<MODE, PRUNE>(xi, (f2){xj[2].x, xj[2].y}, (f2){xj[2].z, xj[2].w}, (f2){xj[3].x, xj[3].y},
+                            (f2){xj[3].z, xj[3].w}, e4.z, e4.w, k0 + 3 < d, box, lj, po.T_inner, A);
+      if (PRUNE) kp[2] = A.keep0, kp[3] = A.keep1;
     }
 #endif
+    if (PRUNE) {
+      // (all G lanes of a row run the same number of chunks, so the shuffles below are group-uniform)
+      const uint32_t ent[4] = {e4.x, e4.y, e4.z, e4.w};
+      const int cnt = (int)kp[0] + (int)kp[1] + (int)kp[2] + (int)kp[3];
+      int incl = cnt;
+#pragma unroll
+      for (int o = 1; o < G; o <<= 1) {
+        const int v = __shfl_up(incl, o, G);
+        if (q >= o) incl += v;
+      }
+      int slot = base + incl - cnt;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (kp[u]) po.fli[chx_fl_addr(p, slot++, n, G)] = ent[u];
+      }
+      base += __shfl(incl, G - 1, G);
+    }
     if (c + 1 < nc) {
       e4 = nx;
 #ifdef CHX_EXP_NO_GATHER
@@ -332,6 +371,7 @@ __device__ __forceinline__ void lj_row_loop(const float4* __restrict__ x4, const
 #endif
     }
   }
+  kept = base;
 }
 
 // One particle's share of its force-list row.  A row is stored in chunks of W = 4 G entries
@@ -347,11 +387,12 @@ __device__ __forceinline__ void lj_row_loop(const float4* __restrict__ x4, const
 // arithmetic is branch-free and packed two entries wide; a lane whose fast form does not apply
 // (unwrapped input coordinates, a list that does not match the positions) redoes its share
 // through the general min_image().
-template <int G>
+template <int G, bool PRUNE = false>
 __device__ __forceinline__ void lj_row(const float4* __restrict__ x4, const uint32_t* __restrict__ fl,
                                        const int32_t* __restrict__ deg, int n, int chunks, int p, int q,
                                        bool valid, const Box3& box, const LJParams& lj, float4& xi_out,
-                                       float& fx, float& fy, float& fz, float& en) {
+                                       float& fx, float& fy, float& fz, float& en,
+                                       const PruneOut& po = PruneOut{nullptr, 0.f}, int* kept_out = nullptr) {
   constexpr int W = 4 * G;
   const int pc = valid ? p : 0;
   const size_t stride = (size_t)n * G;  // uint4 units between consecutive chunks
@@ -370,11 +411,14 @@ __device__ __forceinline__ void lj_row(const float4* __restrict__ x4, const uint
   RowAcc A;
   A.ax = A.ay = A.az = A.ae = f2_splat(0.f);
   A.bad = false;
+  A.keep0 = A.keep1 = false;
+  int kept = 0;
   if (!box.periodic) {
-    lj_row_loop<G, LJ_OPEN>(x4, col, stride, d, nc, q, xi, e4, xj, box, lj, A);
+    lj_row_loop<G, LJ_OPEN, PRUNE>(x4, col, stride, d, nc, q, xi, e4, xj, box, lj, A, po, pc, n, kept);
   } else {
-    lj_row_loop<G, LJ_SHIFT>(x4, col, stride, d, nc, q, xi, e4, xj, box, lj, A);
+    lj_row_loop<G, LJ_SHIFT, PRUNE>(x4, col, stride, d, nc, q, xi, e4, xj, box, lj, A, po, pc, n, kept);
   }
+  if (PRUNE) *kept_out = kept;
   if (__builtin_expect(A.bad, 0)) {
     // general path, one entry at a time (bit-identical to the fast paths wherever those are valid)
     A.ax = A.ay = A.az = A.ae = f2_splat(0.f);
@@ -577,7 +621,7 @@ __device__ __forceinline__ bool integrate_component(const StepArgs& a, int n_kic
   return rare;
 }
 
-template <bool HOT>
+template <bool HOT, bool PRUNE>
 __device__ __forceinline__ StepParticle load_step_particle(const StepArgs& a, long long step, int do_aoa, int p0,
                                                            int pl, int ppb) {
   StepParticle t;
@@ -596,7 +640,9 @@ __device__ __forceinline__ StepParticle load_step_particle(const StepArgs& a, lo
       t.bs = fmul(a.b, fsqrt(fdiv(a.kT, t.m)));
       t.x = a.x_cur[t.pp];
       if (HOT || a.ref4) t.ref = a.ref4[t.pp];
-      if (HOT || a.fli) t.refi = a.refi4[t.pp];
+      // a pruning launch measures against the positions it prunes at (and rewrites refi4 itself)
+      if (PRUNE) t.refi = t.x;
+      else if (HOT || a.fli) t.refi = a.refi4[t.pp];
       const uint32_t o = (HOT || a.perm) ? a.perm[t.pp] : (uint32_t)t.pp;
       if (!HOT && a.noise) {
         const float* row = a.noise + ((size_t)(step - a.noise_step0) * (size_t)a.n + o) * 3;
@@ -610,8 +656,14 @@ __device__ __forceinline__ StepParticle load_step_particle(const StepArgs& a, lo
   return t;
 }
 
-template <int G, bool HOT>
-__global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int n_kicks, int do_aoa) {
+// PRUNE: the launch that refreshes the dynamically pruned inner list (see below): it walks the FULL
+// force list and, next to the forces, copies the entries with |r| < cutoff + inner_skin into the
+// inner list, in order, and records the positions it saw -- the pruning costs no pass of its own.
+// `epoch` counts the refreshes since the state was loaded (-1 before the first): the two
+// "inner list is stale" words hold the epoch in which they were raised, so a refresh invalidates
+// them without anybody having to clear a word another block may be reading.
+template <int G, bool HOT, bool PRUNE>
+__global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int n_kicks, int do_aoa, int epoch) {
   constexpr int PPB = 256 / G;  // particles per block (<= 256)
   if (HOT) {  // what the launcher checked (launch_step_g), restated for the optimiser
     n_kicks = 2, do_aoa = 1;
@@ -624,14 +676,17 @@ __global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int
   if ((long long)a.ctrl[3] <= step) return;  // block-uniform
 #endif
   // Which table this launch walks: the pruned inner list, unless some particle has moved too far
-  // since the last pruning pass (flag raised by an EARLIER launch; the two flag words alternate
-  // with the step parity so that no launch reads a word its own blocks may be writing).
+  // since the last refresh (word raised by an EARLIER launch; the two words alternate with the
+  // step parity so that no launch reads a word its own blocks may be writing).
   // (Requesting both control words together ahead of the branch -- two s_load_dwordx4 in one asm
   // block, since the compiler narrows and sinks plain reads -- measured 3 % SLOWER at N = 32768.)
 #ifndef CHX_EXP_NOCTRL
-  const bool inner = (HOT || a.fli != nullptr) && a.ctrl[4 + (int)(step & 1)] == 0;
+  // (read unconditionally and combined without a short circuit: a branch on `epoch` in front of this
+  // read puts a second exposed scalar round trip ahead of every other load of the launch)
+  const int stale_word = a.ctrl[4 + (int)(step & 1)];
+  const bool inner = !PRUNE && (HOT || a.fli != nullptr) && ((epoch >= 0) & (stale_word != epoch));
 #else
-  const bool inner = HOT || a.fli != nullptr;
+  const bool inner = !PRUNE && (HOT || a.fli != nullptr);
 #endif
   const uint32_t* fl_use = inner ? a.fli : a.fl;
   const int32_t* deg_use = inner ? a.degi : a.deg;
@@ -640,7 +695,7 @@ __global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int
   // ---- operands of this thread's integrate work (threads 0..PPB-1 own one particle each: the
   //      first wavefronts of the block), requested before the force loop so their latency and the
   //      Philox arithmetic hide under it ----
-  const StepParticle tk = load_step_particle<HOT>(a, step, do_aoa, p0, threadIdx.x, PPB);
+  const StepParticle tk = load_step_particle<HOT, PRUNE>(a, step, do_aoa, p0, threadIdx.x, PPB);
 
   const int tid = blk * 256 + threadIdx.x;
   const int p = tid / G;
@@ -649,7 +704,24 @@ __global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int
   float4 xi;
   float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
 #ifndef CHX_EXP_NOFORCE
-  lj_row<G>(a.x_cur, fl_use, deg_use, a.n, a.chunks, p, q, valid, a.box, a.lj, xi, fx, fy, fz, en);
+  if (PRUNE) {
+    constexpr int W = 4 * G;
+    int kept = 0;
+    lj_row<G, true>(a.x_cur, fl_use, deg_use, a.n, a.chunks, p, q, valid, a.box, a.lj, xi, fx, fy, fz, en,
+                    PruneOut{a.fli, a.T_inner}, &kept);
+    if (valid) {
+      // the force kernel gathers whole chunks (chunk 0 speculatively): pad the last touched chunk
+      int end = (kept + W - 1) / W * W;
+      end = end < W ? W : end;
+      for (int sl = kept + q; sl < end; sl += G) a.fli[chx_fl_addr(p, sl, a.n, G)] = (uint32_t)p;
+      if (q == 0) {
+        a.degi[p] = kept;
+        a.refi4[p] = xi;
+      }
+    }
+  } else {
+    lj_row<G>(a.x_cur, fl_use, deg_use, a.n, a.chunks, p, q, valid, a.box, a.lj, xi, fx, fy, fz, en);
+  }
 #endif
 #pragma unroll
   for (int o = G / 2; o > 0; o >>= 1) {
@@ -704,91 +776,27 @@ __global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int
       if ((HOT || a.fli) && (sqi[0] + sqi[1]) + sqi[2] > a.T_half_inner) stale = true;
     }
   }
-  // the inner list stays off until the next pruning pass clears both words
-  if (do_aoa && (HOT || a.fli) && (stale || (!inner && threadIdx.x == 0))) a.ctrl[4 + (int)((step + 1) & 1)] = 1;
-  if ((HOT || a.fli) && !inner && blockIdx.x == 0 && threadIdx.x == 0) a.ctrl[6] += 1;  // launches on the full list
+  // the inner list stays off until the next refresh (a new epoch) outdates the word
+  if (do_aoa && (HOT || a.fli) && epoch >= 0 && (stale || (!inner && !PRUNE && threadIdx.x == 0)))
+    a.ctrl[4 + (int)((step + 1) & 1)] = epoch;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (PRUNE) a.ctrl[7] += 1;                                // refreshes of the inner list
+    else if ((HOT || a.fli) && !inner) a.ctrl[6] += 1;        // launches on the full list
+  }
 }
 
 // ---------------------------------------------------------------------------
 // Dynamic pruning: the reference's list keeps every pair within cutoff + skin of the last build
 // (skin = 0.5 nm in its examples: 3.3x the volume of the cutoff sphere), but a pair can only
-// interact while |r| < cutoff.  Every few steps this pass copies, in order, the entries with
-// |r_now| < cutoff + inner_skin into a second table of the same layout and records the positions
-// it saw; the step kernel walks that table for as long as no particle has moved more than
-// inner_skin / 2 since (checked next to the reference's own skin check) and falls back to the
-// full table otherwise, until the next pass.  A dropped pair was farther than cutoff + inner_skin
-// and each partner moved less than inner_skin / 2, so it is still outside the cutoff: the set of
-// interacting pairs -- the reference's set -- is unchanged; only the summation order differs.
+// interact while |r| < cutoff.  Every few steps a PRUNE launch of k_lj_step copies, in order, the
+// entries with |r_now| < cutoff + inner_skin into a second table of the same layout and records the
+// positions it saw; the following launches walk that table for as long as no particle has moved
+// more than inner_skin / 2 since (checked next to the reference's own skin check) and fall back to
+// the full table otherwise, until the next refresh.  A dropped pair was farther than
+// cutoff + inner_skin and each partner moved less than inner_skin / 2, so it is still outside the
+// cutoff: the set of interacting pairs -- the reference's set -- is unchanged; only the summation
+// order differs.
 // ---------------------------------------------------------------------------
-template <int G>
-__global__ __launch_bounds__(256) void k_fl_prune(StepArgs a, long long step) {
-  if ((long long)a.ctrl[3] <= step) return;
-  constexpr int W = 4 * G;
-  const unsigned blk = xcd_block(blockIdx.x, gridDim.x);
-  const int tid = blk * 256 + threadIdx.x;
-  const int p = tid / G;
-  const int q = tid % G;
-  const bool valid = p < a.n;
-  const int pc = valid ? p : 0;
-  const size_t stride = (size_t)a.n * G;
-  const uint4* col = reinterpret_cast<const uint4*>(a.fl) + (size_t)pc * G + q;
-  const float4 xi = a.x_cur[pc];
-  const int d = valid ? a.deg[pc] : 0;
-  const int nc = (d + W - 1) / W;
-  int base = 0;  // entries kept so far in this row (uniform over the G lanes)
-  for (int c = 0; c < nc; ++c) {
-    const uint4 e4 = col[(size_t)c * stride];
-    const uint32_t ent[4] = {e4.x, e4.y, e4.z, e4.w};
-    float4 xj[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) xj[u] = a.x_cur[ent[u] & ~CHX_FL_HI];
-    bool keep[4];
-    int cnt = 0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      float rx = xi.x - xj[u].x, ry = xi.y - xj[u].y, rz = xi.z - xj[u].z;
-      bool far = false;
-      if (a.box.periodic) {
-        far = !(fabsf(rx) < a.box.lx) | !(fabsf(ry) < a.box.ly) | !(fabsf(rz) < a.box.lz);
-        rx = min_image_fast(rx, a.box.lx, a.box.hx);
-        ry = min_image_fast(ry, a.box.ly, a.box.hy);
-        rz = min_image_fast(rz, a.box.lz, a.box.hz);
-      }
-      // unwrapped coordinates (far): keep the entry, the force kernel sorts it out
-      keep[u] = (c * W + 4 * q + u < d) && (far || (rx * rx + ry * ry) + rz * rz <= a.T_inner);
-      cnt += keep[u] ? 1 : 0;
-    }
-    // ordered compaction over the G lanes that share the row
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < G; o <<= 1) {
-      const int v = __shfl_up(incl, o, G);
-      if (q >= o) incl += v;
-    }
-    int slot = base + incl - cnt;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (keep[u]) a.fli[chx_fl_addr(pc, slot++, a.n, G)] = ent[u];
-    }
-    base += __shfl(incl, G - 1, G);
-  }
-  if (valid) {
-    // the force kernel gathers whole chunks (chunk 0 speculatively): pad the last touched chunk
-    int end = (base + W - 1) / W * W;
-    end = end < W ? W : end;
-    for (int sl = base + q; sl < end; sl += G) a.fli[chx_fl_addr(p, sl, a.n, G)] = (uint32_t)p;
-    if (q == 0) {
-      a.degi[p] = base;
-      a.refi4[p] = xi;
-    }
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    a.ctrl[4] = 0;
-    a.ctrl[5] = 0;
-    a.ctrl[7] += 1;
-  }
-}
-
 template <int G>
 static int launch_lj_fl_g(const float4* x4, const uint32_t* fl, const int32_t* deg, int n, int chunks,
                           Box3 box, LJParams lj, float* f3, float* energy, double* ws, int32_t* ctrl,
@@ -847,22 +855,21 @@ int chx_launch_lj_fl(const float* x4, const uint32_t* fl, const int32_t* deg, in
 }
 
 template <int G>
-static void launch_step_g(const StepArgs& a, long long step, int n_kicks, int do_aoa, bool prune,
+static void launch_step_g(const StepArgs& a, long long step, int n_kicks, int do_aoa, bool prune, int epoch,
                           hipStream_t st) {
   const unsigned blocks = (unsigned)(((int64_t)a.n * G + 255) / 256);
   static const bool dbg = getenv("CHX_DEBUG_SYNC") != nullptr;  // serialise + narrate (fault hunting)
-  if (prune) {
-    if (dbg) fprintf(stderr, "[chx] k_fl_prune<%d> step %lld\n", G, step);
-    hipLaunchKernelGGL((k_fl_prune<G>), dim3(blocks), dim3(256), 0, st, a, step);
-    if (dbg) (void)hipStreamSynchronize(st);
-  }
-  if (dbg) fprintf(stderr, "[chx] k_lj_step<%d> step %lld kicks %d aoa %d\n", G, step, n_kicks, do_aoa);
+  if (dbg) fprintf(stderr, "[chx] k_lj_step<%d> step %lld kicks %d aoa %d prune %d epoch %d\n", G, step, n_kicks, do_aoa, (int)prune, epoch);
   // steady-state launches take the instantiation with the launch-uniform switches folded
   const bool hot = n_kicks == 2 && do_aoa && a.wrap && a.box.periodic && a.ref4 && a.fli && a.perm && !a.noise;
-  if (hot) {
-    hipLaunchKernelGGL((k_lj_step<G, true>), dim3(blocks), dim3(256), 0, st, a, step, n_kicks, do_aoa);
+  if (hot && prune) {
+    hipLaunchKernelGGL((k_lj_step<G, true, true>), dim3(blocks), dim3(256), 0, st, a, step, n_kicks, do_aoa, epoch);
+  } else if (hot) {
+    hipLaunchKernelGGL((k_lj_step<G, true, false>), dim3(blocks), dim3(256), 0, st, a, step, n_kicks, do_aoa, epoch);
+  } else if (prune) {
+    hipLaunchKernelGGL((k_lj_step<G, false, true>), dim3(blocks), dim3(256), 0, st, a, step, n_kicks, do_aoa, epoch);
   } else {
-    hipLaunchKernelGGL((k_lj_step<G, false>), dim3(blocks), dim3(256), 0, st, a, step, n_kicks, do_aoa);
+    hipLaunchKernelGGL((k_lj_step<G, false, false>), dim3(blocks), dim3(256), 0, st, a, step, n_kicks, do_aoa, epoch);
   }
   if (dbg) (void)hipStreamSynchronize(st);
 }
@@ -908,19 +915,20 @@ int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, in
     a.x_cur = reinterpret_cast<const float4*>((i & 1) ? x_odd : x_even);
     a.x_next = (i & 1) ? x_even : x_odd;
     const int nk = i == 0 ? kicks_first : 2;
-    // pruning passes sit at fixed step indices (counted from prune_phase), not at chunk
+    // refreshes of the inner list sit at fixed step indices (counted from prune_phase), not at chunk
     // boundaries: a trajectory does not depend on how its steps are batched into calls
     // (the force-only launch that ends a run is included: it may be the first one after a rebuild)
-    const bool prune = use_inner && (step0 + i >= p->prune_phase) &&
-                       ((step0 + i - p->prune_phase) % p->prune_every == 0);
+    const bool since = use_inner && (step0 + i >= p->prune_phase);
+    const bool prune = since && ((step0 + i - p->prune_phase) % p->prune_every == 0);
+    const int epoch = since ? (int)((step0 + i - p->prune_phase) / p->prune_every) : -1;
     switch (p->g) {
-      case 1: launch_step_g<1>(a, step0 + i, nk, do_aoa, prune, st); break;
-      case 2: launch_step_g<2>(a, step0 + i, nk, do_aoa, prune, st); break;
-      case 4: launch_step_g<4>(a, step0 + i, nk, do_aoa, prune, st); break;
-      case 8: launch_step_g<8>(a, step0 + i, nk, do_aoa, prune, st); break;
-      case 16: launch_step_g<16>(a, step0 + i, nk, do_aoa, prune, st); break;
-      case 32: launch_step_g<32>(a, step0 + i, nk, do_aoa, prune, st); break;
-      case 64: launch_step_g<64>(a, step0 + i, nk, do_aoa, prune, st); break;
+      case 1: launch_step_g<1>(a, step0 + i, nk, do_aoa, prune, epoch, st); break;
+      case 2: launch_step_g<2>(a, step0 + i, nk, do_aoa, prune, epoch, st); break;
+      case 4: launch_step_g<4>(a, step0 + i, nk, do_aoa, prune, epoch, st); break;
+      case 8: launch_step_g<8>(a, step0 + i, nk, do_aoa, prune, epoch, st); break;
+      case 16: launch_step_g<16>(a, step0 + i, nk, do_aoa, prune, epoch, st); break;
+      case 32: launch_step_g<32>(a, step0 + i, nk, do_aoa, prune, epoch, st); break;
+      case 64: launch_step_g<64>(a, step0 + i, nk, do_aoa, prune, epoch, st); break;
       default:
         chx_set_error("chx_launch_lj_steps: unsupported g = %d", p->g);
         return CHX_ERR_INVALID;

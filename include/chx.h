@@ -235,17 +235,18 @@ typedef struct {
   int32_t* ctrl;         /* 8 ints.  [0] violation seen by integrate, [1] halt (set by force kernel),
                             [2] step at which the skin check fired, [3] fused path: first step that
                             must not run (INT32_MAX when clear), [4],[5] inner list stale (by step
-                            parity), [6] launches that ran on the full list, [7] pruning passes */
+                            parity; the value is the refresh epoch the word was raised in),
+                            [6] launches that ran on the full list, [7] refreshes of the inner list */
   double* ws;            /* energy workspace, >= chx_lj_ws_count(n) */
   int32_t external_force; /* != 0: do not launch the LJ force kernel (the caller fills f
                              between single-step chunks: IdealGasPotential and other potentials) */
   int32_t fl_chunks;      /* allocated chunks of the force list: fl holds fl_chunks * n * 4 * g entries */
   /* Dynamically pruned inner list (fused path only; all NULL / 0 = off).  Every prune_every
-   * steps, counted from step index prune_phase, a pass copies the entries of fl with
-   * |r| < cutoff + inner_skin into fl_inner (same geometry as fl), their counts into deg_inner
-   * and the positions it saw into ref_inner4; the step kernel walks fl_inner until some
-   * particle has moved inner_skin / 2 from ref_inner4 and fl itself from then to the next pass.
-   * The interacting pairs are those of fl in either case (see csrc/chx_lj.hip: k_fl_prune). */
+   * steps, counted from step index prune_phase, the step launch walks fl itself and copies the
+   * entries with |r| < cutoff + inner_skin into fl_inner (same geometry as fl), their counts into
+   * deg_inner and the positions it saw into ref_inner4; the following launches walk fl_inner until
+   * some particle has moved inner_skin / 2 from ref_inner4 and fl itself from then to the next
+   * refresh.  The interacting pairs are those of fl in either case (csrc/chx_lj.hip: k_lj_step). */
   uint32_t* fl_inner;
   int32_t* deg_inner;
   float* ref_inner4;
@@ -295,7 +296,7 @@ int chx_langevin_fused_chunk(const chx_langevin_t* p_h, float* x_even, float* x_
                              chx_stream_t stream);
 
 /* Control-block plumbing of the loop above, as ordinary kernels on the caller's stream:
- * chx_ctrl_reset writes {0, 0, 0, INT32_MAX, 1, 1, 0, 0}; chx_publish copies n <= 64 ints into
+ * chx_ctrl_reset writes {0, 0, 0, INT32_MAX, -2, -2, 0, 0}; chx_publish copies n <= 64 ints into
  * HOST-MAPPED pinned memory (host_mapped_dst is the device-visible address of a
  * hipHostMalloc'ed block) with system-scope visibility, so the host can read the block
  * after waiting for the stream without any copy-engine / blit work in the hot loop. */

@@ -11,15 +11,18 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         name = r.get("Kernel_Name", "")
-        m = re.match(r"(?:void )?(k_lj_fl|k_lj_step|k_fl_prune)<(\d+)", name)
+        m = re.match(r"(?:void )?(k_lj_fl|k_lj_step)<(\d+)((?:, (?:true|false))*)>", name)
         if not m:
             continue
         g = int(m.group(2))
+        flags = [f.strip() for f in m.group(3).split(",") if f.strip()]
         n = int(r["Grid_Size"]) // g
         wl = {32768: "c3", 262144: "c4"}.get(n)
         if wl is None:
             continue
-        acc[(wl, m.group(1), g)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        # k_lj_step<G, HOT, PRUNE>: the launches that also refresh the inner list are a kernel of their own
+        kern = m.group(1) + ("+refresh" if m.group(1) == "k_lj_step" and len(flags) == 2 and flags[1] == "true" else "")
+        acc[(wl, kern, g)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 
 res = {}
 rows = []
