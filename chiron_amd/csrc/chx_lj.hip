@@ -663,7 +663,11 @@ __device__ __forceinline__ StepParticle load_step_particle(const StepArgs& a, lo
 // "inner list is stale" words hold the epoch in which they were raised, so a refresh invalidates
 // them without anybody having to clear a word another block may be reading.
 template <int G, bool HOT, bool PRUNE>
-__global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int n_kicks, int do_aoa, int epoch) {
+__global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long step, int epoch, StepArgs a, int n_kicks,
+                                                 int do_aoa) {
+  // (the control block and the step index lead the argument list: they are what the launch needs first,
+  // and leading scalar arguments are the ones the dispatcher can preload into SGPRs)
+  a.ctrl = ctrl_first;
   constexpr int PPB = 256 / G;  // particles per block (<= 256)
   if (HOT) {  // what the launcher checked (launch_step_g), restated for the optimiser
     n_kicks = 2, do_aoa = 1;
@@ -673,7 +677,11 @@ __global__ __launch_bounds__(256) void k_lj_step(StepArgs a, long long step, int
   __shared__ float sF[3 * PPB];
   // (CHX_EXP_*: timing decomposition of scripts/exp_step.sh, never defined in the product build)
 #ifndef CHX_EXP_NOCTRL
-  if ((long long)a.ctrl[3] <= step) return;  // block-uniform
+  // (naming the arguments the first vector loads need in an asm statement ahead of this branch makes
+  // their fetch leave together with the halt word's -- and measured 3 % slower: the stale-word read
+  // turns into a vector load and a second argument fetch still follows the branch)
+  const int halt_step = a.ctrl[3];
+  if ((long long)halt_step <= step) return;  // block-uniform
 #endif
   // Which table this launch walks: the pruned inner list, unless some particle has moved too far
   // since the last refresh (word raised by an EARLIER launch; the two words alternate with the
@@ -863,13 +871,13 @@ static void launch_step_g(const StepArgs& a, long long step, int n_kicks, int do
   // steady-state launches take the instantiation with the launch-uniform switches folded
   const bool hot = n_kicks == 2 && do_aoa && a.wrap && a.box.periodic && a.ref4 && a.fli && a.perm && !a.noise;
   if (hot && prune) {
-    hipLaunchKernelGGL((k_lj_step<G, true, true>), dim3(blocks), dim3(256), 0, st, a, step, n_kicks, do_aoa, epoch);
+    hipLaunchKernelGGL((k_lj_step<G, true, true>), dim3(blocks), dim3(256), 0, st, a.ctrl, step, epoch, a, n_kicks, do_aoa);
   } else if (hot) {
-    hipLaunchKernelGGL((k_lj_step<G, true, false>), dim3(blocks), dim3(256), 0, st, a, step, n_kicks, do_aoa, epoch);
+    hipLaunchKernelGGL((k_lj_step<G, true, false>), dim3(blocks), dim3(256), 0, st, a.ctrl, step, epoch, a, n_kicks, do_aoa);
   } else if (prune) {
-    hipLaunchKernelGGL((k_lj_step<G, false, true>), dim3(blocks), dim3(256), 0, st, a, step, n_kicks, do_aoa, epoch);
+    hipLaunchKernelGGL((k_lj_step<G, false, true>), dim3(blocks), dim3(256), 0, st, a.ctrl, step, epoch, a, n_kicks, do_aoa);
   } else {
-    hipLaunchKernelGGL((k_lj_step<G, false, false>), dim3(blocks), dim3(256), 0, st, a, step, n_kicks, do_aoa, epoch);
+    hipLaunchKernelGGL((k_lj_step<G, false, false>), dim3(blocks), dim3(256), 0, st, a.ctrl, step, epoch, a, n_kicks, do_aoa);
   }
   if (dbg) (void)hipStreamSynchronize(st);
 }

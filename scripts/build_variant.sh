@@ -1,4 +1,4 @@
 #!/bin/bash
 # Build libchx.so with extra -D flags (experiments): scripts/build_variant.sh -DCHX_FL_UNROLL=8
 cd "$(dirname "$0")/../chiron_amd/csrc"
-hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -shared -std=c++17 "$@" *.hip -o ../libchx.so
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -mllvm -amdgpu-kernarg-preload-count=16 -fPIC -shared -std=c++17 "$@" *.hip -o ../libchx.so
