@@ -177,7 +177,7 @@ def roofline_entry(kind: str, n: int, p_nl: int, seconds: float, extra=None):
             pmc = json.load(fh).get(f"{wl}:{'k_lj_step' if kind == 'step' else 'k_lj_fl'}")
         if pmc:
             d["traffic"] = int(pmc["traffic_bytes"])
-            d["traffic_source"] = "profiles/r01e_pmc_hot_kernels.md (PMC passes at the lattice start state)"
+            d["traffic_source"] = "profiles/r01f_pmc_hot_kernels.md (PMC passes at the lattice start state)"
     except (OSError, ValueError):
         pass
     return d
