@@ -132,7 +132,7 @@ def time_kernels(fluid, pot, state, nbr, integ, reps: int):
 
     def one_chunk():
         # 32 launches per C call (exactly how the integrator enqueues them), so the Python call rate
-        # does not bound the measurement; the pruning pass every 32 steps is part of the per-step figure
+        # does not bound the measurement; the inner-list refresh every 32 steps is part of the per-step figure
         even, odd = (st.x_a, st.x_b) if (step[0] & 1) == 0 else (st.x_b, st.x_a)
         ops.langevin_fused_chunk(st.params, even, odd, step[0], per_call, 2, 1)
         step[0] += per_call
