@@ -272,8 +272,8 @@ extern "C" int chx_langevin_fused_chunk(const chx_langevin_t* p, float* x_even, 
   CHX_REQUIRE(p, "null params");
   CHX_REQUIRE(p->n >= 1, "n < 1");
   CHX_REQUIRE(x_even && x_odd && x_even != x_odd, "need two distinct position buffers");
-  CHX_REQUIRE(p->v && p->mass && p->ctrl && p->fl && p->deg, "null pointer");
-  CHX_REQUIRE(p->fl_chunks >= 1, "fl_chunks < 1");
+  CHX_REQUIRE(p->v && p->mass && p->ctrl, "null pointer");
+  CHX_REQUIRE(!p->fl || (p->deg && p->fl_chunks >= 1), "force list without degrees / chunks");
   CHX_REQUIRE(!p->box.periodic || (p->box.lx > 0 && p->box.ly > 0 && p->box.lz > 0),
               "box lengths must be > 0");
   CHX_REQUIRE(n_steps >= 0, "n_steps < 0");

@@ -656,6 +656,54 @@ __device__ __forceinline__ StepParticle load_step_particle(const StepArgs& a, lo
   return t;
 }
 
+// The integrate half of a fused step launch: one particle per thread, packed into the first PPB
+// threads of the block (tk), forces from the block's LDS table sF.
+//      These few wavefronts are the tail of the launch, so the common case (coordinates inside
+//      the box, |x - ref| < L) runs branch-free; a particle that falls outside it is redone
+//      through the general formulas, which give the same bits wherever both apply.
+// Returns true when this thread's particle has moved too far for the pruned inner list.
+template <bool HOT>
+__device__ __forceinline__ bool step_epilogue(const StepArgs& a, const StepParticle& tk, const float* sF, long long step,
+                                              int n_kicks, int do_aoa) {
+  bool stale = false;
+#ifdef CHX_EXP_NOEPI
+  if (tk.live) {  // positions pass through (wrapped input stays wrapped), every operand is consumed
+    reinterpret_cast<float4*>(a.x_next)[tk.pp] = make_float4(
+        tk.x.x, tk.x.y, tk.x.z, sF[3 * threadIdx.x] + tk.z[0] + tk.v[0] + tk.m + tk.bs + tk.ref.x + tk.refi.x);
+  }
+  if (false) {
+#else
+  if (tk.live) {
+#endif
+    const float L[3] = {a.box.lx, a.box.ly, a.box.lz};
+    const float hL[3] = {a.box.hx, a.box.hy, a.box.hz};
+    const float xo[3] = {tk.x.x, tk.x.y, tk.x.z};
+    const float rf[3] = {tk.ref.x, tk.ref.y, tk.ref.z};
+    const float ri[3] = {tk.refi.x, tk.refi.y, tk.refi.z};
+    float vn[3], xn[3], sq[3], sqi[3];
+    bool rare = false;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      rare |= integrate_component<true, HOT>(a, n_kicks, do_aoa, sF[3 * threadIdx.x + c], tk.m, tk.bs, tk.z[c], tk.v[c],
+                                        xo[c], rf[c], ri[c], L[c], hL[c], vn[c], xn[c], sq[c], sqi[c]);
+    if (__builtin_expect(rare, 0)) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        (void)integrate_component<false, HOT>(a, n_kicks, do_aoa, sF[3 * threadIdx.x + c], tk.m, tk.bs, tk.z[c], tk.v[c],
+                                         xo[c], rf[c], ri[c], L[c], hL[c], vn[c], xn[c], sq[c], sqi[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.v[3 * (size_t)tk.pp + c] = vn[c];
+    if (do_aoa) {
+      reinterpret_cast<float4*>(a.x_next)[tk.pp] = make_float4(xn[0], xn[1], xn[2], 0.f);
+      // skin check :241: (rx^2 + ry^2) + rz^2 in the reference's order
+      if ((HOT || a.ref4) && fadd(fadd(sq[0], sq[1]), sq[2]) > a.T_half_skin) atomicMin(&a.ctrl[3], (int)(step + 1));
+      if ((HOT || a.fli) && (sqi[0] + sqi[1]) + sqi[2] > a.T_half_inner) stale = true;
+    }
+  }
+  return stale;
+}
+
 // PRUNE: the launch that refreshes the dynamically pruned inner list (see below): it walks the FULL
 // force list and, next to the forces, copies the entries with |r| < cutoff + inner_skin into the
 // inner list, in order, and records the positions it saw -- the pruning costs no pass of its own.
@@ -744,46 +792,8 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
     sF[3 * pl + 2] = fz;
   }
   __syncthreads();
-  // ---- integrate: one particle per thread, packed into the first PPB threads of the block.
-  //      These few wavefronts are the tail of the launch, so the common case (coordinates inside
-  //      the box, |x - ref| < L) runs branch-free; a particle that falls outside it is redone
-  //      through the general formulas, which give the same bits wherever both apply. ----
-  bool stale = false;
-#ifdef CHX_EXP_NOEPI
-  if (tk.live) {  // positions pass through (wrapped input stays wrapped), every operand is consumed
-    reinterpret_cast<float4*>(a.x_next)[tk.pp] = make_float4(
-        tk.x.x, tk.x.y, tk.x.z, sF[3 * threadIdx.x] + tk.z[0] + tk.v[0] + tk.m + tk.bs + tk.ref.x + tk.refi.x);
-  }
-  if (false) {
-#else
-  if (tk.live) {
-#endif
-    const float L[3] = {a.box.lx, a.box.ly, a.box.lz};
-    const float hL[3] = {a.box.hx, a.box.hy, a.box.hz};
-    const float xo[3] = {tk.x.x, tk.x.y, tk.x.z};
-    const float rf[3] = {tk.ref.x, tk.ref.y, tk.ref.z};
-    const float ri[3] = {tk.refi.x, tk.refi.y, tk.refi.z};
-    float vn[3], xn[3], sq[3], sqi[3];
-    bool rare = false;
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-      rare |= integrate_component<true, HOT>(a, n_kicks, do_aoa, sF[3 * threadIdx.x + c], tk.m, tk.bs, tk.z[c], tk.v[c],
-                                        xo[c], rf[c], ri[c], L[c], hL[c], vn[c], xn[c], sq[c], sqi[c]);
-    if (__builtin_expect(rare, 0)) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        (void)integrate_component<false, HOT>(a, n_kicks, do_aoa, sF[3 * threadIdx.x + c], tk.m, tk.bs, tk.z[c], tk.v[c],
-                                         xo[c], rf[c], ri[c], L[c], hL[c], vn[c], xn[c], sq[c], sqi[c]);
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) a.v[3 * (size_t)tk.pp + c] = vn[c];
-    if (do_aoa) {
-      reinterpret_cast<float4*>(a.x_next)[tk.pp] = make_float4(xn[0], xn[1], xn[2], 0.f);
-      // skin check :241: (rx^2 + ry^2) + rz^2 in the reference's order
-      if ((HOT || a.ref4) && fadd(fadd(sq[0], sq[1]), sq[2]) > a.T_half_skin) atomicMin(&a.ctrl[3], (int)(step + 1));
-      if ((HOT || a.fli) && (sqi[0] + sqi[1]) + sqi[2] > a.T_half_inner) stale = true;
-    }
-  }
+  // ---- integrate: one particle per thread, packed into the first PPB threads of the block ----
+  const bool stale = step_epilogue<HOT>(a, tk, sF, step, n_kicks, do_aoa);
   // the inner list stays off until the next refresh (a new epoch) outdates the word
   if (do_aoa && (HOT || a.fli) && epoch >= 0 && (stale || (!inner && !PRUNE && threadIdx.x == 0)))
     a.ctrl[4 + (int)((step + 1) & 1)] = epoch;
@@ -805,6 +815,77 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
 // cutoff: the set of interacting pairs -- the reference's set -- is unchanged; only the summation
 // order differs.
 // ---------------------------------------------------------------------------
+// all-pairs kernels: 16 lanes per particle, j-tiles of 256 particles staged through LDS
+#define AP_SLICES 16
+#define AP_TILE 256
+
+// ---------------------------------------------------------------------------
+// Fused MD step without a neighbor list: the all-pairs force of k_lj_allpairs (nbr_list=None: no
+// PBC, chiron/potential.py:235-258; PairListNsqrd: PBC, chiron/neighbors.py:1106-1216) followed, in
+// the same launch, by the BAOAB update that consumes it (step_epilogue) -- one launch per step
+// instead of an integrate launch plus a force launch.  16 lanes per particle, 16 particles per
+// block, j-tiles of 256 particles staged through LDS straight from the float4 position buffer.
+// These paths have no skin check (PairListNsqrd.check only looks at N), so nothing ever halts.
+// ---------------------------------------------------------------------------
+// SLICES lanes share one particle: 64 (a whole wavefront) for the small systems this path is meant
+// for -- at N = 512 a lane then evaluates 8 pairs instead of 32, and the launch is a dependent-issue
+// chain, not a throughput problem -- and 16 beyond.
+template <int SLICES>
+__global__ __launch_bounds__(256) void k_ap_step(StepArgs a, long long step, int n_kicks, int do_aoa, int use_cutoff) {
+  constexpr int PPB = 256 / SLICES;
+  __shared__ float4 tile[AP_TILE];
+  __shared__ float sF[3 * PPB];
+  const int p0 = blockIdx.x * PPB;
+  const StepParticle tk = load_step_particle<false, false>(a, step, do_aoa, p0, threadIdx.x, PPB);
+  const int il = threadIdx.x / SLICES;
+  const int sl = threadIdx.x % SLICES;
+  const int i = p0 + il;
+  const bool valid = i < a.n;
+  const float4 xi = a.x_cur[valid ? i : 0];
+  float fx = 0.f, fy = 0.f, fz = 0.f;
+  for (int j0 = 0; j0 < a.n; j0 += AP_TILE) {
+    __syncthreads();
+    const int jj = j0 + threadIdx.x;
+    if (jj < a.n) tile[threadIdx.x] = a.x_cur[jj];
+    __syncthreads();
+    const int cnt = (a.n - j0) < AP_TILE ? (a.n - j0) : AP_TILE;
+    if (valid) {
+      for (int u = sl; u < cnt; u += SLICES) {
+        const int j = j0 + u;
+        if (j == i) continue;
+        const float4 xj = tile[u];
+        const bool hi = j > i;
+        float rx, ry, rz;
+        bool bad;  // branch-free minimum image, general formula for |d| >= L (same bits where both apply)
+        displacement_oriented_fast(a.box, hi, xi.x, xi.y, xi.z, xj.x, xj.y, xj.z, rx, ry, rz, bad);
+        if (__builtin_expect(bad, 0)) displacement_oriented(a.box, hi, xi.x, xi.y, xi.z, xj.x, xj.y, xj.z, rx, ry, rz);
+        const float r2 = norm2(rx, ry, rz);
+        if (!use_cutoff || r2 <= a.lj.T) {
+          float e, fs;
+          lj_pair(r2, a.lj.sig2, a.lj.eps4, a.lj.eps24, e, fs);
+          if (!hi) fs = -fs;
+          fx += fs * rx;
+          fy += fs * ry;
+          fz += fs * rz;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = SLICES / 2; o > 0; o >>= 1) {
+    fx += __shfl_xor(fx, o, CHX_WAVE);
+    fy += __shfl_xor(fy, o, CHX_WAVE);
+    fz += __shfl_xor(fz, o, CHX_WAVE);
+  }
+  if (sl == 0) {
+    sF[3 * il] = fx;
+    sF[3 * il + 1] = fy;
+    sF[3 * il + 2] = fz;
+  }
+  __syncthreads();
+  (void)step_epilogue<false>(a, tk, sF, step, n_kicks, do_aoa);
+}
+
 template <int G>
 static int launch_lj_fl_g(const float4* x4, const uint32_t* fl, const int32_t* deg, int n, int chunks,
                           Box3 box, LJParams lj, float* f3, float* energy, double* ws, int32_t* ctrl,
@@ -923,6 +1004,19 @@ int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, in
     a.x_cur = reinterpret_cast<const float4*>((i & 1) ? x_odd : x_even);
     a.x_next = (i & 1) ? x_even : x_odd;
     const int nk = i == 0 ? kicks_first : 2;
+    if (p->fl == nullptr) {  // no neighbor list: all-pairs force + BAOAB in one launch
+      const int use_cutoff = p->cutoff >= 0.0f ? 1 : 0;
+      if (!use_cutoff) a.lj = make_lj(p->sigma, p->epsilon, 1.0f);
+      a.ref4 = nullptr;  // no skin check on these paths
+      if (a.n <= 2048) {
+        hipLaunchKernelGGL((k_ap_step<64>), dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, st, a, (long long)(step0 + i), nk,
+                           do_aoa, use_cutoff);
+      } else {
+        hipLaunchKernelGGL((k_ap_step<16>), dim3((unsigned)((a.n + 15) / 16)), dim3(256), 0, st, a, (long long)(step0 + i), nk,
+                           do_aoa, use_cutoff);
+      }
+      continue;
+    }
     // refreshes of the inner list sit at fixed step indices (counted from prune_phase), not at chunk
     // boundaries: a trajectory does not depend on how its steps are batched into calls
     // (the force-only launch that ends a run is included: it may be the first one after a rebuild)
@@ -1058,8 +1152,6 @@ extern "C" int chx_lj_nl_energy_force(const float* xyz, const uint32_t* nl, cons
 // all-pairs kernel: 16 lanes per particle (4 particles per wavefront, 16 per
 // block), j-tiles of 256 particles staged through LDS
 // ---------------------------------------------------------------------------
-#define AP_SLICES 16
-#define AP_TILE 256
 
 template <bool WANT_F, bool WANT_E>
 __global__ __launch_bounds__(256) void k_lj_allpairs(const float* __restrict__ x, int stride, int n,

@@ -264,9 +264,7 @@ class _RunState:
         self.kicks_next = 1  # the first step of a run applies only its leading kick
         self.depth = 2  # chunks kept in flight ahead of the host
         self._load(x0, v0)
-        if self.mode == "pairs":
-            ops.langevin_resume(self.params)  # F(x0), :171
-        elif self.mode == "external":
+        if self.mode == "external":
             self._external_force()
 
     # -- layout ------------------------------------------------------------
@@ -307,13 +305,13 @@ class _RunState:
         self.x_a, self.v, self.mass, self.ref4 = ops.pack_langevin(
             x_user, v_user, self.mass_user, self.nbr_list.ref_positions if self.is_verlet else None, perm, self.is_verlet,
             out=prev)  # a rebuild writes into the buffers of the previous load (the state was copied out first)
-        if self.mode == "fused":
+        if self.mode in ("fused", "pairs"):  # one launch per step, positions ping-pong between two buffers
             if getattr(self, "x_b", None) is None:
                 self.x_b = torch.empty_like(self.x_a)  # fully written before it is read
         else:
             self.x_b = None
         self.parity = 0
-        if self.mode != "fused":
+        if self.mode == "external":
             self.f = torch.zeros((n, 3), dtype=torch.float32, device=self.dev)
         else:
             self.f = None
@@ -509,11 +507,14 @@ class _RunState:
         if self.mode == "fused":
             return self._advance_fused(done, stop)
         if self.mode == "pairs":
-            # all-pairs kernels: no skin check exists on this path (PairListNsqrd.check only looks at N)
+            # all-pairs force + BAOAB in one launch per step (k_ap_step); no skin check exists on this
+            # path (PairListNsqrd.check only looks at N), so nothing halts and nothing is read back
             chunk = self.integ.chunk_size
             while done < stop:
                 c = min(chunk, stop - done)
-                ops.langevin_chunk(self.params, done, c, self.kicks_next)
+                even, odd = (self.x_a, self.x_b) if self.parity == 0 else (self.x_b, self.x_a)
+                ops.langevin_fused_chunk(self.params, even, odd, done, c, self.kicks_next, 1)
+                self.parity ^= c & 1
                 self.kicks_next = 2
                 done += c
             return done
@@ -535,5 +536,8 @@ class _RunState:
             rec.event.synchronize()
             self._seen_full, self._seen_prune = int(rec.host[6]), int(rec.host[7])
             self._bank_inner_stats()
+        elif self.mode == "pairs":
+            even, odd = (self.x_a, self.x_b) if self.parity == 0 else (self.x_b, self.x_a)
+            ops.langevin_fused_chunk(self.params, even, odd, n_steps, 1, 1, 0)  # force + one kick, positions stay
         else:
             ops.kick(self.v, self.f, self.mass, self.half_dt)

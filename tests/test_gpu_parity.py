@@ -770,16 +770,22 @@ def test_langevin_device_rng_matches_oracle_stream(ca, O):
     assert np.abs(out.velocities.cpu().numpy() - vo).max() < 1e-4
 
 
-def test_langevin_nolist_and_pairlist(ca, O):
+@pytest.mark.parametrize("n", [200, 2100], ids=["wave-per-particle", "16-lanes-per-particle"])
+def test_langevin_nolist_and_pairlist(ca, O, n):
+    """The paths without a Verlet list run ONE launch per step too (k_ap_step: all-pairs force + BAOAB;
+    a wavefront per particle up to N = 2048, 16 lanes per particle beyond): nbr_list=None is the
+    reference's no-PBC branch (chiron/potential.py:235-258), PairListNsqrd the PBC all-pairs list with
+    a wrap every step and no rebuilds (chiron/neighbors.py:1272-1289).  Both follow the oracle with
+    injected noise; the PBC trajectory is the neighbor-list trajectory (same pairs interact)."""
     u = ca.unit
-    n, steps = 200, 6
+    steps = 6
     x, box = O.lj_lattice(n, 0.5, SIGMA, seed=51)
     pot = lj_pot(ca, n)
     thermo = ca.states.ThermodynamicState(pot, temperature=300 * u.kelvin)
     rng = np.random.default_rng(1)
     noise = rng.normal(size=(steps, n, 3)).astype(f32)
     mass = np.full(n, 39.948, f32)
-    integ = ca.integrators.LangevinIntegrator(timestep=1.0 * u.femtoseconds)
+    integ = ca.integrators.LangevinIntegrator(timestep=1.0 * u.femtoseconds, chunk_size=4)
     state = make_state(ca, x, box)
     state.velocities = np.zeros((n, 3), f32)
     out, _ = integ.run(state, thermo, number_of_steps=steps, nbr_list=None, noise=noise)
@@ -790,9 +796,17 @@ def test_langevin_nolist_and_pairlist(ca, O):
     # PairListNsqrd: PBC all-pairs + wrap each step
     pl = ca.neighbors.PairListNsqrd(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer)
     state = make_state(ca, x, box)
-    out, pl = integ.run(state, thermo, number_of_steps=steps, nbr_list=pl)
+    state.velocities = np.zeros((n, 3), f32)
+    out, pl = integ.run(state, thermo, number_of_steps=steps, nbr_list=pl, noise=noise)
     xw = out.positions.cpu().numpy()
     assert np.isfinite(xw).all() and (xw >= 0).all() and (xw <= box[0, 0]).all()
+    xo, vo, _, _ = O.langevin_run(x, np.zeros((n, 3), f32), box, mass, SIGMA, EPS, CUTOFF, SKIN, 400, 0.001, 1.0, 300.0,
+                                  steps, lambda s: noise[s], use_nbr_list=True)
+    assert np.abs(xw - xo).max() < 3e-6
+    assert np.abs(out.velocities.cpu().numpy() - vo).max() < 2e-4
+    # an odd number of steps leaves the state in the other position buffer; a second run continues from it
+    out2, pl = integ.run(out, thermo, number_of_steps=3, nbr_list=pl, noise=noise[:3])
+    assert np.isfinite(out2.positions.cpu().numpy()).all()
 
 
 def test_langevin_ideal_gas_external_force_path(ca):
