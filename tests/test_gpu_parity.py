@@ -900,6 +900,64 @@ def test_reference_workflow_langevin_lj_fluid(ca, O, tmp_path):
 
 
 # ---------------------------------------------------------------------------
+# multistate (chiron/multistate.py) on the real kernels
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("swap", [None, "neighbors"], ids=["reference-no-swap", "neighbor-swaps"])
+def test_multistate_sampler_on_lj_replicas(ca, O, swap):
+    """chiron/tests/test_multistate.py:211-251 in shape (MultiStateSampler over K thermodynamic states,
+    one MCMCSampler with a LangevinDynamicsMove per state, energy matrix every iteration), with LJ
+    replicas on the HIP kernels instead of harmonic oscillators: after every iteration
+    u_kn[k, r] = beta_k U(x_r) for the replicas' CURRENT positions (fp64 brute-force oracle), each
+    replica keeps its own neighbor list, and with swaps off the state assignment never changes
+    (the reference's placeholder, multistate.py:447-460)."""
+    from chiron_amd.mcmc import LangevinDynamicsMove, MCMCSampler, MoveSchedule
+    from chiron_amd.multistate import MultiStateSampler
+
+    u = ca.unit
+    K, n = 3, 1500
+    x, box = O.lj_lattice(n, 0.3, SIGMA, seed=7)
+    pot = lj_pot(ca, n)
+    temps = [300.0, 330.0, 360.0]
+    thermo = [ca.states.ThermodynamicState(pot, temperature=t * u.kelvin) for t in temps]
+    states, lists = [], []
+    for k in range(K):
+        from chiron_amd.rng import PRNGKey
+
+        st = make_state(ca, x, box)
+        st.current_PRNG_key = PRNGKey(1234, k)
+        states.append(st)
+        lists.append(ca.neighbors.NeighborListNsqrd(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+                                                    skin=SKIN * u.nanometer, n_max_neighbors=180))
+    move = LangevinDynamicsMove(timestep=2.0 * u.femtoseconds, number_of_steps=60)
+    ms = MultiStateSampler(MCMCSampler(MoveSchedule([("LangevinDynamicsMove", move)])), swap=swap)
+    ms.create(thermo, states, lists)
+    ms.run(n_iterations=3, n_mcmc_iterations=1)
+    assert ms.iteration == 3
+    u_kn = ms._reporter.get_property("u_kn")
+    assert u_kn.shape == (4, K, K)
+    finals = ms.sampler_states
+    assign = list(ms._replica_thermodynamic_states)
+    assert sorted(assign) == list(range(K))
+    if swap is None:
+        assert assign == list(range(K))
+    xs = [st.positions.cpu().numpy() for st in finals]
+    assert not np.array_equal(xs[0], xs[1])  # the replicas really are separate trajectories
+    for r in range(K):
+        e64, _, eabs, _ = O.lj_bruteforce_f64(xs[r], box, SIGMA, EPS, CUTOFF)
+        for k in range(K):
+            want = O.reduced_potential(e64, temps[k])
+            assert abs(u_kn[-1][k, r] - want) <= 2e-5 * O.reduced_potential(eabs, temps[k]) + 1e-6
+        # every replica's list is its own, built from its own positions
+        nb = ms._nbr_lists[r]
+        d = nb.ref_positions.cpu().numpy() - xs[r]
+        d -= np.diag(box) * np.round(d / np.diag(box))
+        assert nb.is_built and np.sqrt((d ** 2).sum(1)).max() < 0.26  # within skin / 2 (+ a step) of its own replica
+    # hotter states hold more kinetic energy (velocities follow the state a replica is assigned to)
+    ke = [float((st.velocities ** 2).mean()) for st in finals]
+    assert all(k_ > 0 for k_ in ke)
+
+
+# ---------------------------------------------------------------------------
 # Monte Carlo
 # ---------------------------------------------------------------------------
 def test_mc_displace_matches_oracle(ca, O):
