@@ -267,7 +267,9 @@ def main():
                 exchanges += 1
         return st, exchanges
 
-    # warm-up (untimed): builds the list, the force list, JIT-free anyway
+    # set-up (no steps): first list build, pinned read-back slots, device scratch
+    integ.run(state, rex.my_state, number_of_steps=0, nbr_list=nbr)
+    # warm-up (untimed)
     state, _ = propagate(state, args.warmup)
     rebuilds_before = nbr.n_builds
     prune_before = (getattr(integ, "prune_passes", 0), getattr(integ, "full_list_launches", 0))
