@@ -290,7 +290,10 @@ int chx_langevin_resume(const chx_langevin_t* p_h, chx_stream_t stream);
  * check fires while producing the positions of step s+1 the kernel stores s+1 there
  * and every launch with step >= ctrl[3] is a no-op, so the state is exactly the one
  * the reference rebuilds its list from.  do_aoa == 0: force + kicks only (the trailing
- * kick that ends a run).  Asynchronous. */
+ * kick that ends a run).  With p_h->fl == NULL the force is the all-pairs one of the
+ * branches without a Verlet list (box.periodic == 0: nbr_list=None, chiron/potential.py:235-258;
+ * periodic: PairListNsqrd, chiron/neighbors.py:1106-1216; cutoff < 0: none) in the same single
+ * launch per step; those branches have no skin check, ctrl is not touched.  Asynchronous. */
 int chx_langevin_fused_chunk(const chx_langevin_t* p_h, float* x_even, float* x_odd, int64_t step0,
                              int32_t n_steps, int32_t kicks_first, int32_t do_aoa,
                              chx_stream_t stream);
