@@ -384,3 +384,46 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
     failed(lib.chx_mc_displace_chunk(ctypes.byref(p), 0, 1, None), "n <= 0")
     # the threshold helper and the grid helper are pure host functions
     assert lib.chx_version() == 1
+
+
+def test_sampler_state_copy_with_and_box_token():
+    """``_copy_with`` (what LangevinIntegrator.run returns) equals deepcopy + assignment
+    (chiron/integrators.py:210-214): fresh arrays, a cloned box, the caller's state untouched; the box
+    token -- how the integrator recognises "same box as at the list's last build" without reading the
+    device -- is shared by copies and renewed whenever a box is assigned."""
+    import copy
+
+    x = np.arange(12, dtype=np.float32).reshape(4, 3)
+    box = np.diag([2.0, 3.0, 4.0]).astype(np.float32)
+    Quantity = unit.Quantity
+    st = SamplerState(Quantity(x, unit.nanometer), PRNGKey(3, 4), velocities=Quantity(x * 0.5, unit.nanometer / unit.picosecond),
+                      box_vectors=Quantity(box, unit.nanometer))
+    x2, v2 = torch.full((4, 3), 7.0), torch.full((4, 3), -1.0)
+    new = st._copy_with(x2, v2)
+    ref = copy.deepcopy(st)
+    ref.positions, ref.velocities = x2, v2
+    assert torch.equal(new.positions, ref.positions) and torch.equal(new.velocities, ref.velocities)
+    assert torch.equal(new.box_vectors, st.box_vectors) and new.box_vectors is not st.box_vectors
+    assert new.current_PRNG_key == st.current_PRNG_key and new.number_of_particles == 4
+    assert torch.equal(st.positions, torch.as_tensor(x))  # the source keeps its arrays
+    new.box_vectors[0, 0] = 9.0
+    assert float(st.box_vectors[0, 0]) == 2.0
+    # the token follows the box VALUES
+    assert new._box_token is st._box_token and ref._box_token is st._box_token
+    old = st._box_token
+    st.box_vectors = Quantity(box * 2, unit.nanometer)
+    assert st._box_token is not old and new._box_token is old
+    other = SamplerState(Quantity(x, unit.nanometer), PRNGKey(3, 4), box_vectors=Quantity(box, unit.nanometer))
+    assert other._box_token is not old
+
+
+def test_as_tensor_passes_ready_tensors_through():
+    from chiron_amd._device import as_tensor
+
+    t = torch.arange(6, dtype=torch.float32).reshape(2, 3)
+    out = as_tensor(t)
+    assert out.dtype == torch.float32 and torch.equal(out, t)
+    assert as_tensor(t.double()).dtype == torch.float32
+    nc = torch.arange(12, dtype=torch.float32).reshape(3, 4).t()
+    assert as_tensor(nc).is_contiguous() and torch.equal(as_tensor(nc), nc)
+    assert as_tensor([[1, 2, 3]]).shape == (1, 3)
