@@ -29,7 +29,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import numpy as np
-import torch
 
 WORKLOADS = {
     # name: (N, reduced density)
@@ -39,6 +38,7 @@ WORKLOADS = {
     "c3_liquid": (32768, 0.8),
     "c4_liquid": (262144, 0.8),
 }
+METRIC = "Langevin steps/sec + pair-force GB/s vs HBM roofline, LJ N=32k @1/8 GPU"
 SIGMA_NM, EPS_KCAL, SKIN_NM = 0.34, 0.238, 0.5
 HBM_PEAK_GBS = 8000.0
 
@@ -55,7 +55,52 @@ def parse():
     ap.add_argument("--kernel-reps", type=int, default=200)
     ap.add_argument("--cpu-steps", type=int, default=-1, help="steps of the CPU baseline (-1 = auto, 0 = skip)")
     ap.add_argument("--extra-c4", type=int, default=1, help="also report the N=262,144 pair-force roofline (1 GPU runs)")
+    ap.add_argument("--steady-steps", type=int, default=20000,
+                    help="timed steps of the steady-state figure reported next to `value` (0 = skip)")
+    ap.add_argument("--steady-warmup", type=int, default=2000)
+    ap.add_argument("--dry-run-backend", default=None, choices=["gloo"],
+                    help="launcher/plumbing rehearsal without a GPU: ranks form a gloo group, skip every kernel "
+                         "and run the replica-exchange collective on synthetic energies (the line says dry_run)")
     return ap.parse_args()
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` started by hand (no RANK in the environment): become a launcher.
+
+    Starts N fresh child interpreters of this script, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT as torchrun would set them), relays their output -- rank 0 prints the JSON
+    line -- and returns non-zero if any rank failed.  The launcher itself never initialises the GPU and
+    no process that has touched the GPU is ever re-exec'ed: children are ordinary subprocesses.
+    Replica loop being sharded: chiron/multistate.py:497-531.
+    """
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this host driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = dict(enumerate(procs))
+    while pending:
+        for r, p in list(pending.items()):
+            code = p.poll()
+            if code is None:
+                continue
+            del pending[r]
+            if code != 0:
+                print(f"bench.py launcher: rank {r} exited with code {code}", file=sys.stderr, flush=True)
+                rc = rc or (code if code > 0 else 1)
+                for q in pending.values():  # a dead rank leaves the others waiting in a collective
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
 
 
 def make_system(workload: str, temperature_K: float, chunk: int, build: str):
@@ -89,6 +134,8 @@ def time_kernels(fluid, pot, state, nbr, integ, reps: int):
     k_lj_fl (the pair-force kernel alone, what compute_force() launches).
     Returns (t_step_s, t_force_s, P_nl, force_list)."""
     import ctypes as C
+
+    import torch
 
     from chiron_amd import _lib, ops, unit
     from chiron_amd._device import as_tensor
@@ -212,11 +259,79 @@ def cpu_baseline(workload: str, steps: int):
     }
 
 
+def dry_run(args, rank: int, world: int) -> None:
+    """Launcher / process-group rehearsal on CPU (`--dry-run-backend gloo`): no kernel runs and nothing is
+    measured; the ranks form the group, take the barrier + max-over-ranks timing path of the real run and push
+    synthetic energies through the replica-exchange collective.  The printed line says `"dry_run": true`."""
+    import torch
+    import torch.distributed as dist
+
+    from chiron_amd import unit
+    from chiron_amd.multistate import ReplicaExchange
+    from chiron_amd.rng import PRNGKey
+    from chiron_amd.states import ThermodynamicState
+
+    torch.set_num_threads(1)
+    use_dist = world > 1 or "MASTER_ADDR" in os.environ
+    if use_dist:
+        dist.init_process_group(args.dry_run_backend, rank=rank, world_size=world)
+    from chiron_amd.potential import IdealGasPotential
+    from chiron_amd.topology import Topology
+
+    pot = IdealGasPotential(Topology.homogeneous(4))
+    ladder = [ThermodynamicState(pot, temperature=300.0 * (1.05 ** r) * unit.kelvin) for r in range(world)]
+    rex = ReplicaExchange(ladder, PRNGKey(2024, 7), rank=rank, world_size=world)
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    done = exchanges = 0
+    while done < args.steps:
+        seg = min(args.exchange_interval, args.steps - done)
+        done += seg
+        energy = torch.tensor([-1000.0 - 40.0 * rex.my_state_index + 7.0 * ((done // seg + rank) % 3)], dtype=torch.float64)
+        rex.exchange(energy)
+        exchanges += 1
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ranks = [rank]
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rank)
+        ranks = sorted(gathered)
+    if rank == 0:
+        print(json.dumps({
+            "metric": METRIC, "value": None, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "dry_run": True, "backend": args.dry_run_backend,
+            "config": {"workload": "dry run: no kernels, synthetic energies", "replicas": world,
+                       "group_world_size": dist.get_world_size() if use_dist else 1, "ranks": ranks,
+                       "replica_exchanges": exchanges,
+                       "state_of_replica": [int(v) for v in rex.state_of_replica]},
+        }), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "RANK" not in os.environ and args.gpus > 1:
+        # started by hand: become the launcher BEFORE anything can touch the GPU
+        raise SystemExit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.dry_run_backend:
+        return dry_run(args, rank, world)
+    import torch
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs the MI355X: no CUDA/ROCm device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -226,7 +341,7 @@ def main():
     torch.set_num_threads(1)
     import torch.distributed as dist
 
-    # under torchrun (RANK set) the process group is always created, also for one rank, so that the
+    # under a launcher (RANK set) the process group is always created, also for one rank, so that the
     # RCCL path (init, barrier, all-reduce, all-gather) can be exercised on a single-GPU box
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
     if use_dist:
@@ -267,22 +382,46 @@ def main():
                 exchanges += 1
         return st, exchanges
 
+    def timed(st, n_steps):
+        """barrier + sync, n_steps, barrier + sync; elapsed = max over ranks (per-rank times gathered too)."""
+        builds0 = nbr.n_builds
+        barrier()
+        t0 = time.perf_counter()
+        st, exchanges = propagate(st, n_steps)
+        barrier()
+        mine = time.perf_counter() - t0
+        per_rank = [mine]
+        if use_dist:
+            t = torch.tensor([mine], dtype=torch.float64, device="cuda")
+            out = torch.empty(world, dtype=torch.float64, device="cuda")
+            dist.all_gather_into_tensor(out, t)
+            per_rank = [float(v) for v in out.cpu()]
+        return st, max(per_rank), per_rank, exchanges, nbr.n_builds - builds0
+
     # set-up (no steps): first list build, pinned read-back slots, device scratch
     integ.run(state, rex.my_state, number_of_steps=0, nbr_list=nbr)
     # warm-up (untimed)
     state, _ = propagate(state, args.warmup)
-    rebuilds_before = nbr.n_builds
     prune_before = (getattr(integ, "prune_passes", 0), getattr(integ, "full_list_launches", 0))
-    barrier()
-    t0 = time.perf_counter()
-    state, exchanges = propagate(state, args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    state, elapsed, per_rank, exchanges, rebuilds = timed(state, args.steps)
+    prune_after = (getattr(integ, "prune_passes", 0), getattr(integ, "full_list_launches", 0))
     value = world * args.steps / elapsed
+
+    # Steady-state figure (SURVEY 8d: >= 1000 timed steps after >= 100 warm-up steps, rebuilds included): the
+    # driver's `--steps` may be too short to hold a representative share of list rebuilds and inner-list
+    # refreshes, so the same loop is timed once more over --steady-steps steps in this process.
+    steady = None
+    if args.steady_steps > 0:
+        if args.steps >= args.steady_steps and args.warmup >= min(1000, args.steady_warmup):
+            steady = {"steps": args.steps, "warmup": args.warmup, "steps_per_s": round(value, 2), "rebuilds": rebuilds,
+                      "seconds": round(elapsed, 6), "same_region_as_value": True}
+        else:
+            extra_warm = max(0, args.steady_warmup - args.warmup - args.steps)
+            state, _ = propagate(state, extra_warm)
+            state, s_el, _, s_ex, s_rb = timed(state, args.steady_steps)
+            steady = {"steps": args.steady_steps, "warmup": args.warmup + args.steps + extra_warm,
+                      "steps_per_s": round(world * args.steady_steps / s_el, 2), "rebuilds": s_rb,
+                      "seconds": round(s_el, 6), "replica_exchanges": s_ex, "same_region_as_value": False}
 
     if rank == 0:
         # hot kernels, timed live on the same device / list state
@@ -291,7 +430,7 @@ def main():
         roof = roofline_entry("step", n, p_nl, t_step, info)
         roof_force = roofline_entry("force", n, p_nl, t_force, info)
         out = {
-            "metric": "Langevin steps/sec + pair-force GB/s vs HBM roofline, LJ N=32k @1/8 GPU",
+            "metric": METRIC,
             "value": round(value, 2),
             "unit": "steps/s",
             "n_gpus": world,
@@ -312,14 +451,18 @@ def main():
                 "replicas": world,
                 "parallelism": f"{world} independent replica(s), one per GPU" + (
                     f", label exchange every {args.exchange_interval} steps via one RCCL all-gather" if world > 1 else ""),
+                "group_world_size": dist.get_world_size() if use_dist else 1,
+                "collective_backend": (dist.get_backend() if use_dist else None),
+                "per_rank_steps_per_s": [round(args.steps / t, 2) for t in per_rank],
                 "chunk_steps": args.chunk,
-                "list_rebuilds_in_timed_region": nbr.n_builds - rebuilds_before,
+                "list_rebuilds_in_timed_region": rebuilds,
                 # dynamically pruned inner list (chiron_amd/integrators.py): same interacting pairs
-                "pruning_passes_in_timed_region": getattr(integ, "prune_passes", 0) - prune_before[0],
-                "launches_on_full_list_in_timed_region": getattr(integ, "full_list_launches", 0) - prune_before[1],
+                "pruning_passes_in_timed_region": prune_after[0] - prune_before[0],
+                "launches_on_full_list_in_timed_region": prune_after[1] - prune_before[1],
                 "replica_exchanges": exchanges,
                 "swap_acceptance": (float(rex.n_accepted.sum() / max(1, rex.n_proposed.sum())) if world > 1 else None),
             },
+            "steady_state": steady,
             "roofline": roof,
             "roofline_pair_force": roof_force,
         }
@@ -343,9 +486,8 @@ def main():
             except Exception as exc:  # pragma: no cover - diagnostics only
                 out["roofline_262k"] = {"error": repr(exc)}
         if world == 1 and args.cpu_steps != 0:
-            steps = args.cpu_steps if args.cpu_steps > 0 else (30 if n <= 32768 else 3)
             try:
-                out["cpu_baseline"] = cpu_baseline(args.workload, steps)
+                out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_steps)
             except Exception as exc:  # pragma: no cover
                 out["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)

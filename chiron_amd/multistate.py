@@ -114,22 +114,24 @@ class ReplicaExchange:
         return u
 
     def gather_energies(self, energy: torch.Tensor) -> np.ndarray:
-        """The one collective of the path: all-gather of one fp32 per rank."""
+        """The one collective of the path: all-gather of one fp64 per rank (the reference's energy
+        matrix is fp64, chiron/multistate.py:290-292; the kernels' fp32 energies and host-side fp64
+        volumes both travel unrounded)."""
         import torch.distributed as dist
 
-        e = energy.detach().reshape(1).to(torch.float32)
+        e = energy.detach().reshape(1).to(torch.float64)
         if self.world_size == 1 and not (dist.is_available() and dist.is_initialized()):
-            return e.cpu().numpy().astype(np.float64)
-        out = torch.empty(self.world_size, dtype=torch.float32, device=e.device)
+            return e.cpu().numpy()
+        out = torch.empty(self.world_size, dtype=torch.float64, device=e.device)
         dist.all_gather_into_tensor(out, e)
-        return out.cpu().numpy().astype(np.float64)
+        return out.cpu().numpy()
 
     def exchange(self, energy: torch.Tensor, volume_nm3: Optional[float] = None):
         """Gather, decide, relabel.  Returns (new_state_index, velocity_scale) for this rank."""
         energies = self.gather_energies(energy)
         vols = None
         if volume_nm3 is not None:
-            vols = self.gather_energies(torch.as_tensor([volume_nm3], dtype=torch.float32, device=energy.device))
+            vols = self.gather_energies(torch.as_tensor([volume_nm3], dtype=torch.float64, device=energy.device))
         self.u_kn = self._reduced_row(energies, vols)
         old = self.my_state_index
         new, n_prop, n_acc = neighbor_swap_decisions(self.u_kn, self.state_of_replica, self.iteration, self.key)

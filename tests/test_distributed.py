@@ -155,3 +155,94 @@ def test_multistate_sampler_skeleton():
     ms2.create(thermo, samplers, [None] * K)
     ms2.run(3)
     assert sorted(ms2._replica_thermodynamic_states) == [0, 1, 2]
+
+
+# ---------------------------------------------------------------------------
+# bench.py as its own launcher (the driver's `python bench.py --gpus N` must start N ranks)
+# ---------------------------------------------------------------------------
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_bench(extra, env_extra=None, timeout=240):
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True,
+                         timeout=timeout)
+    lines = [json.loads(l) for l in res.stdout.splitlines() if l.startswith('{"metric"')]
+    return res, lines
+
+
+def test_bench_launcher_starts_n_ranks_gloo_dry_run():
+    """`python bench.py --gpus 2` with no RANK in the environment launches two ranks itself
+    (chiron/multistate.py:497-531 is the loop being sharded); the dry-run switch swaps RCCL for gloo
+    and skips every kernel, so the launcher, the group and the exchange collective run on CPU."""
+    res, lines = _run_bench(["--gpus", "2", "--steps", "3000", "--warmup", "0", "--dry-run-backend", "gloo"])
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert len(lines) == 1, res.stdout  # rank 0 only
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["dry_run"] is True and line["value"] is None
+    assert line["config"]["group_world_size"] == 2 and line["config"]["ranks"] == [0, 1]
+    assert line["config"]["replica_exchanges"] == 3  # 3000 steps, one attempt per 1000
+    assert sorted(line["config"]["state_of_replica"]) == [0, 1]
+
+
+def test_bench_rejects_world_size_mismatch_and_relays_failures():
+    # under a launcher that started a different number of ranks than --gpus says: refuse, do not mislabel
+    res, lines = _run_bench(["--gpus", "4", "--dry-run-backend", "gloo"],
+                            {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    assert res.returncode != 0 and not lines and "WORLD_SIZE=1" in res.stderr
+    # a rank that dies makes the launcher exit non-zero (no GPU here: the real path refuses to run on CPU)
+    if not torch.cuda.is_available():
+        res, lines = _run_bench(["--gpus", "2", "--steps", "10", "--warmup", "0"])
+        assert res.returncode != 0 and not lines
+        assert "launcher: rank" in res.stderr
+
+
+def _skewed_worker(rank: int, world: int, port: int, out_dir: str):
+    import time
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rex = ReplicaExchange(_ladder(world), PRNGKey(5, 6))
+        t0 = time.perf_counter()
+        for it in range(4):
+            if rank == (it % world):
+                time.sleep(0.25)  # one straggler per segment: the others must simply wait in the all-gather
+            e = torch.tensor([-500.0 + 37.0 * ((rank * 3 + it) % 5)], dtype=torch.float32)
+            rex.exchange(e)
+        np.save(os.path.join(out_dir, f"sk_states_{rank}.npy"), rex.state_of_replica)
+        np.save(os.path.join(out_dir, f"sk_ukn_{rank}.npy"), rex.u_kn)
+        np.save(os.path.join(out_dir, f"sk_t_{rank}.npy"), np.array([time.perf_counter() - t0]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replica_exchange_four_ranks_with_stragglers(tmp_path):
+    """World size 4 with a different rank sleeping in every segment: nobody deadlocks at the all-gather,
+    all ranks end with the same permutation and the same fp64 energy matrix."""
+    world = 4
+    mp.spawn(_skewed_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    states = [np.load(tmp_path / f"sk_states_{r}.npy") for r in range(world)]
+    ukn = [np.load(tmp_path / f"sk_ukn_{r}.npy") for r in range(world)]
+    for r in range(1, world):
+        assert np.array_equal(states[0], states[r]) and np.array_equal(ukn[0], ukn[r])
+    assert sorted(states[0]) == list(range(world))
+    assert ukn[0].dtype == np.float64
+    # every rank waited for the four stragglers (4 x 0.25 s), none ran ahead
+    for r in range(world):
+        assert float(np.load(tmp_path / f"sk_t_{r}.npy")[0]) >= 0.95
+
+
+def test_gathered_energies_are_fp64_exact():
+    rex = ReplicaExchange(_ladder(1), PRNGKey(1, 2), rank=0, world_size=1)
+    v = 1234.56789012345
+    got = rex.gather_energies(torch.tensor([v], dtype=torch.float64))
+    assert got.dtype == np.float64 and got[0] == v
+    e32 = np.float32(-7720.9896)
+    assert rex.gather_energies(torch.tensor([e32], dtype=torch.float32))[0] == float(e32)
