@@ -487,6 +487,158 @@ def barostat_log_ratio(u_new: float, u_old: float, n_atoms: int, v_new: float, v
 
 
 # ---------------------------------------------------------------------------
+# Monte Carlo CHAINS: the trial loop itself (chiron/mcmc.py:243-306 update, :357-463 _step,
+# :531-548 _accept_or_reject, :670-787 displacement move, :902-1009 barostat move), restated
+# on this file's own Philox (key split / uniform twins of the product's counter-based key
+# chain, derived here from philox4x32 above, NOT imported from chiron_amd.rng).
+# ---------------------------------------------------------------------------
+STREAM_SPLIT = 0x5EED
+
+
+def key_split(key):
+    """(new_key, subkey): what SamplerState.new_PRNG_key does to the stored key (chiron/states.py:150-154),
+    on the Philox block (0, 0, 0, STREAM_SPLIT)."""
+    o = philox4x32(0, 0, 0, STREAM_SPLIT, int(key[0]), int(key[1]))
+    return (int(o[0]), int(o[1])), (int(o[2]), int(o[3]))
+
+
+def key_uniform(key, counter: int = 0) -> float:
+    """One (0,1) uniform of `key`: first word of the Philox block (0, counter, 0, STREAM_UNIFORM)."""
+    o = philox4x32(0, counter, 0, STREAM_UNIFORM, int(key[0]), int(key[1]))
+    return float(u32_to_uniform(np.asarray(o[0], dtype=np.uint32)))
+
+
+class McList:
+    """The neighbor-list state a chain carries: list arrays + the positions/box it was built from."""
+
+    def __init__(self, x, box, cutoff, skin, n_max):
+        self.cutoff, self.skin = cutoff, skin
+        self.box = np.asarray(box, dtype=f32).copy()
+        self.mask, self.nl, self.n_nbr, self.n_max = neighborlist_build(x, self.box, cutoff, skin, n_max)
+        self.ref = np.asarray(x, dtype=f32).copy()
+        self.builds = 1
+
+    def rebuilt(self, x, box):
+        new = McList(x, box, self.cutoff, self.skin, self.n_max)
+        new.builds = self.builds + 1
+        return new
+
+    def energy(self, x, sigma, epsilon):
+        return float(lj_energy_nbrlist_f32(x, self.nl, self.mask, self.box, sigma, epsilon, self.cutoff))
+
+
+def mc_displacement_update(x, box, lst: McList, key, sigma, epsilon, temperature_K, sigma_d, n_moves, *,
+                           pressure_atm=None, subset_mask=None, autotune=False, autotune_interval=100,
+                           counters=(0, 0, 0), normals_fn=None, energy_fn=None):
+    """One MonteCarloDisplacementMove.update(): n_moves Metropolis trials (chiron/mcmc.py:243-306).
+
+    counters = (n_accepted, n_proposed, number_of_attempts_made) carried between calls (:465-486, :281).
+    normals_fn(subkey) -> (N,3) fp32 replaces this file's Box-Muller draw (tests inject the device's
+    normals to make the proposals bit-identical); energy_fn(x, lst) replaces the fp32 list energy.
+    Returns (x, lst, key, sigma_d, counters, log) with per-trial log entries
+    dict(accepted, energy, energy_proposed, log_ratio, uniform, rebuilt_list).
+    """
+    x = np.asarray(x, dtype=f32).copy()
+    n = x.shape[0]
+    n_acc, n_prop, attempts = counters
+    volume = float(np.prod(_box_lengths(box).astype(np.float64))) if pressure_atm is not None else None
+    efn = energy_fn or (lambda xx, ll: ll.energy(xx, sigma, epsilon))
+    u_cur = None  # :271 -- recomputed at the first trial of every update()
+    e_cur = None
+    log = []
+    for _ in range(n_moves):
+        if u_cur is None:  # :396-406
+            e_cur = efn(x, lst)
+            u_cur = reduced_potential(e_cur, temperature_K, pressure_atm, volume)
+        # ---- _propose (:680-787)
+        key, sub = key_split(key)  # :724 new_PRNG_key
+        z = normals_fn(sub) if normals_fn is not None else philox_normals3(n, 0, STREAM_MC_DISPLACE, sub)
+        xp = mc_displace(x, sigma_d, z, box, subset_mask)  # :733-755 (wrap because a list is present)
+        # :759 (a PairListNsqrd -- lst None here -- only reports a changed particle count, neighbors.py:1272-1289)
+        rebuilt = lst is not None and bool(neighborlist_check(xp, lst.ref, lst.box, lst.skin))
+        lst_p = lst.rebuilt(xp, box) if rebuilt else lst  # :761-770
+        e_p = efn(xp, lst_p)
+        u_p = reduced_potential(e_p, temperature_K, pressure_atm, volume)  # :772-774
+        log_ratio = -u_p + u_cur  # :776
+        # ---- _step (:428-461)
+        key_p = key  # the proposed state is a deep copy taken AFTER the key advanced (:739)
+        uni = None
+        if math.isnan(u_p):
+            decision = False
+        else:
+            key_p, sub2 = key_split(key_p)  # proposed_sampler_state.new_PRNG_key (:434)
+            uni = key_uniform(sub2)
+            decision = metropolis_accept(log_ratio, uni)
+        n_acc += int(decision)  # :465-471
+        n_prop += 1
+        if decision:
+            x, lst, u_cur, e_cur = xp, lst_p, u_p, e_p
+        key = key_p  # accepted: the proposed state's key; rejected: copied over (:459-461)
+        attempts += 1  # :281
+        log.append(dict(accepted=bool(decision), energy=e_cur, energy_proposed=e_p, log_ratio=log_ratio, uniform=uni,
+                        rebuilt_list=rebuilt, sigma_d=sigma_d))
+        if autotune and attempts % autotune_interval == 0 and attempts > 0:  # :296-302, :670-678
+            ratio = n_acc / n_prop
+            if ratio > 0.6:
+                sigma_d = sigma_d * 1.1
+            elif ratio < 0.4:
+                sigma_d = sigma_d / 1.1
+    return x, lst, key, sigma_d, (n_acc, n_prop, attempts), log
+
+
+def mc_barostat_update(x, box, key, temperature_K, pressure_atm, volume_max_scale, n_moves, energy_fn, *,
+                       autotune=False, autotune_interval=100, counters=(0, 0, 0)):
+    """One MonteCarloBarostatMove.update() (chiron/mcmc.py:243-306 with _propose :913-1009).
+
+    energy_fn(x, box) -> potential energy in kJ/mol at the (scaled) configuration: the reference rebuilds a
+    deep-copied list for every proposal (:985-990), so the energy is always over a fresh list.
+    Returns (x, box, key, volume_max_scale, counters, log); log entries dict(accepted, volume, log_ratio, uniform).
+    """
+    x = np.asarray(x, dtype=f32).copy()
+    box = np.asarray(box, dtype=f32).copy()
+    n = x.shape[0]
+    n_acc, n_prop, attempts = counters
+    u_cur = None
+    log = []
+    for _ in range(n_moves):
+        v0 = float(box[0, 0]) * float(box[1, 1]) * float(box[2, 2])  # :950-954 on the fp32 box entries
+        if u_cur is None:
+            u_cur = reduced_potential(energy_fn(x, box), temperature_K, pressure_atm, v0)
+        key, sub = key_split(key)  # :943
+        dv = (2.0 * key_uniform(sub) - 1.0) * (volume_max_scale * v0)  # :957-961
+        v1 = v0 + dv  # :963
+        s = (v1 / v0) ** (1.0 / 3.0)  # :966
+        xp = (x * f32(s)).astype(f32)  # :971-973
+        boxp = (box * f32(s)).astype(f32)  # :975-977
+        vp = float(boxp[0, 0]) * float(boxp[1, 1]) * float(boxp[2, 2])  # states.py:315-319 reads the scaled box
+        u_p = reduced_potential(energy_fn(xp, boxp), temperature_K, pressure_atm, vp)
+        log_ratio = -(u_p - u_cur) + n * math.log(v1 / v0)  # :998-1000
+        key_p = key
+        uni = None
+        if math.isnan(u_p):
+            decision = False
+        else:
+            key_p, sub2 = key_split(key_p)
+            uni = key_uniform(sub2)
+            decision = metropolis_accept(log_ratio, uni)
+        n_acc += int(decision)
+        n_prop += 1
+        if decision:
+            x, box, u_cur = xp, boxp, u_p
+        key = key_p
+        attempts += 1
+        log.append(dict(accepted=bool(decision), log_ratio=log_ratio, uniform=uni, max_volume_scale=volume_max_scale,
+                        volume=float(box[0, 0]) * float(box[1, 1]) * float(box[2, 2])))
+        if autotune and attempts % autotune_interval == 0 and attempts > 0:  # :902-911
+            ratio = n_acc / n_prop
+            if ratio < 0.25:
+                volume_max_scale = volume_max_scale / 1.1
+            elif ratio > 0.75:
+                volume_max_scale = min(volume_max_scale * 1.1, 0.3)
+    return x, box, key, volume_max_scale, (n_acc, n_prop, attempts), log
+
+
+# ---------------------------------------------------------------------------
 # synthetic LJ boxes (SURVEY.md section 8d) -- shared by tests and bench
 # ---------------------------------------------------------------------------
 def lj_lattice(n: int, reduced_density: float, sigma: float, seed: int = 1234, jitter: float = 0.1):

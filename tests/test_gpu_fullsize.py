@@ -202,3 +202,66 @@ def test_c3_mc_device_loop_equals_host_loop(ca, O, monkeypatch):
     assert res[0][1] == res[1][1]
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][3], res[1][3])
     assert not np.array_equal(res[0][3], O.lj_lattice(N3, 0.1, SIGMA, seed=1234)[0])  # at least one rebuild happened
+
+
+def _fp64_forces_on(x, box, idx):
+    """fp64 brute-force LJ force (all N partners, minimum image, plain truncation) on the particles idx
+    (chiron/potential.py:193-213, :322-332)."""
+    L = np.diag(box).astype(np.float64)
+    x64 = x.astype(np.float64)
+    out = np.zeros((len(idx), 3))
+    for k, i in enumerate(idx):
+        r = x64[i] - x64
+        r -= L * np.round(r / L)
+        d2 = (r * r).sum(axis=1)
+        sel = (d2 < CUTOFF ** 2) & (d2 > 0)
+        s6 = (SIGMA ** 2 / d2[sel]) ** 3
+        out[k] = ((24 * EPS * (2 * s6 * s6 - s6) / d2[sel])[:, None] * r[sel]).sum(axis=0)
+    return out
+
+
+@pytest.mark.parametrize("n", [N3, N4], ids=["c3-32768", "c4-262144"])
+def test_step_kernel_step_63_matches_oracle_at_full_size(ca, O, n):
+    """The fused step kernel (k_lj_step, steady-state instantiation, pruned inner list, device Philox) at the
+    BASELINE sizes: a 63-step run gives frame 63 (x, v after the trailing kick); a 64-step run from the same
+    start is bit-identical up to there and adds step 63.  For 48 sampled particles that step is redone by the
+    oracle -- fp64 brute-force forces over ALL N partners on frame 63, O.baoa_half (chiron/integrators.py:181-188)
+    with the oracle's own Philox normals for (particle, step 63), wrap (:239), fp64 forces on the new frame,
+    trailing kick (:195) -- and compared with the kernel's frame 64: x to 5e-6 nm, v to 5e-4."""
+    u = ca.unit
+    steps = 64
+    x0, box = O.lj_lattice(n, 0.1, SIGMA, seed=1234)
+    pot = _pot(ca, n)
+    thermo = ca.states.ThermodynamicState(pot, temperature=300 * u.kelvin)
+    outs = []
+    for k in (steps - 1, steps):
+        ca.utils.PRNG.set_seed(1234)
+        state = ca.states.SamplerState(u.Quantity(x0, u.nanometer), ca.utils.PRNG.get_random_key(),
+                                       box_vectors=u.Quantity(box, u.nanometer))
+        key0 = tuple(state._current_PRNG_key)
+        integ = ca.integrators.LangevinIntegrator(timestep=1.0 * u.femtoseconds, collision_rate=1.0 / u.picoseconds,
+                                                  chunk_size=32)
+        out, nbr = integ.run(state, thermo, number_of_steps=k, nbr_list=_nbr(ca))
+        outs.append((out.positions.cpu().numpy(), out.velocities.cpu().numpy(), integ.n_rebuilds,
+                     getattr(integ, "prune_passes", None)))
+    (xa, va, rb_a, _), (xb, vb, rb_b, prunes) = outs
+    assert rb_a == rb_b == 0  # dt = 1 fs from the lattice: the 0.5 nm skin holds for 64 steps
+    if prunes is not None:
+        assert prunes >= 2  # the inner list was refreshed at steps 0 and 32: step 63 walked the pruned table
+    rng = np.random.default_rng(63)
+    idx = np.unique(np.concatenate([rng.integers(0, n, 46), [0, n - 1]]))
+    mass = np.full(len(idx), 39.948, f32)
+    kT, a, b = O.langevin_constants(300.0, 0.001, 1.0)
+    run_key = O.key_split(key0)[1]  # what SamplerState.new_PRNG_key hands to run() (chiron/integrators.py:124)
+    xi = O.philox_normals3(n, steps - 1, O.STREAM_LANGEVIN, run_key)[idx]
+    f_a = _fp64_forces_on(xa, box, idx)
+    x1, v1 = O.baoa_half(xa[idx], va[idx], f_a.astype(f32), mass, 0.001, a, b, kT, xi)
+    x1 = O.periodic_wrap(x1, box)
+    assert np.abs(xb[idx] - x1).max() < 5e-6, np.abs(xb[idx] - x1).max()
+    f_b = _fp64_forces_on(xb, box, idx)
+    v2 = O.kick(v1, f_b.astype(f32), mass, 0.001)
+    assert np.abs(vb[idx] - v2).max() < 5e-4 * max(1.0, np.abs(v2).max()), np.abs(vb[idx] - v2).max()
+    # the step really moved things: frame 64 is not frame 63
+    assert np.abs(xb[idx] - xa[idx]).max() > 1e-5
+    # and the system is a sane 300 K fluid after 64 steps
+    assert abs((39.948 * vb.astype(np.float64) ** 2).mean() / kT - 1.0) < 0.05

@@ -5,6 +5,7 @@ Bars (SURVEY.md 8c): neighbor indices / masks / counts / dist / r_ij bit-exact;
 energies |E32 - E64| <= 1e-5 * sum|e_ij|; forces max|F32 - F64| <= 1e-5 * max(1, max_i sum_j |f_ij|).
 """
 import copy
+import math
 
 import numpy as np
 import pytest
@@ -1063,6 +1064,109 @@ def test_mc_device_loop_equals_host_loop(ca, O, monkeypatch, kw):
         assert not np.array_equal(host["ref"], O.lj_lattice(500, 0.1, SIGMA, seed=71)[0])  # the list was rebuilt
 
 
+def _decisions_from_reports(rep):
+    """Per-trial accept decisions from the reported running acceptance probability (report_interval = 1)."""
+    p = np.asarray(rep.get_property("acceptance_probability"), dtype=np.float64)
+    acc = np.rint(p * np.arange(1, len(p) + 1)).astype(np.int64)
+    return np.diff(np.concatenate([[0], acc])).astype(bool)
+
+
+@pytest.mark.parametrize("host_loop", [False, True], ids=["device-loop", "host-loop"])
+@pytest.mark.parametrize(
+    "kw",
+    [
+        dict(skin=SKIN, sigma_d=0.03, moves=40, iterations=1),
+        dict(skin=0.05, sigma_d=0.01, moves=60, iterations=2, autotune=True),
+        dict(skin=0.05, sigma_d=0.02, moves=50, iterations=1, subset=[0, 3, 17, 499]),
+    ],
+    ids=["plain", "rebuilds-autotune", "subset"],
+)
+def test_mc_displacement_chain_matches_oracle_chain(ca, O, monkeypatch, kw, host_loop):
+    """MonteCarloDisplacementMove.update() -- BOTH the device-resident trial loop (csrc/chx_mc.hip) and the
+    reference-shaped host loop -- against the oracle's independent restatement of chiron/mcmc.py:243-306,
+    :357-463, :680-787 (oracle.mc_displacement_update: own Philox, own key splits, NumPy energies and lists):
+    accept/reject sequence, per-trial energies, rebuild trials, autotuned sigma, PRNG key chain and final
+    positions.  Pass 1 lets the oracle draw its own normals (libm Box-Muller: proposals agree to 2e-6);
+    pass 2 feeds it the device's normals so that every proposal, hence the whole chain, is bit-identical."""
+    from chiron_amd.rng import PRNGKey
+
+    u = ca.unit
+    n, T = 500, 300.0
+    monkeypatch.setenv("CHX_MC_HOST_LOOP", "1" if host_loop else "0")
+    x0, box = O.lj_lattice(n, 0.1, SIGMA, seed=71)
+    pot = lj_pot(ca, n)
+    state = make_state(ca, x0, box)
+    key0 = tuple(state._current_PRNG_key)
+    thermo = ca.states.ThermodynamicState(pot, temperature=T * u.kelvin)
+    nbr = ca.neighbors.NeighborListCell(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+                                        skin=kw["skin"] * u.nanometer, n_max_neighbors=180)
+    nbr.build_from_state(state)
+    rep = ca_reporter(ca)
+    move = ca.mcmc.MonteCarloDisplacementMove(displacement_sigma=kw["sigma_d"] * u.nanometer, number_of_moves=kw["moves"],
+                                              atom_subset=kw.get("subset"), reporter=rep, report_interval=1,
+                                              autotune=kw.get("autotune", False), autotune_interval=16)
+    assert move._device_loop_applies(state, thermo, nbr) == (not host_loop)
+    st, nb = state, nbr
+    for _ in range(kw["iterations"]):
+        st, thermo, nb = move.update(st, thermo, nb)
+    got_x = st.positions.cpu().numpy()
+    got_dec = _decisions_from_reports(rep)
+    got_e = np.asarray(rep.get_property("potential_energy"), dtype=np.float64)
+    got_sigma = np.asarray(rep.get_property("displacement_sigma"), dtype=np.float64)
+    total = kw["moves"] * kw["iterations"]
+    assert len(got_dec) == total
+
+    mask = None
+    if kw.get("subset"):
+        mask = np.zeros(n, f32)
+        mask[kw["subset"]] = 1.0
+    open_box = ca.ops.make_box(None, False)
+    zeros = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+
+    def device_normals(sub):  # x' = 0 + 1.0 * z, no wrap: the kernel's own Box-Muller output, exactly
+        return ca.ops.mc_displace(zeros, 1.0, open_box, PRNGKey(*sub), 0).cpu().numpy()
+
+    e64, _, eabs, _ = O.lj_bruteforce_f64(x0, box, SIGMA, EPS, CUTOFF)
+    for normals_fn in (None, device_normals):
+        x, key, sig = x0.copy(), key0, kw["sigma_d"]
+        lst = O.McList(x0, box, CUTOFF, kw["skin"], 180)
+        counters, log = (0, 0, 0), []
+        for _ in range(kw["iterations"]):
+            x, lst, key, sig, counters, lg = O.mc_displacement_update(
+                x, box, lst, key, SIGMA, EPS, T, sig, kw["moves"], subset_mask=mask, autotune=kw.get("autotune", False),
+                autotune_interval=16, counters=counters, normals_fn=normals_fn)
+            log += lg
+        want_dec = np.array([l["accepted"] for l in log])
+        # a decision is only comparable when it is not a numerical coin toss: |log u - log ratio| well above
+        # the energy tolerance (1e-5 sum|e| kJ/mol times beta)
+        beta = 1.0 / (O.R_KJ * T)
+        margins = np.array([abs(math.log(l["uniform"]) - l["log_ratio"]) if l["log_ratio"] < 0 else np.inf for l in log])
+        assert margins.min() > 10 * beta * 1e-5 * eabs, "pick another seed: a trial sits on the acceptance threshold"
+        assert np.array_equal(got_dec, want_dec), (np.nonzero(got_dec != want_dec)[0][:5], normals_fn)
+        assert 0 < want_dec.sum() < total or kw.get("subset")
+        assert move.statistics == dict(n_accepted=counters[0], n_proposed=counters[1]) and move.number_of_attemps_made == counters[2]
+        assert tuple(st._current_PRNG_key) == tuple(key), "PRNG key chain differs"
+        want_e = np.array([l["energy"] for l in log])
+        assert np.all(np.abs(got_e - want_e) <= 1e-5 * eabs), np.abs(got_e - want_e).max()
+        assert np.allclose(got_sigma, [l["sigma_d"] for l in log], rtol=1e-12)
+        assert np.isclose(move.displacement_sigma.value_in_unit_system(u.md_unit_system), sig, rtol=1e-12)
+        # list rebuilds happened in the same trials: same reference positions, same list
+        if normals_fn is None:
+            d = got_x - x
+            d -= np.rint(d / np.diag(box)) * np.diag(box)  # a coordinate may wrap on one side only
+            assert np.abs(d).max() <= 2e-6 * max(1, want_dec.sum()), np.abs(d).max()
+            assert np.abs(nb.ref_positions.cpu().numpy() - lst.ref).max() <= 2e-6 * max(1, want_dec.sum()) or np.array_equal(
+                nb.n_neighbors.cpu().numpy(), lst.n_nbr)
+        else:
+            assert np.array_equal(got_x, x), "final positions differ from the oracle chain on identical normals"
+            assert np.array_equal(nb.ref_positions.cpu().numpy(), lst.ref)
+            assert np.array_equal(nb.n_neighbors.cpu().numpy(), lst.n_nbr)
+            if nb.n_max_neighbors == lst.n_max:
+                assert np.array_equal(u32(nb.neighbor_list), lst.nl)
+    if kw["skin"] == 0.05:
+        assert lst.builds > 1, "this case is meant to exercise the rebuild branch"
+
+
 def ca_reporter(ca):
     from chiron_amd.reporters import MCReporter
 
@@ -1094,6 +1198,81 @@ def test_ideal_gas_barostat(ca):
     # positions scaled with the box
     assert np.isclose(float(state.box_vectors[0][0]) ** 3, vol[-1], rtol=1e-4)
 
+
+def test_c1_ideal_gas_mcmc_workload(ca, O):
+    """BASELINE config C1 at its own size: the schedule of Examples/Idealgas.py:16-104 (N = 216 ideal gas at
+    298 K / 1 atm; per iteration 100 displacement moves sigma = 0.1 nm, then 10 barostat moves
+    volume_max_scale = 0.2, both autotuned every 100 attempts; PairListNsqrd with cutoff 0) with the
+    example's own acceptance test (:141-150: <V> within 5 %, sigma_V within 10 % of the ideal-gas
+    expectation) after the example's 10 iterations and again after 100, and the whole chain -- every
+    barostat decision, every reported volume, the autotuned scale, the final box and PRNG key -- against
+    the oracle's restatement of the two moves (oracle.mc_displacement_update / mc_barostat_update)."""
+    u = ca.unit
+    n, T, P = 216, 298.0, 1.0
+    gas = ca.testsystems.IdealGas(nparticles=n, temperature=T * u.kelvin, pressure=P * u.atmosphere)
+    pot = ca.potential.IdealGasPotential(gas.topology)
+    thermo = ca.states.ThermodynamicState(potential=pot, temperature=T * u.kelvin, pressure=P * u.atmosphere)
+    ca.utils.PRNG.set_seed(1234)
+    state = ca.states.SamplerState(positions=gas.positions, current_PRNG_key=ca.utils.PRNG.get_random_key(),
+                                   box_vectors=gas.system.getDefaultPeriodicBoxVectors())
+    key = tuple(state._current_PRNG_key)
+    pairs = ca.neighbors.PairListNsqrd(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=0.0 * u.nanometer)
+    pairs.build_from_state(state)
+    rep = ca_reporter(ca)
+    baro = ca.mcmc.MonteCarloBarostatMove(volume_max_scale=0.2, number_of_moves=10, reporter=rep, autotune=True,
+                                          autotune_interval=100)
+    disp = ca.mcmc.MonteCarloDisplacementMove(displacement_sigma=0.1 * u.nanometer, number_of_moves=100, autotune=True,
+                                              autotune_interval=100)
+    sampler = ca.mcmc.MCMCSampler(ca.mcmc.MoveSchedule([("MonteCarloDisplacementMove", disp),
+                                                        ("MonteCarloBarostatMove", baro)]))
+    ideal_v = gas.get_volume_expectation(thermo).value_in_unit(u.nanometer ** 3)
+    ideal_sd = gas.get_volume_standard_deviation(thermo).value_in_unit(u.nanometer ** 3)
+    assert np.isclose(ideal_v, (n + 1) * O.KB * T / 101325.0 * 1e27, rtol=1e-9)
+
+    # the oracle chain from the same start
+    x = gas.positions.value_in_unit(u.nanometer).astype(f32)
+    box = gas.box_vectors.value_in_unit(u.nanometer).astype(f32)
+    zero = lambda *_: 0.0  # noqa: E731  (IdealGasPotential.compute_energy: 0 for any configuration)
+    sig, vs, cd, cb, vols, dec = 0.1, 0.2, (0, 0, 0), (0, 0, 0), [], []
+
+    st, th, nb = state, thermo, pairs
+    done = 0
+    for upto in (10, 100):
+        st, th, nb = sampler.run(st, th, n_iterations=upto - done, nbr_list=nb)
+        for _ in range(upto - done):
+            x, _, key, sig, cd, _ = O.mc_displacement_update(x, box, None, key, SIGMA, EPS, T, sig, 100, pressure_atm=P,
+                                                             autotune=True, autotune_interval=100, counters=cd, energy_fn=zero)
+            x, box, key, vs, cb, lg = O.mc_barostat_update(x, box, key, T, P, vs, 10, zero, autotune=True,
+                                                           autotune_interval=100, counters=cb)
+            vols += [l["volume"] for l in lg]
+            dec += [l["accepted"] for l in lg]
+        done = upto
+        volume = np.asarray(rep.get_property("volume"), dtype=np.float64)
+        assert volume.shape == (10 * upto,)
+        # Examples/Idealgas.py:141-150
+        assert abs(ideal_v - volume.mean()) / ideal_v < 0.05, (upto, volume.mean(), ideal_v)
+        assert abs(ideal_sd - volume.std()) / ideal_sd < 0.1, (upto, volume.std(), ideal_sd)
+        # chain parity with the oracle
+        assert np.array_equal(_decisions_from_reports(rep), np.array(dec))
+        assert np.allclose(volume, vols, rtol=1e-12)
+        assert baro.statistics == dict(n_accepted=cb[0], n_proposed=cb[1]) and baro.number_of_attemps_made == cb[2]
+        assert disp.statistics == dict(n_accepted=cd[0], n_proposed=cd[1]) and cd[0] == cd[1] == 100 * upto  # U = 0: all accepted
+        assert np.isclose(baro.volume_max_scale, vs, rtol=1e-12)
+        assert np.isclose(disp.displacement_sigma.value_in_unit_system(u.md_unit_system), sig, rtol=1e-12)
+        assert tuple(st._current_PRNG_key) == tuple(key)
+        assert np.array_equal(st.box_vectors.cpu().numpy(), box)
+        assert float(pot.compute_energy(st.positions, nb)) == 0.0
+        got = st.positions.cpu().numpy()
+        L = np.diag(box)
+        assert np.all((got >= 0) & (got <= L))
+        if upto == 10:
+            # the displacement proposals themselves: device Box-Muller vs the oracle's libm one agree to ~2e-6 of
+            # sigma_d per move, and coordinates near 20 nm carry an ulp of 2e-6.  (Not compared after 100
+            # iterations: every ideal-gas displacement is accepted, so the reference's autotune multiplies sigma_d
+            # by 1.1 per iteration -- 0.1 nm x 1.1^100 = 1.4 um -- and fp32 positions lose all absolute meaning.)
+            d = got - x
+            d -= np.rint(d / L) * L
+            assert np.abs(d).max() < 2e-4, np.abs(d).max()
 
 def _methane_system(ca, golden, methane_coords, nbr_kind):
     """Examples/LJ_MCMC.py:10-93: united-atom methane, 1100 beads, NPT state at 140 K / 13 atm."""
