@@ -101,6 +101,9 @@ _F = C.c_float
 SIGNATURES = {
     "chx_version": (C.c_int, []),
     "chx_last_error": (C.c_char_p, []),
+    "chx_source_hash": (C.c_char_p, []),
+    "chx_sizeof_langevin_t": (_I64, []),
+    "chx_sizeof_mc_t": (_I64, []),
     "chx_cutoff_threshold_h": (_F, [_F]),
     "chx_displacement": (C.c_int, [_P, _P, _I64, Box, _P, _P, _P]),
     "chx_wrap": (C.c_int, [_P, _P, _I64, Box, _P]),
@@ -197,6 +200,18 @@ def load() -> C.CDLL:
         fn.argtypes = argtypes
     if lib.chx_version() != 1:
         raise ChxError(f"libchx ABI version {lib.chx_version()} != 1")
+    # the structs are mirrored by hand above: a layout drift would corrupt kernel arguments silently
+    for name, mirror in (("chx_sizeof_langevin_t", LangevinParams), ("chx_sizeof_mc_t", McParams)):
+        if getattr(lib, name)() != C.sizeof(mirror):
+            raise ChxError(f"{name}() = {getattr(lib, name)()} but ctypes mirror {mirror.__name__} is {C.sizeof(mirror)} bytes")
+    # a library built from other sources than the ones beside it is refused (CHX_LIB: deliberate A/B runs)
+    if not os.environ.get("CHX_LIB") and os.environ.get("CHX_ALLOW_STALE_LIB", "0") != "1":
+        from . import build as _build
+
+        have, want = lib.chx_source_hash().decode(), _build.source_hash()
+        if have != want:
+            raise ChxError(f"{LIB_PATH} was built from other sources (hash {have[:16]}, tree {want[:16]}): "
+                           "run `python -c 'import __graft_entry__ as g; g.build()'`")
     _lib = lib
     return lib
 

@@ -1,8 +1,15 @@
-"""Build libchx.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libchx.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+The library carries a sha256 over its sources and flags (``chx_source_hash()``): ``build()`` recompiles
+exactly when that hash differs from the sources on disk -- file times are not consulted, so a checkout
+that resets mtimes or a stale ``.so`` shipped beside edited sources cannot pass for a fresh build.
+"""
 from __future__ import annotations
 
 import glob
+import hashlib
 import os
+import re
 import shutil
 import subprocess
 
@@ -17,26 +24,54 @@ OUT = os.path.join(HERE, "libchx.so")
 # which removes one dependent round trip from every launch (5.5 -> 5.25 us per step at N = 32768).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
          "-mllvm", "-amdgpu-kernarg-preload-count=16", "-fPIC", "-shared", "-std=c++17"]
+_MARK = b"CHX_SOURCE_HASH="
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def _hashed_files():
+    return sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(HERE, "..", "include", "*.h")))
+
+
+def source_hash(flags=None) -> str:
+    """sha256 over file names + contents of every source/header and over the compiler flags."""
+    h = hashlib.sha256()
+    for path in _hashed_files():
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    h.update(" ".join(FLAGS if flags is None else flags).encode())
+    return h.hexdigest()
+
+
+def binary_hash(path: str = OUT):
+    """The hash baked into a built library (read from the file, nothing is loaded); None if absent."""
+    try:
+        with open(path, "rb") as fh:
+            blob = fh.read()
+    except OSError:
+        return None
+    m = re.search(re.escape(_MARK) + rb"([0-9a-f]{64})", blob)
+    return m.group(1).decode() if m else None
+
+
 def needs_build() -> bool:
-    if not os.path.exists(OUT):
-        return True
-    t = os.path.getmtime(OUT)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    return binary_hash() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
+        if verbose:
+            print(f"libchx.so is current (source hash {source_hash()[:16]})")
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + FLAGS + sources() + ["-o", OUT]
+    tmp = OUT + ".tmp"
+    cmd = [hipcc] + FLAGS + [f'-DCHX_SOURCE_HASH="{source_hash()}"'] + sources() + ["-o", tmp]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+    os.replace(tmp, OUT)  # never truncate a library some process may have mapped
     return OUT

@@ -27,6 +27,15 @@ int chx_check_launch(const char* what) {
 extern "C" int chx_version(void) { return CHX_ABI_VERSION; }
 extern "C" const char* chx_last_error(void) { return g_err; }
 
+#ifndef CHX_SOURCE_HASH
+#define CHX_SOURCE_HASH "unhashed"
+#endif
+// the marker prefix lets build.py find the hash in the binary without loading it
+static const char g_source_hash[] = "CHX_SOURCE_HASH=" CHX_SOURCE_HASH;
+extern "C" const char* chx_source_hash(void) { return g_source_hash + 16; }
+extern "C" int64_t chx_sizeof_langevin_t(void) { return (int64_t)sizeof(chx_langevin_t); }
+extern "C" int64_t chx_sizeof_mc_t(void) { return (int64_t)sizeof(chx_mc_t); }
+
 // Largest fp32 t with sqrtf(t) < c.  Host sqrtf is correctly rounded and
 // monotone, as is the device __fsqrt_rn, so the equivalence is exact.
 extern "C" float chx_cutoff_threshold_h(float c) {

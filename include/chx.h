@@ -49,6 +49,14 @@ typedef struct {
 /* --------------------------------------------------------------------- misc */
 int chx_version(void);
 const char* chx_last_error(void);
+/* Build identity: sha256 (hex) over the library's sources (every .hip and .h under csrc/, include/chx.h) and compiler
+ * flags, baked in by chiron_amd/build.py.  The loader refuses a library whose hash differs from the sources
+ * beside it, and build() recompiles exactly when it does (a stale binary cannot pass for a fresh one). */
+const char* chx_source_hash(void);
+/* sizeof(chx_langevin_t) / sizeof(chx_mc_t) as compiled: bindings that mirror the structs by hand
+ * (ctypes, cgo, JNI) assert their own layout against these at load time. */
+int64_t chx_sizeof_langevin_t(void);
+int64_t chx_sizeof_mc_t(void);
 
 /* Largest fp32 t with sqrtf(t) < c (host helper, exact).  `d < c` on the
  * reference's d = sqrt(r2) is then equivalent to `r2 <= T` (neighbors.py:600-602,

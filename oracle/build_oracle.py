@@ -14,7 +14,7 @@ OUT = os.path.join(OUT_DIR, "liboracle.so")
 def build(force: bool = False) -> str:
     os.makedirs(OUT_DIR, exist_ok=True)
     if force or not os.path.exists(OUT) or os.path.getmtime(SRC) > os.path.getmtime(OUT):
-        subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", SRC, "-o", OUT, "-lm"],
+        subprocess.run(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", SRC, "-o", OUT, "-lm"],
                        check=True)
     return OUT
 

@@ -22,6 +22,7 @@ def lib():
         _lib.orc_nl_build_fixed.restype = C.c_int
         _lib.orc_lj_nl.restype = C.c_float
         _lib.orc_langevin_run.restype = C.c_int
+        _lib.orc_langevin_run_cell_omp.restype = C.c_int
     return _lib
 
 
@@ -69,3 +70,44 @@ def langevin_run(x, v, box, mass, sigma, eps, cutoff, skin, m0, dt, a, b, kT, n_
     if rc != 0:
         raise RuntimeError("orc_langevin_run failed")
     return x, v, dict(rebuilds=int(stats[0]), n_max=int(stats[1]), build_seconds=float(stats[2]))
+
+
+def effective_cores() -> int:
+    """CPU cores this process may really use: the affinity mask, capped by the cgroup CPU quota
+    (the containers here run under a CFS quota far below the visible core count)."""
+    n = len(os.sched_getaffinity(0))
+    try:  # cgroup v2
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+        return n
+    except (OSError, ValueError):
+        pass
+    try:  # cgroup v1
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:
+            quota = int(fh.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+            period = int(fh.read())
+        if quota > 0 and period > 0:
+            n = max(1, min(n, int(quota / period + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def langevin_run_cell_omp(x, v, box, mass, sigma, eps, cutoff, skin, dt, a, b, kT, n_steps, noise=None, key=(0, 0),
+                          threads=0, cap0=96):
+    """Cell-list + OpenMP variant of langevin_run: same trajectory bits, O(N) builds, `threads` cores (0 = OpenMP default)."""
+    x = np.ascontiguousarray(x, dtype=np.float32).copy()
+    v = np.ascontiguousarray(v, dtype=np.float32).copy()
+    mass = np.ascontiguousarray(mass, dtype=np.float32)
+    stats = np.zeros(4, np.float64)
+    nz = None if noise is None else _p(np.ascontiguousarray(noise, dtype=np.float32), C.c_float)
+    rc = lib().orc_langevin_run_cell_omp(_p(x, C.c_float), _p(v, C.c_float), x.shape[0], _box(box), _p(mass, C.c_float),
+                                         C.c_float(sigma), C.c_float(eps), C.c_float(cutoff), C.c_float(skin), int(cap0),
+                                         C.c_float(dt), C.c_float(a), C.c_float(b), C.c_float(kT), int(n_steps), nz,
+                                         C.c_uint32(key[0]), C.c_uint32(key[1]), int(threads), _p(stats, C.c_double))
+    if rc != 0:
+        raise RuntimeError("orc_langevin_run_cell_omp failed")
+    return x, v, dict(rebuilds=int(stats[0]), row_capacity=int(stats[1]), build_seconds=float(stats[2]), threads=int(stats[3]))

@@ -178,3 +178,195 @@ int orc_langevin_run(float* x, float* v, int n, orc_box box, const float* mass, 
   free(nl); free(mask); free(nnbr); free(ref); free(F);
   return 0;
 }
+
+/* ==========================================================================
+ * Variant (ii) of SURVEY.md 8(d): the SAME physics as orc_langevin_run, but with an O(N) cell-list
+ * build and OpenMP over particles -- the CPU baseline a production code would run (the faithful
+ * port above is O(N^2) per build and single-threaded, like the reference's vmapped build).
+ *
+ * Bit-identical trajectories to orc_langevin_run by construction (tested in tests/test_oracle_golden.py):
+ *   - a FULL neighbor row per particle (all partners with d_ref < cutoff + skin, ascending id), so the
+ *     force on i is a gather -- no scatter, no atomics, any thread count gives the same bits;
+ *   - the faithful port adds the pair terms of particle i in ascending partner id as well (first the
+ *     reactions `force[j] -= fs r` from the rows of lower ids, then its own row), and every pair is
+ *     evaluated in the reference's orientation r = x_lo - x_hi (chiron/neighbors.py:773-779), so the
+ *     summation order and every rounding coincide;
+ *   - rebuild when any particle has moved >= skin/2 (chiron/neighbors.py:868), checked every step.
+ * stats[0] = rebuilds, [1] = row capacity, [2] = seconds in list builds, [3] = threads used.
+ * ========================================================================== */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct { int nc[3]; float inv[3]; int* start; int* items; } orc_grid;
+
+static int cell_of(const orc_grid* g, const float* p, const float* L) {
+  int c[3];
+  for (int d = 0; d < 3; ++d) {
+    float w = p[d] - floorf(p[d] / L[d]) * L[d];
+    int k = (int)floorf(w * g->inv[d]);
+    c[d] = k < 0 ? 0 : (k >= g->nc[d] ? g->nc[d] - 1 : k);
+  }
+  return (c[2] * g->nc[1] + c[1]) * g->nc[0] + c[0];
+}
+
+/* full rows, ascending partner id; returns max degree (> cap means: grow and call again) */
+static int build_full_rows(const float* x, int n, orc_box box, float cs, int cap, uint32_t* rows, int32_t* deg) {
+  const float L[3] = {box.lx, box.ly, box.lz};
+  orc_grid g;
+  int cells = 1, use_grid = box.periodic;
+  for (int d = 0; d < 3 && use_grid; ++d) {
+    g.nc[d] = (int)floor((double)L[d] / ((double)cs * 1.0001 + 1e-4));
+    if (g.nc[d] < 3) use_grid = 0;
+    else { if (g.nc[d] > 256) g.nc[d] = 256; g.inv[d] = (float)g.nc[d] / L[d]; cells *= g.nc[d]; }
+  }
+  int* cid = NULL;
+  g.start = NULL; g.items = NULL;
+  if (use_grid) {
+    cid = (int*)malloc(sizeof(int) * n);
+    g.start = (int*)calloc((size_t)cells + 1, sizeof(int));
+    g.items = (int*)malloc(sizeof(int) * n);
+    for (int i = 0; i < n; ++i) { cid[i] = cell_of(&g, x + 3 * i, L); g.start[cid[i] + 1]++; }
+    for (int c = 0; c < cells; ++c) g.start[c + 1] += g.start[c];
+    int* cur = (int*)malloc(sizeof(int) * cells);
+    memcpy(cur, g.start, sizeof(int) * cells);
+    for (int i = 0; i < n; ++i) g.items[cur[cid[i]]++] = i;   /* ascending id inside a cell */
+    free(cur);
+  }
+  int mx = 0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(max : mx)
+  for (int i = 0; i < n; ++i) {
+    uint32_t* row = rows + (size_t)i * cap;
+    int cnt = 0;
+    float r[3];
+    if (use_grid) {
+      const int c = cid[i];
+      const int cx = c % g.nc[0], cy = (c / g.nc[0]) % g.nc[1], cz = c / (g.nc[0] * g.nc[1]);
+      for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+        const int ox = (cx + dx + g.nc[0]) % g.nc[0], oy = (cy + dy + g.nc[1]) % g.nc[1], oz = (cz + dz + g.nc[2]) % g.nc[2];
+        const int o = (oz * g.nc[1] + oy) * g.nc[0] + ox;
+        for (int t = g.start[o]; t < g.start[o + 1]; ++t) {
+          const int j = g.items[t];
+          if (j == i) continue;
+          const int lo = i < j ? i : j, hi = i < j ? j : i;
+          if (disp(&box, x + 3 * lo, x + 3 * hi, r) < cs) { if (cnt < cap) row[cnt] = (uint32_t)j; ++cnt; }
+        }
+      }
+      /* the 27 cells are distinct (nc >= 3): no duplicates; order the partners */
+      const int m = cnt < cap ? cnt : cap;
+      for (int a = 1; a < m; ++a) { uint32_t v = row[a]; int b = a - 1; while (b >= 0 && row[b] > v) { row[b + 1] = row[b]; --b; } row[b + 1] = v; }
+    } else {
+      for (int j = 0; j < n; ++j) {
+        if (j == i) continue;
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        if (disp(&box, x + 3 * lo, x + 3 * hi, r) < cs) { if (cnt < cap) row[cnt] = (uint32_t)j; ++cnt; }
+      }
+    }
+    deg[i] = cnt;
+    if (cnt > mx) mx = cnt;
+  }
+  free(cid); free(g.start); free(g.items);
+  return mx;
+}
+
+static double forces_full_rows(const float* x, const uint32_t* rows, const int32_t* deg, int n, int cap, orc_box box,
+                               float sigma, float eps, float rc, float* force) {
+  const float eps4 = (float)(4.0 * (double)eps);
+  double e_total = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : e_total)
+  for (int i = 0; i < n; ++i) {
+    float f[3] = {0.f, 0.f, 0.f};
+    float e_row = 0.0f;
+    const uint32_t* row = rows + (size_t)i * cap;
+    for (int k = 0; k < deg[i]; ++k) {
+      const int j = (int)row[k];
+      const int i_low = i < j;
+      float r[3];
+      const float d = i_low ? disp(&box, x + 3 * i, x + 3 * j, r) : disp(&box, x + 3 * j, x + 3 * i, r);
+      if (!(d < rc)) continue;
+      float s = sigma / d, s2 = s * s, s4 = s2 * s2, s8 = s4 * s4;
+      float s6 = s2 * s4, s12 = s4 * s8;
+      if (i_low) e_row += eps4 * (s12 - s6);   /* each pair's energy once, in its half-list row */
+      const float fs = 24.0f * (eps / (d * d)) * (2.0f * s12 - s6);
+      for (int c = 0; c < 3; ++c) { if (i_low) f[c] += fs * r[c]; else f[c] -= fs * r[c]; }
+    }
+    force[3 * i] = f[0]; force[3 * i + 1] = f[1]; force[3 * i + 2] = f[2];
+    e_total += (double)e_row;
+  }
+  return e_total;
+}
+
+static int rebuild_full(const float* x, int n, orc_box box, float cs, int* cap, uint32_t** rows, int32_t* deg) {
+  for (;;) {
+    *rows = (uint32_t*)realloc(*rows, sizeof(uint32_t) * (size_t)n * (size_t)(*cap));
+    if (!*rows) return -1;
+    const int mx = build_full_rows(x, n, box, cs, *cap, *rows, deg);
+    if (mx <= *cap) return 0;
+    *cap = mx + 16;
+  }
+}
+
+int orc_langevin_run_cell_omp(float* x, float* v, int n, orc_box box, const float* mass, float sigma, float eps,
+                              float rc, float skin, int cap0, float dt, float a, float b, float kT, int n_steps,
+                              const float* noise, uint32_t k0, uint32_t k1, int threads, double* stats) {
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#endif
+  const float hdt = (float)((double)dt * 0.5);
+  const float cs = (float)((double)rc + (double)skin);
+  int cap = cap0 > 0 ? cap0 : 96, rebuilds = 0;
+  double t_build = 0.0;
+  uint32_t* rows = NULL;
+  int32_t* deg = (int32_t*)malloc(sizeof(int32_t) * n);
+  float* ref = (float*)malloc(sizeof(float) * 3 * n);
+  float* F = (float*)malloc(sizeof(float) * 3 * n);
+  if (!deg || !ref || !F) return -1;
+  double t0 = now_s();
+  if (rebuild_full(x, n, box, cs, &cap, &rows, deg)) return -1;
+  t_build += now_s() - t0;
+  memcpy(ref, x, sizeof(float) * 3 * n);
+  forces_full_rows(x, rows, deg, n, cap, box, sigma, eps, rc, F);
+  const float L[3] = {box.lx, box.ly, box.lz};
+  for (int s = 0; s < n_steps; ++s) {
+    int moved = 0;
+#pragma omp parallel for schedule(static) reduction(| : moved)
+    for (int i = 0; i < n; ++i) {
+      const float mi = mass[i];
+      const float sv = sqrtf(kT / mi);
+      float z[3];
+      if (noise) memcpy(z, noise + ((size_t)s * n + i) * 3, sizeof(z));
+      else normals3((uint32_t)i, (uint32_t)s, 1u, k0, k1, z);
+      for (int c = 0; c < 3; ++c) {
+        float vv = v[3 * i + c] + hdt * F[3 * i + c] / mi;
+        float xx = x[3 * i + c] + hdt * vv;
+        vv = (a * vv) + (b * sv * z[c]);
+        xx = xx + hdt * vv;
+        if (box.periodic) xx = xx - floorf(xx / L[c]) * L[c];
+        v[3 * i + c] = vv; x[3 * i + c] = xx;
+      }
+      float r[3];
+      if (disp(&box, x + 3 * i, ref + 3 * i, r) >= skin / 2.0f) moved |= 1;
+    }
+    if (moved) {
+      t0 = now_s();
+      if (rebuild_full(x, n, box, cs, &cap, &rows, deg)) return -1;
+      t_build += now_s() - t0;
+      memcpy(ref, x, sizeof(float) * 3 * n);
+      ++rebuilds;
+    }
+    forces_full_rows(x, rows, deg, n, cap, box, sigma, eps, rc, F);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i)
+      for (int c = 0; c < 3; ++c) v[3 * i + c] = v[3 * i + c] + hdt * F[3 * i + c] / mass[i];
+  }
+  if (stats) {
+    stats[0] = rebuilds; stats[1] = cap; stats[2] = t_build;
+#ifdef _OPENMP
+    stats[3] = omp_get_max_threads();
+#else
+    stats[3] = 1;
+#endif
+  }
+  free(rows); free(deg); free(ref); free(F);
+  return 0;
+}

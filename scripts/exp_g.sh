@@ -1,4 +1,5 @@
 # steps/s of the bench workloads as a function of the lanes-per-particle override
+export CHX_ALLOW_STALE_LIB=1  # variant builds carry no source hash
 cd $GRAFT_REPO_ROOT
 for wl in c3 c4; do
 for g in 2 4 8 16; do

@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
+export CHX_ALLOW_STALE_LIB=1  # variant builds carry no source hash
 run() { # wl steps
   python scripts/rebuild_profile.py $1 $2 2>&1 | grep -v amdgpu.ids | grep "$1:\|inner" | tr '\n' ' '; echo; }
 for cfg in "0.08 16" "0.10 24" "0.12 32" "0.14 40" "0.16 48" "0.20 64"; do

@@ -427,3 +427,57 @@ def test_as_tensor_passes_ready_tensors_through():
     nc = torch.arange(12, dtype=torch.float32).reshape(3, 4).t()
     assert as_tensor(nc).is_contiguous() and torch.equal(as_tensor(nc), nc)
     assert as_tensor([[1, 2, 3]]).shape == (1, 3)
+
+
+def test_host_side_of_the_c_abi_under_address_sanitizer(tmp_path):
+    """the host half of libchx (entry points, argument validation, host helpers) is
+    compiled from the library's own sources with -fsanitize=address,undefined (scripts/build_host_asan.sh) and
+    driven by tests/host_asan/driver.cpp: helper sweeps plus an invalid call of every entry point.  Any
+    sanitizer report or failed expectation makes the driver exit non-zero.  No GPU involved."""
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    out = str(tmp_path / "asan")
+    res = subprocess.run(["bash", os.path.join(root, "scripts", "build_host_asan.sh"), out], capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    run = subprocess.run([os.path.join(out, "host_asan_driver")], capture_output=True, text=True, timeout=300, env=env)
+    assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
+    assert "host ABI checks passed" in run.stdout
+    assert "ERROR: AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr
+
+
+def test_build_is_keyed_on_a_source_hash_not_on_mtimes(monkeypatch):
+    """build() must recompile exactly when sources/flags differ from what the shipped .so was built from."""
+    from chiron_amd import _lib, build as b
+
+    assert os.path.exists(b.OUT), "run __graft_entry__.build() first"
+    have = b.binary_hash()
+    assert have is not None and re.fullmatch(r"[0-9a-f]{64}", have)
+    assert have == b.source_hash() and not b.needs_build()
+    # touching a source (newer mtime, same bytes) does not trigger a rebuild ...
+    src = b.sources()[0]
+    st = os.stat(src)
+    os.utime(src, (st.st_atime, st.st_mtime + 3600))
+    try:
+        assert not b.needs_build()
+    finally:
+        os.utime(src, (st.st_atime, st.st_mtime))
+    # ... a different flag set or different bytes does
+    assert b.source_hash(b.FLAGS + ["-DX"]) != have
+    monkeypatch.setattr(b, "FLAGS", b.FLAGS + ["-DSOMETHING_ELSE"])
+    assert b.needs_build()
+    # and the loader refuses a library that does not match the tree
+    lib = _lib.load()
+    assert lib.chx_source_hash().decode() == have
+    assert lib.chx_sizeof_langevin_t() == __import__("ctypes").sizeof(_lib.LangevinParams)
+    assert lib.chx_sizeof_mc_t() == __import__("ctypes").sizeof(_lib.McParams)
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(_lib.ChxError, match="built from other sources"):
+        _lib.load()
+    monkeypatch.setenv("CHX_ALLOW_STALE_LIB", "1")
+    assert _lib.load() is not None

