@@ -107,6 +107,10 @@ class LangevinIntegrator:
         cache = self.__dict__.setdefault("_run_cache", {})
         kT_key = ("kT", id(temperature))
         if cache.get(kT_key, (None,))[0] is not temperature:
+            stale = [k for k in cache if k[0] == "kT"]
+            if len(stale) >= 16:  # a temperature ladder fits; anything longer-lived must not grow without bound
+                for k in stale:
+                    del cache[k]
             cache[kT_key] = (temperature, float((self.kB * temperature).value_in_unit_system(unit.md_unit_system)))
         kbT_unitless = cache[kT_key][1]
         m_key = ("mass", id(potential.topology), str(x0.device))

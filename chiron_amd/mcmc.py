@@ -252,8 +252,11 @@ class MonteCarloDisplacementMove(MCMove):
             return False
         cls = type(self)
         if (cls._propose is not MonteCarloDisplacementMove._propose or cls._step is not MCMove._step
-                or cls._accept_or_reject is not MCMove._accept_or_reject):
-            return False  # a subclass changed the trial: honour it
+                or cls._accept_or_reject is not MCMove._accept_or_reject
+                or cls._report is not MonteCarloDisplacementMove._report
+                or cls._autotune is not MonteCarloDisplacementMove._autotune
+                or cls._update_statistics is not MCMove._update_statistics):
+            return False  # a subclass changed the trial or its bookkeeping: honour it (host loop calls them all)
         if self.acceptance_method != "Metropolis-Hastings" or self.number_of_moves <= 0:
             return False
         pot = getattr(thermodynamic_state, "potential", None)

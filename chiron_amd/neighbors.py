@@ -268,11 +268,21 @@ class NeighborListNsqrd(PairsBase):
     def build(self, positions, box_vectors):
         """chiron/neighbors.py:628-729"""
         positions = _strip_positions(positions)
-        if box_vectors is not None and box_vectors is getattr(self, "box_vectors", None) and getattr(self, "_box_h", None) is not None:
-            pass  # the very tensor this list already holds (integrator rebuilds): host copy is current
+        private = getattr(self, "_adopt_positions", False)  # the integrator's own rebuild inside run()
+        if (private and box_vectors is not None and box_vectors is getattr(self, "box_vectors", None)
+                and getattr(self, "_box_h", None) is not None):
+            pass  # the very tensor this list already holds, which nobody else can reach: host copy is current
         else:
+            # a build requested from outside says nothing about the state it will be used with: forget the
+            # "same box as the sampler state" token (build_from_state sets it again after the build), and keep a
+            # private copy of the box -- unlike a JAX array a torch tensor can be mutated in place by its owner
+            self._box_token = None
             box_vectors = _strip_box(box_vectors)
-            self.box_vectors = None if box_vectors is None else as_tensor(box_vectors)
+            if box_vectors is None:
+                self.box_vectors = None
+            else:
+                bt = as_tensor(box_vectors)
+                self.box_vectors = bt.clone() if bt is box_vectors else bt
             if self.space.periodic and self.box_vectors is None:
                 # the reference raises from Space.displacement (chiron/neighbors.py:71-72)
                 raise ValueError("box_vectors must be provided for a periodic system")

@@ -1511,3 +1511,72 @@ def test_cpu_tensors_are_refused(ca):
 
     with pytest.raises(ChxError):
         ca.ops.wrap(torch.zeros(4, 3), ca.ops.make_box(np.eye(3, dtype=f32), True))
+
+
+def test_direct_build_forgets_the_box_token_and_copies_the_box(ca, O):
+    """(a) build() called directly says nothing about the sampler state the list will be used with: the
+    "same box" token is dropped, so a later run() rebuilds from the STATE's box as the reference does
+    (chiron/integrators.py:169-170) instead of speculating on the list's stale one.  (b) The list keeps its own
+    copy of the box: mutating the caller's tensor in place (impossible with JAX arrays) cannot desynchronise
+    box_vectors from the host-side copy the kernels use."""
+    u = ca.unit
+    n = 600
+    x, box = O.lj_lattice(n, 0.3, SIGMA, seed=9)
+    state = make_state(ca, x, box)
+    nbr = ca.neighbors.NeighborListCell(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+                                        skin=SKIN * u.nanometer, n_max_neighbors=180)
+    nbr.build_from_state(state)
+    assert nbr._box_token is state._box_token
+    other = (box * 1.25).astype(f32)
+    nbr.build(nm((x * 1.25).astype(f32), ca), nm(other, ca))
+    assert nbr._box_token is None
+    assert np.allclose(nbr.box_vectors.cpu().numpy(), other)
+    pot = lj_pot(ca, n)
+    thermo = ca.states.ThermodynamicState(pot, temperature=300 * u.kelvin)
+    integ = ca.integrators.LangevinIntegrator(timestep=1.0 * u.femtoseconds, collision_rate=1.0 / u.picoseconds)
+    out, nbr2 = integ.run(state, thermo, number_of_steps=3, nbr_list=nbr)
+    assert np.allclose(nbr2.box_vectors.cpu().numpy(), box)  # rebuilt from the state's box
+    L = float(box[0, 0])
+    assert float(out.positions.max()) <= L * (1 + 1e-6)
+    # (b)
+    bt = torch.as_tensor(box).cuda()
+    nbr3 = ca.neighbors.NeighborListCell(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+                                         skin=SKIN * u.nanometer, n_max_neighbors=180)
+    nbr3.build(dev(x), bt)
+    bt.mul_(2.0)
+    assert np.allclose(nbr3.box_vectors.cpu().numpy(), box)
+    assert nbr3._box_h.lx == f32(box[0, 0])
+    nbr3.build(dev(x), bt)  # the same tensor object with new values: the list must notice
+    assert np.allclose(nbr3.box_vectors.cpu().numpy(), 2 * box) and nbr3._box_h.lx == f32(2 * box[0, 0])
+
+
+def test_mc_device_loop_yields_to_overridden_bookkeeping(ca, O):
+    """A subclass that customises _report / _autotune / _update_statistics gets the host loop, which calls them
+    (the device loop builds its reports itself)."""
+    u = ca.unit
+    n = 300
+    x, box = O.lj_lattice(n, 0.1, SIGMA, seed=4)
+    state = make_state(ca, x, box)
+    thermo = ca.states.ThermodynamicState(lj_pot(ca, n), temperature=300 * u.kelvin)
+    nbr = ca.neighbors.NeighborListCell(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+                                        skin=SKIN * u.nanometer, n_max_neighbors=180)
+    nbr.build_from_state(state)
+    base = ca.mcmc.MonteCarloDisplacementMove(displacement_sigma=0.01 * u.nanometer, number_of_moves=5)
+    assert base._device_loop_applies(state, thermo, nbr)
+    seen = []
+
+    class Custom(ca.mcmc.MonteCarloDisplacementMove):
+        def _update_statistics(self, decision):
+            seen.append(bool(decision))
+            super()._update_statistics(decision)
+
+    mv = Custom(displacement_sigma=0.01 * u.nanometer, number_of_moves=5)
+    assert not mv._device_loop_applies(state, thermo, nbr)
+    mv.update(state, thermo, nbr)
+    assert len(seen) == 5 and mv.statistics["n_proposed"] == 5
+
+    class Custom2(ca.mcmc.MonteCarloDisplacementMove):
+        def _report(self, *a, **k):
+            return super()._report(*a, **k)
+
+    assert not Custom2(number_of_moves=1)._device_loop_applies(state, thermo, nbr)
