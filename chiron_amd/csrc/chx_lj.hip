@@ -323,7 +323,13 @@ __device__ __forceinline__ void lj_row_loop(const float4* __restrict__ x4, const
                                             const PruneOut& po, int p, int n, int& kept) {
   constexpr int W = 4 * G;
   int base = 0;  // PRUNE: entries kept so far in this row (uniform over the G lanes)
-  for (int c = 0; c < nc; ++c) {
+  // At least one pass, also for an empty row (every `k < d` test then fails): with a zero-trip loop the
+  // compiler sinks the first index quad and its four gathers below the wait for the row length `d`, which
+  // puts THREE dependent memory round trips (d, indices, positions) in front of the first pair instead of two.
+  // (One lane per particle -- G = 1, N >= 2^18 -- is throughput-bound and measured 6 % SLOWER that way: it keeps
+  // the zero-trip form.)
+  int c = 0;
+  if (G > 1 || nc > 0) do {
     const int k0 = c * W + 4 * q;  // this lane's first entry of the chunk
     uint4 nx = make_uint4(0u, 0u, 0u, 0u);
     if (c + 1 < nc) nx = col[(size_t)(c + 1) * stride];
@@ -370,7 +376,7 @@ __device__ __forceinline__ void lj_row_loop(const float4* __restrict__ x4, const
       xj[3] = x4[e4.w & ~CHX_FL_HI];
 #endif
     }
-  }
+  } while (++c < nc);
   kept = base;
 }
 
@@ -387,25 +393,43 @@ __device__ __forceinline__ void lj_row_loop(const float4* __restrict__ x4, const
 // arithmetic is branch-free and packed two entries wide; a lane whose fast form does not apply
 // (unwrapped input coordinates, a list that does not match the positions) redoes its share
 // through the general min_image().
-template <int G, bool PRUNE = false>
-__device__ __forceinline__ void lj_row(const float4* __restrict__ x4, const uint32_t* __restrict__ fl,
-                                       const int32_t* __restrict__ deg, int n, int chunks, int p, int q,
-                                       bool valid, const Box3& box, const LJParams& lj, float4& xi_out,
-                                       float& fx, float& fy, float& fz, float& en,
-                                       const PruneOut& po = PruneOut{nullptr, 0.f}, int* kept_out = nullptr) {
-  constexpr int W = 4 * G;
-  const int pc = valid ? p : 0;
-  const size_t stride = (size_t)n * G;  // uint4 units between consecutive chunks
-  const uint4* col = reinterpret_cast<const uint4*>(fl) + (size_t)pc * G + q;
-  const float4 xi = x4[pc];
-  int d = deg[pc];
-  const uint4 e4 = col[0];
+// what row_begin has in flight for one lane
+struct RowLoads {
+  float4 xi;
+  int d_raw;  // deg[p] as loaded (not yet masked by `valid`)
+  uint4 e4;
   float4 xj[4];
-  xj[0] = x4[e4.x & ~CHX_FL_HI];
-  xj[1] = x4[e4.y & ~CHX_FL_HI];
-  xj[2] = x4[e4.z & ~CHX_FL_HI];
-  xj[3] = x4[e4.w & ~CHX_FL_HI];
-  d = valid ? d : 0;
+  const uint4* col;
+  int pc;
+};
+
+// Issue the loads of a lane's row: own position, row length, first index quad and its four gathers.
+template <int G>
+__device__ __forceinline__ RowLoads lj_row_begin(const float4* __restrict__ x4, const uint32_t* __restrict__ fl,
+                                                 const int32_t* __restrict__ deg, int n, int p, int q, bool valid) {
+  RowLoads L;
+  L.pc = valid ? p : 0;
+  L.col = reinterpret_cast<const uint4*>(fl) + (size_t)L.pc * G + q;
+  L.xi = x4[L.pc];
+  L.d_raw = deg[L.pc];
+  L.e4 = L.col[0];
+  L.xj[0] = x4[L.e4.x & ~CHX_FL_HI];
+  L.xj[1] = x4[L.e4.y & ~CHX_FL_HI];
+  L.xj[2] = x4[L.e4.z & ~CHX_FL_HI];
+  L.xj[3] = x4[L.e4.w & ~CHX_FL_HI];
+  return L;
+}
+
+template <int G, bool PRUNE = false>
+__device__ __forceinline__ void lj_row_finish(RowLoads& L, const float4* __restrict__ x4, const uint32_t* __restrict__ fl,
+                                              int n, int q, bool valid, const Box3& box, const LJParams& lj,
+                                              float4& xi_out, float& fx, float& fy, float& fz, float& en,
+                                              const PruneOut& po = PruneOut{nullptr, 0.f}, int* kept_out = nullptr) {
+  constexpr int W = 4 * G;
+  const int pc = L.pc;
+  const size_t stride = (size_t)n * G;  // uint4 units between consecutive chunks
+  const float4 xi = L.xi;
+  const int d = valid ? L.d_raw : 0;
   xi_out = xi;
   const int nc = (d + W - 1) / W;
   RowAcc A;
@@ -414,9 +438,9 @@ __device__ __forceinline__ void lj_row(const float4* __restrict__ x4, const uint
   A.keep0 = A.keep1 = false;
   int kept = 0;
   if (!box.periodic) {
-    lj_row_loop<G, LJ_OPEN, PRUNE>(x4, col, stride, d, nc, q, xi, e4, xj, box, lj, A, po, pc, n, kept);
+    lj_row_loop<G, LJ_OPEN, PRUNE>(x4, L.col, stride, d, nc, q, xi, L.e4, L.xj, box, lj, A, po, pc, n, kept);
   } else {
-    lj_row_loop<G, LJ_SHIFT, PRUNE>(x4, col, stride, d, nc, q, xi, e4, xj, box, lj, A, po, pc, n, kept);
+    lj_row_loop<G, LJ_SHIFT, PRUNE>(x4, L.col, stride, d, nc, q, xi, L.e4, L.xj, box, lj, A, po, pc, n, kept);
   }
   if (PRUNE) *kept_out = kept;
   if (__builtin_expect(A.bad, 0)) {
@@ -449,6 +473,17 @@ __device__ __forceinline__ void lj_row(const float4* __restrict__ x4, const uint
   fy += A.ay.x + A.ay.y;
   fz += A.az.x + A.az.y;
   en += A.ae.x + A.ae.y;
+}
+
+template <int G, bool PRUNE = false>
+__device__ __forceinline__ void lj_row(const float4* __restrict__ x4, const uint32_t* __restrict__ fl,
+                                       const int32_t* __restrict__ deg, int n, int chunks, int p, int q,
+                                       bool valid, const Box3& box, const LJParams& lj, float4& xi_out,
+                                       float& fx, float& fy, float& fz, float& en,
+                                       const PruneOut& po = PruneOut{nullptr, 0.f}, int* kept_out = nullptr) {
+  (void)chunks;
+  RowLoads L = lj_row_begin<G>(x4, fl, deg, n, p, q, valid);
+  lj_row_finish<G, PRUNE>(L, x4, fl, n, q, valid, box, lj, xi_out, fx, fy, fz, en, po, kept_out);
 }
 
 // Optional run-time choice of the position buffer (device-resident Monte Carlo, chx_mc.hip):
@@ -548,6 +583,7 @@ struct StepArgs {
 struct StepParticle {
   bool live;
   int pp;
+  uint32_t o;  // original particle id (RNG counter / noise row)
   float m;
   float bs;  // b sigma_v = b sqrt(kT / m), chiron/integrators.py:131,186
   float v[3];
@@ -621,14 +657,16 @@ __device__ __forceinline__ bool integrate_component(const StepArgs& a, int n_kic
   return rare;
 }
 
+// The loads of one particle's integrate work (no arithmetic: see finish_step_particle).
 template <bool HOT, bool PRUNE>
-__device__ __forceinline__ StepParticle load_step_particle(const StepArgs& a, long long step, int do_aoa, int p0,
-                                                           int pl, int ppb) {
+__device__ __forceinline__ StepParticle load_step_operands(const StepArgs& a, long long step, int do_aoa, int p0, int pl,
+                                                           int ppb) {
   StepParticle t;
   t.pp = p0 + pl;
   t.live = pl < ppb && t.pp < a.n;
   t.m = 1.f;
   t.bs = 0.f;
+  t.o = 0u;
   t.v[0] = t.v[1] = t.v[2] = 0.f;
   t.z[0] = t.z[1] = t.z[2] = 0.f;
   t.x = t.ref = t.refi = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -637,22 +675,40 @@ __device__ __forceinline__ StepParticle load_step_particle(const StepArgs& a, lo
 #pragma unroll
     for (int c = 0; c < 3; ++c) t.v[c] = a.v[3 * (size_t)t.pp + c];
     if (do_aoa) {
-      t.bs = fmul(a.b, fsqrt(fdiv(a.kT, t.m)));
       t.x = a.x_cur[t.pp];
       if (HOT || a.ref4) t.ref = a.ref4[t.pp];
       // a pruning launch measures against the positions it prunes at (and rewrites refi4 itself)
       if (PRUNE) t.refi = t.x;
       else if (HOT || a.fli) t.refi = a.refi4[t.pp];
-      const uint32_t o = (HOT || a.perm) ? a.perm[t.pp] : (uint32_t)t.pp;
+      t.o = (HOT || a.perm) ? a.perm[t.pp] : (uint32_t)t.pp;
       if (!HOT && a.noise) {
-        const float* row = a.noise + ((size_t)(step - a.noise_step0) * (size_t)a.n + o) * 3;
+        const float* row = a.noise + ((size_t)(step - a.noise_step0) * (size_t)a.n + t.o) * 3;
         t.z[0] = row[0], t.z[1] = row[1], t.z[2] = row[2];
-      } else {
-        // one Philox block serves the three components of the particle
-        philox_normals3(o, (uint32_t)step, CHX_STREAM_LANGEVIN, a.k0, a.k1, t.z[0], t.z[1], t.z[2]);
       }
     }
   }
+  return t;
+}
+
+// b sigma_v and the O-step noise of the particle: pure arithmetic on the operands above, placed by the
+// caller where it overlaps memory latency (k_lj_step: between the issue of the first neighbor gathers and
+// their use)
+template <bool HOT>
+__device__ __forceinline__ void finish_step_particle(const StepArgs& a, long long step, int do_aoa, StepParticle& t) {
+  if (t.live && do_aoa) {
+    t.bs = fmul(a.b, fsqrt(fdiv(a.kT, t.m)));
+    if (HOT || !a.noise) {
+      // one Philox block serves the three components of the particle
+      philox_normals3(t.o, (uint32_t)step, CHX_STREAM_LANGEVIN, a.k0, a.k1, t.z[0], t.z[1], t.z[2]);
+    }
+  }
+}
+
+template <bool HOT, bool PRUNE>
+__device__ __forceinline__ StepParticle load_step_particle(const StepArgs& a, long long step, int do_aoa, int p0,
+                                                           int pl, int ppb) {
+  StepParticle t = load_step_operands<HOT, PRUNE>(a, step, do_aoa, p0, pl, ppb);
+  finish_step_particle<HOT>(a, step, do_aoa, t);
   return t;
 }
 
@@ -751,7 +807,7 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   // ---- operands of this thread's integrate work (threads 0..PPB-1 own one particle each: the
   //      first wavefronts of the block), requested before the force loop so their latency and the
   //      Philox arithmetic hide under it ----
-  const StepParticle tk = load_step_particle<HOT, PRUNE>(a, step, do_aoa, p0, threadIdx.x, PPB);
+  StepParticle tk = load_step_operands<HOT, PRUNE>(a, step, do_aoa, p0, threadIdx.x, PPB);
 
   const int tid = blk * 256 + threadIdx.x;
   const int p = tid / G;
@@ -760,11 +816,18 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   float4 xi;
   float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
 #ifndef CHX_EXP_NOFORCE
+  // the row's own loads and first gathers go out together with the integrate operands; the Philox draw and
+  // b sigma_v (~500 instructions in the block's first wavefront) run while the gathers are in flight
+  // (with one lane per particle every thread integrates and the launch is throughput-bound: there the
+  // arithmetic stays in front of the row loads, measured 2-3 % faster)
+  if (G == 1) finish_step_particle<HOT>(a, step, do_aoa, tk);
+  RowLoads rl = lj_row_begin<G>(a.x_cur, fl_use, deg_use, a.n, p, q, valid);
+  if (G > 1) finish_step_particle<HOT>(a, step, do_aoa, tk);
   if (PRUNE) {
     constexpr int W = 4 * G;
     int kept = 0;
-    lj_row<G, true>(a.x_cur, fl_use, deg_use, a.n, a.chunks, p, q, valid, a.box, a.lj, xi, fx, fy, fz, en,
-                    PruneOut{a.fli, a.T_inner}, &kept);
+    lj_row_finish<G, true>(rl, a.x_cur, fl_use, a.n, q, valid, a.box, a.lj, xi, fx, fy, fz, en,
+                           PruneOut{a.fli, a.T_inner}, &kept);
     if (valid) {
       // the force kernel gathers whole chunks (chunk 0 speculatively): pad the last touched chunk
       int end = (kept + W - 1) / W * W;
@@ -776,8 +839,10 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
       }
     }
   } else {
-    lj_row<G>(a.x_cur, fl_use, deg_use, a.n, a.chunks, p, q, valid, a.box, a.lj, xi, fx, fy, fz, en);
+    lj_row_finish<G>(rl, a.x_cur, fl_use, a.n, q, valid, a.box, a.lj, xi, fx, fy, fz, en);
   }
+#else
+  finish_step_particle<HOT>(a, step, do_aoa, tk);
 #endif
 #pragma unroll
   for (int o = G / 2; o > 0; o >>= 1) {
