@@ -393,6 +393,20 @@ __device__ __forceinline__ void lj_row_loop(const float4* __restrict__ x4, const
 // arithmetic is branch-free and packed two entries wide; a lane whose fast form does not apply
 // (unwrapped input coordinates, a list that does not match the positions) redoes its share
 // through the general min_image().
+// Loads the optimiser leaves where they are written: relaxed atomic loads at wavefront scope are ordinary
+// global_load instructions (no cache-policy bits), but unlike plain loads they are not sunk below a branch
+// whose other side does not use them.  k_lj_step issues its first row loads this way AHEAD of the halt /
+// stale-list control words, so that the vector round trip overlaps the scalar ones instead of following them.
+__device__ __forceinline__ uint4 pinned_load16(const void* p) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+__device__ __forceinline__ int pinned_load4(const int32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
 // what row_begin has in flight for one lane
 struct RowLoads {
   float4 xi;
@@ -417,6 +431,24 @@ __device__ __forceinline__ RowLoads lj_row_begin(const float4* __restrict__ x4, 
   L.xj[1] = x4[L.e4.y & ~CHX_FL_HI];
   L.xj[2] = x4[L.e4.z & ~CHX_FL_HI];
   L.xj[3] = x4[L.e4.w & ~CHX_FL_HI];
+  return L;
+}
+
+// the same from values that are already on their way (k_lj_step's speculative loads): only the gathers are issued
+template <int G>
+__device__ __forceinline__ RowLoads lj_row_adopt(const float4* __restrict__ x4, const uint4* col, int pc, uint4 xi_bits,
+                                                 int d_raw, uint4 e4) {
+  RowLoads L;
+  L.pc = pc;
+  L.col = col;
+  L.xi = make_float4(__uint_as_float(xi_bits.x), __uint_as_float(xi_bits.y), __uint_as_float(xi_bits.z),
+                     __uint_as_float(xi_bits.w));
+  L.d_raw = d_raw;
+  L.e4 = e4;
+  L.xj[0] = x4[e4.x & ~CHX_FL_HI];
+  L.xj[1] = x4[e4.y & ~CHX_FL_HI];
+  L.xj[2] = x4[e4.z & ~CHX_FL_HI];
+  L.xj[3] = x4[e4.w & ~CHX_FL_HI];
   return L;
 }
 
@@ -767,12 +799,31 @@ __device__ __forceinline__ bool step_epilogue(const StepArgs& a, const StepParti
 // "inner list is stale" words hold the epoch in which they were raised, so a refresh invalidates
 // them without anybody having to clear a word another block may be reading.
 template <int G, bool HOT, bool PRUNE>
-__global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long step, int epoch, StepArgs a, int n_kicks,
-                                                 int do_aoa) {
-  // (the control block and the step index lead the argument list: they are what the launch needs first,
-  // and leading scalar arguments are the ones the dispatcher can preload into SGPRs)
+__global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long step, int epoch, int n_lead,
+                                                 unsigned nblocks, const float4* x_lead, const uint32_t* sfl,
+                                                 const int32_t* sdeg, StepArgs a, int n_kicks, int do_aoa) {
+  // (Leading scalar arguments are the ones the dispatcher preloads into SGPRs: the control block, the step
+  // index and everything the FIRST vector loads need -- particle count, grid size (gridDim would be a fetch
+  // from the dispatch packet), the position buffer and the list this launch most probably walks (sfl, sdeg:
+  // the pruned inner list in the steady state) -- so those loads can leave before any scalar fetch returns.
+  // n_lead == a.n and x_lead == a.x_cur; the copies inside StepArgs arrive with the rest of the block.)
   a.ctrl = ctrl_first;
+  a.n = n_lead;
+  a.x_cur = x_lead;
   constexpr int PPB = 256 / G;  // particles per block (<= 256)
+  const unsigned blk = xcd_block(blockIdx.x, nblocks);
+  const int tid = blk * 256 + threadIdx.x;
+  const int p = tid / G;
+  const int q = tid % G;
+  const bool valid = p < n_lead;
+  // ---- speculative first loads of this lane's row, ahead of the control words (pinned_load*) ----
+  const int pc_s = valid ? p : 0;
+  const uint4* scol = reinterpret_cast<const uint4*>(sfl) + (size_t)pc_s * G + q;
+#ifndef CHX_EXP_NOFORCE
+  const uint4 s_e4 = pinned_load16(scol);
+  const uint4 s_xi = pinned_load16(x_lead + pc_s);
+  const int s_d = pinned_load4(sdeg + pc_s);
+#endif
   if (HOT) {  // what the launcher checked (launch_step_g), restated for the optimiser
     n_kicks = 2, do_aoa = 1;
     a.box.periodic = 1, a.wrap = 1;
@@ -802,17 +853,12 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
 #endif
   const uint32_t* fl_use = inner ? a.fli : a.fl;
   const int32_t* deg_use = inner ? a.degi : a.deg;
-  const unsigned blk = xcd_block(blockIdx.x, gridDim.x);
   const int p0 = blk * PPB;
   // ---- operands of this thread's integrate work (threads 0..PPB-1 own one particle each: the
   //      first wavefronts of the block), requested before the force loop so their latency and the
   //      Philox arithmetic hide under it ----
   StepParticle tk = load_step_operands<HOT, PRUNE>(a, step, do_aoa, p0, threadIdx.x, PPB);
 
-  const int tid = blk * 256 + threadIdx.x;
-  const int p = tid / G;
-  const int q = tid % G;
-  const bool valid = p < a.n;
   float4 xi;
   float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
 #ifndef CHX_EXP_NOFORCE
@@ -821,7 +867,10 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   // (with one lane per particle every thread integrates and the launch is throughput-bound: there the
   // arithmetic stays in front of the row loads, measured 2-3 % faster)
   if (G == 1) finish_step_particle<HOT>(a, step, do_aoa, tk);
-  RowLoads rl = lj_row_begin<G>(a.x_cur, fl_use, deg_use, a.n, p, q, valid);
+  // the speculated list is the one to walk (launch-uniform; the steady state): adopt what is in flight.
+  // Otherwise (inner list gone stale since the host chose) the row is loaded again from the right table.
+  RowLoads rl = (fl_use == sfl) ? lj_row_adopt<G>(a.x_cur, scol, pc_s, s_xi, s_d, s_e4)
+                                : lj_row_begin<G>(a.x_cur, fl_use, deg_use, a.n, p, q, valid);
   if (G > 1) finish_step_particle<HOT>(a, step, do_aoa, tk);
   if (PRUNE) {
     constexpr int W = 4 * G;
@@ -1016,14 +1065,18 @@ static void launch_step_g(const StepArgs& a, long long step, int n_kicks, int do
   if (dbg) fprintf(stderr, "[chx] k_lj_step<%d> step %lld kicks %d aoa %d prune %d epoch %d\n", G, step, n_kicks, do_aoa, (int)prune, epoch);
   // steady-state launches take the instantiation with the launch-uniform switches folded
   const bool hot = n_kicks == 2 && do_aoa && a.wrap && a.box.periodic && a.ref4 && a.fli && a.perm && !a.noise;
+  // the list the launch will most probably walk (the kernel checks: see its speculative loads)
+  const bool spec_inner = a.fli != nullptr && !prune && epoch >= 0;
+  const uint32_t* sfl = spec_inner ? a.fli : a.fl;
+  const int32_t* sdeg = spec_inner ? a.degi : a.deg;
   if (hot && prune) {
-    hipLaunchKernelGGL((k_lj_step<G, true, true>), dim3(blocks), dim3(256), 0, st, a.ctrl, step, epoch, a, n_kicks, do_aoa);
+    hipLaunchKernelGGL((k_lj_step<G, true, true>), dim3(blocks), dim3(256), 0, st, a.ctrl, step, epoch, a.n, blocks, a.x_cur, sfl, sdeg, a, n_kicks, do_aoa);
   } else if (hot) {
-    hipLaunchKernelGGL((k_lj_step<G, true, false>), dim3(blocks), dim3(256), 0, st, a.ctrl, step, epoch, a, n_kicks, do_aoa);
+    hipLaunchKernelGGL((k_lj_step<G, true, false>), dim3(blocks), dim3(256), 0, st, a.ctrl, step, epoch, a.n, blocks, a.x_cur, sfl, sdeg, a, n_kicks, do_aoa);
   } else if (prune) {
-    hipLaunchKernelGGL((k_lj_step<G, false, true>), dim3(blocks), dim3(256), 0, st, a.ctrl, step, epoch, a, n_kicks, do_aoa);
+    hipLaunchKernelGGL((k_lj_step<G, false, true>), dim3(blocks), dim3(256), 0, st, a.ctrl, step, epoch, a.n, blocks, a.x_cur, sfl, sdeg, a, n_kicks, do_aoa);
   } else {
-    hipLaunchKernelGGL((k_lj_step<G, false, false>), dim3(blocks), dim3(256), 0, st, a.ctrl, step, epoch, a, n_kicks, do_aoa);
+    hipLaunchKernelGGL((k_lj_step<G, false, false>), dim3(blocks), dim3(256), 0, st, a.ctrl, step, epoch, a.n, blocks, a.x_cur, sfl, sdeg, a, n_kicks, do_aoa);
   }
   if (dbg) (void)hipStreamSynchronize(st);
 }
