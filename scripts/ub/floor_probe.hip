@@ -116,5 +116,32 @@ int main() {
   bench("E7 1024 x 256, halt + stale control words", [&](int i) { hipLaunchKernelGGL(k_ctrl, dim3(n / 256), dim3(256), 0, 0, ctrl, (long long)i, (i & 1) ? b : a, (i & 1) ? a : b, n); });
   bench("E8 256 x 256 (a quarter of the threads)", [&](int i) { hipLaunchKernelGGL(k_small<256>, dim3(256), dim3(256), 0, 0, (i & 1) ? b : a, (i & 1) ? a : b, 65536); });
   bench("E9 1 x 64 (one wave)", [&](int i) { hipLaunchKernelGGL(k_small<64>, dim3(1), dim3(64), 0, 0, (i & 1) ? b : a, (i & 1) ? a : b, 64); });
+  // the same tiny kernel replayed from a hipGraph (64 dependent launches per graph): is the eager figure the
+  // host's launch rate or the device's dependent-dispatch rate?
+  {
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    hipGraph_t g;
+    hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+    for (int i = 0; i < 64; ++i)
+      hipLaunchKernelGGL(k_small<256>, dim3(n / 256), dim3(256), 0, st, (i & 1) ? b : a, (i & 1) ? a : b, n);
+    CK(hipStreamEndCapture(st, &g));
+    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int r = 0; r < 3; ++r) {
+      CK(hipGraphLaunch(ge, st));
+      CK(hipStreamSynchronize(st));
+      CK(hipEventRecord(e0, st));
+      for (int k = 0; k < 16; ++k) CK(hipGraphLaunch(ge, st));
+      CK(hipEventRecord(e1, st));
+      CK(hipStreamSynchronize(st));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("%-44s %7.3f us/launch\n", "G0 E0 from a 64-node hipGraph", 1e3 * ms / (16 * 64));
+    }
+  }
   return 0;
 }
