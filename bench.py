@@ -224,7 +224,9 @@ def roofline_entry(kind: str, n: int, p_nl: int, seconds: float, extra=None):
             pmc = json.load(fh).get(f"{wl}:{'k_lj_step' if kind == 'step' else 'k_lj_fl'}")
         if pmc:
             d["traffic"] = int(pmc["traffic_bytes"])
-            d["traffic_source"] = "profiles/r01f_pmc_hot_kernels.md (PMC passes at the lattice start state)"
+            d["hbm_GBps_measured"] = round(pmc["traffic_bytes"] / seconds / 1e9, 2)
+            d["traffic_source"] = ("profiles/r02_pmc_hot_kernels.md (separate rocprofv3 --pmc passes over this kernel at the "
+                                   "lattice start state of the same box geometry; not collected in this run)")
     except (OSError, ValueError):
         pass
     return d
