@@ -133,6 +133,7 @@ SIGNATURES = {
     "chx_lj_fl_energy_force": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, Box, _F, _F, _F, _P, _P, _P, _P]),
     "chx_lj_allpairs_energy_force": (C.c_int, [_P, _I32, Box, _F, _F, _F, _P, _P, _P, _P]),
     "chx_init_velocities": (C.c_int, [_P, _P, _I32, _F, _U32, _U32, _P, _P]),
+    "chx_jax_normal": (C.c_int, [_U32, _U32, _I64, _P, _P]),
     "chx_kick": (C.c_int, [_P, _P, _P, _I32, _F, _P]),
     "chx_langevin_chunk": (C.c_int, [C.POINTER(LangevinParams), _I64, _I32, _I32, _P]),
     "chx_langevin_resume": (C.c_int, [C.POINTER(LangevinParams), _P]),

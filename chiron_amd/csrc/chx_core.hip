@@ -215,3 +215,87 @@ extern "C" int chx_publish(const int32_t* src, int32_t* host_mapped_dst, int32_t
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, chx_stream(stream), src, host_mapped_dst, n);
   return chx_check_launch("chx_publish");
 }
+
+// ---------------------------------------------------------------------------
+// Optional JAX-compatible stream: jax.random.normal(key, (count,)) for a classic
+// (non-partitionable) threefry key, so that a run seeded like the reference draws the reference's numbers
+// (chiron/utils.py:29-38,142; chiron/integrators.py:124,179,185; chiron/mcmc.py:731).  Algorithms restated
+// from their publications: Threefry-2x32-20 (Salmon et al., SC'11); jax's random_bits layout (the counters
+// 0..count-1, padded to even length, are split in HALVES that form the two input words, the two output halves
+// are concatenated); uniform = bitcast((bits >> 9) | 0x3F800000) - 1 mapped to [nextafter(-1, 0), 1);
+// normal = sqrt(2) erfinv(u) with the single-precision polynomial of M. Giles (GPU Computing Gems, 2010)
+// that XLA evaluates for float32.  The product's own generator stays Philox (chx_common.h).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int d) { return (x << d) | (x >> (32 - d)); }
+
+__device__ __forceinline__ void threefry2x32(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_t& x1) {
+  const uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
+  const int rot[2][4] = {{13, 15, 26, 6}, {17, 29, 16, 24}};
+  x0 += ks[0];
+  x1 += ks[1];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      x0 += x1;
+      x1 = rotl32(x1, rot[i % 2][r]) ^ x0;
+    }
+    x0 += ks[(i + 1) % 3];
+    x1 += ks[(i + 2) % 3] + (uint32_t)(i + 1);
+  }
+}
+
+__device__ __forceinline__ float erfinv_giles(float x) {
+  float w = -logf(fmul(fsub(1.0f, x), fadd(1.0f, x)));
+  float p;
+  if (w < 5.0f) {
+    w = fsub(w, 2.5f);
+    p = 2.81022636e-08f;
+    p = fadd(3.43273939e-07f, fmul(p, w));
+    p = fadd(-3.5233877e-06f, fmul(p, w));
+    p = fadd(-4.39150654e-06f, fmul(p, w));
+    p = fadd(0.00021858087f, fmul(p, w));
+    p = fadd(-0.00125372503f, fmul(p, w));
+    p = fadd(-0.00417768164f, fmul(p, w));
+    p = fadd(0.246640727f, fmul(p, w));
+    p = fadd(1.50140941f, fmul(p, w));
+  } else {
+    w = fsub(fsqrt(w), 3.0f);
+    p = -0.000200214257f;
+    p = fadd(0.000100950558f, fmul(p, w));
+    p = fadd(0.00134934322f, fmul(p, w));
+    p = fadd(-0.00367342844f, fmul(p, w));
+    p = fadd(0.00573950773f, fmul(p, w));
+    p = fadd(-0.0076224613f, fmul(p, w));
+    p = fadd(0.00943887047f, fmul(p, w));
+    p = fadd(1.00167406f, fmul(p, w));
+    p = fadd(2.83297682f, fmul(p, w));
+  }
+  return fmul(p, x);
+}
+
+__global__ void k_jax_normal(uint32_t k0, uint32_t k1, int64_t count, float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= count) return;
+  const int64_t half = (count + 1) / 2;  // counters are padded to an even length
+  const bool second = e >= half;
+  const int64_t blk = second ? e - half : e;
+  uint32_t x0 = (uint32_t)blk;
+  uint32_t x1 = (blk + half < count) ? (uint32_t)(blk + half) : 0u;  // the padding counter is 0
+  threefry2x32(k0, k1, x0, x1);
+  const uint32_t bits = second ? x1 : x0;
+  const float f = fsub(__uint_as_float((bits >> 9) | 0x3F800000u), 1.0f);
+  const float lo = -0.99999994f;  // nextafter(-1, 0)
+  const float u = fmaxf(lo, fadd(fmul(f, fsub(1.0f, lo)), lo));
+  out[e] = fmul(1.41421356237309504880f, erfinv_giles(u));
+}
+
+extern "C" int chx_jax_normal(uint32_t k0, uint32_t k1, int64_t count, float* out, chx_stream_t stream) {
+  CHX_REQUIRE(count >= 0, "count < 0");
+  CHX_REQUIRE(count < ((int64_t)1 << 32), "count must fit the 32-bit threefry counter");
+  if (count == 0) return CHX_OK;
+  CHX_REQUIRE(out, "null pointer");
+  hipLaunchKernelGGL(k_jax_normal, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, chx_stream(stream), k0, k1, count,
+                     out);
+  return chx_check_launch("chx_jax_normal");
+}

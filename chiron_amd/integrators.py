@@ -26,7 +26,7 @@ import torch
 from . import ops, unit
 from ._device import as_tensor
 from ._lib import Box, LangevinParams
-from .rng import PRNGKey, fold_in
+from .rng import JaxKey, PRNGKey, fold_in, split
 from .states import SamplerState, ThermodynamicState
 
 log = logging.getLogger("chiron_amd")
@@ -160,6 +160,18 @@ class LangevinIntegrator:
                     f"Neighborlist cutoff ({nbr_list.cutoff}) must be the same as the potential cutoff ({potential.cutoff})"
                 )
 
+        chain_key = key
+        if isinstance(key, JaxKey) and noise is None and number_of_steps > 0:
+            # JAX-compatible stream: `key, subkey = random.split(key)`; `random.normal(subkey, x.shape)` per step
+            # (chiron/integrators.py:179,185), generated on the device and fed through the injected-noise path
+            n_atoms = x0.shape[0]
+            if number_of_steps * n_atoms * 12 > (1 << 30):
+                raise ValueError("the threefry-compatible stream materialises the noise of a whole run() call "
+                                 f"({number_of_steps} x {n_atoms} x 3 floats): split the run or use the Philox stream")
+            noise = torch.empty((number_of_steps, n_atoms, 3), dtype=torch.float32, device=x0.device)
+            for s_ in range(number_of_steps):
+                chain_key, subkey = split(chain_key)
+                ops.jax_normal(subkey, (n_atoms, 3), out=noise[s_])
         st = _RunState(self, potential, nbr_list, x0, v0, mass_unitless, kbT_unitless, half_dt, a, b, key, noise, mode)
         if spec0:
             st._unsettled = (nbr_list.ref_positions, v0, 0, 1)
@@ -205,7 +217,8 @@ class LangevinIntegrator:
             st._settle()
 
         updated_sampler_state = sampler_state._copy_with(st.positions_user(), st.velocities_user())  # :210-218
-        updated_sampler_state.current_PRNG_key = fold_in(key, number_of_steps)
+        # the reference returns the key its loop ended with (:216); the counter-based stream folds the step count in
+        updated_sampler_state.current_PRNG_key = chain_key if isinstance(key, JaxKey) else fold_in(key, number_of_steps)
         self.n_rebuilds = st.n_rebuilds
         return updated_sampler_state, st.nbr_list
 

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops, unit
-from .rng import PRNGKey
+from .rng import JaxKey, PRNGKey
 from .rng import uniform as host_uniform
 from .states import SamplerState, ThermodynamicState
 
@@ -250,6 +250,8 @@ class MonteCarloDisplacementMove(MCMove):
 
         if os.environ.get("CHX_MC_HOST_LOOP", "0") == "1":
             return False
+        if isinstance(sampler_state._current_PRNG_key, JaxKey):
+            return False  # the device-resident chain draws from Philox; the threefry stream takes the host loop
         cls = type(self)
         if (cls._propose is not MonteCarloDisplacementMove._propose or cls._step is not MCMove._step
                 or cls._accept_or_reject is not MCMove._accept_or_reject
@@ -427,9 +429,12 @@ class MonteCarloDisplacementMove(MCMove):
                 raise ValueError("box_vectors must be provided for a periodic system")
         else:
             box = ops.make_box(None, False)
+        normals = None
+        if isinstance(key, JaxKey):  # jrandom.normal(key, shape=(nr_of_atoms, 3)), :731
+            normals = ops.jax_normal(key, tuple(current_sampler_state.positions.shape), device=current_sampler_state.positions.device)
         proposed_sampler_state.positions = ops.mc_displace(
             current_sampler_state.positions, unitless_displacement_sigma, box, key, 0,
-            self.atom_subset_mask if self.atom_subset is not None else None,
+            self.atom_subset_mask if self.atom_subset is not None else None, normals,
         )
 
         if current_nbr_list is not None:

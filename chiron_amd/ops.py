@@ -450,6 +450,20 @@ def init_velocities(mass: torch.Tensor, kT: float, key: PRNGKey, normals: Option
     return v
 
 
+def jax_normal(key, shape, device=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``jax.random.normal(key, shape)`` for a threefry key (chiron_amd.rng.JaxKey), generated on the device."""
+    count = 1
+    for d in shape:
+        count *= int(d)
+    if out is None:
+        out = torch.empty(tuple(shape), dtype=torch.float32, device=device or "cuda")
+    _require_device(out)
+    if out.numel() != count or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("jax_normal: `out` must be a contiguous fp32 tensor of the requested shape")
+    check(_lib.load().chx_jax_normal(int(key[0]), int(key[1]), count, _ptr(out), _stream()), "chx_jax_normal")
+    return out
+
+
 def kick(v: torch.Tensor, f: torch.Tensor, mass: torch.Tensor, half_dt: float) -> None:
     _require_device(v, f, mass)
     check(_lib.load().chx_kick(_ptr(v), _ptr(f), _ptr(mass), v.shape[0], C.c_float(half_dt), _stream()), "chx_kick")

@@ -6,7 +6,14 @@ chiron/integrators.py:179,185).  Here a key is an opaque pair of 32-bit words;
 the device kernels draw from Philox4x32-10 keyed by that pair with the counter
 ``(particle_index, step, 0, stream_tag)``, so a trajectory never depends on how
 steps are batched into launches or on the internal particle ordering.  The JAX
-bit stream itself is not reproduced (parity unpinned).
+bit stream itself is not what the product draws from by default.
+
+Optional: ``PRNG.set_seed(seed, stream="threefry")`` hands out ``JaxKey``s instead.  ``split`` and
+``uniform`` then follow ``jax.random`` (classic threefry key handling, restated below from the published
+algorithm), and the integrator / moves draw their normals with ``ops.jax_normal`` (device kernel
+``chx_jax_normal``), so a run seeded like the reference consumes the reference's random numbers -- at the price
+of materialising the noise of a whole ``run()`` call, i.e. meant for reproducing reference results on small
+systems, not for production runs.
 """
 from __future__ import annotations
 
@@ -78,8 +85,63 @@ class PRNGKey(tuple):
         return f"PRNGKey(0x{self[0]:08x}, 0x{self[1]:08x})"
 
 
+class JaxKey(PRNGKey):
+    """A classic ``jax.random`` threefry key (two uint32 words); selects the JAX-compatible stream."""
+
+    @classmethod
+    def from_seed(cls, seed: int) -> "JaxKey":
+        seed = int(seed)  # jax.random.PRNGKey(seed) = (seed >> 32, seed & 0xFFFFFFFF)
+        return cls((seed >> 32) & _MASK, seed & _MASK)
+
+    def __repr__(self):
+        return f"JaxKey(0x{self[0]:08x}, 0x{self[1]:08x})"
+
+
+def _rotl(x: int, d: int) -> int:
+    return ((x << d) | (x >> (32 - d))) & _MASK
+
+
+def threefry2x32(key, x0: int, x1: int) -> Tuple[int, int]:
+    """One Threefry-2x32-20 block (Salmon, Moraes, Dror, Shaw, SC'11)."""
+    k0, k1 = int(key[0]) & _MASK, int(key[1]) & _MASK
+    ks = (k0, k1, k0 ^ k1 ^ 0x1BD11BDA)
+    rot = ((13, 15, 26, 6), (17, 29, 16, 24))
+    x0 = (x0 + ks[0]) & _MASK
+    x1 = (x1 + ks[1]) & _MASK
+    for i in range(5):
+        for r in rot[i % 2]:
+            x0 = (x0 + x1) & _MASK
+            x1 = _rotl(x1, r) ^ x0
+        x0 = (x0 + ks[(i + 1) % 3]) & _MASK
+        x1 = (x1 + ks[(i + 2) % 3] + i + 1) & _MASK
+    return x0, x1
+
+
+def _jax_bits(key, n: int):
+    """jax's random_bits for counters 0..n-1: halves in, concatenated halves out (odd n: one padding counter 0)."""
+    half = (n + 1) // 2
+    lo, hi = [], []
+    for b in range(half):
+        y0, y1 = threefry2x32(key, b, b + half if b + half < n else 0)
+        lo.append(y0)
+        hi.append(y1)
+    return (lo + hi)[:n]
+
+
+def _jax_split(key: "JaxKey") -> Tuple["JaxKey", "JaxKey"]:
+    b = _jax_bits(key, 4)  # jax.random.split(key, 2): bits reshaped (2, 2)
+    return JaxKey(b[0], b[1]), JaxKey(b[2], b[3])
+
+
+def _jax_uniform01(key: "JaxKey") -> float:
+    """float(jax.random.uniform(key)): 23 mantissa bits, [0, 1)."""
+    return (_jax_bits(key, 1)[0] >> 9) * (1.0 / 8388608.0)
+
+
 def split(key: PRNGKey) -> Tuple[PRNGKey, PRNGKey]:
-    """Return (new_key, subkey), the analogue of ``jax.random.split(key)``."""
+    """Return (new_key, subkey), the analogue of ``jax.random.split(key)`` (and exactly it for a JaxKey)."""
+    if isinstance(key, JaxKey):
+        return _jax_split(key)
     o = philox4x32((0, 0, 0, STREAM_SPLIT), key)
     return PRNGKey(o[0], o[1]), PRNGKey(o[2], o[3])
 
@@ -90,6 +152,10 @@ def fold_in(key: PRNGKey, data: int) -> PRNGKey:
 
 
 def uniform(key: PRNGKey, counter: int = 0) -> float:
-    """One (0,1) uniform from ``key`` -- the host twin of the device STREAM_UNIFORM draw."""
+    """One (0,1) uniform from ``key`` -- the host twin of the device STREAM_UNIFORM draw
+    (``jax.random.uniform(key)`` for a JaxKey; ``2 u - 1`` of it is jax's ``uniform(key, minval=-1, maxval=1)``
+    exactly, both being exact in fp32)."""
+    if isinstance(key, JaxKey):
+        return _jax_uniform01(key)
     o = philox4x32((0, int(counter) & _MASK, 0, STREAM_UNIFORM), key)
     return u32_to_uniform(o[0])

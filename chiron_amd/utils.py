@@ -8,7 +8,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import unit
-from .rng import PRNGKey, split
+from .rng import JaxKey, PRNGKey, split
 
 
 class PRNG:
@@ -18,9 +18,13 @@ class PRNG:
     _seed: int = None
 
     @classmethod
-    def set_seed(cls, seed: int) -> None:
+    def set_seed(cls, seed: int, stream: str = "philox") -> None:
+        """``stream="threefry"`` makes every key handed out a ``JaxKey``: splits, uniforms and normals then follow
+        ``jax.random`` (chiron/utils.py:29-38), reproducing the reference's draws (chiron_amd/rng.py)."""
+        if stream not in ("philox", "threefry"):
+            raise ValueError(f"unknown PRNG stream {stream!r} (philox | threefry)")
         cls._seed = seed
-        cls._key = PRNGKey.from_seed(seed)
+        cls._key = JaxKey.from_seed(seed) if stream == "threefry" else PRNGKey.from_seed(seed)
 
     @classmethod
     def get_random_key(cls) -> PRNGKey:
@@ -55,5 +59,8 @@ def initialize_velocities(temperature: unit.Quantity, topology, key: PRNGKey) ->
     kB = unit.BOLTZMANN_CONSTANT_kB * unit.AVOGADRO_CONSTANT_NA
     kbT_unitless = (kB * temperature).value_in_unit_system(unit.md_unit_system)
     mass_unitless = as_tensor(mass.value_in_unit_system(unit.md_unit_system))
-    v0 = ops.init_velocities(mass_unitless, float(kbT_unitless), key)
+    normals = None
+    if isinstance(key, JaxKey):  # random.normal(key, [len(mass), 3]), chiron/utils.py:142
+        normals = ops.jax_normal(key, (mass_unitless.shape[0], 3), device=mass_unitless.device)
+    v0 = ops.init_velocities(mass_unitless, float(kbT_unitless), key, normals)
     return v0 * (unit.nanometer / unit.picosecond)

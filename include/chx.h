@@ -217,6 +217,12 @@ int chx_lj_allpairs_energy_force(const float* xyz, int32_t n, chx_box_t box, flo
 int chx_init_velocities(float* v_out, const float* mass, int32_t n, float kT, uint32_t k0,
                         uint32_t k1, const float* normals, chx_stream_t stream);
 
+/* Optional JAX-compatible noise source: out[0..count) = jax.random.normal(key, (count,))
+ * for a classic threefry key (k0, k1) = the two uint32 words of the jax key -- what the reference draws at
+ * chiron/utils.py:142 (velocities), chiron/integrators.py:185 (O step) and chiron/mcmc.py:731 (displacements).
+ * Feed it to chx_init_velocities / the `noise` field / chx_mc_displace as injected normals. */
+int chx_jax_normal(uint32_t k0, uint32_t k1, int64_t count, float* out, chx_stream_t stream);
+
 /* v += (dt/2) F / m, chiron/integrators.py:181,195 */
 int chx_kick(float* v, const float* f, const float* mass, int32_t n, float half_dt,
              chx_stream_t stream);

@@ -129,6 +129,10 @@ int main() {
   EXPECT_INVALID(chx_lj_allpairs_energy_force(F, -1, ok_box, 0.34f, 1.f, 1.02f, F, F, d.data(), nullptr));
   EXPECT_INVALID(chx_init_velocities(F, F, -1, 2.5f, 1u, 2u, nullptr, nullptr));
   EXPECT_INVALID(chx_kick(F, F, F, -1, 5e-4f, nullptr));
+  EXPECT_INVALID(chx_jax_normal(1u, 2u, -1, F, nullptr));
+  EXPECT_INVALID(chx_jax_normal(1u, 2u, (int64_t)1 << 33, F, nullptr));
+  EXPECT_INVALID(chx_jax_normal(1u, 2u, 8, nullptr, nullptr));
+  EXPECT(chx_jax_normal(1u, 2u, 0, nullptr, nullptr) == CHX_OK);
   EXPECT_INVALID(chx_baoab_step(F, F, F, F, -1, ok_box, 1, 5e-4f, 0.99f, 0.04f, 2.5f, F, 0.5f, 1u, 2u, 0u, nullptr, I, nullptr));
   EXPECT_INVALID(chx_mc_displace(F, F, nullptr, -1, 0.1f, ok_box, 1u, 2u, 0u, nullptr, nullptr));
   EXPECT_INVALID(chx_scale(F, F, -1, 1.1f, nullptr));

@@ -1475,6 +1475,74 @@ def test_barostat_reference_literal_on_the_product_move(ca, golden, monkeypatch)
     assert list(accepted) == decisions
 
 
+def test_jax_normal_kernel_matches_restated_jax_stream(ca):
+    """chx_jax_normal == oracle/jax_prng.normal (NumPy restatement pinned by the reference's literals) for even and
+    odd element counts (jax pads the counter array to an even length and splits it in halves)."""
+    from oracle import jax_prng as JX
+    from chiron_amd.rng import JaxKey
+
+    for key, shape in (((0, 1234), (1, 3)), ((603280156, 445306386), (7, 3)), ((5, 6), (500, 3)), ((9, 9), (64, 3))):
+        got = ca.ops.jax_normal(JaxKey(*key), shape).cpu().numpy()
+        want = JX.normal(key, shape)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 4e-6, (key, shape, np.abs(got - want).max())
+    z = ca.ops.jax_normal(JaxKey(1, 2), (200000, 3)).cpu().numpy().astype(np.float64)
+    assert abs(z.mean()) < 5e-3 and abs(z.std() - 1.0) < 5e-3
+    with pytest.raises(ValueError):
+        ca.ops.jax_normal(JaxKey(1, 2), (4, 3), out=torch.empty((5, 3), device="cuda"))
+
+
+def test_reference_literals_through_the_public_api_with_the_threefry_stream(ca, golden):
+    """SURVEY.md 8f-4 in the PRODUCT: with `PRNG.set_seed(1234, stream="threefry")` the two tests of the reference
+    that depend on its JAX stream run as written in the reference -- no injected noise, no patched draws:
+    chiron/tests/test_mcmc.py:12-84 (five Langevin energies of a harmonic oscillator, refresh_velocities=True) and
+    :340-452 (8 of 10 barostat moves accepted)."""
+    from chiron_amd.potential import HarmonicOscillatorPotential
+    from chiron_amd.reporters import LangevinDynamicsReporter
+    from chiron_amd.rng import JaxKey
+    from chiron_amd.topology import Topology
+
+    u = ca.unit
+    try:
+        g = golden["langevin_ho_jax_prng"]
+        pot = HarmonicOscillatorPotential(Topology.homogeneous(1, "Ar"), g["k_kcal_mol_A2"] * u.kilocalories_per_mole / u.angstrom**2)
+        thermo = ca.states.ThermodynamicState(potential=pot, temperature=g["temperature_K"] * u.kelvin)
+        ca.utils.PRNG.set_seed(g["seed"], stream="threefry")
+        state = ca.states.SamplerState(positions=nm(np.zeros((1, 3), f32), ca), current_PRNG_key=ca.utils.PRNG.get_random_key())
+        assert isinstance(state.current_PRNG_key, JaxKey)
+        reporter = LangevinDynamicsReporter()
+        integ = ca.integrators.LangevinIntegrator(timestep=g["timestep_fs"] * u.femtosecond, reporter=reporter, report_interval=1,
+                                                  refresh_velocities=True)
+        out, _ = integ.run(state, thermo, number_of_steps=5)
+        reporter.flush_buffer()
+        energy = np.asarray(reporter.get_property("potential_energy"), dtype=np.float64).ravel()
+        assert np.allclose(energy, np.array(g["potential_energy"]), rtol=g["rtol"], atol=1e-8), energy
+        assert isinstance(out.current_PRNG_key, JaxKey)
+
+        g = golden["barostat_ideal_gas_jax_prng"]
+        positions = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 0], [1, 0, 1], [0, 1, 1], [1, 1, 1]], f32)
+        L = g["box_nm"]
+        pot = ca.potential.IdealGasPotential(Topology.homogeneous(g["n_particles"]))
+        ca.utils.PRNG.set_seed(g["seed"], stream="threefry")
+        state = ca.states.SamplerState(nm(positions, ca), ca.utils.PRNG.get_random_key(), box_vectors=nm(np.diag([L, L, L]).astype(f32), ca))
+        thermo = ca.states.ThermodynamicState(pot, temperature=g["temperature_K"] * u.kelvin, pressure=g["pressure_atm"] * u.atmosphere)
+        rep = ca_reporter(ca)
+        move = ca.mcmc.MonteCarloBarostatMove(volume_max_scale=g["volume_max_scale"], number_of_moves=g["n_proposed"],
+                                              reporter=rep, report_interval=1)
+        nbr = ca.neighbors.PairListNsqrd(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=0 * u.nanometer)
+        state, thermo, nbr = move.update(state, thermo, nbr)
+        pe = rep.get_property("potential_energy")
+        assert pe[0] == 0 and pe[-1] == 0
+        assert move.statistics == {"n_accepted": g["n_accepted"], "n_proposed": g["n_proposed"]}  # 8 of 10
+        # a displacement move on the same stream: normals from jrandom.normal(key, (N, 3)) (chiron/mcmc.py:731), host loop
+        disp = ca.mcmc.MonteCarloDisplacementMove(displacement_sigma=0.1 * u.nanometer, number_of_moves=3)
+        assert not disp._device_loop_applies(state, thermo, nbr)
+        s2, _, _ = disp.update(state, thermo, nbr)
+        assert isinstance(s2.current_PRNG_key, JaxKey) and disp.statistics["n_accepted"] == 3
+    finally:
+        ca.utils.PRNG.set_seed(1234)  # back to the product's default stream for the tests that follow
+
+
 def test_metropolis_select_kernel(ca):
     from chiron_amd.rng import PRNGKey
 

@@ -481,3 +481,45 @@ def test_build_is_keyed_on_a_source_hash_not_on_mtimes(monkeypatch):
         _lib.load()
     monkeypatch.setenv("CHX_ALLOW_STALE_LIB", "1")
     assert _lib.load() is not None
+
+
+def test_threefry_stream_host_twins_follow_jax():
+    """chiron_amd.rng's JaxKey handling (product code) against the Random123 known answers and against the oracle's
+    independent NumPy restatement of jax.random (oracle/jax_prng.py, pinned by the reference's literals)."""
+    from chiron_amd import rng
+    from oracle import jax_prng as JX
+
+    # Random123 kat_vectors, threefry2x32 20 rounds
+    assert rng.threefry2x32((0, 0), 0, 0) == (0x6B200159, 0x99BA4EFE)
+    assert rng.threefry2x32((0xFFFFFFFF, 0xFFFFFFFF), 0xFFFFFFFF, 0xFFFFFFFF) == (0x1CB996FC, 0xBB002BE7)
+    assert rng.threefry2x32((0x13198A2E, 0x03707344), 0x243F6A88, 0x85A308D3) == (0xC4923A9C, 0x483DF7A0)
+    for seed in (0, 1234, 2**33 + 17):
+        k = rng.JaxKey.from_seed(seed)
+        assert tuple(k) == JX.PRNGKey(seed)
+        for _ in range(3):
+            new, sub = rng.split(k)
+            a, b = JX.split(tuple(k))
+            assert isinstance(new, rng.JaxKey) and isinstance(sub, rng.JaxKey)
+            assert tuple(new) == a and tuple(sub) == b
+            assert rng.uniform(sub) == float(JX.uniform(b))
+            assert 2.0 * rng.uniform(sub) - 1.0 == float(JX.uniform(b, (), -1.0, 1.0))
+            for n in (1, 2, 5, 8):
+                assert rng._jax_bits(sub, n) == [int(v) for v in JX.random_bits(b, n)]
+            k = new
+    # the default stream is untouched and the two key types do not mix
+    p = rng.PRNGKey(1, 2)
+    assert type(rng.split(p)[0]) is rng.PRNGKey and rng.split(p) != rng.split(rng.JaxKey(1, 2))
+    PRNG.set_seed(7, stream="threefry")
+    try:
+        k1 = PRNG.get_random_key()
+        assert isinstance(k1, rng.JaxKey) and tuple(k1) == JX.split(JX.PRNGKey(7))[1]
+        st = SamplerState(unit.Quantity(np.zeros((2, 3)), unit.nanometer), k1)
+        sub = st.new_PRNG_key  # chiron/states.py:150-154 on the jax stream
+        assert tuple(sub) == JX.split(tuple(k1))[1] and tuple(st.current_PRNG_key) == JX.split(tuple(k1))[0]
+        import copy as _copy
+
+        assert isinstance(_copy.deepcopy(st).current_PRNG_key, rng.JaxKey)
+        with pytest.raises(ValueError):
+            PRNG.set_seed(1, stream="mt19937")
+    finally:
+        PRNG.set_seed(1234)
