@@ -58,6 +58,11 @@ def parse():
     ap.add_argument("--steady-steps", type=int, default=20000,
                     help="timed steps of the steady-state figure reported next to `value` (0 = skip)")
     ap.add_argument("--steady-warmup", type=int, default=2000)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend of the real run (nccl = RCCL over xGMI; gloo only for rehearsals)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a box with fewer GPUs than ranks: rank r uses device r mod device_count (RCCL "
+                         "refuses two ranks on one device, so combine with --backend gloo); the line says shared_gpu")
     ap.add_argument("--dry-run-backend", default=None, choices=["gloo"],
                     help="launcher/plumbing rehearsal without a GPU: ranks form a gloo group, skip every kernel "
                          "and run the replica-exchange collective on synthetic energies (the line says dry_run)")
@@ -365,6 +370,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs the MI355X: no CUDA/ROCm device visible (there is no CPU fallback)")
+    if args.share_gpu:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     # The host side of this path only launches kernels.  torch's intra-op CPU pool (one thread per
     # visible core) must not wake up inside a CPU-quota'd container: the burst gets the whole
@@ -376,7 +383,11 @@ def main():
     # RCCL path (init, barrier, all-reduce, all-gather) can be exercised on a single-GPU box
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
     if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"  # where the timing collectives live
     exchange_on = world > 1 or (use_dist and os.environ.get("CHX_BENCH_EXCHANGE", "0") == "1")
 
     from chiron_amd import _lib, ops, unit
@@ -423,8 +434,8 @@ def main():
         mine = time.perf_counter() - t0
         per_rank = [mine]
         if use_dist:
-            t = torch.tensor([mine], dtype=torch.float64, device="cuda")
-            out = torch.empty(world, dtype=torch.float64, device="cuda")
+            t = torch.tensor([mine], dtype=torch.float64, device=coll_dev)
+            out = torch.empty(world, dtype=torch.float64, device=coll_dev)
             dist.all_gather_into_tensor(out, t)
             per_rank = [float(v) for v in out.cpu()]
         return st, max(per_rank), per_rank, exchanges, nbr.n_builds - builds0
@@ -481,9 +492,11 @@ def main():
                 "n_particles": n,
                 "replicas": world,
                 "parallelism": f"{world} independent replica(s), one per GPU" + (
-                    f", label exchange every {args.exchange_interval} steps via one RCCL all-gather" if world > 1 else ""),
+                    f", label exchange every {args.exchange_interval} steps via one "
+                    f"{'RCCL' if args.backend == 'nccl' else args.backend} all-gather" if world > 1 else ""),
                 "group_world_size": dist.get_world_size() if use_dist else 1,
                 "collective_backend": (dist.get_backend() if use_dist else None),
+                "shared_gpu": bool(args.share_gpu),
                 "per_rank_steps_per_s": [round(args.steps / t, 2) for t in per_rank],
                 "chunk_steps": args.chunk,
                 "list_rebuilds_in_timed_region": rebuilds,

@@ -122,6 +122,8 @@ class ReplicaExchange:
         e = energy.detach().reshape(1).to(torch.float64)
         if self.world_size == 1 and not (dist.is_available() and dist.is_initialized()):
             return e.cpu().numpy()
+        if dist.get_backend() == "gloo":
+            e = e.cpu()  # gloo gathers host tensors (CPU tests, single-GPU rehearsals); RCCL gathers in place on the device
         out = torch.empty(self.world_size, dtype=torch.float64, device=e.device)
         dist.all_gather_into_tensor(out, e)
         return out.cpu().numpy()

@@ -265,3 +265,31 @@ def test_step_kernel_step_63_matches_oracle_at_full_size(ca, O, n):
     assert np.abs(xb[idx] - xa[idx]).max() > 1e-5
     # and the system is a sane 300 K fluid after 64 steps
     assert abs((39.948 * vb.astype(np.float64) ** 2).mean() / kT - 1.0) < 0.05
+
+
+def test_c5_replica_exchange_rehearsal_four_replicas_on_one_gpu():
+    """Config C5's workflow on real kernels with the one GPU this box has: `bench.py --gpus 4` launches four ranks
+    itself (no torchrun), each propagating its own C3 replica (temperature ladder) with the HIP kernels on the shared
+    device and exchanging labels every 1000 steps; the collective runs over gloo because RCCL refuses two ranks on
+    one device -- the RCCL transport itself is what the driver's 8-GPU run exercises."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--backend", "gloo", "--share-gpu",
+                          "--steps", "3000", "--warmup", "200", "--steady-steps", "0", "--cpu-steps", "0", "--extra-c4", "0"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [json.loads(l) for l in res.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = lines[0]
+    cfg = d["config"]
+    assert d["n_gpus"] == 4 and cfg["group_world_size"] == 4 and cfg["collective_backend"] == "gloo" and cfg["shared_gpu"]
+    assert cfg["replica_exchanges"] == 3 and len(cfg["per_rank_steps_per_s"]) == 4
+    assert all(v > 1000 for v in cfg["per_rank_steps_per_s"])  # every rank really stepped its replica
+    assert d["value"] > 4 * 1000 and d["scaling"] == "weak"
+    assert cfg["swap_acceptance"] is not None and 0.0 <= cfg["swap_acceptance"] <= 1.0
+    assert d["roofline"]["kernel_us"] > 0
