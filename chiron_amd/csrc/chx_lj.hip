@@ -407,6 +407,26 @@ __device__ __forceinline__ int pinned_load4(const int32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
+// write-through stores (see step_epilogue)
+typedef float f3v __attribute__((ext_vector_type(3)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_wt4(float4* p, float4 v) {
+#ifdef CHX_EXP_PLAIN_STORES
+  *p = v;
+#else
+  const f4v t = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+#endif
+}
+__device__ __forceinline__ void store_wt3(float* p, float a, float b, float c) {
+#ifdef CHX_EXP_PLAIN_STORES
+  p[0] = a, p[1] = b, p[2] = c;
+#else
+  const f3v t = {a, b, c};
+  asm volatile("global_store_dwordx3 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+#endif
+}
+
 // what row_begin has in flight for one lane
 struct RowLoads {
   float4 xi;
@@ -560,11 +580,7 @@ __global__ __launch_bounds__(256) void k_lj_fl(const float4* __restrict__ x4,
     }
     if (WANT_E) en += __shfl_xor(en, o, CHX_WAVE);
   }
-  if (WANT_F && valid && q == 0) {
-    f3[3 * (size_t)p] = fx;
-    f3[3 * (size_t)p + 1] = fy;
-    f3[3 * (size_t)p + 2] = fz;
-  }
+  if (WANT_F && valid && q == 0) store_wt3(f3 + 3 * (size_t)p, fx, fy, fz);  // write-through: see step_epilogue
   if (WANT_E) {
     // every pair is visited from both ends
     double mine = (valid && q == 0) ? 0.5 * (double)en : 0.0;
@@ -780,10 +796,12 @@ __device__ __forceinline__ bool step_epilogue(const StepArgs& a, const StepParti
         (void)integrate_component<false, HOT>(a, n_kicks, do_aoa, sF[3 * threadIdx.x + c], tk.m, tk.bs, tk.z[c], tk.v[c],
                                          xo[c], rf[c], ri[c], L[c], hL[c], vn[c], xn[c], sq[c], sqi[c]);
     }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) a.v[3 * (size_t)tk.pp + c] = vn[c];
+    // The step's results leave as WRITE-THROUGH stores (sc1): nothing the next launch needs stays dirty in
+    // this XCD's L2, so the write-back at the kernel boundary has nothing to do (the boundary costs about
+    // B / 6 TB/s for B dirty bytes: 7.3 MB at N = 262144), and the next launch finds L2 cold either way.
+    store_wt3(a.v + 3 * (size_t)tk.pp, vn[0], vn[1], vn[2]);
     if (do_aoa) {
-      reinterpret_cast<float4*>(a.x_next)[tk.pp] = make_float4(xn[0], xn[1], xn[2], 0.f);
+      store_wt4(reinterpret_cast<float4*>(a.x_next) + tk.pp, make_float4(xn[0], xn[1], xn[2], 0.f));
       // skin check :241: (rx^2 + ry^2) + rz^2 in the reference's order
       if ((HOT || a.ref4) && fadd(fadd(sq[0], sq[1]), sq[2]) > a.T_half_skin) atomicMin(&a.ctrl[3], (int)(step + 1));
       if ((HOT || a.fli) && (sqi[0] + sqi[1]) + sqi[2] > a.T_half_inner) stale = true;
@@ -791,6 +809,36 @@ __device__ __forceinline__ bool step_epilogue(const StepArgs& a, const StepParti
   }
   return stale;
 }
+
+#ifdef CHX_EXP_STAMPS
+// Diagnostic build only (scripts/exp_stamps.sh): wave 0 of every block records where its time goes.
+// g_stamps[slot][block][0..7]: s_memtime at entry / first row loads back / first gathers back / force loop done /
+// after the barrier / end, then s_memrealtime (100 MHz) at entry and at the end.  slot = step & 3.
+#define CHX_STAMP_BLOCKS 4096
+__device__ unsigned long long g_stamps[4][CHX_STAMP_BLOCKS][8];
+__device__ __forceinline__ unsigned long long stamp_clk() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+__device__ __forceinline__ unsigned long long stamp_rt() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+extern "C" int chx_debug_read_stamps(unsigned long long* out_h) {
+  return hipMemcpyFromSymbol(out_h, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : -1;
+}
+#define CHX_STAMP(i, v) do { if (threadIdx.x == 0 && blk < CHX_STAMP_BLOCKS) g_stamps[step & 3][blk][i] = (v); } while (0)
+#define CHX_STAMP_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define CHX_STAMP(i, v) do { } while (0)
+#define CHX_STAMP_WAIT() do { } while (0)
+#endif
 
 // PRUNE: the launch that refreshes the dynamically pruned inner list (see below): it walks the FULL
 // force list and, next to the forces, copies the entries with |r| < cutoff + inner_skin into the
@@ -812,6 +860,10 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   a.x_cur = x_lead;
   constexpr int PPB = 256 / G;  // particles per block (<= 256)
   const unsigned blk = xcd_block(blockIdx.x, nblocks);
+#ifdef CHX_EXP_STAMPS
+  CHX_STAMP(6, stamp_rt());
+  CHX_STAMP(0, stamp_clk());
+#endif
   const int tid = blk * 256 + threadIdx.x;
   const int p = tid / G;
   const int q = tid % G;
@@ -869,9 +921,18 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   if (G == 1) finish_step_particle<HOT>(a, step, do_aoa, tk);
   // the speculated list is the one to walk (launch-uniform; the steady state): adopt what is in flight.
   // Otherwise (inner list gone stale since the host chose) the row is loaded again from the right table.
+#ifdef CHX_EXP_STAMPS
+  CHX_STAMP_WAIT();  // first row loads (and the integrate operands) are back
+  CHX_STAMP(1, stamp_clk());
+#endif
   RowLoads rl = (fl_use == sfl) ? lj_row_adopt<G>(a.x_cur, scol, pc_s, s_xi, s_d, s_e4)
                                 : lj_row_begin<G>(a.x_cur, fl_use, deg_use, a.n, p, q, valid);
   if (G > 1) finish_step_particle<HOT>(a, step, do_aoa, tk);
+#ifdef CHX_EXP_STAMPS
+  CHX_STAMP(7, stamp_clk());  // (slot 7 reused: Philox done, gathers still in flight)
+  CHX_STAMP_WAIT();           // first gathers are back
+  CHX_STAMP(2, stamp_clk());
+#endif
   if (PRUNE) {
     constexpr int W = 4 * G;
     int kept = 0;
@@ -893,6 +954,7 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
 #else
   finish_step_particle<HOT>(a, step, do_aoa, tk);
 #endif
+  CHX_STAMP(3, stamp_clk());
 #pragma unroll
   for (int o = G / 2; o > 0; o >>= 1) {
     fx += __shfl_xor(fx, o, CHX_WAVE);
@@ -906,11 +968,17 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
     sF[3 * pl + 2] = fz;
   }
   __syncthreads();
+  CHX_STAMP(4, stamp_clk());
   // ---- integrate: one particle per thread, packed into the first PPB threads of the block ----
   const bool stale = step_epilogue<HOT>(a, tk, sF, step, n_kicks, do_aoa);
   // the inner list stays off until the next refresh (a new epoch) outdates the word
   if (do_aoa && (HOT || a.fli) && epoch >= 0 && (stale || (!inner && !PRUNE && threadIdx.x == 0)))
     a.ctrl[4 + (int)((step + 1) & 1)] = epoch;
+#ifdef CHX_EXP_STAMPS
+  CHX_STAMP(5, stamp_clk());
+  // (slot 6 holds the entry real-time stamp; the end one goes to a second array row via slot arithmetic)
+  if (threadIdx.x == 0 && blk < CHX_STAMP_BLOCKS) g_stamps[step & 3][blk][6] = (g_stamps[step & 3][blk][6] & 0xFFFFFFFFull) | (stamp_rt() << 32);
+#endif
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (PRUNE) a.ctrl[7] += 1;                                // refreshes of the inner list
     else if ((HOT || a.fli) && !inner) a.ctrl[6] += 1;        // launches on the full list
