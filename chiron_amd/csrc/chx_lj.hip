@@ -407,6 +407,37 @@ __device__ __forceinline__ int pinned_load4(const int32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
+// Sum over the G lanes that share a particle, result in every lane of the group.  Levels inside a row of 16
+// lanes use DPP operand swizzles (quad permutes, half-row / row mirror: no LDS crossbar round trip as with
+// ds_bpermute); wider groups finish with shuffles.  Fixed association, the same in every kernel.
+__device__ __forceinline__ float dpp_f(float v, const int ctrl_sel) {
+  const int i = __float_as_int(v);
+  int r;
+  switch (ctrl_sel) {
+    case 0: r = __builtin_amdgcn_update_dpp(i, i, 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]: lane ^ 1
+    case 1: r = __builtin_amdgcn_update_dpp(i, i, 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]: lane ^ 2
+    case 2: r = __builtin_amdgcn_update_dpp(i, i, 0x141, 0xF, 0xF, true); break;  // row_half_mirror: 7 - lane in 8
+    default: r = __builtin_amdgcn_update_dpp(i, i, 0x140, 0xF, 0xF, true); break; // row_mirror: 15 - lane in 16
+  }
+  return __int_as_float(r);
+}
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#ifdef CHX_EXP_SHFL_REDUCE
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, CHX_WAVE);
+  return v;
+#else
+  if (G >= 2) v += dpp_f(v, 0);
+  if (G >= 4) v += dpp_f(v, 1);   // every lane of a quad now holds the quad's sum
+  if (G >= 8) v += dpp_f(v, 2);   // ... of a half row
+  if (G >= 16) v += dpp_f(v, 3);  // ... of a row
+#pragma unroll
+  for (int o = 16; o < G; o <<= 1) v += __shfl_xor(v, o, CHX_WAVE);
+  return v;
+#endif
+}
+
 // write-through stores (see step_epilogue)
 typedef float f3v __attribute__((ext_vector_type(3)));
 typedef float f4v __attribute__((ext_vector_type(4)));
@@ -571,15 +602,8 @@ __global__ __launch_bounds__(256) void k_lj_fl(const float4* __restrict__ x4,
   float4 xi;
   float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
   lj_row<G>(x4, fl, deg, n, chunks, p, q, valid, box, lj, xi, fx, fy, fz, en);
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) {
-    if (WANT_F) {
-      fx += __shfl_xor(fx, o, CHX_WAVE);
-      fy += __shfl_xor(fy, o, CHX_WAVE);
-      fz += __shfl_xor(fz, o, CHX_WAVE);
-    }
-    if (WANT_E) en += __shfl_xor(en, o, CHX_WAVE);
-  }
+  if (WANT_F) fx = group_sum<G>(fx), fy = group_sum<G>(fy), fz = group_sum<G>(fz);
+  if (WANT_E) en = group_sum<G>(en);
   if (WANT_F && valid && q == 0) store_wt3(f3 + 3 * (size_t)p, fx, fy, fz);  // write-through: see step_epilogue
   if (WANT_E) {
     // every pair is visited from both ends
@@ -955,12 +979,7 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   finish_step_particle<HOT>(a, step, do_aoa, tk);
 #endif
   CHX_STAMP(3, stamp_clk());
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) {
-    fx += __shfl_xor(fx, o, CHX_WAVE);
-    fy += __shfl_xor(fy, o, CHX_WAVE);
-    fz += __shfl_xor(fz, o, CHX_WAVE);
-  }
+  fx = group_sum<G>(fx), fy = group_sum<G>(fy), fz = group_sum<G>(fz);
   if (q == 0) {
     const int pl = threadIdx.x / G;
     sF[3 * pl] = fx;
