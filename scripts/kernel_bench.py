@@ -34,7 +34,11 @@ for wl in sys.argv[1:] or ["c3", "c4"]:
         else:
             os.environ["CHX_FL_G"] = g
         fluid, pot, state, thermo, nbr, integ = bench.make_system(wl, 300.0, 32, "cell")
-        nbr.build_from_state(state)
+        warm = int(os.environ.get("KB_WARM", "0"))  # measure on an equilibrated state instead of the lattice start
+        if warm:
+            state, nbr = integ.run(state, thermo, number_of_steps=warm, nbr_list=nbr)
+        if not (warm and os.environ.get("KB_KEEP_LIST")):  # KB_KEEP_LIST: time on the list the run ended with
+            nbr.build_from_state(state)
         fl = nbr.force_list
         n = fl.n
         p_nl = int(nbr.n_neighbors.sum())
@@ -51,7 +55,7 @@ for wl in sys.argv[1:] or ["c3", "c4"]:
         from chiron_amd.utils import get_list_of_mass
         from chiron_amd._device import as_tensor
         mass = as_tensor(get_list_of_mass(fluid.topology).value_in_unit_system(unit.md_unit_system))
-        v0 = torch.zeros((n, 3), device="cuda")
+        v0 = state.velocities if state.velocities is not None else torch.zeros((n, 3), device="cuda")
         st = _RunState(integ, pot, nbr, state.positions, v0, mass, 2.494, half_dt, a, b, state.current_PRNG_key, None, "fused")
         st.params.skin = 1e6
         step = [0]
