@@ -199,7 +199,7 @@ class LangevinIntegrator:
         while done < number_of_steps:
             stop = next_stop(done)
             before = done
-            done = st.advance_to(done, stop)
+            done = st.advance_to(done, stop, final=(stop == number_of_steps))
             if bar is not None:
                 bar.update(done - before)
             last = done - 1
@@ -469,15 +469,24 @@ class _RunState:
         self.integ.prune_passes = getattr(self.integ, "prune_passes", 0) + getattr(self, "_seen_prune", 0)
         self._seen_full = self._seen_prune = 0
 
-    def _advance_fused(self, done: int, stop: int) -> int:
+    def _advance_fused(self, done: int, stop: int, final: bool = False) -> int:
         chunk = self.integ.chunk_size
         pending = collections.deque()
         nxt = done
+        self._kick_rec = None
         while done < stop:
             while len(pending) < self.depth and nxt < stop:
                 c = min(chunk, stop - nxt)
                 pending.append(self._enqueue_fused(nxt, c))
                 nxt += c
+            if final and nxt == stop and self._kick_rec is None:
+                # every step of the run is enqueued: the trailing half-kick (chiron/integrators.py:195) rides right
+                # behind them instead of waiting for the host to read the last chunk's control block.  Like every
+                # launch of a chunk it turns into a no-op if the skin check fires first (step index = stop).
+                keep = self.kicks_next
+                self.kicks_next = 1
+                self._kick_rec = self._enqueue_fused(stop, 1, do_aoa=0)
+                self.kicks_next = keep
             rec = pending.popleft()
             if _TRACE_RUN:
                 import time as _t
@@ -493,6 +502,7 @@ class _RunState:
             if not self._settle():
                 # the speculative rebuild before this chunk overflowed a capacity: redo from its step
                 pending.clear()
+                self._kick_rec = None
                 done = nxt = self._unsettled_step
                 continue
             halt = int(rec.host[3])
@@ -501,13 +511,15 @@ class _RunState:
                 # skin check fired while producing x_halt: steps < halt ran, everything queued behind is a
                 # no-op; the rebuild is enqueued behind those launches, nothing waits for them
                 pending.clear()
+                self._kick_rec = None  # (it ran as a no-op)
                 self.parity = rec.parity0 ^ ((halt - rec.s0) & 1)
                 self._bank_inner_stats()
                 self._rebuild(halt, speculative=True)
                 done = nxt = halt
             else:
                 done = rec.s0 + rec.n
-        self._settle()  # a rebuild at the very last step: nothing ran on its list yet
+        if not self._settle():  # a rebuild at the very last step: nothing ran on its list yet
+            self._kick_rec = None
         return done
 
     # -- other paths -------------------------------------------------------
@@ -519,10 +531,11 @@ class _RunState:
         else:
             self.f.fill_(float(F))
 
-    def advance_to(self, done: int, stop: int) -> int:
-        """Run steps [done, stop); returns the new step count (== stop)."""
+    def advance_to(self, done: int, stop: int, final: bool = False) -> int:
+        """Run steps [done, stop); returns the new step count (== stop).  ``final``: ``stop`` is the end of the
+        run (the fused path then enqueues the trailing kick behind the last chunk, see ``final_kick``)."""
         if self.mode == "fused":
-            return self._advance_fused(done, stop)
+            return self._advance_fused(done, stop, final)
         if self.mode == "pairs":
             # all-pairs force + BAOAB in one launch per step (k_ap_step); no skin check exists on this
             # path (PairListNsqrd.check only looks at N), so nothing halts and nothing is read back
@@ -548,8 +561,11 @@ class _RunState:
     def final_kick(self, n_steps: int):
         """Trailing half-kick of the last step (chiron/integrators.py:195)."""
         if self.mode == "fused":
-            self.kicks_next = 1
-            rec = self._enqueue_fused(n_steps, 1, do_aoa=0)
+            rec = getattr(self, "_kick_rec", None)  # already in flight behind the last chunk?
+            self._kick_rec = None
+            if rec is None:
+                self.kicks_next = 1
+                rec = self._enqueue_fused(n_steps, 1, do_aoa=0)
             rec.event.synchronize()
             self._seen_full, self._seen_prune = int(rec.host[6]), int(rec.host[7])
             self._bank_inner_stats()
