@@ -1648,3 +1648,65 @@ def test_mc_device_loop_yields_to_overridden_bookkeeping(ca, O):
             return super()._report(*a, **k)
 
     assert not Custom2(number_of_moves=1)._device_loop_applies(state, thermo, nbr)
+
+
+def test_reference_mcmc_workflows_on_a_harmonic_oscillator(ca, O):
+    """The MCMC-class workflows of chiron/tests/test_mcmc.py:87-286 on the product, with nbr_list=None (no wrap, no
+    list: chiron/mcmc.py:756-770) and a generic (non-LJ) potential -- the host-shaped trial loop:
+    (1) LangevinDynamicsMove inside MCMCSampler (:87-165); (2) MonteCarloDisplacementMove with atom_subset=[0] on
+    one particle (:166-226); (3) the same move on a HarmonicOscillatorArray (:227-286).  (2) and (3) are followed
+    trial by trial by the oracle's chain (same key splits, oracle normals, HO energy in NumPy)."""
+    from chiron_amd.potential import HarmonicOscillatorPotential
+    from chiron_amd.reporters import LangevinDynamicsReporter
+    from chiron_amd.topology import Topology
+
+    u = ca.unit
+    k_q = 100.0 * u.kilocalories_per_mole / u.angstrom**2  # openmmtools HarmonicOscillator default K
+    k_md = 100.0 * 4.184 / 0.01
+    T = 300.0
+
+    def ho_energy(x64):
+        return float(f32(0.5 * k_md) * np.sum((x64 * x64).astype(f32), dtype=f32))
+
+    # (1) Langevin dynamics as an MCMC move
+    pot = HarmonicOscillatorPotential(Topology.homogeneous(1, "Ar"), k_q)
+    thermo = ca.states.ThermodynamicState(pot, temperature=T * u.kelvin, volume=30 * u.angstrom**3)
+    ca.utils.PRNG.set_seed(1234)
+    state = ca.states.SamplerState(nm(np.zeros((1, 3), f32), ca), current_PRNG_key=ca.utils.PRNG.get_random_key())
+    rep = LangevinDynamicsReporter()
+    move = ca.mcmc.LangevinDynamicsMove(number_of_steps=10, refresh_velocities=True, reporter=rep, report_interval=1)
+    sampler = ca.mcmc.MCMCSampler(ca.mcmc.MoveSchedule([("LangevinMove", move)]))
+    s1, _, _ = sampler.run(state, thermo, n_iterations=2)
+    rep.flush_buffer()
+    assert np.asarray(rep.get_property("potential_energy")).shape[0] == 20 and np.isfinite(s1.positions.cpu().numpy()).all()
+
+    # (2) + (3): displacement moves, chain vs oracle
+    for n_part, subset in ((1, [0]), (5, None)):
+        x0 = np.zeros((n_part, 3), f32)
+        x0[:, 0] = np.arange(n_part, dtype=f32)  # HarmonicOscillatorArray: particles spaced along x, each bound to its site
+        pot = HarmonicOscillatorPotential(Topology.homogeneous(n_part, "Ar"), k_q, x0=u.Quantity(x0.astype(np.float64), u.nanometer))
+        thermo = ca.states.ThermodynamicState(pot, temperature=T * u.kelvin, volume=30 * u.angstrom**3)
+        ca.utils.PRNG.set_seed(1234)
+        state = ca.states.SamplerState(nm(x0, ca), current_PRNG_key=ca.utils.PRNG.get_random_key())
+        key = tuple(state._current_PRNG_key)
+        rep = ca_reporter(ca)
+        mv = ca.mcmc.MonteCarloDisplacementMove(number_of_moves=10, displacement_sigma=0.1 * u.angstrom, atom_subset=subset,
+                                                reporter=rep, report_interval=1)
+        sampler = ca.mcmc.MCMCSampler(ca.mcmc.MoveSchedule([("MonteCarloDisplacementMove", mv)]))
+        s2, _, n2 = sampler.run(state, thermo, n_iterations=2)
+        assert n2 is None and mv.statistics["n_proposed"] == 20
+        mask = None
+        if subset is not None:
+            mask = np.zeros(n_part, f32)
+            mask[subset] = 1.0
+        x, cnt, log = x0.copy(), (0, 0, 0), []
+        for _ in range(2):
+            x, _, key, _, cnt, lg = O.mc_displacement_update(x, None, None, key, 1.0, 1.0, T, 0.01, 10, subset_mask=mask,
+                                                             counters=cnt, energy_fn=lambda xx, ll: ho_energy(xx - x0))
+            log += lg
+        assert np.array_equal(_decisions_from_reports(rep), np.array([l["accepted"] for l in log]))
+        assert mv.statistics == dict(n_accepted=cnt[0], n_proposed=cnt[1])
+        assert tuple(s2._current_PRNG_key) == tuple(key)
+        got_e = np.asarray(rep.get_property("potential_energy"), dtype=np.float64)
+        assert np.allclose(got_e, [l["energy"] for l in log], rtol=2e-4, atol=1e-6)
+        assert np.abs(s2.positions.cpu().numpy() - x).max() < 2e-6 * 20
