@@ -349,7 +349,7 @@ def dry_run(args, rank: int, world: int) -> None:
             "warmup": args.warmup, "dry_run": True, "backend": args.dry_run_backend,
             "config": {"workload": "dry run: no kernels, synthetic energies", "replicas": world,
                        "group_world_size": dist.get_world_size() if use_dist else 1, "ranks": ranks,
-                       "replica_exchanges": exchanges,
+                       "replica_exchanges": exchanges, "exchange_interval_steps": args.exchange_interval,
                        "state_of_replica": [int(v) for v in rex.state_of_replica]},
         }), flush=True)
     if use_dist:
@@ -412,39 +412,56 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    since_exchange = [0]  # steps since the last exchange attempt: the cadence carries across propagate() calls
+
     def propagate(st, n_steps):
-        """n_steps Langevin steps; with several replicas, exchange every --exchange-interval steps."""
+        """n_steps Langevin steps; with several replicas, one exchange attempt every --exchange-interval steps of
+        the replica's life (not one per call: a 20-step timed region must not be charged a whole exchange)."""
         nb = nbr
         done = 0
         exchanges = 0
         while done < n_steps:
-            seg = min(args.exchange_interval, n_steps - done) if exchange_on else n_steps - done
+            seg = min(args.exchange_interval - since_exchange[0], n_steps - done) if exchange_on else n_steps - done
             st, nb = integ.run(st, rex.my_state, number_of_steps=seg, nbr_list=nb)
             done += seg
-            if exchange_on:
+            since_exchange[0] += seg
+            if exchange_on and since_exchange[0] >= args.exchange_interval:
                 energy = pot.compute_energy(st.positions, nb)
                 _, vscale = rex.exchange(energy)
                 if vscale != 1.0:
                     st.velocities = ops.scale(st.velocities, vscale)
                 exchanges += 1
+                since_exchange[0] = 0
         return st, exchanges
 
     def timed(st, n_steps):
-        """barrier + sync, n_steps, barrier + sync; elapsed = max over ranks (per-rank times gathered too)."""
+        """barrier + sync, n_steps, sync [clock], barrier; elapsed = max over ranks of the per-rank times (gathered).
+        The closing barrier brackets the region but is not charged to it: every rank stops its clock when ITS
+        device has drained, and the slowest rank's time is the job's time."""
         builds0 = nbr.n_builds
         barrier()
         t0 = time.perf_counter()
         st, exchanges = propagate(st, n_steps)
-        barrier()
+        torch.cuda.synchronize()
         mine = time.perf_counter() - t0
         per_rank = [mine]
         if use_dist:
+            dist.barrier()
             t = torch.tensor([mine], dtype=torch.float64, device=coll_dev)
             out = torch.empty(world, dtype=torch.float64, device=coll_dev)
             dist.all_gather_into_tensor(out, t)
             per_rank = [float(v) for v in out.cpu()]
         return st, max(per_rank), per_rank, exchanges, nbr.n_builds - builds0
 
+    if use_dist:
+        # communicator set-up and the first use of each collective are one-off costs (hundreds of ms with RCCL):
+        # pay them here, never inside a timed region
+        dist.barrier()
+        warm = torch.zeros(1, dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(warm, op=dist.ReduceOp.MAX)
+        dist.all_gather_into_tensor(torch.empty(world, dtype=torch.float64, device=coll_dev), warm)
+        rex.gather_energies(torch.zeros(1, dtype=torch.float64, device="cuda"))
+        torch.cuda.synchronize()
     # set-up (no steps): first list build, pinned read-back slots, device scratch
     integ.run(state, rex.my_state, number_of_steps=0, nbr_list=nbr)
     # warm-up (untimed)
@@ -514,6 +531,7 @@ def main():
                 "pruning_passes_in_timed_region": prune_after[0] - prune_before[0],
                 "launches_on_full_list_in_timed_region": prune_after[1] - prune_before[1],
                 "replica_exchanges": exchanges,
+                "exchange_interval_steps": (args.exchange_interval if exchange_on else None),
                 "swap_acceptance": (float(rex.n_accepted.sum() / max(1, rex.n_proposed.sum())) if world > 1 else None),
             },
             "steady_state": steady,
