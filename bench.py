@@ -464,6 +464,16 @@ def main():
         torch.cuda.synchronize()
     # set-up (no steps): first list build, pinned read-back slots, device scratch
     integ.run(state, rex.my_state, number_of_steps=0, nbr_list=nbr)
+    if exchange_on:
+        # one complete exchange cycle on a throw-away copy of the exchange state: energy kernel, read-back,
+        # all-gather, decisions -- every first-use cost of that path is paid here, and `rex` itself is untouched
+        t_w = time.perf_counter()
+        rex_warm = ReplicaExchange(ladder, PRNGKey(2024, 7), rank=rank, world_size=world)
+        for _ in range(2):
+            rex_warm.exchange(pot.compute_energy(state.positions, nbr))
+        torch.cuda.synchronize()
+        if os.environ.get("CHX_BENCH_DEBUG"):
+            print(f"[bench] exchange warm-up: {1e3 * (time.perf_counter() - t_w):.2f} ms", file=sys.stderr, flush=True)
     # warm-up (untimed)
     state, _ = propagate(state, args.warmup)
     prune_before = (getattr(integ, "prune_passes", 0), getattr(integ, "full_list_launches", 0))
