@@ -32,13 +32,20 @@ int chx_launch_lj_fl(const float* x4, const uint32_t* fl, const int32_t* deg, in
                      chx_box_t box, float sigma, float epsilon, float cutoff, float* f3,
                      float* energy, double* ws, int32_t* ctrl, hipStream_t st,
                      const chx_fl_select_t* select = nullptr);
-// Force-list addressing: a row is stored in chunks of W = CHX_FL_QUAD * g entries,
-// fl[chunk][particle][W], so lane q of the g lanes that own a particle reads its four
-// entries 4q..4q+3 of a chunk with one 16-byte load.
+// Force-list addressing: a row is stored in chunks of W = CHX_FL_QUAD * g entries, fl[chunk][particle][W], and lane q
+// of the g lanes that own a particle reads the four words 4q..4q+3 of a chunk with one 16-byte load.  Inside a chunk the
+// row is INTERLEAVED over the lanes: row entry e (0 <= e < W, in the row's order) sits in word 4 (e % g) + e / g, so
+// word u of lane q is row entry u g + q and the u-th gather instruction of a group fetches g CONSECUTIVE row entries --
+// neighbors that are adjacent in the (cell-ordered) position array and mostly share 128-byte lines -- instead of
+// entries 4 apart from each other: at liquid density the gathers are bound by the L1's line-lookup rate.
 #define CHX_FL_QUAD 4
+__host__ __device__ __forceinline__ int chx_fl_word(int e, int g) {  // row entry within a chunk -> word within the chunk
+  const int sh = 31 - __builtin_clz((unsigned)g);                    // g is a power of two
+  return CHX_FL_QUAD * (e & (g - 1)) + (e >> sh);
+}
 __device__ __forceinline__ size_t chx_fl_addr(int p, int k, int n, int g) {
-  const int sh = 31 - __clz(CHX_FL_QUAD * g);  // g is a power of two
-  return ((((size_t)(k >> sh)) * (size_t)n + (size_t)p) << sh) + (size_t)(k & ((1 << sh) - 1));
+  const int sh = 31 - __clz(CHX_FL_QUAD * g);
+  return ((((size_t)(k >> sh)) * (size_t)n + (size_t)p) << sh) + (size_t)chx_fl_word(k & ((1 << sh) - 1), g);
 }
 // number of per-block partials the list kernel leaves in ws for (n, g)
 static inline int chx_lj_fl_blocks(int n, int g) { return (int)(((int64_t)n * g + 255) / 256); }

@@ -330,7 +330,7 @@ __device__ __forceinline__ void lj_row_loop(const float4* __restrict__ x4, const
   // the zero-trip form.)
   int c = 0;
   if (G > 1 || nc > 0) do {
-    const int k0 = c * W + 4 * q;  // this lane's first entry of the chunk
+    const int k0 = c * W + q;  // row index of this lane's word 0; word u is row entry k0 + u G (chx_fl_word)
     uint4 nx = make_uint4(0u, 0u, 0u, 0u);
     if (c + 1 < nc) nx = col[(size_t)(c + 1) * stride];
     bool kp[4] = {false, false, false, false};
@@ -339,31 +339,31 @@ __device__ __forceinline__ void lj_row_loop(const float4* __restrict__ x4, const
 #else
     if (k0 < d) {
       lj_pair2<MODE, PRUNE>(xi, (f2){xj[0].x, xj[0].y}, (f2){xj[0].z, xj[0].w}, (f2){xj[1].x, xj[1].y},
-                            (f2){xj[1].z, xj[1].w}, e4.x, e4.y, k0 + 1 < d, box, lj, po.T_inner, A);
+                            (f2){xj[1].z, xj[1].w}, e4.x, e4.y, k0 + G < d, box, lj, po.T_inner, A);
       if (PRUNE) kp[0] = A.keep0, kp[1] = A.keep1;
     }
-    if (k0 + 2 < d) {
+    if (k0 + 2 * G < d) {
       lj_pair2<MODE, PRUNE>(xi, (f2){xj[2].x, xj[2].y}, (f2){xj[2].z, xj[2].w}, (f2){xj[3].x, xj[3].y},
-                            (f2){xj[3].z, xj[3].w}, e4.z, e4.w, k0 + 3 < d, box, lj, po.T_inner, A);
+                            (f2){xj[3].z, xj[3].w}, e4.z, e4.w, k0 + 3 * G < d, box, lj, po.T_inner, A);
       if (PRUNE) kp[2] = A.keep0, kp[3] = A.keep1;
     }
 #endif
     if (PRUNE) {
       // (all G lanes of a row run the same number of chunks, so the shuffles below are group-uniform)
+      // kept entries go out in ROW order: word u of lanes 0..G-1, then word u + 1 (the chunk's interleaving)
       const uint32_t ent[4] = {e4.x, e4.y, e4.z, e4.w};
-      const int cnt = (int)kp[0] + (int)kp[1] + (int)kp[2] + (int)kp[3];
-      int incl = cnt;
-#pragma unroll
-      for (int o = 1; o < G; o <<= 1) {
-        const int v = __shfl_up(incl, o, G);
-        if (q >= o) incl += v;
-      }
-      int slot = base + incl - cnt;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        if (kp[u]) po.fli[chx_fl_addr(p, slot++, n, G)] = ent[u];
+        const int mine = (int)kp[u];
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) {
+          const int v = __shfl_up(incl, o, G);
+          if (q >= o) incl += v;
+        }
+        if (kp[u]) po.fli[chx_fl_addr(p, base + incl - mine, n, G)] = ent[u];
+        base += __shfl(incl, G - 1, G);
       }
-      base += __shfl(incl, G - 1, G);
     }
     if (c + 1 < nc) {
       e4 = nx;
@@ -532,7 +532,7 @@ __device__ __forceinline__ void lj_row_finish(RowLoads& L, const float4* __restr
     const uint32_t* row = fl + ((size_t)pc * G + q) * 4;
     for (int c = 0; c < nc; ++c) {
       for (int u = 0; u < 4; ++u) {
-        if (c * W + 4 * q + u >= d) break;
+        if (c * W + u * G + q >= d) break;
         const uint32_t en_t = row[(size_t)c * stride * 4 + u];
         const float4 xo = x4[en_t & ~CHX_FL_HI];
         const bool hi = (en_t & CHX_FL_HI) != 0u;

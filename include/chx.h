@@ -149,10 +149,12 @@ int chx_pl_calculate(const float* xyz, int32_t n, chx_box_t box, float cutoff,
 /* Force list: an internal FULL neighbor table derived from the public half
  * list, laid out for the force kernel: particle p (internal order, p =
  * inv[original id], inv may be NULL = identity) owns deg[p] entries; g lanes
- * cooperate on one particle and a row is stored in chunks of W = 4 g entries:
- * entry k lives at fl[((k / W) * n + p) * W + (k % W)], so lane q reads its
- * entries 4q..4q+3 of a chunk with one 16-byte load (fl must be 16-byte
- * aligned).  Entry = internal index of the neighbor | CHX_FL_HI when the
+ * cooperate on one particle and a row is stored in chunks of W = 4 g entries,
+ * interleaved over the lanes inside a chunk: entry k (e = k % W) lives at
+ * fl[((k / W) * n + p) * W + 4 (e % g) + e / g], so lane q reads words 4q..4q+3
+ * of a chunk with one 16-byte load (fl must be 16-byte aligned) and word u of
+ * lane q is row entry u g + q: the u-th gather of a lane group touches g
+ * consecutive row entries.  Entry = internal index of the neighbor | CHX_FL_HI when the
  * neighbor's ORIGINAL id is the larger one (the pair is then stored in this
  * particle's row of the reference half list and r_ij = x_p - x_q as in
  * chiron/neighbors.py:777-779; otherwise r_ij = x_q - x_p and the force on p
