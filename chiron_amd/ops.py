@@ -294,7 +294,7 @@ def _choose_g(maxdeg: int, n: int) -> int:
 
     Measured on MI355X (scripts/exp_prune.sh, scripts/kernel_bench.py): the kernels want
     >= 2^18 lanes in flight to fill 256 CUs, as few lanes per particle as that allows (less
-    reduction, fewer idle lanes, all workgroups resident at once), and no more than ~48 listed
+    reduction, fewer idle lanes, all workgroups resident at once), and no more than ~96 listed
     entries per lane (the step kernel mostly walks the pruned list, about half of that).
     """
     env = os.environ.get("CHX_FL_G")
@@ -303,7 +303,7 @@ def _choose_g(maxdeg: int, n: int) -> int:
     g = 1  # one lane per particle once that alone fills the chip (N >= 2^18: no reduction, no idle partner lanes)
     while g < 64 and n * g < (1 << 18):
         g *= 2
-    while g < 64 and maxdeg > 48 * g:
+    while g < 64 and maxdeg > 96 * g:  # (96: at rho* = 0.8, N = 262144 four lanes per particle beat eight by 6 %)
         g *= 2
     while g > 1 and g > max(1, maxdeg):
         g //= 2
