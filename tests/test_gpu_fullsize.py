@@ -6,6 +6,8 @@ random SAMPLES of rows/particles (bit-exact for neighbor rows, fp64 tolerance fo
 independent kernels/layouts, permutation and translation invariance, independence of the
 trajectory from how steps are batched into launches.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -246,7 +248,7 @@ def test_step_kernel_step_63_matches_oracle_at_full_size(ca, O, n):
                      getattr(integ, "prune_passes", None)))
     (xa, va, rb_a, _), (xb, vb, rb_b, prunes) = outs
     assert rb_a == rb_b == 0  # dt = 1 fs from the lattice: the 0.5 nm skin holds for 64 steps
-    if prunes is not None:
+    if prunes is not None and os.environ.get("CHX_PRUNE_EVERY") is None and os.environ.get("CHX_INNER_SKIN") is None:
         assert prunes >= 2  # the inner list was refreshed at steps 0 and 32: step 63 walked the pruned table
     rng = np.random.default_rng(63)
     idx = np.unique(np.concatenate([rng.integers(0, n, 46), [0, n - 1]]))
