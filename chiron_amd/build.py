@@ -22,8 +22,13 @@ OUT = os.path.join(HERE, "libchx.so")
 # -amdgpu-kernarg-preload-count: leading scalar kernel arguments arrive in SGPRs with the wave instead
 # of through a first scalar load (gfx940+); the step kernel leads with its control block and step index,
 # which removes one dependent round trip from every launch (5.5 -> 5.25 us per step at N = 32768).
+# -fno-slp-vectorize: the packed fp32 math of the list kernels is written out explicitly (f2 / v_pk_*); the SLP
+# vectoriser adds nothing to it, but it does pair up scalar reads of the step kernel's by-value argument block
+# (box half-lengths) into overlapping vector loads that SROA cannot split -- the leftover 12-byte array then lands in
+# LDS, indexed by the flat work-item id, which makes every wavefront fetch the workgroup size from the AQL dispatch
+# packet in HOST memory: 24-30 us per launch instead of 5 (measured in round 2).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
-         "-mllvm", "-amdgpu-kernarg-preload-count=16", "-fPIC", "-shared", "-std=c++17"]
+         "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-fPIC", "-shared", "-std=c++17"]
 _MARK = b"CHX_SOURCE_HASH="
 
 

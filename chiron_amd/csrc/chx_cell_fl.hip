@@ -283,7 +283,8 @@ __global__ void k_pack_langevin(const float* __restrict__ x3, const float* __res
   v[3 * (size_t)p + 1] = v3[3 * o + 1];
   v[3 * (size_t)p + 2] = v3[3 * o + 2];
   mass_out[p] = mass[o];
-  if (ref4) ref4[p] = make_float4(ref3[3 * o], ref3[3 * o + 1], ref3[3 * o + 2], 0.f);
+  // (.w: the particle's mass -- the fused step kernel reads it from here instead of loading mass[] as well)
+  if (ref4) ref4[p] = make_float4(ref3[3 * o], ref3[3 * o + 1], ref3[3 * o + 2], mass[o]);
 }
 
 extern "C" int chx_pack_langevin(const float* x3, const float* v3, const float* mass,

@@ -505,8 +505,8 @@ __device__ __forceinline__ RowLoads lj_row_adopt(const float4* __restrict__ x4, 
 
 template <int G, bool PRUNE = false>
 __device__ __forceinline__ void lj_row_finish(RowLoads& L, const float4* __restrict__ x4, const uint32_t* __restrict__ fl,
-                                              int n, int q, bool valid, const Box3& box, const LJParams& lj,
-                                              float4& xi_out, float& fx, float& fy, float& fz, float& en,
+                                              int n, int q, bool valid, const Box3& box, bool periodic,
+                                              const LJParams& lj, float4& xi_out, float& fx, float& fy, float& fz, float& en,
                                               const PruneOut& po = PruneOut{nullptr, 0.f}, int* kept_out = nullptr) {
   constexpr int W = 4 * G;
   const int pc = L.pc;
@@ -520,7 +520,7 @@ __device__ __forceinline__ void lj_row_finish(RowLoads& L, const float4* __restr
   A.bad = false;
   A.keep0 = A.keep1 = false;
   int kept = 0;
-  if (!box.periodic) {
+  if (!periodic) {
     lj_row_loop<G, LJ_OPEN, PRUNE>(x4, L.col, stride, d, nc, q, xi, L.e4, L.xj, box, lj, A, po, pc, n, kept);
   } else {
     lj_row_loop<G, LJ_SHIFT, PRUNE>(x4, L.col, stride, d, nc, q, xi, L.e4, L.xj, box, lj, A, po, pc, n, kept);
@@ -566,7 +566,7 @@ __device__ __forceinline__ void lj_row(const float4* __restrict__ x4, const uint
                                        const PruneOut& po = PruneOut{nullptr, 0.f}, int* kept_out = nullptr) {
   (void)chunks;
   RowLoads L = lj_row_begin<G>(x4, fl, deg, n, p, q, valid);
-  lj_row_finish<G, PRUNE>(L, x4, fl, n, q, valid, box, lj, xi_out, fx, fy, fz, en, po, kept_out);
+  lj_row_finish<G, PRUNE>(L, x4, fl, n, q, valid, box, box.periodic != 0, lj, xi_out, fx, fy, fz, en, po, kept_out);
 }
 
 // Optional run-time choice of the position buffer (device-resident Monte Carlo, chx_mc.hip):
@@ -646,9 +646,9 @@ struct StepArgs {
   // dynamically pruned inner list (NULL: always run on the full force list)
   uint32_t* fli;
   int32_t* degi;
-  float4* refi4;        // positions at the last pruning pass
+  float4* refi4;        // (unused since round 2: the path length since the last pruning pass rides in x4.w)
   float T_inner;        // r2 <= T_inner: kept by the pruning pass  ((cutoff + inner skin)^2, padded up)
-  float T_half_inner;   // a particle that moved r2 > T_half_inner since the pass invalidates the inner list
+  float half_inner;     // a particle whose path since the pass is longer than this invalidates the inner list
 };
 
 // operands of one particle's integrate work
@@ -659,7 +659,8 @@ struct StepParticle {
   float m;
   float bs;  // b sigma_v = b sqrt(kT / m), chiron/integrators.py:131,186
   float v[3];
-  float4 x, ref, refi;
+  float4 x, ref;
+  float path0;  // path length travelled since the last pruning pass, before this step (x.w; 0 in a pruning launch)
   float z[3];
 };
 
@@ -673,7 +674,7 @@ struct StepParticle {
 //   * min_image_fast == min_image for |d| < L (tests/test_host_logic.py, exhaustive on the CPU).
 template <bool FAST, bool HOT>
 __device__ __forceinline__ bool integrate_component(const StepArgs& a, int n_kicks, int do_aoa, float F, float m,
-                                                    float bs, float z, float v, float xo, float rf, float ri, float L,
+                                                    float bs, float z, float v, float xo, float rf, float L,
                                                     float hL, float& vn, float& xn, float& sq, float& sqi) {
   // HOT: the steady-state launch (both kicks, A-O-A, periodic wrap, skin check, inner list), with
   // the launch-uniform switches folded at compile time
@@ -691,6 +692,8 @@ __device__ __forceinline__ bool integrate_component(const StepArgs& a, int n_kic
     float xc = fadd(xo, fmul(a.hdt, vc));      // A  :183
     vc = fadd(fmul(a.a, vc), fmul(bs, z));     // O  :186
     xc = fadd(xc, fmul(a.hdt, vc));            // A  :188
+    // speed-only bookkeeping for the pruned inner list: this step's (unwrapped) displacement, squared
+    if (has_inner) sqi = (xc - xo) * (xc - xo);
     if (do_wrap) {                             // :239
       if (FAST) {
         rare |= !(__float_as_uint(xc) < __float_as_uint(L));
@@ -711,19 +714,6 @@ __device__ __forceinline__ bool integrate_component(const StepArgs& a, int n_kic
       }
       sq = fmul(r, r);
     }
-    if (has_inner) {
-      // speed-only bookkeeping: anything the fast formula cannot vouch for counts as "moved too far"
-      float r = fsub(xc, ri);
-      if (periodic) {
-        if (FAST) {
-          const bool far = !(fabsf(r) < L);
-          r = far ? __builtin_inff() : min_image_fast(r, L, hL);
-        } else {
-          r = min_image(r, L, hL);
-        }
-      }
-      sqi = r * r;
-    }
   }
   vn = vc;
   return rare;
@@ -741,17 +731,21 @@ __device__ __forceinline__ StepParticle load_step_operands(const StepArgs& a, lo
   t.o = 0u;
   t.v[0] = t.v[1] = t.v[2] = 0.f;
   t.z[0] = t.z[1] = t.z[2] = 0.f;
-  t.x = t.ref = t.refi = make_float4(0.f, 0.f, 0.f, 0.f);
+  t.x = t.ref = make_float4(0.f, 0.f, 0.f, 0.f);
+  t.path0 = 0.f;
   if (t.live) {
-    t.m = a.mass[t.pp];
+    // (with a Verlet list the mass rides in ref4.w -- chx_pack_langevin puts it there -- and needs no load of its own)
+    if (!(HOT || a.ref4)) t.m = a.mass[t.pp];
 #pragma unroll
     for (int c = 0; c < 3; ++c) t.v[c] = a.v[3 * (size_t)t.pp + c];
+    if (HOT || a.ref4) {
+      t.ref = a.ref4[t.pp];
+      t.m = t.ref.w;
+    }
     if (do_aoa) {
       t.x = a.x_cur[t.pp];
-      if (HOT || a.ref4) t.ref = a.ref4[t.pp];
-      // a pruning launch measures against the positions it prunes at (and rewrites refi4 itself)
-      if (PRUNE) t.refi = t.x;
-      else if (HOT || a.fli) t.refi = a.refi4[t.pp];
+      // the path travelled since the last pruning pass rides in x4.w; a pruning launch starts it over
+      t.path0 = PRUNE ? 0.f : t.x.w;
       t.o = (HOT || a.perm) ? a.perm[t.pp] : (uint32_t)t.pp;
       if (!HOT && a.noise) {
         const float* row = a.noise + ((size_t)(step - a.noise_step0) * (size_t)a.n + t.o) * 3;
@@ -797,38 +791,41 @@ __device__ __forceinline__ bool step_epilogue(const StepArgs& a, const StepParti
 #ifdef CHX_EXP_NOEPI
   if (tk.live) {  // positions pass through (wrapped input stays wrapped), every operand is consumed
     reinterpret_cast<float4*>(a.x_next)[tk.pp] = make_float4(
-        tk.x.x, tk.x.y, tk.x.z, sF[3 * threadIdx.x] + tk.z[0] + tk.v[0] + tk.m + tk.bs + tk.ref.x + tk.refi.x);
+        tk.x.x, tk.x.y, tk.x.z, sF[3 * threadIdx.x] + tk.z[0] + tk.v[0] + tk.m + tk.bs + tk.ref.x + tk.path0);
   }
   if (false) {
 #else
   if (tk.live) {
 #endif
-    const float L[3] = {a.box.lx, a.box.ly, a.box.lz};
-    const float hL[3] = {a.box.hx, a.box.hy, a.box.hz};
-    const float xo[3] = {tk.x.x, tk.x.y, tk.x.z};
-    const float rf[3] = {tk.ref.x, tk.ref.y, tk.ref.z};
-    const float ri[3] = {tk.refi.x, tk.refi.y, tk.refi.z};
-    float vn[3], xn[3], sq[3], sqi[3];
-    bool rare = false;
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-      rare |= integrate_component<true, HOT>(a, n_kicks, do_aoa, sF[3 * threadIdx.x + c], tk.m, tk.bs, tk.z[c], tk.v[c],
-                                        xo[c], rf[c], ri[c], L[c], hL[c], vn[c], xn[c], sq[c], sqi[c]);
+    // (three explicit calls on scalars: local arrays of box lengths here ended up as a per-thread array in LDS)
+    float vn0, vn1, vn2, xn0, xn1, xn2, sq0, sq1, sq2, si0, si1, si2;
+    const float F0 = sF[3 * threadIdx.x], F1 = sF[3 * threadIdx.x + 1], F2 = sF[3 * threadIdx.x + 2];
+    bool rare = integrate_component<true, HOT>(a, n_kicks, do_aoa, F0, tk.m, tk.bs, tk.z[0], tk.v[0], tk.x.x, tk.ref.x,
+                                               a.box.lx, a.box.hx, vn0, xn0, sq0, si0);
+    rare |= integrate_component<true, HOT>(a, n_kicks, do_aoa, F1, tk.m, tk.bs, tk.z[1], tk.v[1], tk.x.y, tk.ref.y,
+                                           a.box.ly, a.box.hy, vn1, xn1, sq1, si1);
+    rare |= integrate_component<true, HOT>(a, n_kicks, do_aoa, F2, tk.m, tk.bs, tk.z[2], tk.v[2], tk.x.z, tk.ref.z,
+                                           a.box.lz, a.box.hz, vn2, xn2, sq2, si2);
     if (__builtin_expect(rare, 0)) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        (void)integrate_component<false, HOT>(a, n_kicks, do_aoa, sF[3 * threadIdx.x + c], tk.m, tk.bs, tk.z[c], tk.v[c],
-                                         xo[c], rf[c], ri[c], L[c], hL[c], vn[c], xn[c], sq[c], sqi[c]);
+      (void)integrate_component<false, HOT>(a, n_kicks, do_aoa, F0, tk.m, tk.bs, tk.z[0], tk.v[0], tk.x.x, tk.ref.x,
+                                            a.box.lx, a.box.hx, vn0, xn0, sq0, si0);
+      (void)integrate_component<false, HOT>(a, n_kicks, do_aoa, F1, tk.m, tk.bs, tk.z[1], tk.v[1], tk.x.y, tk.ref.y,
+                                            a.box.ly, a.box.hy, vn1, xn1, sq1, si1);
+      (void)integrate_component<false, HOT>(a, n_kicks, do_aoa, F2, tk.m, tk.bs, tk.z[2], tk.v[2], tk.x.z, tk.ref.z,
+                                            a.box.lz, a.box.hz, vn2, xn2, sq2, si2);
     }
+    const float vn[3] = {vn0, vn1, vn2}, xn[3] = {xn0, xn1, xn2}, sq[3] = {sq0, sq1, sq2}, sqi[3] = {si0, si1, si2};
     // The step's results leave as WRITE-THROUGH stores (sc1): nothing the next launch needs stays dirty in
     // this XCD's L2, so the write-back at the kernel boundary has nothing to do (the boundary costs about
     // B / 6 TB/s for B dirty bytes: 7.3 MB at N = 262144), and the next launch finds L2 cold either way.
     store_wt3(a.v + 3 * (size_t)tk.pp, vn[0], vn[1], vn[2]);
     if (do_aoa) {
-      store_wt4(reinterpret_cast<float4*>(a.x_next) + tk.pp, make_float4(xn[0], xn[1], xn[2], 0.f));
+      // x4.w: path length since the last pruning pass (a sum of per-step displacements bounds the displacement)
+      const float path = tk.path0 + __builtin_sqrtf((sqi[0] + sqi[1]) + sqi[2]);
+      store_wt4(reinterpret_cast<float4*>(a.x_next) + tk.pp, make_float4(xn[0], xn[1], xn[2], path));
       // skin check :241: (rx^2 + ry^2) + rz^2 in the reference's order
       if ((HOT || a.ref4) && fadd(fadd(sq[0], sq[1]), sq[2]) > a.T_half_skin) atomicMin(&a.ctrl[3], (int)(step + 1));
-      if ((HOT || a.fli) && (sqi[0] + sqi[1]) + sqi[2] > a.T_half_inner) stale = true;
+      if ((HOT || a.fli) && path > a.half_inner) stale = true;
     }
   }
   return stale;
@@ -879,9 +876,8 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   // from the dispatch packet), the position buffer and the list this launch most probably walks (sfl, sdeg:
   // the pruned inner list in the steady state) -- so those loads can leave before any scalar fetch returns.
   // n_lead == a.n and x_lead == a.x_cur; the copies inside StepArgs arrive with the rest of the block.)
-  a.ctrl = ctrl_first;
-  a.n = n_lead;
-  a.x_cur = x_lead;
+  // `a` is NEVER written (see the note at the launch-uniform switches below): ctrl_first == a.ctrl,
+  // n_lead == a.n and x_lead == a.x_cur; code that runs before the argument block has arrived uses the leading copies.
   constexpr int PPB = 256 / G;  // particles per block (<= 256)
   const unsigned blk = xcd_block(blockIdx.x, nblocks);
 #ifdef CHX_EXP_STAMPS
@@ -900,18 +896,20 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   const uint4 s_xi = pinned_load16(x_lead + pc_s);
   const int s_d = pinned_load4(sdeg + pc_s);
 #endif
-  if (HOT) {  // what the launcher checked (launch_step_g), restated for the optimiser
-    n_kicks = 2, do_aoa = 1;
-    a.box.periodic = 1, a.wrap = 1;
-    a.noise = nullptr;
-  }
+  if (HOT) n_kicks = 2, do_aoa = 1;  // what the launcher checked (launch_step_g), restated for the optimiser
+  // The other launch-uniform switches are folded where they are read (`HOT || ...`).  Do NOT write them into the
+  // by-value argument struct (or a copy of its box): the struct then lives in a private copy, the vectoriser reads
+  // overlapping pairs of the box half-lengths from it, SROA gives up, and the backend parks the leftover array in
+  // LDS indexed by the flat work-item id -- which needs the workgroup size from the DISPATCH PACKET, a scalar load
+  // from host memory in every wavefront: the launch then takes 24-30 us instead of 5 (measured, round 2).
+  const bool periodic = HOT || a.box.periodic != 0;
   __shared__ float sF[3 * PPB];
   // (CHX_EXP_*: timing decomposition of scripts/exp_step.sh, never defined in the product build)
 #ifndef CHX_EXP_NOCTRL
   // (naming the arguments the first vector loads need in an asm statement ahead of this branch makes
   // their fetch leave together with the halt word's -- and measured 3 % slower: the stale-word read
   // turns into a vector load and a second argument fetch still follows the branch)
-  const int halt_step = a.ctrl[3];
+  const int halt_step = ctrl_first[3];
   if ((long long)halt_step <= step) return;  // block-uniform
 #endif
   // Which table this launch walks: the pruned inner list, unless some particle has moved too far
@@ -922,7 +920,7 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
 #ifndef CHX_EXP_NOCTRL
   // (read unconditionally and combined without a short circuit: a branch on `epoch` in front of this
   // read puts a second exposed scalar round trip ahead of every other load of the launch)
-  const int stale_word = a.ctrl[4 + (int)(step & 1)];
+  const int stale_word = ctrl_first[4 + (int)(step & 1)];
   const bool inner = !PRUNE && (HOT || a.fli != nullptr) && ((epoch >= 0) & (stale_word != epoch));
 #else
   const bool inner = !PRUNE && (HOT || a.fli != nullptr);
@@ -960,20 +958,17 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   if (PRUNE) {
     constexpr int W = 4 * G;
     int kept = 0;
-    lj_row_finish<G, true>(rl, a.x_cur, fl_use, a.n, q, valid, a.box, a.lj, xi, fx, fy, fz, en,
+    lj_row_finish<G, true>(rl, a.x_cur, fl_use, a.n, q, valid, a.box, periodic, a.lj, xi, fx, fy, fz, en,
                            PruneOut{a.fli, a.T_inner}, &kept);
     if (valid) {
       // the force kernel gathers whole chunks (chunk 0 speculatively): pad the last touched chunk
       int end = (kept + W - 1) / W * W;
       end = end < W ? W : end;
       for (int sl = kept + q; sl < end; sl += G) a.fli[chx_fl_addr(p, sl, a.n, G)] = (uint32_t)p;
-      if (q == 0) {
-        a.degi[p] = kept;
-        a.refi4[p] = xi;
-      }
+      if (q == 0) a.degi[p] = kept;
     }
   } else {
-    lj_row_finish<G>(rl, a.x_cur, fl_use, a.n, q, valid, a.box, a.lj, xi, fx, fy, fz, en);
+    lj_row_finish<G>(rl, a.x_cur, fl_use, a.n, q, valid, a.box, periodic, a.lj, xi, fx, fy, fz, en);
   }
 #else
   finish_step_particle<HOT>(a, step, do_aoa, tk);
@@ -992,15 +987,15 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   const bool stale = step_epilogue<HOT>(a, tk, sF, step, n_kicks, do_aoa);
   // the inner list stays off until the next refresh (a new epoch) outdates the word
   if (do_aoa && (HOT || a.fli) && epoch >= 0 && (stale || (!inner && !PRUNE && threadIdx.x == 0)))
-    a.ctrl[4 + (int)((step + 1) & 1)] = epoch;
+    ctrl_first[4 + (int)((step + 1) & 1)] = epoch;
 #ifdef CHX_EXP_STAMPS
   CHX_STAMP(5, stamp_clk());
   // (slot 6 holds the entry real-time stamp; the end one goes to a second array row via slot arithmetic)
   if (threadIdx.x == 0 && blk < CHX_STAMP_BLOCKS) g_stamps[step & 3][blk][6] = (g_stamps[step & 3][blk][6] & 0xFFFFFFFFull) | (stamp_rt() << 32);
 #endif
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (PRUNE) a.ctrl[7] += 1;                                // refreshes of the inner list
-    else if ((HOT || a.fli) && !inner) a.ctrl[6] += 1;        // launches on the full list
+    if (PRUNE) ctrl_first[7] += 1;                            // refreshes of the inner list
+    else if ((HOT || a.fli) && !inner) ctrl_first[6] += 1;    // launches on the full list
   }
 }
 
@@ -1203,7 +1198,7 @@ int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, in
     const float rk = (p->cutoff + p->inner_skin) * 1.00001f;
     const float hm = 0.5f * p->inner_skin * 0.9999f;
     a.T_inner = rk * rk;
-    a.T_half_inner = hm * hm;
+    a.half_inner = hm;
   }
   for (int i = 0; i < n_steps; ++i) {
     a.x_cur = reinterpret_cast<const float4*>((i & 1) ? x_odd : x_even);

@@ -176,7 +176,7 @@ int chx_permute_unpack(const float* src, int32_t src_stride, const uint32_t* per
                        float* dst3, chx_stream_t stream);
 int chx_invert_perm(const uint32_t* perm, int32_t n, uint32_t* inv_out, chx_stream_t stream);
 /* one launch: x4[p] = x3[perm[p]], v[p] = v3[perm[p]], mass_out[p] = mass[perm[p]],
- * ref4[p] = ref3[perm[p]] (ref4_out may be NULL) */
+ * ref4[p] = (ref3[perm[p]], mass_out[p]) (ref4_out may be NULL) */
 int chx_pack_langevin(const float* x3, const float* v3, const float* mass, const float* ref3,
                       const uint32_t* perm, int32_t n, float* x4_out, float* v_out, float* mass_out,
                       float* ref4_out, chx_stream_t stream);
@@ -235,7 +235,8 @@ typedef struct {
   float* x4;             /* (n,4) positions, internal order            (in/out) */
   float* v;              /* (n,3) velocities, internal order           (in/out) */
   float* f;              /* (n,3) forces, internal order               (in/out) */
-  const float* ref4;     /* (n,4) positions at the last list build, or NULL (no list) */
+  const float* ref4;     /* (n,4) positions at the last list build, or NULL (no list); .w = the particle's MASS
+                            (chx_pack_langevin writes it: the fused step kernel takes the mass from here) */
   const float* mass;     /* (n)   masses, internal order */
   const uint32_t* perm;  /* (n)   internal -> original id (RNG counter / noise row), NULL = identity */
   const uint32_t* fl;    /* force list (see above), NULL -> all-pairs kernel */
@@ -260,9 +261,9 @@ typedef struct {
   /* Dynamically pruned inner list (fused path only; all NULL / 0 = off).  Every prune_every
    * steps, counted from step index prune_phase, the step launch walks fl itself and copies the
    * entries with |r| < cutoff + inner_skin into fl_inner (same geometry as fl), their counts into
-   * deg_inner and the positions it saw into ref_inner4; the following launches walk fl_inner until
-   * some particle has moved inner_skin / 2 from ref_inner4 and fl itself from then to the next
-   * refresh.  The interacting pairs are those of fl in either case (csrc/chx_lj.hip: k_lj_step). */
+   * deg_inner and restarts every particle's path length (the .w of the position buffers, a running sum of
+   * per-step displacements); the following launches walk fl_inner until some particle's path exceeds
+   * inner_skin / 2 and fl itself from then to the next refresh (ref_inner4 is unused since round 2).  The interacting pairs are those of fl in either case (csrc/chx_lj.hip: k_lj_step). */
   uint32_t* fl_inner;
   int32_t* deg_inner;
   float* ref_inner4;

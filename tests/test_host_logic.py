@@ -523,3 +523,32 @@ def test_threefry_stream_host_twins_follow_jax():
             PRNG.set_seed(1, stream="mt19937")
     finally:
         PRNG.set_seed(1234)
+
+
+def test_no_kernel_reads_the_dispatch_packet(tmp_path):
+    """Guard against a 5x performance cliff found in round 2: when the compiler parks a private array in LDS it
+    indexes it by the flat work-item id, which needs the workgroup size from the AQL dispatch packet -- a scalar
+    load from HOST memory in every wavefront (the fused step kernel took 24-30 us per launch instead of 5).  No
+    kernel of the library may need the dispatch pointer, and the step kernel's LDS use must be exactly its force
+    table.  (Device assembly only: no GPU involved.)"""
+    import shutil
+    import subprocess
+
+    from chiron_amd import build as b
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    flags = [f for f in b.FLAGS if f not in ("-shared", "-fPIC")]
+    for src in b.sources():
+        out = str(tmp_path / (os.path.basename(src) + ".s"))
+        subprocess.run([hipcc] + flags + ["-S", "--offload-device-only", "-o", out, src], check=True, capture_output=True, timeout=600)
+        text = open(out).read()
+        assert ".amdhsa_user_sgpr_dispatch_ptr 1" not in text, f"{os.path.basename(src)}: a kernel reads the dispatch packet"
+        if src.endswith("chx_lj.hip"):
+            sizes = {}
+            for m in re.finditer(r"\.amdhsa_kernel _Z9k_lj_stepILi(\d+)ELb[01]ELb[01]EE\S*\s+\.amdhsa_group_segment_fixed_size (\d+)", text):
+                sizes.setdefault(int(m.group(1)), set()).add(int(m.group(2)))
+            assert sizes, "no k_lj_step instantiation found"
+            for g, lds in sizes.items():
+                assert lds == {3 * (256 // g) * 4}, (g, lds)  # sF[3 * PPB] floats and nothing else
