@@ -303,7 +303,8 @@ int chx_langevin_resume(const chx_langevin_t* p_h, chx_stream_t stream);
  * trailing kick of the previous step + leading kick of this one), then A-O-A, wrap
  * and the skin check, and writes the new positions to the other buffer
  * (chiron/integrators.py:179-195 with :193-195 of step s-1 merged into step s).
- * p_h->x4 / p_h->f are ignored.  ctrl[3] must hold INT32_MAX on entry; when the skin
+ * p_h->x4 / p_h->f are ignored.  The .w of the two position buffers belongs to the kernel (path length since
+ * the last refresh of the inner list; chx_pack_langevin initialises it to 0).  ctrl[3] must hold INT32_MAX on entry; when the skin
  * check fires while producing the positions of step s+1 the kernel stores s+1 there
  * and every launch with step >= ctrl[3] is a no-op, so the state is exactly the one
  * the reference rebuilds its list from.  do_aoa == 0: force + kicks only (the trailing

@@ -20,3 +20,5 @@ for rep in range(4):
     out.append(steps / (time.perf_counter() - t0))
 t_step, t_force, p_nl, fl = bench.time_kernels(fluid, pot, state, nbr, integ, 200)
 print("e2e windows:", [round(v) for v in out], " time_kernels step %.2f us force %.2f us" % (t_step * 1e6, t_force * 1e6))
+fl = nbr.force_list
+print("ptrs: fl %x deg %x pos %x" % (fl.fl.data_ptr(), fl.deg.data_ptr(), state.positions.data_ptr()))
