@@ -1188,10 +1188,10 @@ int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, in
   a.noise = p->noise;
   a.noise_step0 = p->noise_step0;
   a.ctrl = p->ctrl;
-  const bool use_inner = p->fl_inner && p->deg_inner && p->ref_inner4 && p->prune_every > 0 && p->inner_skin > 0.f;
+  const bool use_inner = p->fl_inner && p->deg_inner && p->prune_every > 0 && p->inner_skin > 0.f;  // (ref_inner4: unused)
   a.fli = use_inner ? p->fl_inner : nullptr;
   a.degi = use_inner ? p->deg_inner : nullptr;
-  a.refi4 = use_inner ? reinterpret_cast<float4*>(p->ref_inner4) : nullptr;
+  a.refi4 = nullptr;
   {
     // keep |r| < cutoff + inner_skin (padded up), distrust the table once a particle has moved
     // inner_skin / 2 (padded down): the paddings dwarf fp32 rounding

@@ -370,12 +370,15 @@ class _RunState:
         if self.fl is not None and self.is_verlet:
             inner, every = self._inner_list_settings(skin)
             if every > 0:
-                if getattr(self, "fl_inner", None) is None or self.fl_inner.shape != self.fl.fl.shape:
-                    self.fl_inner = torch.empty_like(self.fl.fl)
-                    self.deg_inner = torch.empty_like(self.fl.deg)
-                    self.ref_inner4 = torch.empty_like(self.x_a)
+                # (kept on the integrator between run() calls: every launch of a run is enqueued behind the previous
+                # run's on the same stream, and the first launch after a load refreshes the table)
+                keep = self.integ.__dict__.setdefault("_inner_scratch", {})
+                if keep.get("shape") != tuple(self.fl.fl.shape) or keep["fl"].device != self.fl.fl.device:
+                    keep["shape"] = tuple(self.fl.fl.shape)
+                    keep["fl"] = torch.empty_like(self.fl.fl)
+                    keep["deg"] = torch.empty_like(self.fl.deg)
+                self.fl_inner, self.deg_inner = keep["fl"], keep["deg"]
                 p.fl_inner, p.deg_inner = self.fl_inner.data_ptr(), self.deg_inner.data_ptr()
-                p.ref_inner4 = self.ref_inner4.data_ptr()
                 p.inner_skin, p.prune_every, p.prune_phase = inner, every, step
         self.params = p
 
