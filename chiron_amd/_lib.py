@@ -54,6 +54,7 @@ class LangevinParams(C.Structure):
         ("inner_skin", C.c_float),
         ("prune_every", C.c_int32),
         ("prune_phase", C.c_int64),
+        ("host_ctrl", C.c_void_p),
     ]
 
 

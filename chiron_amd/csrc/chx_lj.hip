@@ -647,6 +647,7 @@ struct StepArgs {
   uint32_t* fli;
   int32_t* degi;
   float4* refi4;        // (unused since round 2: the path length since the last pruning pass rides in x4.w)
+  int32_t* host_ctrl;   // host-mapped copy of the control block (chx_langevin_t::host_ctrl), or NULL
   float T_inner;        // r2 <= T_inner: kept by the pruning pass  ((cutoff + inner skin)^2, padded up)
   float half_inner;     // a particle whose path since the pass is longer than this invalidates the inner list
 };
@@ -824,7 +825,11 @@ __device__ __forceinline__ bool step_epilogue(const StepArgs& a, const StepParti
       const float path = tk.path0 + __builtin_sqrtf((sqi[0] + sqi[1]) + sqi[2]);
       store_wt4(reinterpret_cast<float4*>(a.x_next) + tk.pp, make_float4(xn[0], xn[1], xn[2], path));
       // skin check :241: (rx^2 + ry^2) + rz^2 in the reference's order
-      if ((HOT || a.ref4) && fadd(fadd(sq[0], sq[1]), sq[2]) > a.T_half_skin) atomicMin(&a.ctrl[3], (int)(step + 1));
+      if ((HOT || a.ref4) && fadd(fadd(sq[0], sq[1]), sq[2]) > a.T_half_skin) {
+        atomicMin(&a.ctrl[3], (int)(step + 1));
+        // (tell the host at once: the copy this launch published when it started cannot know yet)
+        if (a.host_ctrl) __hip_atomic_store(&a.host_ctrl[3], (int)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       if ((HOT || a.fli) && path > a.half_inner) stale = true;
     }
   }
@@ -905,6 +910,10 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   const bool periodic = HOT || a.box.periodic != 0;
   __shared__ float sF[3 * PPB];
   // (CHX_EXP_*: timing decomposition of scripts/exp_step.sh, never defined in the product build)
+  // the control block as this launch finds it goes to the host-mapped copy (one wavefront, system-scope stores;
+  // no-op launches publish too: that is how the host learns about a halt)
+  if (a.host_ctrl != nullptr && blockIdx.x == 0 && threadIdx.x < 8)
+    __hip_atomic_store(&a.host_ctrl[threadIdx.x], ctrl_first[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifndef CHX_EXP_NOCTRL
   // (naming the arguments the first vector loads need in an asm statement ahead of this branch makes
   // their fetch leave together with the halt word's -- and measured 3 % slower: the stale-word read
@@ -1188,6 +1197,7 @@ int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, in
   a.noise = p->noise;
   a.noise_step0 = p->noise_step0;
   a.ctrl = p->ctrl;
+  a.host_ctrl = p->fl != nullptr ? p->host_ctrl : nullptr;
   const bool use_inner = p->fl_inner && p->deg_inner && p->prune_every > 0 && p->inner_skin > 0.f;  // (ref_inner4: unused)
   a.fli = use_inner ? p->fl_inner : nullptr;
   a.degi = use_inner ? p->deg_inner : nullptr;

@@ -446,22 +446,25 @@ class _RunState:
     # -- fused neighbor-list path -------------------------------------------
     def _enqueue_fused(self, s0: int, n: int, do_aoa: int = 1) -> _Pending:
         even, odd = (self.x_a, self.x_b) if self.parity == 0 else (self.x_b, self.x_a)
+        # pinned read-back slots are allocated once per integrator (pinning memory can take milliseconds);
+        # a slot is reused only after the chunk that owned it has been waited for
+        ring = getattr(self.integ, "_pinned_ring", None)
+        if ring is None or len(ring) < self.depth + 3:
+            ring = self.integ._pinned_ring = [torch.empty((8,), dtype=torch.int32, pin_memory=True)
+                                              for _ in range(self.depth + 3)]
+            self.integ._ring_next = 0
+        host = ring[self.integ._ring_next % len(ring)]
+        self.integ._ring_next += 1
+        # every launch of the chunk copies the control block into this slot when it starts (and a halting thread
+        # stores the halt word there directly): no separate publish launch per chunk
+        self.params.host_ctrl = host.data_ptr()
         ops.langevin_fused_chunk(self.params, even, odd, s0, n, self.kicks_next, do_aoa)
         rec = _Pending()
         rec.s0, rec.n, rec.parity0 = s0, n, self.parity
         if do_aoa:
             self.parity ^= n & 1
             self.kicks_next = 2
-        # pinned read-back slots are allocated once per integrator (pinning memory can take milliseconds);
-        # a slot is reused only after the chunk that owned it has been waited for
-        ring = getattr(self.integ, "_pinned_ring", None)
-        if ring is None or len(ring) < self.depth + 2:
-            ring = self.integ._pinned_ring = [torch.empty((8,), dtype=torch.int32, pin_memory=True)
-                                              for _ in range(self.depth + 2)]
-            self.integ._ring_next = 0
-        rec.host = ring[self.integ._ring_next % len(ring)]
-        self.integ._ring_next += 1
-        ops.publish(self.ctrl, rec.host, 8)  # a kernel on this stream: no copy engine / blit queue in the loop
+        rec.host = host
         rec.event = torch.cuda.Event()
         rec.event.record()
         return rec
@@ -570,6 +573,15 @@ class _RunState:
                 self.kicks_next = 1
                 rec = self._enqueue_fused(n_steps, 1, do_aoa=0)
             rec.event.synchronize()
+            if int(rec.host[3]) <= n_steps:
+                # The skin check fired in the run's very last step and its word reached the host only with this
+                # launch's own copy of the control block (see chx_langevin_t::host_ctrl): the kick above ran as a
+                # no-op.  Rebuild exactly as _advance_fused does for a halt at the end of a chunk, then kick.
+                self._bank_inner_stats()
+                self._rebuild(n_steps, speculative=False)
+                self.kicks_next = 1
+                rec = self._enqueue_fused(n_steps, 1, do_aoa=0)
+                rec.event.synchronize()
             self._seen_full, self._seen_prune = int(rec.host[6]), int(rec.host[7])
             self._bank_inner_stats()
         elif self.mode == "pairs":

@@ -270,6 +270,13 @@ typedef struct {
   float inner_skin;
   int32_t prune_every;
   int64_t prune_phase;
+  /* Optional (fused neighbor-list path): device-visible address of a HOST-MAPPED pinned block of 8 ints.  Every
+   * step launch copies the control block there when it starts (system-scope stores by one wavefront), and a thread
+   * that raises the halt word also stores it there directly, so the host can read the state of a chunk after
+   * waiting for the stream WITHOUT a separate chx_publish launch.  What the host reads is complete up to the
+   * chunk's last launch; a halt raised by that very launch is normally there too (its direct store) and otherwise
+   * shows up with the next launch -- which is a no-op by then, so nothing is lost but a little time.  NULL = off. */
+  int32_t* host_ctrl;
 } chx_langevin_t;
 
 /* One BAOAB update on user-order (n,3) arrays, in place: v += half_dt F/m; x += half_dt v;
