@@ -284,7 +284,8 @@ def test_library_exports_every_declared_symbol():
     assert lib.chx_version() == 1
     # struct layouts agree with the header (x86-64 SysV)
     assert ctypes.sizeof(_lib.Box) == 16
-    assert ctypes.sizeof(_lib.LangevinParams) == 216
+    assert ctypes.sizeof(_lib.LangevinParams) == 224 == lib.chx_sizeof_langevin_t()
+    assert _lib.LangevinParams.host_ctrl.offset == 216
     assert _lib.LangevinParams.fl_inner.offset == 176 and _lib.LangevinParams.prune_phase.offset == 208
     # struct-by-value marshalling rule of include/chx.h: no float scalars before a box that follows
     # five or more integer/pointer arguments (mis-marshalled by this image's libffi)
