@@ -646,7 +646,6 @@ struct StepArgs {
   // dynamically pruned inner list (NULL: always run on the full force list)
   uint32_t* fli;
   int32_t* degi;
-  float4* refi4;        // (unused since round 2: the path length since the last pruning pass rides in x4.w)
   int32_t* host_ctrl;   // host-mapped copy of the control block (chx_langevin_t::host_ctrl), or NULL
   float T_inner;        // r2 <= T_inner: kept by the pruning pass  ((cutoff + inner skin)^2, padded up)
   float half_inner;     // a particle whose path since the pass is longer than this invalidates the inner list
@@ -868,7 +867,7 @@ extern "C" int chx_debug_read_stamps(unsigned long long* out_h) {
 
 // PRUNE: the launch that refreshes the dynamically pruned inner list (see below): it walks the FULL
 // force list and, next to the forces, copies the entries with |r| < cutoff + inner_skin into the
-// inner list, in order, and records the positions it saw -- the pruning costs no pass of its own.
+// inner list, in order, and restarts every particle's path length (x4.w) -- the pruning costs no pass of its own.
 // `epoch` counts the refreshes since the state was loaded (-1 before the first): the two
 // "inner list is stale" words hold the epoch in which they were raised, so a refresh invalidates
 // them without anybody having to clear a word another block may be reading.
@@ -1012,13 +1011,13 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
 // Dynamic pruning: the reference's list keeps every pair within cutoff + skin of the last build
 // (skin = 0.5 nm in its examples: 3.3x the volume of the cutoff sphere), but a pair can only
 // interact while |r| < cutoff.  Every few steps a PRUNE launch of k_lj_step copies, in order, the
-// entries with |r_now| < cutoff + inner_skin into a second table of the same layout and records the
-// positions it saw; the following launches walk that table for as long as no particle has moved
-// more than inner_skin / 2 since (checked next to the reference's own skin check) and fall back to
-// the full table otherwise, until the next refresh.  A dropped pair was farther than
-// cutoff + inner_skin and each partner moved less than inner_skin / 2, so it is still outside the
-// cutoff: the set of interacting pairs -- the reference's set -- is unchanged; only the summation
-// order differs.
+// entries with |r_now| < cutoff + inner_skin into a second table of the same layout and restarts the
+// path length every particle travels from then on (x4.w: a running sum of per-step displacements, which
+// bounds the displacement); the following launches walk that table for as long as no particle's path has
+// grown beyond inner_skin / 2 (checked next to the reference's own skin check) and fall back to the
+// full table otherwise, until the next refresh.  A dropped pair was farther than cutoff + inner_skin
+// and each partner has moved less than inner_skin / 2, so it is still outside the cutoff: the set of
+// interacting pairs -- the reference's set -- is unchanged; only the summation order differs.
 // ---------------------------------------------------------------------------
 // all-pairs kernels: 16 lanes per particle, j-tiles of 256 particles staged through LDS
 #define AP_SLICES 16
@@ -1201,7 +1200,6 @@ int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, in
   const bool use_inner = p->fl_inner && p->deg_inner && p->prune_every > 0 && p->inner_skin > 0.f;  // (ref_inner4: unused)
   a.fli = use_inner ? p->fl_inner : nullptr;
   a.degi = use_inner ? p->deg_inner : nullptr;
-  a.refi4 = nullptr;
   {
     // keep |r| < cutoff + inner_skin (padded up), distrust the table once a particle has moved
     // inner_skin / 2 (padded down): the paddings dwarf fp32 rounding
