@@ -1710,3 +1710,44 @@ def test_reference_mcmc_workflows_on_a_harmonic_oscillator(ca, O):
         got_e = np.asarray(rep.get_property("potential_energy"), dtype=np.float64)
         assert np.allclose(got_e, [l["energy"] for l in log], rtol=2e-4, atol=1e-6)
         assert np.abs(s2.positions.cpu().numpy() - x).max() < 2e-6 * 20
+
+
+@pytest.mark.parametrize("where", ["end-of-run", "end-of-chunk", "mid-chunk"])
+def test_langevin_halt_at_chunk_and_run_boundaries_matches_oracle(ca, O, where):
+    """The skin check firing in the LAST step of a run (the rebuild then happens after the loop's last A-O-A and
+    before the trailing force + kick, chiron/integrators.py:188-195 with :239-242) and in the last step of a chunk:
+    the cases in which the halt word reaches the host late -- with the trailing-kick launch or with the first
+    launch of the next chunk (include/chx.h: chx_langevin_t::host_ctrl).  Rebuild count, the rebuilt list and the
+    trajectory must be the oracle's in every case."""
+    n, skin = 400, 0.02
+    rng = np.random.default_rng(5)
+    mass = np.full(n, 39.948, f32)
+    kT = O.R_KJ * 300.0
+    noise = rng.normal(size=(40, n, 3)).astype(f32)
+    x, box = O.lj_lattice(n, 0.3, SIGMA, seed=43)
+    v0 = O.initial_velocities(mass, kT, rng.normal(size=(n, 3)).astype(f32))
+
+    def oracle(steps):
+        return O.langevin_run(x, v0, box, mass, SIGMA, EPS, CUTOFF, skin, 250, 0.004, 1.0, 300.0, steps, lambda s: noise[s])
+
+    # first rebuild step of the reference trajectory: the smallest number of steps after which one rebuild has happened
+    h = next(k for k in range(1, 40) if oracle(k)[2] >= 1)
+    assert 2 <= h <= 30
+    if where == "end-of-run":
+        steps, chunk = h, 7 if h % 7 else 5   # the halt comes out of the run's last step, not at a chunk end
+    elif where == "end-of-chunk":
+        steps, chunk = h + 9, h               # ... out of the last launch of the first chunk
+    else:
+        steps, chunk = h + 9, h + 3           # (control: in the middle of a chunk)
+    _, _, pot, state, thermo, nbr, integ = _langevin_setup(ca, O, n, 0.3, 43, skin, 4.0, "NeighborListNsqrd", 250)
+    integ.chunk_size = chunk
+    state.velocities = v0
+    out, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr, noise=noise[:steps])
+    xo, vo, rebuilds, (nl_mask, nl, n_max) = oracle(steps)
+    assert rebuilds >= 1 and integ.n_rebuilds == rebuilds
+    assert np.abs(out.positions.cpu().numpy() - xo).max() < 1e-5
+    assert np.abs(out.velocities.cpu().numpy() - vo).max() < 5e-4 * max(1.0, np.abs(vo).max())
+    assert nbr.n_max_neighbors == n_max and np.array_equal(u32(nbr.neighbor_list), nl)
+    if where == "end-of-run":
+        # rebuilt from the final positions: the list's reference positions ARE the returned positions
+        assert np.array_equal(nbr.ref_positions.cpu().numpy(), out.positions.cpu().numpy())
