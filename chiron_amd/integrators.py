@@ -243,6 +243,11 @@ class LangevinIntegrator:
         self.reporter.report(d)
 
 
+# how the host gets to see the control block of a chunk: copied by every step launch itself (default), or by a
+# publish launch behind the chunk (CHX_HOST_CTRL=0; a list so that A/B scripts can flip it in-process)
+_HOST_CTRL_IN_KERNEL = [os.environ.get("CHX_HOST_CTRL", "1") != "0"]
+
+
 class _Pending:
     __slots__ = ("s0", "n", "parity0", "host", "event")
 
@@ -457,8 +462,11 @@ class _RunState:
         self.integ._ring_next += 1
         # every launch of the chunk copies the control block into this slot when it starts (and a halting thread
         # stores the halt word there directly): no separate publish launch per chunk
-        self.params.host_ctrl = host.data_ptr()
+        in_kernel = _HOST_CTRL_IN_KERNEL[0]
+        self.params.host_ctrl = host.data_ptr() if in_kernel else None
         ops.langevin_fused_chunk(self.params, even, odd, s0, n, self.kicks_next, do_aoa)
+        if not in_kernel:
+            ops.publish(self.ctrl, host, 8)  # the older scheme: one publish launch per chunk
         rec = _Pending()
         rec.s0, rec.n, rec.parity0 = s0, n, self.parity
         if do_aoa:
