@@ -446,7 +446,11 @@ __device__ __forceinline__ void store_wt4(float4* p, float4 v) {
   *p = v;
 #else
   const f4v t = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+  // (s_nop: a VMEM store of more than 64 bits reads its data registers a cycle or two after it issues; the
+  // compiler pads that hazard for its own stores but cannot see one inside an asm statement, and -- in an
+  // experimental variant of the integrate tail -- was caught recycling the first data register for the next
+  // value: velocities came out holding path lengths)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
 #endif
 }
 __device__ __forceinline__ void store_wt3(float* p, float a, float b, float c) {
@@ -454,7 +458,7 @@ __device__ __forceinline__ void store_wt3(float* p, float a, float b, float c) {
   p[0] = a, p[1] = b, p[2] = c;
 #else
   const f3v t = {a, b, c};
-  asm volatile("global_store_dwordx3 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+  asm volatile("global_store_dwordx3 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
 #endif
 }
 

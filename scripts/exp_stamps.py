@@ -73,3 +73,9 @@ for gi in range(0, nb, grp):
     print(f"    blocks {gi:5d}-{min(nb, gi + grp) - 1:5d}: body {body[sl].mean():6.2f} (max {body[sl].max():6.2f})  row loads {rowl[sl].mean():5.2f}  loop {loop[sl].mean():5.2f}")
 worst = np.argsort(body)[-12:]
 print("  slowest blocks:", [(int(b_), round(float(body[b_]), 2)) for b_ in worst])
+
+# ---- shader clock seen by the kernel: s_memtime cycles per s_memrealtime tick (100 MHz)
+cyc = (s[:, :, 5] - s[:, :, 0]).astype(np.float64)
+drt = (rt1 - rt0) * 100.0  # ticks
+ok = drt > 50
+print(f"  shader clock (median over blocks): {np.median(cyc[ok] / drt[ok]) * 0.1:.3f} GHz;  start-to-start {np.median(np.diff(np.sort(rt0.min(axis=1)))):.2f} us")
