@@ -104,12 +104,17 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
       displacement_oriented_fast(box, hi, xi, yi, zi, xk.x, xk.y, xk.z, rx, ry, rz, bad);
       if (__builtin_expect(bad, 0)) displacement_oriented(box, hi, xi, yi, zi, xk.x, xk.y, xk.z, rx, ry, rz);
       ok = (j != i) & (norm2(rx, ry, rz) <= T);
+#ifdef CHX_EXP_BUILD_NOTEST
+      ok = ok && xk.x == 12345.f;  // (timing decomposition: no hits, nothing stored)
+#endif
     }
     const unsigned long long lt = (1ull << lane) - 1ull;
     const unsigned long long b = __ballot(ok);
     if (b) {
       const int slot = count_f + __popcll(b & lt);
+#ifndef CHX_EXP_BUILD_NOFL
       if (ok && slot < fcap) fl[chx_fl_addr(w, slot, n, fg)] = (uint32_t)k | (hi ? CHX_FL_HI : 0u);
+#endif
       count_f += __popcll(b);
     }
     const bool okh = ok && hi;
@@ -140,8 +145,14 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
     const uint32_t v = cand[t];
     mn = v < mn ? v : mn;
     int rank = 0;
+#ifdef CHX_EXP_BUILD_NOSORT
+    rank = t;
+#else
     for (int u = 0; u < kept; ++u) rank += cand[u] < v ? 1 : 0;
+#endif
+#ifndef CHX_EXP_BUILD_NONL
     if (rank < m) nl_row[rank] = v;
+#endif
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {

@@ -286,6 +286,28 @@ extern "C" int chx_langevin_fused_chunk(const chx_langevin_t* p, float* x_even, 
   return chx_check_launch("chx_langevin_fused_chunk");
 }
 
+extern "C" int chx_langevin_fused_run(const chx_langevin_t* p, float* x_even, float* x_odd, int64_t step0,
+                                      int32_t n_steps, int32_t kicks_first, int32_t window,
+                                      int32_t* n_enqueued_out, chx_stream_t stream) {
+  CHX_REQUIRE(p && n_enqueued_out, "null pointer");
+  *n_enqueued_out = 0;
+  CHX_REQUIRE(p->n >= 1, "n < 1");
+  CHX_REQUIRE(x_even && x_odd && x_even != x_odd, "need two distinct position buffers");
+  CHX_REQUIRE(p->v && p->mass && p->ctrl, "null pointer");
+  CHX_REQUIRE(p->fl && p->deg && p->fl_chunks >= 1, "the launch window needs the force-list path");
+  CHX_REQUIRE(p->host_ctrl, "the launch window polls host_ctrl");
+  CHX_REQUIRE(window >= 1, "window < 1");
+  CHX_REQUIRE(!p->box.periodic || (p->box.lx > 0 && p->box.ly > 0 && p->box.lz > 0),
+              "box lengths must be > 0");
+  CHX_REQUIRE(n_steps >= 0, "n_steps < 0");
+  CHX_REQUIRE(kicks_first >= 0 && kicks_first <= 2, "kicks_first must be 0, 1 or 2");
+  CHX_REQUIRE(step0 >= 0 && step0 + n_steps < (1ll << 31) - 1, "step index out of range");
+  int rc = chx_launch_lj_steps(p, x_even, x_odd, step0, n_steps, kicks_first, 1, chx_stream(stream), window,
+                               n_enqueued_out);
+  if (rc != CHX_OK) return rc;
+  return chx_check_launch("chx_langevin_fused_run");
+}
+
 extern "C" int chx_langevin_resume(const chx_langevin_t* p, chx_stream_t stream) {
   int rc = validate_langevin(p);
   if (rc != CHX_OK) return rc;

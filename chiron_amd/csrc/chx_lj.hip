@@ -11,6 +11,7 @@
 // bit-identical to the reference's; only the summation order differs.
 #include <cstdio>
 #include <cstdlib>
+#include <time.h>
 
 #include "chx_common.h"
 #include "chx_internal.h"
@@ -915,8 +916,11 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   // (CHX_EXP_*: timing decomposition of scripts/exp_step.sh, never defined in the product build)
   // the control block as this launch finds it goes to the host-mapped copy (one wavefront, system-scope stores;
   // no-op launches publish too: that is how the host learns about a halt)
+  // word 0 of the copy is this launch's step index: "launch `step` has begun", i.e. every earlier launch of the
+  // stream has finished -- what chx_langevin_fused_run's launch window counts with
   if (a.host_ctrl != nullptr && blockIdx.x == 0 && threadIdx.x < 8)
-    __hip_atomic_store(&a.host_ctrl[threadIdx.x], ctrl_first[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&a.host_ctrl[threadIdx.x], threadIdx.x == 0 ? (int)step : ctrl_first[threadIdx.x], __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
 #ifndef CHX_EXP_NOCTRL
   // (naming the arguments the first vector loads need in an asm statement ahead of this branch makes
   // their fetch leave together with the halt word's -- and measured 3 % slower: the stale-word read
@@ -1006,8 +1010,13 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   if (threadIdx.x == 0 && blk < CHX_STAMP_BLOCKS) g_stamps[step & 3][blk][6] = (g_stamps[step & 3][blk][6] & 0xFFFFFFFFull) | (stamp_rt() << 32);
 #endif
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (PRUNE) ctrl_first[7] += 1;                            // refreshes of the inner list
-    else if ((HOT || a.fli) && !inner) ctrl_first[6] += 1;    // launches on the full list
+    // (the counters go to the host copy as they change: the copy made at launch start cannot hold this launch's own)
+    const int w = PRUNE ? 7 : 6;
+    if (PRUNE || ((HOT || a.fli) && !inner)) {  // refreshes of the inner list / launches on the full list
+      const int c = ctrl_first[w] + 1;
+      ctrl_first[w] = c;
+      if (a.host_ctrl != nullptr) __hip_atomic_store(&a.host_ctrl[w], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -1176,8 +1185,13 @@ static void launch_step_g(const StepArgs& a, long long step, int n_kicks, int do
 }
 
 // launch i of the chunk reads (i even ? x_even : x_odd) and writes the other buffer
+// window > 0 (needs p->host_ctrl, readable by the host at the same address): launch step s only once fewer than
+// `window` earlier launches are still waiting to begin, and stop at the first step the halt word rules out;
+// *n_enqueued = launches made.  What the host polls is the copy of the control block every launch stores into
+// host_ctrl when it begins (word 0 = its step index, word 3 = the halt word).
 int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, int64_t step0,
-                        int n_steps, int kicks_first, int do_aoa, hipStream_t st) {
+                        int n_steps, int kicks_first, int do_aoa, hipStream_t st, int window, int32_t* n_enqueued) {
+  if (n_enqueued) *n_enqueued = 0;
   StepArgs a;
   a.n = p->n;
   a.v = p->v;
@@ -1212,7 +1226,30 @@ int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, in
     a.T_inner = rk * rk;
     a.half_inner = hm;
   }
+  const bool throttle = window > 0 && a.host_ctrl != nullptr;
   for (int i = 0; i < n_steps; ++i) {
+    if (throttle) {
+      const long long s = step0 + i;
+      const volatile int32_t* hc = a.host_ctrl;
+      int last = hc[0];
+      timespec t0{};
+      for (unsigned spins = 0;; ++spins) {
+        if ((long long)hc[3] <= s) return CHX_OK;  // the skin check has fired: launches from s on would be no-ops
+        const int begun = hc[0];                   // newest launch that has begun; begun+1 .. s-1 are still waiting
+        if (s - begun <= window) break;
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFF) == 0xFFFF) {  // a stream that makes no progress for a minute is not coming back
+          timespec t1;
+          clock_gettime(CLOCK_MONOTONIC, &t1);
+          if (begun != last || t0.tv_sec == 0) last = begun, t0 = t1;
+          else if (t1.tv_sec - t0.tv_sec > 60) {
+            chx_set_error("chx_langevin_fused_run: no step launch has begun for 60 s (step %lld, newest begun %d)", s, begun);
+            return CHX_ERR_LAUNCH;
+          }
+        }
+      }
+    }
+    if (n_enqueued) *n_enqueued = i + 1;
     a.x_cur = reinterpret_cast<const float4*>((i & 1) ? x_odd : x_even);
     a.x_next = (i & 1) ? x_even : x_odd;
     const int nk = i == 0 ? kicks_first : 2;

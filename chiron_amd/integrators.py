@@ -50,7 +50,8 @@ class LangevinIntegrator:
     """Langevin dynamics with the BAOAB splitting (Leimkuhler & Matthews 2013).
 
     Same constructor and ``run`` signature as chiron/integrators.py:25-105.
-    ``chunk_size`` (steps enqueued per launch batch) is the only addition.
+    ``chunk_size`` (steps enqueued per launch batch) and ``launch_window`` (launches kept queued ahead of the
+    device) are the only additions; neither changes a trajectory.
     """
 
     def __init__(
@@ -62,6 +63,7 @@ class LangevinIntegrator:
         reporter=None,
         save_traj_in_memory: bool = False,
         chunk_size: int = 32,
+        launch_window: Optional[int] = None,
     ) -> None:
         self.kB = unit.BOLTZMANN_CONSTANT_kB * unit.AVOGADRO_CONSTANT_NA
         self.timestep = timestep
@@ -75,6 +77,11 @@ class LangevinIntegrator:
         self.refresh_velocities = refresh_velocities
         self._move_iteration = 0
         self.chunk_size = max(1, int(chunk_size))
+        # step launches the host keeps queued ahead of the device on the neighbor-list path (0: the older scheme, two
+        # whole chunks ahead).  After the skin check fires everything still queued is dead time in front of the rebuild.
+        if launch_window is None:
+            launch_window = int(os.environ.get("CHX_LAUNCH_WINDOW", "16"))
+        self.launch_window = max(0, int(launch_window))
         self.n_rebuilds = 0  # neighbor-list rebuilds triggered inside the last run()
 
     # ------------------------------------------------------------------
@@ -346,6 +353,8 @@ class _RunState:
             if self.is_verlet:
                 skin = float(self.nbr_list.skin.value_in_unit_system(unit.md_unit_system))
         ops.ctrl_reset(self.ctrl)
+        if self.mode == "fused" and self._windowed():
+            self._open_generation(step)
         p = LangevinParams()
         p.n = n
         p.g = self.fl.g if self.fl is not None else 1
@@ -385,7 +394,55 @@ class _RunState:
                 self.fl_inner, self.deg_inner = keep["fl"], keep["deg"]
                 p.fl_inner, p.deg_inner = self.fl_inner.data_ptr(), self.deg_inner.data_ptr()
                 p.inner_skin, p.prune_every, p.prune_phase = inner, every, step
+        if self.mode == "fused" and self._windowed():
+            p.host_ctrl = self._gen[2].data_ptr()
         self.params = p
+
+    # -- host-visible control block of the launch window ---------------------------------------
+    def _windowed(self) -> bool:
+        return self.integ.launch_window > 0 and _HOST_CTRL_IN_KERNEL[0]
+
+    def _open_generation(self, step: int):
+        """A *generation* = the step launches between two loads of the state (list rebuilds).  All of them copy
+        the control block into one host-mapped slot (chx_langevin_t::host_ctrl), and no launch of another
+        generation writes there -- the no-op launches still in flight when the host starts a rebuild keep storing
+        the OLD halt word, so the next generation needs a slot of its own.  A slot is taken from a ring of four and
+        reused only after the launches that wrote to it have run (``_close_generation`` leaves an event)."""
+        if getattr(self, "_gen", None) is not None and self._gen[3]:
+            self._close_generation()
+        ring = self.integ.__dict__.setdefault("_gen_ring", [])
+        if not ring:
+            for _ in range(4):
+                t = torch.empty((8,), dtype=torch.int32, pin_memory=True)
+                ring.append([t.numpy(), None, t, False])  # [host view, event of the last launch, tensor, open?]
+            self.integ._gen_next = 0
+        slot = ring[self.integ._gen_next % len(ring)]
+        self.integ._gen_next += 1
+        if slot[1] is not None:
+            slot[1].synchronize()
+            slot[1] = None
+        elif slot[3]:  # left open by a run that ended in an exception
+            torch.cuda.current_stream().synchronize()
+        # what chx_ctrl_reset writes, with word 0 = "the launch before `step` has begun": nothing is queued
+        slot[0][:] = (step - 1, 0, 0, _INT_MAX, -2, -2, 0, 0)
+        slot[3] = True
+        self._gen, self._gen_step0 = slot, step
+
+    def _close_generation(self):
+        """Every launch of the current generation is enqueued: leave an event behind the last one."""
+        ev = torch.cuda.Event()
+        ev.record()
+        self._gen[1], self._gen[3] = ev, False
+        self.__dict__.setdefault("_closed", []).append(self._gen)
+
+    def _bank_closed(self):
+        """Fold the counters of finished generations (full-list launches, refreshes of the inner list) into the
+        integrator's totals."""
+        for slot in self.__dict__.pop("_closed", []):
+            if slot[1] is not None:
+                slot[1].synchronize()
+            self.integ.full_list_launches = getattr(self.integ, "full_list_launches", 0) + int(slot[0][6])
+            self.integ.prune_passes = getattr(self.integ, "prune_passes", 0) + int(slot[0][7])
 
     def _x_cur(self) -> torch.Tensor:
         return self.x_a if self.parity == 0 else self.x_b
@@ -536,6 +593,70 @@ class _RunState:
             self._kick_rec = None
         return done
 
+    # -- fused neighbor-list path, bounded launch queue --------------------------------------------
+    def _enqueue_window(self, s0: int, n: int) -> int:
+        even, odd = (self.x_a, self.x_b) if self.parity == 0 else (self.x_b, self.x_a)
+        sent = ops.langevin_fused_run(self.params, even, odd, s0, n, self.kicks_next, self.integ.launch_window)
+        if sent:
+            self.parity ^= sent & 1
+            self.kicks_next = 2
+        return sent
+
+    def _enqueue_kick(self, step: int):
+        """Force + trailing half-kick (chiron/integrators.py:195) as launch ``step``: a no-op if the skin check
+        has fired by then, like every launch of the generation."""
+        even, odd = (self.x_a, self.x_b) if self.parity == 0 else (self.x_b, self.x_a)
+        ops.langevin_fused_chunk(self.params, even, odd, step, 1, 1, 0)
+        ev = torch.cuda.Event()
+        ev.record()
+        ev.synchronize()
+
+    def _advance_windowed(self, done: int, stop: int, final: bool = False) -> int:
+        """Steps [done, stop) through ``chx_langevin_fused_run``: the C loop keeps at most ``launch_window``
+        launches queued ahead of the device and returns early when it sees the halt word, so a rebuild starts
+        behind a handful of no-op launches instead of up to two chunks of them."""
+        chunk = self.integ.chunk_size
+        enq = done  # first step not enqueued yet
+        self._kick_sent = False
+        while True:
+            while enq < stop:
+                c = min(chunk, stop - enq)
+                sent = self._enqueue_window(enq, c)
+                enq += sent
+                if sent < c:
+                    break  # the launch loop saw the halt word
+                pend = getattr(self, "_unsettled", None)
+                if pend is not None and enq - pend[2] >= max(chunk, self.integ.launch_window + 1):
+                    # (that many launches after a speculative rebuild its status block has long arrived)
+                    if not self._settle():
+                        enq = self._unsettled_step
+            if enq == stop:
+                if final and not self._kick_sent:
+                    self._enqueue_kick(stop)  # (waits: everything up to here has run)
+                    self._kick_sent = True
+                else:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    ev.synchronize()
+            if not self._settle():
+                # the speculative list these launches ran on was rejected (whatever they halted on or produced is
+                # void): the state is back at the rebuild step, on the list the synchronous build made
+                enq = self._unsettled_step
+                self._kick_sent = False
+                continue
+            halt = int(self._gen[0][3])
+            if halt > stop:
+                break
+            # the skin check fired while producing x_halt: steps < halt ran, the launches queued behind are no-ops
+            # and the rebuild is enqueued behind them
+            self._kick_sent = False
+            self.parity = (halt - self._gen_step0) & 1
+            self._close_generation()  # (before the rebuild's kernels: the event must not wait for them)
+            self._rebuild(halt, speculative=True)
+            self._bank_closed()
+            enq = halt
+        return stop
+
     # -- other paths -------------------------------------------------------
     def _external_force(self):
         """Potentials without a fused kernel: ask the potential (reference integrators.py:171,193)."""
@@ -549,6 +670,8 @@ class _RunState:
         """Run steps [done, stop); returns the new step count (== stop).  ``final``: ``stop`` is the end of the
         run (the fused path then enqueues the trailing kick behind the last chunk, see ``final_kick``)."""
         if self.mode == "fused":
+            if self._windowed():
+                return self._advance_windowed(done, stop, final)
             return self._advance_fused(done, stop, final)
         if self.mode == "pairs":
             # all-pairs force + BAOAB in one launch per step (k_ap_step); no skin check exists on this
@@ -574,7 +697,19 @@ class _RunState:
 
     def final_kick(self, n_steps: int):
         """Trailing half-kick of the last step (chiron/integrators.py:195)."""
-        if self.mode == "fused":
+        if self.mode == "fused" and self._windowed():
+            if not getattr(self, "_kick_sent", False):
+                self._enqueue_kick(n_steps)
+            if int(self._gen[0][3]) <= n_steps:
+                # the skin check fired in the run's very last step and the kick ran as a no-op: rebuild exactly as
+                # _advance_windowed does, then kick
+                self.parity = (n_steps - self._gen_step0) & 1
+                self._rebuild(n_steps, speculative=False)
+                self._enqueue_kick(n_steps)
+            self._kick_sent = False
+            self._close_generation()
+            self._bank_closed()
+        elif self.mode == "fused":
             rec = getattr(self, "_kick_rec", None)  # already in flight behind the last chunk?
             self._kick_rec = None
             if rec is None:

@@ -482,6 +482,22 @@ def langevin_fused_chunk(params: LangevinParams, x_even: torch.Tensor, x_odd: to
     )
 
 
+_n_enqueued = C.c_int32(0)
+
+
+def langevin_fused_run(params: LangevinParams, x_even: torch.Tensor, x_odd: torch.Tensor, step0: int,
+                       n_steps: int, kicks_first: int, window: int) -> int:
+    """``langevin_fused_chunk`` with a bounded launch queue (include/chx.h: chx_langevin_fused_run).
+    Returns the number of launches made: fewer than ``n_steps`` when the host saw the halt word."""
+    _require_device(x_even, x_odd)
+    check(
+        _lib.load().chx_langevin_fused_run(C.byref(params), _ptr(x_even), _ptr(x_odd), step0, n_steps, kicks_first, window,
+                                           C.byref(_n_enqueued), _stream()),
+        "chx_langevin_fused_run",
+    )
+    return _n_enqueued.value
+
+
 def ctrl_reset(ctrl: torch.Tensor) -> None:
     _require_device(ctrl)
     check(_lib.load().chx_ctrl_reset(_ptr(ctrl), _stream()), "chx_ctrl_reset")

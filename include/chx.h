@@ -275,7 +275,9 @@ typedef struct {
    * that raises the halt word also stores it there directly, so the host can read the state of a chunk after
    * waiting for the stream WITHOUT a separate chx_publish launch.  What the host reads is complete up to the
    * chunk's last launch; a halt raised by that very launch is normally there too (its direct store) and otherwise
-   * shows up with the next launch -- which is a no-op by then, so nothing is lost but a little time.  NULL = off. */
+   * shows up with the next launch -- which is a no-op by then, so nothing is lost but a little time.  Word 0 of
+   * the copy is the step index of the newest launch that has begun (not ctrl[0]); words 6 and 7 are also stored
+   * whenever they change.  NULL = off. */
   int32_t* host_ctrl;
 } chx_langevin_t;
 
@@ -322,6 +324,22 @@ int chx_langevin_resume(const chx_langevin_t* p_h, chx_stream_t stream);
 int chx_langevin_fused_chunk(const chx_langevin_t* p_h, float* x_even, float* x_odd, int64_t step0,
                              int32_t n_steps, int32_t kicks_first, int32_t do_aoa,
                              chx_stream_t stream);
+
+/* The same launches as chx_langevin_fused_chunk(do_aoa = 1) on the force-list path, with a bounded launch queue:
+ * step s is enqueued only once fewer than `window` earlier step launches are still waiting to begin, and the call
+ * stops enqueuing at the first step >= the halt word -- launches the skin check (chiron/integrators.py:239-241) has
+ * already turned into no-ops.  *n_enqueued_out = launches made (n_steps unless it stopped early).  The host side polls
+ * p_h->host_ctrl, which is required and must be readable by the host at the same address (hipHostMalloc'ed memory):
+ * every step launch stores the control block there when it begins, word 0 replaced by its step index and word 3 the
+ * halt word (a halting thread also stores word 3 directly).  Before the first call after a chx_ctrl_reset the
+ * caller sets host_ctrl[0] = step0 - 1 and host_ctrl[3] = INT32_MAX.  Returns when the launches are enqueued (at
+ * most `window` of them not yet begun), not when they have run: a halt raised by the last few launches is for the
+ * next call, or for the caller's wait on the stream, to find.  Why: after a halt everything still queued is dead
+ * time in front of the list rebuild (about 2 us per no-op launch), so the queue should be as short as the host's
+ * launch latency allows rather than a fixed number of chunks. */
+int chx_langevin_fused_run(const chx_langevin_t* p_h, float* x_even, float* x_odd, int64_t step0,
+                           int32_t n_steps, int32_t kicks_first, int32_t window,
+                           int32_t* n_enqueued_out, chx_stream_t stream);
 
 /* Control-block plumbing of the loop above, as ordinary kernels on the caller's stream:
  * chx_ctrl_reset writes {0, 0, 0, INT32_MAX, -2, -2, 0, 0}; chx_publish copies n <= 64 ints into
