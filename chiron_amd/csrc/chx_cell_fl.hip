@@ -285,7 +285,16 @@ __global__ void k_pack_langevin(const float* __restrict__ x3, const float* __res
                                 const float* __restrict__ mass, const float* __restrict__ ref3,
                                 const uint32_t* __restrict__ perm, int n, float4* __restrict__ x4,
                                 float* __restrict__ v, float* __restrict__ mass_out,
-                                float4* __restrict__ ref4) {
+                                float4* __restrict__ ref4, int32_t* __restrict__ ctrl,
+                                const int32_t* __restrict__ pub_src, int32_t* __restrict__ pub_host) {
+  // riders of the integrator's rebuild (one launch instead of three): the control-block reset of chx_ctrl_reset
+  // and the copy of the build's status block to host-mapped memory of chx_publish
+  if (blockIdx.x == 0) {
+    const int t = threadIdx.x;
+    if (ctrl != nullptr && t < 8) ctrl[t] = t == 3 ? 0x7FFFFFFF : ((t == 4 || t == 5) ? -2 : 0);
+    if (pub_src != nullptr && t >= 64 && t < 72)
+      __hip_atomic_store(&pub_host[t - 64], pub_src[t - 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const size_t o = perm ? perm[p] : (uint32_t)p;
@@ -300,13 +309,16 @@ __global__ void k_pack_langevin(const float* __restrict__ x3, const float* __res
 
 extern "C" int chx_pack_langevin(const float* x3, const float* v3, const float* mass,
                                  const float* ref3, const uint32_t* perm, int32_t n, float* x4_out,
-                                 float* v_out, float* mass_out, float* ref4_out, chx_stream_t stream) {
+                                 float* v_out, float* mass_out, float* ref4_out, int32_t* ctrl_reset,
+                                 const int32_t* publish_src8, int32_t* publish_host_dst8, chx_stream_t stream) {
   CHX_REQUIRE(n >= 0, "n < 0");
-  if (n == 0) return CHX_OK;
-  CHX_REQUIRE(x3 && v3 && mass && x4_out && v_out && mass_out, "null pointer");
+  CHX_REQUIRE((publish_src8 == nullptr) == (publish_host_dst8 == nullptr), "publish needs both a source and a destination");
+  if (n == 0 && !ctrl_reset && !publish_src8) return CHX_OK;
+  CHX_REQUIRE(n == 0 || (x3 && v3 && mass && x4_out && v_out && mass_out), "null pointer");
   CHX_REQUIRE(!ref4_out || ref3, "ref4_out without ref3");
-  hipLaunchKernelGGL(k_pack_langevin, dim3((n + 255) / 256), dim3(256), 0, chx_stream(stream), x3, v3, mass,
+  const unsigned blocks = n > 0 ? (unsigned)((n + 255) / 256) : 1u;
+  hipLaunchKernelGGL(k_pack_langevin, dim3(blocks), dim3(256), 0, chx_stream(stream), x3, v3, mass,
                      ref3, perm, n, reinterpret_cast<float4*>(x4_out), v_out, mass_out,
-                     reinterpret_cast<float4*>(ref4_out));
+                     reinterpret_cast<float4*>(ref4_out), ctrl_reset, publish_src8, publish_host_dst8);
   return chx_check_launch("chx_pack_langevin");
 }

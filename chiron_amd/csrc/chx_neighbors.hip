@@ -128,10 +128,12 @@ __global__ void k_cell_assign(const float* __restrict__ xyz, int n, Box3 box, Ce
 // single-block exclusive scan: cell_start[0..ncell] from cell_count; zeroes cell_count (reused as
 // cursor).  Tiles of 1024 cells, coalesced loads, wave-shuffle scans (two barriers per tile).
 __global__ __launch_bounds__(1024) void k_cell_scan(int32_t* __restrict__ cell_count,
-                                                    int32_t* __restrict__ cell_start, int ncell) {
+                                                    int32_t* __restrict__ cell_start, int ncell,
+                                                    int32_t* __restrict__ status, int status_len) {
   __shared__ int32_t wsum[16];
   __shared__ int32_t carry_s;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (t < status_len) status[t] = 0;  // (the build kernels behind this one accumulate into it: no memset launch)
   if (t == 0) carry_s = 0;
   __syncthreads();
   for (int base = 0; base < ncell; base += 1024) {
@@ -325,14 +327,14 @@ int chx_cell_prepare(const float* xyz, int n, chx_box_t box, float cutoff_plus_s
   g.ncx = nc_h[0]; g.ncy = nc_h[1]; g.ncz = nc_h[2];
   g.sx = (float)nc_h[0] / box.lx; g.sy = (float)nc_h[1] / box.ly; g.sz = (float)nc_h[2] / box.lz;
   *g_out = g;
-  if (hipMemsetAsync(cell_count, 0, sizeof(int32_t) * ((size_t)ncell + 1), st) != hipSuccess ||
-      hipMemsetAsync(status, 0, sizeof(int32_t) * status_len, st) != hipSuccess) {
+  CHX_REQUIRE(status_len >= 0 && status_len <= 1024, "status block too long");
+  if (hipMemsetAsync(cell_count, 0, sizeof(int32_t) * ((size_t)ncell + 1), st) != hipSuccess) {
     chx_set_error("chx_cell_prepare: hipMemsetAsync failed");
     return CHX_ERR_LAUNCH;
   }
   const unsigned pb = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(k_cell_assign, dim3(pb), dim3(256), 0, st, xyz, n, b3, g, cell_of, cell_count);
-  hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, st, cell_count, cell_start, ncell);
+  hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, st, cell_count, cell_start, ncell, status, status_len);
   hipLaunchKernelGGL(k_cell_scatter, dim3(pb), dim3(256), 0, st, cell_of, n, cell_start, cell_count,
                      sorted_ids);
   hipLaunchKernelGGL(k_cell_sort, dim3((unsigned)(((int64_t)ncell * CHX_WAVE + 255) / 256)), dim3(256), 0, st,

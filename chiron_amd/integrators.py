@@ -80,7 +80,7 @@ class LangevinIntegrator:
         # step launches the host keeps queued ahead of the device on the neighbor-list path (0: the older scheme, two
         # whole chunks ahead).  After the skin check fires everything still queued is dead time in front of the rebuild.
         if launch_window is None:
-            launch_window = int(os.environ.get("CHX_LAUNCH_WINDOW", "16"))
+            launch_window = int(os.environ.get("CHX_LAUNCH_WINDOW", "12"))
         self.launch_window = max(0, int(launch_window))
         self.n_rebuilds = 0  # neighbor-list rebuilds triggered inside the last run()
 
@@ -148,7 +148,7 @@ class LangevinIntegrator:
                     and getattr(nbr_list, "_box_token", None) is not None
                     and nbr_list._box_token is getattr(sampler_state, "_box_token", None)
                     and isinstance(x0, torch.Tensor) and x0.is_cuda and x0.dtype == torch.float32):
-                spec0 = nbr_list._build_speculative(x0.clone())
+                spec0 = nbr_list._build_speculative(x0.clone(), publish=False)  # (_RunState._load copies the status)
             if not spec0:
                 nbr_list.build_from_state(sampler_state)
         if is_lj and isinstance(nbr_list, NeighborListNsqrd):
@@ -259,6 +259,18 @@ class _Pending:
     __slots__ = ("s0", "n", "parity0", "host", "event")
 
 
+class _Slot:
+    """Host-mapped copy of the control block for one generation of step launches (_RunState._open_generation)."""
+
+    __slots__ = ("tensor", "host", "open", "dirty", "step0")
+
+    def __init__(self):
+        self.tensor = torch.empty((8,), dtype=torch.int32, pin_memory=True)
+        self.host = self.tensor.numpy()  # (a view: reading an element costs ~0.1 us instead of a tensor op)
+        self.open = self.dirty = False
+        self.step0 = 0
+
+
 class _RunState:
     """Device-resident state of one ``run`` call in the kernels' internal layout."""
 
@@ -331,9 +343,15 @@ class _RunState:
         n = self.n
         # one launch: positions (current buffer when parity == 0), velocities, masses, reference positions
         prev = (self.x_a, self.v, self.mass, self.ref4) if getattr(self, "x_a", None) is not None else None
+        # riders on the pack launch: the control-block reset and, after a speculative build, the copy of its status
+        # block to the host (one launch instead of three)
+        pub = self.nbr_list._take_publish() if self.mode == "fused" and hasattr(self.nbr_list, "_take_publish") else None
         self.x_a, self.v, self.mass, self.ref4 = ops.pack_langevin(
             x_user, v_user, self.mass_user, self.nbr_list.ref_positions if self.is_verlet else None, perm, self.is_verlet,
-            out=prev)  # a rebuild writes into the buffers of the previous load (the state was copied out first)
+            out=prev,  # a rebuild writes into the buffers of the previous load (the state was copied out first)
+            ctrl=self.ctrl, publish=pub)
+        if pub is not None:
+            self.nbr_list._published(record=not self._windowed())  # (the launch window tells without an event)
         if self.mode in ("fused", "pairs"):  # one launch per step, positions ping-pong between two buffers
             if getattr(self, "x_b", None) is None:
                 self.x_b = torch.empty_like(self.x_a)  # fully written before it is read
@@ -351,8 +369,10 @@ class _RunState:
             box = self.nbr_list._box_h
             wrap = 1
             if self.is_verlet:
-                skin = float(self.nbr_list.skin.value_in_unit_system(unit.md_unit_system))
-        ops.ctrl_reset(self.ctrl)
+                sk = getattr(self, "_skin_md", None)  # (unit arithmetic is slow Python: once per skin object)
+                if sk is None or sk[0] is not self.nbr_list.skin:
+                    sk = self._skin_md = (self.nbr_list.skin, float(self.nbr_list.skin.value_in_unit_system(unit.md_unit_system)))
+                skin = sk[1]
         if self.mode == "fused" and self._windowed():
             self._open_generation(step)
         p = LangevinParams()
@@ -395,7 +415,7 @@ class _RunState:
                 p.fl_inner, p.deg_inner = self.fl_inner.data_ptr(), self.deg_inner.data_ptr()
                 p.inner_skin, p.prune_every, p.prune_phase = inner, every, step
         if self.mode == "fused" and self._windowed():
-            p.host_ctrl = self._gen[2].data_ptr()
+            p.host_ctrl = self._gen.tensor.data_ptr()
         self.params = p
 
     # -- host-visible control block of the launch window ---------------------------------------
@@ -406,43 +426,43 @@ class _RunState:
         """A *generation* = the step launches between two loads of the state (list rebuilds).  All of them copy
         the control block into one host-mapped slot (chx_langevin_t::host_ctrl), and no launch of another
         generation writes there -- the no-op launches still in flight when the host starts a rebuild keep storing
-        the OLD halt word, so the next generation needs a slot of its own.  A slot is taken from a ring of four and
-        reused only after the launches that wrote to it have run (``_close_generation`` leaves an event)."""
-        if getattr(self, "_gen", None) is not None and self._gen[3]:
+        the OLD halt word, so the next generation needs a slot of its own.  Slots come from a ring of four; one is
+        reused (and its counters banked) only once its launches are known to have run: a later generation has
+        begun a launch of its own, which the stream orders behind them -- no event, no wait in the common case."""
+        cur = getattr(self, "_gen", None)
+        if cur is not None and cur.open:
             self._close_generation()
         ring = self.integ.__dict__.setdefault("_gen_ring", [])
         if not ring:
-            for _ in range(4):
-                t = torch.empty((8,), dtype=torch.int32, pin_memory=True)
-                ring.append([t.numpy(), None, t, False])  # [host view, event of the last launch, tensor, open?]
+            ring.extend(_Slot() for _ in range(4))
             self.integ._gen_next = 0
         slot = ring[self.integ._gen_next % len(ring)]
         self.integ._gen_next += 1
-        if slot[1] is not None:
-            slot[1].synchronize()
-            slot[1] = None
-        elif slot[3]:  # left open by a run that ended in an exception
-            torch.cuda.current_stream().synchronize()
+        if slot.open or slot.dirty:
+            if not (cur is not None and cur is not slot and int(cur.host[0]) >= cur.step0):
+                torch.cuda.current_stream().synchronize()  # (a run that ended in an exception, a zero-step run)
+            self._retire(slot)
         # what chx_ctrl_reset writes, with word 0 = "the launch before `step` has begun": nothing is queued
-        slot[0][:] = (step - 1, 0, 0, _INT_MAX, -2, -2, 0, 0)
-        slot[3] = True
+        slot.host[:] = (step - 1, 0, 0, _INT_MAX, -2, -2, 0, 0)
+        slot.open, slot.dirty, slot.step0 = True, False, step
         self._gen, self._gen_step0 = slot, step
 
     def _close_generation(self):
-        """Every launch of the current generation is enqueued: leave an event behind the last one."""
-        ev = torch.cuda.Event()
-        ev.record()
-        self._gen[1], self._gen[3] = ev, False
-        self.__dict__.setdefault("_closed", []).append(self._gen)
+        """Every launch of the current generation is enqueued."""
+        self._gen.open, self._gen.dirty = False, True
 
-    def _bank_closed(self):
-        """Fold the counters of finished generations (full-list launches, refreshes of the inner list) into the
-        integrator's totals."""
-        for slot in self.__dict__.pop("_closed", []):
-            if slot[1] is not None:
-                slot[1].synchronize()
-            self.integ.full_list_launches = getattr(self.integ, "full_list_launches", 0) + int(slot[0][6])
-            self.integ.prune_passes = getattr(self.integ, "prune_passes", 0) + int(slot[0][7])
+    def _retire(self, slot):
+        """The launches that wrote to ``slot`` have run: fold its counters (launches on the full list, refreshes of
+        the inner list) into the integrator's totals."""
+        self.integ.full_list_launches = getattr(self.integ, "full_list_launches", 0) + int(slot.host[6])
+        self.integ.prune_passes = getattr(self.integ, "prune_passes", 0) + int(slot.host[7])
+        slot.open = slot.dirty = False
+
+    def _retire_all(self):
+        """After a wait for the stream: every closed generation has run."""
+        for slot in self.integ.__dict__.get("_gen_ring", []):
+            if slot.dirty and not slot.open:
+                self._retire(slot)
 
     def _x_cur(self) -> torch.Tensor:
         return self.x_a if self.parity == 0 else self.x_b
@@ -473,8 +493,10 @@ class _RunState:
         if prof:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        x_user, v_user = self.positions_user(), self.velocities_user()
-        spec = speculative and _SPECULATIVE_REBUILD and self.nbr_list._build_speculative(x_user)
+        # (the build only needs the positions: its kernels are on their way before the velocities are unpacked)
+        x_user = self.positions_user()
+        spec = speculative and _SPECULATIVE_REBUILD and self.nbr_list._build_speculative(x_user, publish=False)
+        v_user = self.velocities_user()
         if not spec:
             self.nbr_list._adopt_positions = True  # x_user is a fresh tensor nobody else holds
             try:
@@ -496,7 +518,15 @@ class _RunState:
         if pend is None:
             return True
         self._unsettled = None
-        if self.nbr_list._confirm_build():
+        if self.mode == "fused" and self._windowed():
+            # the build's status block reaches the host with the pack launch of the load that followed the build;
+            # a step launch of that load's generation has begun => it is there.  Otherwise wait for the stream.
+            if int(self._gen.host[0]) < self._gen_step0:
+                torch.cuda.current_stream().synchronize()
+            ok = self.nbr_list._confirm_build(wait=False)
+        else:
+            ok = self.nbr_list._confirm_build()
+        if ok:
             return True
         x_user, v_user, step, kicks = pend
         torch.cuda.synchronize()
@@ -644,16 +674,15 @@ class _RunState:
                 enq = self._unsettled_step
                 self._kick_sent = False
                 continue
-            halt = int(self._gen[0][3])
+            halt = int(self._gen.host[3])
             if halt > stop:
                 break
             # the skin check fired while producing x_halt: steps < halt ran, the launches queued behind are no-ops
             # and the rebuild is enqueued behind them
             self._kick_sent = False
             self.parity = (halt - self._gen_step0) & 1
-            self._close_generation()  # (before the rebuild's kernels: the event must not wait for them)
+            self._close_generation()
             self._rebuild(halt, speculative=True)
-            self._bank_closed()
             enq = halt
         return stop
 
@@ -700,7 +729,7 @@ class _RunState:
         if self.mode == "fused" and self._windowed():
             if not getattr(self, "_kick_sent", False):
                 self._enqueue_kick(n_steps)
-            if int(self._gen[0][3]) <= n_steps:
+            if int(self._gen.host[3]) <= n_steps:
                 # the skin check fired in the run's very last step and the kick ran as a no-op: rebuild exactly as
                 # _advance_windowed does, then kick
                 self.parity = (n_steps - self._gen_step0) & 1
@@ -708,7 +737,7 @@ class _RunState:
                 self._enqueue_kick(n_steps)
             self._kick_sent = False
             self._close_generation()
-            self._bank_closed()
+            self._retire_all()  # (_enqueue_kick waited for the stream)
         elif self.mode == "fused":
             rec = getattr(self, "_kick_rec", None)  # already in flight behind the last chunk?
             self._kick_rec = None

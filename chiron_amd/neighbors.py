@@ -320,7 +320,7 @@ class NeighborListNsqrd(PairsBase):
         self.n_builds += 1
 
     # -- unsynchronised rebuild (integrator only) ---------------------------------------------
-    def _build_speculative(self, positions: torch.Tensor) -> bool:
+    def _build_speculative(self, positions: torch.Tensor, publish: bool = True) -> bool:
         """Rebuild from ``positions`` WITHOUT waiting for the build's status block.
 
         The reference synchronises inside every build (chiron/neighbors.py:709) to decide whether
@@ -330,7 +330,8 @@ class NeighborListNsqrd(PairsBase):
         long arrived) and, if a capacity did overflow, redoes the build through ``build()`` -- the
         caller then discards whatever it ran on the speculative list.  The overflowing kernel bounds
         its writes, so a speculative list is always safe to walk.  Returns False (nothing enqueued)
-        when this fast path does not apply.
+        when this fast path does not apply.  ``publish=False``: the caller copies the status block to the host
+        itself (``_take_publish`` / ``_published``: the integrator lets its pack launch do it).
         """
         if not (self.is_built and self._use_cell_list and getattr(self, "_box_h", None) is not None
                 and self._box_h.periodic and getattr(self, "_fl_geo", None) is not None and self._cs_md is not None):
@@ -353,9 +354,15 @@ class NeighborListNsqrd(PairsBase):
         host = getattr(self, "_status_host", None)
         if host is None:
             host = self._status_host = torch.empty((8,), dtype=torch.int32, pin_memory=True)
-        ops.publish(status, host, 8)
-        ev = torch.cuda.Event()
-        ev.record()
+        ev = getattr(self, "_spec_event", None)
+        if ev is None:
+            ev = self._spec_event = torch.cuda.Event()  # (one event, recorded again by every speculative build)
+        if publish:
+            ops.publish(status, host, 8)
+            ev.record()
+            self._pending_publish, self._spec_recorded = None, True
+        else:
+            self._pending_publish = (status, host)
         self._spec = (ev, m, g, chunks)
         self._nl, self._nl_mask, self._first = nl, None, first
         self.n_neighbors = n_nbr
@@ -364,7 +371,21 @@ class NeighborListNsqrd(PairsBase):
         self.n_builds += 1
         return True
 
-    def _confirm_build(self) -> bool:
+    def _take_publish(self):
+        """(status block, pinned host block) a ``_build_speculative(publish=False)`` left for the caller to copy,
+        or None; the caller reports back with ``_published`` once the copying launch is enqueued."""
+        pub = getattr(self, "_pending_publish", None)
+        self._pending_publish = None
+        return pub
+
+    def _published(self, record: bool = True):
+        """``record=False``: the caller has its own way of knowing when the copy has landed and will confirm with
+        ``_confirm_build(wait=False)``."""
+        self._spec_recorded = record
+        if record:
+            self._spec_event.record()
+
+    def _confirm_build(self, wait: bool = True) -> bool:
         """True if the last ``_build_speculative`` produced the list ``build()`` would have; otherwise
         the list has been rebuilt synchronously from the same positions and False is returned."""
         spec = getattr(self, "_spec", None)
@@ -372,7 +393,16 @@ class NeighborListNsqrd(PairsBase):
             return True
         self._spec = None
         ev, m, g, chunks = spec
-        ev.synchronize()
+        pub = self._take_publish()
+        if pub is not None:  # nobody copied the status block yet
+            ops.publish(pub[0], pub[1], 8)
+            ev.record()
+            self._spec_recorded, wait = True, True
+        if wait:
+            if getattr(self, "_spec_recorded", True):
+                ev.synchronize()
+            else:
+                torch.cuda.current_stream().synchronize()
         st = self._status_host.tolist()
         # [0] on-chip candidate overflow, [1] max n_neighbors, [2] rows with exactly m entries (the
         # reference's growth trigger), [3] max force-list degree, [4] force-list rows that did not fit

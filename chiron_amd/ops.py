@@ -204,9 +204,10 @@ def nl_finish_padding(nl: torch.Tensor, first: torch.Tensor, n_nbr: torch.Tensor
     return mask
 
 
-def pack_langevin(x3, v3, mass, ref3, perm, want_ref: bool, out=None):
+def pack_langevin(x3, v3, mass, ref3, perm, want_ref: bool, out=None, ctrl=None, publish=None):
     """User-order state -> internal order in one launch: (x4, v, mass_internal, ref4 or None).
-    ``out`` = a previous result of the same shapes to write into."""
+    ``out`` = a previous result of the same shapes to write into.  Riders on the same launch: ``ctrl`` = control
+    block to reset (``ctrl_reset``), ``publish`` = (device block of 8 ints, pinned host block) to copy (``publish``)."""
     x3, v3, mass = _f32(x3), _f32(v3), _f32(mass)
     _require_device(x3, v3, mass, perm)
     n = x3.shape[0]
@@ -223,7 +224,9 @@ def pack_langevin(x3, v3, mass, ref3, perm, want_ref: bool, out=None):
         _require_device(ref3)
     check(
         _lib.load().chx_pack_langevin(_ptr(x3), _ptr(v3), _ptr(mass), _ptr(ref3) if want_ref else None, _ptr(perm), n,
-                                      _ptr(x4), _ptr(v), _ptr(m_int), _ptr(ref4), _stream()),
+                                      _ptr(x4), _ptr(v), _ptr(m_int), _ptr(ref4), _ptr(ctrl),
+                                      _ptr(publish[0]) if publish else None,
+                                      C.c_void_p(publish[1].data_ptr()) if publish else None, _stream()),
         "chx_pack_langevin",
     )
     return x4, v, m_int, ref4

@@ -176,10 +176,13 @@ int chx_permute_unpack(const float* src, int32_t src_stride, const uint32_t* per
                        float* dst3, chx_stream_t stream);
 int chx_invert_perm(const uint32_t* perm, int32_t n, uint32_t* inv_out, chx_stream_t stream);
 /* one launch: x4[p] = x3[perm[p]], v[p] = v3[perm[p]], mass_out[p] = mass[perm[p]],
- * ref4[p] = (ref3[perm[p]], mass_out[p]) (ref4_out may be NULL) */
+ * ref4[p] = (ref3[perm[p]], mass_out[p]) (ref4_out may be NULL).  Optional riders, so that a list rebuild inside
+ * the Langevin loop costs one launch here instead of three: ctrl_reset != NULL -> what chx_ctrl_reset writes;
+ * publish_src8 / publish_host_dst8 != NULL -> what chx_publish(src, dst, 8) does (the build's status block). */
 int chx_pack_langevin(const float* x3, const float* v3, const float* mass, const float* ref3,
                       const uint32_t* perm, int32_t n, float* x4_out, float* v_out, float* mass_out,
-                      float* ref4_out, chx_stream_t stream);
+                      float* ref4_out, int32_t* ctrl_reset, const int32_t* publish_src8,
+                      int32_t* publish_host_dst8, chx_stream_t stream);
 
 /* LJPotential.compute_energy / compute_force over the neighbor list:
  * E = sum over listed pairs with d < cutoff of 4 eps ((s/d)^12 - (s/d)^6)

@@ -35,7 +35,6 @@ wrap(I._RunState, "velocities_user")
 wrap(I._RunState, "_load")
 wrap(I._RunState, "_open_generation")
 wrap(I._RunState, "_close_generation")
-wrap(I._RunState, "_bank_closed")
 wrap(I._RunState, "_inner_list_settings")
 wrap(type(nbr), "_build_speculative")
 wrap(ops, "nl_build_cell_fl", "ops.nl_build_cell_fl")

@@ -121,7 +121,8 @@ int main() {
   EXPECT_INVALID(chx_permute_pack(F, nullptr, -1, F, 4, nullptr));
   EXPECT_INVALID(chx_permute_unpack(F, 4, nullptr, -1, F, nullptr));
   EXPECT_INVALID(chx_invert_perm(U, -1, U, nullptr));
-  EXPECT_INVALID(chx_pack_langevin(F, F, F, F, U, -1, F, F, F, F, nullptr));
+  EXPECT_INVALID(chx_pack_langevin(F, F, F, F, U, -1, F, F, F, F, nullptr, nullptr, nullptr, nullptr));
+  EXPECT_INVALID(chx_pack_langevin(F, F, F, F, U, 4, F, F, F, F, nullptr, I, nullptr, nullptr));  // publish without a destination
   EXPECT_INVALID(chx_lj_fl_energy_force(F, U, I, -1, 8, 1, ok_box, 0.34f, 1.f, 1.02f, F, F, d.data(), nullptr));
   EXPECT_INVALID(chx_lj_fl_energy_force(F, U, I, 4, 8, 1, ok_box, 0.34f, 1.f, 1.02f, nullptr, nullptr, d.data(), nullptr));
   EXPECT_INVALID(chx_lj_fl_energy_force(F, U, I, 4, 8, 1, ok_box, 0.34f, 1.f, 1.02f, nullptr, F, nullptr, nullptr));
@@ -154,6 +155,27 @@ int main() {
   EXPECT_INVALID(chx_langevin_fused_chunk(&lp, F, F, 0, -1, 1, 1, nullptr));
   lp.v = F, lp.mass = F, lp.ctrl = I, lp.fl = U, lp.deg = I, lp.ref4 = F, lp.g = 3, lp.fl_chunks = 1;
   EXPECT_INVALID(chx_langevin_fused_chunk(&lp, F, F, 0, 1, 1, 1, nullptr));  // g = 3 is not a supported lane count
+  // the bounded launch queue: needs the force-list path, a host-visible control block, a window and an out pointer
+  int32_t sent = -1;
+  EXPECT_INVALID(chx_langevin_fused_run(nullptr, F, F, 0, 1, 1, 4, &sent, nullptr));
+  EXPECT_INVALID(chx_langevin_fused_run(&lp, F, F, 0, 1, 1, 4, nullptr, nullptr));
+  EXPECT_INVALID(chx_langevin_fused_run(&lp, F, F, 0, 1, 1, 4, &sent, nullptr));  // host_ctrl == NULL
+  lp.host_ctrl = I;
+  EXPECT_INVALID(chx_langevin_fused_run(&lp, F, F, 0, 1, 1, 0, &sent, nullptr));  // window < 1
+  EXPECT_INVALID(chx_langevin_fused_run(&lp, F, F, 0, -1, 1, 4, &sent, nullptr));
+  {
+    // the halt word already rules out the first step: nothing is launched (so the bad lane count is never reached)
+    int32_t hc[8] = {6, 0, 0, 7, -2, -2, 0, 0};
+    lp.host_ctrl = hc;
+    sent = -1;
+    int rc = chx_langevin_fused_run(&lp, F, F, 7, 5, 2, 4, &sent, nullptr);
+    (void)rc;  // (without a device the trailing hipGetLastError may complain; what matters is that nothing was launched)
+    EXPECT(sent == 0);
+    // a free window and no halt: the first launch is attempted and rejected for its lane count
+    hc[3] = 0x7fffffff;
+    EXPECT_INVALID(chx_langevin_fused_run(&lp, F, F, 7, 5, 2, 4, &sent, nullptr));
+    lp.host_ctrl = I;
+  }
   EXPECT_INVALID(chx_mc_displace_chunk(nullptr, 0, 1, nullptr));
   chx_mc_t mp;
   memset(&mp, 0, sizeof(mp));

@@ -704,19 +704,19 @@ def test_langevin_speculative_rebuild(ca, O, monkeypatch, sabotage):
     cls = type(nbr)
     orig_spec, orig_confirm, orig_geo = cls._build_speculative, cls._confirm_build, cls._fl_geometry
 
-    def spec(self, positions):
+    def spec(self, positions, **kw):
         calls["spec"] += 1
         if sabotage and calls["spec"] == 1:
             monkeypatch.setattr(cls, "_fl_geometry", lambda s, n_: (1, 1))  # room for four entries per row
             try:
-                return orig_spec(self, positions)
+                return orig_spec(self, positions, **kw)
             finally:
                 monkeypatch.setattr(cls, "_fl_geometry", orig_geo)
-        return orig_spec(self, positions)
+        return orig_spec(self, positions, **kw)
 
-    def confirm(self):
+    def confirm(self, **kw):
         pending = getattr(self, "_spec", None) is not None
-        ok = orig_confirm(self)
+        ok = orig_confirm(self, **kw)
         if pending and not ok:
             calls["rejected"] += 1
         return ok
@@ -1712,8 +1712,9 @@ def test_reference_mcmc_workflows_on_a_harmonic_oscillator(ca, O):
         assert np.abs(s2.positions.cpu().numpy() - x).max() < 2e-6 * 20
 
 
+@pytest.mark.parametrize("window", [0, 1, 16])
 @pytest.mark.parametrize("where", ["end-of-run", "end-of-chunk", "mid-chunk"])
-def test_langevin_halt_at_chunk_and_run_boundaries_matches_oracle(ca, O, where):
+def test_langevin_halt_at_chunk_and_run_boundaries_matches_oracle(ca, O, where, window):
     """The skin check firing in the LAST step of a run (the rebuild then happens after the loop's last A-O-A and
     before the trailing force + kick, chiron/integrators.py:188-195 with :239-242) and in the last step of a chunk:
     the cases in which the halt word reaches the host late -- with the trailing-kick launch or with the first
@@ -1741,6 +1742,7 @@ def test_langevin_halt_at_chunk_and_run_boundaries_matches_oracle(ca, O, where):
         steps, chunk = h + 9, h + 3           # (control: in the middle of a chunk)
     _, _, pot, state, thermo, nbr, integ = _langevin_setup(ca, O, n, 0.3, 43, skin, 4.0, "NeighborListNsqrd", 250)
     integ.chunk_size = chunk
+    integ.launch_window = window  # 0: two chunks in flight; else the bounded launch queue (chx_langevin_fused_run)
     state.velocities = v0
     out, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr, noise=noise[:steps])
     xo, vo, rebuilds, (nl_mask, nl, n_max) = oracle(steps)
@@ -1751,3 +1753,31 @@ def test_langevin_halt_at_chunk_and_run_boundaries_matches_oracle(ca, O, where):
     if where == "end-of-run":
         # rebuilt from the final positions: the list's reference positions ARE the returned positions
         assert np.array_equal(nbr.ref_positions.cpu().numpy(), out.positions.cpu().numpy())
+
+
+@pytest.mark.parametrize("reports", [False, True], ids=["one-segment", "report-segments"])
+def test_langevin_launch_window_does_not_change_the_trajectory(ca, O, reports):
+    """The bounded launch queue (LangevinIntegrator.launch_window -> chx_langevin_fused_run) only changes how far the
+    host runs ahead of the device: trajectory, rebuild count, pruning counters and the rebuilt list are the same
+    bits for every window, for the older two-chunks-in-flight scheme (window 0), with the Philox stream and
+    with the run cut into report segments.  Thin skin + large time step: a rebuild every few steps."""
+    n, skin, steps = 2500, 0.05, 150
+    ref = None
+    for window, chunk in ((0, 32), (1, 32), (2, 5), (16, 32), (64, 7), (16, 1)):
+        x, box, pot, state, thermo, nbr, integ = _langevin_setup(ca, O, n, 0.3, 43, skin, 4.0)
+        integ.chunk_size, integ.launch_window = chunk, window
+        if reports:
+            integ.report_interval, integ.save_traj_in_memory = 11, True
+        ca.utils.PRNG.set_seed(77)
+        state.current_PRNG_key = ca.utils.PRNG.get_random_key()
+        out, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr)
+        got = (out.positions.clone(), out.velocities.clone(), integ.n_rebuilds, integ.prune_passes, integ.full_list_launches,
+               nbr.neighbor_list.clone(), [t.clone() for t in integ.traj])
+        assert integ.n_rebuilds >= 5
+        if ref is None:
+            ref = got
+            continue
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (window, chunk)
+        assert got[2:5] == ref[2:5], (window, chunk, got[2:5], ref[2:5])
+        assert torch.equal(got[5], ref[5])
+        assert len(got[6]) == len(ref[6]) and all(torch.equal(a, b) for a, b in zip(got[6], ref[6]))

@@ -375,6 +375,21 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
     failed(lib.chx_fl_fill(ctypes.c_void_p(64), ctypes.c_void_p(64), 8, 4, None, 3, ctypes.c_void_p(64),
                            ctypes.c_void_p(64), None), "power of two")
     failed(lib.chx_langevin_fused_chunk(None, None, None, 0, 1, 1, 1, None), "null params")
+    sent = ctypes.c_int32(-1)
+    failed(lib.chx_langevin_fused_run(None, None, None, 0, 1, 1, 4, ctypes.byref(sent), None), "null pointer")
+    lp = _lib.LangevinParams()
+    lp.n = 4
+    lp.v = lp.mass = lp.ctrl = lp.fl = lp.deg = 64
+    lp.fl_chunks = 1
+    failed(lib.chx_langevin_fused_run(ctypes.byref(lp), ctypes.c_void_p(64), ctypes.c_void_p(128), 0, 1, 1, 4,
+                                      ctypes.byref(sent), None), "host_ctrl")
+    hc = (ctypes.c_int32 * 8)(6, 0, 0, 7, -2, -2, 0, 0)
+    lp.host_ctrl = ctypes.addressof(hc)
+    failed(lib.chx_langevin_fused_run(ctypes.byref(lp), ctypes.c_void_p(64), ctypes.c_void_p(128), 0, 1, 1, 0,
+                                      ctypes.byref(sent), None), "window")
+    # the halt word (7) already rules out step 7: the launch loop stops before its first launch
+    lib.chx_langevin_fused_run(ctypes.byref(lp), ctypes.c_void_p(64), ctypes.c_void_p(128), 7, 5, 2, 4, ctypes.byref(sent), None)
+    assert sent.value == 0
     failed(lib.chx_mc_displace_chunk(None, 0, 1, None), "null parameter block")
     failed(lib.chx_lj_nl_energy_force(None, None, None, 8, 0, box, f(1), f(1), f(1), None, None, None, None), "m >= 1")
     failed(lib.chx_baoab_step(None, None, None, None, -3, box, 1, f(1), f(1), f(1), f(1), None, f(1), 0, 0, 0, None,
