@@ -9,32 +9,20 @@
 //       in scan order (nearly ascending neighbor index), with no atomics and no sort.
 // Both come from the same fp32 predicate evaluated in the reference's orientation
 // (x_lo - x_hi by original id), so the pair sets are identical by construction.
+#include <cstdlib>
+
 #include "chx_common.h"
 #include "chx_internal.h"
 
 #define CHX_CELL_CAP 1024  // half-row candidates kept on chip per row
 
 
-__global__ __launch_bounds__(256) void k_nl_build_cell_fl(
-    const float4* __restrict__ xs4, int n, int m, Box3 box, float T, CellGrid g,
-    const int32_t* __restrict__ cell_of, const int32_t* __restrict__ cell_start,
-    const uint32_t* __restrict__ sorted_ids, uint32_t* __restrict__ nl, uint32_t* __restrict__ first_out,
-    int32_t* __restrict__ n_nbr, int fg, int fcap, uint32_t* __restrict__ fl, int32_t* __restrict__ deg,
-    int32_t* __restrict__ status) {
-  __shared__ uint32_t cand_all[4][CHX_CELL_CAP];
-  const int lane = lane_id();
-  const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (w >= n) return;
-  uint32_t* cand = cand_all[threadIdx.x >> 6];
-  const uint32_t i = sorted_ids[w];
-  const float4 xw = xs4[w];  // positions in cell order: candidate loads below are coalesced
-  const float xi = xw.x, yi = xw.y, zi = xw.z;
-  const int c = __float_as_int(xw.w);
-  const int cx = c % g.ncx, cy = (c / g.ncx) % g.ncy, cz = c / (g.ncx * g.ncy);
-  // The 27 surrounding cells are at most 18 contiguous index ranges of the cell-ordered arrays
-  // (the three x-neighbours of a (y,z) row are adjacent except across the periodic seam).  Lane r
-  // fetches the bounds of range r -- all 18 in one round trip -- and a wave-wide prefix sum
-  // flattens them, so the candidate loop below runs with every lane busy.
+// The 27 cells around cell (cx,cy,cz) are at most 18 contiguous index ranges of the cell-ordered arrays (the three
+// x-neighbours of a (y,z) row are adjacent except across the periodic seam).  Lane r < 18 fetches the bounds of
+// range r -- all 18 in one round trip -- and a wave-wide prefix sum flattens them into one candidate index space
+// [0, total): rng_s[r] = first array index of range r, rng_o[r] = flat index of its first candidate (LDS, per wave).
+__device__ __forceinline__ int cell_ranges(const CellGrid& g, int cx, int cy, int cz, const int32_t* __restrict__ cell_start,
+                                           int lane, int* rng_s, int* rng_o) {
   int rs = 0, re = 0;
   if (lane < 18) {
     const int combo = lane >> 1, sub = lane & 1;
@@ -64,13 +52,32 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
     if (lane >= o) incl += v;
   }
   const int total = __shfl(incl, 17, CHX_WAVE);
-  int* rng_s = reinterpret_cast<int*>(cand) + CHX_CELL_CAP - 40;  // tail of this wave's LDS slice
-  int* rng_o = rng_s + 20;
   if (lane < 18) {
     rng_s[lane] = rs;
     rng_o[lane] = incl - len;
   }
   __threadfence_block();
+  return total;
+}
+
+// One wavefront builds the rows of ONE particle (cell-order index w): scans the 27 surrounding cells, writes the
+// force-list row in scan order (WRITE_FL) and the half row rank-sorted ascending, as jnp.where(mask, size=M) returns
+// it.  cand = this wave's CHX_CELL_CAP words of LDS.
+template <bool WRITE_FL>
+__device__ __forceinline__ void build_row_of_particle(
+    int w, uint32_t* cand, const float4* __restrict__ xs4, int n, int m, const Box3& box, float T, const CellGrid& g,
+    const int32_t* __restrict__ cell_start, const uint32_t* __restrict__ sorted_ids, uint32_t* __restrict__ nl,
+    uint32_t* __restrict__ first_out, int32_t* __restrict__ n_nbr, int fg, int fcap, uint32_t* __restrict__ fl,
+    int32_t* __restrict__ deg, int32_t* __restrict__ status) {
+  const int lane = lane_id();
+  const uint32_t i = sorted_ids[w];
+  const float4 xw = xs4[w];  // positions in cell order: candidate loads below are coalesced
+  const float xi = xw.x, yi = xw.y, zi = xw.z;
+  const int c = __float_as_int(xw.w);
+  const int cx = c % g.ncx, cy = (c / g.ncx) % g.ncy, cz = c / (g.ncx * g.ncy);
+  int* rng_s = reinterpret_cast<int*>(cand) + CHX_CELL_CAP - 40;  // tail of this wave's LDS slice
+  int* rng_o = rng_s + 20;
+  const int total = cell_ranges(g, cx, cy, cz, cell_start, lane, rng_s, rng_o);
   int count_h = 0, count_f = 0;
   int r = 0;  // range holding this lane's candidate; candidates only move forward
   // candidate of the NEXT iteration is requested before the current one is processed, so the
@@ -104,18 +111,15 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
       displacement_oriented_fast(box, hi, xi, yi, zi, xk.x, xk.y, xk.z, rx, ry, rz, bad);
       if (__builtin_expect(bad, 0)) displacement_oriented(box, hi, xi, yi, zi, xk.x, xk.y, xk.z, rx, ry, rz);
       ok = (j != i) & (norm2(rx, ry, rz) <= T);
-#ifdef CHX_EXP_BUILD_NOTEST
-      ok = ok && xk.x == 12345.f;  // (timing decomposition: no hits, nothing stored)
-#endif
     }
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const unsigned long long b = __ballot(ok);
-    if (b) {
-      const int slot = count_f + __popcll(b & lt);
-#ifndef CHX_EXP_BUILD_NOFL
-      if (ok && slot < fcap) fl[chx_fl_addr(w, slot, n, fg)] = (uint32_t)k | (hi ? CHX_FL_HI : 0u);
-#endif
-      count_f += __popcll(b);
+    if (WRITE_FL) {
+      const unsigned long long b = __ballot(ok);
+      if (b) {
+        const int slot = count_f + __popcll(b & lt);
+        if (ok && slot < fcap) fl[chx_fl_addr(w, slot, n, fg)] = (uint32_t)k | (hi ? CHX_FL_HI : 0u);
+        count_f += __popcll(b);
+      }
     }
     const bool okh = ok && hi;
     const unsigned long long bh = __ballot(okh);
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
   }
   // force-list row: the force kernel gathers whole chunks (and chunk 0 speculatively), so the
   // unused slots of the chunks it can touch must hold a valid index; later chunks are never read
-  {
+  if (WRITE_FL) {
     const int wd = CHX_FL_QUAD * fg;
     const int used = count_f < fcap ? count_f : fcap;
     int end = (used + wd - 1) / wd * wd;
@@ -145,14 +149,8 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
     const uint32_t v = cand[t];
     mn = v < mn ? v : mn;
     int rank = 0;
-#ifdef CHX_EXP_BUILD_NOSORT
-    rank = t;
-#else
     for (int u = 0; u < kept; ++u) rank += cand[u] < v ? 1 : 0;
-#endif
-#ifndef CHX_EXP_BUILD_NONL
     if (rank < m) nl_row[rank] = v;
-#endif
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -162,13 +160,196 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
   if (lane == 0) {
     n_nbr[i] = count_h;
     first_out[i] = mn;
-    deg[w] = count_f < fcap ? count_f : fcap;
+    if (WRITE_FL) deg[w] = count_f < fcap ? count_f : fcap;
     // only the rare failure cases touch the shared status words here (one hot address serialises
     // atomics chip-wide); the maxima the host needs are reduced by k_nl_summary
     if (count_h > CHX_CELL_CAP - 40) atomicOr(&status[0], 1);
-    if (count_f > fcap) {
+    if (WRITE_FL && count_f > fcap) {
       atomicAdd(&status[4], 1);
       atomicMax(&status[3], count_f);
+    }
+  }
+  __threadfence_block();  // (cand is reused by the caller's next row)
+}
+
+// one wavefront per PARTICLE (the general kernel: any row length up to the on-chip candidate buffer)
+__global__ __launch_bounds__(256) void k_nl_build_cell_fl(
+    const float4* __restrict__ xs4, int n, int m, Box3 box, float T, CellGrid g,
+    const int32_t* __restrict__ cell_of, const int32_t* __restrict__ cell_start,
+    const uint32_t* __restrict__ sorted_ids, uint32_t* __restrict__ nl, uint32_t* __restrict__ first_out,
+    int32_t* __restrict__ n_nbr, int fg, int fcap, uint32_t* __restrict__ fl, int32_t* __restrict__ deg,
+    int32_t* __restrict__ status) {
+  __shared__ uint32_t cand_all[4][CHX_CELL_CAP];
+  const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (w >= n) return;
+  build_row_of_particle<true>(w, cand_all[threadIdx.x >> 6], xs4, n, m, box, T, g, cell_start, sorted_ids, nl, first_out,
+                              n_nbr, fg, fcap, fl, deg, status);
+}
+
+// One wavefront per CELL: the (about ten at the BASELINE density) particles of a cell share their 27-cell
+// neighbourhood, so the candidates are fetched once per cell -- one per lane, 64 at a time -- and tested against
+// every particle of the cell in turn (its position broadcast from a lane: v_readlane), instead of once per particle.
+// The per-particle kernel above is bound by VALU issue (PMC: ~1000 vector instructions per row, of which the range
+// search, the candidate loads and the prologue are more than half); here those are shared by the cell's rows.
+// Rows come out as the per-particle kernel writes them: force-list rows in the same scan order, half rows
+// rank-sorted ascending.  Half-row hits go to their row of `nl` unsorted first and are sorted in place at the end;
+// a row too long for that (> m or > CHX_ROW_SORT_CAP entries) is redone by build_row_of_particle.
+#define CHX_ROW_SORT_CAP 256
+__device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+__global__ __launch_bounds__(256) void k_nl_build_cellwise_fl(
+    const float4* __restrict__ xs4, int n, int m, Box3 box, float T, CellGrid g, int ncell, int split,
+    const int32_t* __restrict__ cell_start, const uint32_t* __restrict__ sorted_ids, uint32_t* __restrict__ nl,
+    uint32_t* __restrict__ first_out, int32_t* __restrict__ n_nbr, int fg, int fcap, uint32_t* __restrict__ fl,
+    int32_t* __restrict__ deg, int32_t* __restrict__ status) {
+  __shared__ uint32_t cand_all[4][CHX_CELL_CAP];  // sort staging (first CHX_ROW_SORT_CAP words) + ranges (tail)
+  const int lane = lane_id();
+  // `split` wavefronts share a cell, each taking a contiguous slice of its particles (few cells = few wavefronts:
+  // the launch then lives on latency, and more, shorter waves beat fewer candidate fetches)
+  const int wid = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  const int c = wid / split;
+  if (c >= ncell) return;
+  int h0 = cell_start[c], h1 = cell_start[c + 1];
+  {
+    const int per = (h1 - h0 + split - 1) / split;
+    h0 += (wid % split) * per;
+    h1 = h0 + per < h1 ? h0 + per : h1;
+  }
+  if (h1 <= h0) return;
+  uint32_t* cand = cand_all[threadIdx.x >> 6];
+  int* rng_s = reinterpret_cast<int*>(cand) + CHX_CELL_CAP - 40;
+  int* rng_o = rng_s + 20;
+  const int cx = c % g.ncx, cy = (c / g.ncx) % g.ncy, cz = c / (g.ncx * g.ncy);
+  const int total = cell_ranges(g, cx, cy, cz, cell_start, lane, rng_s, rng_o);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int hb = h0; hb < h1; hb += CHX_WAVE) {  // the cell's particles, 64 at a time: lane l holds particle hb + l
+    const int nh = h1 - hb < CHX_WAVE ? h1 - hb : CHX_WAVE;
+    float4 xh = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t ih = 0;
+    if (lane < nh) {
+      xh = xs4[hb + lane];
+      ih = sorted_ids[hb + lane];
+    }
+    int cf = 0, ch = 0;  // entries written so far to the force-list row / half row of this lane's particle
+    int r = 0, k_n = 0;
+    uint32_t j_n = 0;
+    float4 x_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < total) {
+      while (r < 17 && rng_o[r + 1] <= lane) ++r;
+      k_n = rng_s[r] + (lane - rng_o[r]);
+      j_n = sorted_ids[k_n];
+      x_n = xs4[k_n];
+    }
+    for (int t0 = 0; t0 < total; t0 += CHX_WAVE) {
+      const int t = t0 + lane;
+      const uint32_t j = j_n;
+      const int k = k_n;
+      const float4 xk = x_n;
+      if (t + CHX_WAVE < total) {  // next 64 candidates: in flight while this batch meets the cell's particles
+        const int tn = t + CHX_WAVE;
+        while (r < 17 && rng_o[r + 1] <= tn) ++r;
+        k_n = rng_s[r] + (tn - rng_o[r]);
+        j_n = sorted_ids[k_n];
+        x_n = xs4[k_n];
+      }
+      const bool live = t < total;
+      for (int ii = 0; ii < nh; ++ii) {
+        const float xi = rl_f(xh.x, ii), yi = rl_f(xh.y, ii), zi = rl_f(xh.z, ii);
+        const uint32_t i = (uint32_t)rl_i((int)ih, ii);
+        bool ok = false, hi = false;
+        if (live) {
+          hi = j > i;
+          float rx, ry, rz;  // x_i - x_j for row i of the half list, x_j - x_i for row j
+          bool bad;
+          displacement_oriented_fast(box, hi, xi, yi, zi, xk.x, xk.y, xk.z, rx, ry, rz, bad);
+          if (__builtin_expect(bad, 0)) displacement_oriented(box, hi, xi, yi, zi, xk.x, xk.y, xk.z, rx, ry, rz);
+          ok = (j != i) & (norm2(rx, ry, rz) <= T);
+        }
+        // (no branch on "any hit in this batch": two thirds of the (particle, batch) pairs have one, and a
+        // straight-line body lets the compiler overlap consecutive particles)
+        const unsigned long long b = __ballot(ok);
+        {
+          const int base = rl_i(cf, ii);
+          const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+          if (ok && slot < fcap) fl[chx_fl_addr(hb + ii, slot, n, fg)] = (uint32_t)k | (hi ? CHX_FL_HI : 0u);
+          cf = lane == ii ? base + __popcll(b) : cf;
+        }
+        const bool okh = ok && hi;
+        const unsigned long long bh = __ballot(okh);
+        {
+          const int base = rl_i(ch, ii);
+          const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bh >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bh, 0u));
+          if (okh && slot < m) nl[(size_t)i * m + slot] = j;  // unsorted; sorted in place below
+          ch = lane == ii ? base + __popcll(bh) : ch;
+        }
+      }
+    }
+    // the half-row entries written above are read back below by other lanes of this wavefront: same CU, same
+    // (write-through) L1, so a workgroup-scope fence is all it takes.  (A device-scope fence here writes back the
+    // XCD's whole L2 once per cell: measured 3x slower than the per-particle kernel.)
+    __threadfence_block();
+    for (int ii = 0; ii < nh; ++ii) {
+      const int count_f = rl_i(cf, ii), count_h = rl_i(ch, ii);
+      const int w = hb + ii;
+      const uint32_t i = (uint32_t)rl_i((int)ih, ii);
+      {
+        // force-list row: the force kernel gathers whole chunks (and chunk 0 speculatively), so the unused slots of
+        // the chunks it can touch must hold a valid index (the row's own: a zero-length pair stays on the fast path)
+        const int wd = CHX_FL_QUAD * fg;
+        const int used = count_f < fcap ? count_f : fcap;
+        int end = (used + wd - 1) / wd * wd;
+        end = end < wd ? wd : end;
+        end = end < fcap ? end : fcap;
+        for (int sl = used + lane; sl < end; sl += CHX_WAVE) fl[chx_fl_addr(w, sl, n, fg)] = (uint32_t)w;
+      }
+      if (count_h > m || count_h > CHX_ROW_SORT_CAP) {
+        // too long to sort in place (and rows beyond m entries were not stored completely): the general path
+        // rebuilds this half row from scratch (it writes n_nbr, first_out and the status flags itself)
+        build_row_of_particle<false>(w, cand, xs4, n, m, box, T, g, cell_start, sorted_ids, nl, first_out, n_nbr, fg, fcap,
+                                     fl, deg, status);
+        // (cell_ranges inside rewrote the same values into the tail of cand)
+      } else {
+        uint32_t* nl_row = nl + (size_t)i * m;
+        uint32_t v[CHX_ROW_SORT_CAP / CHX_WAVE];
+        uint32_t mn = 0xFFFFFFFFu;
+#pragma unroll
+        for (int q = 0; q < CHX_ROW_SORT_CAP / CHX_WAVE; ++q) {
+          const int t = q * CHX_WAVE + lane;
+          v[q] = 0xFFFFFFFFu;
+          if (q * CHX_WAVE < count_h && t < count_h) {
+            v[q] = nl_row[t];
+            cand[t] = v[q];
+            mn = v[q] < mn ? v[q] : mn;
+          }
+        }
+        __threadfence_block();
+#pragma unroll
+        for (int q = 0; q < CHX_ROW_SORT_CAP / CHX_WAVE; ++q) {
+          if (q * CHX_WAVE < count_h) {  // wave-uniform
+            int rank = 0;
+            for (int u = 0; u < count_h; ++u) rank += cand[u] < v[q] ? 1 : 0;
+            if (q * CHX_WAVE + lane < count_h) nl_row[rank] = v[q];
+          }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const uint32_t other = __shfl_xor(mn, o, CHX_WAVE);
+          mn = other < mn ? other : mn;
+        }
+        if (lane == 0) {
+          n_nbr[i] = count_h;
+          first_out[i] = mn;
+        }
+        __threadfence_block();  // (cand is reused for the next row)
+      }
+      if (lane == 0) {
+        deg[w] = count_f < fcap ? count_f : fcap;
+        if (count_f > fcap) {
+          atomicAdd(&status[4], 1);
+          atomicMax(&status[3], count_f);
+        }
+      }
     }
   }
 }
@@ -244,9 +425,26 @@ extern "C" int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_
   const unsigned wb = (unsigned)(((int64_t)n * CHX_WAVE + 255) / 256);
   float4* xs4 = reinterpret_cast<float4*>(xs4_out);
   hipLaunchKernelGGL(k_gather_sorted, dim3((n + 255) / 256), dim3(256), 0, st, xyz, sorted_ids, cell_of, n, xs4);
-  hipLaunchKernelGGL(k_nl_build_cell_fl, dim3(wb), dim3(256), 0, st, xs4, n, m, make_box3(box), T, grid,
-                     cell_of, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, chunks * CHX_FL_QUAD * g,
-                     fl_out, deg_out, status8);
+  // One wavefront per particle, or -- when there are enough cells to fill the chip with one wavefront each -- one
+  // per cell, the cell's particles sharing their candidate scan (measured: N = 262144 / 27000 cells 355 -> 263 us;
+  // N = 32768 / 3375 cells 51 -> 83 us, or 51 -> 51 with four wavefronts per cell: too few, too long wavefronts
+  // live on latency).  Both write the same bits; CHX_BUILD_KERNEL=particle|cell forces one (tests, A/B).
+  static const int forced = [] { const char* e = getenv("CHX_BUILD_KERNEL"); return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'c' ? 2 : 0)); }();
+  const bool per_particle = forced == 1 || (forced == 0 && (int64_t)grid.ncx * grid.ncy * grid.ncz < 8192);
+  if (per_particle) {
+    hipLaunchKernelGGL(k_nl_build_cell_fl, dim3(wb), dim3(256), 0, st, xs4, n, m, make_box3(box), T, grid,
+                       cell_of, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, chunks * CHX_FL_QUAD * g,
+                       fl_out, deg_out, status8);
+  } else {
+    const int ncell = grid.ncx * grid.ncy * grid.ncz;
+    static const int split_env = [] { const char* e = getenv("CHX_BUILD_SPLIT"); return e ? atoi(e) : 0; }();
+    int split = split_env > 0 ? split_env : (8192 + ncell - 1) / ncell;  // (only > 1 when the kernel is forced)
+    split = split < 1 ? 1 : (split > 16 ? 16 : split);
+    const unsigned cb = (unsigned)(((int64_t)ncell * split * CHX_WAVE + 255) / 256);
+    hipLaunchKernelGGL(k_nl_build_cellwise_fl, dim3(cb), dim3(256), 0, st, xs4, n, m, make_box3(box), T, grid, ncell,
+                       split, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, chunks * CHX_FL_QUAD * g,
+                       fl_out, deg_out, status8);
+  }
   const unsigned sb = (unsigned)((n + 255) / 256 < 64 ? (n + 255) / 256 : 64);
   hipLaunchKernelGGL(k_nl_summary, dim3(sb), dim3(256), 0, st, n_nbr_out, deg_out, n, m, status8);
   return chx_check_launch("chx_nl_build_cell_fl");

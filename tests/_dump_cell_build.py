@@ -1,0 +1,37 @@
+"""Helper of test_gpu_parity.py::test_both_cell_build_kernels_write_the_same_bits: builds a few neighbor lists with
+whatever kernel CHX_BUILD_KERNEL selects and dumps every array the build produces.  usage: <out.npz>"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from chiron_amd import neighbors, unit as u
+from oracle import chiron_oracle as O
+
+out = {}
+# (particles, reduced density, skin, initial n_max_neighbors): dilute and dense cells, a tiny initial capacity
+# (rows longer than n_max_neighbors: the growth loop and the cell-wise kernel's long-row path), a box of 3 cells per axis
+for tag, (n, rho, skin, m0) in {"dilute": (4000, 0.1, 0.5, 180), "dense": (6000, 0.8, 0.3, 180), "grow": (3000, 0.6, 0.4, 12),
+                                "three_cells": (700, 0.5, 0.1, 60)}.items():
+    x, box = O.lj_lattice(n, rho, 0.34, seed=17)
+    x = (x + np.random.default_rng(3).normal(scale=0.03, size=x.shape)).astype(np.float32)
+    nbr = neighbors.NeighborListCell(neighbors.OrthogonalPeriodicSpace(), cutoff=1.02 * u.nanometer, skin=skin * u.nanometer,
+                                        n_max_neighbors=m0)
+    xt = torch.tensor(x, device="cuda")
+    nbr.build(xt, torch.tensor(box, device="cuda"))
+    fl = nbr.force_list
+    out[tag + "_nl"] = nbr.neighbor_list.cpu().numpy()
+    out[tag + "_mask"] = nbr.neighbor_mask.cpu().numpy()
+    out[tag + "_n"] = nbr.n_neighbors.cpu().numpy()
+    out[tag + "_m"] = np.array([nbr.n_max_neighbors])
+    if fl is not None:
+        deg = fl.deg.cpu().numpy()
+        table = fl.fl.cpu().numpy()
+        out[tag + "_deg"] = deg
+        out[tag + "_perm"] = fl.perm.cpu().numpy()
+        out[tag + "_geo"] = np.array([fl.g, fl.chunks])
+        # only the entries the kernels may read are defined: whole chunks up to the row's end (at least chunk 0)
+        w = 4 * fl.g
+        used = np.maximum((deg + w - 1) // w, 1)
+        keep = np.arange(table.shape[0])[:, None] < used[None, :]
+        out[tag + "_fl"] = np.where(keep[:, :, None], table, 0)
+np.savez(sys.argv[1], **out)

@@ -1781,3 +1781,27 @@ def test_langevin_launch_window_does_not_change_the_trajectory(ca, O, reports):
         assert got[2:5] == ref[2:5], (window, chunk, got[2:5], ref[2:5])
         assert torch.equal(got[5], ref[5])
         assert len(got[6]) == len(ref[6]) and all(torch.equal(a, b) for a, b in zip(got[6], ref[6]))
+
+
+def test_both_cell_build_kernels_write_the_same_bits(tmp_path):
+    """The one-pass cell build has two kernels (csrc/chx_cell_fl.hip): one wavefront per particle and one per cell
+    (the cell's particles share the scan of their 27-cell neighbourhood; chosen when there are enough cells to fill
+    the chip).  Padded list, mask, counts, the grown n_max_neighbors, force-list rows, degrees and the internal order
+    must be identical bits -- dilute and dense cells, rows longer than the initial capacity, three cells per axis."""
+    import os
+    import subprocess
+    import sys
+
+    got = {}
+    for kern in ("particle", "cell"):
+        path = tmp_path / f"{kern}.npz"
+        env = dict(os.environ, CHX_BUILD_KERNEL=kern)
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_dump_cell_build.py"), str(path)],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[kern] = np.load(path)
+    a, b = got["particle"], got["cell"]
+    assert sorted(a.files) == sorted(b.files) and len(a.files) >= 30
+    for key in a.files:
+        assert np.array_equal(a[key], b[key]), key
+    assert int(a["grow_m"][0]) > 12  # the growth loop really ran (rows longer than the initial capacity)
