@@ -129,6 +129,7 @@ SIGNATURES = {
     "chx_fl_sort": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
     "chx_permute_pack": (C.c_int, [_P, _P, _I32, _P, _I32, _P]),
     "chx_permute_unpack": (C.c_int, [_P, _I32, _P, _I32, _P, _P]),
+    "chx_unpack_langevin": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P]),
     "chx_invert_perm": (C.c_int, [_P, _I32, _P, _P]),
     "chx_lj_ws_count": (_I64, [_I32]),
     "chx_lj_fl_energy_force": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, Box, _F, _F, _F, _P, _P, _P, _P]),

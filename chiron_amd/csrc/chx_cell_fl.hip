@@ -354,16 +354,6 @@ __global__ __launch_bounds__(256) void k_nl_build_cellwise_fl(
   }
 }
 
-// positions in cell order; .w carries the particle's cell index (as int bits) so the build kernel
-// needs no dependent cell_of[sorted_ids[w]] round trip
-__global__ void k_gather_sorted(const float* __restrict__ xyz, const uint32_t* __restrict__ sorted_ids,
-                                const int32_t* __restrict__ cell_of, int n, float4* __restrict__ xs4) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
-  const size_t j = sorted_ids[k];
-  xs4[k] = make_float4(xyz[3 * j], xyz[3 * j + 1], xyz[3 * j + 2], __int_as_float(cell_of[j]));
-}
-
 // status[1] = max n_nbr, status[2] = #rows with n_nbr == m, status[3] = max full degree
 __global__ __launch_bounds__(256) void k_nl_summary(const int32_t* __restrict__ n_nbr,
                                                     const int32_t* __restrict__ deg, int n, int m,
@@ -419,12 +409,11 @@ extern "C" int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_
   hipStream_t st = chx_stream(stream);
   CellGrid grid;
   int rc = chx_cell_prepare(xyz, n, box, cutoff_plus_skin, nc_h, cell_of, cell_count, cell_start,
-                            sorted_ids, status8, 8, &grid, st);
+                            sorted_ids, status8, 8, &grid, st, xs4_out);  // (the cell sort also emits xs4)
   if (rc != CHX_OK) return rc;
   const float T = chx_cutoff_threshold_h(cutoff_plus_skin);
   const unsigned wb = (unsigned)(((int64_t)n * CHX_WAVE + 255) / 256);
   float4* xs4 = reinterpret_cast<float4*>(xs4_out);
-  hipLaunchKernelGGL(k_gather_sorted, dim3((n + 255) / 256), dim3(256), 0, st, xyz, sorted_ids, cell_of, n, xs4);
   // One wavefront per particle, or -- when there are enough cells to fill the chip with one wavefront each -- one
   // per cell, the cell's particles sharing their candidate scan (measured: N = 262144 / 27000 cells 355 -> 263 us;
   // N = 32768 / 3375 cells 51 -> 83 us, or 51 -> 51 with four wavefronts per cell: too few, too long wavefronts

@@ -152,6 +152,33 @@ extern "C" int chx_permute_unpack(const float* src, int32_t src_stride, const ui
   return chx_check_launch("chx_permute_unpack");
 }
 
+// inverse of chx_pack_langevin in one launch: positions (rows of 4 floats) and velocities (rows of 3) back to user order
+__global__ void k_unpack_langevin(const float4* __restrict__ x4, const float* __restrict__ v,
+                                  const uint32_t* __restrict__ perm, int n, float* __restrict__ x3,
+                                  float* __restrict__ v3) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const size_t o = perm ? perm[p] : (uint32_t)p;
+  const float4 x = x4[p];
+  const float a = v[3 * (size_t)p], b = v[3 * (size_t)p + 1], c = v[3 * (size_t)p + 2];
+  x3[3 * o] = x.x;
+  x3[3 * o + 1] = x.y;
+  x3[3 * o + 2] = x.z;
+  v3[3 * o] = a;
+  v3[3 * o + 1] = b;
+  v3[3 * o + 2] = c;
+}
+
+extern "C" int chx_unpack_langevin(const float* x4, const float* v, const uint32_t* perm, int32_t n,
+                                   float* x3_out, float* v3_out, chx_stream_t stream) {
+  CHX_REQUIRE(n >= 0, "n < 0");
+  if (n == 0) return CHX_OK;
+  CHX_REQUIRE(x4 && v && x3_out && v3_out, "null pointer");
+  hipLaunchKernelGGL(k_unpack_langevin, dim3((n + 255) / 256), dim3(256), 0, chx_stream(stream),
+                     reinterpret_cast<const float4*>(x4), v, perm, n, x3_out, v3_out);
+  return chx_check_launch("chx_unpack_langevin");
+}
+
 __global__ void k_invert_perm(const uint32_t* __restrict__ perm, int n, uint32_t* __restrict__ inv) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < n) inv[perm[p]] = (uint32_t)p;

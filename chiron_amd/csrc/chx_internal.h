@@ -10,11 +10,11 @@ struct CellGrid {
   float sx, sy, sz;  // nc / L
 };
 
-// Bin particles into cells (chx_neighbors.hip): cell_of, cell_start, sorted_ids; zeroes status.
+// Bin particles into cells (chx_neighbors.hip): cell_of, cell_start, sorted_ids [, xs4_out]; zeroes status.
 int chx_cell_prepare(const float* xyz, int n, chx_box_t box, float cutoff_plus_skin,
                      const int32_t* nc_h, int32_t* cell_of, int32_t* cell_count, int32_t* cell_start,
                      uint32_t* sorted_ids, int32_t* status, int status_len, CellGrid* g_out,
-                     hipStream_t st);
+                     hipStream_t st, float* xs4_out = nullptr);  // xs4_out: positions in cell order, .w = cell index
 
 // ctrl != NULL: the kernel is part of a Langevin chunk and turns into a no-op
 // (setting ctrl[1]) when ctrl[0] says the skin check fired.

@@ -177,14 +177,24 @@ __global__ void k_cell_scatter(const int32_t* __restrict__ cell_of, int n,
 // Cells with more particles than that (reduced densities far above a liquid's) fall back
 // to a serial insertion sort by lane 0.
 #define CHX_SORT_PER_LANE 4
+// xs4 != NULL: also emit the positions in cell order, .w = the cell index as int bits (what the one-pass build reads:
+// its candidate loads are then coalesced and it needs no dependent cell_of[sorted_ids[w]] round trip).
+__device__ __forceinline__ void cell_emit_sorted(const float* __restrict__ xyz, float4* __restrict__ xs4, int at, uint32_t id, int c) {
+  xs4[at] = make_float4(xyz[3 * (size_t)id], xyz[3 * (size_t)id + 1], xyz[3 * (size_t)id + 2], __int_as_float(c));
+}
+
 __global__ __launch_bounds__(256) void k_cell_sort(const int32_t* __restrict__ cell_start, int ncell,
-                                                   uint32_t* __restrict__ sorted_ids) {
+                                                   uint32_t* __restrict__ sorted_ids, const float* __restrict__ xyz,
+                                                   float4* __restrict__ xs4) {
   const int lane = lane_id();
   const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (c >= ncell) return;
   const int s = cell_start[c], e = cell_start[c + 1];
   const int np = e - s;
-  if (np <= 1) return;
+  if (np <= 1) {
+    if (xs4 != nullptr && np == 1 && lane == 0) cell_emit_sorted(xyz, xs4, s, sorted_ids[s], c);
+    return;
+  }
   if (np > CHX_WAVE * CHX_SORT_PER_LANE) {
     if (lane == 0) {
       for (int a = s + 1; a < e; ++a) {
@@ -196,6 +206,10 @@ __global__ __launch_bounds__(256) void k_cell_sort(const int32_t* __restrict__ c
         }
         sorted_ids[b + 1] = v;
       }
+    }
+    if (xs4 != nullptr) {
+      __threadfence_block();  // lane 0's stores, read back by the whole wavefront
+      for (int t = lane; t < np; t += CHX_WAVE) cell_emit_sorted(xyz, xs4, s + t, sorted_ids[s + t], c);
     }
     return;
   }
@@ -223,7 +237,10 @@ __global__ __launch_bounds__(256) void k_cell_sort(const int32_t* __restrict__ c
   // every id was read into registers above before any lane writes
 #pragma unroll
   for (int k = 0; k < CHX_SORT_PER_LANE; ++k) {
-    if (k * CHX_WAVE + lane < np) sorted_ids[s + rank[k]] = mine[k];
+    if (k * CHX_WAVE + lane < np) {
+      sorted_ids[s + rank[k]] = mine[k];
+      if (xs4 != nullptr) cell_emit_sorted(xyz, xs4, s + rank[k], mine[k], c);
+    }
   }
 }
 
@@ -312,7 +329,7 @@ __global__ __launch_bounds__(256) void k_nl_build_cell(
 int chx_cell_prepare(const float* xyz, int n, chx_box_t box, float cutoff_plus_skin,
                      const int32_t* nc_h, int32_t* cell_of, int32_t* cell_count, int32_t* cell_start,
                      uint32_t* sorted_ids, int32_t* status, int status_len, CellGrid* g_out,
-                     hipStream_t st) {
+                     hipStream_t st, float* xs4_out) {
   CHX_REQUIRE(box.periodic && box.lx > 0 && box.ly > 0 && box.lz > 0, "periodic box required");
   CHX_REQUIRE(nc_h[0] >= 3 && nc_h[1] >= 3 && nc_h[2] >= 3, "need >= 3 cells per axis");
   const int64_t ncell64 = (int64_t)nc_h[0] * nc_h[1] * nc_h[2];
@@ -338,7 +355,7 @@ int chx_cell_prepare(const float* xyz, int n, chx_box_t box, float cutoff_plus_s
   hipLaunchKernelGGL(k_cell_scatter, dim3(pb), dim3(256), 0, st, cell_of, n, cell_start, cell_count,
                      sorted_ids);
   hipLaunchKernelGGL(k_cell_sort, dim3((unsigned)(((int64_t)ncell * CHX_WAVE + 255) / 256)), dim3(256), 0, st,
-                     cell_start, ncell, sorted_ids);
+                     cell_start, ncell, sorted_ids, xyz, reinterpret_cast<float4*>(xs4_out));
   return CHX_OK;
 }
 

@@ -223,7 +223,7 @@ class LangevinIntegrator:
         elif mode == "fused":
             st._settle()
 
-        updated_sampler_state = sampler_state._copy_with(st.positions_user(), st.velocities_user())  # :210-218
+        updated_sampler_state = sampler_state._copy_with(*st.state_user())  # :210-218
         # the reference returns the key its loop ended with (:216); the counter-based stream folds the step count in
         updated_sampler_state.current_PRNG_key = chain_key if isinstance(key, JaxKey) else fold_in(key, number_of_steps)
         self.n_rebuilds = st.n_rebuilds
@@ -475,6 +475,17 @@ class _RunState:
         )
         return out
 
+    def state_user(self):
+        """(positions, velocities) in user order, one launch."""
+        x3 = torch.empty((self.n, 3), dtype=torch.float32, device=self.dev)
+        v3 = torch.empty((self.n, 3), dtype=torch.float32, device=self.dev)
+        ops.check(
+            ops._lib.load().chx_unpack_langevin(ops._ptr(self._x_cur()), ops._ptr(self.v), ops._ptr(self.perm), self.n,
+                                                ops._ptr(x3), ops._ptr(v3), ops._stream()),
+            "chx_unpack_langevin",
+        )
+        return x3, v3
+
     def positions_user(self) -> torch.Tensor:
         return self._unpack(self._x_cur())
 
@@ -493,10 +504,8 @@ class _RunState:
         if prof:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        # (the build only needs the positions: its kernels are on their way before the velocities are unpacked)
-        x_user = self.positions_user()
+        x_user, v_user = self.state_user()
         spec = speculative and _SPECULATIVE_REBUILD and self.nbr_list._build_speculative(x_user, publish=False)
-        v_user = self.velocities_user()
         if not spec:
             self.nbr_list._adopt_positions = True  # x_user is a fresh tensor nobody else holds
             try:

@@ -175,6 +175,9 @@ int chx_permute_pack(const float* src3, const uint32_t* perm, int32_t n, float* 
 int chx_permute_unpack(const float* src, int32_t src_stride, const uint32_t* perm, int32_t n,
                        float* dst3, chx_stream_t stream);
 int chx_invert_perm(const uint32_t* perm, int32_t n, uint32_t* inv_out, chx_stream_t stream);
+/* one launch, the inverse of chx_pack_langevin: x3_out[perm[p]] = x4[p].xyz, v3_out[perm[p]] = v[p] */
+int chx_unpack_langevin(const float* x4, const float* v, const uint32_t* perm, int32_t n,
+                        float* x3_out, float* v3_out, chx_stream_t stream);
 /* one launch: x4[p] = x3[perm[p]], v[p] = v3[perm[p]], mass_out[p] = mass[perm[p]],
  * ref4[p] = (ref3[perm[p]], mass_out[p]) (ref4_out may be NULL).  Optional riders, so that a list rebuild inside
  * the Langevin loop costs one launch here instead of three: ctrl_reset != NULL -> what chx_ctrl_reset writes;

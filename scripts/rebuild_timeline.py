@@ -36,6 +36,9 @@ def reb(self, step=0, speculative=False):
 
 
 I._RunState._rebuild = reb
+if os.environ.get("NOGC") == "1":
+    import gc
+    gc.collect(); gc.disable()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 state, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr)
 torch.cuda.synchronize(); wall = time.perf_counter() - t0

@@ -123,6 +123,9 @@ int main() {
   EXPECT_INVALID(chx_invert_perm(U, -1, U, nullptr));
   EXPECT_INVALID(chx_pack_langevin(F, F, F, F, U, -1, F, F, F, F, nullptr, nullptr, nullptr, nullptr));
   EXPECT_INVALID(chx_pack_langevin(F, F, F, F, U, 4, F, F, F, F, nullptr, I, nullptr, nullptr));  // publish without a destination
+  EXPECT_INVALID(chx_unpack_langevin(F, F, U, -1, F, F, nullptr));
+  EXPECT_INVALID(chx_unpack_langevin(F, nullptr, U, 4, F, F, nullptr));
+  EXPECT(chx_unpack_langevin(nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr) == CHX_OK);
   EXPECT_INVALID(chx_lj_fl_energy_force(F, U, I, -1, 8, 1, ok_box, 0.34f, 1.f, 1.02f, F, F, d.data(), nullptr));
   EXPECT_INVALID(chx_lj_fl_energy_force(F, U, I, 4, 8, 1, ok_box, 0.34f, 1.f, 1.02f, nullptr, nullptr, d.data(), nullptr));
   EXPECT_INVALID(chx_lj_fl_energy_force(F, U, I, 4, 8, 1, ok_box, 0.34f, 1.f, 1.02f, nullptr, F, nullptr, nullptr));
