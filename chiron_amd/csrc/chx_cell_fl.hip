@@ -17,6 +17,11 @@
 #define CHX_CELL_CAP 1024  // half-row candidates kept on chip per row
 
 
+// set bits of a ballot below this lane (v_mbcnt: two instructions instead of mask, and, two popcounts)
+__device__ __forceinline__ int lanes_below(unsigned long long ballot) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ballot, 0u));
+}
+
 // The 27 cells around cell (cx,cy,cz) are at most 18 contiguous index ranges of the cell-ordered arrays (the three
 // x-neighbours of a (y,z) row are adjacent except across the periodic seam).  Lane r < 18 fetches the bounds of
 // range r -- all 18 in one round trip -- and a wave-wide prefix sum flattens them into one candidate index space
@@ -26,8 +31,9 @@ __device__ __forceinline__ int cell_ranges(const CellGrid& g, int cx, int cy, in
   int rs = 0, re = 0;
   if (lane < 18) {
     const int combo = lane >> 1, sub = lane & 1;
-    const int zz = (cz + combo / 3 - 1 + g.ncz) % g.ncz;
-    const int yy = (cy + combo % 3 - 1 + g.ncy) % g.ncy;
+    int zz = cz + combo / 3 - 1, yy = cy + combo % 3 - 1;  // periodic wrap without a division
+    zz = zz < 0 ? zz + g.ncz : (zz >= g.ncz ? zz - g.ncz : zz);
+    yy = yy < 0 ? yy + g.ncy : (yy >= g.ncy ? yy - g.ncy : yy);
     const int row = (zz * g.ncy + yy) * g.ncx;
     int a0 = 0, a1 = 0;
     if (g.ncx == 3) {
@@ -73,8 +79,8 @@ __device__ __forceinline__ void build_row_of_particle(
   const uint32_t i = sorted_ids[w];
   const float4 xw = xs4[w];  // positions in cell order: candidate loads below are coalesced
   const float xi = xw.x, yi = xw.y, zi = xw.z;
-  const int c = __float_as_int(xw.w);
-  const int cx = c % g.ncx, cy = (c / g.ncx) % g.ncy, cz = c / (g.ncx * g.ncy);
+  const int c = __float_as_int(xw.w);  // packed by k_cell_sort: 10 bits per axis
+  const int cx = c & 1023, cy = (c >> 10) & 1023, cz = c >> 20;
   int* rng_s = reinterpret_cast<int*>(cand) + CHX_CELL_CAP - 40;  // tail of this wave's LDS slice
   int* rng_o = rng_s + 20;
   const int total = cell_ranges(g, cx, cy, cz, cell_start, lane, rng_s, rng_o);
@@ -112,11 +118,10 @@ __device__ __forceinline__ void build_row_of_particle(
       if (__builtin_expect(bad, 0)) displacement_oriented(box, hi, xi, yi, zi, xk.x, xk.y, xk.z, rx, ry, rz);
       ok = (j != i) & (norm2(rx, ry, rz) <= T);
     }
-    const unsigned long long lt = (1ull << lane) - 1ull;
     if (WRITE_FL) {
       const unsigned long long b = __ballot(ok);
       if (b) {
-        const int slot = count_f + __popcll(b & lt);
+        const int slot = count_f + lanes_below(b);
         if (ok && slot < fcap) fl[chx_fl_addr(w, slot, n, fg)] = (uint32_t)k | (hi ? CHX_FL_HI : 0u);
         count_f += __popcll(b);
       }
@@ -124,7 +129,7 @@ __device__ __forceinline__ void build_row_of_particle(
     const bool okh = ok && hi;
     const unsigned long long bh = __ballot(okh);
     if (bh) {
-      const int slot = count_h + __popcll(bh & lt);
+      const int slot = count_h + lanes_below(bh);
       if (okh && slot < CHX_CELL_CAP - 40) cand[slot] = j;
       count_h += __popcll(bh);
     }
@@ -222,7 +227,6 @@ __global__ __launch_bounds__(256) void k_nl_build_cellwise_fl(
   int* rng_o = rng_s + 20;
   const int cx = c % g.ncx, cy = (c / g.ncx) % g.ncy, cz = c / (g.ncx * g.ncy);
   const int total = cell_ranges(g, cx, cy, cz, cell_start, lane, rng_s, rng_o);
-  const unsigned long long lt = (1ull << lane) - 1ull;
   for (int hb = h0; hb < h1; hb += CHX_WAVE) {  // the cell's particles, 64 at a time: lane l holds particle hb + l
     const int nh = h1 - hb < CHX_WAVE ? h1 - hb : CHX_WAVE;
     float4 xh = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(256) void k_nl_build_cellwise_fl(
         const unsigned long long b = __ballot(ok);
         {
           const int base = rl_i(cf, ii);
-          const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+          const int slot = base + lanes_below(b);
           if (ok && slot < fcap) fl[chx_fl_addr(hb + ii, slot, n, fg)] = (uint32_t)k | (hi ? CHX_FL_HI : 0u);
           cf = lane == ii ? base + __popcll(b) : cf;
         }
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(256) void k_nl_build_cellwise_fl(
         const unsigned long long bh = __ballot(okh);
         {
           const int base = rl_i(ch, ii);
-          const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bh >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bh, 0u));
+          const int slot = base + lanes_below(bh);
           if (okh && slot < m) nl[(size_t)i * m + slot] = j;  // unsorted; sorted in place below
           ch = lane == ii ? base + __popcll(bh) : ch;
         }

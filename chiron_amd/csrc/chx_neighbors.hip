@@ -177,7 +177,7 @@ __global__ void k_cell_scatter(const int32_t* __restrict__ cell_of, int n,
 // Cells with more particles than that (reduced densities far above a liquid's) fall back
 // to a serial insertion sort by lane 0.
 #define CHX_SORT_PER_LANE 4
-// xs4 != NULL: also emit the positions in cell order, .w = the cell index as int bits (what the one-pass build reads:
+// xs4 != NULL: also emit the positions in cell order, .w = the cell's packed grid coordinates as int bits (what the one-pass build reads:
 // its candidate loads are then coalesced and it needs no dependent cell_of[sorted_ids[w]] round trip).
 __device__ __forceinline__ void cell_emit_sorted(const float* __restrict__ xyz, float4* __restrict__ xs4, int at, uint32_t id, int c) {
   xs4[at] = make_float4(xyz[3 * (size_t)id], xyz[3 * (size_t)id + 1], xyz[3 * (size_t)id + 2], __int_as_float(c));
@@ -185,11 +185,14 @@ __device__ __forceinline__ void cell_emit_sorted(const float* __restrict__ xyz, 
 
 __global__ __launch_bounds__(256) void k_cell_sort(const int32_t* __restrict__ cell_start, int ncell,
                                                    uint32_t* __restrict__ sorted_ids, const float* __restrict__ xyz,
-                                                   float4* __restrict__ xs4) {
+                                                   float4* __restrict__ xs4, int ncx, int ncy) {
   const int lane = lane_id();
-  const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (c >= ncell) return;
-  const int s = cell_start[c], e = cell_start[c + 1];
+  const int ci = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (ci >= ncell) return;
+  // what goes into xs4[].w: the cell's grid coordinates, 10 bits each (chx_cell_grid_h keeps every axis <= 1024 cells),
+  // so the build kernel's rows need no integer divisions to find their 27 neighbours
+  const int c = (ci % ncx) | (((ci / ncx) % ncy) << 10) | ((ci / (ncx * ncy)) << 20);
+  const int s = cell_start[ci], e = cell_start[ci + 1];
   const int np = e - s;
   if (np <= 1) {
     if (xs4 != nullptr && np == 1 && lane == 0) cell_emit_sorted(xyz, xs4, s, sorted_ids[s], c);
@@ -355,7 +358,7 @@ int chx_cell_prepare(const float* xyz, int n, chx_box_t box, float cutoff_plus_s
   hipLaunchKernelGGL(k_cell_scatter, dim3(pb), dim3(256), 0, st, cell_of, n, cell_start, cell_count,
                      sorted_ids);
   hipLaunchKernelGGL(k_cell_sort, dim3((unsigned)(((int64_t)ncell * CHX_WAVE + 255) / 256)), dim3(256), 0, st,
-                     cell_start, ncell, sorted_ids, xyz, reinterpret_cast<float4*>(xs4_out));
+                     cell_start, ncell, sorted_ids, xyz, reinterpret_cast<float4*>(xs4_out), g.ncx, g.ncy);
   return CHX_OK;
 }
 
