@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--steady-steps", type=int, default=20000,
                     help="timed steps of the steady-state figure reported next to `value` (0 = skip)")
     ap.add_argument("--steady-warmup", type=int, default=2000)
+    ap.add_argument("--clock-warmup-s", type=float, default=3.0,
+                    help="seconds of untimed stepping in front of the --warmup steps: the card's graphics clock takes "
+                         "0-2 s of load to leave its idle level (scripts/mode_probe.py), 10 %% in steps/s")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend of the real run (nccl = RCCL over xGMI; gloo only for rehearsals)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -474,6 +477,18 @@ def main():
         torch.cuda.synchronize()
         if os.environ.get("CHX_BENCH_DEBUG"):
             print(f"[bench] exchange warm-up: {1e3 * (time.perf_counter() - t_w):.2f} ms", file=sys.stderr, flush=True)
+    # clock warm-up (untimed, no exchanges: a time-based loop must not contain collectives).  A process finds the card
+    # at its idle graphics clock (rocm-smi: 2.1-2.2 GHz against 2.4 under load) and the same loop runs 152-159 k
+    # steps/s instead of 175-177 k until the clock has come up, which takes anything from no time to 2 s of load
+    # (scripts/mode_probe.py; round 1 and most of round 2 called this the box's "slow mode").  Production runs last
+    # hours, so the figure of merit is the one at the loaded clock; the W warm-up steps follow as the contract says.
+    clock_warm_s = 0.0
+    if args.clock_warmup_s > 0:
+        t_c = time.perf_counter()
+        while time.perf_counter() - t_c < args.clock_warmup_s:
+            state, _ = integ.run(state, rex.my_state, number_of_steps=5000, nbr_list=nbr)
+            torch.cuda.synchronize()
+        clock_warm_s = time.perf_counter() - t_c
     # warm-up (untimed)
     state, _ = propagate(state, args.warmup)
     prune_before = (getattr(integ, "prune_passes", 0), getattr(integ, "full_list_launches", 0))
@@ -486,10 +501,8 @@ def main():
     # refreshes, so the same loop is timed once more over --steady-steps steps in this process.
     steady = None
     if args.steady_steps > 0:
-        # one MI355X box shows 137-164 k steps/s for the SAME binary and trajectory from one process to the next
-        # (scripts/clock_probe.sh: fclk/mclk constant, the slow runs coincide with the SoC clock being awake and a
-        # higher package power, i.e. with something outside this process), so the steady-state figure is the median
-        # of three back-to-back windows and all three are reported
+        # (the median of three back-to-back windows, all three reported: before the clock warm-up above existed the
+        # same binary showed 137-164 k steps/s from one process to the next)
         extra_warm = max(0, args.steady_warmup - args.warmup - args.steps)
         state, _ = propagate(state, extra_warm)
         windows = []
@@ -536,6 +549,8 @@ def main():
                 "shared_gpu": bool(args.share_gpu),
                 "per_rank_steps_per_s": [round(args.steps / t, 2) for t in per_rank],
                 "chunk_steps": args.chunk,
+                "launch_window": integ.launch_window,
+                "clock_warmup_s": round(clock_warm_s, 2),
                 "list_rebuilds_in_timed_region": rebuilds,
                 # dynamically pruned inner list (chiron_amd/integrators.py): same interacting pairs
                 "pruning_passes_in_timed_region": prune_after[0] - prune_before[0],
