@@ -295,16 +295,21 @@ def fl_chunks_for(maxdeg: int, g: int) -> int:
 def _choose_g(maxdeg: int, n: int) -> int:
     """Lanes that cooperate on one particle in the list kernels.
 
-    Measured on MI355X (scripts/exp_prune.sh, scripts/kernel_bench.py): the kernels want
-    >= 2^18 lanes in flight to fill 256 CUs, as few lanes per particle as that allows (less
-    reduction, fewer idle lanes, all workgroups resident at once), and no more than ~96 listed
-    entries per lane (the step kernel mostly walks the pruned list, about half of that).
+    Measured on MI355X at the loaded clock (scripts/ab_g.py, Langevin steps/s on the rho* = 0.1 fluid; best G and
+    the runners-up): N = 8192: 8 (16: -10 %, 32: -17 %); 16384: 8 (4: -4 %, 16: -7 %); 32768: 4 (8: -2 %, 2: -15 %);
+    65536: 4 (2: -7 %, 8: -15 %); 131072: 2 (4: -4 %, 1: -11 %); 262144: 1 (2: equal, 4: -4 %).  I.e. about 2^18 lanes
+    in flight for the large systems, 2^17 below N = 2^16 and never more than 8 lanes per particle for the sake of the
+    lane count alone: a row of the pruned list has ~14 entries and a chunk 4 G slots, so beyond G = 4..8 the extra
+    lanes mostly evaluate padding, pay a longer reduction and double the workgroups to dispatch.  No more than ~96
+    listed entries per lane (the step kernel mostly walks the pruned list, about half of that).
     """
     env = os.environ.get("CHX_FL_G")
     if env:
         return int(env)
     g = 1  # one lane per particle once that alone fills the chip (N >= 2^18: no reduction, no idle partner lanes)
-    while g < 64 and n * g < (1 << 18):
+    # (dense rows keep the 2^18 target at every size: rho* = 0.8, N = 32768: 8 lanes 82 k steps/s, 4: 77 k, 16: 73 k)
+    lanes = (1 << 18) if (n >= (1 << 16) or maxdeg > 128) else (1 << 17)
+    while g < 8 and n * g < lanes:
         g *= 2
     while g < 64 and maxdeg > 96 * g:  # (96: at rho* = 0.8, N = 262144 four lanes per particle beat eight by 6 %)
         g *= 2
