@@ -67,5 +67,15 @@ for wl in sys.argv[1:] or ["c3", "c4"]:
         CH = 64  # launches per C call: a single launch per ctypes call is host-bound at ~5 us
         if os.environ.get("KB_FULL_LIST"):
             st.params.prune_every = 0  # walk the full list (default: production pruning, a pass every 32 steps included)
-        t_s = ev_time(one, reps=20, warm=3) / CH
+        # clock warm-up: the card needs 0-2 s of load to reach 2.4 GHz.  CAVEAT: the skin check is disabled here, so the
+        # list is never rebuilt while this spins; after ~10^5 steps the pruned list holds only the few pairs of the stale
+        # full list that are still close and the step launch reads 4.0 us instead of the 5.1 us of a live run
+        # (scripts/chunk_age_probe.py measures the real loop).  Use it for A/B decompositions, not for absolute numbers.
+        spin = float(os.environ.get("KB_SPIN_S", "0"))
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < spin:
+            for _ in range(50):
+                one()
+            torch.cuda.synchronize()
+        t_s = ev_time(one, reps=int(os.environ.get("KB_REPS", "20")), warm=3) / CH
         print(f"{wl} g={fl.g} maxdeg={fl.maxdeg} P_nl={p_nl} alg={alg/1e6:.2f}MB  force {t_f:7.2f} us ({alg/t_f/1e3:7.1f} GB/s, {alg/t_f/8e6*100:5.1f}%)   fused step {t_s:7.2f} us")
