@@ -561,6 +561,10 @@ def test_no_kernel_reads_the_dispatch_packet(tmp_path):
         subprocess.run([hipcc] + flags + ["-S", "--offload-device-only", "-o", out, src], check=True, capture_output=True, timeout=600)
         text = open(out).read()
         assert ".amdhsa_user_sgpr_dispatch_ptr 1" not in text, f"{os.path.basename(src)}: a kernel reads the dispatch packet"
+        # ... and none may spill to or park a struct in scratch memory (a RowLoads returned through a conditional
+        # expression once put 224 bytes per lane there)
+        spilled = re.findall(r"\.amdhsa_kernel (\S+)\s+(?:\.amdhsa_group_segment_fixed_size \d+\s+)?\.amdhsa_private_segment_fixed_size ([1-9]\d*)", text)
+        assert not spilled, f"{os.path.basename(src)}: kernels with scratch memory: {spilled[:4]}"
         if src.endswith("chx_lj.hip"):
             sizes = {}
             for m in re.finditer(r"\.amdhsa_kernel _Z9k_lj_stepILi(\d+)ELb[01]ELb[01]EE\S*\s+\.amdhsa_group_segment_fixed_size (\d+)", text):
