@@ -4,6 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 export CHX_ALLOW_STALE_LIB=1
+export CHX_BUILD_KERNEL=particle  # the switches live in the per-particle routine
 for v in "" "-DCHX_EXP_BUILD_NOFL" "-DCHX_EXP_BUILD_NONL" "-DCHX_EXP_BUILD_NOSORT" "-DCHX_EXP_BUILD_NOFL -DCHX_EXP_BUILD_NONL -DCHX_EXP_BUILD_NOSORT" "-DCHX_EXP_BUILD_NOTEST"; do
   bash scripts/build_variant.sh $v
   echo "== variant: ${v:-product}"
