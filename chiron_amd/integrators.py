@@ -162,7 +162,10 @@ class LangevinIntegrator:
             if not nbr_list.is_built:
                 raise ValueError("Neighborlist must be built before use")
             lc = nbr_list.cutoff
-            if lc is not None and lc.value_in_unit_system(unit.md_unit_system) != potential.cutoff:
+            lc_key = ("list_cutoff",)
+            if lc is not None and cache.get(lc_key, (None,))[0] is not lc:  # (unit arithmetic: once per cutoff object)
+                cache[lc_key] = (lc, lc.value_in_unit_system(unit.md_unit_system))
+            if lc is not None and cache[lc_key][1] != potential.cutoff:
                 raise ValueError(
                     f"Neighborlist cutoff ({nbr_list.cutoff}) must be the same as the potential cutoff ({potential.cutoff})"
                 )

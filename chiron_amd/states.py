@@ -88,7 +88,7 @@ class SamplerState:
         for name, value in self.__dict__.items():
             if isinstance(value, unit.Quantity) and isinstance(value._value, torch.Tensor):
                 value = unit.Quantity(value._value.clone(), value.unit)
-            elif name not in ("_distance_unit", "_time_unit", "_current_PRNG_key", "_box_token"):
+            elif name not in ("_distance_unit", "_time_unit", "_current_PRNG_key", "_box_token", "_v_unit"):
                 import copy
 
                 value = copy.deepcopy(value, memo)
@@ -103,14 +103,21 @@ class SamplerState:
         if self._box_vectors is not None:
             new._box_vectors = unit.Quantity(self._box_vectors._value.clone(), self._box_vectors.unit)
         new._positions = unit.Quantity(positions, self._distance_unit)
-        new._velocities = unit.Quantity(velocities, self._distance_unit / self._time_unit)
+        new._velocities = unit.Quantity(velocities, self._velocity_unit())
         return new
+
+    def _velocity_unit(self):
+        """distance / time (unit arithmetic is exact-rational Python: once per pair of units, not per run() call)"""
+        cached = self.__dict__.get("_v_unit")
+        if cached is None or cached[0] is not self._distance_unit or cached[1] is not self._time_unit:
+            cached = self.__dict__["_v_unit"] = (self._distance_unit, self._time_unit, self._distance_unit / self._time_unit)
+        return cached[2]
 
     def _to_md(self, q: unit.Quantity) -> unit.Quantity:
         value = q.value_in_unit_system(unit.md_unit_system)
         target = self._distance_unit
         if q.unit.is_compatible(unit.nanometer / unit.picosecond):
-            target = self._distance_unit / self._time_unit
+            target = self._velocity_unit()
         return unit.Quantity(as_tensor(value), target)
 
     # -- read-only views ---------------------------------------------------
@@ -159,14 +166,14 @@ class SamplerState:
         if isinstance(velocities, unit.Quantity):
             self._velocities = self._to_md(velocities)
         else:
-            self._velocities = unit.Quantity(as_tensor(velocities), self._distance_unit / self._time_unit)
+            self._velocities = unit.Quantity(as_tensor(velocities), self._velocity_unit())
 
     @property
     def distance_unit(self) -> unit.Unit:
         return self._distance_unit
 
     def velocity_unit(self) -> unit.Unit:
-        return self._distance_unit / self._time_unit
+        return self._velocity_unit()
 
     @property
     def current_PRNG_key(self) -> PRNGKey:
