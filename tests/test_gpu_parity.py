@@ -1805,3 +1805,44 @@ def test_both_cell_build_kernels_write_the_same_bits(tmp_path):
     for key in a.files:
         assert np.array_equal(a[key], b[key]), key
     assert int(a["grow_m"][0]) > 12  # the growth loop really ran (rows longer than the initial capacity)
+
+
+def test_langevin_run_after_an_interrupted_run(ca, O, monkeypatch):
+    """A run() that dies half-way (here: its first rebuild raises) leaves its generation of step launches open --
+    the host-mapped control slot, launches possibly still queued.  The integrator must come back clean: the next
+    run() on the same object gives the bits of a fresh integrator, also after enough runs to cycle through the whole
+    ring of control slots."""
+    n, skin, steps = 2500, 0.05, 60
+    x, box, pot, state, thermo, nbr, integ = _langevin_setup(ca, O, n, 0.3, 43, skin, 4.0)
+    rs = ca.integrators._RunState
+    orig = rs._rebuild
+    calls = {"n": 0}
+
+    def boom(self, step=0, speculative=False):
+        calls["n"] += 1
+        if calls["n"] == 1:
+            raise RuntimeError("interrupted")
+        return orig(self, step, speculative)
+
+    monkeypatch.setattr(rs, "_rebuild", boom)
+    ca.utils.PRNG.set_seed(5)
+    key = ca.utils.PRNG.get_random_key()
+    rng = np.random.default_rng(11)
+    v0 = O.initial_velocities(np.full(n, 39.948, f32), O.R_KJ * 300.0, rng.normal(size=(n, 3)).astype(f32))
+    state.velocities = v0
+    state.current_PRNG_key = key  # (run() draws its key from the state and advances it: reset before every run)
+    with pytest.raises(RuntimeError, match="interrupted"):
+        integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr)
+    monkeypatch.setattr(rs, "_rebuild", orig)
+    outs = []
+    for _ in range(6):  # more runs than control slots in the ring
+        state.current_PRNG_key = key
+        out, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr)
+        outs.append(out)
+    x2, box2, pot2, state2, thermo2, nbr2, integ2 = _langevin_setup(ca, O, n, 0.3, 43, skin, 4.0)
+    state2.velocities = v0
+    state2.current_PRNG_key = key
+    ref, _ = integ2.run(state2, thermo2, number_of_steps=steps, nbr_list=nbr2)
+    assert integ.n_rebuilds == integ2.n_rebuilds >= 2
+    for out in outs:  # every run starts from the same state and key: same trajectory every time
+        assert torch.equal(out.positions, ref.positions) and torch.equal(out.velocities, ref.velocities)
