@@ -487,6 +487,8 @@ class NeighborListNsqrd(PairsBase):
                 new._scratch = None  # kernel work arrays are not part of the list
             elif k in ("_spec", "_status_host"):
                 setattr(new, k, None)
+            elif k in ("_spec_event", "_pending_publish"):
+                continue  # plumbing of the speculative rebuild: the copy starts without any
             elif isinstance(v, torch.Tensor):
                 setattr(new, k, v.clone())
             else:
