@@ -141,7 +141,27 @@ def make_system(workload: str, temperature_K: float, chunk: int, build: str):
     return fluid, pot, state, thermo, nbr, integ
 
 
-def time_kernels(fluid, pot, state, nbr, integ, reps: int):
+def read_sclk_mhz(device_index: int = 0):
+    """Graphics clock of the card as rocm-smi shows it right now (MHz), or None.  Context for the reader of the JSON
+    line: the same binary runs 152-159 k steps/s at the card's idle clock level (2.1-2.2 GHz) and 175-179 k at the
+    loaded one (2.4 GHz), and the governor moves between the two on its own schedule (scripts/mode_probe.py)."""
+    import re
+    import shutil
+    import subprocess
+
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    try:
+        out = subprocess.run([exe, "--showclocks"], capture_output=True, text=True, timeout=15).stdout
+    except Exception:  # pragma: no cover - diagnostics only
+        return None
+    for line in out.splitlines():
+        m = re.match(rf"\s*GPU\[{device_index}\]\s*:\s*sclk clock level:\s*\S+\s*\((\d+)Mhz\)", line)
+        if m:
+            return int(m.group(1))
+    return None
+
+
+def time_kernels(fluid, pot, state, nbr, integ, reps: int, spin_s: float = 1.0):
     """HIP-event timing (on the launch stream) of the two hot kernels on the current list:
     k_lj_step (fused pair force + BAOAB, what the timed region launches once per step) and
     k_lj_fl (the pair-force kernel alone, what compute_force() launches).
@@ -164,20 +184,38 @@ def time_kernels(fluid, pot, state, nbr, integ, reps: int):
     args = (ops._ptr(x4), ops._ptr(fl.fl), ops._ptr(fl.deg), n, fl.g, fl.chunks, box, C.c_float(pot.sigma),
             C.c_float(pot.epsilon), C.c_float(pot.cutoff), ops._ptr(f3), None, ops._ptr(fl.ws))
 
+    force_launch = lambda: lib.chx_lj_fl_energy_force(*args, ops._stream())
+
+    def spin(seconds: float):
+        """Load the card with the (state-neutral) pair-force kernel: by the time the kernels are timed the host has
+        been busy building systems and lists, and the graphics clock is back at its idle level (bench.py main: clock
+        warm-up).  Spinning the STEP kernel instead would age the list: its skin check is disabled here, and a pruned
+        list made from a stale full list is short and fast."""
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(200):
+                force_launch()
+            torch.cuda.synchronize()
+
     def timed(fn, count):
+        """Median of three event-timed repetitions (a single ~1 ms sample can sit in a momentary clock dip)."""
         for _ in range(10):
             fn()
-        torch.cuda.synchronize()
-        start = torch.cuda.Event(enable_timing=True)
-        stop = torch.cuda.Event(enable_timing=True)
-        start.record()
-        for _ in range(count):
-            fn()
-        stop.record()
-        torch.cuda.synchronize()
-        return start.elapsed_time(stop) * 1e-3 / count
+        samples = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            start = torch.cuda.Event(enable_timing=True)
+            stop = torch.cuda.Event(enable_timing=True)
+            start.record()
+            for _ in range(count):
+                fn()
+            stop.record()
+            torch.cuda.synchronize()
+            samples.append(start.elapsed_time(stop) * 1e-3 / count)
+        return sorted(samples)[1]
 
-    t_force = timed(lambda: lib.chx_lj_fl_energy_force(*args, ops._stream()), reps)
+    spin(spin_s)
+    t_force = timed(force_launch, reps)
 
     # the fused step kernel on the same state; a huge skin keeps the check from ever firing so that
     # every launch does the full work (the comparison itself still runs)
@@ -197,7 +235,10 @@ def time_kernels(fluid, pot, state, nbr, integ, reps: int):
         ops.langevin_fused_chunk(st.params, even, odd, step[0], per_call, 2, 1)
         step[0] += per_call
 
-    t_step = timed(one_chunk, max(2, reps // per_call)) / per_call
+    spin(0.5 * spin_s)
+    # (20 chunks = 640 launches per sample at the default --kernel-reps: long enough that filling and draining the
+    # launch queue does not show, short enough that the list -- never rebuilt here -- does not age)
+    t_step = timed(one_chunk, max(2, reps // 10)) / per_call
     p_nl = int(torch.minimum(nbr.n_neighbors, torch.tensor(nbr.n_max_neighbors, device=x4.device)).sum().item())
     return t_step, t_force, p_nl, fl
 
@@ -495,6 +536,7 @@ def main():
     state, elapsed, per_rank, exchanges, rebuilds = timed(state, args.steps)
     prune_after = (getattr(integ, "prune_passes", 0), getattr(integ, "full_list_launches", 0))
     value = world * args.steps / elapsed
+    sclk = {}  # (read only after the steady-state windows: a rocm-smi call idles the card for half a second)
 
     # Steady-state figure (>= 1000 timed steps after >= 100 warm-up steps, rebuilds included): the
     # driver's `--steps` may be too short to hold a representative share of list rebuilds and inner-list
@@ -516,8 +558,10 @@ def main():
                   "windows": windows, "statistic": "median of 3 windows"}
 
     if rank == 0:
+        sclk["after_steady_state"] = read_sclk_mhz(local_rank)
         # hot kernels, timed live on the same device / list state
         t_step, t_force, p_nl, fl = time_kernels(fluid, pot, state, nbr, integ, args.kernel_reps)
+        sclk["after_kernel_timing"] = read_sclk_mhz(local_rank)
         info = {"lanes_per_particle": fl.g, "max_degree": fl.maxdeg}
         roof = roofline_entry("step", n, p_nl, t_step, info)
         roof_force = roofline_entry("force", n, p_nl, t_force, info)
@@ -551,6 +595,7 @@ def main():
                 "chunk_steps": args.chunk,
                 "launch_window": integ.launch_window,
                 "clock_warmup_s": round(clock_warm_s, 2),
+                "sclk_mhz": sclk,
                 "list_rebuilds_in_timed_region": rebuilds,
                 # dynamically pruned inner list (chiron_amd/integrators.py): same interacting pairs
                 "pruning_passes_in_timed_region": prune_after[0] - prune_before[0],
