@@ -6,11 +6,12 @@ launch per step on the neighbor-list path: ``k_lj_step`` evaluates the pair forc
 in the same kernel, applies the half-kicks that consume it followed by A-O-A, the
 periodic wrap and the skin check of the *next* step (the trailing kick :195 of step
 s-1 is merged with the leading kick :181 of step s; the arithmetic and its order are
-unchanged).  Steps are enqueued in chunks from C, two chunks ahead of the host.  The
-skin check that the reference turns into a Python ``if`` every step (:241) records the
-step at which it fires in device memory; later launches of the in-flight chunks turn
-into no-ops, and the host rebuilds the neighbor list from exactly the positions the
-reference would have rebuilt it from, then resumes.
+unchanged).  Steps are enqueued from C behind a bounded launch queue (``launch_window``
+launches ahead of the device, ``chx_langevin_fused_run``).  The skin check that the
+reference turns into a Python ``if`` every step (:241) records the step at which it
+fires in device memory and in a host-mapped copy the C loop polls; the few launches
+still queued turn into no-ops, and the host rebuilds the neighbor list from exactly the
+positions the reference would have rebuilt it from, then resumes.
 """
 from __future__ import annotations
 
