@@ -90,7 +90,7 @@ class McParams(C.Structure):
 
 
 # indices into the chx_mc_t state block (include/chx.h)
-MC_CUR, MC_ACCEPTED, MC_PROPOSED, MC_HALT, MC_KEY0, MC_KEY1, MC_STATE_WORDS = 0, 1, 2, 3, 4, 5, 8
+MC_CUR, MC_ACCEPTED, MC_PROPOSED, MC_HALT, MC_KEY0, MC_KEY1, MC_SLOT_WORDS, MC_STATE_WORDS = 0, 1, 2, 3, 4, 5, 8, 16
 
 _P = C.c_void_p
 _I32 = C.c_int32

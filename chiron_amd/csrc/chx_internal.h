@@ -21,9 +21,10 @@ int chx_cell_prepare(const float* xyz, int n, chx_box_t box, float cutoff_plus_s
 //
 // select != NULL (device-resident Monte Carlo): the positions are read from x4 or from
 // select->x4_alt, whichever state[CHX_MC_CUR] ^ flip names, and the launch is a no-op once
-// state[CHX_MC_HALT] <= trial; with energy == NULL the per-block partials stay in ws.
+// *halt <= trial; with energy == NULL the per-block partials stay in ws.
 struct chx_fl_select_t {
-  const int32_t* state;
+  const int32_t* state;  // the slot of this trial (CHX_MC_CUR is read from it)
+  const int32_t* halt;   // the shared halt word
   const float* x4_alt;
   int flip;
   long long trial;

@@ -579,6 +579,7 @@ __device__ __forceinline__ void lj_row(const float4* __restrict__ x4, const uint
 // other (proposed) one; the launch is a no-op once state[CHX_MC_HALT] <= trial.
 struct FlSelect {
   const int32_t* state;
+  const int32_t* halt;
   const float4* x4_alt;
   int flip;
   long long trial;
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(256) void k_lj_fl(const float4* __restrict__ x4,
     return;
   }
   if (sel.state != nullptr) {  // Monte Carlo chunk: positions live in one of two buffers
-    if ((long long)sel.state[CHX_MC_HALT] <= sel.trial) return;
+    if ((long long)sel.halt[0] <= sel.trial) return;
     if (((sel.state[CHX_MC_CUR] ^ sel.flip) & 1) != 0) x4 = sel.x4_alt;
   }
   const unsigned blk = xcd_block(blockIdx.x, gridDim.x);
@@ -1140,9 +1141,10 @@ int chx_launch_lj_fl(const float* x4, const uint32_t* fl, const int32_t* deg, in
   const float4* xx = reinterpret_cast<const float4*>(x4);
   const Box3 b3 = make_box3(box);
   const LJParams lj = make_lj(sigma, epsilon, cutoff);
-  FlSelect sel = {nullptr, nullptr, 0, 0};
+  FlSelect sel = {nullptr, nullptr, nullptr, 0, 0};
   if (select) {
     sel.state = select->state;
+    sel.halt = select->halt;
     sel.x4_alt = reinterpret_cast<const float4*>(select->x4_alt);
     sel.flip = select->flip;
     sel.trial = select->trial;

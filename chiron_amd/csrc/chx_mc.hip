@@ -4,7 +4,7 @@
 //   key = split; x' = wrap(x + sigma N(0,1)); [rebuild list if skin check]; u' = beta U(x');
 //   key = split; accept iff -(u'-u) >= 0 or uniform(key) < exp(-(u'-u))
 // with a host round trip per trial.  Here a whole chunk of trials is enqueued at once:
-// three launches per trial (propose + skin check, list-kernel energy, decide), the
+// two launches per trial (decision of the previous trial + proposal + skin check; list-kernel energy), the
 // accepted configuration changes hands by flipping a buffer index in device memory, the
 // PRNG chain key lives on the device and advances by the same two splits per trial, and
 // the first trial whose proposal violates the skin halts the chunk (every later launch is
@@ -13,6 +13,7 @@
 #include "chx_internal.h"
 
 #include <limits.h>
+#include <stdlib.h>
 
 struct McArgs {
   int n;
@@ -42,17 +43,73 @@ __device__ __forceinline__ void mc_split(uint32_t k0, uint32_t k1, uint32_t& c0,
   s1 = o.w;
 }
 
-__global__ __launch_bounds__(256) void k_mc_propose(McArgs a, long long trial) {
-  if ((long long)a.state[CHX_MC_HALT] <= trial) return;
+// One launch of the trial loop.  DECIDE: take the decision of trial `trial - 1` from the partials its energy launch
+// left in ws -- EVERY workgroup does, redundantly and identically (fixed summation order, one thread's arithmetic),
+// because the proposal below needs the outcome and a launch boundary costs more than this; workgroup 0 records it.
+// PROPOSE: propose trial `trial`.  The chain state (current buffer, counters, key; energies) lives in two slots that
+// take turns by trial parity: the state BEFORE trial t's proposal sits in slot t & 1, so a launch reads one slot
+// and (workgroup 0) writes the other, and no workgroup reads what another one of the same launch writes.
+template <bool DECIDE, bool PROPOSE>
+__global__ __launch_bounds__(256) void k_mc_step(McArgs a, long long trial, int log_slot) {
+  if ((long long)a.state[CHX_MC_HALT] <= trial - (DECIDE ? 1 : 0)) return;  // (the halt word is shared: slot 0)
   const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= a.n) return;
-  const bool cur_b = (a.state[CHX_MC_CUR] & 1) != 0;
-  const float4* x = cur_b ? a.xb : a.xa;
+  // both candidates for "the current configuration" are requested before the decision is known
+  float4 xa_p = make_float4(0.f, 0.f, 0.f, 0.f), xb_p = xa_p;
+  if (PROPOSE && p < a.n) {
+    xa_p = a.xa[p];
+    xb_p = a.xb[p];
+  }
+  const int32_t* in = a.state + CHX_MC_SLOT_WORDS * (int)((DECIDE ? trial - 1 : trial) & 1);
+  int cur = in[CHX_MC_CUR];
+  uint32_t key0 = (uint32_t)in[CHX_MC_KEY0], key1 = (uint32_t)in[CHX_MC_KEY1];
+  if (DECIDE) {
+    __shared__ int32_t sh[3];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < a.nblocks; i += 256) s += a.ws[i];
+    s = block_sum<256>(s);
+    if (threadIdx.x == 0) {
+      const double* e_in = a.energy + 2 * (int)((trial - 1) & 1);
+      const float e_prop = (float)s;  // the potential energy is an fp32 number (k_sum_ws)
+      uint32_t c0, c1, p0, p1, d0, d1, u0, u1;
+      mc_split(key0, key1, c0, c1, p0, p1);  // proposal key
+      mc_split(c0, c1, d0, d1, u0, u1);      // acceptance key
+      const double U = (double)u32_to_uniform(philox4x32(make_uint4(0u, 0u, 0u, CHX_STREAM_UNIFORM), u0, u1).x);
+      const double up = a.beta * (double)e_prop;
+      const double uc = a.beta * e_in[0];
+      const double lp = -up + uc;  // log_proposal_ratio  :770
+      int acc = 0;
+      if (!isnan(up)) acc = (-lp <= 0.0 || U < exp(lp)) ? 1 : 0;  // :428-429, :544-545
+      const int new_cur = cur ^ acc;
+      sh[0] = new_cur;
+      sh[1] = (int32_t)d0;
+      sh[2] = (int32_t)d1;
+      if (blockIdx.x == 0) {
+        int32_t* out = a.state + CHX_MC_SLOT_WORDS * (int)(trial & 1);
+        double* e_out = a.energy + 2 * (int)(trial & 1);
+        const double e_cur = acc ? (double)e_prop : e_in[0];
+        out[CHX_MC_CUR] = new_cur;
+        out[CHX_MC_ACCEPTED] = in[CHX_MC_ACCEPTED] + acc;
+        out[CHX_MC_PROPOSED] = in[CHX_MC_PROPOSED] + 1;
+        out[CHX_MC_KEY0] = (int32_t)d0;
+        out[CHX_MC_KEY1] = (int32_t)d1;
+        e_out[0] = e_cur;
+        e_out[1] = (double)e_prop;
+        if (a.accept_log) a.accept_log[log_slot] = acc;
+        if (a.energy_log) a.energy_log[log_slot] = (float)e_cur;
+      }
+    }
+    __syncthreads();
+    cur = sh[0];
+    key0 = (uint32_t)sh[1];
+    key1 = (uint32_t)sh[2];
+  }
+  if (!PROPOSE || p >= a.n) return;
+  const bool cur_b = (cur & 1) != 0;
+  const float4 xi = cur_b ? xb_p : xa_p;
   float4* xo = cur_b ? a.xa : a.xb;
   uint32_t c0, c1, k0, k1;
-  mc_split((uint32_t)a.state[CHX_MC_KEY0], (uint32_t)a.state[CHX_MC_KEY1], c0, c1, k0, k1);
+  mc_split(key0, key1, c0, c1, k0, k1);
   const uint32_t o = a.perm ? a.perm[p] : (uint32_t)p;
-  const float4 xi = x[p];
   float z0, z1, z2;
   philox_normals3(o, 0u, CHX_STREAM_MC_DISPLACE, k0, k1, z0, z1, z2);
   // normal * sigma [* mask] then x + d   (chiron/mcmc.py:733-748)
@@ -74,35 +131,6 @@ __global__ __launch_bounds__(256) void k_mc_propose(McArgs a, long long trial) {
   float rx, ry, rz;
   displacement(a.box, xn, yn, zn, r0.x, r0.y, r0.z, rx, ry, rz);
   if (norm2(rx, ry, rz) > a.T_half_skin) atomicMin(&a.state[CHX_MC_HALT], (int)trial);  // neighbors.py:868
-}
-
-__global__ __launch_bounds__(256) void k_mc_decide(McArgs a, long long trial, int log_slot) {
-  if ((long long)a.state[CHX_MC_HALT] <= trial) return;
-  double s = 0.0;
-  for (int i = threadIdx.x; i < a.nblocks; i += 256) s += a.ws[i];
-  s = block_sum<256>(s);
-  if (threadIdx.x != 0) return;
-  const float e_prop = (float)s;  // the potential energy is an fp32 number (k_sum_ws)
-  uint32_t c0, c1, p0, p1, d0, d1, u0, u1;
-  mc_split((uint32_t)a.state[CHX_MC_KEY0], (uint32_t)a.state[CHX_MC_KEY1], c0, c1, p0, p1);  // proposal key
-  mc_split(c0, c1, d0, d1, u0, u1);                                                          // acceptance key
-  a.state[CHX_MC_KEY0] = (int32_t)d0;
-  a.state[CHX_MC_KEY1] = (int32_t)d1;
-  const double U = (double)u32_to_uniform(philox4x32(make_uint4(0u, 0u, 0u, CHX_STREAM_UNIFORM), u0, u1).x);
-  const double up = a.beta * (double)e_prop;
-  const double uc = a.beta * a.energy[0];
-  const double lp = -up + uc;  // log_proposal_ratio  :770
-  int acc = 0;
-  if (!isnan(up)) acc = (-lp <= 0.0 || U < exp(lp)) ? 1 : 0;  // :428-429, :544-545
-  a.energy[1] = (double)e_prop;
-  if (acc) {
-    a.energy[0] = (double)e_prop;
-    a.state[CHX_MC_CUR] ^= 1;
-  }
-  a.state[CHX_MC_ACCEPTED] += acc;
-  a.state[CHX_MC_PROPOSED] += 1;
-  if (a.accept_log) a.accept_log[log_slot] = acc;
-  if (a.energy_log) a.energy_log[log_slot] = (float)a.energy[0];
 }
 
 extern "C" int chx_mc_displace_chunk(const chx_mc_t* p, int64_t trial0, int32_t n_trials,
@@ -135,18 +163,27 @@ extern "C" int chx_mc_displace_chunk(const chx_mc_t* p, int64_t trial0, int32_t 
   a.ws = p->ws;
   a.nblocks = chx_lj_fl_blocks(p->n, p->g);
   chx_fl_select_t sel;
-  sel.state = p->state;
+  sel.halt = p->state + CHX_MC_HALT;
   sel.x4_alt = p->x_b;
   sel.flip = 1;  // the proposed configuration sits in the buffer that is NOT current
   const unsigned pb = (unsigned)((p->n + 255) / 256);
+  // CHX_MC_DECIDE_LAUNCH=1: every decision a one-block launch of its own (three launches per trial; A/B, tests)
+  static const bool decide_launch = [] { const char* e = getenv("CHX_MC_DECIDE_LAUNCH"); return e && e[0] == '1'; }();
   for (int i = 0; i < n_trials; ++i) {
     const long long t = trial0 + i;
-    hipLaunchKernelGGL(k_mc_propose, dim3(pb), dim3(256), 0, st, a, t);
+    if (i == 0 || decide_launch) {
+      hipLaunchKernelGGL((k_mc_step<false, true>), dim3(pb), dim3(256), 0, st, a, t, 0);
+    } else {
+      hipLaunchKernelGGL((k_mc_step<true, true>), dim3(pb), dim3(256), 0, st, a, t, i - 1);  // decides trial t - 1
+    }
+    sel.state = p->state + CHX_MC_SLOT_WORDS * (int)(t & 1);
     sel.trial = t;
     int rc = chx_launch_lj_fl(p->x_a, p->fl, p->deg, p->n, p->g, p->fl_chunks, p->box, p->sigma,
                               p->epsilon, p->cutoff, nullptr, nullptr, p->ws, nullptr, st, &sel);
     if (rc != CHX_OK) return rc;
-    hipLaunchKernelGGL(k_mc_decide, dim3(1), dim3(256), 0, st, a, t, i);
+    if (i == n_trials - 1 || decide_launch) {
+      hipLaunchKernelGGL((k_mc_step<true, false>), dim3(1), dim3(256), 0, st, a, t + 1, i);  // decides trial t
+    }
   }
   return chx_check_launch("chx_mc_displace_chunk");
 }

@@ -283,8 +283,9 @@ class MonteCarloDisplacementMove(MCMove):
             self.atom_subset_mask = torch.as_tensor(mask, device=sampler_state.positions.device)
         return self.atom_subset_mask if self.atom_subset is not None else None
 
-    def _device_context(self, sampler_state, thermodynamic_state, nbr_list, energy: float):
-        """Pack the configuration into the force list's internal order and fill ``chx_mc_t``."""
+    def _device_context(self, sampler_state, thermodynamic_state, nbr_list, energy: float, trial: int = 0):
+        """Pack the configuration into the force list's internal order and fill ``chx_mc_t``; ``trial`` = index of
+        the first trial the device loop will run from this context."""
         pot = thermodynamic_state.potential
         fl = nbr_list.force_list
         dev = sampler_state.positions.device
@@ -294,11 +295,14 @@ class MonteCarloDisplacementMove(MCMove):
         ctx["x_a"] = fl.pack(sampler_state.positions, 4)
         ctx["x_b"] = torch.empty_like(ctx["x_a"])
         ctx["ref4"] = fl.pack(nbr_list.ref_positions, 4)
+        # two state slots that take turns by trial parity (include/chx.h: chx_mc_displace_chunk): the chain enters the
+        # device loop at trial `trial`, so its state goes into slot trial & 1; the halt word is shared (slot 0)
+        slot = _lib.MC_SLOT_WORDS * (trial & 1)
         st = np.zeros(_lib.MC_STATE_WORDS, dtype=np.uint32)
         st[_lib.MC_HALT] = 0x7FFFFFFF
-        st[_lib.MC_KEY0], st[_lib.MC_KEY1] = key[0], key[1]
+        st[slot + _lib.MC_KEY0], st[slot + _lib.MC_KEY1] = key[0], key[1]
         ctx["state"] = torch.from_numpy(st.view(np.int32)).to(dev)
-        ctx["energy"] = torch.from_numpy(np.array([energy, energy], dtype=np.float64)).to(dev)
+        ctx["energy"] = torch.from_numpy(np.array([energy, energy, energy, energy], dtype=np.float64)).to(dev)
         ctx["accept_log"] = torch.zeros((self._DEVICE_CHUNK,), dtype=torch.int32, device=dev)
         ctx["energy_log"] = torch.zeros((self._DEVICE_CHUNK,), dtype=torch.float32, device=dev)
         mask = self._subset_mask(sampler_state)
@@ -348,7 +352,7 @@ class MonteCarloDisplacementMove(MCMove):
         sampler_state = copy.deepcopy(sampler_state)  # the caller's object keeps its positions
         pot = thermodynamic_state.potential
         energy = float(pot.compute_energy(sampler_state.positions, nbr_list))  # :392-399
-        ctx = self._device_context(sampler_state, thermodynamic_state, nbr_list, energy)
+        ctx = self._device_context(sampler_state, thermodynamic_state, nbr_list, energy, 0)
         total = self.number_of_moves
         i = 0
         while i < total:
@@ -372,23 +376,28 @@ class MonteCarloDisplacementMove(MCMove):
                 i += done
             if halted:
                 # trial `halt` trips the skin check: run it on the reference's rebuild branch
-                cur = ctx["x_b"] if (int(st[_lib.MC_CUR]) & 1) else ctx["x_a"]
+                # (i == halt now: the chain state sits in slot i & 1)
+                so = _lib.MC_SLOT_WORDS * (i & 1)
+                cur = ctx["x_b"] if (int(st[so + _lib.MC_CUR]) & 1) else ctx["x_a"]
                 sampler_state.positions = ctx["fl"].unpack(cur)
-                sampler_state._current_PRNG_key = PRNGKey(int(st[_lib.MC_KEY0]) & 0xFFFFFFFF, int(st[_lib.MC_KEY1]) & 0xFFFFFFFF)
+                sampler_state._current_PRNG_key = PRNGKey(int(st[so + _lib.MC_KEY0]) & 0xFFFFFFFF,
+                                                          int(st[so + _lib.MC_KEY1]) & 0xFFFFFFFF)
                 self._current_reduced_potential = thermodynamic_state.reduced_potential_from_energy(energy, sampler_state)
                 sampler_state, thermodynamic_state, nbr_list = self._step(sampler_state, thermodynamic_state, nbr_list)
                 energy = float(pot.compute_energy(sampler_state.positions, nbr_list))
                 self._after_attempt(i, energy, sigma_md)
                 i += 1
                 if i < total:
-                    ctx = self._device_context(sampler_state, thermodynamic_state, nbr_list, energy)
+                    ctx = self._device_context(sampler_state, thermodynamic_state, nbr_list, energy, i)
                 else:
                     ctx = None
         if ctx is not None:
             st = ctx["state"].cpu().numpy()
-            cur = ctx["x_b"] if (int(st[_lib.MC_CUR]) & 1) else ctx["x_a"]
+            so = _lib.MC_SLOT_WORDS * (i & 1)  # i == total trials done: the chain state sits in slot i & 1
+            cur = ctx["x_b"] if (int(st[so + _lib.MC_CUR]) & 1) else ctx["x_a"]
             sampler_state.positions = ctx["fl"].unpack(cur)
-            sampler_state._current_PRNG_key = PRNGKey(int(st[_lib.MC_KEY0]) & 0xFFFFFFFF, int(st[_lib.MC_KEY1]) & 0xFFFFFFFF)
+            sampler_state._current_PRNG_key = PRNGKey(int(st[so + _lib.MC_KEY0]) & 0xFFFFFFFF,
+                                                      int(st[so + _lib.MC_KEY1]) & 0xFFFFFFFF)
         self._current_reduced_potential = thermodynamic_state.reduced_potential_from_energy(energy, sampler_state)
         self._move_iteration += 1
         return sampler_state, thermodynamic_state, nbr_list

@@ -377,7 +377,10 @@ int chx_metropolis_select(float* x_cur, const float* x_prop, int64_t count,
 
 /* Device-resident MonteCarloDisplacementMove loop on the force list: n_trials
  * consecutive propose / energy / Metropolis trials (chiron/mcmc.py:243-306, :357-463,
- * :680-787) enqueued back to back, three launches per trial and no host round trip:
+ * :680-787) enqueued back to back, TWO launches per trial and no host round trip (the decision of trial t is taken
+ * at the head of the launch that proposes trial t+1 -- by every workgroup, redundantly and identically, from the
+ * energy launch's per-block partials: a launch of its own would cost more than the arithmetic; the chunk's last
+ * decision is a one-block launch):
  *   propose  x' = wrap(x + sigma_d N(0,1) [* mask]) into the spare buffer + skin check
  *            against ref4 (chiron/neighbors.py:868); the proposal key is the subkey of
  *            split(chain key) -- what SamplerState.new_PRNG_key would hand out
@@ -389,17 +392,21 @@ int chx_metropolis_select(float* x_cur, const float* x_prop, int64_t count,
  *            advances by two splits per trial, exactly like the host path.
  * When the skin check fires in trial t the kernels store t in state[CHX_MC_HALT] and every
  * launch of trial >= t is a no-op: the caller runs that trial through the rebuild path and
- * resumes.  state is CHX_MC_STATE_WORDS ints (indices below); energy[0] = current
- * potential energy (kJ/mol), energy[1] = last proposed.  accept_log / energy_log
- * (n_trials entries each, may be NULL) record the decision and the current energy after
- * every trial, indexed by trial - trial0.  Asynchronous. */
+ * resumes.  state is CHX_MC_STATE_WORDS ints: TWO slots of CHX_MC_SLOT_WORDS words (indices below, slot s at
+ * offset s * CHX_MC_SLOT_WORDS) that take turns by trial parity -- a launch reads one and writes the other, so no
+ * workgroup reads what another one of the same launch writes.  On entry slot (trial0 & 1) holds the chain state; after
+ * the chunk slot (T & 1) does, T = the halt trial if the chunk halted, else trial0 + n_trials.  The halt word is
+ * shared: always state[CHX_MC_HALT] of slot 0.  energy follows the same rule: [2 s] = current potential energy
+ * (kJ/mol) of slot s, [2 s + 1] = last proposed.  accept_log / energy_log (n_trials entries each, may be NULL) record
+ * the decision and the current energy after every trial, indexed by trial - trial0.  Asynchronous. */
 #define CHX_MC_CUR 0       /* which buffer (0: x_a, 1: x_b) holds the current configuration */
 #define CHX_MC_ACCEPTED 1  /* running counters */
 #define CHX_MC_PROPOSED 2
 #define CHX_MC_HALT 3      /* first trial that did not run; INT32_MAX when clear */
 #define CHX_MC_KEY0 4      /* PRNG chain key */
 #define CHX_MC_KEY1 5
-#define CHX_MC_STATE_WORDS 8
+#define CHX_MC_SLOT_WORDS 8
+#define CHX_MC_STATE_WORDS 16
 typedef struct chx_mc_t {
   int32_t n;
   int32_t g;               /* lanes per particle of the force list */
@@ -418,8 +425,8 @@ typedef struct chx_mc_t {
   float sigma, epsilon, cutoff;
   float reserved2;
   double beta;             /* mol/kJ */
-  int32_t* state;          /* CHX_MC_STATE_WORDS ints */
-  double* energy;          /* [0] current, [1] proposed */
+  int32_t* state;          /* CHX_MC_STATE_WORDS ints (two slots, see above) */
+  double* energy;          /* 4 doubles: [2 s] current, [2 s + 1] proposed, of slot s */
   int32_t* accept_log;
   float* energy_log;
   double* ws;              /* chx_lj_ws_count(n) doubles */

@@ -1,7 +1,7 @@
 # GPU test suite under the tuning overrides (lanes per particle, pruning cadence, launch queue, build kernel, host
 # control-block scheme): every combination must pass
 cd $GRAFT_REPO_ROOT
-for env in "CHX_SYNC_REBUILD=1" "CHX_LAUNCH_WINDOW=0" "CHX_LAUNCH_WINDOW=1" "CHX_LAUNCH_WINDOW=3 CHX_FL_G=2" "CHX_HOST_CTRL=0" \
+for env in "CHX_SYNC_REBUILD=1" "CHX_LAUNCH_WINDOW=0" "CHX_LAUNCH_WINDOW=1" "CHX_LAUNCH_WINDOW=3 CHX_FL_G=2" "CHX_HOST_CTRL=0" "CHX_MC_DECIDE_LAUNCH=1" \
            "CHX_BUILD_KERNEL=cell" "CHX_BUILD_KERNEL=cell CHX_BUILD_SPLIT=3" "CHX_BUILD_KERNEL=particle" \
            "CHX_FL_G=1" "CHX_FL_G=8" "CHX_FL_G=16" "CHX_FL_G=64" "CHX_PRUNE_EVERY=0" "CHX_PRUNE_EVERY=1" \
            "CHX_PRUNE_EVERY=7 CHX_INNER_SKIN=0.02" "CHX_PRUNE_EVERY=50 CHX_INNER_SKIN=0.3"; do
