@@ -1,7 +1,7 @@
-"""Acceptance statistics of the test-sized MC systems for a few displacement sigmas (GPU box only)."""
+"""Acceptance statistics of the test-sized MC systems for a few displacement sigmas (GPU box only; a helper for
+choosing the parameters of the Monte Carlo tests -- it uses the oracle's lattice generator, so it lives under tests/)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 import chiron_amd as ca
 from chiron_amd import unit as u, mcmc, neighbors, states, potential
