@@ -183,6 +183,30 @@ def test_c4_langevin_is_independent_of_launch_batching(ca, O):
     assert x.min() >= 0.0 and x.max() < L * (1 + 1e-6)
 
 
+@pytest.mark.parametrize("n", [N3, N4], ids=["c3-32768", "c4-262144"])
+def test_launch_window_and_chunked_scheme_agree_at_full_size(ca, O, n, monkeypatch):
+    """The metric configuration's loop, both ways: the bounded launch queue (chx_langevin_fused_run, the default) and
+    the older two-chunks-in-flight scheme end in the same bits -- positions, velocities, rebuild count, rebuilt list --
+    at N = 32,768 (lanes per particle 4, per-particle build kernel) and N = 262,144 (one lane, cell-wise build kernel).
+    Thin skin: several rebuilds inside a short run."""
+    orig = ca.integrators.LangevinIntegrator.__init__
+    res = []
+    for window in (None, 0):
+        def init(self, *a, _w=window, **k):
+            orig(self, *a, **k)
+            if _w is not None:
+                self.launch_window = _w
+        monkeypatch.setattr(ca.integrators.LangevinIntegrator, "__init__", init)
+        res.append(_run_langevin(ca, O, n, 32, 160 if n == N3 else 96, 0.06))
+    monkeypatch.setattr(ca.integrators.LangevinIntegrator, "__init__", orig)
+    (a, nbr_a, integ_a), (b, nbr_b, integ_b) = res
+    assert integ_a.launch_window > 0 and integ_b.launch_window == 0
+    assert integ_a.n_rebuilds == integ_b.n_rebuilds >= 1
+    assert torch.equal(a.positions, b.positions) and torch.equal(a.velocities, b.velocities)
+    assert torch.equal(nbr_a.ref_positions, nbr_b.ref_positions) and torch.equal(nbr_a.n_neighbors, nbr_b.n_neighbors)
+    assert (integ_a.prune_passes, integ_a.full_list_launches) == (integ_b.prune_passes, integ_b.full_list_launches)
+
+
 def test_c3_mc_device_loop_equals_host_loop(ca, O, monkeypatch):
     """MonteCarloDisplacementMove at N = 32,768: device-resident loop == reference-shaped host loop."""
     u = ca.unit
