@@ -490,7 +490,7 @@ def langevin_fused_chunk(params: LangevinParams, x_even: torch.Tensor, x_odd: to
     )
 
 
-_n_enqueued = C.c_int32(0)
+_tls = __import__("threading").local()  # (MultiStateSampler may drive two replicas from two threads)
 
 
 def langevin_fused_run(params: LangevinParams, x_even: torch.Tensor, x_odd: torch.Tensor, step0: int,
@@ -498,12 +498,15 @@ def langevin_fused_run(params: LangevinParams, x_even: torch.Tensor, x_odd: torc
     """``langevin_fused_chunk`` with a bounded launch queue (include/chx.h: chx_langevin_fused_run).
     Returns the number of launches made: fewer than ``n_steps`` when the host saw the halt word."""
     _require_device(x_even, x_odd)
+    out = getattr(_tls, "n_enqueued", None)
+    if out is None:
+        out = _tls.n_enqueued = C.c_int32(0)
     check(
         _lib.load().chx_langevin_fused_run(C.byref(params), _ptr(x_even), _ptr(x_odd), step0, n_steps, kicks_first, window,
-                                           C.byref(_n_enqueued), _stream()),
+                                           C.byref(out), _stream()),
         "chx_langevin_fused_run",
     )
-    return _n_enqueued.value
+    return out.value
 
 
 def ctrl_reset(ctrl: torch.Tensor) -> None:

@@ -958,6 +958,49 @@ def test_multistate_sampler_on_lj_replicas(ca, O, swap):
     assert all(k_ > 0 for k_ in ke)
 
 
+def test_multistate_concurrent_replicas_give_the_serial_results(ca, O):
+    """``MultiStateSampler(concurrent_replicas=2)`` propagates two replicas side by side (two threads, two HIP streams:
+    a step of a medium-size system leaves the card mostly idle).  Replicas are independent between mixing steps, so
+    positions, velocities, PRNG keys, neighbor lists, state assignment and the whole u_kn history must be the serial
+    loop's bits -- five replicas (an odd number: the lanes get unequal shares), swaps on, thin skin (rebuilds inside
+    every segment, so both threads sit in the C launch loop and in the rebuild path at the same time)."""
+    from chiron_amd.mcmc import LangevinDynamicsMove, MCMCSampler, MoveSchedule
+    from chiron_amd.multistate import MultiStateSampler
+    from chiron_amd.rng import PRNGKey
+
+    u = ca.unit
+    K, n = 5, 2500
+    x, box = O.lj_lattice(n, 0.3, SIGMA, seed=7)
+    pot = lj_pot(ca, n)
+    temps = [300.0 * 1.08 ** k for k in range(K)]
+
+    def run(workers):
+        thermo = [ca.states.ThermodynamicState(pot, temperature=t * u.kelvin) for t in temps]
+        states, lists = [], []
+        for k in range(K):
+            st = make_state(ca, x, box)
+            st.current_PRNG_key = PRNGKey(4321, k)
+            states.append(st)
+            lists.append(ca.neighbors.NeighborListCell(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+                                                       skin=0.06 * u.nanometer, n_max_neighbors=180))
+        move = LangevinDynamicsMove(timestep=4.0 * u.femtoseconds, number_of_steps=120)
+        ms = MultiStateSampler(MCMCSampler(MoveSchedule([("LangevinDynamicsMove", move)])), swap="neighbors",
+                               concurrent_replicas=workers)
+        ms.create(thermo, states, lists)
+        ms.run(n_iterations=4, n_mcmc_iterations=1)
+        torch.cuda.synchronize()
+        return ms
+
+    a, b = run(1), run(2)
+    assert np.array_equal(a._reporter.get_property("u_kn"), b._reporter.get_property("u_kn"))
+    assert list(a._replica_thermodynamic_states) == list(b._replica_thermodynamic_states)
+    for sa, sb, la, lb in zip(a._sampler_states, b._sampler_states, a._nbr_lists, b._nbr_lists):
+        assert torch.equal(sa.positions, sb.positions) and torch.equal(sa.velocities, sb.velocities)
+        assert tuple(sa.current_PRNG_key) == tuple(sb.current_PRNG_key)
+        assert torch.equal(la.ref_positions, lb.ref_positions) and torch.equal(la.neighbor_list, lb.neighbor_list)
+        assert la.n_builds == lb.n_builds and la.n_builds > 5  # rebuilds happened inside the segments
+
+
 # ---------------------------------------------------------------------------
 # Monte Carlo
 # ---------------------------------------------------------------------------
