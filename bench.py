@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--kernel-reps", type=int, default=200)
     ap.add_argument("--cpu-steps", type=int, default=-1, help="steps of the CPU baseline (-1 = auto, 0 = skip)")
     ap.add_argument("--extra-c4", type=int, default=1, help="also report the N=262,144 pair-force roofline (1 GPU runs)")
+    ap.add_argument("--extra-overlap", type=int, default=1,
+                    help="also report the aggregate rate of TWO independent replicas of the workload driven from two "
+                         "threads / HIP streams on the one card (1 GPU runs; not the headline: one replica per GPU)")
     ap.add_argument("--steady-steps", type=int, default=20000,
                     help="timed steps of the steady-state figure reported next to `value` (0 = skip)")
     ap.add_argument("--steady-warmup", type=int, default=2000)
@@ -139,6 +142,47 @@ def make_system(workload: str, temperature_K: float, chunk: int, build: str):
     nbr = cls(OrthogonalPeriodicSpace(), cutoff=cutoff, skin=SKIN_NM * unit.nanometer, n_max_neighbors=m0)
     integ = LangevinIntegrator(timestep=1.0 * unit.femtoseconds, collision_rate=1.0 / unit.picoseconds, chunk_size=chunk)
     return fluid, pot, state, thermo, nbr, integ
+
+
+def two_replica_overlap(args, steps: int):
+    """Two independent replicas of the benched workload (300 K and 315 K, their own lists, integrators and PRNG keys) on
+    ONE card, each driven by a thread of its own on a HIP stream of its own: a step at this size is a latency chain
+    that leaves the card mostly idle, so the two overlap.  Reported beside the headline, never as it (the BASELINE
+    configuration is one replica per GPU)."""
+    import threading
+
+    import torch
+
+    systems = [make_system(args.workload, t, args.chunk, args.build) for t in (300.0, 315.0)]
+    streams = [torch.cuda.Stream() for _ in systems]
+    rates = [0.0, 0.0]
+
+    def drive(k: int, n_steps: int, record: bool):
+        fluid, pot, state, thermo, nbr, integ = systems[k]
+        with torch.cuda.stream(streams[k]):
+            t0 = time.perf_counter()
+            state, nbr = integ.run(state, thermo, number_of_steps=n_steps, nbr_list=nbr)
+            streams[k].synchronize()
+            if record:
+                rates[k] = n_steps / (time.perf_counter() - t0)
+        systems[k] = (fluid, pot, state, thermo, nbr, integ)
+
+    def both(n_steps: int, record: bool):
+        threads = [threading.Thread(target=drive, args=(k, n_steps, record)) for k in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+
+    both(2000, False)  # lists, scratch, pinned slots
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    both(steps, True)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    return {"replicas": 2, "steps_each": steps, "aggregate_steps_per_s": round(2 * steps / wall, 2),
+            "per_replica_steps_per_s": [round(r, 2) for r in rates],
+            "note": "two threads, two HIP streams, one process, one card; not the headline configuration"}
 
 
 def read_sclk_mhz(device_index: int = 0):
@@ -608,6 +652,11 @@ def main():
             "roofline": roof,
             "roofline_pair_force": roof_force,
         }
+        if world == 1 and args.extra_overlap:
+            try:
+                out["two_replicas_one_gpu"] = two_replica_overlap(args, args.steps if args.steps >= 2000 else 20000)
+            except Exception as exc:  # pragma: no cover - diagnostics only
+                out["two_replicas_one_gpu"] = {"error": repr(exc)}
         if world == 1 and args.extra_c4 and args.workload != "c4":
             try:
                 fluid4, pot4, state4, thermo4, nbr4, integ4 = make_system("c4", 300.0, args.chunk, "cell")
