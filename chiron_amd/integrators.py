@@ -333,8 +333,11 @@ class _RunState:
         inner = float(env_skin) if env_skin is not None else getattr(self.integ, "inner_skin_nm", None)
         every = int(env_every) if env_every is not None else getattr(self.integ, "prune_every", 32)
         if inner is None:
-            # little to prune under a thin skin; tiny systems are pure launch latency
-            inner = 0.12 if (skin >= 0.3 and self.n >= 2048) else 0.0
+            # little to prune under a thin skin; tiny systems are pure launch latency.  0.12 nm keeps a 300 K argon
+            # fluid on the pruned table for all 32 steps of an epoch; where the step is throughput-bound (N >= 2^17)
+            # the shorter rows of 0.10 nm are worth +2 % and the handful of full-list launches per 20 000 steps they
+            # cost is not (scripts/ab_inner.py: N = 131 072 +2 %, 262 144 +1.5-2 %; 32 768 and 65 536 equal)
+            inner = (0.10 if self.n >= (1 << 17) else 0.12) if (skin >= 0.3 and self.n >= 2048) else 0.0
         if inner <= 0.0 or every <= 0 or inner >= skin:
             return 0.0, 0
         return inner, every
