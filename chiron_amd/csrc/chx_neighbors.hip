@@ -113,6 +113,11 @@ __device__ __forceinline__ int cell_coord(float x, float L, float s, int nc) {
   return c >= nc ? nc - 1 : c;
 }
 
+__global__ void k_zero_i32(int32_t* __restrict__ p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
 __global__ void k_cell_assign(const float* __restrict__ xyz, int n, Box3 box, CellGrid g,
                               int32_t* __restrict__ cell_of, int32_t* __restrict__ cell_count) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -348,10 +353,9 @@ int chx_cell_prepare(const float* xyz, int n, chx_box_t box, float cutoff_plus_s
   g.sx = (float)nc_h[0] / box.lx; g.sy = (float)nc_h[1] / box.ly; g.sz = (float)nc_h[2] / box.lz;
   *g_out = g;
   CHX_REQUIRE(status_len >= 0 && status_len <= 1024, "status block too long");
-  if (hipMemsetAsync(cell_count, 0, sizeof(int32_t) * ((size_t)ncell + 1), st) != hipSuccess) {
-    chx_set_error("chx_cell_prepare: hipMemsetAsync failed");
-    return CHX_ERR_LAUNCH;
-  }
+  // (a kernel, not hipMemsetAsync: the runtime's fill path can block the calling thread on a signal of its own, and
+  // a rebuild inside the Langevin loop must not put the host to sleep -- scripts/host_speed_probe.py)
+  hipLaunchKernelGGL(k_zero_i32, dim3((unsigned)((ncell + 1 + 255) / 256)), dim3(256), 0, st, cell_count, ncell + 1);
   const unsigned pb = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(k_cell_assign, dim3(pb), dim3(256), 0, st, xyz, n, b3, g, cell_of, cell_count);
   hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, st, cell_count, cell_start, ncell, status, status_len);
