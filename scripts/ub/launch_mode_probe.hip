@@ -41,6 +41,13 @@ __global__ __launch_bounds__(256) void k_step(int32_t* ctrl, long long step, int
   (void)ctrl;
 }
 
+// last node of a captured batch: counts finished batches where the host can see it
+__global__ void k_tick(int32_t* ctr, int32_t* host) {
+  const int v = ctr[0] + 1;
+  ctr[0] = v;
+  __hip_atomic_store(&host[1], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 static double now() {
   timespec t;
   clock_gettime(CLOCK_MONOTONIC, &t);
@@ -77,22 +84,55 @@ int main(int argc, char** argv) {
     }
     CK(hipDeviceSynchronize());
   };
+  // argv[5] = G > 0: the same chain replayed from a hipGraph of G step launches (+ the tick), at most two replays in flight
+  const int graph_len = argc > 5 ? atoi(argv[5]) : 0;
+  hipGraphExec_t gexec = nullptr;
+  hipStream_t gs = st;
+  if (graph_len > 0) {
+    if (!gs) CK(hipStreamCreateWithFlags(&gs, hipStreamNonBlocking));
+    Big gb = big;
+    gb.host_ctrl = nullptr;
+    hipGraph_t g;
+    CK(hipStreamBeginCapture(gs, hipStreamCaptureModeGlobal));
+    for (int i = 0; i < graph_len; ++i) {
+      gb.in = (i & 1) ? b : a;
+      gb.out = (i & 1) ? a : b;
+      hipLaunchKernelGGL(k_step, dim3(n / 256), dim3(256), 0, gs, ctrl, (long long)i, n, gb);
+    }
+    hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, gs, ctrl, host);
+    CK(hipStreamEndCapture(gs, &g));
+    CK(hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0));
+    CK(hipMemset(ctrl, 0, 64));
+    host[1] = 0;
+  }
+  auto run_graph = [&](int count) {  // count launches = count / graph_len replays
+    volatile int32_t* hc = host;
+    const int replays = count / graph_len;
+    const int base = hc[1];
+    for (int r = 0; r < replays; ++r) {
+      while ((base + r) - hc[1] >= 2) __builtin_ia32_pause();
+      CK(hipGraphLaunch(gexec, gs));
+    }
+    CK(hipStreamSynchronize(gs));
+  };
   host[0] = -1;
   double t0 = now();
   long long s = 0;
   while (now() - t0 < 3.0) {  // clock warm-up
-    run(2000, s);
+    if (graph_len > 0) run_graph(2048);
+    else run(2000, s);
     s += 2000;
   }
   for (int rep = 0; rep < 5; ++rep) {
     rusage r0, r1;
     getrusage(RUSAGE_THREAD, &r0);
     const double t1 = now();
-    run(launches, s);
+    if (graph_len > 0) run_graph(launches);
+    else run(launches, s);
     s += launches;
     const double dt = now() - t1;
     getrusage(RUSAGE_THREAD, &r1);
-    printf("stream mode %d, window %s, query every %d: %d launches: %.0f per second (%.2f us each), voluntary context switches %ld, involuntary %ld\n", mode, throttle ? "on" : "off", query_every, launches,
+    printf("stream mode %d, window %s, query every %d, graph of %d: %d launches: %.0f per second (%.2f us each), voluntary context switches %ld, involuntary %ld\n", mode, throttle ? "on" : "off", query_every, graph_len, launches,
            launches / dt, 1e6 * dt / launches, r1.ru_nvcsw - r0.ru_nvcsw, r1.ru_nivcsw - r0.ru_nivcsw);
   }
   return 0;
