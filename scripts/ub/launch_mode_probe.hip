@@ -48,6 +48,49 @@ __global__ void k_tick(int32_t* ctr, int32_t* host) {
   __hip_atomic_store(&host[1], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// the same step with its argument block in device memory (kernarg = a few scalars + one pointer)
+__global__ __launch_bounds__(256) void k_step_ptr(int32_t* ctrl, long long step, int n, const Big* bp, int flip) {
+  Big b = *bp;
+  if (flip) {
+    const float4* t = b.in;
+    b.in = b.out;
+    b.out = const_cast<float4*>(t);
+  }
+  if (b.host_ctrl && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&b.host_ctrl[0], (int)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  float4 v = b.in[t];
+  const int j = ((int)(v.x * 1e3f) & 0x7fffffff) % n;
+  const float4 w = b.in[j];
+#pragma unroll 1
+  for (int k = 0; k < 200; ++k) v.y = v.y * 0.999f + w.x * 1e-3f;
+  v.x = w.x * 0.5f + v.x * 0.5f;
+  b.out[t] = v;
+  (void)ctrl;
+}
+
+__global__ __launch_bounds__(256) void k_step_ptr_mid(int32_t* ctrl, long long step, int n, const Big* bp, int flip, long long p0,
+                                                      long long p1, long long p2, long long p3, long long p4, long long p5,
+                                                      long long p6, long long p7) {
+  Big b = *bp;
+  if (flip) {
+    const float4* t = b.in;
+    b.in = b.out;
+    b.out = const_cast<float4*>(t);
+  }
+  if (b.host_ctrl && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&b.host_ctrl[0], (int)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  float4 v = b.in[t];
+  const int j = ((int)(v.x * 1e3f) & 0x7fffffff) % n;
+  const float4 w = b.in[j];
+#pragma unroll 1
+  for (int k = 0; k < 200; ++k) v.y = v.y * 0.999f + w.x * 1e-3f;
+  v.x = w.x * 0.5f + v.x * 0.5f + (float)((p0 ^ p1 ^ p2 ^ p3 ^ p4 ^ p5 ^ p6 ^ p7) & 0) ;
+  b.out[t] = v;
+  (void)ctrl;
+}
+
 static double now() {
   timespec t;
   clock_gettime(CLOCK_MONOTONIC, &t);
@@ -72,6 +115,15 @@ int main(int argc, char** argv) {
   const int query_every = argc > 4 ? atoi(argv[4]) : 0;  // > 0: hipStreamQuery from the launching thread every so many launches
   if (mode == 1) CK(hipStreamCreate(&st));
   if (mode == 2) CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  const int small_kernarg = argc > 6 ? atoi(argv[6]) : 0;  // 1: argument block in device memory
+  Big* big_d = nullptr;
+  if (small_kernarg) {
+    Big tmp = big;
+    tmp.in = a;
+    tmp.out = b;
+    CK(hipMalloc(&big_d, sizeof(Big)));
+    CK(hipMemcpy(big_d, &tmp, sizeof(Big), hipMemcpyHostToDevice));
+  }
   auto run = [&](int count, long long s0) {
     volatile int32_t* hc = host;
     for (int i = 0; i < count; ++i) {
@@ -79,7 +131,9 @@ int main(int argc, char** argv) {
       while (throttle && s - hc[0] > window) __builtin_ia32_pause();
       big.in = (i & 1) ? b : a;
       big.out = (i & 1) ? a : b;
-      hipLaunchKernelGGL(k_step, dim3(n / 256), dim3(256), 0, st, ctrl, s, n, big);
+      if (small_kernarg == 2) hipLaunchKernelGGL(k_step_ptr_mid, dim3(n / 256), dim3(256), 0, st, ctrl, s, n, big_d, i & 1, 1ll, 2ll, 3ll, 4ll, 5ll, 6ll, 7ll, 8ll);
+      else if (small_kernarg) hipLaunchKernelGGL(k_step_ptr, dim3(n / 256), dim3(256), 0, st, ctrl, s, n, big_d, i & 1);
+      else hipLaunchKernelGGL(k_step, dim3(n / 256), dim3(256), 0, st, ctrl, s, n, big);
       if (query_every > 0 && (i % query_every) == query_every - 1) (void)hipStreamQuery(st);
     }
     CK(hipDeviceSynchronize());
@@ -132,7 +186,7 @@ int main(int argc, char** argv) {
     s += launches;
     const double dt = now() - t1;
     getrusage(RUSAGE_THREAD, &r1);
-    printf("stream mode %d, window %s, query every %d, graph of %d: %d launches: %.0f per second (%.2f us each), voluntary context switches %ld, involuntary %ld\n", mode, throttle ? "on" : "off", query_every, graph_len, launches,
+    printf("stream mode %d, window %s, query every %d, graph of %d, small kernarg %d: %d launches: %.0f per second (%.2f us each), voluntary context switches %ld, involuntary %ld\n", mode, throttle ? "on" : "off", query_every, graph_len, small_kernarg, launches,
            launches / dt, 1e6 * dt / launches, r1.ru_nvcsw - r0.ru_nvcsw, r1.ru_nivcsw - r0.ru_nivcsw);
   }
   return 0;
