@@ -130,39 +130,60 @@ __global__ void k_cell_assign(const float* __restrict__ xyz, int n, Box3 box, Ce
   atomicAdd(&cell_count[c], 1);
 }
 
-// single-block exclusive scan: cell_start[0..ncell] from cell_count; zeroes cell_count (reused as
-// cursor).  Tiles of 1024 cells, coalesced loads, wave-shuffle scans (two barriers per tile).
+// single-block exclusive scan: cell_start[0..ncell] from cell_count; zeroes cell_count (reused as cursor).
+// Every wavefront owns one contiguous segment of the cells (a multiple of 64): pass 1 adds the segment up with
+// independent coalesced loads, ONE barrier hands the 16 segment totals around, pass 2 rereads the segment (L2) and
+// writes the running prefix with wave-shuffle scans, 256 counts per trip (four independent loads per lane).  (The tile-by-tile form this replaces -- 1024 cells per trip, three barriers and one exposed load
+// latency per trip -- took 30 us for the 27 000 cells of N = 262 144.)
 __global__ __launch_bounds__(1024) void k_cell_scan(int32_t* __restrict__ cell_count,
                                                     int32_t* __restrict__ cell_start, int ncell,
                                                     int32_t* __restrict__ status, int status_len) {
-  __shared__ int32_t wsum[16];
-  __shared__ int32_t carry_s;
+  __shared__ int32_t wtot[16];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   if (t < status_len) status[t] = 0;  // (the build kernels behind this one accumulate into it: no memset launch)
-  if (t == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < ncell; base += 1024) {
-    const int c = base + t;
-    const int32_t v = c < ncell ? cell_count[c] : 0;
-    int32_t incl = v;
+  const int seg = ((ncell + 15) / 16 + CHX_WAVE - 1) & ~(CHX_WAVE - 1);
+  const int s0 = wv * seg < ncell ? wv * seg : ncell;
+  const int s1 = s0 + seg < ncell ? s0 + seg : ncell;
+  int32_t acc = 0;
+  for (int b = s0; b < s1; b += 4 * CHX_WAVE) {  // four independent loads in flight per lane
+    int32_t v[4];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int32_t u = __shfl_up(incl, o, CHX_WAVE);
-      if (lane >= o) incl += u;
+    for (int q = 0; q < 4; ++q) {
+      const int c = b + q * CHX_WAVE + lane;
+      v[q] = c < s1 ? cell_count[c] : 0;
     }
-    if (lane == 63) wsum[wv] = incl;
-    __syncthreads();
-    int32_t before = carry_s;
-    for (int k = 0; k < wv; ++k) before += wsum[k];
-    if (c < ncell) {
-      cell_start[c] = before + incl - v;
-      cell_count[c] = 0;
-    }
-    __syncthreads();
-    if (t == 1023) carry_s = before + incl;
-    __syncthreads();
+    acc += (v[0] + v[1]) + (v[2] + v[3]);
   }
-  if (t == 0) cell_start[ncell] = carry_s;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, CHX_WAVE);
+  if (lane == 0) wtot[wv] = acc;
+  __syncthreads();
+  int32_t carry = 0;
+  for (int k = 0; k < wv; ++k) carry += wtot[k];
+  for (int b = s0; b < s1; b += 4 * CHX_WAVE) {
+    int32_t v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = b + q * CHX_WAVE + lane;
+      v[q] = c < s1 ? cell_count[c] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = b + q * CHX_WAVE + lane;
+      int32_t incl = v[q];
+#pragma unroll
+      for (int o = 1; o < CHX_WAVE; o <<= 1) {
+        const int32_t u = __shfl_up(incl, o, CHX_WAVE);
+        if (lane >= o) incl += u;
+      }
+      if (c < s1) {
+        cell_start[c] = carry + incl - v[q];
+        cell_count[c] = 0;
+      }
+      carry += __shfl(incl, CHX_WAVE - 1, CHX_WAVE);
+    }
+  }
+  if (t == 1023) cell_start[ncell] = carry;  // (the last wavefront's segment ends at ncell, or is empty: carry = total)
 }
 
 __global__ void k_cell_scatter(const int32_t* __restrict__ cell_of, int n,
