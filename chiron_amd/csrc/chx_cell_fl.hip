@@ -10,6 +10,7 @@
 // Both come from the same fp32 predicate evaluated in the reference's orientation
 // (x_lo - x_hi by original id), so the pair sets are identical by construction.
 #include <cstdlib>
+#include <type_traits>
 
 #include "chx_common.h"
 #include "chx_internal.h"
@@ -208,9 +209,13 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
 // The per-particle kernel above is bound by VALU issue (PMC: ~1000 vector instructions per row, of which the range
 // search, the candidate loads and the prologue are more than half); here those are shared by the cell's rows.
 // Rows come out as the per-particle kernel writes them: force-list rows in the same scan order, half rows
-// rank-sorted ascending.  Half-row hits go to their row of `nl` unsorted first and are sorted in place at the end;
-// a row too long for that (> m or > CHX_ROW_SORT_CAP entries) is redone by build_row_of_particle.
+// rank-sorted ascending.  Half-row hits wait for the sort in this wave's LDS slice (one 64-word row per particle, up
+// to 15 particles per pass; C4: 309 -> 299 us per build call against the scheme below); a pass with more particles
+// writes them to their row of `nl` unsorted first and sorts in place at the end; a row too long for either (> m, > 64
+// resp. CHX_ROW_SORT_CAP entries) is redone by build_row_of_particle.
 #define CHX_ROW_SORT_CAP 256
+#define CHX_LDS_ROW_WORDS 64  // on-chip half rows: words per row ...
+#define CHX_LDS_ROWS 15       // ... and rows per pass (15 x 64 words + the 40 words of the range table <= CHX_CELL_CAP)
 __device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
@@ -247,6 +252,10 @@ __global__ __launch_bounds__(256) void k_nl_build_cellwise_fl(
       ih = sorted_ids[hb + lane];
     }
     int cf = 0, ch = 0;  // entries written so far to the force-list row / half row of this lane's particle
+    // Half-row hits wait for their rank sort on chip when the pass has few enough particles (the BASELINE density:
+    // ~10 per cell): row ii owns CHX_LDS_ROW_WORDS words of this wave's LDS slice, nothing is written to `nl`
+    // unsorted and read back.  Denser cells keep the older scheme (unsorted to the row of `nl`, sorted in place).
+    const bool lds_rows = nh <= CHX_LDS_ROWS;
     int r = 0, k_n = 0;
     uint32_t j_n = 0;
     float4 x_n = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -256,54 +265,64 @@ __global__ __launch_bounds__(256) void k_nl_build_cellwise_fl(
       j_n = sorted_ids[k_n];
       x_n = xs4[k_n];
     }
-    for (int t0 = 0; t0 < total; t0 += CHX_WAVE) {
-      const int t = t0 + lane;
-      const uint32_t j = j_n;
-      const int k = k_n;
-      const float4 xk = x_n;
-      if (t + CHX_WAVE < total) {  // next 64 candidates: in flight while this batch meets the cell's particles
-        const int tn = t + CHX_WAVE;
-        while (r < 17 && rng_o[r + 1] <= tn) ++r;
-        k_n = rng_s[r] + (tn - rng_o[r]);
-        j_n = sorted_ids[k_n];
-        x_n = xs4[k_n];
+    auto scan = [&](auto on_chip) __attribute__((always_inline)) {
+      constexpr bool ON_CHIP = decltype(on_chip)::value;
+      for (int t0 = 0; t0 < total; t0 += CHX_WAVE) {
+        const int t = t0 + lane;
+        const uint32_t j = j_n;
+        const int k = k_n;
+        const float4 xk = x_n;
+        if (t + CHX_WAVE < total) {  // next 64 candidates: in flight while this batch meets the cell's particles
+          const int tn = t + CHX_WAVE;
+          while (r < 17 && rng_o[r + 1] <= tn) ++r;
+          k_n = rng_s[r] + (tn - rng_o[r]);
+          j_n = sorted_ids[k_n];
+          x_n = xs4[k_n];
+        }
+        const bool live = t < total;
+        for (int ii = 0; ii < nh; ++ii) {
+          const float xi = rl_f(xh.x, ii), yi = rl_f(xh.y, ii), zi = rl_f(xh.z, ii);
+          const uint32_t i = (uint32_t)rl_i((int)ih, ii);
+          bool ok = false, hi = false;
+          if (live) {
+            hi = j > i;
+            float rx, ry, rz;  // x_i - x_j for row i of the half list, x_j - x_i for row j
+            bool bad;
+            displacement_oriented_fast(box, hi, xi, yi, zi, xk.x, xk.y, xk.z, rx, ry, rz, bad);
+            if (__builtin_expect(bad, 0)) displacement_oriented(box, hi, xi, yi, zi, xk.x, xk.y, xk.z, rx, ry, rz);
+            ok = (j != i) & (norm2(rx, ry, rz) <= T);
+          }
+          // (no branch on "any hit in this batch": two thirds of the (particle, batch) pairs have one, and a
+          // straight-line body lets the compiler overlap consecutive particles)
+          const unsigned long long b = __ballot(ok);
+          {
+            const int base = rl_i(cf, ii);
+            const int slot = base + lanes_below(b);
+            if (ok && slot < fcap) fl[chx_fl_addr(hb + ii, slot, n, fg)] = (uint32_t)k | (hi ? CHX_FL_HI : 0u);
+            cf = lane == ii ? base + __popcll(b) : cf;
+          }
+          const bool okh = ok && hi;
+          const unsigned long long bh = __ballot(okh);
+          {
+            const int base = rl_i(ch, ii);
+            const int slot = base + lanes_below(bh);
+            if (ON_CHIP) {
+              if (okh && slot < CHX_LDS_ROW_WORDS) cand[ii * CHX_LDS_ROW_WORDS + slot] = j;
+            } else {
+              if (okh && slot < m) nl[(size_t)i * m + slot] = j;  // unsorted; sorted in place below
+            }
+            ch = lane == ii ? base + __popcll(bh) : ch;
+          }
+        }
       }
-      const bool live = t < total;
-      for (int ii = 0; ii < nh; ++ii) {
-        const float xi = rl_f(xh.x, ii), yi = rl_f(xh.y, ii), zi = rl_f(xh.z, ii);
-        const uint32_t i = (uint32_t)rl_i((int)ih, ii);
-        bool ok = false, hi = false;
-        if (live) {
-          hi = j > i;
-          float rx, ry, rz;  // x_i - x_j for row i of the half list, x_j - x_i for row j
-          bool bad;
-          displacement_oriented_fast(box, hi, xi, yi, zi, xk.x, xk.y, xk.z, rx, ry, rz, bad);
-          if (__builtin_expect(bad, 0)) displacement_oriented(box, hi, xi, yi, zi, xk.x, xk.y, xk.z, rx, ry, rz);
-          ok = (j != i) & (norm2(rx, ry, rz) <= T);
-        }
-        // (no branch on "any hit in this batch": two thirds of the (particle, batch) pairs have one, and a
-        // straight-line body lets the compiler overlap consecutive particles)
-        const unsigned long long b = __ballot(ok);
-        {
-          const int base = rl_i(cf, ii);
-          const int slot = base + lanes_below(b);
-          if (ok && slot < fcap) fl[chx_fl_addr(hb + ii, slot, n, fg)] = (uint32_t)k | (hi ? CHX_FL_HI : 0u);
-          cf = lane == ii ? base + __popcll(b) : cf;
-        }
-        const bool okh = ok && hi;
-        const unsigned long long bh = __ballot(okh);
-        {
-          const int base = rl_i(ch, ii);
-          const int slot = base + lanes_below(bh);
-          if (okh && slot < m) nl[(size_t)i * m + slot] = j;  // unsorted; sorted in place below
-          ch = lane == ii ? base + __popcll(bh) : ch;
-        }
-      }
-    }
+    };
+    if (lds_rows) scan(std::true_type{});
+    else scan(std::false_type{});
     // the half-row entries written above are read back below by other lanes of this wavefront: same CU, same
     // (write-through) L1, so a workgroup-scope fence is all it takes.  (A device-scope fence here writes back the
     // XCD's whole L2 once per cell: measured 3x slower than the per-particle kernel.)
     __threadfence_block();
+    unsigned long long redo = 0;  // rows the general routine has to rebuild (it uses this wave's whole LDS slice)
     for (int ii = 0; ii < nh; ++ii) {
       const int count_f = rl_i(cf, ii), count_h = rl_i(ch, ii);
       const int w = hb + ii;
@@ -318,12 +337,32 @@ __global__ __launch_bounds__(256) void k_nl_build_cellwise_fl(
         end = end < fcap ? end : fcap;
         for (int sl = used + lane; sl < end; sl += CHX_WAVE) fl[chx_fl_addr(w, sl, n, fg)] = (uint32_t)w;
       }
-      if (count_h > m || count_h > CHX_ROW_SORT_CAP) {
-        // too long to sort in place (and rows beyond m entries were not stored completely): the general path
-        // rebuilds this half row from scratch (it writes n_nbr, first_out and the status flags itself)
-        build_row_of_particle<false>(w, cand, xs4, n, m, box, T, g, cell_start, sorted_ids, nl, first_out, n_nbr, fg, fcap,
-                                     fl, deg, status);
-        // (cell_ranges inside rewrote the same values into the tail of cand)
+      if (lane == 0) {
+        deg[w] = count_f < fcap ? count_f : fcap;
+        if (count_f > fcap) {
+          atomicAdd(&status[4], 1);
+          atomicMax(&status[3], count_f);
+        }
+      }
+      if (count_h > m || count_h > (lds_rows ? CHX_LDS_ROW_WORDS : CHX_ROW_SORT_CAP)) {
+        redo |= 1ull << ii;  // too long to sort this way (and not stored completely)
+      } else if (lds_rows) {
+        uint32_t* nl_row = nl + (size_t)i * m;
+        const uint32_t* row = cand + ii * CHX_LDS_ROW_WORDS;
+        const uint32_t v = lane < count_h ? row[lane] : 0xFFFFFFFFu;
+        int rank = 0;
+        for (int u = 0; u < count_h; ++u) rank += row[u] < v ? 1 : 0;
+        if (lane < count_h) nl_row[rank] = v;
+        uint32_t mn = v;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const uint32_t other = __shfl_xor(mn, o, CHX_WAVE);
+          mn = other < mn ? other : mn;
+        }
+        if (lane == 0) {
+          n_nbr[i] = count_h;
+          first_out[i] = mn;
+        }
       } else {
         uint32_t* nl_row = nl + (size_t)i * m;
         uint32_t v[CHX_ROW_SORT_CAP / CHX_WAVE];
@@ -358,13 +397,14 @@ __global__ __launch_bounds__(256) void k_nl_build_cellwise_fl(
         }
         __threadfence_block();  // (cand is reused for the next row)
       }
-      if (lane == 0) {
-        deg[w] = count_f < fcap ? count_f : fcap;
-        if (count_f > fcap) {
-          atomicAdd(&status[4], 1);
-          atomicMax(&status[3], count_f);
-        }
-      }
+    }
+    while (redo) {
+      // the general path rebuilds these half rows from scratch (it writes n_nbr, first_out and the status flags itself;
+      // cell_ranges inside rewrites the same values into the tail of cand)
+      const int ii = __builtin_ctzll(redo);
+      redo &= redo - 1;
+      build_row_of_particle<false>(hb + ii, cand, xs4, n, m, box, T, g, cell_start, sorted_ids, nl, first_out, n_nbr, fg, fcap,
+                                   fl, deg, status);
     }
   }
 }

@@ -11,9 +11,14 @@ out = {}
 # (particles, reduced density, skin, initial n_max_neighbors): dilute and dense cells, a tiny initial capacity
 # (rows longer than n_max_neighbors: the growth loop and the cell-wise kernel's long-row path), a box of 3 cells per axis
 for tag, (n, rho, skin, m0) in {"dilute": (4000, 0.1, 0.5, 180), "dense": (6000, 0.8, 0.3, 180), "grow": (3000, 0.6, 0.4, 12),
-                                "three_cells": (700, 0.5, 0.1, 60)}.items():
+                                "three_cells": (700, 0.5, 0.1, 60),
+                                # ~15 particles per cell: passes on either side of the cell-wise kernel's on-chip-row limit,
+                                # and half rows of the lowest ids longer than an on-chip row
+                                "mixed": (5000, 0.15, 0.5, 180)}.items():
     x, box = O.lj_lattice(n, rho, 0.34, seed=17)
     x = (x + np.random.default_rng(3).normal(scale=0.03, size=x.shape)).astype(np.float32)
+    if tag == "mixed":  # uniformly random instead of a jittered lattice: cell occupancies scatter like a Poisson variable
+        x = (np.random.default_rng(4).uniform(size=x.shape) * np.diag(box)).astype(np.float32)
     nbr = neighbors.NeighborListCell(neighbors.OrthogonalPeriodicSpace(), cutoff=1.02 * u.nanometer, skin=skin * u.nanometer,
                                         n_max_neighbors=m0)
     xt = torch.tensor(x, device="cuda")
