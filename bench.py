@@ -209,7 +209,7 @@ def time_kernels(fluid, pot, state, nbr, integ, reps: int, spin_s: float = 1.0):
     """HIP-event timing (on the launch stream) of the two hot kernels on the current list:
     k_lj_step (fused pair force + BAOAB, what the timed region launches once per step) and
     k_lj_fl (the pair-force kernel alone, what compute_force() launches).
-    Returns (t_step_s, t_force_s, P_nl, force_list)."""
+    Returns (t_step_s, t_force_s, P_nl, force_list); the samples behind the two times ride on force_list.timing_samples_us."""
     import ctypes as C
 
     import torch
@@ -242,11 +242,14 @@ def time_kernels(fluid, pot, state, nbr, integ, reps: int, spin_s: float = 1.0):
             torch.cuda.synchronize()
 
     def timed(fn, count):
-        """Median of three event-timed repetitions (a single ~1 ms sample can sit in a momentary clock dip)."""
+        """Fastest of seven event-timed repetitions of `count` launches each, and all seven.  Everything that disturbs a
+        sample only ever ADDS to it -- a momentary clock dip, and above all the host: some processes launch in bursts
+        slower than this kernel runs (the runtime's lock collisions), the queue runs dry and the
+        events then time the host.  The figure wanted here is the kernel's."""
         for _ in range(10):
             fn()
         samples = []
-        for _ in range(3):
+        for _ in range(7):
             torch.cuda.synchronize()
             start = torch.cuda.Event(enable_timing=True)
             stop = torch.cuda.Event(enable_timing=True)
@@ -256,10 +259,10 @@ def time_kernels(fluid, pot, state, nbr, integ, reps: int, spin_s: float = 1.0):
             stop.record()
             torch.cuda.synchronize()
             samples.append(start.elapsed_time(stop) * 1e-3 / count)
-        return sorted(samples)[1]
+        return min(samples), [round(1e6 * v, 3) for v in samples]
 
     spin(spin_s)
-    t_force = timed(force_launch, reps)
+    t_force, force_samples = timed(force_launch, reps)
 
     # the fused step kernel on the same state; a huge skin keeps the check from ever firing so that
     # every launch does the full work (the comparison itself still runs)
@@ -282,8 +285,12 @@ def time_kernels(fluid, pot, state, nbr, integ, reps: int, spin_s: float = 1.0):
     spin(0.5 * spin_s)
     # (20 chunks = 640 launches per sample at the default --kernel-reps: long enough that filling and draining the
     # launch queue does not show, short enough that the list -- never rebuilt here -- does not age)
-    t_step = timed(one_chunk, max(2, reps // 10)) / per_call
+    t_step, step_samples = timed(one_chunk, max(2, reps // 10))
+    t_step /= per_call
     p_nl = int(torch.minimum(nbr.n_neighbors, torch.tensor(nbr.n_max_neighbors, device=x4.device)).sum().item())
+    fl.timing_samples_us = {"step": [round(v / per_call, 3) for v in step_samples], "force": force_samples,
+                            "statistic": "fastest of 7 event-timed samples (per-launch averages over "
+                                         f"{max(2, reps // 10) * per_call} step / {reps} force launches each)"}
     return t_step, t_force, p_nl, fl
 
 
@@ -619,8 +626,9 @@ def main():
         t_step, t_force, p_nl, fl = time_kernels(fluid, pot, state, nbr, integ, args.kernel_reps)
         sclk["after_kernel_timing"] = read_sclk_mhz(local_rank)
         info = {"lanes_per_particle": fl.g, "max_degree": fl.maxdeg}
-        roof = roofline_entry("step", n, p_nl, t_step, info)
-        roof_force = roofline_entry("force", n, p_nl, t_force, info)
+        ts_ = getattr(fl, "timing_samples_us", None) or {}
+        roof = roofline_entry("step", n, p_nl, t_step, dict(info, kernel_us_samples=ts_.get("step"), statistic=ts_.get("statistic")))
+        roof_force = roofline_entry("force", n, p_nl, t_force, dict(info, kernel_us_samples=ts_.get("force"), statistic=ts_.get("statistic")))
         out = {
             "metric": METRIC,
             "value": round(value, 2),
@@ -675,8 +683,9 @@ def main():
                 nbr4.build_from_state(state4)
                 ts4, tf4, p4, fl4 = time_kernels(fluid4, pot4, state4, nbr4, integ4, args.kernel_reps)
                 info4 = {"lanes_per_particle": fl4.g, "max_degree": fl4.maxdeg}
-                out["roofline_262k"] = roofline_entry("force", fluid4.n_particles, p4, tf4, info4)
-                out["roofline_262k_step"] = roofline_entry("step", fluid4.n_particles, p4, ts4, info4)
+                ts4_ = getattr(fl4, "timing_samples_us", None) or {}
+                out["roofline_262k"] = roofline_entry("force", fluid4.n_particles, p4, tf4, dict(info4, kernel_us_samples=ts4_.get("force")))
+                out["roofline_262k_step"] = roofline_entry("step", fluid4.n_particles, p4, ts4, dict(info4, kernel_us_samples=ts4_.get("step")))
                 # (past the lattice start: the fluid clusters over the first picoseconds and the lists grow)
                 state4, nbr4 = integ4.run(state4, thermo4, number_of_steps=1000, nbr_list=nbr4)  # warm-up
                 torch.cuda.synchronize()
