@@ -241,7 +241,7 @@ def time_kernels(fluid, pot, state, nbr, integ, reps: int, spin_s: float = 1.0):
                 force_launch()
             torch.cuda.synchronize()
 
-    def timed(fn, count):
+    def timed(fn, count, before_each=None):
         """Fastest of seven event-timed repetitions of `count` launches each, and all seven.  Everything that disturbs a
         sample only ever ADDS to it -- a momentary clock dip, and above all the host: some processes launch in bursts
         slower than this kernel runs (the runtime's lock collisions), the queue runs dry and the
@@ -250,6 +250,8 @@ def time_kernels(fluid, pot, state, nbr, integ, reps: int, spin_s: float = 1.0):
             fn()
         samples = []
         for _ in range(7):
+            if before_each is not None:
+                before_each()
             torch.cuda.synchronize()
             start = torch.cuda.Event(enable_timing=True)
             stop = torch.cuda.Event(enable_timing=True)
@@ -282,10 +284,21 @@ def time_kernels(fluid, pot, state, nbr, integ, reps: int, spin_s: float = 1.0):
         ops.langevin_fused_chunk(st.params, even, odd, step[0], per_call, 2, 1)
         step[0] += per_call
 
+    def fresh_state():
+        # every sample starts from the state the list was built from: with its skin check off the list is never
+        # rebuilt, and a pruned list made from an ever staler full list grows short and fast (N = 262 144: 12.9 us
+        # in the first 640 launches, 10.9 in the seventh).  Two chunks put the first refresh of the inner list and
+        # the filling of the launch queue in front of the timed launches.
+        st._load(state.positions, v, 0)
+        st.params.skin = 1.0e6
+        step[0] = 0
+        one_chunk()
+        one_chunk()
+
     spin(0.5 * spin_s)
     # (20 chunks = 640 launches per sample at the default --kernel-reps: long enough that filling and draining the
-    # launch queue does not show, short enough that the list -- never rebuilt here -- does not age)
-    t_step, step_samples = timed(one_chunk, max(2, reps // 10))
+    # launch queue does not show, short enough that the list does not age)
+    t_step, step_samples = timed(one_chunk, max(2, reps // 10), before_each=fresh_state)
     t_step /= per_call
     p_nl = int(torch.minimum(nbr.n_neighbors, torch.tensor(nbr.n_max_neighbors, device=x4.device)).sum().item())
     fl.timing_samples_us = {"step": [round(v / per_call, 3) for v in step_samples], "force": force_samples,
