@@ -481,6 +481,11 @@ def main():
         return dry_run(args, rank, world)
     import torch
 
+    # a few neighbouring CPUs for this process and the HIP runtime threads it is about to get (before the first GPU
+    # call): chiron_amd._device.pin_process_cpus has the why; CHX_PIN_CPUS=0 turns it off
+    from chiron_amd._device import pin_process_cpus
+
+    pinned_cpus = pin_process_cpus()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs the MI355X: no CUDA/ROCm device visible (there is no CPU fallback)")
     if args.share_gpu:
@@ -671,6 +676,7 @@ def main():
                 "per_rank_steps_per_s": [round(args.steps / t, 2) for t in per_rank],
                 "chunk_steps": args.chunk,
                 "launch_window": integ.launch_window,
+                "pinned_cpus": pinned_cpus,
                 "clock_warmup_s": round(clock_warm_s, 2),
                 "sclk_mhz": sclk,
                 "list_rebuilds_in_timed_region": rebuilds,

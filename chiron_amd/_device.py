@@ -27,6 +27,40 @@ _NP_DTYPE = {
 }
 
 
+def pin_process_cpus(width: int = 4):
+    """Restrict this process -- and every thread created from here on, the HIP runtime's helpers included -- to
+    ``width`` neighbouring CPUs around the one it is running on.  Call it before the first GPU call.
+
+    Why: the Langevin loop issues one kernel launch every ~5 us from one thread, and the HIP runtime's launch path
+    shares a lock with one of its helper threads.  On a many-core host (256 hardware threads on the MI355X boxes)
+    the scheduler is free to put the two on far-apart cores, and one process in three then launches in a slower
+    regime (thousands of futex waits per 100 000 launches, 3-12 % fewer steps per second).  A
+    bare HIP launch loop pinned to two CPUs was fast in 8 processes of 8, unpinned in 4 of 8
+    (``scripts/ub/env_sweep2.sh``).  ``CHX_PIN_CPUS=0`` turns it off, ``CHX_PIN_CPUS=<n>`` sets the width.
+    Returns the CPU list now in force (None if nothing was changed)."""
+    import os
+
+    req = os.environ.get("CHX_PIN_CPUS", "")
+    if req == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    if req.isdigit():
+        width = int(req)
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) <= width:
+        return None
+    try:
+        here = os.sched_getcpu() if hasattr(os, "sched_getcpu") else allowed[0]
+    except OSError:  # pragma: no cover
+        here = allowed[0]
+    at = allowed.index(here) if here in allowed else 0
+    at -= at % width
+    cpus = allowed[at:at + width]
+    if len(cpus) < width:
+        cpus = allowed[-width:]
+    os.sched_setaffinity(0, cpus)
+    return cpus
+
+
 def default_device() -> torch.device:
     """``cuda`` (ROCm) when a GPU is visible, else ``cpu`` (host logic/tests only)."""
     if _FORCED_DEVICE is not None:

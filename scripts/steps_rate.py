@@ -4,6 +4,8 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 torch.set_num_threads(1)
+from chiron_amd._device import pin_process_cpus
+print("cpus:", pin_process_cpus(), file=sys.stderr)
 import bench
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3"

@@ -572,3 +572,42 @@ def test_no_kernel_reads_the_dispatch_packet(tmp_path):
             assert sizes, "no k_lj_step instantiation found"
             for g, lds in sizes.items():
                 assert lds == {3 * (256 // g) * 4}, (g, lds)  # sF[3 * PPB] floats and nothing else
+
+
+def test_pin_process_cpus_picks_a_neighbourhood_and_can_be_switched_off():
+    """``pin_process_cpus``: an aligned group of neighbouring CPUs around the current one, all
+    of them allowed before; CHX_PIN_CPUS=0 leaves the affinity alone, CHX_PIN_CPUS=<n> sets the width.  Run in child
+    processes: the affinity of the test runner itself must not change."""
+    import os
+    import subprocess
+    import sys
+
+    if not hasattr(os, "sched_setaffinity") or len(os.sched_getaffinity(0)) < 4:
+        pytest.skip("needs sched_setaffinity and at least four CPUs")
+    code = ("import os, json; before = sorted(os.sched_getaffinity(0)); "
+            "from chiron_amd._device import pin_process_cpus; got = pin_process_cpus(); "
+            "print(json.dumps([before, got, sorted(os.sched_getaffinity(0))]))")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def child(env_value):
+        env = dict(os.environ, PYTHONPATH=root)
+        env.pop("CHX_PIN_CPUS", None)
+        if env_value is not None:
+            env["CHX_PIN_CPUS"] = env_value
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        import json
+
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    before, got, after = child(None)
+    if len(before) > 4:
+        assert got == after and len(got) == 4 and set(got) <= set(before)
+        at = before.index(got[0])
+        assert at % 4 == 0 and got == before[at:at + 4]
+    else:
+        assert got is None and after == before
+    before, got, after = child("0")
+    assert got is None and after == before
+    before, got, after = child("2")
+    assert got == after and len(got) == 2 and set(got) <= set(before)
