@@ -27,7 +27,7 @@ _NP_DTYPE = {
 }
 
 
-def pin_process_cpus(width: int = 4):
+def pin_process_cpus(width: int = 4, slot: Optional[int] = None):
     """Restrict this process -- and every thread created from here on, the HIP runtime's helpers included -- to
     ``width`` neighbouring CPUs around the one it is running on.  Call it before the first GPU call.
 
@@ -37,6 +37,8 @@ def pin_process_cpus(width: int = 4):
     regime (thousands of futex waits per 100 000 launches, 3-12 % fewer steps per second).  A
     bare HIP launch loop pinned to two CPUs was fast in 8 processes of 8, unpinned in 4 of 8
     (``scripts/ub/env_sweep2.sh``).  ``CHX_PIN_CPUS=0`` turns it off, ``CHX_PIN_CPUS=<n>`` sets the width.
+    ``slot`` (default: ``LOCAL_RANK``, else 0) moves the group on by that many groups, so that the ranks of one node,
+    which a launcher starts from the same place, end up on different CPUs.
     Returns the CPU list now in force (None if nothing was changed)."""
     import os
 
@@ -52,11 +54,17 @@ def pin_process_cpus(width: int = 4):
         here = os.sched_getcpu() if hasattr(os, "sched_getcpu") else allowed[0]
     except OSError:  # pragma: no cover
         here = allowed[0]
-    at = allowed.index(here) if here in allowed else 0
-    at -= at % width
+    if slot is None:
+        lr = os.environ.get("LOCAL_RANK", "0")
+        slot = int(lr) if lr.isdigit() else 0
+    groups = len(allowed) // width
+    if "LOCAL_RANK" in os.environ:
+        # ranks of one node: group = local rank, whatever CPU each happens to start on (two ranks on one group
+        # of four CPUs, each with a polling launch thread, lose a quarter of their rate)
+        at = slot % groups * width
+    else:
+        at = ((allowed.index(here) if here in allowed else 0) // width + slot) % groups * width
     cpus = allowed[at:at + width]
-    if len(cpus) < width:
-        cpus = allowed[-width:]
     os.sched_setaffinity(0, cpus)
     return cpus
 

@@ -589,9 +589,12 @@ def test_pin_process_cpus_picks_a_neighbourhood_and_can_be_switched_off():
             "print(json.dumps([before, got, sorted(os.sched_getaffinity(0))]))")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-    def child(env_value):
+    def child(env_value, local_rank=None):
         env = dict(os.environ, PYTHONPATH=root)
         env.pop("CHX_PIN_CPUS", None)
+        env.pop("LOCAL_RANK", None)
+        if local_rank is not None:
+            env["LOCAL_RANK"] = str(local_rank)
         if env_value is not None:
             env["CHX_PIN_CPUS"] = env_value
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
@@ -611,3 +614,6 @@ def test_pin_process_cpus_picks_a_neighbourhood_and_can_be_switched_off():
     assert got is None and after == before
     before, got, after = child("2")
     assert got == after and len(got) == 2 and set(got) <= set(before)
+    if len(before) >= 8:  # the ranks of one node get different groups
+        g0, g1 = child(None, 0)[1], child(None, 1)[1]
+        assert len(g0) == len(g1) == 4 and not set(g0) & set(g1)
