@@ -27,6 +27,52 @@ _NP_DTYPE = {
 }
 
 
+def _parse_cpulist(text: str):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_local_cpus(device_index: int, sysfs: str = "/sys"):
+    """CPUs of the NUMA node GPU ``device_index`` hangs off, read from sysfs without touching the GPU: the KFD
+    topology lists the compute nodes this process may use in the order the runtime enumerates them (plain integer
+    lists in ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES are applied on top), each with its PCI location, and the PCI
+    device knows its ``local_cpulist``.  None when any of that is not there or not understood."""
+    import os
+
+    try:
+        base = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
+        gpus = []
+        for name in sorted((d for d in os.listdir(base) if d.isdigit()), key=int):
+            try:
+                with open(os.path.join(base, name, "properties")) as fh:
+                    props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(props)
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):
+            v = os.environ.get(var, "").strip()
+            if v:
+                idx = [t.strip() for t in v.split(",")]
+                if not all(t.isdigit() for t in idx):
+                    return None
+                gpus = [gpus[int(t)] for t in idx if int(t) < len(gpus)]
+        if not 0 <= device_index < len(gpus):
+            return None
+        loc, dom = int(gpus[device_index]["location_id"]), int(gpus[device_index].get("domain", "0"))
+        bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7:x}"
+        with open(os.path.join(sysfs, "bus/pci/devices", bdf, "local_cpulist")) as fh:
+            cpus = _parse_cpulist(fh.read())
+        return cpus or None
+    except (OSError, ValueError, KeyError, IndexError):
+        return None
+
+
 def pin_process_cpus(width: int = 4, slot: Optional[int] = None):
     """Restrict this process -- and every thread created from here on, the HIP runtime's helpers included -- to
     ``width`` neighbouring CPUs around the one it is running on.  Call it before the first GPU call.
@@ -37,8 +83,8 @@ def pin_process_cpus(width: int = 4, slot: Optional[int] = None):
     regime (thousands of futex waits per 100 000 launches, 3-12 % fewer steps per second).  A
     bare HIP launch loop pinned to two CPUs was fast in 8 processes of 8, unpinned in 4 of 8
     (``scripts/ub/env_sweep2.sh``).  ``CHX_PIN_CPUS=0`` turns it off, ``CHX_PIN_CPUS=<n>`` sets the width.
-    ``slot`` (default: ``LOCAL_RANK``, else 0) moves the group on by that many groups, so that the ranks of one node,
-    which a launcher starts from the same place, end up on different CPUs.
+    ``slot`` (default: ``LOCAL_RANK``, else 0) = the GPU this process drives: the group is taken from the CPUs of that
+    GPU's NUMA node when sysfs tells (``gpu_local_cpus``), and the ranks of one node get different groups.
     Returns the CPU list now in force (None if nothing was changed)."""
     import os
 
@@ -57,6 +103,11 @@ def pin_process_cpus(width: int = 4, slot: Optional[int] = None):
     if slot is None:
         lr = os.environ.get("LOCAL_RANK", "0")
         slot = int(lr) if lr.isdigit() else 0
+    near = gpu_local_cpus(slot)
+    if near:
+        near = sorted(set(near) & set(allowed))
+        if len(near) > width:
+            allowed = near
     groups = len(allowed) // width
     if "LOCAL_RANK" in os.environ:
         # ranks of one node: group = local rank, whatever CPU each happens to start on (two ranks on one group

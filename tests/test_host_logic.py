@@ -617,3 +617,34 @@ def test_pin_process_cpus_picks_a_neighbourhood_and_can_be_switched_off():
     if len(before) >= 8:  # the ranks of one node get different groups
         g0, g1 = child(None, 0)[1], child(None, 1)[1]
         assert len(g0) == len(g1) == 4 and not set(g0) & set(g1)
+
+
+def test_gpu_local_cpus_reads_the_numa_neighbourhood_from_sysfs(tmp_path, monkeypatch):
+    """``gpu_local_cpus`` (what ``pin_process_cpus`` chooses its CPUs from): KFD topology order of the compute nodes,
+    PCI address from location_id / domain, the device's local_cpulist; integer VISIBLE_DEVICES lists are applied,
+    anything else (UUIDs, a missing tree) gives None and the caller falls back to the CPUs it is allowed."""
+    from chiron_amd import _device as D
+
+    def mk(rel, text):
+        path = tmp_path / rel
+        path.parent.mkdir(parents=True, exist_ok=True)
+        path.write_text(text)
+
+    mk("class/kfd/kfd/topology/nodes/0/properties", "cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+    mk("class/kfd/kfd/topology/nodes/2/properties", "simd_count 1024\nlocation_id 3328\ndomain 0\n")      # 0000:0d:00.0
+    mk("class/kfd/kfd/topology/nodes/10/properties", "simd_count 1024\nlocation_id 58624\ndomain 0\n")    # 0000:e5:00.0
+    mk("bus/pci/devices/0000:0d:00.0/local_cpulist", "0-63,128-191\n")
+    mk("bus/pci/devices/0000:e5:00.0/local_cpulist", "64-127,192-255\n")
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    root = str(tmp_path)
+    assert D.gpu_local_cpus(0, root) == list(range(0, 64)) + list(range(128, 192))
+    assert D.gpu_local_cpus(1, root) == list(range(64, 128)) + list(range(192, 256))  # node 10 sorts after node 2
+    assert D.gpu_local_cpus(2, root) is None
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1")
+    assert D.gpu_local_cpus(0, root)[0] == 64
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "GPU-0123abcd")
+    assert D.gpu_local_cpus(0, root) is None
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    assert D.gpu_local_cpus(0, str(tmp_path / "nowhere")) is None
+    assert D._parse_cpulist("3,5-7\n") == [3, 5, 6, 7]
