@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 from chiron_amd import unit
+from chiron_amd._device import pin_process_cpus
 from chiron_amd.mcmc import MCMCSampler, MonteCarloBarostatMove, MonteCarloDisplacementMove, MoveSchedule
 from chiron_amd.neighbors import OrthogonalPeriodicSpace, PairListNsqrd
 from chiron_amd.potential import IdealGasPotential
@@ -18,6 +19,8 @@ from chiron_amd.reporters import MCReporter
 from chiron_amd.states import SamplerState, ThermodynamicState
 from chiron_amd.testsystems import IdealGas
 from chiron_amd.utils import PRNG
+
+pin_process_cpus()  # a few CPUs near the GPU for this process and the HIP runtime's threads
 
 iterations = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 gas = IdealGas(nparticles=216, temperature=298 * unit.kelvin, pressure=1 * unit.atmosphere)

@@ -11,6 +11,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import torch
 
+from chiron_amd._device import pin_process_cpus
+
+pin_process_cpus()  # a few CPUs near the GPU for this process and the HIP runtime's threads
+
 from chiron_amd import unit
 from chiron_amd.integrators import LangevinIntegrator
 from chiron_amd.neighbors import NeighborListNsqrd, OrthogonalPeriodicSpace

@@ -12,6 +12,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 from chiron_amd import unit
+from chiron_amd._device import pin_process_cpus
 from chiron_amd.mcmc import (LangevinDynamicsMove, MCMCSampler, MonteCarloBarostatMove,
                              MonteCarloDisplacementMove, MoveSchedule)
 from chiron_amd.neighbors import NeighborListNsqrd, OrthogonalPeriodicSpace
@@ -20,6 +21,8 @@ from chiron_amd.reporters import LangevinDynamicsReporter, MCReporter
 from chiron_amd.states import SamplerState, ThermodynamicState
 from chiron_amd.topology import Element, Topology
 from chiron_amd.utils import PRNG
+
+pin_process_cpus()  # a few CPUs near the GPU for this process and the HIP runtime's threads
 
 iterations = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 n_particles = 1100
