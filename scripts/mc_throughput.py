@@ -3,6 +3,8 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 torch.set_num_threads(1)
+from chiron_amd._device import pin_process_cpus
+print('cpus:', pin_process_cpus(), file=sys.stderr)  # CHX_PIN_CPUS=0: unpinned
 import bench
 from chiron_amd import unit as u, mcmc
 
