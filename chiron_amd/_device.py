@@ -116,7 +116,10 @@ def pin_process_cpus(width: int = 4, slot: Optional[int] = None):
     else:
         at = ((allowed.index(here) if here in allowed else 0) // width + slot) % groups * width
     cpus = allowed[at:at + width]
-    os.sched_setaffinity(0, cpus)  # (the calling thread; threads it creates from now on inherit)
+    try:
+        os.sched_setaffinity(0, cpus)  # (the calling thread; threads it creates from now on inherit)
+    except OSError:  # a sandbox that does not allow it: run unpinned
+        return None
     try:  # threads that exist already (an imported library's pools): idle, but keep the process in one place
         for tid in os.listdir("/proc/self/task"):
             try:
