@@ -485,6 +485,7 @@ def main():
     # call): chiron_amd._device.pin_process_cpus has the why; CHX_PIN_CPUS=0 turns it off
     from chiron_amd._device import pin_process_cpus
 
+    all_cpus = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None  # (the CPU baseline gets them back)
     pinned_cpus = pin_process_cpus()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs the MI355X: no CUDA/ROCm device visible (there is no CPU fallback)")
@@ -717,10 +718,21 @@ def main():
             except Exception as exc:  # pragma: no cover - diagnostics only
                 out["roofline_262k"] = {"error": repr(exc)}
         if world == 1 and args.cpu_steps != 0:
+            # the CPU restatement runs on every core the process was given, not on the few the GPU loop is pinned to:
+            # its OpenMP threads are created inside this call and inherit the mask in force here
+            mask_now = os.sched_getaffinity(0) if all_cpus is not None else None
             try:
+                if all_cpus is not None and pinned_cpus:
+                    os.sched_setaffinity(0, all_cpus)
                 out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_steps)
             except Exception as exc:  # pragma: no cover
                 out["cpu_baseline"] = {"error": repr(exc)}
+            finally:
+                if mask_now is not None:
+                    try:
+                        os.sched_setaffinity(0, mask_now)
+                    except OSError:  # pragma: no cover
+                        pass
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
