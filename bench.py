@@ -37,7 +37,7 @@ WORKLOADS = {
     "c4": (262144, 0.1),
     "c3_liquid": (32768, 0.8),
     "c4_liquid": (262144, 0.8),
-    # intermediate sizes at the BASELINE density (tuning sweeps, scripts/exp_g.sh)
+    # intermediate sizes at the BASELINE density (tuning sweeps)
     "n8k": (8192, 0.1),
     "n16k": (16384, 0.1),
     "n64k": (65536, 0.1),

@@ -82,7 +82,7 @@ def pin_process_cpus(width: int = 4, slot: Optional[int] = None):
     the scheduler is free to put the two on far-apart cores, and one process in three then launches in a slower
     regime (thousands of futex waits per 100 000 launches, 3-12 % fewer steps per second).  A
     bare HIP launch loop pinned to two CPUs was fast in 8 processes of 8, unpinned in 4 of 8
-    (``scripts/ub/env_sweep2.sh``).  ``CHX_PIN_CPUS=0`` turns it off, ``CHX_PIN_CPUS=<n>`` sets the width.
+    (round-2 sweep of a bare HIP launch probe).  ``CHX_PIN_CPUS=0`` turns it off, ``CHX_PIN_CPUS=<n>`` sets the width.
     ``slot`` (default: ``LOCAL_RANK``, else 0) = the GPU this process drives: the group is taken from the CPUs of that
     GPU's NUMA node when sysfs tells (``gpu_local_cpus``), and the ranks of one node get different groups.
     Returns the CPU list now in force (None if nothing was changed)."""

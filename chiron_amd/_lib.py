@@ -157,6 +157,8 @@ SIGNATURES = {
     ),
 }
 
+ABI_VERSION = 2  # include/chx.h: CHX_ABI_VERSION (history there)
+
 _lib: Optional[C.CDLL] = None
 
 
@@ -202,20 +204,23 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.chx_version() != 1:
-        raise ChxError(f"libchx ABI version {lib.chx_version()} != 1")
+    if lib.chx_version() != ABI_VERSION:
+        raise ChxError(f"libchx ABI version {lib.chx_version()} != {ABI_VERSION} (include/chx.h: CHX_ABI_VERSION)")
     # the structs are mirrored by hand above: a layout drift would corrupt kernel arguments silently
     for name, mirror in (("chx_sizeof_langevin_t", LangevinParams), ("chx_sizeof_mc_t", McParams)):
         if getattr(lib, name)() != C.sizeof(mirror):
             raise ChxError(f"{name}() = {getattr(lib, name)()} but ctypes mirror {mirror.__name__} is {C.sizeof(mirror)} bytes")
-    # a library built from other sources than the ones beside it is refused (CHX_LIB: deliberate A/B runs)
+    # a library built from other sources than the ones beside it is refused (CHX_LIB: deliberate A/B runs).  A
+    # binary-only install -- libchx.so shipped without csrc/ -- has nothing to compare against and loads as it is;
+    # the comparison is made once per process (8 ranks: 8 x 13 small files, not 8 x every load() call).
     if not os.environ.get("CHX_LIB") and os.environ.get("CHX_ALLOW_STALE_LIB", "0") != "1":
         from . import build as _build
 
-        have, want = lib.chx_source_hash().decode(), _build.source_hash()
-        if have != want:
-            raise ChxError(f"{LIB_PATH} was built from other sources (hash {have[:16]}, tree {want[:16]}): "
-                           "run `python -c 'import __graft_entry__ as g; g.build()'`")
+        if _build.sources():
+            have, want = lib.chx_source_hash().decode(), _build.source_hash()
+            if have != want:
+                raise ChxError(f"{LIB_PATH} was built from other sources (hash {have[:16]}, tree {want[:16]}): "
+                               "run `python -c 'import __graft_entry__ as g; g.build()'`")
     _lib = lib
     return lib
 

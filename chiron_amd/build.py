@@ -67,16 +67,56 @@ def needs_build() -> bool:
     return binary_hash() != source_hash()
 
 
+def _object_key(src: str, flags) -> str:
+    """Cache key of one translation unit: its own text, every header (any of them may be included) and the flags."""
+    h = hashlib.sha256()
+    for path in [src] + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(HERE, "..", "include", "*.h"))):
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    h.update(" ".join(flags).encode())
+    return h.hexdigest()[:24]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Translation units are compiled in parallel into ``_obj/`` (kept out of git and off the GPU box), each keyed by
+    the hash of its text + headers + flags, so an edit recompiles one file; the link step bakes the tree's hash in
+    through a one-line stamp unit."""
     if not force and not needs_build():
         if verbose:
             print(f"libchx.so is current (source hash {source_hash()[:16]})")
         return OUT
+    from concurrent.futures import ThreadPoolExecutor
+
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    objdir = os.path.join(HERE, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in FLAGS if f != "-shared"]
+    tree = source_hash()
+
+    def compile_one(src):
+        # (the hash string is compiled into chx_core.hip only: every other unit is independent of the tree's hash)
+        extra = [f'-DCHX_SOURCE_HASH="{tree}"'] if os.path.basename(src) == "chx_core.hip" else []
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + "." + _object_key(src, cflags + extra) + ".o")
+        if force or not os.path.exists(obj):
+            cmd = [hipcc] + cflags + extra + ["-c", src, "-o", obj + ".tmp"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+            os.replace(obj + ".tmp", obj)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, sources()))
+    for stale in set(glob.glob(os.path.join(objdir, "*.o"))) - set(objs):
+        os.remove(stale)
     tmp = OUT + ".tmp"
-    cmd = [hipcc] + FLAGS + [f'-DCHX_SOURCE_HASH="{source_hash()}"'] + sources() + ["-o", tmp]
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", tmp]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
     os.replace(tmp, OUT)  # never truncate a library some process may have mapped
+    if binary_hash(OUT) != tree:
+        raise RuntimeError("libchx.so does not carry the hash of the tree it was built from")
     return OUT

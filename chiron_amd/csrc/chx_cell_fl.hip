@@ -118,17 +118,12 @@ __device__ __forceinline__ void build_row_of_particle(
       displacement_oriented_fast(box, hi, xi, yi, zi, xk.x, xk.y, xk.z, rx, ry, rz, bad);
       if (__builtin_expect(bad, 0)) displacement_oriented(box, hi, xi, yi, zi, xk.x, xk.y, xk.z, rx, ry, rz);
       ok = (j != i) & (norm2(rx, ry, rz) <= T);
-#ifdef CHX_EXP_BUILD_NOTEST
-      ok = ok && xk.x == 12345.f;  // (timing decomposition of scripts/exp_build.sh: no hits, nothing stored)
-#endif
     }
     if (WRITE_FL) {
       const unsigned long long b = __ballot(ok);
       if (b) {
         const int slot = count_f + lanes_below(b);
-#ifndef CHX_EXP_BUILD_NOFL
         if (ok && slot < fcap) fl[chx_fl_addr(w, slot, n, fg)] = (uint32_t)k | (hi ? CHX_FL_HI : 0u);
-#endif
         count_f += __popcll(b);
       }
     }
@@ -160,14 +155,8 @@ __device__ __forceinline__ void build_row_of_particle(
     const uint32_t v = cand[t];
     mn = v < mn ? v : mn;
     int rank = 0;
-#ifdef CHX_EXP_BUILD_NOSORT
-    rank = t;
-#else
     for (int u = 0; u < kept; ++u) rank += cand[u] < v ? 1 : 0;
-#endif
-#ifndef CHX_EXP_BUILD_NONL
     if (rank < m) nl_row[rank] = v;
-#endif
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {

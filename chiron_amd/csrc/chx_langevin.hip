@@ -7,6 +7,8 @@
 // and the pair-force kernel.  The arithmetic keeps the reference's operation
 // order and one rounding per operation, so with injected noise a trajectory
 // matches the fp32 oracle up to the force summation order.
+#include <cstdlib>
+
 #include "chx_common.h"
 #include "chx_internal.h"
 
@@ -266,6 +268,25 @@ extern "C" int chx_langevin_chunk(const chx_langevin_t* p, int64_t step0, int32_
   return chx_check_launch("chx_langevin_chunk");
 }
 
+// ABI 2: the fused step kernel takes the particle's mass from ref4[p].w (chx_pack_langevin puts it there).  A ref4
+// produced any other way (chx_permute_pack pads with 0) would give m = 0 and inf / NaN velocities without any error;
+// with CHX_DEBUG_SYNC set the entry points look at the first row before they launch.
+static int debug_check_ref4(const chx_langevin_t* p, hipStream_t st, const char* who) {
+  static const bool dbg = getenv("CHX_DEBUG_SYNC") != nullptr;
+  if (!dbg || !p->fl || !p->ref4) return CHX_OK;
+  float row[4] = {0.f, 0.f, 0.f, 0.f};
+  if (hipStreamSynchronize(st) != hipSuccess ||
+      hipMemcpy(row, p->ref4, sizeof(row), hipMemcpyDeviceToHost) != hipSuccess) {
+    chx_set_error("%s: cannot read ref4[0] (debug check)", who);
+    return CHX_ERR_LAUNCH;
+  }
+  if (!(row[3] > 0.0f)) {
+    chx_set_error("%s: ref4[0].w = %g is not a mass: ref4 must come from chx_pack_langevin (ABI 2)", who, (double)row[3]);
+    return CHX_ERR_INVALID;
+  }
+  return CHX_OK;
+}
+
 extern "C" int chx_langevin_fused_chunk(const chx_langevin_t* p, float* x_even, float* x_odd,
                                         int64_t step0, int32_t n_steps, int32_t kicks_first,
                                         int32_t do_aoa, chx_stream_t stream) {
@@ -280,7 +301,9 @@ extern "C" int chx_langevin_fused_chunk(const chx_langevin_t* p, float* x_even, 
   CHX_REQUIRE(kicks_first >= 0 && kicks_first <= 2, "kicks_first must be 0, 1 or 2");
   CHX_REQUIRE(step0 >= 0 && step0 + n_steps < (1ll << 31) - 1, "step index out of range");
   CHX_REQUIRE(do_aoa || n_steps <= 1, "force-only mode takes a single launch");
-  int rc = chx_launch_lj_steps(p, x_even, x_odd, step0, n_steps, kicks_first, do_aoa,
+  int rc = debug_check_ref4(p, chx_stream(stream), "chx_langevin_fused_chunk");
+  if (rc != CHX_OK) return rc;
+  rc = chx_launch_lj_steps(p, x_even, x_odd, step0, n_steps, kicks_first, do_aoa,
                                chx_stream(stream));
   if (rc != CHX_OK) return rc;
   return chx_check_launch("chx_langevin_fused_chunk");
@@ -302,7 +325,9 @@ extern "C" int chx_langevin_fused_run(const chx_langevin_t* p, float* x_even, fl
   CHX_REQUIRE(n_steps >= 0, "n_steps < 0");
   CHX_REQUIRE(kicks_first >= 0 && kicks_first <= 2, "kicks_first must be 0, 1 or 2");
   CHX_REQUIRE(step0 >= 0 && step0 + n_steps < (1ll << 31) - 1, "step index out of range");
-  int rc = chx_launch_lj_steps(p, x_even, x_odd, step0, n_steps, kicks_first, 1, chx_stream(stream), window,
+  int rc = debug_check_ref4(p, chx_stream(stream), "chx_langevin_fused_run");
+  if (rc != CHX_OK) return rc;
+  rc = chx_launch_lj_steps(p, x_even, x_odd, step0, n_steps, kicks_first, 1, chx_stream(stream), window,
                                n_enqueued_out);
   if (rc != CHX_OK) return rc;
   return chx_check_launch("chx_langevin_fused_run");

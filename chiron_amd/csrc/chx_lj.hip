@@ -11,6 +11,8 @@
 // bit-identical to the reference's; only the summation order differs.
 #include <cstdio>
 #include <cstdlib>
+#include <sched.h>
+#include <sys/prctl.h>
 #include <time.h>
 
 #include "chx_common.h"
@@ -196,12 +198,8 @@ struct LJParams {
 // then caches one spatial slab of positions instead of all of them.  Bijective for any grid size;
 // placement is a speed matter only.
 __device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nb) {
-#ifdef CHX_NO_XCD_REMAP
-  return b;
-#else
   const unsigned q = nb / 8u, r = nb % 8u, x = b % 8u, i = b / 8u;
   return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + i;
-#endif
 }
 
 #define CHX_FL_INVALID 0xFFFFFFFFu
@@ -248,7 +246,7 @@ __device__ __forceinline__ f2 pk_yy(f2 a, f2 b) {
 //   LJ_SHIFT  periodic: min_image2_t (the three candidates), |d| < L checked per pair.
 // (A third form for particles far from every box face -- t = d + L/2 lies in [0, L), so
 // r = t - L/2 with a range check on t -- saves a quarter of the arithmetic and was measured to
-// change nothing: at N = 262144 the kernel waits on the L1's gather rate, scripts/exp_gather.sh.)
+// change nothing: at N = 262144 the kernel waits on the L1's gather rate)
 #define LJ_OPEN 0
 #define LJ_SHIFT 2
 
@@ -335,9 +333,6 @@ __device__ __forceinline__ void lj_row_loop(const float4* __restrict__ x4, const
     uint4 nx = make_uint4(0u, 0u, 0u, 0u);
     if (c + 1 < nc) nx = col[(size_t)(c + 1) * stride];
     bool kp[4] = {false, false, false, false};
-#ifdef CHX_EXP_NO_MATH
-    if (k0 < d) { A.ax += (f2){xj[0].x + xj[1].y, xj[2].z + xj[3].x}; }
-#else
     if (k0 < d) {
       lj_pair2<MODE, PRUNE>(xi, (f2){xj[0].x, xj[0].y}, (f2){xj[0].z, xj[0].w}, (f2){xj[1].x, xj[1].y},
                             (f2){xj[1].z, xj[1].w}, e4.x, e4.y, k0 + G < d, box, lj, po.T_inner, A);
@@ -348,7 +343,6 @@ __device__ __forceinline__ void lj_row_loop(const float4* __restrict__ x4, const
                             (f2){xj[3].z, xj[3].w}, e4.z, e4.w, k0 + 3 * G < d, box, lj, po.T_inner, A);
       if (PRUNE) kp[2] = A.keep0, kp[3] = A.keep1;
     }
-#endif
     if (PRUNE) {
       // (all G lanes of a row run the same number of chunks, so the shuffles below are group-uniform)
       // kept entries go out in ROW order: word u of lanes 0..G-1, then word u + 1 (the chunk's interleaving)
@@ -368,14 +362,10 @@ __device__ __forceinline__ void lj_row_loop(const float4* __restrict__ x4, const
     }
     if (c + 1 < nc) {
       e4 = nx;
-#ifdef CHX_EXP_NO_GATHER
-      xj[0].x += 0.01f; xj[1].y += 0.01f; xj[2].z += 0.01f; xj[3].x += 0.01f;
-#else
       xj[0] = x4[e4.x & ~CHX_FL_HI];
       xj[1] = x4[e4.y & ~CHX_FL_HI];
       xj[2] = x4[e4.z & ~CHX_FL_HI];
       xj[3] = x4[e4.w & ~CHX_FL_HI];
-#endif
     }
   } while (++c < nc);
   kept = base;
@@ -424,11 +414,6 @@ __device__ __forceinline__ float dpp_f(float v, const int ctrl_sel) {
 }
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
-#ifdef CHX_EXP_SHFL_REDUCE
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, CHX_WAVE);
-  return v;
-#else
   if (G >= 2) v += dpp_f(v, 0);
   if (G >= 4) v += dpp_f(v, 1);   // every lane of a quad now holds the quad's sum
   if (G >= 8) v += dpp_f(v, 2);   // ... of a half row
@@ -436,31 +421,22 @@ __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
   for (int o = 16; o < G; o <<= 1) v += __shfl_xor(v, o, CHX_WAVE);
   return v;
-#endif
 }
 
 // write-through stores (see step_epilogue)
 typedef float f3v __attribute__((ext_vector_type(3)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_wt4(float4* p, float4 v) {
-#ifdef CHX_EXP_PLAIN_STORES
-  *p = v;
-#else
   const f4v t = {v.x, v.y, v.z, v.w};
   // (s_nop: a VMEM store of more than 64 bits reads its data registers a cycle or two after it issues; the
   // compiler pads that hazard for its own stores but cannot see one inside an asm statement, and -- in an
   // experimental variant of the integrate tail -- was caught recycling the first data register for the next
   // value: velocities came out holding path lengths)
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
-#endif
 }
 __device__ __forceinline__ void store_wt3(float* p, float a, float b, float c) {
-#ifdef CHX_EXP_PLAIN_STORES
-  p[0] = a, p[1] = b, p[2] = c;
-#else
   const f3v t = {a, b, c};
   asm volatile("global_store_dwordx3 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
-#endif
 }
 
 // what row_begin has in flight for one lane
@@ -794,15 +770,7 @@ template <bool HOT>
 __device__ __forceinline__ bool step_epilogue(const StepArgs& a, const StepParticle& tk, const float* sF, long long step,
                                               int n_kicks, int do_aoa) {
   bool stale = false;
-#ifdef CHX_EXP_NOEPI
-  if (tk.live) {  // positions pass through (wrapped input stays wrapped), every operand is consumed
-    reinterpret_cast<float4*>(a.x_next)[tk.pp] = make_float4(
-        tk.x.x, tk.x.y, tk.x.z, sF[3 * threadIdx.x] + tk.z[0] + tk.v[0] + tk.m + tk.bs + tk.ref.x + tk.path0);
-  }
-  if (false) {
-#else
   if (tk.live) {
-#endif
     // (three explicit calls on scalars: local arrays of box lengths here ended up as a per-thread array in LDS)
     float vn0, vn1, vn2, xn0, xn1, xn2, sq0, sq1, sq2, si0, si1, si2;
     const float F0 = sF[3 * threadIdx.x], F1 = sF[3 * threadIdx.x + 1], F2 = sF[3 * threadIdx.x + 2];
@@ -841,35 +809,6 @@ __device__ __forceinline__ bool step_epilogue(const StepArgs& a, const StepParti
   return stale;
 }
 
-#ifdef CHX_EXP_STAMPS
-// Diagnostic build only (scripts/exp_stamps.sh): wave 0 of every block records where its time goes.
-// g_stamps[slot][block][0..7]: s_memtime at entry / first row loads back / first gathers back / force loop done /
-// after the barrier / end, then s_memrealtime (100 MHz) at entry and at the end.  slot = step & 3.
-#define CHX_STAMP_BLOCKS 4096
-__device__ unsigned long long g_stamps[4][CHX_STAMP_BLOCKS][8];
-__device__ __forceinline__ unsigned long long stamp_clk() {
-  unsigned long long t;
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  __builtin_amdgcn_sched_barrier(0);
-  return t;
-}
-__device__ __forceinline__ unsigned long long stamp_rt() {
-  unsigned long long t;
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  __builtin_amdgcn_sched_barrier(0);
-  return t;
-}
-extern "C" int chx_debug_read_stamps(unsigned long long* out_h) {
-  return hipMemcpyFromSymbol(out_h, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : -1;
-}
-#define CHX_STAMP(i, v) do { if (threadIdx.x == 0 && blk < CHX_STAMP_BLOCKS) g_stamps[step & 3][blk][i] = (v); } while (0)
-#define CHX_STAMP_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#else
-#define CHX_STAMP(i, v) do { } while (0)
-#define CHX_STAMP_WAIT() do { } while (0)
-#endif
 
 // PRUNE: the launch that refreshes the dynamically pruned inner list (see below): it walks the FULL
 // force list and, next to the forces, copies the entries with |r| < cutoff + inner_skin into the
@@ -890,10 +829,6 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   // n_lead == a.n and x_lead == a.x_cur; code that runs before the argument block has arrived uses the leading copies.
   constexpr int PPB = 256 / G;  // particles per block (<= 256)
   const unsigned blk = xcd_block(blockIdx.x, nblocks);
-#ifdef CHX_EXP_STAMPS
-  CHX_STAMP(6, stamp_rt());
-  CHX_STAMP(0, stamp_clk());
-#endif
   const int tid = blk * 256 + threadIdx.x;
   const int p = tid / G;
   const int q = tid % G;
@@ -901,11 +836,9 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   // ---- speculative first loads of this lane's row, ahead of the control words (pinned_load*) ----
   const int pc_s = valid ? p : 0;
   const uint4* scol = reinterpret_cast<const uint4*>(sfl) + (size_t)pc_s * G + q;
-#ifndef CHX_EXP_NOFORCE
   const uint4 s_e4 = pinned_load16(scol);
   const uint4 s_xi = pinned_load16(x_lead + pc_s);
   const int s_d = pinned_load4(sdeg + pc_s);
-#endif
   if (HOT) n_kicks = 2, do_aoa = 1;  // what the launcher checked (launch_step_g), restated for the optimiser
   // The other launch-uniform switches are folded where they are read (`HOT || ...`).  Do NOT write them into the
   // by-value argument struct (or a copy of its box): the struct then lives in a private copy, the vectoriser reads
@@ -914,7 +847,6 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   // from host memory in every wavefront: the launch then takes 24-30 us instead of 5 (measured, round 2).
   const bool periodic = HOT || a.box.periodic != 0;
   __shared__ float sF[3 * PPB];
-  // (CHX_EXP_*: timing decomposition of scripts/exp_step.sh, never defined in the product build)
   // the control block as this launch finds it goes to the host-mapped copy (one wavefront, system-scope stores;
   // no-op launches publish too: that is how the host learns about a halt)
   // word 0 of the copy is this launch's step index: "launch `step` has begun", i.e. every earlier launch of the
@@ -922,26 +854,20 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   if (a.host_ctrl != nullptr && blockIdx.x == 0 && threadIdx.x < 8)
     __hip_atomic_store(&a.host_ctrl[threadIdx.x], threadIdx.x == 0 ? (int)step : ctrl_first[threadIdx.x], __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_SYSTEM);
-#ifndef CHX_EXP_NOCTRL
   // (naming the arguments the first vector loads need in an asm statement ahead of this branch makes
   // their fetch leave together with the halt word's -- and measured 3 % slower: the stale-word read
   // turns into a vector load and a second argument fetch still follows the branch)
   const int halt_step = ctrl_first[3];
   if ((long long)halt_step <= step) return;  // block-uniform
-#endif
   // Which table this launch walks: the pruned inner list, unless some particle has moved too far
   // since the last refresh (word raised by an EARLIER launch; the two words alternate with the
   // step parity so that no launch reads a word its own blocks may be writing).
   // (Requesting both control words together ahead of the branch -- two s_load_dwordx4 in one asm
   // block, since the compiler narrows and sinks plain reads -- measured 3 % SLOWER at N = 32768.)
-#ifndef CHX_EXP_NOCTRL
   // (read unconditionally and combined without a short circuit: a branch on `epoch` in front of this
   // read puts a second exposed scalar round trip ahead of every other load of the launch)
   const int stale_word = ctrl_first[4 + (int)(step & 1)];
   const bool inner = !PRUNE && (HOT || a.fli != nullptr) && ((epoch >= 0) & (stale_word != epoch));
-#else
-  const bool inner = !PRUNE && (HOT || a.fli != nullptr);
-#endif
   const uint32_t* fl_use = inner ? a.fli : a.fl;
   const int32_t* deg_use = inner ? a.degi : a.deg;
   const int p0 = blk * PPB;
@@ -952,7 +878,6 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
 
   float4 xi;
   float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
-#ifndef CHX_EXP_NOFORCE
   // the row's own loads and first gathers go out together with the integrate operands; the Philox draw and
   // b sigma_v (~500 instructions in the block's first wavefront) run while the gathers are in flight
   // (with one lane per particle every thread integrates and the launch is throughput-bound: there the
@@ -960,18 +885,9 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   if (G == 1) finish_step_particle<HOT>(a, step, do_aoa, tk);
   // the speculated list is the one to walk (launch-uniform; the steady state): adopt what is in flight.
   // Otherwise (inner list gone stale since the host chose) the row is loaded again from the right table.
-#ifdef CHX_EXP_STAMPS
-  CHX_STAMP_WAIT();  // first row loads (and the integrate operands) are back
-  CHX_STAMP(1, stamp_clk());
-#endif
   RowLoads rl = (fl_use == sfl) ? lj_row_adopt<G>(a.x_cur, scol, pc_s, s_xi, s_d, s_e4)
                                 : lj_row_begin<G>(a.x_cur, fl_use, deg_use, a.n, p, q, valid);
   if (G > 1) finish_step_particle<HOT>(a, step, do_aoa, tk);
-#ifdef CHX_EXP_STAMPS
-  CHX_STAMP(7, stamp_clk());  // (slot 7 reused: Philox done, gathers still in flight)
-  CHX_STAMP_WAIT();           // first gathers are back
-  CHX_STAMP(2, stamp_clk());
-#endif
   if (PRUNE) {
     constexpr int W = 4 * G;
     int kept = 0;
@@ -987,10 +903,6 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   } else {
     lj_row_finish<G>(rl, a.x_cur, fl_use, a.n, q, valid, a.box, periodic, a.lj, xi, fx, fy, fz, en);
   }
-#else
-  finish_step_particle<HOT>(a, step, do_aoa, tk);
-#endif
-  CHX_STAMP(3, stamp_clk());
   fx = group_sum<G>(fx), fy = group_sum<G>(fy), fz = group_sum<G>(fz);
   if (q == 0) {
     const int pl = threadIdx.x / G;
@@ -999,17 +911,11 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
     sF[3 * pl + 2] = fz;
   }
   __syncthreads();
-  CHX_STAMP(4, stamp_clk());
   // ---- integrate: one particle per thread, packed into the first PPB threads of the block ----
   const bool stale = step_epilogue<HOT>(a, tk, sF, step, n_kicks, do_aoa);
   // the inner list stays off until the next refresh (a new epoch) outdates the word
   if (do_aoa && (HOT || a.fli) && epoch >= 0 && (stale || (!inner && !PRUNE && threadIdx.x == 0)))
     ctrl_first[4 + (int)((step + 1) & 1)] = epoch;
-#ifdef CHX_EXP_STAMPS
-  CHX_STAMP(5, stamp_clk());
-  // (slot 6 holds the entry real-time stamp; the end one goes to a second array row via slot arithmetic)
-  if (threadIdx.x == 0 && blk < CHX_STAMP_BLOCKS) g_stamps[step & 3][blk][6] = (g_stamps[step & 3][blk][6] & 0xFFFFFFFFull) | (stamp_rt() << 32);
-#endif
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // (the counters go to the host copy as they change: the copy made at launch start cannot hold this launch's own)
     const int w = PRUNE ? 7 : 6;
@@ -1186,6 +1092,43 @@ static void launch_step_g(const StepArgs& a, long long step, int n_kicks, int do
   if (dbg) (void)hipStreamSynchronize(st);
 }
 
+// ---------------------------------------------------------------------------
+// How the launch window waits for the device when its queue is full.
+//   sleep (default): nanosleep between polls, with the thread's timer slack lowered once so that a 5 us nap is
+//                    not rounded up to the kernel's default 50 us; the queue refills in bursts (see the loop).
+//   spin  (CHX_POLL=spin): busy-wait with the architecture's relax hint -- one core at 100 % per rank.
+// Eight ranks on one host share its CPU quota with eight HIP helper threads.
+// ---------------------------------------------------------------------------
+struct PollPolicy {
+  long sleep_ns;  // 0: spin
+};
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield" ::: "memory");
+#else
+  sched_yield();
+#endif
+}
+static PollPolicy poll_policy() {
+  static const long ns = [] {
+    const char* e = getenv("CHX_POLL");
+    if (e && (e[0] == 's' && e[1] == 'p')) return 0L;  // "spin"
+    const char* n = getenv("CHX_POLL_SLEEP_NS");
+    long v = n ? atol(n) : 5000L;
+    return v < 0 ? 0L : v;
+  }();
+  if (ns > 0) {
+    static thread_local bool slack_set = false;
+    if (!slack_set) {
+      (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);  // this thread only; 1 us
+      slack_set = true;
+    }
+  }
+  return PollPolicy{ns};
+}
+
 // launch i of the chunk reads (i even ? x_even : x_odd) and writes the other buffer
 // window > 0 (needs p->host_ctrl, readable by the host at the same address): launch step s only once fewer than
 // `window` earlier launches are still waiting to begin, and stop at the first step the halt word rules out;
@@ -1229,24 +1172,39 @@ int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, in
     a.half_inner = hm;
   }
   const bool throttle = window > 0 && a.host_ctrl != nullptr;
+  const PollPolicy poll = poll_policy();
   for (int i = 0; i < n_steps; ++i) {
     if (throttle) {
       const long long s = step0 + i;
       const volatile int32_t* hc = a.host_ctrl;
-      int last = hc[0];
-      timespec t0{};
-      for (unsigned spins = 0;; ++spins) {
-        if ((long long)hc[3] <= s) return CHX_OK;  // the skin check has fired: launches from s on would be no-ops
-        const int begun = hc[0];                   // newest launch that has begun; begun+1 .. s-1 are still waiting
-        if (s - begun <= window) break;
-        __builtin_ia32_pause();
-        if ((spins & 0xFFFF) == 0xFFFF) {  // a stream that makes no progress for a minute is not coming back
-          timespec t1;
-          clock_gettime(CLOCK_MONOTONIC, &t1);
-          if (begun != last || t0.tv_sec == 0) last = begun, t0 = t1;
-          else if (t1.tv_sec - t0.tv_sec > 60) {
-            chx_set_error("chx_langevin_fused_run: no step launch has begun for 60 s (step %lld, newest begun %d)", s, begun);
-            return CHX_ERR_LAUNCH;
+      if ((long long)hc[3] <= s) return CHX_OK;  // the skin check has fired: launches from s on would be no-ops
+      if (s - hc[0] > window) {
+        // The queue is full.  Spinning here keeps one core at 100 % per rank for nothing: the device needs
+        // ~5 us per queued launch.  The sleeping policy therefore lets the queue drain to `low` launches before
+        // it refills it in one burst (the host enqueues a launch in ~2.5 us, so the burst outruns the device),
+        // sleeping in between; the spinning policy (CHX_POLL=spin) refills launch by launch.
+        const int low = poll.sleep_ns > 0 ? window - window / 2 : window;
+        int last = hc[0];
+        bool timing = false;
+        timespec t0{};
+        for (unsigned spins = 0;; ++spins) {
+          if ((long long)hc[3] <= s) return CHX_OK;
+          const int begun = hc[0];  // newest launch that has begun; begun+1 .. s-1 are still waiting
+          if (s - begun <= low) break;
+          if (poll.sleep_ns > 0) {
+            const timespec nap = {0, poll.sleep_ns};
+            nanosleep(&nap, nullptr);
+          } else {
+            cpu_relax();
+          }
+          if (poll.sleep_ns > 0 || (spins & 0xFFFF) == 0xFFFF) {  // a stream that makes no progress for a minute is not coming back
+            timespec t1;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if (begun != last || !timing) last = begun, t0 = t1, timing = true;
+            else if (t1.tv_sec - t0.tv_sec > 60) {
+              chx_set_error("chx_langevin_fused_run: no step launch has begun for 60 s (step %lld, newest begun %d)", s, begun);
+              return CHX_ERR_LAUNCH;
+            }
           }
         }
       }

@@ -361,6 +361,9 @@ int chx_cell_prepare(const float* xyz, int n, chx_box_t box, float cutoff_plus_s
                      hipStream_t st, float* xs4_out) {
   CHX_REQUIRE(box.periodic && box.lx > 0 && box.ly > 0 && box.lz > 0, "periodic box required");
   CHX_REQUIRE(nc_h[0] >= 3 && nc_h[1] >= 3 && nc_h[2] >= 3, "need >= 3 cells per axis");
+  // k_cell_sort packs a cell's grid coordinates into 10 bits per axis (xs4.w) and the build kernels decode them
+  // with & 1023: a longer axis would alias cells silently (chx_cell_grid_h never produces one)
+  CHX_REQUIRE(nc_h[0] <= 1024 && nc_h[1] <= 1024 && nc_h[2] <= 1024, "at most 1024 cells per axis");
   const int64_t ncell64 = (int64_t)nc_h[0] * nc_h[1] * nc_h[2];
   CHX_REQUIRE(ncell64 < (1ll << 30), "too many cells");
   // the grid must respect the geometric guarantee (edge >= cutoff + skin)
@@ -375,7 +378,7 @@ int chx_cell_prepare(const float* xyz, int n, chx_box_t box, float cutoff_plus_s
   *g_out = g;
   CHX_REQUIRE(status_len >= 0 && status_len <= 1024, "status block too long");
   // (a kernel, not hipMemsetAsync: the runtime's fill path can block the calling thread on a signal of its own, and
-  // a rebuild inside the Langevin loop must not put the host to sleep -- scripts/host_speed_probe.py)
+  // a rebuild inside the Langevin loop must not put the host to sleep -- DESIGN.md section 6)
   hipLaunchKernelGGL(k_zero_i32, dim3((unsigned)((ncell + 1 + 255) / 256)), dim3(256), 0, st, cell_count, ncell + 1);
   const unsigned pb = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(k_cell_assign, dim3(pb), dim3(256), 0, st, xyz, n, b3, g, cell_of, cell_count);

@@ -85,6 +85,26 @@ class LangevinIntegrator:
         self.launch_window = max(0, int(launch_window))
         self.n_rebuilds = 0  # neighbor-list rebuilds triggered inside the last run()
 
+    # Per-process device resources a run() leaves on the integrator for the next one: host-mapped pinned slots the
+    # step kernel stores into, device scratch, cached unit arithmetic keyed by object identity.  A copy must not
+    # share them (two integrators polling one slot) and cannot clone them (a deep-copied pinned tensor is pageable
+    # memory, and its numpy view no longer aliases it): it starts without and allocates its own on first use.
+    # MultiStateSampler deep-copies its sampler, chiron/multistate.py:266-268.
+    _PER_PROCESS_STATE = ("_gen_ring", "_gen_next", "_pinned_ring", "_ring_next", "_dev_scratch", "_inner_scratch",
+                          "_run_cache")
+
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if k not in self._PER_PROCESS_STATE}
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
+    def __deepcopy__(self, memo):
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        new.__dict__.update({k: copy.deepcopy(v, memo) for k, v in self.__getstate__().items()})
+        return new
+
     # ------------------------------------------------------------------
     def run(
         self,
@@ -336,7 +356,7 @@ class _RunState:
             # little to prune under a thin skin; tiny systems are pure launch latency.  0.12 nm keeps a 300 K argon
             # fluid on the pruned table for all 32 steps of an epoch; where the step is throughput-bound (N >= 2^17)
             # the shorter rows of 0.10 nm are worth +2 % and the handful of full-list launches per 20 000 steps they
-            # cost is not (scripts/ab_inner.py: N = 131 072 +2 %, 262 144 +1.5-2 %; 32 768 and 65 536 equal)
+            # cost is not (round-2 in-process A/B: N = 131 072 +2 %, 262 144 +1.5-2 %; 32 768 and 65 536 equal)
             inner = (0.10 if self.n >= (1 << 17) else 0.12) if (skin >= 0.3 and self.n >= 2048) else 0.0
         if inner <= 0.0 or every <= 0 or inner >= skin:
             return 0.0, 0

@@ -295,7 +295,7 @@ def fl_chunks_for(maxdeg: int, g: int) -> int:
 def _choose_g(maxdeg: int, n: int) -> int:
     """Lanes that cooperate on one particle in the list kernels.
 
-    Measured on MI355X at the loaded clock (scripts/ab_g.py, Langevin steps/s on the rho* = 0.1 fluid; best G and
+    Measured on MI355X at the loaded clock (round-2 in-process A/B, Langevin steps/s on the rho* = 0.1 fluid; best G and
     the runners-up): N = 8192: 8 (16: -10 %, 32: -17 %); 16384: 8 (4: -4 %, 16: -7 %); 32768: 4 (8: -2 %, 2: -15 %);
     65536: 4 (2: -7 %, 8: -15 %); 131072: 2 (4: -4 %, 1: -11 %); 262144: 1 (2: equal, 4: -4 %).  I.e. about 2^18 lanes
     in flight for the large systems, 2^17 below N = 2^16 and never more than 8 lanes per particle for the sake of the

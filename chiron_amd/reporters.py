@@ -79,11 +79,24 @@ class _SimulationReporter:
         return np.array(values)
 
     def save(self, path=None) -> str:
-        """Dump everything reported so far to one ``.npz`` (one array per key, first axis = frames)."""
+        """Dump everything reported so far to one ``.npz``: one array per key, first axis = frames -- the layout of
+        the reference's HDF5 log (one resizable dataset per key, chiron/reporters.py:133-144).  A later ``save``
+        rewrites the file with every frame reported so far, so the file always equals what the reference's
+        append-on-flush log would hold."""
+        import os
+
         path = str(path or self.log_file_path)
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
         self.flush_buffer()
         np.savez(path, **{k: np.array(v) for k, v in self._store.items()})
         return path
+
+    @staticmethod
+    def load(path) -> Dict[str, np.ndarray]:
+        """Read a file written by ``save`` back: {key: array with first axis = frames} (what reading the reference's
+        log with h5py gives, chiron/reporters.py:176-203)."""
+        with np.load(str(path), allow_pickle=False) as f:
+            return {k: f[k] for k in f.files}
 
 
 class LangevinDynamicsReporter(_SimulationReporter):

@@ -36,7 +36,17 @@ typedef void* chx_stream_t;
 #define CHX_ERR_LAUNCH (-2)
 #define CHX_ERR_UNSUPPORTED (-3)
 
-#define CHX_ABI_VERSION 1
+/* ABI history (chx_version() returns this; a binding compares it with the header it was written against):
+ *   1  round 1.
+ *   2  round 2/3 -- INCOMPATIBLE with 1: chx_pack_langevin takes three more pointers (ctrl_reset, publish_src8,
+ *      publish_host_dst8); chx_langevin_t grew host_ctrl (and, in round 3, the reference-event fields below it); the
+ *      fused step kernel takes the particle's MASS from ref4[p].w (a ref4 packed with chx_permute_pack has w = 0 and
+ *      is refused: chx_langevin_fused_chunk / _run check ref4[0].w > 0 when CHX_DEBUG_SYNC is set, and
+ *      chx_pack_langevin is the one supported producer); x4[p].w belongs to the kernel (path length); the words of a
+ *      force-list chunk are interleaved over the lanes (see "Force list" below); chx_mc_t::state is
+ *      CHX_MC_STATE_WORDS = 16 ints (two slots) and chx_mc_t::energy 4 doubles -- the struct's SIZE did not change,
+ *      so chx_sizeof_mc_t() cannot tell; this version number does. */
+#define CHX_ABI_VERSION 2
 
 /* high bit of a force-list entry: neighbor has the HIGHER original particle id */
 #define CHX_FL_HI 0x80000000u

@@ -17,8 +17,13 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        path = build_oracle.OUT if os.path.exists(build_oracle.OUT) else build_oracle.build()
-        _lib = C.CDLL(path)
+        # always through build(): it compares the hash baked into the binary with oracle.c and recompiles on any
+        # difference (a stale checker must never load)
+        _lib = C.CDLL(build_oracle.build())
+        _lib.orc_source_hash.restype = C.c_char_p
+        assert _lib.orc_source_hash().decode().endswith(build_oracle.source_hash()), "liboracle.so is stale"
+        _lib.orc_full_rows_cell.restype = C.c_int
+        _lib.orc_lj_cell_f64.restype = C.c_int
         _lib.orc_nl_build_fixed.restype = C.c_int
         _lib.orc_lj_nl.restype = C.c_float
         _lib.orc_langevin_run.restype = C.c_int
@@ -111,3 +116,44 @@ def langevin_run_cell_omp(x, v, box, mass, sigma, eps, cutoff, skin, dt, a, b, k
     if rc != 0:
         raise RuntimeError("orc_langevin_run_cell_omp failed")
     return x, v, dict(rebuilds=int(stats[0]), row_capacity=int(stats[1]), build_seconds=float(stats[2]), threads=int(stats[3]))
+
+
+def full_rows_cell(x, box, cutoff_and_skin, threads=0, cap0=96):
+    """Every particle's FULL row (all partners with d < cutoff + skin in the reference's fp32 arithmetic, ascending id)
+    through the oracle's own cell grid: (rows (n, cap) uint32, deg (n,) int32).  Half row i of the reference
+    (chiron/neighbors.py:548-626) = the entries of full row i that are > i."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n, cap = x.shape[0], int(cap0)
+    while True:
+        rows = np.zeros((n, cap), np.uint32)
+        deg = np.zeros(n, np.int32)
+        mx = lib().orc_full_rows_cell(_p(x, C.c_float), n, _box(box), C.c_float(cutoff_and_skin), cap, _p(rows, C.c_uint32),
+                                      _p(deg, C.c_int32), int(threads))
+        if mx <= cap:
+            return rows, deg
+        cap = mx + 16
+
+
+def half_list_from_full_rows(rows, deg):
+    """(n_neighbors (n,), flat ascending neighbor ids row after row) of the reference's half list."""
+    n, cap = rows.shape
+    valid = np.arange(cap)[None, :] < deg[:, None]
+    half = valid & (rows > np.arange(n, dtype=np.uint32)[:, None])
+    return half.sum(axis=1).astype(np.int32), rows[half]
+
+
+def lj_cell_f64(x, box, sigma, eps, cutoff, threads=0, cap0=64):
+    """fp64 LJ energy + forces on ALL particles (interacting set = the reference's fp32 `d < cutoff`, values fp64):
+    (E, force64 (n,3), sum|e_ij|, max_i max_c sum_j|f_ij,c|, n_pairs)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n, cap = x.shape[0], int(cap0)
+    f = np.zeros((n, 3), np.float64)
+    stats = np.zeros(4, np.float64)
+    while True:
+        rc = lib().orc_lj_cell_f64(_p(x, C.c_float), n, _box(box), C.c_float(sigma), C.c_float(eps), C.c_float(cutoff), cap,
+                                   _p(f, C.c_double), _p(stats, C.c_double), int(threads))
+        if rc == 0:
+            return float(stats[0]), f, float(stats[1]), float(stats[2]), int(stats[3])
+        if rc < 0:
+            raise MemoryError("orc_lj_cell_f64")
+        cap = rc + 16

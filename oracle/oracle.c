@@ -19,6 +19,13 @@
 
 typedef struct { int periodic; float lx, ly, lz; } orc_box;
 
+/* identity of the text this binary was compiled from (oracle/build_oracle.py bakes it in and refuses a binary whose
+ * hash differs from oracle.c beside it: a stale checker must not pass for a fresh one) */
+#ifndef ORC_SOURCE_HASH
+#define ORC_SOURCE_HASH "unhashed"
+#endif
+const char* orc_source_hash(void) { return "ORC_SOURCE_HASH=" ORC_SOURCE_HASH; }
+
 static inline float mod_floor(float t, float L) { /* jnp.mod, neighbors.py:79 */
   float m = fmodf(t, L);
   if (m != 0.0f && ((m < 0.0f) != (L < 0.0f))) m += L;
@@ -368,5 +375,63 @@ int orc_langevin_run_cell_omp(float* x, float* v, int n, orc_box box, const floa
 #endif
   }
   free(rows); free(deg); free(ref); free(F);
+  return 0;
+}
+
+/* ==========================================================================
+ * Full-size checkers (tests/test_gpu_fullsize.py): every row of the list and every particle's force at
+ * N = 32 768 / 262 144, where the O(N^2) routines above are out of reach.
+ * ========================================================================== */
+
+/* Full rows (all partners j != i with d_ref < cs in the reference's fp32 arithmetic and orientation, ascending id)
+ * through the cell grid above; returns the largest degree (> cap: grow and call again).  The reference's half row
+ * i (chiron/neighbors.py:548-626) is the part of full row i with j > i. */
+int orc_full_rows_cell(const float* x, int n, orc_box box, float cs, int cap, uint32_t* rows, int32_t* deg, int threads) {
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#endif
+  return build_full_rows(x, n, box, cs, cap, rows, deg);
+}
+
+/* LJ energy and forces on ALL particles in fp64 (chiron/potential.py:193-213, closed-form gradient :322-332).
+ * The interacting SET is the reference's: the fp32 predicate d < rc of chiron/neighbors.py:782 on the fp32 minimum
+ * image (a pair one ulp from the cutoff must not flip between oracle and kernel: its force is ~0.03 kJ/mol/nm,
+ * far above the tolerance); the VALUES are fp64 on the same coordinates with an fp64 minimum image.
+ * force64 (n,3); stats[0] = E, [1] = sum over pairs |e_ij|, [2] = max_i max_c sum_j |f_ij,c|, [3] = pairs.
+ * Returns 0, or the required row capacity if `cap` was too small. */
+int orc_lj_cell_f64(const float* x, int n, orc_box box, float sigma, float eps, float rc, int cap, double* force64,
+                    double* stats, int threads) {
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#endif
+  uint32_t* rows = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n * (size_t)cap);
+  int32_t* deg = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  if (!rows || !deg) { free(rows); free(deg); return -1; }
+  const int mx = build_full_rows(x, n, box, rc, cap, rows, deg);
+  if (mx > cap) { free(rows); free(deg); return mx; }
+  const double L[3] = {box.lx, box.ly, box.lz};
+  double e_tot = 0.0, e_abs = 0.0, f_abs_max = 0.0, pairs = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : e_tot, e_abs, pairs) reduction(max : f_abs_max)
+  for (int i = 0; i < n; ++i) {
+    double f[3] = {0, 0, 0}, fa[3] = {0, 0, 0};
+    const uint32_t* row = rows + (size_t)i * cap;
+    for (int k = 0; k < deg[i]; ++k) {
+      const int j = (int)row[k];
+      double r[3], d2 = 0.0;
+      for (int c = 0; c < 3; ++c) {
+        r[c] = (double)x[3 * i + c] - (double)x[3 * j + c];
+        if (box.periodic) r[c] -= L[c] * nearbyint(r[c] / L[c]);
+        d2 += r[c] * r[c];
+      }
+      const double s2 = (double)sigma * (double)sigma / d2, s6 = s2 * s2 * s2;
+      const double e = 4.0 * (double)eps * (s6 * s6 - s6);
+      const double fs = 24.0 * (double)eps * (2.0 * s6 * s6 - s6) / d2;
+      for (int c = 0; c < 3; ++c) { f[c] += fs * r[c]; fa[c] += fabs(fs * r[c]); }
+      if (i < j) { e_tot += e; e_abs += fabs(e); pairs += 1.0; }
+    }
+    for (int c = 0; c < 3; ++c) { force64[3 * (size_t)i + c] = f[c]; if (fa[c] > f_abs_max) f_abs_max = fa[c]; }
+  }
+  if (stats) { stats[0] = e_tot; stats[1] = e_abs; stats[2] = f_abs_max; stats[3] = pairs; }
+  free(rows); free(deg);
   return 0;
 }

@@ -151,6 +151,55 @@ def test_c4_force_energy_properties(ca, O, c4):
     assert abs(e_s - e0) <= 1e-5 * abs(e0)
 
 
+@pytest.fixture(scope="module")
+def CO():
+    from oracle import c_oracle
+
+    c_oracle.lib()  # (compiles oracle/oracle.c on first use, hash-checked: oracle/build_oracle.py)
+    return c_oracle
+
+
+@pytest.mark.parametrize("n", [N3, N4], ids=["c3-32768", "c4-262144"])
+def test_every_list_row_and_every_force_match_the_oracle_at_full_size(ca, O, CO, n):
+    """ALL N particles, not a sample (round-2 review): (a) every row of the neighbor list -- counts and ids, bit
+    exact -- against the C oracle's cell-grid restatement of chiron/neighbors.py:548-626 (itself pinned to the
+    O(N^2) oracle in the CPU suite); (b) every particle's force and the total energy from the force-list kernel
+    against fp64 (chiron/potential.py:193-213, :322-332) at SURVEY 8(c)'s tolerances; (c) the same for the
+    public-half-list kernel."""
+    x, box = O.lj_lattice(n, 0.1, SIGMA, seed=1234)
+    nbr = _nbr(ca)
+    nbr.build(x, box)
+    assert nbr._perm is not None, "cell path was not taken"
+    rows, deg = CO.full_rows_cell(x, box, CUTOFF + SKIN, threads=CO.effective_cores())
+    want_n, want_flat = CO.half_list_from_full_rows(rows, deg)
+    n_nbr = nbr.n_neighbors.cpu().numpy()
+    assert np.array_equal(n_nbr, want_n)
+    nl = nbr.neighbor_list.cpu().numpy().view(np.uint32)
+    m = nl.shape[1]
+    real = np.arange(m)[None, :] < n_nbr[:, None]
+    assert np.array_equal(nl[real], want_flat)  # every real entry of every row, in order
+    # padding rule (:603-623) and mask on every row
+    first = np.where(n_nbr > 0, nl[:, 0], 0).astype(np.int64)
+    fill = np.where(first == np.arange(n), first + 1, first)
+    assert np.array_equal(nl.astype(np.int64)[~real], np.broadcast_to(fill[:, None], nl.shape)[~real])
+    assert np.array_equal(nbr.neighbor_mask.cpu().numpy(), real.astype(np.int32))
+    del rows, want_flat, real
+    # forces / energy on perturbed positions inside the skin guarantee
+    pot = _pot(ca, n)
+    rng = np.random.default_rng(7)
+    x2 = (x + rng.normal(0, 0.04, size=x.shape)).astype(f32)
+    e64, f64, eabs, fabs_max, pairs = CO.lj_cell_f64(x2, box, SIGMA, EPS, CUTOFF, threads=CO.effective_cores())
+    assert pairs > 5 * n // 2  # ~5.6 partners inside the cutoff at rho* = 0.1 (SURVEY 8)
+    e, f = pot.compute_energy_and_force(x2, nbr)
+    f = f.cpu().numpy().astype(np.float64)
+    assert abs(float(e) - e64) <= 1e-5 * eabs, (float(e), e64, eabs)
+    err = np.abs(f - f64).max()
+    assert err <= 1e-5 * max(1.0, fabs_max), (err, fabs_max)
+    f_h, e_h = ca.ops.lj_nl_energy_force(dev(x2), nbr.neighbor_list, nbr.n_neighbors, nbr._box_h, SIGMA, EPS, CUTOFF)
+    assert abs(float(e_h[0]) - e64) <= 1e-5 * eabs
+    assert np.abs(f_h.cpu().numpy().astype(np.float64) - f64).max() <= 2e-5 * max(1.0, fabs_max)  # (float atomics)
+
+
 def _run_langevin(ca, O, n, chunk, steps, skin, seed=1234):
     u = ca.unit
     x, box = O.lj_lattice(n, 0.1, SIGMA, seed=seed)
@@ -234,28 +283,12 @@ def test_c3_mc_device_loop_equals_host_loop(ca, O, monkeypatch):
     assert not np.array_equal(res[0][3], O.lj_lattice(N3, 0.1, SIGMA, seed=1234)[0])  # at least one rebuild happened
 
 
-def _fp64_forces_on(x, box, idx):
-    """fp64 brute-force LJ force (all N partners, minimum image, plain truncation) on the particles idx
-    (chiron/potential.py:193-213, :322-332)."""
-    L = np.diag(box).astype(np.float64)
-    x64 = x.astype(np.float64)
-    out = np.zeros((len(idx), 3))
-    for k, i in enumerate(idx):
-        r = x64[i] - x64
-        r -= L * np.round(r / L)
-        d2 = (r * r).sum(axis=1)
-        sel = (d2 < CUTOFF ** 2) & (d2 > 0)
-        s6 = (SIGMA ** 2 / d2[sel]) ** 3
-        out[k] = ((24 * EPS * (2 * s6 * s6 - s6) / d2[sel])[:, None] * r[sel]).sum(axis=0)
-    return out
-
-
 @pytest.mark.parametrize("n", [N3, N4], ids=["c3-32768", "c4-262144"])
-def test_step_kernel_step_63_matches_oracle_at_full_size(ca, O, n):
+def test_step_kernel_step_63_matches_oracle_at_full_size(ca, O, CO, n):
     """The fused step kernel (k_lj_step, steady-state instantiation, pruned inner list, device Philox) at the
     BASELINE sizes: a 63-step run gives frame 63 (x, v after the trailing kick); a 64-step run from the same
-    start is bit-identical up to there and adds step 63.  For 48 sampled particles that step is redone by the
-    oracle -- fp64 brute-force forces over ALL N partners on frame 63, O.baoa_half (chiron/integrators.py:181-188)
+    start is bit-identical up to there and adds step 63.  For EVERY particle that step is redone by the
+    oracle -- fp64 forces on frame 63 (oracle/oracle.c: orc_lj_cell_f64), O.baoa_half (chiron/integrators.py:181-188)
     with the oracle's own Philox normals for (particle, step 63), wrap (:239), fp64 forces on the new frame,
     trailing kick (:195) -- and compared with the kernel's frame 64: x to 5e-6 nm, v to 5e-4."""
     u = ca.unit
@@ -278,19 +311,24 @@ def test_step_kernel_step_63_matches_oracle_at_full_size(ca, O, n):
     assert rb_a == rb_b == 0  # dt = 1 fs from the lattice: the 0.5 nm skin holds for 64 steps
     if prunes is not None and os.environ.get("CHX_PRUNE_EVERY") is None and os.environ.get("CHX_INNER_SKIN") is None:
         assert prunes >= 2  # the inner list was refreshed at steps 0 and 32: step 63 walked the pruned table
-    rng = np.random.default_rng(63)
-    idx = np.unique(np.concatenate([rng.integers(0, n, 46), [0, n - 1]]))
-    mass = np.full(len(idx), 39.948, f32)
+    # every particle (round 2 compared 48): fp64 forces over the oracle's own cell grid
+    idx = np.arange(n)
+    mass = np.full(n, 39.948, f32)
     kT, a, b = O.langevin_constants(300.0, 0.001, 1.0)
     run_key = O.key_split(key0)[1]  # what SamplerState.new_PRNG_key hands to run() (chiron/integrators.py:124)
-    xi = O.philox_normals3(n, steps - 1, O.STREAM_LANGEVIN, run_key)[idx]
-    f_a = _fp64_forces_on(xa, box, idx)
-    x1, v1 = O.baoa_half(xa[idx], va[idx], f_a.astype(f32), mass, 0.001, a, b, kT, xi)
+    xi = O.philox_normals3(n, steps - 1, O.STREAM_LANGEVIN, run_key)
+    cores = CO.effective_cores()
+    f_a = CO.lj_cell_f64(xa, box, SIGMA, EPS, CUTOFF, threads=cores)[1]
+    x1, v1 = O.baoa_half(xa, va, f_a.astype(f32), mass, 0.001, a, b, kT, xi)
     x1 = O.periodic_wrap(x1, box)
-    assert np.abs(xb[idx] - x1).max() < 5e-6, np.abs(xb[idx] - x1).max()
-    f_b = _fp64_forces_on(xb, box, idx)
+    # (a coordinate that lands within rounding of a box face may wrap on one side only: compare modulo L)
+    L = float(box[0, 0])
+    dx = np.abs(xb - x1)
+    dx = np.minimum(dx, np.abs(dx - L))
+    assert dx.max() < 5e-6, dx.max()
+    f_b = CO.lj_cell_f64(xb, box, SIGMA, EPS, CUTOFF, threads=cores)[1]
     v2 = O.kick(v1, f_b.astype(f32), mass, 0.001)
-    assert np.abs(vb[idx] - v2).max() < 5e-4 * max(1.0, np.abs(v2).max()), np.abs(vb[idx] - v2).max()
+    assert np.abs(vb - v2).max() < 5e-4 * max(1.0, np.abs(v2).max()), np.abs(vb - v2).max()
     # the step really moved things: frame 64 is not frame 63
     assert np.abs(xb[idx] - xa[idx]).max() > 1e-5
     # and the system is a sane 300 K fluid after 64 steps

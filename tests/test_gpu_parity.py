@@ -771,16 +771,20 @@ def test_langevin_device_rng_matches_oracle_stream(ca, O):
     assert np.abs(out.velocities.cpu().numpy() - vo).max() < 1e-4
 
 
-@pytest.mark.parametrize("n", [200, 2100], ids=["wave-per-particle", "16-lanes-per-particle"])
-def test_langevin_nolist_and_pairlist(ca, O, n):
+@pytest.mark.parametrize("n,rho", [(200, 0.5), (2100, 0.5), (512, 0.1)],
+                         ids=["wave-per-particle", "16-lanes-per-particle", "c2-n512-rho0.1"])
+def test_langevin_nolist_and_pairlist(ca, O, n, rho):
     """The paths without a Verlet list run ONE launch per step too (k_ap_step: all-pairs force + BAOAB;
     a wavefront per particle up to N = 2048, 16 lanes per particle beyond): nbr_list=None is the
     reference's no-PBC branch (chiron/potential.py:235-258), PairListNsqrd the PBC all-pairs list with
     a wrap every step and no rebuilds (chiron/neighbors.py:1272-1289).  Both follow the oracle with
-    injected noise; the PBC trajectory is the neighbor-list trajectory (same pairs interact)."""
+    injected noise; the PBC trajectory is the neighbor-list trajectory (same pairs interact).  The third case is
+    BASELINE.json's C2 itself: N = 512 at rho* = 0.1 (box edge 5.8601 nm, Examples/LJ_langevin.py)."""
     u = ca.unit
     steps = 6
-    x, box = O.lj_lattice(n, 0.5, SIGMA, seed=51)
+    x, box = O.lj_lattice(n, rho, SIGMA, seed=51)
+    if (n, rho) == (512, 0.1):
+        assert abs(float(box[0, 0]) - 5.8601) < 1e-3
     pot = lj_pot(ca, n)
     thermo = ca.states.ThermodynamicState(pot, temperature=300 * u.kelvin)
     rng = np.random.default_rng(1)
@@ -1893,3 +1897,33 @@ def test_langevin_run_after_an_interrupted_run(ca, O, monkeypatch):
     assert integ.n_rebuilds == integ2.n_rebuilds >= 2
     for out in outs:  # every run starts from the same state and key: same trajectory every time
         assert torch.equal(out.positions, ref.positions) and torch.equal(out.velocities, ref.velocities)
+
+
+def test_deep_copied_integrator_and_sampler_run_on_fresh_slots(ca, O):
+    """Advisor finding (round 2): MultiStateSampler deep-copies its MCMC sampler (chiron/multistate.py:266-268), and a
+    LangevinIntegrator that has run owns host-mapped pinned slots the step kernel stores into.  A copy must allocate
+    its own: run, deep-copy the move and the integrator, run the copies -- same trajectory as the original's second
+    run, halts seen (rebuilds happen), nothing shared."""
+    import copy
+
+    n = 3000
+    x, box, pot, state, thermo, nbr, integ = _langevin_setup(ca, O, n, 0.1, 77, 0.05, 2.0)
+    out1, nbr1 = integ.run(state, thermo, number_of_steps=150, nbr_list=nbr)
+    assert integ.n_rebuilds >= 1 and "_gen_ring" in integ.__dict__  # the launch window ran and left its slots
+    clone = copy.deepcopy(integ)
+    assert "_gen_ring" not in clone.__dict__ and "_dev_scratch" not in clone.__dict__
+    a, nbr_a = integ.run(copy.deepcopy(out1), thermo, number_of_steps=150, nbr_list=copy.deepcopy(nbr1))
+    b, nbr_b = clone.run(copy.deepcopy(out1), thermo, number_of_steps=150, nbr_list=copy.deepcopy(nbr1))
+    assert clone.n_rebuilds == integ.n_rebuilds >= 1
+    assert torch.equal(a.positions, b.positions) and torch.equal(a.velocities, b.velocities)
+    ring_a, ring_b = integ.__dict__["_gen_ring"], clone.__dict__["_gen_ring"]
+    assert all(sa.tensor.data_ptr() != sb.tensor.data_ptr() for sa in ring_a for sb in ring_b)
+    assert all(s.tensor.is_pinned() and s.host.ctypes.data == s.tensor.data_ptr() for s in ring_b)
+    # the same through a move inside a sampler, as MultiStateSampler holds it
+    move = ca.mcmc.LangevinDynamicsMove(timestep=2.0 * ca.unit.femtoseconds, number_of_steps=120)
+    sampler = ca.mcmc.MCMCSampler(ca.mcmc.MoveSchedule([("langevin", move)]))
+    s1, t1, n1 = sampler.run(copy.deepcopy(out1), thermo, n_iterations=1, nbr_list=copy.deepcopy(nbr1))
+    sampler2 = copy.deepcopy(sampler)
+    s2, _, _ = sampler2.run(copy.deepcopy(s1), thermo, n_iterations=1, nbr_list=copy.deepcopy(n1))
+    s3, _, _ = sampler.run(copy.deepcopy(s1), thermo, n_iterations=1, nbr_list=copy.deepcopy(n1))
+    assert torch.isfinite(s2.positions).all() and torch.equal(s2.positions, s3.positions)

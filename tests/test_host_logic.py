@@ -281,7 +281,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/chx.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
-    assert lib.chx_version() == 1
+    assert lib.chx_version() == _lib.ABI_VERSION == 2
     # struct layouts agree with the header (x86-64 SysV)
     assert ctypes.sizeof(_lib.Box) == 16
     assert ctypes.sizeof(_lib.LangevinParams) == 224 == lib.chx_sizeof_langevin_t()
@@ -399,7 +399,7 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
     p.n = 0
     failed(lib.chx_mc_displace_chunk(ctypes.byref(p), 0, 1, None), "n <= 0")
     # the threshold helper and the grid helper are pure host functions
-    assert lib.chx_version() == 1
+    assert lib.chx_version() == _lib.ABI_VERSION == 2
 
 
 def test_sampler_state_copy_with_and_box_token():
@@ -648,3 +648,88 @@ def test_gpu_local_cpus_reads_the_numa_neighbourhood_from_sysfs(tmp_path, monkey
     monkeypatch.delenv("HIP_VISIBLE_DEVICES")
     assert D.gpu_local_cpus(0, str(tmp_path / "nowhere")) is None
     assert D._parse_cpulist("3,5-7\n") == [3, 5, 6, 7]
+
+
+# ---------------------------------------------------------------------------
+# round 3: advisor findings
+# ---------------------------------------------------------------------------
+def test_integrator_copies_drop_per_process_device_state():
+    """MultiStateSampler deep-copies its sampler (chiron/multistate.py:266-268).  What a run() leaves on the
+    integrator -- host-mapped pinned slots the step kernel stores into, device scratch, identity-keyed caches --
+    must not be cloned (a deep-copied pinned tensor is pageable, its numpy view no longer aliases it) nor shared."""
+    import pickle
+
+    from chiron_amd.integrators import LangevinIntegrator
+    from chiron_amd.mcmc import LangevinDynamicsMove
+
+    integ = LangevinIntegrator(timestep=2.0 * unit.femtoseconds, report_interval=7)
+    marker = object()
+    for name in LangevinIntegrator._PER_PROCESS_STATE:
+        setattr(integ, name, marker)
+    integ.n_rebuilds = 3
+    for clone in (copy.deepcopy(integ), copy.copy(integ), pickle.loads(pickle.dumps(LangevinIntegrator(report_interval=7)))):
+        for name in LangevinIntegrator._PER_PROCESS_STATE:
+            assert name not in clone.__dict__, name
+        assert clone.report_interval == 7
+    clone = copy.deepcopy(integ)
+    assert clone.n_rebuilds == 3 and clone.timestep is not integ.timestep
+    assert clone.timestep.value_in_unit(unit.femtoseconds) == 2.0
+    assert getattr(integ, "_gen_ring") is marker  # the original keeps its resources
+    # through the objects that hold an integrator
+    move = LangevinDynamicsMove(timestep=1.0 * unit.femtoseconds, number_of_steps=5)
+    move.integrator._gen_ring = marker
+    m2 = copy.deepcopy(move)
+    assert m2.integrator is not move.integrator and "_gen_ring" not in m2.integrator.__dict__
+    assert move.integrator._gen_ring is marker
+
+
+def test_cell_build_refuses_a_grid_axis_beyond_its_packed_coordinates():
+    """The cell kernels carry a cell's grid coordinates in 10 bits per axis; a caller-supplied grid with a longer
+    axis would alias cells silently (advisor finding, round 2).  Refused before any launch."""
+    import ctypes
+
+    from chiron_amd import _lib
+
+    lib = _lib.load()
+    box = _lib.Box(1, 4000.0, 10.0, 10.0)
+    nc = (ctypes.c_int32 * 3)(2000, 3, 3)
+    p = ctypes.c_void_p(64)
+    rc = lib.chx_nl_build_cell(p, 8, 8, box, ctypes.c_float(1.5), nc, p, p, p, p, p, p, p, p, None)
+    assert rc < 0 and "1024 cells per axis" in lib.chx_last_error().decode()
+    rc = lib.chx_nl_build_cell_fl(p, 8, 8, box, ctypes.c_float(1.5), nc, p, p, p, p, p, p, p, p, 4, 1, p, p, p, None)
+    assert rc < 0 and "1024 cells per axis" in lib.chx_last_error().decode()
+    # the helper itself never hands out such a grid
+    total = lib.chx_cell_grid_h(_lib.Box(1, 4000.0, 4000.0, 4000.0), ctypes.c_float(1.5), 1 << 30, nc)
+    assert max(nc) <= 1024 and total == nc[0] * nc[1] * nc[2]
+
+
+def test_reporter_npz_round_trip(tmp_path):
+    """the on-disk log keeps the reference's layout -- one array per key, first axis = frames
+    (chiron/reporters.py:133-144) -- and reads back what was reported, across flushes and a second save."""
+    from chiron_amd.reporters import BaseReporter, LangevinDynamicsReporter, MCReporter
+
+    BaseReporter.set_directory(str(tmp_path / "logs"))
+    try:
+        rep = LangevinDynamicsReporter(buffer_size=2)
+        assert str(rep.log_file_path).endswith("langevin_reporter.npz")
+        frames = []
+        for i in range(5):
+            x = torch.full((4, 3), float(i))
+            frames.append(x.numpy().copy())
+            rep.report({"positions": x, "potential_energy": np.float32(-i), "step": i, "box_vectors": np.eye(3, dtype=np.float32)})
+        path = rep.save()
+        back = LangevinDynamicsReporter.load(path)
+        assert sorted(back) == ["box_vectors", "positions", "potential_energy", "step"]
+        assert back["positions"].shape == (5, 4, 3) and back["box_vectors"].shape == (5, 3, 3)
+        assert np.array_equal(back["positions"], np.stack(frames))
+        assert np.array_equal(back["step"], np.arange(5)) and np.array_equal(back["potential_energy"], -np.arange(5, dtype=np.float32))
+        for key in back:  # the file equals what get_property serves from memory
+            assert np.array_equal(back[key], rep.get_property(key)), key
+        rep.report({"positions": torch.zeros(4, 3), "potential_energy": np.float32(9), "step": 5, "box_vectors": np.eye(3, dtype=np.float32)})
+        again = LangevinDynamicsReporter.load(rep.save())
+        assert again["positions"].shape[0] == 6 and int(again["step"][-1]) == 5
+        mc = MCReporter(1)
+        mc.report({"n_accepted": 3})
+        assert MCReporter.load(mc.save(tmp_path / "mc.npz"))["n_accepted"].tolist() == [3]
+    finally:
+        BaseReporter.set_directory(None)

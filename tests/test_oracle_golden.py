@@ -1,5 +1,6 @@
 """Pin the CPU oracle against every known answer the reference's tests hold."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -399,3 +400,60 @@ def test_c_oracle_cell_omp_variant_is_bit_identical_to_the_faithful_port():
             assert s2["rebuilds"] == s1["rebuilds"] and s2["threads"] == threads
             assert np.array_equal(x1, x2) and np.array_equal(v1, v2)
     assert CO.effective_cores() >= 1
+
+
+def test_c_oracle_full_size_checkers_against_the_numpy_oracle():
+    """The two routines the full-size GPU tests lean on (every list row, every particle's fp64 force at N = 32 768 /
+    262 144) pinned at sizes the NumPy oracle reaches: full rows through the C cell grid give the O(N^2) half list
+    bit for bit; the fp64 cell-list energy / forces equal the fp64 brute force over all pairs."""
+    from oracle import c_oracle as CO
+
+    sigma, eps, cutoff, skin = 0.34, 0.238 * 4.184, 1.02, 0.5
+    for n, rho, seed in ((1500, 0.5, 11), (4096, 0.1, 12), (900, 0.8, 13)):
+        x, box = O.lj_lattice(n, rho, sigma, seed=seed)
+        rng = np.random.default_rng(seed)
+        x = O.periodic_wrap((x + rng.normal(0, 0.03, x.shape)).astype(np.float32), box)
+        rows, deg = CO.full_rows_cell(x, box, cutoff + skin, threads=2, cap0=8)  # (cap0 small: the growth path runs)
+        nn, flat = CO.half_list_from_full_rows(rows, deg)
+        m = int(nn.max()) + 1
+        mask, nl, nnbr = CO.nl_build_fixed(x, box, cutoff + skin, m)
+        real = np.arange(m)[None, :] < nnbr[:, None]
+        assert np.array_equal(nn, nnbr) and np.array_equal(flat, nl[real])
+        # ... and the NumPy oracle's row for a few particles
+        for i in (0, n // 2, n - 2):
+            _, d = O.periodic_displacement(np.broadcast_to(x[i], (n, 3)), x, box)
+            want = np.nonzero((d < np.float32(cutoff + skin)) & (np.arange(n) > i))[0]
+            assert np.array_equal(rows[i, :deg[i]][rows[i, :deg[i]] > i], want)
+        e, f, eabs, fabs, pairs = CO.lj_cell_f64(x, box, sigma, eps, cutoff, threads=2, cap0=4)
+        # (the C routine takes fp32 parameters, like the kernels: hand the brute force the same rounded values)
+        e64, f64, eabs64, fmax64 = O.lj_bruteforce_f64(x, box, float(f32(sigma)), float(f32(eps)), float(f32(cutoff)))
+        assert abs(e - e64) <= 1e-12 * eabs64 and abs(eabs - eabs64) <= 1e-12 * eabs64
+        assert np.abs(f - f64).max() <= 1e-11 * max(1.0, fmax64)
+        assert pairs > n  # a fluid, not a gas of isolated particles
+
+
+def test_c_oracle_binary_cannot_go_stale(tmp_path, monkeypatch):
+    """oracle/_build/liboracle.so carries the hash of oracle.c + flags; build() recompiles on any difference and
+    c_oracle.lib() always goes through build() (round-2 review: an existing binary used to load unchecked)."""
+    import shutil
+
+    from oracle import build_oracle
+
+    assert build_oracle.binary_hash(build_oracle.build()) == build_oracle.source_hash()
+    src = tmp_path / "oracle.c"
+    shutil.copy(build_oracle.SRC, src)
+    out = tmp_path / "liboracle.so"
+    monkeypatch.setattr(build_oracle, "SRC", str(src))
+    monkeypatch.setattr(build_oracle, "OUT", str(out))
+    monkeypatch.setattr(build_oracle, "OUT_DIR", str(tmp_path))
+    build_oracle.build()
+    first = build_oracle.binary_hash(str(out))
+    assert first == build_oracle.source_hash()
+    stamp = out.stat().st_mtime_ns
+    build_oracle.build()
+    assert out.stat().st_mtime_ns == stamp  # current: not rebuilt
+    src.write_text(src.read_text() + "\n/* edited */\n")
+    os.utime(src, ns=(1, 1))  # an OLD mtime: file times are not what decides
+    assert build_oracle.binary_hash(str(out)) != build_oracle.source_hash()
+    build_oracle.build()
+    assert build_oracle.binary_hash(str(out)) == build_oracle.source_hash() != first
