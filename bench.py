@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--kernel-reps", type=int, default=200)
     ap.add_argument("--cpu-steps", type=int, default=-1, help="steps of the CPU baseline (-1 = auto, 0 = skip)")
     ap.add_argument("--extra-c4", type=int, default=1, help="also report the N=262,144 pair-force roofline (1 GPU runs)")
+    ap.add_argument("--c4-equilibration", type=int, default=20000,
+                    help="steps (fs) the N=262,144 fluid is propagated from the lattice start before anything is quoted on it")
+    ap.add_argument("--extra-c2", type=int, default=1, help="also report C2 (N=512, all-pairs path) steps/s and pairs/s (1 GPU runs)")
     ap.add_argument("--extra-overlap", type=int, default=1,
                     help="also report the aggregate rate of TWO independent replicas of the workload driven from two "
                          "threads / HIP streams on the one card (1 GPU runs; not the headline: one replica per GPU)")
@@ -242,10 +245,9 @@ def time_kernels(fluid, pot, state, nbr, integ, reps: int, spin_s: float = 1.0):
             torch.cuda.synchronize()
 
     def timed(fn, count, before_each=None):
-        """Fastest of seven event-timed repetitions of `count` launches each, and all seven.  Everything that disturbs a
-        sample only ever ADDS to it -- a momentary clock dip, and above all the host: some processes launch in bursts
-        slower than this kernel runs (the runtime's lock collisions), the queue runs dry and the
-        events then time the host.  The figure wanted here is the kernel's."""
+        """MEDIAN of seven event-timed repetitions of `count` launches each, and all seven (round-2 review: the headline
+        statistic is the median; a disturbed sample -- a clock dip, a host that launches in bursts slower than the
+        kernel runs -- shows in the list beside it)."""
         for _ in range(10):
             fn()
         samples = []
@@ -261,7 +263,7 @@ def time_kernels(fluid, pot, state, nbr, integ, reps: int, spin_s: float = 1.0):
             stop.record()
             torch.cuda.synchronize()
             samples.append(start.elapsed_time(stop) * 1e-3 / count)
-        return min(samples), [round(1e6 * v, 3) for v in samples]
+        return sorted(samples)[len(samples) // 2], [round(1e6 * v, 3) for v in samples]
 
     spin(spin_s)
     t_force, force_samples = timed(force_launch, reps)
@@ -302,9 +304,66 @@ def time_kernels(fluid, pot, state, nbr, integ, reps: int, spin_s: float = 1.0):
     t_step /= per_call
     p_nl = int(torch.minimum(nbr.n_neighbors, torch.tensor(nbr.n_max_neighbors, device=x4.device)).sum().item())
     fl.timing_samples_us = {"step": [round(v / per_call, 3) for v in step_samples], "force": force_samples,
-                            "statistic": "fastest of 7 event-timed samples (per-launch averages over "
+                            "statistic": "median of 7 event-timed samples (per-launch averages over "
                                          f"{max(2, reps // 10) * per_call} step / {reps} force launches each)"}
     return t_step, t_force, p_nl, fl
+
+
+def c2_block(chunk: int, steps: int = 20000):
+    """BASELINE.json's C2 ("report for C2-C4 on 1 GPU"): LJ fluid N = 512 at rho* = 0.1 with the all-pairs
+    structure (PairListNsqrd, PBC, chiron/neighbors.py:910-1289; workload of Examples/LJ_langevin.py:80-91) through
+    LangevinIntegrator.run -- one k_ap_step launch per MD step.  Compute-bound by construction (24 N algorithmic
+    bytes for N(N-1)/2 pair evaluations), so the kernel is quoted in pairs/s, not GB/s."""
+    import torch
+
+    from chiron_amd import ops, unit
+    from chiron_amd._device import as_tensor
+    from chiron_amd.integrators import _RunState, langevin_constants
+    from chiron_amd.neighbors import OrthogonalPeriodicSpace, PairListNsqrd
+    from chiron_amd.utils import get_list_of_mass
+
+    fluid, pot, state, thermo, _, integ = make_system("c2", 300.0, chunk, "cell")
+    n = fluid.n_particles
+    pl = PairListNsqrd(OrthogonalPeriodicSpace(), cutoff=3.0 * SIGMA_NM * unit.nanometer)
+    state, pl = integ.run(state, thermo, number_of_steps=2000, nbr_list=pl)  # warm-up, velocities, scratch
+    torch.cuda.synchronize()
+    rates = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        state, pl = integ.run(state, thermo, number_of_steps=steps, nbr_list=pl)
+        torch.cuda.synchronize()
+        rates.append(steps / (time.perf_counter() - t0))
+    # the kernel alone: back-to-back launches, 64 per C call, HIP events on the launch stream
+    half_dt, a, b = langevin_constants(integ.timestep, integ.collision_rate)
+    mass = as_tensor(get_list_of_mass(fluid.topology).value_in_unit_system(unit.md_unit_system))
+    st = _RunState(integ, pot, pl, state.positions, state.velocities, mass, 2.494, half_dt, a, b, state.current_PRNG_key, None, "pairs")
+    step = [0]
+
+    def one_chunk():
+        even, odd = (st.x_a, st.x_b) if (step[0] & 1) == 0 else (st.x_b, st.x_a)
+        ops.langevin_fused_chunk(st.params, even, odd, step[0], 64, 2, 1)
+        step[0] += 64
+
+    for _ in range(10):
+        one_chunk()
+    samples = []
+    for _ in range(7):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            one_chunk()
+        e1.record()
+        torch.cuda.synchronize()
+        samples.append(e0.elapsed_time(e1) * 1e-3 / (20 * 64))
+    t_k = sorted(samples)[3]
+    pairs = n * (n - 1) // 2
+    return {"workload": f"LJ fluid N={n} rho*=0.1, PairListNsqrd (all pairs, PBC) + LangevinIntegrator, one k_ap_step launch per step",
+            "n_particles": n, "steps_per_s": round(sorted(rates)[1], 2), "steps_per_s_windows": [round(r, 2) for r in rates],
+            "timed_steps_per_window": steps, "kernel": "k_ap_step<64> (all-pairs force + BAOAB + wrap, a wavefront per particle)",
+            "kernel_us": round(1e6 * t_k, 3), "kernel_us_samples": [round(1e6 * v, 3) for v in samples],
+            "pairs_per_launch": pairs, "pairs_per_s": round(pairs / t_k, 1), "algorithmic_bytes": (24 + 72) * n,
+            "bound": "launch latency / fp32 VALU (compute-bound by construction: report pairs/s, SURVEY 8d)"}
 
 
 def roofline_entry(kind: str, n: int, p_nl: int, seconds: float, extra=None):
@@ -333,18 +392,25 @@ def roofline_entry(kind: str, n: int, p_nl: int, seconds: float, extra=None):
     }
     if extra:
         d.update(extra)
-    # HBM traffic per launch from the committed PMC passes (profiles/pmc_traffic.json: separate
-    # rocprofv3 --pmc runs, 2 x FETCH_SIZE + WRITE_SIZE with the gfx950 correction); those passes
-    # profile the same kernel on the same box geometry at the lattice start state.
+    # HBM traffic per launch from the committed PMC passes (profiles/pmc_traffic.json: separate rocprofv3 --pmc runs of
+    # scripts/pmc_collect.sh, 2 x FETCH_SIZE + WRITE_SIZE with the gfx950 correction).  One system state per entry
+    # (round-2 review): the passes run on the fluid equilibrated for `equilibration_steps` steps and record its P_nl;
+    # the counters are quoted only when this run's list holds the same number of pairs to 2 %.
     wl = {32768: "c3", 262144: "c4"}.get(n)
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             pmc = json.load(fh).get(f"{wl}:{'k_lj_step' if kind == 'step' else 'k_lj_fl'}")
         if pmc:
-            d["traffic"] = int(pmc["traffic_bytes"])
-            d["hbm_GBps_measured"] = round(pmc["traffic_bytes"] / seconds / 1e9, 2)
-            d["traffic_source"] = ("profiles/r02_pmc_hot_kernels.md (separate rocprofv3 --pmc passes over this kernel at the "
-                                   "lattice start state of the same box geometry; not collected in this run)")
+            pmc_pairs = pmc.get("list_pairs")
+            if pmc_pairs and abs(pmc_pairs - p_nl) <= 0.02 * p_nl:
+                d["traffic"] = int(pmc["traffic_bytes"])
+                d["hbm_GBps_measured"] = round(pmc["traffic_bytes"] / seconds / 1e9, 2)
+                d["traffic_source"] = (f"{pmc.get('source', 'profiles/pmc_traffic.json')}: separate rocprofv3 --pmc passes over this "
+                                       f"kernel on the same box geometry equilibrated for {pmc.get('equilibration_steps')} steps "
+                                       f"(P_nl = {pmc_pairs}, this run {p_nl}); not collected in this run")
+            else:
+                d["traffic_note"] = (f"profiles/pmc_traffic.json was collected on a state with P_nl = {pmc_pairs}; this run's list "
+                                     f"holds {p_nl} pairs: not the same system state, traffic withheld")
     except (OSError, ValueError):
         pass
     return d
@@ -644,7 +710,8 @@ def main():
         # hot kernels, timed live on the same device / list state
         t_step, t_force, p_nl, fl = time_kernels(fluid, pot, state, nbr, integ, args.kernel_reps)
         sclk["after_kernel_timing"] = read_sclk_mhz(local_rank)
-        info = {"lanes_per_particle": fl.g, "max_degree": fl.maxdeg}
+        info = {"lanes_per_particle": fl.g, "max_degree": fl.maxdeg,
+                "system_state": "the replica as the timed regions left it (equilibrated; list from its last rebuild)"}
         ts_ = getattr(fl, "timing_samples_us", None) or {}
         roof = roofline_entry("step", n, p_nl, t_step, dict(info, kernel_us_samples=ts_.get("step"), statistic=ts_.get("statistic")))
         roof_force = roofline_entry("force", n, p_nl, t_force, dict(info, kernel_us_samples=ts_.get("force"), statistic=ts_.get("statistic")))
@@ -697,23 +764,34 @@ def main():
                 out["two_replicas_one_gpu"] = two_replica_overlap(args, args.steps if args.steps >= 2000 else 20000)
             except Exception as exc:  # pragma: no cover - diagnostics only
                 out["two_replicas_one_gpu"] = {"error": repr(exc)}
+        if world == 1 and args.extra_c2 and args.workload != "c2":
+            try:
+                out["c2"] = c2_block(args.chunk)
+            except Exception as exc:  # pragma: no cover - diagnostics only
+                out["c2"] = {"error": repr(exc)}
         if world == 1 and args.extra_c4 and args.workload != "c4":
             try:
                 fluid4, pot4, state4, thermo4, nbr4, integ4 = make_system("c4", 300.0, args.chunk, "cell")
-                nbr4.build_from_state(state4)
+                # ONE system state for everything quoted at C4 (round-2 review): the fluid equilibrated for
+                # --c4-equilibration steps (20 ps) -- the lattice start has 17 % fewer listed pairs and runs 10 % faster
+                state4, nbr4 = integ4.run(state4, thermo4, number_of_steps=args.c4_equilibration, nbr_list=nbr4)
+                torch.cuda.synchronize()
                 ts4, tf4, p4, fl4 = time_kernels(fluid4, pot4, state4, nbr4, integ4, args.kernel_reps)
-                info4 = {"lanes_per_particle": fl4.g, "max_degree": fl4.maxdeg}
+                info4 = {"lanes_per_particle": fl4.g, "max_degree": fl4.maxdeg, "equilibration_steps": args.c4_equilibration}
                 ts4_ = getattr(fl4, "timing_samples_us", None) or {}
-                out["roofline_262k"] = roofline_entry("force", fluid4.n_particles, p4, tf4, dict(info4, kernel_us_samples=ts4_.get("force")))
-                out["roofline_262k_step"] = roofline_entry("step", fluid4.n_particles, p4, ts4, dict(info4, kernel_us_samples=ts4_.get("step")))
-                # (past the lattice start: the fluid clusters over the first picoseconds and the lists grow)
-                state4, nbr4 = integ4.run(state4, thermo4, number_of_steps=1000, nbr_list=nbr4)  # warm-up
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                integ4.run(state4, thermo4, number_of_steps=4000, nbr_list=nbr4)
-                torch.cuda.synchronize()
-                out["steps_per_s_262k"] = round(4000 / (time.perf_counter() - t0), 2)
-                out["rebuilds_262k"] = integ4.n_rebuilds
+                out["roofline_262k"] = roofline_entry("force", fluid4.n_particles, p4, tf4, dict(info4, kernel_us_samples=ts4_.get("force"), statistic=ts4_.get("statistic")))
+                out["roofline_262k_step"] = roofline_entry("step", fluid4.n_particles, p4, ts4, dict(info4, kernel_us_samples=ts4_.get("step"), statistic=ts4_.get("statistic")))
+                rates4, rb4 = [], []
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    state4, nbr4 = integ4.run(state4, thermo4, number_of_steps=4000, nbr_list=nbr4)
+                    torch.cuda.synchronize()
+                    rates4.append(round(4000 / (time.perf_counter() - t0), 2))
+                    rb4.append(integ4.n_rebuilds)
+                out["steps_per_s_262k"] = sorted(rates4)[1]
+                out["steps_per_s_262k_windows"] = rates4
+                out["rebuilds_262k"] = rb4[rates4.index(sorted(rates4)[1])]
                 del fluid4, pot4, state4, nbr4
             except Exception as exc:  # pragma: no cover - diagnostics only
                 out["roofline_262k"] = {"error": repr(exc)}

@@ -7,6 +7,19 @@ on gfx950 -- MI355X_MICROARCH.md, HBM / rocprofv3 section), averaged over the di
 import collections, csv, glob, json, os, re, sys
 
 root, out_json, out_md = sys.argv[1:4]
+# the system state the passes ran on: P_nl per workload from the benchmark's own output, equilibration from meta.json
+pairs = {}
+for f in sorted(glob.glob(os.path.join(root, "pass*.log"))):
+    for line in open(f, errors="replace"):
+        m = re.match(r"(c\d\w*) g=\d+ .*P_nl=(\d+)", line)
+        if m:
+            pairs.setdefault(m.group(1), set()).add(int(m.group(2)))
+for wl, v in pairs.items():
+    assert len(v) == 1, f"the passes of {wl} did not run on one state: P_nl = {sorted(v)}"
+try:
+    meta = json.load(open(os.path.join(root, "meta.json")))
+except OSError:
+    meta = {}
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
@@ -32,6 +45,9 @@ for (wl, kern, g), c in sorted(acc.items()):
     write = avg.get("WRITE_SIZE", 0.0) * 1024
     e = {
         "lanes_per_particle": g,
+        "list_pairs": (sorted(pairs[wl])[0] if wl in pairs else None),
+        "equilibration_steps": meta.get("equilibration_steps"),
+        "source": f"profiles/{os.path.basename(out_md)}",
         "fetch_size_bytes_raw": fetch,
         "write_size_bytes": write,
         "traffic_bytes": 2 * fetch + write,
@@ -50,7 +66,8 @@ for (wl, kern, g), c in sorted(acc.items()):
 json.dump(res, open(out_json, "w"), indent=1)
 with open(out_md, "w") as fh:
     fh.write("# PMC passes over the hot kernels (scripts/pmc_collect.sh: one counter group per rocprofv3 --pmc pass,\n"
-             "# `python3 scripts/kernel_bench.py c3 c4`, lattice start state)\n\n"
+             f"# `python3 scripts/kernel_bench.py c3 c4` on the fluid equilibrated for {meta.get('equilibration_steps')} steps; "
+             f"P_nl = {dict((k, sorted(v)[0]) for k, v in pairs.items())})\n\n"
              "HBM traffic per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters, gfx950 FETCH_SIZE correction).\n\n"
              "| workload | kernel | HBM traffic MB | FETCH_SIZE MB (raw) | WRITE_SIZE MB | L2 hit | L1 hit | SQ_WAIT_ANY / wave cycles | "
              "SQ_ACTIVE_INST_ANY / wave cycles | VALU wave instructions |\n|---|---|---:|---:|---:|---:|---:|---:|---:|---:|\n")
