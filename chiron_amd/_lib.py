@@ -55,7 +55,14 @@ class LangevinParams(C.Structure):
         ("prune_every", C.c_int32),
         ("prune_phase", C.c_int64),
         ("host_ctrl", C.c_void_p),
+        ("snap4", C.c_void_p),
+        ("trigger_frac", C.c_float),
+        ("ev_log_cap", C.c_int32),
+        ("ev_log", C.c_void_p),
     ]
+
+
+CTRL_WORDS = 16  # include/chx.h: CHX_CTRL_WORDS
 
 
 class McParams(C.Structure):
@@ -116,10 +123,11 @@ SIGNATURES = {
     ),
     "chx_nl_build_cell_fl": (
         C.c_int,
-        [_P, _I32, _I32, Box, _F, C.POINTER(_I32), _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P],
+        [_P, _I32, _I32, Box, _F, C.POINTER(_I32), _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _I32, _P],
     ),
     "chx_nl_finish_padding": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),
-    "chx_pack_langevin": (C.c_int, [_P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "chx_pack_langevin": (C.c_int, [_P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _I32, _P, _P, _P]),
+    "chx_repack_langevin": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _I32, _P]),
     "chx_nl_calculate": (C.c_int, [_P, _P, _P, _I32, _I32, Box, _F, _P, _P, _P, _P, _P]),
     "chx_nl_check": (C.c_int, [_P, _P, _I32, Box, _F, _P, _P]),
     "chx_pl_build": (C.c_int, [_I32, _P, _P, _P]),
@@ -140,7 +148,7 @@ SIGNATURES = {
     "chx_langevin_chunk": (C.c_int, [C.POINTER(LangevinParams), _I64, _I32, _I32, _P]),
     "chx_langevin_resume": (C.c_int, [C.POINTER(LangevinParams), _P]),
     "chx_langevin_fused_chunk": (C.c_int, [C.POINTER(LangevinParams), _P, _P, _I64, _I32, _I32, _I32, _P]),
-    "chx_langevin_fused_run": (C.c_int, [C.POINTER(LangevinParams), _P, _P, _I64, _I32, _I32, _I32, C.POINTER(C.c_int32), _P]),
+    "chx_langevin_fused_run": (C.c_int, [C.POINTER(LangevinParams), _P, _P, _I64, _I32, _I32, _I32, _I32, C.POINTER(C.c_int32), _P]),
     "chx_ctrl_reset": (C.c_int, [_P, _P]),
     "chx_publish": (C.c_int, [_P, _P, _I32, _P]),
     "chx_mc_displace": (C.c_int, [_P, _P, _P, _I32, _F, Box, _U32, _U32, _U32, _P, _P]),

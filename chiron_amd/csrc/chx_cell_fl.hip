@@ -186,10 +186,12 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
     int32_t* __restrict__ n_nbr, int fg, int fcap, uint32_t* __restrict__ fl, int32_t* __restrict__ deg,
     int32_t* __restrict__ status) {
   __shared__ uint32_t cand_all[4][CHX_CELL_CAP];
-  const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (w >= n) return;
-  build_row_of_particle<true>(w, cand_all[threadIdx.x >> 6], xs4, n, m, box, T, g, cell_start, sorted_ids, nl, first_out,
-                              n_nbr, fg, fcap, fl, deg, status);
+  // (grid-stride over the rows: a launch with fewer wavefronts than rows -- the background builds of the deferred
+  // scheme, which must leave most wave slots to the step kernels running beside them -- walks several rows per wave)
+  const int waves = (int)((gridDim.x * blockDim.x) >> 6);
+  for (int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += waves)
+    build_row_of_particle<true>(w, cand_all[threadIdx.x >> 6], xs4, n, m, box, T, g, cell_start, sorted_ids, nl, first_out,
+                                n_nbr, fg, fcap, fl, deg, status);
 }
 
 // One wavefront per CELL: the (about ten at the BASELINE density) particles of a cell share their 27-cell
@@ -442,7 +444,7 @@ extern "C" int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_
                                     int32_t* cell_count, int32_t* cell_start, uint32_t* sorted_ids,
                                     int32_t* status8, uint32_t* nl_rows_out, uint32_t* first_out,
                                     int32_t* n_nbr_out, int32_t g, int32_t chunks, uint32_t* fl_out,
-                                    int32_t* deg_out, float* xs4_out, chx_stream_t stream) {
+                                    int32_t* deg_out, float* xs4_out, int32_t max_blocks, chx_stream_t stream) {
   CHX_REQUIRE(n >= 1 && m >= 1, "need n >= 1, m >= 1");
   CHX_REQUIRE(xyz && nc_h && cell_of && cell_count && cell_start && sorted_ids && status8 &&
                   nl_rows_out && first_out && n_nbr_out && fl_out && deg_out && xs4_out,
@@ -465,7 +467,8 @@ extern "C" int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_
   static const int forced = [] { const char* e = getenv("CHX_BUILD_KERNEL"); return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'c' ? 2 : 0)); }();
   const bool per_particle = forced == 1 || (forced == 0 && (int64_t)grid.ncx * grid.ncy * grid.ncz < 8192);
   if (per_particle) {
-    hipLaunchKernelGGL(k_nl_build_cell_fl, dim3(wb), dim3(256), 0, st, xs4, n, m, make_box3(box), T, grid,
+    const unsigned pb = (max_blocks > 0 && (unsigned)max_blocks < wb) ? (unsigned)max_blocks : wb;
+    hipLaunchKernelGGL(k_nl_build_cell_fl, dim3(pb), dim3(256), 0, st, xs4, n, m, make_box3(box), T, grid,
                        cell_of, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, chunks * CHX_FL_QUAD * g,
                        fl_out, deg_out, status8);
   } else {
@@ -516,13 +519,17 @@ __global__ void k_pack_langevin(const float* __restrict__ x3, const float* __res
                                 const float* __restrict__ mass, const float* __restrict__ ref3,
                                 const uint32_t* __restrict__ perm, int n, float4* __restrict__ x4,
                                 float* __restrict__ v, float* __restrict__ mass_out,
-                                float4* __restrict__ ref4, int32_t* __restrict__ ctrl,
+                                float4* __restrict__ ref4, int32_t* __restrict__ ctrl, int ctrl_keep,
                                 const int32_t* __restrict__ pub_src, int32_t* __restrict__ pub_host) {
   // riders of the integrator's rebuild (one launch instead of three): the control-block reset of chx_ctrl_reset
   // and the copy of the build's status block to host-mapped memory of chx_publish
   if (blockIdx.x == 0) {
     const int t = threadIdx.x;
-    if (ctrl != nullptr && t < 8) ctrl[t] = t == 3 ? 0x7FFFFFFF : ((t == 4 || t == 5) ? -2 : 0);
+    if (ctrl != nullptr && t < CHX_CTRL_WORDS) {
+      // (deferred rebuilds: the reference's event counters / booked events survive a repack into another order)
+      const bool keep = ((ctrl_keep & 1) && (t == 8 || t == 9)) || ((ctrl_keep & 2) && (t == 10 || t == 11));
+      if (!keep) ctrl[t] = chx_ctrl_reset_word(t);
+    }
     if (pub_src != nullptr && t >= 64 && t < 72)
       __hip_atomic_store(&pub_host[t - 64], pub_src[t - 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -541,7 +548,8 @@ __global__ void k_pack_langevin(const float* __restrict__ x3, const float* __res
 extern "C" int chx_pack_langevin(const float* x3, const float* v3, const float* mass,
                                  const float* ref3, const uint32_t* perm, int32_t n, float* x4_out,
                                  float* v_out, float* mass_out, float* ref4_out, int32_t* ctrl_reset,
-                                 const int32_t* publish_src8, int32_t* publish_host_dst8, chx_stream_t stream) {
+                                 int32_t ctrl_keep, const int32_t* publish_src8, int32_t* publish_host_dst8,
+                                 chx_stream_t stream) {
   CHX_REQUIRE(n >= 0, "n < 0");
   CHX_REQUIRE((publish_src8 == nullptr) == (publish_host_dst8 == nullptr), "publish needs both a source and a destination");
   if (n == 0 && !ctrl_reset && !publish_src8) return CHX_OK;
@@ -550,6 +558,55 @@ extern "C" int chx_pack_langevin(const float* x3, const float* v3, const float* 
   const unsigned blocks = n > 0 ? (unsigned)((n + 255) / 256) : 1u;
   hipLaunchKernelGGL(k_pack_langevin, dim3(blocks), dim3(256), 0, chx_stream(stream), x3, v3, mass,
                      ref3, perm, n, reinterpret_cast<float4*>(x4_out), v_out, mass_out,
-                     reinterpret_cast<float4*>(ref4_out), ctrl_reset, publish_src8, publish_host_dst8);
+                     reinterpret_cast<float4*>(ref4_out), ctrl_reset, (int)ctrl_keep, publish_src8,
+                     publish_host_dst8);
   return chx_check_launch("chx_pack_langevin");
+}
+
+// ---------------------------------------------------------------------------
+// deferred rebuilds: the state changes its internal order on the device (include/chx.h: chx_repack_langevin)
+// ---------------------------------------------------------------------------
+__global__ void k_repack_invert(const uint32_t* __restrict__ perm_old, int n, uint32_t* __restrict__ inv) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) inv[perm_old[q]] = (uint32_t)q;
+}
+
+__global__ void k_repack_langevin(const float4* __restrict__ x_old, const float* __restrict__ v_old,
+                                  const float4* __restrict__ ref_old, const uint32_t* __restrict__ inv,
+                                  const uint32_t* __restrict__ perm_new, int n, float4* __restrict__ x_new,
+                                  float* __restrict__ v_new, float4* __restrict__ ref_new, float* __restrict__ mass_new,
+                                  int32_t* __restrict__ ctrl, int ctrl_keep) {
+  if (blockIdx.x == 0 && ctrl != nullptr && threadIdx.x < CHX_CTRL_WORDS) {
+    const int t = threadIdx.x;
+    const bool keep = ((ctrl_keep & 1) && (t == 8 || t == 9)) || ((ctrl_keep & 2) && (t == 10 || t == 11));
+    if (!keep) ctrl[t] = chx_ctrl_reset_word(t);
+  }
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t q = inv[perm_new[p]];
+  const float4 x = x_old[q];
+  const float4 r = ref_old[q];
+  x_new[p] = make_float4(x.x, x.y, x.z, 0.f);  // (.w, the path length, starts over: the first launch refreshes the inner list)
+  v_new[3 * (size_t)p] = v_old[3 * (size_t)q];
+  v_new[3 * (size_t)p + 1] = v_old[3 * (size_t)q + 1];
+  v_new[3 * (size_t)p + 2] = v_old[3 * (size_t)q + 2];
+  ref_new[p] = r;
+  mass_new[p] = r.w;
+}
+
+extern "C" int chx_repack_langevin(const float* x4_old, const float* v_old, const float* ref4_old,
+                                   const uint32_t* perm_old, const uint32_t* perm_new, uint32_t* inv_ws, int32_t n,
+                                   float* x4_new, float* v_new, float* ref4_new, float* mass_new, int32_t* ctrl_reset,
+                                   int32_t ctrl_keep, chx_stream_t stream) {
+  CHX_REQUIRE(n >= 1, "n < 1");
+  CHX_REQUIRE(x4_old && v_old && ref4_old && perm_old && perm_new && inv_ws && x4_new && v_new && ref4_new && mass_new,
+              "null pointer");
+  CHX_REQUIRE(x4_old != x4_new && v_old != v_new && ref4_old != ref4_new, "outputs must not alias the inputs");
+  hipStream_t st = chx_stream(stream);
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_repack_invert, dim3(blocks), dim3(256), 0, st, perm_old, n, inv_ws);
+  hipLaunchKernelGGL(k_repack_langevin, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(x4_old), v_old,
+                     reinterpret_cast<const float4*>(ref4_old), inv_ws, perm_new, n, reinterpret_cast<float4*>(x4_new),
+                     v_new, reinterpret_cast<float4*>(ref4_new), mass_new, ctrl_reset, (int)ctrl_keep);
+  return chx_check_launch("chx_repack_langevin");
 }

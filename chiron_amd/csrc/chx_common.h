@@ -22,6 +22,11 @@ int chx_check_launch(const char* what);
 
 static inline hipStream_t chx_stream(chx_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// word t of a freshly reset control block (include/chx.h: chx_langevin_t::ctrl, chx_ctrl_reset)
+__host__ __device__ __forceinline__ int chx_ctrl_reset_word(int t) {
+  return (t == 3 || t == 12) ? 0x7FFFFFFF : ((t == 4 || t == 5) ? -2 : ((t == 9 || t == 10 || t == 11) ? -1 : 0));
+}
+
 struct Box3 {
   int periodic;
   float lx, ly, lz;

@@ -219,7 +219,7 @@ extern "C" int chx_scale(const float* in, float* out, int64_t count, float s, ch
 __global__ void k_ctrl_reset(int32_t* __restrict__ ctrl) {
   // [3] = no halt; [4],[5] = -2: "inner list stale" words hold the refresh epoch they were raised in
   // (k_lj_step), -2 is no epoch
-  if (threadIdx.x < 8) ctrl[threadIdx.x] = threadIdx.x == 3 ? 0x7FFFFFFF : ((threadIdx.x == 4 || threadIdx.x == 5) ? -2 : 0);
+  if (threadIdx.x < CHX_CTRL_WORDS) ctrl[threadIdx.x] = chx_ctrl_reset_word((int)threadIdx.x);
 }
 
 extern "C" int chx_ctrl_reset(int32_t* ctrl, chx_stream_t stream) {

@@ -54,7 +54,7 @@ static inline int chx_lj_fl_blocks(int n, int g) { return (int)(((int64_t)n * g 
 // (i even ? x_even : x_odd) and writes the other buffer.  do_aoa == 0: force + kicks only.
 int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, int64_t step0,
                         int n_steps, int kicks_first, int do_aoa, hipStream_t st, int window = 0,
-                        int32_t* n_enqueued = nullptr);
+                        int32_t* n_enqueued = nullptr, int watch_trigger = 0);
 int chx_launch_lj_allpairs(const float* x, int stride, int n, chx_box_t box, float sigma,
                            float epsilon, float cutoff, float* f3, float* energy, double* ws,
                            int32_t* ctrl, hipStream_t st);

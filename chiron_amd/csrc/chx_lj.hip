@@ -9,6 +9,7 @@
 // particle id, chiron/neighbors.py:773-779), min-imaged as in :79, and the cutoff
 // mask is the exact `d < cutoff` of :782, so the set of interacting pairs is
 // bit-identical to the reference's; only the summation order differs.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <sched.h>
@@ -610,7 +611,7 @@ struct StepArgs {
   const float4* x_cur;
   float* x_next;  // (n,4)
   float* v;       // (n,3)
-  const float4* ref4;
+  float4* ref4;   // written only at a reference rebuild event of the deferred scheme (snap4 set)
   const float* mass;
   const uint32_t* perm;
   const uint32_t* fl;
@@ -631,6 +632,11 @@ struct StepArgs {
   int32_t* host_ctrl;   // host-mapped copy of the control block (chx_langevin_t::host_ctrl), or NULL
   float T_inner;        // r2 <= T_inner: kept by the pruning pass  ((cutoff + inner skin)^2, padded up)
   float half_inner;     // a particle whose path since the pass is longer than this invalidates the inner list
+  // deferred rebuilds (chx_langevin_t::snap4; nullptr = the halting scheme)
+  const float4* snap4;  // positions the force list was built from
+  float T_trigger;      // |x - snap|^2 > T_trigger: time to build the next list
+  int32_t* ev_log;
+  int ev_cap;
 };
 
 // operands of one particle's integrate work
@@ -641,7 +647,7 @@ struct StepParticle {
   float m;
   float bs;  // b sigma_v = b sqrt(kT / m), chiron/integrators.py:131,186
   float v[3];
-  float4 x, ref;
+  float4 x, ref, snap;
   float path0;  // path length travelled since the last pruning pass, before this step (x.w; 0 in a pruning launch)
   float z[3];
 };
@@ -656,8 +662,8 @@ struct StepParticle {
 //   * min_image_fast == min_image for |d| < L (tests/test_host_logic.py, exhaustive on the CPU).
 template <bool FAST, bool HOT>
 __device__ __forceinline__ bool integrate_component(const StepArgs& a, int n_kicks, int do_aoa, float F, float m,
-                                                    float bs, float z, float v, float xo, float rf, float L,
-                                                    float hL, float& vn, float& xn, float& sq, float& sqi) {
+                                                    float bs, float z, float v, float xo, float rf, float sf, float L,
+                                                    float hL, float& vn, float& xn, float& sq, float& sqi, float& sqs) {
   // HOT: the steady-state launch (both kicks, A-O-A, periodic wrap, skin check, inner list), with
   // the launch-uniform switches folded at compile time
   const bool periodic = HOT || a.box.periodic;
@@ -669,7 +675,7 @@ __device__ __forceinline__ bool integrate_component(const StepArgs& a, int n_kic
   const float kick = fdiv(fmul(a.hdt, F), m);
   float vc = v;
   for (int k = 0; k < n_kicks; ++k) vc = fadd(vc, kick);  // B  :181 / :195
-  xn = 0.f, sq = 0.f, sqi = 0.f;
+  xn = 0.f, sq = 0.f, sqi = 0.f, sqs = 0.f;
   if (do_aoa) {
     float xc = fadd(xo, fmul(a.hdt, vc));      // A  :183
     vc = fadd(fmul(a.a, vc), fmul(bs, z));     // O  :186
@@ -696,6 +702,18 @@ __device__ __forceinline__ bool integrate_component(const StepArgs& a, int n_kic
       }
       sq = fmul(r, r);
     }
+    if (a.snap4 != nullptr) {  // deferred rebuilds: distance from the positions the force list was built from
+      float r = fsub(xc, sf);
+      if (periodic) {
+        if (FAST) {
+          rare |= !(fabsf(r) < L);
+          r = min_image_fast(r, L, hL);
+        } else {
+          r = min_image(r, L, hL);
+        }
+      }
+      sqs = fmul(r, r);
+    }
   }
   vn = vc;
   return rare;
@@ -713,7 +731,7 @@ __device__ __forceinline__ StepParticle load_step_operands(const StepArgs& a, lo
   t.o = 0u;
   t.v[0] = t.v[1] = t.v[2] = 0.f;
   t.z[0] = t.z[1] = t.z[2] = 0.f;
-  t.x = t.ref = make_float4(0.f, 0.f, 0.f, 0.f);
+  t.x = t.ref = t.snap = make_float4(0.f, 0.f, 0.f, 0.f);
   t.path0 = 0.f;
   if (t.live) {
     // (with a Verlet list the mass rides in ref4.w -- chx_pack_langevin puts it there -- and needs no load of its own)
@@ -724,8 +742,11 @@ __device__ __forceinline__ StepParticle load_step_operands(const StepArgs& a, lo
       t.ref = a.ref4[t.pp];
       t.m = t.ref.w;
     }
+    if (a.snap4 && do_aoa) t.snap = a.snap4[t.pp];
+    // (a reference rebuild event of the deferred scheme copies the input positions into ref4 even in the force-only
+    // launch that ends a run)
+    if (do_aoa || a.snap4 != nullptr) t.x = a.x_cur[t.pp];
     if (do_aoa) {
-      t.x = a.x_cur[t.pp];
       // the path travelled since the last pruning pass rides in x4.w; a pruning launch starts it over
       t.path0 = PRUNE ? 0.f : t.x.w;
       t.o = (HOT || a.perm) ? a.perm[t.pp] : (uint32_t)t.pp;
@@ -768,47 +789,70 @@ __device__ __forceinline__ StepParticle load_step_particle(const StepArgs& a, lo
 // Returns true when this thread's particle has moved too far for the pruned inner list.
 template <bool HOT>
 __device__ __forceinline__ bool step_epilogue(const StepArgs& a, const StepParticle& tk, const float* sF, long long step,
-                                              int n_kicks, int do_aoa) {
+                                              int n_kicks, int do_aoa, bool is_event = false) {
   bool stale = false;
   if (tk.live) {
     // (three explicit calls on scalars: local arrays of box lengths here ended up as a per-thread array in LDS)
-    float vn0, vn1, vn2, xn0, xn1, xn2, sq0, sq1, sq2, si0, si1, si2;
+    float vn0, vn1, vn2, xn0, xn1, xn2, sq0, sq1, sq2, si0, si1, si2, ss0, ss1, ss2;
     const float F0 = sF[3 * threadIdx.x], F1 = sF[3 * threadIdx.x + 1], F2 = sF[3 * threadIdx.x + 2];
-    bool rare = integrate_component<true, HOT>(a, n_kicks, do_aoa, F0, tk.m, tk.bs, tk.z[0], tk.v[0], tk.x.x, tk.ref.x,
-                                               a.box.lx, a.box.hx, vn0, xn0, sq0, si0);
-    rare |= integrate_component<true, HOT>(a, n_kicks, do_aoa, F1, tk.m, tk.bs, tk.z[1], tk.v[1], tk.x.y, tk.ref.y,
-                                           a.box.ly, a.box.hy, vn1, xn1, sq1, si1);
-    rare |= integrate_component<true, HOT>(a, n_kicks, do_aoa, F2, tk.m, tk.bs, tk.z[2], tk.v[2], tk.x.z, tk.ref.z,
-                                           a.box.lz, a.box.hz, vn2, xn2, sq2, si2);
+    // deferred rebuilds: a launch that starts with a reference rebuild event measures the skin check of its new
+    // positions from its INPUT positions -- the reference positions the rebuild has just taken
+    // (chiron/integrators.py:241-242: build(x) stores ref_positions = x, chiron/neighbors.py:671)
+    const float r0 = is_event ? tk.x.x : tk.ref.x, r1 = is_event ? tk.x.y : tk.ref.y, r2 = is_event ? tk.x.z : tk.ref.z;
+    bool rare = integrate_component<true, HOT>(a, n_kicks, do_aoa, F0, tk.m, tk.bs, tk.z[0], tk.v[0], tk.x.x, r0, tk.snap.x,
+                                               a.box.lx, a.box.hx, vn0, xn0, sq0, si0, ss0);
+    rare |= integrate_component<true, HOT>(a, n_kicks, do_aoa, F1, tk.m, tk.bs, tk.z[1], tk.v[1], tk.x.y, r1, tk.snap.y,
+                                           a.box.ly, a.box.hy, vn1, xn1, sq1, si1, ss1);
+    rare |= integrate_component<true, HOT>(a, n_kicks, do_aoa, F2, tk.m, tk.bs, tk.z[2], tk.v[2], tk.x.z, r2, tk.snap.z,
+                                           a.box.lz, a.box.hz, vn2, xn2, sq2, si2, ss2);
     if (__builtin_expect(rare, 0)) {
-      (void)integrate_component<false, HOT>(a, n_kicks, do_aoa, F0, tk.m, tk.bs, tk.z[0], tk.v[0], tk.x.x, tk.ref.x,
-                                            a.box.lx, a.box.hx, vn0, xn0, sq0, si0);
-      (void)integrate_component<false, HOT>(a, n_kicks, do_aoa, F1, tk.m, tk.bs, tk.z[1], tk.v[1], tk.x.y, tk.ref.y,
-                                            a.box.ly, a.box.hy, vn1, xn1, sq1, si1);
-      (void)integrate_component<false, HOT>(a, n_kicks, do_aoa, F2, tk.m, tk.bs, tk.z[2], tk.v[2], tk.x.z, tk.ref.z,
-                                            a.box.lz, a.box.hz, vn2, xn2, sq2, si2);
+      (void)integrate_component<false, HOT>(a, n_kicks, do_aoa, F0, tk.m, tk.bs, tk.z[0], tk.v[0], tk.x.x, r0, tk.snap.x,
+                                            a.box.lx, a.box.hx, vn0, xn0, sq0, si0, ss0);
+      (void)integrate_component<false, HOT>(a, n_kicks, do_aoa, F1, tk.m, tk.bs, tk.z[1], tk.v[1], tk.x.y, r1, tk.snap.y,
+                                            a.box.ly, a.box.hy, vn1, xn1, sq1, si1, ss1);
+      (void)integrate_component<false, HOT>(a, n_kicks, do_aoa, F2, tk.m, tk.bs, tk.z[2], tk.v[2], tk.x.z, r2, tk.snap.z,
+                                            a.box.lz, a.box.hz, vn2, xn2, sq2, si2, ss2);
     }
     const float vn[3] = {vn0, vn1, vn2}, xn[3] = {xn0, xn1, xn2}, sq[3] = {sq0, sq1, sq2}, sqi[3] = {si0, si1, si2};
     // The step's results leave as WRITE-THROUGH stores (sc1): nothing the next launch needs stays dirty in
     // this XCD's L2, so the write-back at the kernel boundary has nothing to do (the boundary costs about
     // B / 6 TB/s for B dirty bytes: 7.3 MB at N = 262144), and the next launch finds L2 cold either way.
     store_wt3(a.v + 3 * (size_t)tk.pp, vn[0], vn[1], vn[2]);
+    // the reference's rebuild (its side effect on the state): reference positions := this launch's input positions
+    if (is_event) store_wt4(a.ref4 + tk.pp, make_float4(tk.x.x, tk.x.y, tk.x.z, tk.m));
     if (do_aoa) {
       // x4.w: path length since the last pruning pass (a sum of per-step displacements bounds the displacement)
       const float path = tk.path0 + __builtin_sqrtf((sqi[0] + sqi[1]) + sqi[2]);
       store_wt4(reinterpret_cast<float4*>(a.x_next) + tk.pp, make_float4(xn[0], xn[1], xn[2], path));
       // skin check :241: (rx^2 + ry^2) + rz^2 in the reference's order
-      if ((HOT || a.ref4) && fadd(fadd(sq[0], sq[1]), sq[2]) > a.T_half_skin) {
-        atomicMin(&a.ctrl[3], (int)(step + 1));
-        // (tell the host at once: the copy this launch published when it started cannot know yet)
-        if (a.host_ctrl) __hip_atomic_store(&a.host_ctrl[3], (int)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const bool moved = (HOT || a.ref4) && fadd(fadd(sq[0], sq[1]), sq[2]) > a.T_half_skin;
+      if (a.snap4 == nullptr) {
+        if (moved) {
+          atomicMin(&a.ctrl[3], (int)(step + 1));
+          // (tell the host at once: the copy this launch published when it started cannot know yet)
+          if (a.host_ctrl) __hip_atomic_store(&a.host_ctrl[3], (int)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      } else {
+        // deferred rebuilds: the reference's check only books its rebuild for the next launch (the word of the
+        // OTHER step parity: no launch reads a word its own blocks write; every writer stores the same value) ...
+        if (moved) a.ctrl[10 + (int)((step + 1) & 1)] = (int)(step + 1);
+        // ... and what halts the stream is the force list running out of its guarantee (distance from ITS positions)
+        const float d2s = (ss0 + ss1) + ss2;
+        if (d2s > a.T_half_skin) {
+          atomicMin(&a.ctrl[3], (int)(step + 1));
+          if (a.host_ctrl) __hip_atomic_store(&a.host_ctrl[3], (int)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (d2s > a.T_trigger) {
+          const int old = atomicMin(&a.ctrl[12], (int)(step + 1));
+          if (old > (int)(step + 1) && a.host_ctrl)  // (first raiser of this step: the host hears of it at once)
+            __hip_atomic_store(&a.host_ctrl[12], (int)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
       }
       if ((HOT || a.fli) && path > a.half_inner) stale = true;
     }
   }
   return stale;
 }
-
 
 // PRUNE: the launch that refreshes the dynamically pruned inner list (see below): it walks the FULL
 // force list and, next to the forces, copies the entries with |r| < cutoff + inner_skin into the
@@ -851,7 +895,7 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   // no-op launches publish too: that is how the host learns about a halt)
   // word 0 of the copy is this launch's step index: "launch `step` has begun", i.e. every earlier launch of the
   // stream has finished -- what chx_langevin_fused_run's launch window counts with
-  if (a.host_ctrl != nullptr && blockIdx.x == 0 && threadIdx.x < 8)
+  if (a.host_ctrl != nullptr && blockIdx.x == 0 && threadIdx.x < CHX_CTRL_WORDS)
     __hip_atomic_store(&a.host_ctrl[threadIdx.x], threadIdx.x == 0 ? (int)step : ctrl_first[threadIdx.x], __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_SYSTEM);
   // (naming the arguments the first vector loads need in an asm statement ahead of this branch makes
@@ -870,6 +914,9 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   const bool inner = !PRUNE && (HOT || a.fli != nullptr) && ((epoch >= 0) & (stale_word != epoch));
   const uint32_t* fl_use = inner ? a.fli : a.fl;
   const int32_t* deg_use = inner ? a.degi : a.deg;
+  // deferred rebuilds: did the previous launch book a reference rebuild for this step? (launch-uniform; the word of
+  // this step's parity was last written by an EARLIER launch, and a stale value never equals a later step)
+  const bool is_event = a.snap4 != nullptr && ctrl_first[10 + (int)(step & 1)] == (int)step;
   const int p0 = blk * PPB;
   // ---- operands of this thread's integrate work (threads 0..PPB-1 own one particle each: the
   //      first wavefronts of the block), requested before the force loop so their latency and the
@@ -912,11 +959,21 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   }
   __syncthreads();
   // ---- integrate: one particle per thread, packed into the first PPB threads of the block ----
-  const bool stale = step_epilogue<HOT>(a, tk, sF, step, n_kicks, do_aoa);
+  const bool stale = step_epilogue<HOT>(a, tk, sF, step, n_kicks, do_aoa, is_event);
   // the inner list stays off until the next refresh (a new epoch) outdates the word
   if (do_aoa && (HOT || a.fli) && epoch >= 0 && (stale || (!inner && !PRUNE && threadIdx.x == 0)))
     ctrl_first[4 + (int)((step + 1) & 1)] = epoch;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (is_event) {  // the reference's rebuild count and the step it happened at (chiron/integrators.py:242)
+      const int c = ctrl_first[8] + 1;
+      ctrl_first[8] = c;
+      ctrl_first[9] = (int)step;
+      if (a.ev_log != nullptr && a.ev_cap > 0) a.ev_log[(c - 1) % a.ev_cap] = (int)step;
+      if (a.host_ctrl != nullptr) {
+        __hip_atomic_store(&a.host_ctrl[8], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&a.host_ctrl[9], (int)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
     // (the counters go to the host copy as they change: the copy made at launch start cannot hold this launch's own)
     const int w = PRUNE ? 7 : 6;
     if (PRUNE || ((HOT || a.fli) && !inner)) {  // refreshes of the inner list / launches on the full list
@@ -1135,12 +1192,13 @@ static PollPolicy poll_policy() {
 // *n_enqueued = launches made.  What the host polls is the copy of the control block every launch stores into
 // host_ctrl when it begins (word 0 = its step index, word 3 = the halt word).
 int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, int64_t step0,
-                        int n_steps, int kicks_first, int do_aoa, hipStream_t st, int window, int32_t* n_enqueued) {
+                        int n_steps, int kicks_first, int do_aoa, hipStream_t st, int window, int32_t* n_enqueued,
+                        int watch_trigger) {
   if (n_enqueued) *n_enqueued = 0;
   StepArgs a;
   a.n = p->n;
   a.v = p->v;
-  a.ref4 = reinterpret_cast<const float4*>(p->ref4);
+  a.ref4 = reinterpret_cast<float4*>(p->ref4);
   a.mass = p->mass;
   a.perm = p->perm;
   a.fl = p->fl;
@@ -1171,13 +1229,21 @@ int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, in
     a.T_inner = rk * rk;
     a.half_inner = hm;
   }
+  // deferred rebuilds need both position sets and the force-list path
+  const bool deferred = p->snap4 != nullptr && p->fl != nullptr && p->ref4 != nullptr;
+  a.snap4 = deferred ? reinterpret_cast<const float4*>(p->snap4) : nullptr;
+  a.T_trigger = (deferred && p->trigger_frac > 0.f) ? chx_cutoff_threshold_h(p->skin * 0.5f * p->trigger_frac) : INFINITY;
+  a.ev_log = deferred ? p->ev_log : nullptr;
+  a.ev_cap = deferred ? p->ev_log_cap : 0;
   const bool throttle = window > 0 && a.host_ctrl != nullptr;
+  const bool watch = throttle && deferred && watch_trigger != 0;
   const PollPolicy poll = poll_policy();
   for (int i = 0; i < n_steps; ++i) {
     if (throttle) {
       const long long s = step0 + i;
       const volatile int32_t* hc = a.host_ctrl;
       if ((long long)hc[3] <= s) return CHX_OK;  // the skin check has fired: launches from s on would be no-ops
+      if (watch && hc[12] != 0x7FFFFFFF) return CHX_OK;  // the caller schedules the next force list from here
       if (s - hc[0] > window) {
         // The queue is full.  Spinning here keeps one core at 100 % per rank for nothing: the device needs
         // ~5 us per queued launch.  The sleeping policy therefore lets the queue drain to `low` launches before
@@ -1189,6 +1255,7 @@ int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, in
         timespec t0{};
         for (unsigned spins = 0;; ++spins) {
           if ((long long)hc[3] <= s) return CHX_OK;
+          if (watch && hc[12] != 0x7FFFFFFF) return CHX_OK;
           const int begun = hc[0];  // newest launch that has begun; begun+1 .. s-1 are still waiting
           if (s - begun <= low) break;
           if (poll.sleep_ns > 0) {
@@ -1217,6 +1284,7 @@ int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, in
       const int use_cutoff = p->cutoff >= 0.0f ? 1 : 0;
       if (!use_cutoff) a.lj = make_lj(p->sigma, p->epsilon, 1.0f);
       a.ref4 = nullptr;  // no skin check on these paths
+      a.snap4 = nullptr;
       if (a.n <= 2048) {
         hipLaunchKernelGGL((k_ap_step<64>), dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, st, a, (long long)(step0 + i), nk,
                            do_aoa, use_cutoff);

@@ -26,7 +26,7 @@ import torch
 
 from . import ops, unit
 from ._device import as_tensor
-from ._lib import Box, LangevinParams
+from ._lib import CTRL_WORDS, Box, LangevinParams
 from .rng import JaxKey, PRNGKey, fold_in, split
 from .states import SamplerState, ThermodynamicState
 
@@ -35,6 +35,14 @@ log = logging.getLogger("chiron_amd")
 _INT_MAX = 2**31 - 1
 _TRACE_RUN = __import__("os").environ.get("CHX_TRACE_RUN") == "1"
 _SPECULATIVE_REBUILD = __import__("os").environ.get("CHX_SYNC_REBUILD") != "1"
+# Deferred rebuilds (include/chx.h: chx_langevin_t::snap4): the force list follows a schedule of its own, built on a
+# second stream ahead of time, and the reference's rebuild events are taken on the device.  OFF by default: measured in
+# round 3 (profiles/r03_deferred_rebuild.md) it breaks even at N = 32 768 and loses 3 % at N = 262 144 -- the build's
+# kernels are not hidden by the step kernels beside them, they share the chip with them, and the earlier switch costs
+# 28 % more builds.  CHX_DEFERRED_REBUILD=1 turns it on (a list, so that tests / A-B scripts can flip it in-process).
+_DEFERRED = [__import__("os").environ.get("CHX_DEFERRED_REBUILD", "0") == "1"]
+_EV_LOG_CAP = 4096
+_PROFILE_DEFER = __import__("os").environ.get("CHX_PROFILE_DEFER") == "1"  # host seconds per phase -> integ.defer_profile
 
 
 def langevin_constants(timestep, collision_rate):
@@ -91,7 +99,7 @@ class LangevinIntegrator:
     # memory, and its numpy view no longer aliases it): it starts without and allocates its own on first use.
     # MultiStateSampler deep-copies its sampler, chiron/multistate.py:266-268.
     _PER_PROCESS_STATE = ("_gen_ring", "_gen_next", "_pinned_ring", "_ring_next", "_dev_scratch", "_inner_scratch",
-                          "_run_cache")
+                          "_run_cache", "_defer_scratch", "_rebuild_log")
 
     def __getstate__(self):
         return {k: v for k, v in self.__dict__.items() if k not in self._PER_PROCESS_STATE}
@@ -145,6 +153,9 @@ class LangevinIntegrator:
         if cache.get(m_key, (None,))[0] is not mass._value:
             cache[m_key] = (mass._value, as_tensor(mass.value_in_unit_system(unit.md_unit_system)))
         mass_unitless = cache[m_key][1]
+        if len(cache[m_key]) < 3:  # lightest particle: the speed cap behind the deferred rebuilds' lead time
+            cache[m_key] = cache[m_key] + (float(np.min(np.asarray(mass.value_in_unit_system(unit.md_unit_system)))),)
+        self._m_min = cache[m_key][2]
         c_key = ("dt",)
         if cache.get(c_key, (None, None))[:2] != (id(self.timestep), id(self.collision_rate)):
             cache[c_key] = (id(self.timestep), id(self.collision_rate), langevin_constants(self.timestep, self.collision_rate),
@@ -237,7 +248,9 @@ class LangevinIntegrator:
             elapsed_step = last + base
             if done == stop and elapsed_step % self.report_interval == 0:  # :197-205
                 if has_reporter:
-                    self._report(st.positions_user(), potential, st.nbr_list, last, self._move_iteration, elapsed_step)
+                    # (deferred rebuilds: the list the steps run on is the one that is valid for these positions; the
+                    # caller's list is brought up to the reference's last rebuild when the run ends)
+                    self._report(st.positions_user(), potential, st.report_list(), last, self._move_iteration, elapsed_step)
                 if self.save_traj_in_memory:
                     self.traj.append(st.positions_user())
         if bar is not None:
@@ -247,11 +260,22 @@ class LangevinIntegrator:
         elif mode == "fused":
             st._settle()
 
+        st.finish()
         updated_sampler_state = sampler_state._copy_with(*st.state_user())  # :210-218
         # the reference returns the key its loop ended with (:216); the counter-based stream folds the step count in
         updated_sampler_state.current_PRNG_key = chain_key if isinstance(key, JaxKey) else fold_in(key, number_of_steps)
         self.n_rebuilds = st.n_rebuilds
+        self._rebuild_log = st.rebuild_log
         return updated_sampler_state, st.nbr_list
+
+    @property
+    def rebuild_steps(self):
+        """Step indices (within the last ``run``) at which the reference rebuilt its neighbor list
+        (chiron/integrators.py:241-242), in order: the ones the host carried out and the ones the step kernel took
+        on the device (deferred rebuilds)."""
+        host_events, dev_log = getattr(self, "_rebuild_log", ([], None))
+        dev = [] if dev_log is None else [int(v) for v in dev_log.cpu().tolist()]
+        return sorted(list(host_events) + dev)
 
     def _wrap_and_rebuild_neighborlist(self, x, nbr_list):
         """chiron/integrators.py:220-243 (kept for API parity; ``run`` fuses this on the device)."""
@@ -283,13 +307,29 @@ class _Pending:
     __slots__ = ("s0", "n", "parity0", "host", "event")
 
 
+class _Deferred:
+    """Schedule of the force list when it is decoupled from the reference's rebuilds (_RunState._setup_deferred).
+    phase 0: cruising (the launch loop watches the trigger word); 1: triggered, snapshot due at ``s_snap``;
+    2: the side stream is building, switch due at ``s_adopt``."""
+
+    __slots__ = ("lead", "adopt", "theta", "window", "side", "builders", "snap_event", "next", "phase", "s_snap", "s_adopt",
+                 "builder", "disabled", "n_side_builds", "n_adoptions", "n_internal_halts", "late_triggers")
+
+    def __init__(self):
+        self.phase = 0
+        self.s_snap = self.s_adopt = -1
+        self.builder = None
+        self.disabled = False
+        self.n_side_builds = self.n_adoptions = self.n_internal_halts = self.late_triggers = 0
+
+
 class _Slot:
     """Host-mapped copy of the control block for one generation of step launches (_RunState._open_generation)."""
 
     __slots__ = ("tensor", "host", "open", "dirty", "step0")
 
     def __init__(self):
-        self.tensor = torch.empty((8,), dtype=torch.int32, pin_memory=True)
+        self.tensor = torch.empty((CTRL_WORDS,), dtype=torch.int32, pin_memory=True)
         self.host = self.tensor.numpy()  # (a view: reading an element costs ~0.1 us instead of a tensor op)
         self.open = self.dirty = False
         self.step0 = 0
@@ -320,17 +360,183 @@ class _RunState:
         if keep.get("key") != sk:
             keep.clear()
             keep["key"] = sk
-            keep["ctrl"] = torch.zeros((8,), dtype=torch.int32, device=self.dev)
+            keep["ctrl"] = torch.zeros((CTRL_WORDS,), dtype=torch.int32, device=self.dev)
+            keep["ev_log"] = torch.zeros((_EV_LOG_CAP,), dtype=torch.int32, device=self.dev)
             keep["ws"] = torch.empty((int(ops._lib.load().chx_lj_ws_count(self.n)),), dtype=torch.float64, device=self.dev)
-        self.ctrl, self.ws = keep["ctrl"], keep["ws"]
+        self.ctrl, self.ws, self.ev_log = keep["ctrl"], keep["ws"], keep["ev_log"]
         self.is_verlet = isinstance(nbr_list, NeighborListNsqrd)
         self.is_pairlist = isinstance(nbr_list, PairListNsqrd)
         self.n_rebuilds = 0
         self.kicks_next = 1  # the first step of a run applies only its leading kick
         self.depth = 2  # chunks kept in flight ahead of the host
+        self._defer = None
+        self.rebuild_log = ([], None)
+        self._snap_is_ref = False
+        self._host_events = []  # steps of the reference rebuilds the HOST carried out (halting scheme)
+        self._setup_deferred()
         self._load(x0, v0)
         if self.mode == "external":
             self._external_force()
+
+    # -- deferred rebuilds ---------------------------------------------------
+    def _setup_deferred(self):
+        """Decide whether this run decouples the force list's rebuild schedule from the reference's
+        (include/chx.h: chx_langevin_t::snap4; DESIGN.md section 4) and with which constants.
+
+        The schedule is a function of the trajectory alone: a particle farther than ``theta * skin/2`` from the
+        positions the force list was built from raises the trigger word at step t; the next list is built from the
+        positions of step ``t + lead`` (on a second stream) and takes over at step ``t + lead + adopt``.  ``lead``
+        covers the launches already queued when the host hears of the trigger, ``adopt`` the build's duration, and
+        ``theta`` leaves the fastest particles (5.5 sigma_v) enough room to reach neither skin/2 before the switch.
+        Where that room does not exist -- thin skins, long time steps, lists that last a few dozen steps -- or the
+        public list is close to its row capacity (the reference's growth rule, chiron/neighbors.py:709-727, looks at
+        every rebuild's row counts, which a deferred public rebuild never sees), the halting scheme stays."""
+        self._defer = None
+        if not (_DEFERRED[0] and self.mode == "fused" and self._windowed() and self.is_verlet):
+            return
+        lst = self.nbr_list
+        skin = float(lst.skin.value_in_unit_system(unit.md_unit_system))
+        lead = int(os.environ.get("CHX_DEFER_LEAD", "16"))
+        adopt = int(os.environ.get("CHX_DEFER_ADOPT", "32" if self.n < (1 << 17) else "48"))
+        if lead < 5 or adopt < 1 or skin <= 0.0:
+            return
+        m_min = getattr(self.integ, "_m_min", None)
+        if not m_min or m_min <= 0.0:
+            return
+        v_cap = 5.5 * float(np.sqrt(self.kT / m_min))           # nm / ps
+        margin = (lead + adopt + 4) * 2.0 * self.half_dt * v_cap  # nm travelled between trigger and switch, at most
+        theta = 1.0 - margin / (0.5 * skin)
+        env_theta = os.environ.get("CHX_DEFER_THETA")
+        if env_theta is not None:
+            theta = float(env_theta)
+        if not (0.25 <= theta < 1.0):
+            return
+        max_n = getattr(lst, "_last_max_n", None)
+        if max_n is None or max_n > 0.85 * int(lst.n_max_neighbors):
+            return
+        if lst._clone_builder() is None:
+            return
+        d = self._defer = _Deferred()
+        d.lead, d.adopt, d.theta = lead, adopt, float(theta)
+        d.window = max(1, min(self.integ.launch_window, lead - 4))
+        keep = self.integ.__dict__.setdefault("_defer_scratch", {})
+        if keep.get("key") != (self.n, str(self.dev)):
+            keep.clear()
+            keep["key"] = (self.n, str(self.dev))
+            keep["side"] = torch.cuda.Stream(device=self.dev)
+            keep["builders"] = [None, None]
+            keep["event"] = torch.cuda.Event()
+        d.side, d.builders, d.snap_event = keep["side"], keep["builders"], keep["event"]
+        d.next = 0
+
+    def _next_builder(self):
+        d = self._defer
+        b = d.builders[d.next]
+        src = self.nbr_list
+        if b is None or b._fl_geo != src.__dict__.get("_fl_geo", b._fl_geo) or b._box_h is not src._box_h:
+            nb = src._clone_builder()
+            if b is not None:
+                nb._scratch = b._scratch  # (work arrays: sizes are functions of n and the grid)
+            b = d.builders[d.next] = nb
+        b.n_max_neighbors = src.n_max_neighbors
+        d.next ^= 1
+        return b
+
+    def _start_side_build(self, step: int):
+        """Launch ``step`` is next: snapshot the positions it will read and build the next force list from them on
+        the side stream.  Nothing waits: the step stream carries on with the current list."""
+        d = self._defer
+        if _PROFILE_DEFER:
+            import time as _t
+
+            t_p = _t.perf_counter()
+        x_snap = self.positions_user()  # (a fresh tensor, allocated and written on the step stream)
+        d.snap_event.record()
+        d.side.wait_event(d.snap_event)
+        b = self._next_builder()
+        with ops.launch_stream(d.side):
+            ok = b._build_speculative(x_snap, publish=True, stream=d.side)
+        if not ok:  # (cannot happen for a clone of a cell-built list)
+            raise RuntimeError("deferred rebuild: the side build did not take the one-pass cell path")
+        d.builder, d.phase, d.s_adopt = b, 2, step + d.adopt
+        d.n_side_builds += 1
+        if _PROFILE_DEFER:
+            prof = self.integ.__dict__.setdefault("defer_profile", {"snapshot_build_s": 0.0, "confirm_s": 0.0, "adopt_s": 0.0})
+            prof["snapshot_build_s"] += _t.perf_counter() - t_p
+
+    def _abandon_side_build(self):
+        """A build in flight that will not be used: nothing may free or reuse its arrays before it is done."""
+        d = self._defer
+        if d is not None and d.phase == 2 and d.builder is not None:
+            ev = getattr(d.builder, "_spec_event", None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+            d.builder._spec = None
+        if d is not None:
+            d.phase, d.builder = 0, None
+
+    def _adopt(self, step: int):
+        """Launch ``step`` is the first on the list the side stream has built: the state changes into that list's
+        order ON THE DEVICE (two small launches, no round trip through user order), the launch parameters are pointed
+        at the new list, and a new generation of launches begins.  The reference's bookkeeping -- reference positions,
+        booked events, counters -- travels with the state."""
+        d = self._defer
+        b = d.builder
+        if _PROFILE_DEFER:
+            import time as _t
+
+            t_p = _t.perf_counter()
+        b._confirm_build()  # (host wait for the side build -- long done; a capacity overflow rebuilds synchronously)
+        if _PROFILE_DEFER:
+            t_c = _t.perf_counter()
+        fl = b.force_list
+        keep = self.integ.__dict__["_defer_scratch"]
+        alt = keep.get("alt")
+        if alt is None or alt["v"].shape != self.v.shape:
+            alt = keep["alt"] = dict(v=torch.empty_like(self.v), ref4=torch.empty_like(self.ref4),
+                                     mass=torch.empty_like(self.mass),
+                                     inv=torch.empty((self.n,), dtype=torch.int32, device=self.dev))
+        x_src, x_dst = (self.x_a, self.x_b) if self.parity == 0 else (self.x_b, self.x_a)
+        ops.repack_langevin(x_src, self.v, self.ref4, self.perm, fl.perm, alt["inv"], x_dst, alt["v"], alt["ref4"], alt["mass"],
+                            ctrl=self.ctrl, ctrl_keep=3)
+        self.v, alt["v"] = alt["v"], self.v
+        self.ref4, alt["ref4"] = alt["ref4"], self.ref4
+        self.mass, alt["mass"] = alt["mass"], self.mass
+        self.parity ^= 1
+        self.fl, self.perm, self._owner = fl, fl.perm, b
+        self._close_generation()
+        self._open_generation(step)
+        p = self.params
+        p.g, p.fl_chunks = fl.g, fl.chunks
+        p.v, p.ref4, p.mass = self.v.data_ptr(), self.ref4.data_ptr(), self.mass.data_ptr()
+        p.perm, p.fl, p.deg = fl.perm.data_ptr(), fl.fl.data_ptr(), fl.deg.data_ptr()
+        p.host_ctrl = self._gen.tensor.data_ptr()
+        self._point_params_at_list(p, b, step)
+        self._snap_is_ref = False
+        d.phase, d.builder = 0, None
+        d.n_adoptions += 1
+        if _PROFILE_DEFER:
+            prof = self.integ.__dict__.setdefault("defer_profile", {"snapshot_build_s": 0.0, "confirm_s": 0.0, "adopt_s": 0.0})
+            prof["confirm_s"] += t_c - t_p
+            prof["adopt_s"] += _t.perf_counter() - t_c
+
+    def _rebuild_internal(self, step: int):
+        """The force list ran out of its guarantee before its successor was ready (the halt word fired at ``step``
+        on the list's own positions): build the next one here and now, from the halted state.  No reference event is
+        involved; one that is booked for this very step stays booked (``ctrl_keep``)."""
+        d = self._defer
+        self._abandon_side_build()
+        x_user, v_user = self.state_user()
+        ref_user = self._unpack(self.ref4)
+        b = self._next_builder()
+        b._adopt_positions = True
+        try:
+            b.build(x_user.clone(), b.box_vectors)
+        finally:
+            b._adopt_positions = False
+        self._load(x_user, v_user, step, owner=b, ref_user=ref_user, ctrl_keep=3)
+        self._snap_is_ref = False
+        d.n_internal_halts += 1
 
     # -- layout ------------------------------------------------------------
     def _pack(self, src, stride, perm):
@@ -362,9 +568,16 @@ class _RunState:
             return 0.0, 0
         return inner, every
 
-    def _load(self, x_user: torch.Tensor, v_user: torch.Tensor, step: int = 0):
-        """(Re)pack user-order arrays into the internal order of the current force list."""
-        self.fl = self.nbr_list.force_list if self.mode == "fused" else None
+    def _load(self, x_user: torch.Tensor, v_user: torch.Tensor, step: int = 0, owner=None, ref_user=None, ctrl_keep: int = 0):
+        """(Re)pack user-order arrays into the internal order of the current force list.
+
+        ``owner``: the list object whose force list the steps run on from here (default: the caller's ``nbr_list``;
+        with deferred rebuilds one of the integrator's private builders).  ``ref_user``: the reference's reference
+        positions when they are not the owner's (deferred rebuilds: the public list's positions travel separately).
+        ``ctrl_keep``: what survives the control-block reset (ops.pack_langevin)."""
+        owner = self.nbr_list if owner is None else owner
+        self._owner = owner
+        self.fl = owner.force_list if self.mode == "fused" else None
         perm = self.fl.perm if self.fl is not None else None
         self.perm = perm
         n = self.n
@@ -372,13 +585,15 @@ class _RunState:
         prev = (self.x_a, self.v, self.mass, self.ref4) if getattr(self, "x_a", None) is not None else None
         # riders on the pack launch: the control-block reset and, after a speculative build, the copy of its status
         # block to the host (one launch instead of three)
-        pub = self.nbr_list._take_publish() if self.mode == "fused" and hasattr(self.nbr_list, "_take_publish") else None
+        pub = owner._take_publish() if self.mode == "fused" and hasattr(owner, "_take_publish") else None
+        if ref_user is None and self.is_verlet:
+            ref_user = owner.ref_positions
         self.x_a, self.v, self.mass, self.ref4 = ops.pack_langevin(
-            x_user, v_user, self.mass_user, self.nbr_list.ref_positions if self.is_verlet else None, perm, self.is_verlet,
+            x_user, v_user, self.mass_user, ref_user if self.is_verlet else None, perm, self.is_verlet,
             out=prev,  # a rebuild writes into the buffers of the previous load (the state was copied out first)
-            ctrl=self.ctrl, publish=pub)
+            ctrl=self.ctrl, publish=pub, ctrl_keep=ctrl_keep)
         if pub is not None:
-            self.nbr_list._published(record=not self._windowed())  # (the launch window tells without an event)
+            owner._published(record=not self._windowed())  # (the launch window tells without an event)
         if self.mode in ("fused", "pairs"):  # one launch per step, positions ping-pong between two buffers
             if getattr(self, "x_b", None) is None:
                 self.x_b = torch.empty_like(self.x_a)  # fully written before it is read
@@ -428,6 +643,16 @@ class _RunState:
         p.ctrl = self.ctrl.data_ptr()
         p.ws = self.ws.data_ptr()
         p.external_force = 1 if self.mode == "external" else 0
+        if self.mode == "fused" and self._windowed():
+            p.host_ctrl = self._gen.tensor.data_ptr()
+        self._skin_now = skin
+        self._point_params_at_list(p, owner, step)
+        self.params = p
+
+    def _point_params_at_list(self, p, owner, step: int):
+        """The fields of the launch parameters that belong to the force list the steps run on: the pruned inner list
+        (restarted at ``step``) and, with deferred rebuilds, the positions the list was built from."""
+        n, skin = self.n, self._skin_now
         if self.fl is not None and self.is_verlet:
             inner, every = self._inner_list_settings(skin)
             if every > 0:
@@ -441,9 +666,19 @@ class _RunState:
                 self.fl_inner, self.deg_inner = keep["fl"], keep["deg"]
                 p.fl_inner, p.deg_inner = self.fl_inner.data_ptr(), self.deg_inner.data_ptr()
                 p.inner_skin, p.prune_every, p.prune_phase = inner, every, step
-        if self.mode == "fused" and self._windowed():
-            p.host_ctrl = self._gen.tensor.data_ptr()
-        self.params = p
+        d = self._defer
+        if d is not None and self.fl is not None:
+            # the positions the force list was built from, in its own order: the build's cell-ordered copy
+            scratch = getattr(owner, "_scratch", None)
+            xs4 = scratch["arrays"][4] if scratch and scratch.get("arrays") is not None else None
+            if xs4 is None or xs4.shape[0] != n:  # (cannot happen: the scheme is only set up on cell-built lists)
+                raise RuntimeError("deferred rebuild: the force list's owner holds no cell-ordered positions")
+            self.snap4 = xs4
+            p.snap4 = xs4.data_ptr()
+            p.trigger_frac = d.theta
+            p.ev_log, p.ev_log_cap = self.ev_log.data_ptr(), _EV_LOG_CAP
+            if owner is self.nbr_list:
+                self._snap_is_ref = True  # (a load on the public list: its positions are the reference's)
 
     # -- host-visible control block of the launch window ---------------------------------------
     def _windowed(self) -> bool:
@@ -470,9 +705,9 @@ class _RunState:
                 torch.cuda.current_stream().synchronize()  # (a run that ended in an exception, a zero-step run)
             self._retire(slot)
         # what chx_ctrl_reset writes, with word 0 = "the launch before `step` has begun": nothing is queued
-        slot.host[:] = (step - 1, 0, 0, _INT_MAX, -2, -2, 0, 0)
+        slot.host[:] = (step - 1, 0, 0, _INT_MAX, -2, -2, 0, 0, 0, -1, -1, -1, _INT_MAX, 0, 0, 0)
         slot.open, slot.dirty, slot.step0 = True, False, step
-        self._gen, self._gen_step0 = slot, step
+        self._gen, self._gen_step0, self._gen_parity0 = slot, step, self.parity
 
     def _close_generation(self):
         """Every launch of the current generation is enqueued."""
@@ -531,6 +766,7 @@ class _RunState:
         if prof:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
+        self._abandon_side_build()  # (deferred scheme: a next list in the making is obsolete now)
         x_user, v_user = self.state_user()
         spec = speculative and _SPECULATIVE_REBUILD and self.nbr_list._build_speculative(x_user, publish=False)
         if not spec:
@@ -539,9 +775,12 @@ class _RunState:
                 self.nbr_list.build(x_user, self.nbr_list.box_vectors)
             finally:
                 self.nbr_list._adopt_positions = False
-        self._load(x_user, v_user, step)
+        # (deferred scheme: the device's event counters carry on; an event it booked for this very step is the one
+        # being carried out here)
+        self._load(x_user, v_user, step, ctrl_keep=1 if self._defer is not None else 0)
         self._unsettled = (x_user, v_user, step, self.kicks_next) if spec else None
         self.n_rebuilds += 1
+        self._host_events.append(step)
         if prof:
             torch.cuda.synchronize()
             self.integ.rebuild_seconds = getattr(self.integ, "rebuild_seconds", 0.0) + time.perf_counter() - t0
@@ -566,10 +805,26 @@ class _RunState:
             return True
         x_user, v_user, step, kicks = pend
         torch.cuda.synchronize()
-        self._load(x_user, v_user, step)
+        if self._defer is not None:
+            # whatever ran on the rejected list is void, its reference events included: the device log tells how many
+            # rebuilds the reference had made BEFORE this step (the host-made ones are not in it)
+            self._abandon_side_build()
+            self._restore_event_count(step)
+        self._load(x_user, v_user, step, ctrl_keep=1 if self._defer is not None else 0)
         self.kicks_next = kicks
         self._unsettled_step = step
         return False
+
+    def _restore_event_count(self, step: int):
+        """Rewind the device's reference-event bookkeeping to the state before launch ``step`` (stream idle)."""
+        host = self.ctrl.cpu()
+        count = int(host[8])
+        if count > _EV_LOG_CAP:
+            raise RuntimeError("cannot rewind the rebuild-event log: more events than it holds")
+        log = self.ev_log[:count].cpu().tolist()
+        kept = [t for t in log if t < step]
+        fix = torch.tensor([len(kept), kept[-1] if kept else -1], dtype=torch.int32, device=self.dev)
+        self.ctrl[8:10].copy_(fix)
 
     # -- fused neighbor-list path -------------------------------------------
     def _enqueue_fused(self, s0: int, n: int, do_aoa: int = 1) -> _Pending:
@@ -578,7 +833,7 @@ class _RunState:
         # a slot is reused only after the chunk that owned it has been waited for
         ring = getattr(self.integ, "_pinned_ring", None)
         if ring is None or len(ring) < self.depth + 3:
-            ring = self.integ._pinned_ring = [torch.empty((8,), dtype=torch.int32, pin_memory=True)
+            ring = self.integ._pinned_ring = [torch.empty((CTRL_WORDS,), dtype=torch.int32, pin_memory=True)
                                               for _ in range(self.depth + 3)]
             self.integ._ring_next = 0
         host = ring[self.integ._ring_next % len(ring)]
@@ -589,7 +844,7 @@ class _RunState:
         self.params.host_ctrl = host.data_ptr() if in_kernel else None
         ops.langevin_fused_chunk(self.params, even, odd, s0, n, self.kicks_next, do_aoa)
         if not in_kernel:
-            ops.publish(self.ctrl, host, 8)  # the older scheme: one publish launch per chunk
+            ops.publish(self.ctrl, host, CTRL_WORDS)  # the older scheme: one publish launch per chunk
         rec = _Pending()
         rec.s0, rec.n, rec.parity0 = s0, n, self.parity
         if do_aoa:
@@ -660,9 +915,11 @@ class _RunState:
         return done
 
     # -- fused neighbor-list path, bounded launch queue --------------------------------------------
-    def _enqueue_window(self, s0: int, n: int) -> int:
+    def _enqueue_window(self, s0: int, n: int, watch: bool = False) -> int:
         even, odd = (self.x_a, self.x_b) if self.parity == 0 else (self.x_b, self.x_a)
-        sent = ops.langevin_fused_run(self.params, even, odd, s0, n, self.kicks_next, self.integ.launch_window)
+        d = self._defer
+        window = self.integ.launch_window if d is None or d.disabled else d.window
+        sent = ops.langevin_fused_run(self.params, even, odd, s0, n, self.kicks_next, window, watch)
         if sent:
             self.parity ^= sent & 1
             self.kicks_next = 2
@@ -680,16 +937,43 @@ class _RunState:
     def _advance_windowed(self, done: int, stop: int, final: bool = False) -> int:
         """Steps [done, stop) through ``chx_langevin_fused_run``: the C loop keeps at most ``launch_window``
         launches queued ahead of the device and returns early when it sees the halt word, so a rebuild starts
-        behind a handful of no-op launches instead of up to two chunks of them."""
+        behind a handful of no-op launches instead of up to two chunks of them.
+
+        With deferred rebuilds (``self._defer``) the halt word is the exception: the loop also returns when it sees
+        the trigger word, and this method then takes the snapshot for the next force list at step trigger + lead and
+        switches to that list at snapshot + adopt -- both fixed by the trajectory, whatever the chunking."""
         chunk = self.integ.chunk_size
         enq = done  # first step not enqueued yet
         self._kick_sent = False
+        d = self._defer
         while True:
             while enq < stop:
-                c = min(chunk, stop - enq)
-                sent = self._enqueue_window(enq, c)
+                limit, watch = stop, False
+                if d is not None:
+                    if d.phase == 1:
+                        if enq >= d.s_snap:
+                            self._start_side_build(enq)
+                            continue
+                        limit = min(limit, d.s_snap)
+                    elif d.phase == 2:
+                        if enq >= d.s_adopt:
+                            self._adopt(enq)
+                            continue
+                        limit = min(limit, d.s_adopt)
+                    else:
+                        watch = True
+                c = min(chunk, limit - enq)
+                sent = self._enqueue_window(enq, c, watch)
                 enq += sent
                 if sent < c:
+                    if watch and int(self._gen.host[3]) > enq and int(self._gen.host[12]) != _INT_MAX:
+                        # a particle has used up theta of the force list's skin: schedule the next list
+                        trig = int(self._gen.host[12])
+                        d.phase, d.s_snap = 1, trig + d.lead
+                        if d.s_snap < enq:  # (the host was held up for longer than `lead` launches)
+                            d.s_snap = enq
+                            d.late_triggers += 1
+                        continue
                     break  # the launch loop saw the halt word
                 pend = getattr(self, "_unsettled", None)
                 if pend is not None and enq - pend[2] >= max(chunk, self.integ.launch_window + 1):
@@ -716,11 +1000,53 @@ class _RunState:
             # the skin check fired while producing x_halt: steps < halt ran, the launches queued behind are no-ops
             # and the rebuild is enqueued behind them
             self._kick_sent = False
-            self.parity = (halt - self._gen_step0) & 1
+            self.parity = (self._gen_parity0 + halt - self._gen_step0) & 1
             self._close_generation()
-            self._rebuild(halt, speculative=True)
+            self._halt_rebuild(halt, speculative=True)
             enq = halt
         return stop
+
+    def report_list(self):
+        """The list a report's energy is evaluated with (chiron/integrators.py:278): the caller's list in the halting
+        scheme -- rebuilt at every reference event, as in the reference -- and the force list's owner otherwise (same
+        cutoff, same skin, valid for the current positions)."""
+        return self.nbr_list if self._defer is None else self._owner
+
+    def finish(self):
+        """End of ``run()`` (the stream is idle): the reference's rebuild count, and -- deferred scheme -- the public
+        list, which the reference would have rebuilt at every event.  Here it is rebuilt once, from the positions of
+        the LAST event, and only when somebody reads it (NeighborListNsqrd._defer_build)."""
+        self.rebuild_log = (list(self._host_events), None)
+        d = self._defer
+        if d is None:
+            return
+        self._abandon_side_build()
+        gen = getattr(self, "_gen", None)
+        n_dev = int(gen.host[8]) if gen is not None else 0
+        if n_dev <= 0:
+            return
+        if n_dev > _EV_LOG_CAP:
+            log.warning("more reference rebuild events in one run() than the device log holds; rebuild_steps is truncated")
+        self.n_rebuilds += n_dev
+        self.rebuild_log = (list(self._host_events), self.ev_log[:min(n_dev, _EV_LOG_CAP)].clone())
+        last_dev = int(gen.host[9])
+        last_host = self._host_events[-1] if self._host_events else -1
+        if last_dev > last_host:
+            self.nbr_list._defer_build(self._unpack(self.ref4), n_dev)
+        else:  # the host's own rebuild was the latest: the public list is current
+            self.nbr_list.n_builds += n_dev
+        for k in ("n_side_builds", "n_adoptions", "n_internal_halts", "late_triggers"):
+            setattr(self.integ, k, getattr(self.integ, k, 0) + getattr(d, k))
+
+    def _halt_rebuild(self, halt: int, speculative: bool):
+        """The halt word fired at ``halt``.  Halting scheme: that IS the reference's rebuild.  Deferred scheme: the
+        force list has run out of its own guarantee; when its positions are still the reference's (no switch since
+        the last rebuild the host made) the two coincide and the reference's rebuild is carried out here, otherwise
+        only the force list is renewed."""
+        if self._defer is None or self._snap_is_ref:
+            self._rebuild(halt, speculative=speculative)
+        else:
+            self._rebuild_internal(halt)
 
     # -- other paths -------------------------------------------------------
     def _external_force(self):
@@ -768,8 +1094,9 @@ class _RunState:
             if int(self._gen.host[3]) <= n_steps:
                 # the skin check fired in the run's very last step and the kick ran as a no-op: rebuild exactly as
                 # _advance_windowed does, then kick
-                self.parity = (n_steps - self._gen_step0) & 1
-                self._rebuild(n_steps, speculative=False)
+                self.parity = (self._gen_parity0 + n_steps - self._gen_step0) & 1
+                self._close_generation()
+                self._halt_rebuild(n_steps, speculative=False)
                 self._enqueue_kick(n_steps)
             self._kick_sent = False
             self._close_generation()

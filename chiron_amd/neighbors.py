@@ -258,6 +258,7 @@ class NeighborListNsqrd(PairsBase):
                         self._fl_geo = (n, g, chunks)
                         continue
                     self._last_maxdeg = st[3]
+                    self._last_max_n = st[1]
                     force_list = ops.ForceList.prebuilt(fl, deg, sorted_ids, g, chunks, st[3])
                     return dict(nl=nl, first=first, mask=None, n_nbr=n_nbr, perm=sorted_ids, fl=force_list,
                                 max_n=st[1], n_eq=st[2])
@@ -320,7 +321,7 @@ class NeighborListNsqrd(PairsBase):
         self.n_builds += 1
 
     # -- unsynchronised rebuild (integrator only) ---------------------------------------------
-    def _build_speculative(self, positions: torch.Tensor, publish: bool = True) -> bool:
+    def _build_speculative(self, positions: torch.Tensor, publish: bool = True, stream=None) -> bool:
         """Rebuild from ``positions`` WITHOUT waiting for the build's status block.
 
         The reference synchronises inside every build (chiron/neighbors.py:709) to decide whether
@@ -331,7 +332,9 @@ class NeighborListNsqrd(PairsBase):
         caller then discards whatever it ran on the speculative list.  The overflowing kernel bounds
         its writes, so a speculative list is always safe to walk.  Returns False (nothing enqueued)
         when this fast path does not apply.  ``publish=False``: the caller copies the status block to the host
-        itself (``_take_publish`` / ``_published``: the integrator lets its pack launch do it).
+        itself (``_take_publish`` / ``_published``: the integrator lets its pack launch do it).  ``stream``: the
+        ``torch.cuda.Stream`` the kernels are being launched on when that is not torch's current one
+        (``ops.launch_stream``): the completion event is recorded there.
         """
         if not (self.is_built and self._use_cell_list and getattr(self, "_box_h", None) is not None
                 and self._box_h.periodic and getattr(self, "_fl_geo", None) is not None and self._cs_md is not None):
@@ -350,7 +353,7 @@ class NeighborListNsqrd(PairsBase):
         self.ref_positions = positions  # a fresh tensor nobody else holds
         self._cutoff_and_skin = cs
         nl, first, n_nbr, sorted_ids, fl, deg, status = ops.nl_build_cell_fl(
-            positions, self._box_h, cs, m, ncell, nc, g, chunks, self._scratch)
+            positions, self._box_h, cs, m, ncell, nc, g, chunks, self._scratch, max_blocks=getattr(self, "_bg_blocks", 0))
         host = getattr(self, "_status_host", None)
         if host is None:
             host = self._status_host = torch.empty((8,), dtype=torch.int32, pin_memory=True)
@@ -359,7 +362,10 @@ class NeighborListNsqrd(PairsBase):
             ev = self._spec_event = torch.cuda.Event()  # (one event, recorded again by every speculative build)
         if publish:
             ops.publish(status, host, 8)
-            ev.record()
+            if stream is not None:
+                ev.record(stream)
+            else:
+                ev.record()
             self._pending_publish, self._spec_recorded = None, True
         else:
             self._pending_publish = (status, host)
@@ -408,6 +414,7 @@ class NeighborListNsqrd(PairsBase):
         # reference's growth trigger), [3] max force-list degree, [4] force-list rows that did not fit
         if st[0] == 0 and st[2] == 0 and st[4] == 0 and st[1] <= m:
             self._last_maxdeg = st[3]
+            self._last_max_n = st[1]
             self._force_list.maxdeg = st[3]
             return True
         if _DEBUG_BUILD:
@@ -419,6 +426,58 @@ class NeighborListNsqrd(PairsBase):
         finally:
             self._adopt_positions = False
         return False
+
+    # -- deferred rebuilds (integrator only) ----------------------------------------------------
+    def _clone_builder(self):
+        """A private list builder with this list's geometry and capacities and buffers of its own: what the integrator
+        builds its NEXT force list with, on another stream, while the steps still run on the current one
+        (``LangevinIntegrator``: deferred rebuilds).  None when the one-pass cell build does not apply."""
+        if not (self.is_built and self._use_cell_list and getattr(self, "_box_h", None) is not None and self._box_h.periodic
+                and getattr(self, "_fl_geo", None) is not None and self._cs_md is not None
+                and self.__dict__.get("_perm") is not None):
+            return None
+        b = self.__class__.__new__(self.__class__)
+        b._use_cell_list = True
+        b._cutoff, b._skin, b._cs_md = self._cutoff, self._skin, self._cs_md
+        b.n_max_neighbors = self.n_max_neighbors
+        b.space = self.space
+        b.box_vectors, b._box_h, b._box_token = self.box_vectors, self._box_h, None
+        b._fl_geo = self._fl_geo
+        b._last_maxdeg = getattr(self, "_last_maxdeg", 0)
+        b._force_list = None
+        b._nl = b._nl_mask = b._first = None
+        b._scratch = None
+        b.n_builds = 0
+        b.is_built = True
+        # background builds: workgroups of the wave-per-particle kernel in flight (0 = one wavefront per row)
+        b._bg_blocks = int(os.environ.get("CHX_DEFER_BG_BLOCKS", "512"))
+        return b
+
+    _DEFERRED_ATTRS = ("ref_positions", "n_neighbors", "_nl", "_nl_mask", "_first", "_perm", "_force_list")
+
+    def _defer_build(self, ref_positions: torch.Tensor, n_events: int) -> None:
+        """The reference rebuilt this list ``n_events`` times inside ``run()`` and the last rebuild was from
+        ``ref_positions`` (chiron/integrators.py:241-242) -- but nobody has looked at it since: the arrays are built
+        from those positions the first time one of them is read (``__getattr__``).  ``is_built`` stays True, as in the
+        reference; ``n_builds`` counts the reference's rebuilds."""
+        for name in self._DEFERRED_ATTRS:
+            self.__dict__.pop(name, None)
+        self.__dict__["_deferred"] = ref_positions
+        self.n_builds += int(n_events)
+
+    def __getattr__(self, name):
+        # (reached only when normal lookup fails: costs nothing on the hot path)
+        if name in NeighborListNsqrd._DEFERRED_ATTRS and "_deferred" in self.__dict__:
+            pos = self.__dict__.pop("_deferred")
+            builds = self.n_builds
+            self._adopt_positions = True  # a tensor nobody else holds
+            try:
+                self.build(pos, self.box_vectors)
+            finally:
+                self._adopt_positions = False
+            self.n_builds = builds  # already counted by _defer_build
+            return self.__dict__[name]
+        raise AttributeError(f"{type(self).__name__!r} object has no attribute {name!r}")
 
     def _finish_padding(self):
         """Padding (:603-620) and mask (:623) are produced on first use: the MD loop never reads them."""

@@ -43,9 +43,36 @@ _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _CUR_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
 
 
+_stream_tls = __import__("threading").local()
+
+
+class launch_stream:
+    """``with launch_stream(side): ...``: kernels launched by this module inside the block go to ``side`` (a
+    ``torch.cuda.Stream``) while torch's CURRENT stream -- and with it the stream the caching allocator books new
+    tensors on -- stays what it was.  The deferred list rebuild uses it: the arrays of the next force list are
+    allocated on the step stream, where they will live, and only the build's kernels run on the side stream (events
+    order the two); allocating under ``torch.cuda.stream(side)`` instead would tie the blocks to the side stream's
+    pool and let them be reused there while the step stream still reads them."""
+
+    def __init__(self, stream):
+        self.raw = None if stream is None else C.c_void_p(stream.cuda_stream)
+
+    def __enter__(self):
+        self.prev = getattr(_stream_tls, "raw", None)
+        _stream_tls.raw = self.raw
+        return self
+
+    def __exit__(self, *exc):
+        _stream_tls.raw = self.prev
+        return False
+
+
 def _stream():
     """torch's current HIP stream as a raw handle.  ``torch.cuda.current_stream()`` builds a Python
     Stream object (~9 us, a dozen times per integrator call); the raw accessor is a plain C call."""
+    over = getattr(_stream_tls, "raw", None)
+    if over is not None:
+        return over
     if _RAW_STREAM is not None and _CUR_DEVICE is not None:
         return C.c_void_p(_RAW_STREAM(_CUR_DEVICE()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -155,7 +182,7 @@ def nl_build_cell(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: int, 
 
 
 def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: int, ncell: int, nc, g: int, chunks: int,
-                     scratch: Optional[dict] = None):
+                     scratch: Optional[dict] = None, max_blocks: int = 0):
     """One-pass cell build (half-list rows without padding + force list).
 
     Returns (nl_rows, first, n_nbr, sorted_ids, fl, deg, status8); nothing is synchronised here.
@@ -188,7 +215,7 @@ def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: in
         _lib.load().chx_nl_build_cell_fl(
             _ptr(xyz), n, m, box, C.c_float(cutoff_plus_skin), nc, _ptr(cell_of), _ptr(cell_count), _ptr(cell_start),
             _ptr(sorted_ids), _ptr(status), _ptr(nl), _ptr(first), _ptr(n_nbr), g, chunks, _ptr(fl), _ptr(deg),
-            _ptr(xs4), _stream(),
+            _ptr(xs4), int(max_blocks), _stream(),
         ),
         "chx_nl_build_cell_fl",
     )
@@ -204,10 +231,11 @@ def nl_finish_padding(nl: torch.Tensor, first: torch.Tensor, n_nbr: torch.Tensor
     return mask
 
 
-def pack_langevin(x3, v3, mass, ref3, perm, want_ref: bool, out=None, ctrl=None, publish=None):
+def pack_langevin(x3, v3, mass, ref3, perm, want_ref: bool, out=None, ctrl=None, publish=None, ctrl_keep: int = 0):
     """User-order state -> internal order in one launch: (x4, v, mass_internal, ref4 or None).
     ``out`` = a previous result of the same shapes to write into.  Riders on the same launch: ``ctrl`` = control
-    block to reset (``ctrl_reset``), ``publish`` = (device block of 8 ints, pinned host block) to copy (``publish``)."""
+    block to reset (``ctrl_reset``; ``ctrl_keep`` bit 0 / 1: leave the reference-event counters / booked events alone),
+    ``publish`` = (device block of 8 ints, pinned host block) to copy (``publish``)."""
     x3, v3, mass = _f32(x3), _f32(v3), _f32(mass)
     _require_device(x3, v3, mass, perm)
     n = x3.shape[0]
@@ -224,12 +252,24 @@ def pack_langevin(x3, v3, mass, ref3, perm, want_ref: bool, out=None, ctrl=None,
         _require_device(ref3)
     check(
         _lib.load().chx_pack_langevin(_ptr(x3), _ptr(v3), _ptr(mass), _ptr(ref3) if want_ref else None, _ptr(perm), n,
-                                      _ptr(x4), _ptr(v), _ptr(m_int), _ptr(ref4), _ptr(ctrl),
+                                      _ptr(x4), _ptr(v), _ptr(m_int), _ptr(ref4), _ptr(ctrl), int(ctrl_keep),
                                       _ptr(publish[0]) if publish else None,
                                       C.c_void_p(publish[1].data_ptr()) if publish else None, _stream()),
         "chx_pack_langevin",
     )
     return x4, v, m_int, ref4
+
+
+def repack_langevin(x4_old, v_old, ref4_old, perm_old, perm_new, inv_ws, x4_new, v_new, ref4_new, mass_new, ctrl=None,
+                    ctrl_keep: int = 0) -> None:
+    """Internal order of the current force list -> order of the next one, on the device (include/chx.h)."""
+    _require_device(x4_old, v_old, ref4_old, perm_old, perm_new, inv_ws, x4_new, v_new, ref4_new, mass_new)
+    check(
+        _lib.load().chx_repack_langevin(_ptr(x4_old), _ptr(v_old), _ptr(ref4_old), _ptr(perm_old), _ptr(perm_new), _ptr(inv_ws),
+                                        x4_old.shape[0], _ptr(x4_new), _ptr(v_new), _ptr(ref4_new), _ptr(mass_new), _ptr(ctrl),
+                                        int(ctrl_keep), _stream()),
+        "chx_repack_langevin",
+    )
 
 
 def nl_calculate(xyz, nl, nl_mask, box: Box, cutoff: float):
@@ -494,16 +534,17 @@ _tls = __import__("threading").local()  # (MultiStateSampler may drive two repli
 
 
 def langevin_fused_run(params: LangevinParams, x_even: torch.Tensor, x_odd: torch.Tensor, step0: int,
-                       n_steps: int, kicks_first: int, window: int) -> int:
+                       n_steps: int, kicks_first: int, window: int, watch_trigger: bool = False) -> int:
     """``langevin_fused_chunk`` with a bounded launch queue (include/chx.h: chx_langevin_fused_run).
-    Returns the number of launches made: fewer than ``n_steps`` when the host saw the halt word."""
+    Returns the number of launches made: fewer than ``n_steps`` when the host saw the halt word (or, with
+    ``watch_trigger``, the trigger word of the deferred rebuilds)."""
     _require_device(x_even, x_odd)
     out = getattr(_tls, "n_enqueued", None)
     if out is None:
         out = _tls.n_enqueued = C.c_int32(0)
     check(
         _lib.load().chx_langevin_fused_run(C.byref(params), _ptr(x_even), _ptr(x_odd), step0, n_steps, kicks_first, window,
-                                           C.byref(out), _stream()),
+                                           1 if watch_trigger else 0, C.byref(out), _stream()),
         "chx_langevin_fused_run",
     )
     return out.value

@@ -122,13 +122,16 @@ int chx_nl_build_cell(const float* xyz, int32_t n, int32_t m, chx_box_t box, flo
  * candidate buffer (nothing valid); [1] max n_nbr; [2] number of rows with n_nbr == m
  * (the reference's growth trigger, :709); [3] max full degree; [4] rows whose full
  * degree exceeded the capacity (force list invalid, retry with more chunks).
- * xs4_out (n,4): the positions in internal (cell) order, x4[p] = xyz[sorted_ids[p]]. */
+ * xs4_out (n,4): the positions in internal (cell) order, x4[p] = xyz[sorted_ids[p]].
+ * max_blocks > 0: a BACKGROUND build -- the wave-per-particle kernel is launched with at most that many workgroups
+ * (of four wavefronts) and walks the rows grid-stride, so that step kernels running on another stream beside it keep
+ * most of the wave slots (deferred rebuilds, chx_langevin_t::snap4); 0: one wavefront per row.  Same bits either way. */
 int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_box_t box, float cutoff_plus_skin,
                          const int32_t* nc_h, int32_t* cell_of, int32_t* cell_count,
                          int32_t* cell_start, uint32_t* sorted_ids, int32_t* status8,
                          uint32_t* nl_rows_out, uint32_t* first_out, int32_t* n_nbr_out, int32_t g,
                          int32_t chunks, uint32_t* fl_out, int32_t* deg_out, float* xs4_out,
-                         chx_stream_t stream);
+                         int32_t max_blocks, chx_stream_t stream);
 int chx_nl_finish_padding(uint32_t* nl_inout, const uint32_t* first, const int32_t* n_nbr, int32_t n,
                           int32_t m, int32_t* nl_mask_out, chx_stream_t stream);
 
@@ -190,12 +193,25 @@ int chx_unpack_langevin(const float* x4, const float* v, const uint32_t* perm, i
                         float* x3_out, float* v3_out, chx_stream_t stream);
 /* one launch: x4[p] = x3[perm[p]], v[p] = v3[perm[p]], mass_out[p] = mass[perm[p]],
  * ref4[p] = (ref3[perm[p]], mass_out[p]) (ref4_out may be NULL).  Optional riders, so that a list rebuild inside
- * the Langevin loop costs one launch here instead of three: ctrl_reset != NULL -> what chx_ctrl_reset writes;
+ * the Langevin loop costs one launch here instead of three: ctrl_reset != NULL -> what chx_ctrl_reset writes, except
+ * that ctrl_keep bit 0 leaves the reference-event counters ([8], [9]) and bit 1 the event words ([10], [11]) as they
+ * are (deferred rebuilds: a repack into the order of the next force list must not lose a rebuild event that is booked
+ * for the very next launch, nor the count so far);
  * publish_src8 / publish_host_dst8 != NULL -> what chx_publish(src, dst, 8) does (the build's status block). */
 int chx_pack_langevin(const float* x3, const float* v3, const float* mass, const float* ref3,
                       const uint32_t* perm, int32_t n, float* x4_out, float* v_out, float* mass_out,
-                      float* ref4_out, int32_t* ctrl_reset, const int32_t* publish_src8,
+                      float* ref4_out, int32_t* ctrl_reset, int32_t ctrl_keep, const int32_t* publish_src8,
                       int32_t* publish_host_dst8, chx_stream_t stream);
+
+/* Deferred rebuilds (chx_langevin_t::snap4): move the Langevin state from the internal order of the current force
+ * list (perm_old: internal -> original id) into the order of the next one (perm_new) on the device, two launches and
+ * no round trip through user order: x4_new[p] = (x4_old[q].xyz, 0), v_new[p] = v_old[q], ref4_new[p] = ref4_old[q]
+ * (xyz and the mass in .w), mass_new[p] = ref4_old[q].w with q = the old internal index of original id perm_new[p].
+ * inv_ws: n uint32 of scratch.  The outputs must not alias the inputs.  ctrl_reset / ctrl_keep: as in
+ * chx_pack_langevin. */
+int chx_repack_langevin(const float* x4_old, const float* v_old, const float* ref4_old, const uint32_t* perm_old,
+                        const uint32_t* perm_new, uint32_t* inv_ws, int32_t n, float* x4_new, float* v_new,
+                        float* ref4_new, float* mass_new, int32_t* ctrl_reset, int32_t ctrl_keep, chx_stream_t stream);
 
 /* LJPotential.compute_energy / compute_force over the neighbor list:
  * E = sum over listed pairs with d < cutoff of 4 eps ((s/d)^12 - (s/d)^6)
@@ -251,8 +267,10 @@ typedef struct {
   float* x4;             /* (n,4) positions, internal order            (in/out) */
   float* v;              /* (n,3) velocities, internal order           (in/out) */
   float* f;              /* (n,3) forces, internal order               (in/out) */
-  const float* ref4;     /* (n,4) positions at the last list build, or NULL (no list); .w = the particle's MASS
-                            (chx_pack_langevin writes it: the fused step kernel takes the mass from here) */
+  float* ref4;           /* (n,4) positions at the reference's last list build, or NULL (no list); .w = the particle's
+                            MASS (chx_pack_langevin writes it: the fused step kernel takes the mass from here).  Read
+                            only, except with snap4 set (deferred rebuilds, below): the kernel then rewrites the xyz
+                            of every row at a reference rebuild event */
   const float* mass;     /* (n)   masses, internal order */
   const uint32_t* perm;  /* (n)   internal -> original id (RNG counter / noise row), NULL = identity */
   const uint32_t* fl;    /* force list (see above), NULL -> all-pairs kernel */
@@ -265,11 +283,15 @@ typedef struct {
   uint32_t k0, k1;       /* Philox key of this run */
   const float* noise;    /* optional injected O-step noise, (n_noise_steps, n, 3) in ORIGINAL order */
   int64_t noise_step0;   /* step index of noise row 0 */
-  int32_t* ctrl;         /* 8 ints.  [0] violation seen by integrate, [1] halt (set by force kernel),
+  int32_t* ctrl;         /* CHX_CTRL_WORDS (16) ints.  [0] violation seen by integrate, [1] halt (set by force kernel),
                             [2] step at which the skin check fired, [3] fused path: first step that
                             must not run (INT32_MAX when clear), [4],[5] inner list stale (by step
                             parity; the value is the refresh epoch the word was raised in),
-                            [6] launches that ran on the full list, [7] refreshes of the inner list */
+                            [6] launches that ran on the full list, [7] refreshes of the inner list;
+                            deferred rebuilds (snap4 set): [8] reference rebuild events since the block was reset,
+                            [9] step of the last one, [10],[11] event words by step parity (value s = "launch s starts
+                            with a reference rebuild"; -1 when clear), [12] first step whose positions passed the
+                            trigger distance from snap4 (INT32_MAX when clear), [13..15] reserved */
   double* ws;            /* energy workspace, >= chx_lj_ws_count(n) */
   int32_t external_force; /* != 0: do not launch the LJ force kernel (the caller fills f
                              between single-step chunks: IdealGasPotential and other potentials) */
@@ -294,8 +316,30 @@ typedef struct {
    * shows up with the next launch -- which is a no-op by then, so nothing is lost but a little time.  Word 0 of
    * the copy is the step index of the newest launch that has begun (not ctrl[0]); words 6 and 7 are also stored
    * whenever they change.  NULL = off. */
-  int32_t* host_ctrl;
+  int32_t* host_ctrl;    /* CHX_CTRL_WORDS ints */
+  /* Deferred list rebuilds (fused neighbor-list path; snap4 == NULL = off: the halting scheme described at
+   * chx_langevin_fused_chunk).  The reference rebuilds its list -- and takes new reference positions -- whenever a
+   * particle has moved skin/2 from them (chiron/integrators.py:239-242, chiron/neighbors.py:868); what the FORCE needs
+   * is only a list that still holds every pair inside the cutoff.  With snap4 set the two are decoupled:
+   *   - fl / deg were built from the positions snap4 (same cutoff + skin) and stay exhaustive while no particle is
+   *     farther than skin/2 from its snap4 row: THAT check raises the halt word ctrl[3] as before;
+   *   - the reference's own check against ref4 no longer halts anything: the launch that sees it fire for the
+   *     positions of step s+1 stores s+1 in the event word of that parity, and launch s+1 starts by copying its input
+   *     positions into ref4 (the reference's new reference positions, from which the caller can build the PUBLIC list
+   *     whenever somebody wants to see it), counting the event in ctrl[8] / ctrl[9] and logging its step in
+   *     ev_log[(count - 1) % ev_log_cap] (optional);
+   *   - a particle farther than trigger_frac * skin/2 from snap4 raises ctrl[12] (first such step, like the halt word):
+   *     the caller's cue to build the next force list from a snapshot taken a fixed number of steps later, on another
+   *     stream, and to switch to it a fixed number of steps after that -- before the halt distance is reached.
+   * Rebuild events, reference positions and interacting pairs are exactly those of the halting scheme; trajectories
+   * differ from it only through the summation order of the forces (the internal order follows snap4, not ref4). */
+  const float* snap4;     /* (n,4) positions the force list was built from, internal order (.w is not read) */
+  float trigger_frac;     /* in (0, 1]; <= 0: never raise ctrl[12] */
+  int32_t ev_log_cap;
+  int32_t* ev_log;
 } chx_langevin_t;
+
+#define CHX_CTRL_WORDS 16
 
 /* One BAOAB update on user-order (n,3) arrays, in place: v += half_dt F/m; x += half_dt v;
  * v = a v + b sqrt(kT/m) xi; x += half_dt v; [wrap]; rebuild_flag_out[0] = any particle moved
@@ -352,13 +396,14 @@ int chx_langevin_fused_chunk(const chx_langevin_t* p_h, float* x_even, float* x_
  * most `window` of them not yet begun), not when they have run: a halt raised by the last few launches is for the
  * next call, or for the caller's wait on the stream, to find.  Why: after a halt everything still queued is dead
  * time in front of the list rebuild (about 2 us per no-op launch), so the queue should be as short as the host's
- * launch latency allows rather than a fixed number of chunks. */
+ * launch latency allows rather than a fixed number of chunks.
+ * watch_trigger != 0 (deferred rebuilds): also stop enqueuing as soon as the trigger word host_ctrl[12] is set. */
 int chx_langevin_fused_run(const chx_langevin_t* p_h, float* x_even, float* x_odd, int64_t step0,
-                           int32_t n_steps, int32_t kicks_first, int32_t window,
+                           int32_t n_steps, int32_t kicks_first, int32_t window, int32_t watch_trigger,
                            int32_t* n_enqueued_out, chx_stream_t stream);
 
 /* Control-block plumbing of the loop above, as ordinary kernels on the caller's stream:
- * chx_ctrl_reset writes {0, 0, 0, INT32_MAX, -2, -2, 0, 0}; chx_publish copies n <= 64 ints into
+ * chx_ctrl_reset writes {0, 0, 0, INT32_MAX, -2, -2, 0, 0,  0, -1, -1, -1, INT32_MAX, 0, 0, 0}; chx_publish copies n <= 64 ints into
  * HOST-MAPPED pinned memory (host_mapped_dst is the device-visible address of a
  * hipHostMalloc'ed block) with system-scope visibility, so the host can read the block
  * after waiting for the stream without any copy-engine / blit work in the hot loop. */

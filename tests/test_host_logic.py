@@ -284,8 +284,9 @@ def test_library_exports_every_declared_symbol():
     assert lib.chx_version() == _lib.ABI_VERSION == 2
     # struct layouts agree with the header (x86-64 SysV)
     assert ctypes.sizeof(_lib.Box) == 16
-    assert ctypes.sizeof(_lib.LangevinParams) == 224 == lib.chx_sizeof_langevin_t()
-    assert _lib.LangevinParams.host_ctrl.offset == 216
+    assert ctypes.sizeof(_lib.LangevinParams) == 248 == lib.chx_sizeof_langevin_t()
+    assert _lib.LangevinParams.host_ctrl.offset == 216 and _lib.LangevinParams.snap4.offset == 224
+    assert _lib.LangevinParams.trigger_frac.offset == 232 and _lib.LangevinParams.ev_log.offset == 240
     assert _lib.LangevinParams.fl_inner.offset == 176 and _lib.LangevinParams.prune_phase.offset == 208
     # struct-by-value marshalling rule of include/chx.h: no float scalars before a box that follows
     # five or more integer/pointer arguments (mis-marshalled by this image's libffi)
@@ -376,20 +377,27 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
                            ctypes.c_void_p(64), None), "power of two")
     failed(lib.chx_langevin_fused_chunk(None, None, None, 0, 1, 1, 1, None), "null params")
     sent = ctypes.c_int32(-1)
-    failed(lib.chx_langevin_fused_run(None, None, None, 0, 1, 1, 4, ctypes.byref(sent), None), "null pointer")
+    failed(lib.chx_langevin_fused_run(None, None, None, 0, 1, 1, 4, 0, ctypes.byref(sent), None), "null pointer")
     lp = _lib.LangevinParams()
     lp.n = 4
     lp.v = lp.mass = lp.ctrl = lp.fl = lp.deg = 64
     lp.fl_chunks = 1
-    failed(lib.chx_langevin_fused_run(ctypes.byref(lp), ctypes.c_void_p(64), ctypes.c_void_p(128), 0, 1, 1, 4,
+    failed(lib.chx_langevin_fused_run(ctypes.byref(lp), ctypes.c_void_p(64), ctypes.c_void_p(128), 0, 1, 1, 4, 0,
                                       ctypes.byref(sent), None), "host_ctrl")
-    hc = (ctypes.c_int32 * 8)(6, 0, 0, 7, -2, -2, 0, 0)
+    hc = (ctypes.c_int32 * _lib.CTRL_WORDS)(6, 0, 0, 7, -2, -2, 0, 0, 0, -1, -1, -1, 2**31 - 1, 0, 0, 0)
     lp.host_ctrl = ctypes.addressof(hc)
-    failed(lib.chx_langevin_fused_run(ctypes.byref(lp), ctypes.c_void_p(64), ctypes.c_void_p(128), 0, 1, 1, 0,
+    failed(lib.chx_langevin_fused_run(ctypes.byref(lp), ctypes.c_void_p(64), ctypes.c_void_p(128), 0, 1, 1, 0, 0,
                                       ctypes.byref(sent), None), "window")
     # the halt word (7) already rules out step 7: the launch loop stops before its first launch
-    lib.chx_langevin_fused_run(ctypes.byref(lp), ctypes.c_void_p(64), ctypes.c_void_p(128), 7, 5, 2, 4, ctypes.byref(sent), None)
+    lib.chx_langevin_fused_run(ctypes.byref(lp), ctypes.c_void_p(64), ctypes.c_void_p(128), 7, 5, 2, 4, 0, ctypes.byref(sent), None)
     assert sent.value == 0
+    # deferred rebuilds: a set trigger word stops a watching loop before its first launch, and only a watching one
+    hc[3], hc[12] = 2**31 - 1, 3
+    lp.snap4 = lp.ref4 = 64
+    lp.skin = 0.5
+    lib.chx_langevin_fused_run(ctypes.byref(lp), ctypes.c_void_p(64), ctypes.c_void_p(128), 7, 5, 2, 4, 1, ctypes.byref(sent), None)
+    assert sent.value == 0
+    lp.snap4 = None
     failed(lib.chx_mc_displace_chunk(None, 0, 1, None), "null parameter block")
     failed(lib.chx_lj_nl_energy_force(None, None, None, 8, 0, box, f(1), f(1), f(1), None, None, None, None), "m >= 1")
     failed(lib.chx_baoab_step(None, None, None, None, -3, box, 1, f(1), f(1), f(1), f(1), None, f(1), 0, 0, 0, None,
@@ -696,7 +704,7 @@ def test_cell_build_refuses_a_grid_axis_beyond_its_packed_coordinates():
     p = ctypes.c_void_p(64)
     rc = lib.chx_nl_build_cell(p, 8, 8, box, ctypes.c_float(1.5), nc, p, p, p, p, p, p, p, p, None)
     assert rc < 0 and "1024 cells per axis" in lib.chx_last_error().decode()
-    rc = lib.chx_nl_build_cell_fl(p, 8, 8, box, ctypes.c_float(1.5), nc, p, p, p, p, p, p, p, p, 4, 1, p, p, p, None)
+    rc = lib.chx_nl_build_cell_fl(p, 8, 8, box, ctypes.c_float(1.5), nc, p, p, p, p, p, p, p, p, 4, 1, p, p, p, 0, None)
     assert rc < 0 and "1024 cells per axis" in lib.chx_last_error().decode()
     # the helper itself never hands out such a grid
     total = lib.chx_cell_grid_h(_lib.Box(1, 4000.0, 4000.0, 4000.0), ctypes.c_float(1.5), 1 << 30, nc)
