@@ -1927,3 +1927,114 @@ def test_deep_copied_integrator_and_sampler_run_on_fresh_slots(ca, O):
     s2, _, _ = sampler2.run(copy.deepcopy(s1), thermo, n_iterations=1, nbr_list=copy.deepcopy(n1))
     s3, _, _ = sampler.run(copy.deepcopy(s1), thermo, n_iterations=1, nbr_list=copy.deepcopy(n1))
     assert torch.isfinite(s2.positions).all() and torch.equal(s2.positions, s3.positions)
+
+
+# ---------------------------------------------------------------------------
+# deferred list rebuilds (opt-in: CHX_DEFERRED_REBUILD=1; include/chx.h: chx_langevin_t::snap4)
+# ---------------------------------------------------------------------------
+def _deferred_run(ca, O, deferred, steps, chunk=32, window=None, n=4096, dt_fs=2.0, seed=61, reporter=None, interval=100):
+    from chiron_amd import integrators
+
+    u = ca.unit
+    x, box = O.lj_lattice(n, 0.1, SIGMA, seed=seed)
+    pot = lj_pot(ca, n)
+    state = make_state(ca, x, box)
+    thermo = ca.states.ThermodynamicState(pot, temperature=300 * u.kelvin)
+    nbr = ca.neighbors.NeighborListCell(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+                                        skin=SKIN * u.nanometer, n_max_neighbors=180)
+    kw = {} if window is None else {"launch_window": window}
+    integ = ca.integrators.LangevinIntegrator(timestep=dt_fs * u.femtoseconds, collision_rate=1.0 / u.picoseconds,
+                                              chunk_size=chunk, reporter=reporter, report_interval=interval, **kw)
+    old = integrators._DEFERRED[0]
+    integrators._DEFERRED[0] = deferred
+    try:
+        key_before = state.current_PRNG_key
+        out, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr)
+    finally:
+        integrators._DEFERRED[0] = old
+    return x, box, pot, out, nbr, integ, key_before
+
+
+def test_deferred_rebuilds_keep_the_reference_events_and_the_public_list(ca, O):
+    """With the force list on a schedule of its own -- built ahead of time on a side stream, switched in by a device
+    repack -- the REFERENCE's rebuilds become events the step kernel takes itself.  Same events at the same steps as
+    the halting scheme and as the C oracle (chiron/integrators.py:239-242), same trajectory up to the summation order
+    of the forces, and the caller's list ends as the reference's would: built from the positions of the last event."""
+    from oracle import c_oracle as CO
+    import chiron_amd.rng as R
+
+    steps, n = 700, 4096
+    x, box, pot, a, nbr_a, integ_a, key0 = _deferred_run(ca, O, True, steps)
+    _, _, _, b, nbr_b, integ_b, _ = _deferred_run(ca, O, False, steps)
+    assert integ_a.n_adoptions >= 2 and integ_a.n_side_builds >= integ_a.n_adoptions  # the scheme really ran
+    assert integ_a.n_internal_halts == 0 and integ_a.late_triggers == 0
+    assert integ_a.n_rebuilds == integ_b.n_rebuilds >= 3
+    assert integ_a.rebuild_steps == integ_b.rebuild_steps and len(integ_a.rebuild_steps) == integ_a.n_rebuilds
+    dx = (a.positions - b.positions).abs()
+    L = float(box[0, 0])
+    dx = torch.minimum(dx, (dx - L).abs())
+    assert dx.max().item() < 2e-4 and (a.velocities - b.velocities).abs().max().item() < 2e-2
+    # the caller's list: resolved on first access, from the positions of the LAST event
+    assert "_deferred" in nbr_a.__dict__ and "n_neighbors" not in nbr_a.__dict__
+    assert nbr_a.is_built and nbr_a.n_builds == nbr_b.n_builds
+    ref = nbr_a.ref_positions  # (first access: builds)
+    assert "_deferred" not in nbr_a.__dict__
+    dref = (ref - nbr_b.ref_positions).abs()
+    assert torch.minimum(dref, (dref - L).abs()).max().item() < 2e-4
+    mask, nl, nnbr = CO.nl_build_fixed(ref.cpu().numpy(), box, CUTOFF + SKIN, int(nbr_a.n_max_neighbors))
+    assert np.array_equal(nbr_a.n_neighbors.cpu().numpy(), nnbr) and np.array_equal(u32(nbr_a.neighbor_list), nl)
+    # its energy is the energy of the final frame (the list is valid for it: no event since)
+    e_list = float(pot.compute_energy(a.positions, nbr_a))
+    e64 = CO.lj_cell_f64(a.positions.cpu().numpy(), box, SIGMA, EPS, CUTOFF)[0]
+    assert abs(e_list - e64) <= 2e-5 * abs(e64) + 1e-3
+    # the C oracle on the same Philox stream: same number of rebuilds, same trajectory within chaos-free tolerance
+    _, run_key = R.split(key0)
+    mass = np.full(n, 39.948, f32)
+    kT, ca_, cb_ = O.langevin_constants(300.0, 0.002, 1.0)
+    v0 = O.initial_velocities(mass, kT, O.philox_normals3(n, 0, O.STREAM_VELOCITY, tuple(run_key)))
+    xo, vo, st = CO.langevin_run_cell_omp(x, v0, box, mass, SIGMA, EPS, CUTOFF, SKIN, 0.002, ca_, cb_, kT, steps, None,
+                                          tuple(run_key), threads=CO.effective_cores())
+    assert st["rebuilds"] == integ_a.n_rebuilds
+    do = np.abs(a.positions.cpu().numpy() - xo)
+    assert np.minimum(do, np.abs(do - L)).max() < 5e-4
+
+
+def test_deferred_rebuilds_do_not_depend_on_launch_batching(ca, O):
+    """Snapshot and switch steps are functions of the trajectory (trigger step + lead, + adopt): chunk sizes, launch
+    windows (capped at lead - 4 while the trigger is watched) and report stops give the same bits."""
+    steps = 500
+    runs = [_deferred_run(ca, O, True, steps, chunk=32), _deferred_run(ca, O, True, steps, chunk=5),
+            _deferred_run(ca, O, True, steps, chunk=32, window=3), _deferred_run(ca, O, True, steps, chunk=17, window=64)]
+    from chiron_amd.reporters import LangevinDynamicsReporter
+
+    rep = LangevinDynamicsReporter("deferred_probe", buffer_size=1)
+    runs.append(_deferred_run(ca, O, True, steps, chunk=32, reporter=rep, interval=70))
+    ref = runs[0]
+    assert ref[5].n_adoptions >= 1
+    for r in runs[1:]:
+        assert torch.equal(r[3].positions, ref[3].positions) and torch.equal(r[3].velocities, ref[3].velocities)
+        assert r[5].rebuild_steps == ref[5].rebuild_steps and r[5].n_adoptions == ref[5].n_adoptions
+    # the reported energies are energies of the reported frames (evaluated on the list the steps run on)
+    from oracle import c_oracle as CO
+
+    frames, energy = np.asarray(rep.get_property("positions")), np.asarray(rep.get_property("potential_energy"), dtype=np.float64).ravel()
+    assert len(frames) == len(energy) >= 7
+    for k in (0, len(frames) // 2, len(frames) - 1):
+        e64 = CO.lj_cell_f64(frames[k], ref[1], SIGMA, EPS, CUTOFF)[0]
+        assert abs(energy[k] - e64) <= 2e-5 * abs(e64) + 1e-3
+
+
+def test_deferred_rebuilds_fall_back_when_the_list_is_short_lived(ca, O):
+    """Thin skin: there is no room between trigger and switch (theta < 0.25), the run takes the halting scheme."""
+    from chiron_amd import integrators
+
+    n, steps, skin = 2500, 40, 0.05
+    x, box, pot, state, thermo, nbr, integ = _langevin_setup(ca, O, n, 0.3, 43, skin, 4.0)
+    old = integrators._DEFERRED[0]
+    integrators._DEFERRED[0] = True
+    try:
+        out, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr)
+    finally:
+        integrators._DEFERRED[0] = old
+    assert integ.n_rebuilds >= 1 and getattr(integ, "n_adoptions", 0) == 0
+    assert "_deferred" not in nbr.__dict__ and len(integ.rebuild_steps) == integ.n_rebuilds
