@@ -660,7 +660,7 @@ struct StepParticle {
 //     floats under L is at least 2^-24 L), tested on the bit patterns so that -0.0 takes the
 //     general path (it wraps to +0.0);
 //   * min_image_fast == min_image for |d| < L (tests/test_host_logic.py, exhaustive on the CPU).
-template <bool FAST, bool HOT>
+template <bool FAST, bool HOT, bool DEFER>
 __device__ __forceinline__ bool integrate_component(const StepArgs& a, int n_kicks, int do_aoa, float F, float m,
                                                     float bs, float z, float v, float xo, float rf, float sf, float L,
                                                     float hL, float& vn, float& xn, float& sq, float& sqi, float& sqs) {
@@ -702,7 +702,7 @@ __device__ __forceinline__ bool integrate_component(const StepArgs& a, int n_kic
       }
       sq = fmul(r, r);
     }
-    if (a.snap4 != nullptr) {  // deferred rebuilds: distance from the positions the force list was built from
+    if (DEFER) {  // deferred rebuilds: distance from the positions the force list was built from
       float r = fsub(xc, sf);
       if (periodic) {
         if (FAST) {
@@ -720,7 +720,7 @@ __device__ __forceinline__ bool integrate_component(const StepArgs& a, int n_kic
 }
 
 // The loads of one particle's integrate work (no arithmetic: see finish_step_particle).
-template <bool HOT, bool PRUNE>
+template <bool HOT, bool PRUNE, bool DEFER = false>
 __device__ __forceinline__ StepParticle load_step_operands(const StepArgs& a, long long step, int do_aoa, int p0, int pl,
                                                            int ppb) {
   StepParticle t;
@@ -742,10 +742,10 @@ __device__ __forceinline__ StepParticle load_step_operands(const StepArgs& a, lo
       t.ref = a.ref4[t.pp];
       t.m = t.ref.w;
     }
-    if (a.snap4 && do_aoa) t.snap = a.snap4[t.pp];
+    if (DEFER && do_aoa) t.snap = a.snap4[t.pp];
     // (a reference rebuild event of the deferred scheme copies the input positions into ref4 even in the force-only
     // launch that ends a run)
-    if (do_aoa || a.snap4 != nullptr) t.x = a.x_cur[t.pp];
+    if (do_aoa || DEFER) t.x = a.x_cur[t.pp];
     if (do_aoa) {
       // the path travelled since the last pruning pass rides in x4.w; a pruning launch starts it over
       t.path0 = PRUNE ? 0.f : t.x.w;
@@ -787,7 +787,7 @@ __device__ __forceinline__ StepParticle load_step_particle(const StepArgs& a, lo
 //      the box, |x - ref| < L) runs branch-free; a particle that falls outside it is redone
 //      through the general formulas, which give the same bits wherever both apply.
 // Returns true when this thread's particle has moved too far for the pruned inner list.
-template <bool HOT>
+template <bool HOT, bool DEFER = false>
 __device__ __forceinline__ bool step_epilogue(const StepArgs& a, const StepParticle& tk, const float* sF, long long step,
                                               int n_kicks, int do_aoa, bool is_event = false) {
   bool stale = false;
@@ -798,19 +798,20 @@ __device__ __forceinline__ bool step_epilogue(const StepArgs& a, const StepParti
     // deferred rebuilds: a launch that starts with a reference rebuild event measures the skin check of its new
     // positions from its INPUT positions -- the reference positions the rebuild has just taken
     // (chiron/integrators.py:241-242: build(x) stores ref_positions = x, chiron/neighbors.py:671)
-    const float r0 = is_event ? tk.x.x : tk.ref.x, r1 = is_event ? tk.x.y : tk.ref.y, r2 = is_event ? tk.x.z : tk.ref.z;
-    bool rare = integrate_component<true, HOT>(a, n_kicks, do_aoa, F0, tk.m, tk.bs, tk.z[0], tk.v[0], tk.x.x, r0, tk.snap.x,
+    const bool ev = DEFER && is_event;
+    const float r0 = ev ? tk.x.x : tk.ref.x, r1 = ev ? tk.x.y : tk.ref.y, r2 = ev ? tk.x.z : tk.ref.z;
+    bool rare = integrate_component<true, HOT, DEFER>(a, n_kicks, do_aoa, F0, tk.m, tk.bs, tk.z[0], tk.v[0], tk.x.x, r0, tk.snap.x,
                                                a.box.lx, a.box.hx, vn0, xn0, sq0, si0, ss0);
-    rare |= integrate_component<true, HOT>(a, n_kicks, do_aoa, F1, tk.m, tk.bs, tk.z[1], tk.v[1], tk.x.y, r1, tk.snap.y,
+    rare |= integrate_component<true, HOT, DEFER>(a, n_kicks, do_aoa, F1, tk.m, tk.bs, tk.z[1], tk.v[1], tk.x.y, r1, tk.snap.y,
                                            a.box.ly, a.box.hy, vn1, xn1, sq1, si1, ss1);
-    rare |= integrate_component<true, HOT>(a, n_kicks, do_aoa, F2, tk.m, tk.bs, tk.z[2], tk.v[2], tk.x.z, r2, tk.snap.z,
+    rare |= integrate_component<true, HOT, DEFER>(a, n_kicks, do_aoa, F2, tk.m, tk.bs, tk.z[2], tk.v[2], tk.x.z, r2, tk.snap.z,
                                            a.box.lz, a.box.hz, vn2, xn2, sq2, si2, ss2);
     if (__builtin_expect(rare, 0)) {
-      (void)integrate_component<false, HOT>(a, n_kicks, do_aoa, F0, tk.m, tk.bs, tk.z[0], tk.v[0], tk.x.x, r0, tk.snap.x,
+      (void)integrate_component<false, HOT, DEFER>(a, n_kicks, do_aoa, F0, tk.m, tk.bs, tk.z[0], tk.v[0], tk.x.x, r0, tk.snap.x,
                                             a.box.lx, a.box.hx, vn0, xn0, sq0, si0, ss0);
-      (void)integrate_component<false, HOT>(a, n_kicks, do_aoa, F1, tk.m, tk.bs, tk.z[1], tk.v[1], tk.x.y, r1, tk.snap.y,
+      (void)integrate_component<false, HOT, DEFER>(a, n_kicks, do_aoa, F1, tk.m, tk.bs, tk.z[1], tk.v[1], tk.x.y, r1, tk.snap.y,
                                             a.box.ly, a.box.hy, vn1, xn1, sq1, si1, ss1);
-      (void)integrate_component<false, HOT>(a, n_kicks, do_aoa, F2, tk.m, tk.bs, tk.z[2], tk.v[2], tk.x.z, r2, tk.snap.z,
+      (void)integrate_component<false, HOT, DEFER>(a, n_kicks, do_aoa, F2, tk.m, tk.bs, tk.z[2], tk.v[2], tk.x.z, r2, tk.snap.z,
                                             a.box.lz, a.box.hz, vn2, xn2, sq2, si2, ss2);
     }
     const float vn[3] = {vn0, vn1, vn2}, xn[3] = {xn0, xn1, xn2}, sq[3] = {sq0, sq1, sq2}, sqi[3] = {si0, si1, si2};
@@ -819,14 +820,14 @@ __device__ __forceinline__ bool step_epilogue(const StepArgs& a, const StepParti
     // B / 6 TB/s for B dirty bytes: 7.3 MB at N = 262144), and the next launch finds L2 cold either way.
     store_wt3(a.v + 3 * (size_t)tk.pp, vn[0], vn[1], vn[2]);
     // the reference's rebuild (its side effect on the state): reference positions := this launch's input positions
-    if (is_event) store_wt4(a.ref4 + tk.pp, make_float4(tk.x.x, tk.x.y, tk.x.z, tk.m));
+    if (ev) store_wt4(a.ref4 + tk.pp, make_float4(tk.x.x, tk.x.y, tk.x.z, tk.m));
     if (do_aoa) {
       // x4.w: path length since the last pruning pass (a sum of per-step displacements bounds the displacement)
       const float path = tk.path0 + __builtin_sqrtf((sqi[0] + sqi[1]) + sqi[2]);
       store_wt4(reinterpret_cast<float4*>(a.x_next) + tk.pp, make_float4(xn[0], xn[1], xn[2], path));
       // skin check :241: (rx^2 + ry^2) + rz^2 in the reference's order
       const bool moved = (HOT || a.ref4) && fadd(fadd(sq[0], sq[1]), sq[2]) > a.T_half_skin;
-      if (a.snap4 == nullptr) {
+      if (!DEFER) {
         if (moved) {
           atomicMin(&a.ctrl[3], (int)(step + 1));
           // (tell the host at once: the copy this launch published when it started cannot know yet)
@@ -860,7 +861,7 @@ __device__ __forceinline__ bool step_epilogue(const StepArgs& a, const StepParti
 // `epoch` counts the refreshes since the state was loaded (-1 before the first): the two
 // "inner list is stale" words hold the epoch in which they were raised, so a refresh invalidates
 // them without anybody having to clear a word another block may be reading.
-template <int G, bool HOT, bool PRUNE>
+template <int G, bool HOT, bool PRUNE, bool DEFER>
 __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long step, int epoch, int n_lead,
                                                  unsigned nblocks, const float4* x_lead, const uint32_t* sfl,
                                                  const int32_t* sdeg, StepArgs a, int n_kicks, int do_aoa) {
@@ -916,12 +917,12 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   const int32_t* deg_use = inner ? a.degi : a.deg;
   // deferred rebuilds: did the previous launch book a reference rebuild for this step? (launch-uniform; the word of
   // this step's parity was last written by an EARLIER launch, and a stale value never equals a later step)
-  const bool is_event = a.snap4 != nullptr && ctrl_first[10 + (int)(step & 1)] == (int)step;
+  const bool is_event = DEFER && ctrl_first[10 + (int)(step & 1)] == (int)step;
   const int p0 = blk * PPB;
   // ---- operands of this thread's integrate work (threads 0..PPB-1 own one particle each: the
   //      first wavefronts of the block), requested before the force loop so their latency and the
   //      Philox arithmetic hide under it ----
-  StepParticle tk = load_step_operands<HOT, PRUNE>(a, step, do_aoa, p0, threadIdx.x, PPB);
+  StepParticle tk = load_step_operands<HOT, PRUNE, DEFER>(a, step, do_aoa, p0, threadIdx.x, PPB);
 
   float4 xi;
   float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
@@ -959,7 +960,7 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   }
   __syncthreads();
   // ---- integrate: one particle per thread, packed into the first PPB threads of the block ----
-  const bool stale = step_epilogue<HOT>(a, tk, sF, step, n_kicks, do_aoa, is_event);
+  const bool stale = step_epilogue<HOT, DEFER>(a, tk, sF, step, n_kicks, do_aoa, is_event);
   // the inner list stays off until the next refresh (a new epoch) outdates the word
   if (do_aoa && (HOT || a.fli) && epoch >= 0 && (stale || (!inner && !PRUNE && threadIdx.x == 0)))
     ctrl_first[4 + (int)((step + 1) & 1)] = epoch;
@@ -1137,15 +1138,24 @@ static void launch_step_g(const StepArgs& a, long long step, int n_kicks, int do
   const bool spec_inner = a.fli != nullptr && !prune && epoch >= 0;
   const uint32_t* sfl = spec_inner ? a.fli : a.fl;
   const int32_t* sdeg = spec_inner ? a.degi : a.deg;
-  if (hot && prune) {
-    hipLaunchKernelGGL((k_lj_step<G, true, true>), dim3(blocks), dim3(256), 0, st, a.ctrl, step, epoch, a.n, blocks, a.x_cur, sfl, sdeg, a, n_kicks, do_aoa);
-  } else if (hot) {
-    hipLaunchKernelGGL((k_lj_step<G, true, false>), dim3(blocks), dim3(256), 0, st, a.ctrl, step, epoch, a.n, blocks, a.x_cur, sfl, sdeg, a, n_kicks, do_aoa);
-  } else if (prune) {
-    hipLaunchKernelGGL((k_lj_step<G, false, true>), dim3(blocks), dim3(256), 0, st, a.ctrl, step, epoch, a.n, blocks, a.x_cur, sfl, sdeg, a, n_kicks, do_aoa);
+  // DEFER (deferred rebuilds, chx_langevin_t::snap4) is a template parameter, not a run-time switch: compiled into the
+  // one kernel, its extra registers and branches cost the halting scheme's steady-state launch 2.5 % (measured, round 3)
+#define CHX_LAUNCH_STEP(HOT_, PRUNE_, DEFER_)                                                                             \
+  hipLaunchKernelGGL((k_lj_step<G, HOT_, PRUNE_, DEFER_>), dim3(blocks), dim3(256), 0, st, a.ctrl, step, epoch, a.n, blocks, \
+                     a.x_cur, sfl, sdeg, a, n_kicks, do_aoa)
+  const bool defer = a.snap4 != nullptr;
+  if (defer) {
+    if (hot && prune) CHX_LAUNCH_STEP(true, true, true);
+    else if (hot) CHX_LAUNCH_STEP(true, false, true);
+    else if (prune) CHX_LAUNCH_STEP(false, true, true);
+    else CHX_LAUNCH_STEP(false, false, true);
   } else {
-    hipLaunchKernelGGL((k_lj_step<G, false, false>), dim3(blocks), dim3(256), 0, st, a.ctrl, step, epoch, a.n, blocks, a.x_cur, sfl, sdeg, a, n_kicks, do_aoa);
+    if (hot && prune) CHX_LAUNCH_STEP(true, true, false);
+    else if (hot) CHX_LAUNCH_STEP(true, false, false);
+    else if (prune) CHX_LAUNCH_STEP(false, true, false);
+    else CHX_LAUNCH_STEP(false, false, false);
   }
+#undef CHX_LAUNCH_STEP
   if (dbg) (void)hipStreamSynchronize(st);
 }
 

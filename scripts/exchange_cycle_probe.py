@@ -21,10 +21,10 @@ marks = {}
 orig = I._RunState._enqueue_window
 
 
-def enq(self, s0, n):
+def enq(self, s0, n, *a, **k):
     if s0 == 0:
         marks["first_launch"] = time.perf_counter()
-    return orig(self, s0, n)
+    return orig(self, s0, n, *a, **k)
 
 
 I._RunState._enqueue_window = enq
