@@ -575,7 +575,7 @@ def test_no_kernel_reads_the_dispatch_packet(tmp_path):
         assert not spilled, f"{os.path.basename(src)}: kernels with scratch memory: {spilled[:4]}"
         if src.endswith("chx_lj.hip"):
             sizes = {}
-            for m in re.finditer(r"\.amdhsa_kernel _Z9k_lj_stepILi(\d+)ELb[01]ELb[01]EE\S*\s+\.amdhsa_group_segment_fixed_size (\d+)", text):
+            for m in re.finditer(r"\.amdhsa_kernel _Z9k_lj_stepILi(\d+)ELb[01]ELb[01]ELb[01]EE\S*\s+\.amdhsa_group_segment_fixed_size (\d+)", text):
                 sizes.setdefault(int(m.group(1)), set()).add(int(m.group(2)))
             assert sizes, "no k_lj_step instantiation found"
             for g, lds in sizes.items():
