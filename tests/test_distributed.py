@@ -190,6 +190,36 @@ def test_bench_launcher_starts_n_ranks_gloo_dry_run():
     assert sorted(line["config"]["state_of_replica"]) == [0, 1]
 
 
+def test_bench_launcher_eight_ranks_gloo_dry_run_and_torchrun():
+    """The configuration the driver measures at round end, C5: eight ranks.  (a) `python bench.py --gpus 8` as its own
+    launcher; (b) under the driver's own command line, `python -m torch.distributed.run --nproc-per-node 8 ... bench.py
+    --gpus 8` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).  Dry run: gloo, no kernels -- launcher,
+    group, barrier + max-over-ranks timing and the exchange collective with all eight ranks in it."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    res, lines = _run_bench(["--gpus", "8", "--steps", "4000", "--warmup", "0", "--dry-run-backend", "gloo"], timeout=400)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert len(lines) == 1, res.stdout
+    cfg = lines[0]["config"]
+    assert lines[0]["n_gpus"] == 8 and cfg["group_world_size"] == 8 and cfg["ranks"] == list(range(8))
+    assert cfg["replica_exchanges"] == 4 and sorted(cfg["state_of_replica"]) == list(range(8))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2000",
+                          "--warmup", "0", "--dry-run-backend", "gloo"], env=env, capture_output=True, text=True, timeout=400)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [json.loads(l) for l in res.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 8 and lines[0]["config"]["group_world_size"] == 8
+    assert lines[0]["config"]["replica_exchanges"] == 2
+
+
 def test_bench_rejects_world_size_mismatch_and_relays_failures():
     # under a launcher that started a different number of ranks than --gpus says: refuse, do not mislabel
     res, lines = _run_bench(["--gpus", "4", "--dry-run-backend", "gloo"],
