@@ -131,6 +131,44 @@ def pin_process_cpus(width: int = 4, slot: Optional[int] = None):
     return cpus
 
 
+def launch_regime_probe(run_steps, launches: int = 20000, threshold: int = 150) -> dict:
+    """Is this process in the HIP runtime's slow launch regime?  (one fresh process in about
+    eight launches 3-12 % slower for its whole life -- its launching thread collides with a helper thread of the
+    runtime, ~10 us per collision -- whatever the pinning, the poll policy or the runtime's environment knobs.)
+
+    ``run_steps(n)`` must push ``n`` step launches through ``chx_langevin_fused_run`` from the calling thread and
+    return when they are enqueued or done.  While it runs the launch window busy-waits instead of sleeping, so the only
+    voluntary context switches the launching thread can make are futex waits inside the runtime: a fast process makes
+    0-5 of them per 20 000 launches, a mildly slow one 400-700, a badly slow one 900-1800 (round-2 measurements).
+    Returns {"voluntary_switches", "launches", "slow"}.  A driver that finds itself slow before it has joined any
+    collective can simply be started again: the regime is drawn anew by every process (bench.py does that)."""
+    import threading
+
+    from . import _lib
+
+    lib = _lib.load()
+
+    def switches() -> int:
+        try:
+            with open(f"/proc/self/task/{threading.get_native_id()}/status") as fh:
+                for line in fh:
+                    if line.startswith("voluntary_ctxt_switches"):
+                        return int(line.split()[1])
+        except (OSError, ValueError):
+            pass
+        return -1
+
+    prev = lib.chx_set_poll_sleep_ns(0)
+    try:
+        before = switches()
+        run_steps(int(launches))
+        after = switches()
+    finally:
+        lib.chx_set_poll_sleep_ns(prev)
+    count = after - before if before >= 0 and after >= 0 else -1
+    return {"voluntary_switches": count, "launches": int(launches), "slow": count > threshold * launches / 20000.0}
+
+
 def default_device() -> torch.device:
     """``cuda`` (ROCm) when a GPU is visible, else ``cpu`` (host logic/tests only)."""
     if _FORCED_DEVICE is not None:

@@ -1178,14 +1178,21 @@ static inline void cpu_relax() {
   sched_yield();
 #endif
 }
+// (run-time switchable: chx_set_poll_sleep_ns -- the launch-regime probe of chiron_amd/_device.py spins for its
+// measurement, where a voluntary context switch of the launching thread can only be a collision with the runtime)
+static long g_poll_sleep_ns = [] {
+  const char* e = getenv("CHX_POLL");
+  if (e && (e[0] == 's' && e[1] == 'p')) return 0L;  // "spin"
+  const char* n = getenv("CHX_POLL_SLEEP_NS");
+  long v = n ? atol(n) : 5000L;
+  return v < 0 ? 0L : v;
+}();
+extern "C" int64_t chx_set_poll_sleep_ns(int64_t ns) {
+  const long old = __atomic_exchange_n(&g_poll_sleep_ns, (long)(ns < 0 ? 0 : ns), __ATOMIC_RELAXED);
+  return (int64_t)old;
+}
 static PollPolicy poll_policy() {
-  static const long ns = [] {
-    const char* e = getenv("CHX_POLL");
-    if (e && (e[0] == 's' && e[1] == 'p')) return 0L;  // "spin"
-    const char* n = getenv("CHX_POLL_SLEEP_NS");
-    long v = n ? atol(n) : 5000L;
-    return v < 0 ? 0L : v;
-  }();
+  const long ns = __atomic_load_n(&g_poll_sleep_ns, __ATOMIC_RELAXED);
   if (ns > 0) {
     static thread_local bool slack_set = false;
     if (!slack_set) {

@@ -402,6 +402,11 @@ int chx_langevin_fused_run(const chx_langevin_t* p_h, float* x_even, float* x_od
                            int32_t n_steps, int32_t kicks_first, int32_t window, int32_t watch_trigger,
                            int32_t* n_enqueued_out, chx_stream_t stream);
 
+/* How chx_langevin_fused_run waits when its launch queue is full: sleep_ns > 0 -- nanosleep that long between polls
+ * (default 5000, or CHX_POLL_SLEEP_NS; the queue refills in bursts of window / 2 launches); 0 -- busy-wait
+ * (CHX_POLL=spin).  Host-side setting of the calling process; returns the previous value. */
+int64_t chx_set_poll_sleep_ns(int64_t sleep_ns);
+
 /* Control-block plumbing of the loop above, as ordinary kernels on the caller's stream:
  * chx_ctrl_reset writes {0, 0, 0, INT32_MAX, -2, -2, 0, 0,  0, -1, -1, -1, INT32_MAX, 0, 0, 0}; chx_publish copies n <= 64 ints into
  * HOST-MAPPED pinned memory (host_mapped_dst is the device-visible address of a
