@@ -34,7 +34,7 @@ for f in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"),
         if wl is None:
             continue
         # k_lj_step<G, HOT, PRUNE>: the launches that also refresh the inner list are a kernel of their own
-        kern = m.group(1) + ("+refresh" if m.group(1) == "k_lj_step" and len(flags) == 2 and flags[1] == "true" else "")
+        kern = m.group(1) + ("+refresh" if m.group(1) == "k_lj_step" and len(flags) >= 2 and flags[1] == "true" else "")
         acc[(wl, kern, g)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 
 res = {}
