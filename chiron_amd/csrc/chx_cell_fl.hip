@@ -179,6 +179,11 @@ __device__ __forceinline__ void build_row_of_particle(
 }
 
 // one wavefront per PARTICLE (the general kernel: any row length up to the on-chip candidate buffer)
+// STRIDE: grid-stride over the rows -- a launch with fewer wavefronts than rows (the background builds of the deferred
+// scheme, which leave most wave slots to the step kernels running beside them) walks several rows per wave.  A
+// template parameter: the loop around the row costs the ordinary one-wave-per-row launch 13 % (46 -> 52 us at
+// N = 32768, rocprofv3, round 3).
+template <bool STRIDE>
 __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
     const float4* __restrict__ xs4, int n, int m, Box3 box, float T, CellGrid g,
     const int32_t* __restrict__ cell_of, const int32_t* __restrict__ cell_start,
@@ -186,12 +191,17 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
     int32_t* __restrict__ n_nbr, int fg, int fcap, uint32_t* __restrict__ fl, int32_t* __restrict__ deg,
     int32_t* __restrict__ status) {
   __shared__ uint32_t cand_all[4][CHX_CELL_CAP];
-  // (grid-stride over the rows: a launch with fewer wavefronts than rows -- the background builds of the deferred
-  // scheme, which must leave most wave slots to the step kernels running beside them -- walks several rows per wave)
-  const int waves = (int)((gridDim.x * blockDim.x) >> 6);
-  for (int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += waves)
-    build_row_of_particle<true>(w, cand_all[threadIdx.x >> 6], xs4, n, m, box, T, g, cell_start, sorted_ids, nl, first_out,
+  const int w0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (!STRIDE) {
+    if (w0 >= n) return;
+    build_row_of_particle<true>(w0, cand_all[threadIdx.x >> 6], xs4, n, m, box, T, g, cell_start, sorted_ids, nl, first_out,
                                 n_nbr, fg, fcap, fl, deg, status);
+  } else {
+    const int waves = (int)((gridDim.x * blockDim.x) >> 6);
+    for (int w = w0; w < n; w += waves)
+      build_row_of_particle<true>(w, cand_all[threadIdx.x >> 6], xs4, n, m, box, T, g, cell_start, sorted_ids, nl, first_out,
+                                  n_nbr, fg, fcap, fl, deg, status);
+  }
 }
 
 // One wavefront per CELL: the (about ten at the BASELINE density) particles of a cell share their 27-cell
@@ -467,10 +477,15 @@ extern "C" int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_
   static const int forced = [] { const char* e = getenv("CHX_BUILD_KERNEL"); return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'c' ? 2 : 0)); }();
   const bool per_particle = forced == 1 || (forced == 0 && (int64_t)grid.ncx * grid.ncy * grid.ncz < 8192);
   if (per_particle) {
-    const unsigned pb = (max_blocks > 0 && (unsigned)max_blocks < wb) ? (unsigned)max_blocks : wb;
-    hipLaunchKernelGGL(k_nl_build_cell_fl, dim3(pb), dim3(256), 0, st, xs4, n, m, make_box3(box), T, grid,
-                       cell_of, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, chunks * CHX_FL_QUAD * g,
-                       fl_out, deg_out, status8);
+    if (max_blocks > 0 && (unsigned)max_blocks < wb) {
+      hipLaunchKernelGGL((k_nl_build_cell_fl<true>), dim3((unsigned)max_blocks), dim3(256), 0, st, xs4, n, m, make_box3(box), T,
+                         grid, cell_of, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, chunks * CHX_FL_QUAD * g,
+                         fl_out, deg_out, status8);
+    } else {
+      hipLaunchKernelGGL((k_nl_build_cell_fl<false>), dim3(wb), dim3(256), 0, st, xs4, n, m, make_box3(box), T, grid,
+                         cell_of, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, chunks * CHX_FL_QUAD * g,
+                         fl_out, deg_out, status8);
+    }
   } else {
     const int ncell = grid.ncx * grid.ncy * grid.ncz;
     static const int split_env = [] { const char* e = getenv("CHX_BUILD_SPLIT"); return e ? atoi(e) : 0; }();
