@@ -2038,3 +2038,45 @@ def test_deferred_rebuilds_fall_back_when_the_list_is_short_lived(ca, O):
         integrators._DEFERRED[0] = old
     assert integ.n_rebuilds >= 1 and getattr(integ, "n_adoptions", 0) == 0
     assert "_deferred" not in nbr.__dict__ and len(integ.rebuild_steps) == integ.n_rebuilds
+
+
+def test_deferred_rebuilds_survive_a_list_that_runs_out_early(ca, O, monkeypatch):
+    """The schedule's prediction can fail (here it is made to: the trigger fires at 98 % of the skin, far too late for
+    lead + adopt steps): the halt word then fires on the force list's OWN positions.  While those are still the
+    reference's (no switch yet) the halt IS the reference's rebuild and the host carries it out, abandoning the build in
+    flight; after a switch only the force list is renewed, on the spot, and a reference event booked for that very
+    step stays booked.  Either way: the halting scheme's events, trajectory and final list."""
+    monkeypatch.setenv("CHX_DEFER_THETA", "0.98")
+    steps = 600
+    x, box, pot, a, nbr_a, integ_a, _ = _deferred_run(ca, O, True, steps)
+    monkeypatch.delenv("CHX_DEFER_THETA")
+    _, _, _, b, nbr_b, integ_b, _ = _deferred_run(ca, O, False, steps)
+    assert integ_a.n_rebuilds == integ_b.n_rebuilds >= 3 and integ_a.rebuild_steps == integ_b.rebuild_steps
+    # the first generation's halt coincides with the reference's first rebuild: carried out by the host
+    host_events, dev_log = integ_a._rebuild_log
+    assert len(host_events) >= 1 and host_events[0] == integ_b.rebuild_steps[0]
+    L = float(box[0, 0])
+    dx = (a.positions - b.positions).abs()
+    assert torch.minimum(dx, (dx - L).abs()).max().item() < 2e-4
+    ref = nbr_a.ref_positions
+    dref = (ref - nbr_b.ref_positions).abs()
+    assert torch.minimum(dref, (dref - L).abs()).max().item() < 2e-4
+    assert nbr_a.n_builds == nbr_b.n_builds
+    # ... and after a switch: the first switch is allowed to happen on schedule, every later trigger comes too late
+    from chiron_amd import integrators
+
+    orig_adopt = integrators._RunState._adopt
+
+    def adopt_then_sabotage(self, step):
+        orig_adopt(self, step)
+        self._defer.theta = 0.985
+        self.params.trigger_frac = 0.985
+
+    monkeypatch.setattr(integrators._RunState, "_adopt", adopt_then_sabotage)
+    _, _, _, c, nbr_c, integ_c, _ = _deferred_run(ca, O, True, steps)
+    assert integ_c.n_adoptions >= 1 and integ_c.n_internal_halts >= 1
+    assert integ_c.n_rebuilds == integ_b.n_rebuilds and integ_c.rebuild_steps == integ_b.rebuild_steps
+    dx = (c.positions - b.positions).abs()
+    assert torch.minimum(dx, (dx - L).abs()).max().item() < 2e-4
+    dref = (nbr_c.ref_positions - nbr_b.ref_positions).abs()
+    assert torch.minimum(dref, (dref - L).abs()).max().item() < 2e-4
