@@ -402,15 +402,17 @@ def roofline_entry(kind: str, n: int, p_nl: int, seconds: float, extra=None):
             pmc = json.load(fh).get(f"{wl}:{'k_lj_step' if kind == 'step' else 'k_lj_fl'}")
         if pmc:
             pmc_pairs = pmc.get("list_pairs")
-            if pmc_pairs and abs(pmc_pairs - p_nl) <= 0.02 * p_nl:
+            same_layout = extra is None or extra.get("lanes_per_particle") in (None, pmc.get("lanes_per_particle"))
+            if pmc_pairs and abs(pmc_pairs - p_nl) <= 0.02 * p_nl and same_layout:
                 d["traffic"] = int(pmc["traffic_bytes"])
                 d["hbm_GBps_measured"] = round(pmc["traffic_bytes"] / seconds / 1e9, 2)
                 d["traffic_source"] = (f"{pmc.get('source', 'profiles/pmc_traffic.json')}: separate rocprofv3 --pmc passes over this "
                                        f"kernel on the same box geometry equilibrated for {pmc.get('equilibration_steps')} steps "
                                        f"(P_nl = {pmc_pairs}, this run {p_nl}); not collected in this run")
             else:
-                d["traffic_note"] = (f"profiles/pmc_traffic.json was collected on a state with P_nl = {pmc_pairs}; this run's list "
-                                     f"holds {p_nl} pairs: not the same system state, traffic withheld")
+                d["traffic_note"] = (f"profiles/pmc_traffic.json was collected on a state with P_nl = {pmc_pairs} and "
+                                     f"{pmc.get('lanes_per_particle')} lane(s) per particle; this run's list holds {p_nl} pairs"
+                                     f"{'' if same_layout else ' in another lane layout'}: not the same state, traffic withheld")
     except (OSError, ValueError):
         pass
     return d

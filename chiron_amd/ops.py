@@ -346,9 +346,12 @@ def _choose_g(maxdeg: int, n: int) -> int:
     env = os.environ.get("CHX_FL_G")
     if env:
         return int(env)
-    g = 1  # one lane per particle once that alone fills the chip (N >= 2^18: no reduction, no idle partner lanes)
+    g = 1  # one lane per particle once that alone fills the chip twice over (N >= 2^19)
     # (dense rows keep the 2^18 target at every size: rho* = 0.8, N = 32768: 8 lanes 82 k steps/s, 4: 77 k, 16: 73 k)
-    lanes = (1 << 18) if (n >= (1 << 16) or maxdeg > 128) else (1 << 17)
+    # N = 262144: round 2 tuned on the lattice start, where one and two lanes were equal; on the EQUILIBRATED fluid (rows
+    # of 10..64 entries instead of a narrow band around 31: a wave of 64 one-lane rows waits for its longest) two lanes
+    # per particle are worth -5 % on the pair-force kernel and +1 % steps/s (round 3: 58.0-58.1 k against 57.4-57.6 k)
+    lanes = (1 << 19) if n >= (1 << 18) else ((1 << 18) if (n >= (1 << 16) or maxdeg > 128) else (1 << 17))
     while g < 8 and n * g < lanes:
         g *= 2
     while g < 64 and maxdeg > 96 * g:  # (96: at rho* = 0.8, N = 262144 four lanes per particle beat eight by 6 %)

@@ -236,7 +236,7 @@ def test_c4_langevin_is_independent_of_launch_batching(ca, O):
 def test_launch_window_and_chunked_scheme_agree_at_full_size(ca, O, n, monkeypatch):
     """The metric configuration's loop, both ways: the bounded launch queue (chx_langevin_fused_run, the default) and
     the older two-chunks-in-flight scheme end in the same bits -- positions, velocities, rebuild count, rebuilt list --
-    at N = 32,768 (lanes per particle 4, per-particle build kernel) and N = 262,144 (one lane, cell-wise build kernel).
+    at N = 32,768 (lanes per particle 4, per-particle build kernel) and N = 262,144 (two lanes, cell-wise build kernel).
     Thin skin: several rebuilds inside a short run."""
     import os
 
