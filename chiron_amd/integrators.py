@@ -136,6 +136,19 @@ class LangevinIntegrator:
         temperature = thermodynamic_state.temperature
         x0 = sampler_state.positions
 
+        # The list build of chiron/integrators.py:169 goes to the device FIRST: nothing below depends on it until the
+        # state is packed, and the first step launch has to wait for its ~80 us of device time -- every microsecond of
+        # host work done before it is enqueued is a microsecond the device idles at the start of a run() (measured,
+        # round 3: 35 us of a 276 us 20-step run).  A list this integrator has built before for the same box is
+        # rebuilt without waiting for its status block (validated after the first chunk, see _RunState._settle).
+        is_lj = isinstance(potential, LJPotential)
+        spec0 = False
+        if (nbr_list is not None and is_lj and _SPECULATIVE_REBUILD and isinstance(nbr_list, NeighborListNsqrd)
+                and getattr(nbr_list, "_box_token", None) is not None
+                and nbr_list._box_token is getattr(sampler_state, "_box_token", None)
+                and isinstance(x0, torch.Tensor) and x0.is_cuda and x0.dtype == torch.float32):
+            spec0 = nbr_list._build_speculative(x0.clone(), publish=False)  # (_RunState._load copies the status)
+
         key = sampler_state.new_PRNG_key  # :124
 
         # unit arithmetic is slow Python (exact rationals) and the mass upload a host->device copy:
@@ -171,18 +184,8 @@ class LangevinIntegrator:
             sampler_state.velocities = initialize_velocities(temperature, potential.topology, key)
         v0 = sampler_state.velocities
 
-        is_lj = isinstance(potential, LJPotential)
-        spec0 = False
-        if nbr_list is not None:  # :169
-            # a list this integrator has built before for the same box: enqueue the build without
-            # waiting for its status block (validated after the first chunk, see _RunState._settle)
-            if (is_lj and _SPECULATIVE_REBUILD and isinstance(nbr_list, NeighborListNsqrd)
-                    and getattr(nbr_list, "_box_token", None) is not None
-                    and nbr_list._box_token is getattr(sampler_state, "_box_token", None)
-                    and isinstance(x0, torch.Tensor) and x0.is_cuda and x0.dtype == torch.float32):
-                spec0 = nbr_list._build_speculative(x0.clone(), publish=False)  # (_RunState._load copies the status)
-            if not spec0:
-                nbr_list.build_from_state(sampler_state)
+        if nbr_list is not None and not spec0:  # :169
+            nbr_list.build_from_state(sampler_state)
         if is_lj and isinstance(nbr_list, NeighborListNsqrd):
             mode = "fused"
         elif is_lj and (nbr_list is None or isinstance(nbr_list, PairListNsqrd)):
@@ -261,7 +264,7 @@ class LangevinIntegrator:
             st._settle()
 
         st.finish()
-        updated_sampler_state = sampler_state._copy_with(*st.state_user())  # :210-218
+        updated_sampler_state = sampler_state._copy_with(*st.final_state_user())  # :210-218
         # the reference returns the key its loop ended with (:216); the counter-based stream folds the step count in
         updated_sampler_state.current_PRNG_key = chain_key if isinstance(key, JaxKey) else fold_in(key, number_of_steps)
         self.n_rebuilds = st.n_rebuilds
@@ -370,6 +373,7 @@ class _RunState:
         self.kicks_next = 1  # the first step of a run applies only its leading kick
         self.depth = 2  # chunks kept in flight ahead of the host
         self._defer = None
+        self._final_state = None
         self.rebuild_log = ([], None)
         self._snap_is_ref = False
         self._host_events = []  # steps of the reference rebuilds the HOST carried out (halting scheme)
@@ -748,6 +752,11 @@ class _RunState:
         )
         return x3, v3
 
+    def final_state_user(self):
+        """(positions, velocities) a finished run() returns: the copy enqueued behind the final kick when there is one."""
+        cached, self._final_state = getattr(self, "_final_state", None), None
+        return cached if cached is not None else self.state_user()
+
     def positions_user(self) -> torch.Tensor:
         return self._unpack(self._x_cur())
 
@@ -925,11 +934,14 @@ class _RunState:
             self.kicks_next = 2
         return sent
 
-    def _enqueue_kick(self, step: int):
+    def _enqueue_kick(self, step: int, with_state: bool = False):
         """Force + trailing half-kick (chiron/integrators.py:195) as launch ``step``: a no-op if the skin check
-        has fired by then, like every launch of the generation."""
+        has fired by then, like every launch of the generation.  ``with_state``: the copy of positions and velocities
+        back to user order that ends a run() is enqueued right behind it, before the host waits (it is void, and
+        taken again, in the rare case that the kick turns out to have been a no-op)."""
         even, odd = (self.x_a, self.x_b) if self.parity == 0 else (self.x_b, self.x_a)
         ops.langevin_fused_chunk(self.params, even, odd, step, 1, 1, 0)
+        self._final_state = self.state_user() if with_state else None
         ev = torch.cuda.Event()
         ev.record()
         ev.synchronize()
@@ -982,7 +994,7 @@ class _RunState:
                         enq = self._unsettled_step
             if enq == stop:
                 if final and not self._kick_sent:
-                    self._enqueue_kick(stop)  # (waits: everything up to here has run)
+                    self._enqueue_kick(stop, with_state=True)  # (waits: everything up to here has run)
                     self._kick_sent = True
                 else:
                     ev = torch.cuda.Event()
@@ -993,10 +1005,12 @@ class _RunState:
                 # void): the state is back at the rebuild step, on the list the synchronous build made
                 enq = self._unsettled_step
                 self._kick_sent = False
+                self._final_state = None
                 continue
             halt = int(self._gen.host[3])
             if halt > stop:
                 break
+            self._final_state = None
             # the skin check fired while producing x_halt: steps < halt ran, the launches queued behind are no-ops
             # and the rebuild is enqueued behind them
             self._kick_sent = False
@@ -1094,6 +1108,7 @@ class _RunState:
             if int(self._gen.host[3]) <= n_steps:
                 # the skin check fired in the run's very last step and the kick ran as a no-op: rebuild exactly as
                 # _advance_windowed does, then kick
+                self._final_state = None
                 self.parity = (self._gen_parity0 + n_steps - self._gen_step0) & 1
                 self._close_generation()
                 self._halt_rebuild(n_steps, speculative=False)

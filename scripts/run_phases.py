@@ -1,0 +1,50 @@
+"""Host time line inside a short LangevinIntegrator.run(K) (GPU box only): medians over many calls of the time from entry
+to each mark.  usage: python scripts/run_phases.py [K] [workload]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+torch.set_num_threads(1)
+from chiron_amd._device import pin_process_cpus
+pin_process_cpus()
+import bench
+from chiron_amd import integrators as I, neighbors as N
+
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+wl = sys.argv[2] if len(sys.argv) > 2 else "c3"
+fluid, pot, state, thermo, nbr, integ = bench.make_system(wl, 300.0, 32, "cell")
+marks = {}
+
+def wrap(obj, name, tag, when="after"):
+    orig = getattr(obj, name)
+    def f(*a, **k):
+        if when == "before":
+            marks.setdefault(tag, time.perf_counter())
+        r = orig(*a, **k)
+        if when == "after":
+            marks[tag] = time.perf_counter()
+        return r
+    setattr(obj, name, f)
+
+wrap(N.NeighborListNsqrd, "_build_speculative", "1 build enqueued")
+wrap(I._RunState, "__init__", "2 state packed (pack enqueued)")
+wrap(I._RunState, "_enqueue_window", "3 first steps enqueued", "before")
+wrap(I._RunState, "final_kick", "4 kick done (device drained)")
+wrap(I._RunState, "state_user", "5 state unpacked (enqueued)")
+state, nbr = integ.run(state, thermo, number_of_steps=0, nbr_list=nbr)
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < 3.0:
+    state, nbr = integ.run(state, thermo, number_of_steps=2000, nbr_list=nbr)
+rows = []
+for _ in range(400):
+    torch.cuda.synchronize()
+    marks.clear()
+    ta = time.perf_counter()
+    state, nbr = integ.run(state, thermo, number_of_steps=K, nbr_list=nbr)
+    tb = time.perf_counter()
+    torch.cuda.synchronize()
+    tc = time.perf_counter()
+    rows.append([marks.get(k, ta) - ta for k in sorted(marks)] + [tb - ta, tc - ta])
+    keys = sorted(marks)
+r = 1e6 * np.median(np.array(rows), axis=0)
+for k, v in zip(keys + ["6 run() returned", "7 device idle"], r):
+    print(f"  {k:36s} {v:8.1f} us")
