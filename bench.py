@@ -208,7 +208,7 @@ def read_sclk_mhz(device_index: int = 0):
     return None
 
 
-def time_kernels(fluid, pot, state, nbr, integ, reps: int, spin_s: float = 1.0):
+def time_kernels(fluid, pot, state, nbr, integ, reps: int, spin_s: float = 1.0, force_only: bool = False):
     """HIP-event timing (on the launch stream) of the two hot kernels on the current list:
     k_lj_step (fused pair force + BAOAB, what the timed region launches once per step) and
     k_lj_fl (the pair-force kernel alone, what compute_force() launches).
@@ -267,6 +267,9 @@ def time_kernels(fluid, pot, state, nbr, integ, reps: int, spin_s: float = 1.0):
 
     spin(spin_s)
     t_force, force_samples = timed(force_launch, reps)
+    if force_only:
+        p_nl = int(torch.minimum(nbr.n_neighbors, torch.tensor(nbr.n_max_neighbors, device=x4.device)).sum().item())
+        return None, t_force, p_nl, fl
 
     # the fused step kernel on the same state; a huge skin keeps the check from ever firing so that
     # every launch does the full work (the comparison itself still runs)
@@ -370,9 +373,13 @@ def roofline_entry(kind: str, n: int, p_nl: int, seconds: float, extra=None):
     """Algorithmic bytes per launch: pair force 24 N + 16 P_nl; the fused step adds the
     BAOAB traffic B_lang = 60 N (x, v, F in; x, v out) + 12 N (reference positions of the skin check)."""
     force_bytes = 24 * n + 16 * p_nl
+    note = None
     if kind == "step":
         algorithmic = force_bytes + 72 * n
         name = "k_lj_step (fused pair force + BAOAB + wrap + skin check; one launch per MD step)"
+        note = ("the launch walks the dynamically pruned inner list, while the algorithmic bytes are defined on the reference's "
+                "list (SURVEY 8d: P_nl = its non-padding entries): read `frac` as useful work per second against the HBM "
+                "peak, `hbm_GBps_measured` as the bandwidth the launch really draws")
     else:
         algorithmic = force_bytes
         name = "k_lj_fl (pair force over the neighbor list)"
@@ -390,6 +397,8 @@ def roofline_entry(kind: str, n: int, p_nl: int, seconds: float, extra=None):
         "n_particles": n,
         "list_pairs": p_nl,
     }
+    if note:
+        d["note"] = note
     if extra:
         d.update(extra)
     # HBM traffic per launch from the committed PMC passes (profiles/pmc_traffic.json: separate rocprofv3 --pmc runs of
@@ -774,6 +783,14 @@ def main():
         if world == 1 and args.extra_c4 and args.workload != "c4":
             try:
                 fluid4, pot4, state4, thermo4, nbr4, integ4 = make_system("c4", 300.0, args.chunk, "cell")
+                # (for continuity with rounds 1-2, which quoted this kernel on the jittered-lattice start: the same kernel
+                # on that state, named as such -- 17 % fewer listed pairs, rows of nearly equal length)
+                nbr4.build_from_state(state4)
+                _, tf0, p0, fl0 = time_kernels(fluid4, pot4, state4, nbr4, integ4, args.kernel_reps, force_only=True)
+                out["roofline_262k_lattice_start"] = roofline_entry(
+                    "force", fluid4.n_particles, p0, tf0,
+                    {"lanes_per_particle": fl0.g, "system_state": "jittered-lattice start (what rounds 1-2 quoted; NOT the target "
+                                                                   "figure: roofline_262k is, on the equilibrated fluid)"})
                 # ONE system state for everything quoted at C4 (round-2 review): the fluid equilibrated for
                 # --c4-equilibration steps (20 ps) -- the lattice start has 17 % fewer listed pairs and runs 10 % faster
                 state4, nbr4 = integ4.run(state4, thermo4, number_of_steps=args.c4_equilibration, nbr_list=nbr4)
