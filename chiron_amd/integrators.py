@@ -561,13 +561,26 @@ class _RunState:
         """
         env_skin, env_every = os.environ.get("CHX_INNER_SKIN"), os.environ.get("CHX_PRUNE_EVERY")
         inner = float(env_skin) if env_skin is not None else getattr(self.integ, "inner_skin_nm", None)
-        every = int(env_every) if env_every is not None else getattr(self.integ, "prune_every", 32)
+        # Refresh cadence: where the step is a latency chain (N < 2^17) the refreshing launch (+4 us) is worth spreading
+        # over 32 steps; where it is throughput-bound the table should be short instead -- refreshed more often, with a
+        # thinner inner skin (round-3 sweep on the equilibrated fluid, fresh processes alternating: N = 262 144
+        # 58.0 -> 60.1 k steps/s at 20 steps / 0.06 nm against 32 / 0.10; N = 131 072 +1 % at 24 / 0.072)
+        default_every = 32 if self.n < (1 << 17) else (24 if self.n < (1 << 18) else 20)
+        every = int(env_every) if env_every is not None else getattr(self.integ, "prune_every", default_every)
         if inner is None:
-            # little to prune under a thin skin; tiny systems are pure launch latency.  0.12 nm keeps a 300 K argon
-            # fluid on the pruned table for all 32 steps of an epoch; where the step is throughput-bound (N >= 2^17)
-            # the shorter rows of 0.10 nm are worth +2 % and the handful of full-list launches per 20 000 steps they
-            # cost is not (round-2 in-process A/B: N = 131 072 +2 %, 262 144 +1.5-2 %; 32 768 and 65 536 equal)
-            inner = (0.10 if self.n >= (1 << 17) else 0.12) if (skin >= 0.3 and self.n >= 2048) else 0.0
+            # little to prune under a thin skin; tiny systems are pure launch latency.  Otherwise the inner skin is what
+            # the fastest particles (5 sigma_v) travel between two refreshes, on both sides of a pair, with 20 % to
+            # spare: 2.4 * every * dt * 5 sqrt(kT / m_min) -- 0.096 nm for argon at 300 K, dt = 1 fs, every = 32 (round
+            # 2 had tuned 0.12 / 0.10 nm by hand for exactly that system; 0.096 measures the same at N = 32 768 and
+            # +1.3 % at N = 65 536), and the right length again for a hotter replica, a lighter particle, a longer step
+            m_min = getattr(self.integ, "_m_min", None)
+            if m_min is None and skin >= 0.3 and self.n >= 2048:  # (a state built outside run(): benches, probes)
+                m_min = self.integ._m_min = float(self.mass_user.min().item())
+            if skin >= 0.3 and self.n >= 2048 and m_min and every > 0:
+                inner = 2.4 * every * (2.0 * self.half_dt) * 5.0 * float(np.sqrt(self.kT / m_min))
+                inner = min(max(inner, 0.02), 0.6 * skin)
+            else:
+                inner = 0.0
         if inner <= 0.0 or every <= 0 or inner >= skin:
             return 0.0, 0
         return inner, every
