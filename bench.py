@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--c4-equilibration", type=int, default=20000,
                     help="steps (fs) the N=262,144 fluid is propagated from the lattice start before anything is quoted on it")
     ap.add_argument("--extra-c2", type=int, default=1, help="also report C2 (N=512, all-pairs path) steps/s and pairs/s (1 GPU runs)")
+    ap.add_argument("--extra-mc", type=int, default=1, help="also report Monte Carlo displacement trials/s at the workload (1 GPU runs)")
     ap.add_argument("--extra-overlap", type=int, default=1,
                     help="also report the aggregate rate of TWO independent replicas of the workload driven from two "
                          "threads / HIP streams on the one card (1 GPU runs; not the headline: one replica per GPU)")
@@ -367,6 +368,36 @@ def c2_block(chunk: int, steps: int = 20000):
             "kernel_us": round(1e6 * t_k, 3), "kernel_us_samples": [round(1e6 * v, 3) for v in samples],
             "pairs_per_launch": pairs, "pairs_per_s": round(pairs / t_k, 1), "algorithmic_bytes": (24 + 72) * n,
             "bound": "launch latency / fp32 VALU (compute-bound by construction: report pairs/s, SURVEY 8d)"}
+
+
+def mc_block(args, trials: int = 4096):
+    """The Metropolis half of the north star at the metric's configuration: MonteCarloDisplacementMove on the C3 fluid
+    (chiron/mcmc.py:243-306, :357-463, :680-787) through the device-resident trial loop -- propose + skin check, energy
+    over the force list, decision at the head of the next proposal launch: two launches per trial, no host round trip.
+    The displacement is small enough (0.001 nm) that most trials are accepted and the list lasts; rebuild trials count."""
+    import torch
+
+    from chiron_amd import unit
+    from chiron_amd.mcmc import MonteCarloDisplacementMove
+
+    fluid, pot, state, thermo, nbr, integ = make_system(args.workload, 300.0, args.chunk, args.build)
+    state, nbr = integ.run(state, thermo, number_of_steps=2000, nbr_list=nbr)  # off the lattice
+    move = MonteCarloDisplacementMove(displacement_sigma=0.001 * unit.nanometer, number_of_moves=trials, report_interval=10 ** 9)
+    nbr.build_from_state(state)
+    state, thermo, nbr = move.update(state, thermo, nbr)  # warm-up: buffers, first chunk
+    torch.cuda.synchronize()
+    rates = []
+    for _ in range(3):
+        builds0 = nbr.n_builds
+        t0 = time.perf_counter()
+        state, thermo, nbr = move.update(state, thermo, nbr)
+        torch.cuda.synchronize()
+        rates.append(trials / (time.perf_counter() - t0))
+    st = move.statistics
+    return {"move": "MonteCarloDisplacementMove, sigma = 0.001 nm, all particles, device-resident trial loop (two launches per trial)",
+            "n_particles": fluid.n_particles, "trials_per_s": round(sorted(rates)[1], 1), "trials_per_s_windows": [round(r, 1) for r in rates],
+            "trials_per_window": trials, "acceptance": round(st["n_accepted"] / max(1, st["n_proposed"]), 4),
+            "list_rebuilds_last_window": nbr.n_builds - builds0}
 
 
 def roofline_entry(kind: str, n: int, p_nl: int, seconds: float, extra=None):
@@ -775,6 +806,11 @@ def main():
                 out["two_replicas_one_gpu"] = two_replica_overlap(args, args.steps if args.steps >= 2000 else 20000)
             except Exception as exc:  # pragma: no cover - diagnostics only
                 out["two_replicas_one_gpu"] = {"error": repr(exc)}
+        if world == 1 and args.extra_mc:
+            try:
+                out["mc_displacement"] = mc_block(args)
+            except Exception as exc:  # pragma: no cover - diagnostics only
+                out["mc_displacement"] = {"error": repr(exc)}
         if world == 1 and args.extra_c2 and args.workload != "c2":
             try:
                 out["c2"] = c2_block(args.chunk)
