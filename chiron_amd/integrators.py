@@ -565,7 +565,10 @@ class _RunState:
         # over 32 steps; where it is throughput-bound the table should be short instead -- refreshed more often, with a
         # thinner inner skin (round-3 sweep on the equilibrated fluid, fresh processes alternating: N = 262 144
         # 58.0 -> 60.1 k steps/s at 20 steps / 0.06 nm against 32 / 0.10; N = 131 072 +1 % at 24 / 0.072)
-        default_every = 32 if self.n < (1 << 17) else (24 if self.n < (1 << 18) else 20)
+        # (dense rows -- rho* = 0.8: 300 listed partners -- make the refreshing launch itself expensive: 32 steps there
+        # at every size; N = 262 144 at rho* = 0.8: 16.3 k steps/s at 32 against 16.1 k at 20)
+        dense = self.fl is not None and int(getattr(self.fl, "maxdeg", 0) or 0) > 128
+        default_every = 32 if (self.n < (1 << 17) or dense) else (24 if self.n < (1 << 18) else 20)
         every = int(env_every) if env_every is not None else getattr(self.integ, "prune_every", default_every)
         if inner is None:
             # little to prune under a thin skin; tiny systems are pure launch latency.  Otherwise the inner skin is what
