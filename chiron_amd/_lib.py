@@ -150,6 +150,7 @@ SIGNATURES = {
     "chx_langevin_fused_chunk": (C.c_int, [C.POINTER(LangevinParams), _P, _P, _I64, _I32, _I32, _I32, _P]),
     "chx_langevin_fused_run": (C.c_int, [C.POINTER(LangevinParams), _P, _P, _I64, _I32, _I32, _I32, _I32, C.POINTER(C.c_int32), _P]),
     "chx_set_poll_sleep_ns": (_I64, [_I64]),
+    "chx_poll_stats": (C.c_int, [C.POINTER(_I64), _I32]),
     "chx_ctrl_reset": (C.c_int, [_P, _P]),
     "chx_publish": (C.c_int, [_P, _P, _I32, _P]),
     "chx_mc_displace": (C.c_int, [_P, _P, _P, _I32, _F, Box, _U32, _U32, _U32, _P, _P]),

@@ -1180,6 +1180,15 @@ static inline void cpu_relax() {
 }
 // (run-time switchable: chx_set_poll_sleep_ns -- the launch-regime probe of chiron_amd/_device.py spins for its
 // measurement, where a voluntary context switch of the launching thread can only be a collision with the runtime)
+// diagnostics of the sleeping window (chx_poll_stats): waits, naps, wake-ups that found the queue (nearly) empty, ns asleep
+static int64_t g_poll_stats[4] = {0, 0, 0, 0};
+extern "C" int chx_poll_stats(int64_t* out4_h, int32_t reset) {
+  if (out4_h)
+    for (int i = 0; i < 4; ++i) out4_h[i] = __atomic_load_n(&g_poll_stats[i], __ATOMIC_RELAXED);
+  if (reset)
+    for (int i = 0; i < 4; ++i) __atomic_store_n(&g_poll_stats[i], 0, __ATOMIC_RELAXED);
+  return CHX_OK;
+}
 static long g_poll_sleep_ns = [] {
   const char* e = getenv("CHX_POLL");
   if (e && (e[0] == 's' && e[1] == 'p')) return 0L;  // "spin"
@@ -1270,14 +1279,23 @@ int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, in
         int last = hc[0];
         bool timing = false;
         timespec t0{};
+        if (poll.sleep_ns > 0) g_poll_stats[0] += 1;
         for (unsigned spins = 0;; ++spins) {
           if ((long long)hc[3] <= s) return CHX_OK;
           if (watch && hc[12] != 0x7FFFFFFF) return CHX_OK;
           const int begun = hc[0];  // newest launch that has begun; begun+1 .. s-1 are still waiting
-          if (s - begun <= low) break;
+          if (s - begun <= low) {
+            if (poll.sleep_ns > 0 && s - begun <= 2) g_poll_stats[2] += 1;  // overslept: the queue is all but dry
+            break;
+          }
           if (poll.sleep_ns > 0) {
             const timespec nap = {0, poll.sleep_ns};
+            timespec n0, n1;
+            clock_gettime(CLOCK_MONOTONIC, &n0);
             nanosleep(&nap, nullptr);
+            clock_gettime(CLOCK_MONOTONIC, &n1);
+            g_poll_stats[1] += 1;
+            g_poll_stats[3] += (n1.tv_sec - n0.tv_sec) * 1000000000LL + (n1.tv_nsec - n0.tv_nsec);
           } else {
             cpu_relax();
           }

@@ -406,6 +406,9 @@ int chx_langevin_fused_run(const chx_langevin_t* p_h, float* x_even, float* x_od
  * (default 5000, or CHX_POLL_SLEEP_NS; the queue refills in bursts of window / 2 launches); 0 -- busy-wait
  * (CHX_POLL=spin).  Host-side setting of the calling process; returns the previous value. */
 int64_t chx_set_poll_sleep_ns(int64_t sleep_ns);
+/* Diagnostics of the sleeping window since the last reset: out4_h = {waits on a full queue, naps, wake-ups that found
+ * two or fewer launches still queued (the nap outlasted the queue), nanoseconds spent in nanosleep}. */
+int chx_poll_stats(int64_t* out4_h, int32_t reset);
 
 /* Control-block plumbing of the loop above, as ordinary kernels on the caller's stream:
  * chx_ctrl_reset writes {0, 0, 0, INT32_MAX, -2, -2, 0, 0,  0, -1, -1, -1, INT32_MAX, 0, 0, 0}; chx_publish copies n <= 64 ints into

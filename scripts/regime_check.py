@@ -16,9 +16,17 @@ t0 = time.perf_counter()
 while time.perf_counter() - t0 < 2.5:
     state, nbr = integ.run(state, thermo, number_of_steps=2000, nbr_list=nbr)
     torch.cuda.synchronize()
+import ctypes
+from chiron_amd import _lib
+lib = _lib.load()
+lib.chx_poll_stats(None, 1)
 res = []
 for _ in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     state, nbr = integ.run(state, thermo, number_of_steps=20000, nbr_list=nbr)
     torch.cuda.synchronize(); res.append(20000 / (time.perf_counter() - t0))
-print(f"probe {probe}  ->  median {sorted(res)[1]:.0f} steps/s {[round(r) for r in res]}")
+st = (ctypes.c_int64 * 4)()
+lib.chx_poll_stats(st, 0)
+waits, naps, dry, ns = [int(v) for v in st]
+print(f"probe {probe}  ->  median {sorted(res)[1]:.0f} steps/s {[round(r) for r in res]}  poll: {waits} waits, {naps} naps "
+      f"({ns / max(1, naps) / 1e3:.1f} us each), {dry} dry wake-ups ({100.0 * dry / max(1, waits):.2f} %)")
