@@ -370,6 +370,37 @@ def c2_block(chunk: int, steps: int = 20000):
             "bound": "launch latency / fp32 VALU (compute-bound by construction: report pairs/s, SURVEY 8d)"}
 
 
+def short_run_block(integ, thermo, state, nbr, k: int, calls: int = 200):
+    """Consecutive run(k) calls, each continuing from the state the previous one returned: what a short call costs with
+    the reference's list build on entry (chiron/integrators.py:169; what `value` is measured with) and with the list
+    carried over from the previous call (the integrator's default for runs this short: the build on entry shrinks to
+    "reference positions := x0", the caller's list is rebuilt only if it is read)."""
+    import torch
+
+    from chiron_amd import integrators
+
+    out = {"steps_per_call": k, "calls": calls, "statistic": "median wall time of one call between two device synchronisations"}
+    keep = integrators._CARRY[0]
+    try:
+        for name, carry in (("list_build_on_entry", False), ("list_carried_over", True)):
+            integrators._CARRY[0] = carry
+            integ.n_carried_runs = 0
+            state, nbr = integ.run(state, thermo, number_of_steps=k, nbr_list=nbr)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(calls):
+                t0 = time.perf_counter()
+                state, nbr = integ.run(state, thermo, number_of_steps=k, nbr_list=nbr)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            med = sorted(ts)[len(ts) // 2]
+            out[name] = {"us_per_call": round(1e6 * med, 1), "steps_per_s": round(k / med, 1),
+                         "calls_carried": int(getattr(integ, "n_carried_runs", 0))}
+    finally:
+        integrators._CARRY[0] = keep
+    return state, nbr, out
+
+
 def mc_block(args, trials: int = 4096):
     """The Metropolis half of the north star at the metric's configuration: MonteCarloDisplacementMove on the C3 fluid
     (chiron/mcmc.py:243-306, :357-463, :680-787) through the device-resident trial loop -- propose + skin check, energy
@@ -684,6 +715,12 @@ def main():
         dist.all_gather_into_tensor(torch.empty(world, dtype=torch.float64, device=coll_dev), warm)
         rex.gather_energies(torch.zeros(1, dtype=torch.float64, device="cuda"))
         torch.cuda.synchronize()
+    # `value`, the warm-up in front of it and the steady-state windows all run with the reference's list build on every
+    # run() entry (chiron/integrators.py:169), as in rounds 1-2: the integrator's list carry-over for short calls is
+    # measured separately (`short_run`)
+    from chiron_amd import integrators as _integrators
+
+    _integrators._CARRY[0] = False
     # set-up (no steps): first list build, pinned read-back slots, device scratch
     integ.run(state, rex.my_state, number_of_steps=0, nbr_list=nbr)
     if exchange_on:
@@ -801,6 +838,12 @@ def main():
             "roofline": roof,
             "roofline_pair_force": roof_force,
         }
+        out["config"]["list_carry_over"] = False
+        if world == 1:
+            try:
+                state, nbr, out["short_run"] = short_run_block(integ, rex.my_state, state, nbr, args.steps if args.steps <= 64 else 20)
+            except Exception as exc:  # pragma: no cover - diagnostics only
+                out["short_run"] = {"error": repr(exc)}
         if world == 1 and args.extra_overlap:
             try:
                 out["two_replicas_one_gpu"] = two_replica_overlap(args, args.steps if args.steps >= 2000 else 20000)

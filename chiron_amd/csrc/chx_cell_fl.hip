@@ -625,3 +625,32 @@ extern "C" int chx_repack_langevin(const float* x4_old, const float* v_old, cons
                      v_new, reinterpret_cast<float4*>(ref4_new), mass_new, ctrl_reset, (int)ctrl_keep);
   return chx_check_launch("chx_repack_langevin");
 }
+
+// ---------------------------------------------------------------------------
+// list carry-over: may launch `step` walk a force list that was built from other positions?  (include/chx.h:
+// chx_validate_snap)
+// ---------------------------------------------------------------------------
+__global__ void k_validate_snap(const float4* __restrict__ x4, const float4* __restrict__ snap4, int n, Box3 box,
+                                float T_half_skin, int step, int32_t* __restrict__ ctrl, int32_t* __restrict__ host_ctrl) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const float4 x = x4[p], s = snap4[p];
+  float rx, ry, rz;
+  displacement(box, x.x, x.y, x.z, s.x, s.y, s.z, rx, ry, rz);
+  // (NaN positions fail the comparison's negation: they halt too, and the rebuild reports them)
+  if (!(norm2(rx, ry, rz) <= T_half_skin)) {
+    atomicMin(&ctrl[3], step);
+    if (host_ctrl != nullptr) __hip_atomic_store(&host_ctrl[3], step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+extern "C" int chx_validate_snap(const float* x4, const float* snap4, int32_t n, chx_box_t box, float skin, int32_t step,
+                                 int32_t* ctrl, int32_t* host_ctrl, chx_stream_t stream) {
+  CHX_REQUIRE(n >= 1, "n < 1");
+  CHX_REQUIRE(x4 && snap4 && ctrl, "null pointer");
+  CHX_REQUIRE(skin > 0.f && step >= 0, "need skin > 0 and step >= 0");
+  hipLaunchKernelGGL(k_validate_snap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, chx_stream(stream),
+                     reinterpret_cast<const float4*>(x4), reinterpret_cast<const float4*>(snap4), n, make_box3(box),
+                     chx_cutoff_threshold_h(skin * 0.5f), (int)step, ctrl, host_ctrl);
+  return chx_check_launch("chx_validate_snap");
+}

@@ -42,6 +42,14 @@ _SPECULATIVE_REBUILD = __import__("os").environ.get("CHX_SYNC_REBUILD") != "1"
 # 28 % more builds.  CHX_DEFERRED_REBUILD=1 turns it on (a list, so that tests / A-B scripts can flip it in-process).
 _DEFERRED = [__import__("os").environ.get("CHX_DEFERRED_REBUILD", "0") == "1"]
 _EV_LOG_CAP = 4096
+# List carry-over: a short run() that continues the trajectory of the previous one (same integrator, same list object,
+# the very position tensor that run returned, untouched) starts on the force list its predecessor ended on instead of
+# building one -- the reference's run-start build (chiron/integrators.py:169) shrinks to "reference positions := x0" and
+# the caller's list is rebuilt from x0 only if somebody reads it.  CHX_LIST_CARRY=0 switches it off;
+# runs longer than CHX_LIST_CARRY_MAX_STEPS keep the build on entry: a carried list is older, so it runs out of its
+# guarantee sooner, and from ~100 steps on the renewals cost what the build would have (measured, round 3).
+_CARRY = [__import__("os").environ.get("CHX_LIST_CARRY", "1") != "0"]
+_CARRY_MAX_STEPS = int(__import__("os").environ.get("CHX_LIST_CARRY_MAX_STEPS", "64"))
 _PROFILE_DEFER = __import__("os").environ.get("CHX_PROFILE_DEFER") == "1"  # host seconds per phase -> integ.defer_profile
 
 
@@ -99,7 +107,7 @@ class LangevinIntegrator:
     # memory, and its numpy view no longer aliases it): it starts without and allocates its own on first use.
     # MultiStateSampler deep-copies its sampler, chiron/multistate.py:266-268.
     _PER_PROCESS_STATE = ("_gen_ring", "_gen_next", "_pinned_ring", "_ring_next", "_dev_scratch", "_inner_scratch",
-                          "_run_cache", "_defer_scratch", "_rebuild_log")
+                          "_run_cache", "_defer_scratch", "_rebuild_log", "_carry")
 
     def __getstate__(self):
         return {k: v for k, v in self.__dict__.items() if k not in self._PER_PROCESS_STATE}
@@ -143,7 +151,10 @@ class LangevinIntegrator:
         # rebuilt without waiting for its status block (validated after the first chunk, see _RunState._settle).
         is_lj = isinstance(potential, LJPotential)
         spec0 = False
-        if (nbr_list is not None and is_lj and _SPECULATIVE_REBUILD and isinstance(nbr_list, NeighborListNsqrd)
+        carried = self._take_carry(sampler_state, nbr_list, number_of_steps) if is_lj else None
+        if carried is not None:
+            pass  # (no build: _RunState validates the carried force list against x0 on the device)
+        elif (nbr_list is not None and is_lj and _SPECULATIVE_REBUILD and isinstance(nbr_list, NeighborListNsqrd)
                 and getattr(nbr_list, "_box_token", None) is not None
                 and nbr_list._box_token is getattr(sampler_state, "_box_token", None)
                 and isinstance(x0, torch.Tensor) and x0.is_cuda and x0.dtype == torch.float32):
@@ -184,7 +195,7 @@ class LangevinIntegrator:
             sampler_state.velocities = initialize_velocities(temperature, potential.topology, key)
         v0 = sampler_state.velocities
 
-        if nbr_list is not None and not spec0:  # :169
+        if nbr_list is not None and not spec0 and carried is None:  # :169
             nbr_list.build_from_state(sampler_state)
         if is_lj and isinstance(nbr_list, NeighborListNsqrd):
             mode = "fused"
@@ -217,7 +228,8 @@ class LangevinIntegrator:
             for s_ in range(number_of_steps):
                 chain_key, subkey = split(chain_key)
                 ops.jax_normal(subkey, (n_atoms, 3), out=noise[s_])
-        st = _RunState(self, potential, nbr_list, x0, v0, mass_unitless, kbT_unitless, half_dt, a, b, key, noise, mode)
+        st = _RunState(self, potential, nbr_list, x0, v0, mass_unitless, kbT_unitless, half_dt, a, b, key, noise, mode,
+                       carry=carried)
         if spec0:
             st._unsettled = (nbr_list.ref_positions, v0, 0, 1)
 
@@ -240,6 +252,9 @@ class LangevinIntegrator:
             to_report = (-(step + base)) % self.report_interval  # steps until the next reporting step
             return min(number_of_steps, step + to_report + 1)
 
+        # (host work that does not depend on the steps goes in front of them: behind them the device would wait for it)
+        # the reference returns the key its loop ended with (:216); the counter-based stream folds the step count in
+        key_out = chain_key if isinstance(key, JaxKey) else fold_in(key, number_of_steps)
         done = 0
         while done < number_of_steps:
             stop = next_stop(done)
@@ -265,11 +280,46 @@ class LangevinIntegrator:
 
         st.finish()
         updated_sampler_state = sampler_state._copy_with(*st.final_state_user())  # :210-218
-        # the reference returns the key its loop ended with (:216); the counter-based stream folds the step count in
-        updated_sampler_state.current_PRNG_key = chain_key if isinstance(key, JaxKey) else fold_in(key, number_of_steps)
+        st.offer_carry(updated_sampler_state)
+        updated_sampler_state.current_PRNG_key = key_out
         self.n_rebuilds = st.n_rebuilds
         self._rebuild_log = st.rebuild_log
         return updated_sampler_state, st.nbr_list
+
+    def _take_carry(self, sampler_state, nbr_list, number_of_steps: int):
+        """The private list object whose force list this run may start on (list carry-over), or None.
+
+        Offered by the previous ``run()`` (``_RunState.offer_carry``) and taken only when this call continues that
+        trajectory: same list object, same box values, same cutoff and skin, and ``sampler_state.positions`` IS the
+        tensor that run returned, not written to since -- positions from anywhere else (a Monte Carlo move, another
+        replica) take the ordinary path.  Whether the list really covers x0 is then checked on the device
+        (chx_validate_snap)."""
+        from .neighbors import NeighborListNsqrd
+
+        offer, self._carry = self.__dict__.get("_carry"), None
+        if offer is None or not _CARRY[0] or _DEFERRED[0] or not (0 < number_of_steps <= _CARRY_MAX_STEPS):
+            return None
+        if not (self.launch_window > 0 and _HOST_CTRL_IN_KERNEL[0] and isinstance(nbr_list, NeighborListNsqrd)):
+            return None
+        if (hasattr(self, "reporter") and self.reporter is not None) or self.save_traj_in_memory:
+            return None
+        x0 = sampler_state.positions
+        if not (offer["public"] is nbr_list and x0 is offer["x"] and x0._version == offer["x_version"]
+                and nbr_list.is_built and nbr_list._cs_md is not None and nbr_list._cs_md == offer["cs_md"]
+                and nbr_list._skin is offer["skin"]
+                and getattr(nbr_list, "_box_token", None) is not None
+                and nbr_list._box_token is getattr(sampler_state, "_box_token", None)
+                and nbr_list._box_token is offer["box_token"]):
+            return None
+        owner = offer["owner"]
+        if owner is nbr_list:
+            owner = nbr_list._detach_for_carry()
+            if owner is None:
+                return None
+        max_n = getattr(owner, "_last_max_n", None)
+        if max_n is None or max_n > 0.85 * int(nbr_list.n_max_neighbors):  # (the reference's growth rule needs to see
+            return None                                                   # every build's row counts: _setup_deferred)
+        return owner
 
     @property
     def rebuild_steps(self):
@@ -341,7 +391,8 @@ class _Slot:
 class _RunState:
     """Device-resident state of one ``run`` call in the kernels' internal layout."""
 
-    def __init__(self, integ, potential, nbr_list, x0, v0, mass, kT, half_dt, a, b, key: PRNGKey, noise, mode: str):
+    def __init__(self, integ, potential, nbr_list, x0, v0, mass, kT, half_dt, a, b, key: PRNGKey, noise, mode: str,
+                 carry=None):
         from .neighbors import NeighborListNsqrd, PairListNsqrd
 
         self.integ = integ
@@ -377,8 +428,16 @@ class _RunState:
         self.rebuild_log = ([], None)
         self._snap_is_ref = False
         self._host_events = []  # steps of the reference rebuilds the HOST carried out (halting scheme)
-        self._setup_deferred()
-        self._load(x0, v0)
+        self._carried = carry if (carry is not None and mode == "fused" and self.is_verlet and self._windowed()) else None
+        if self._carried is not None:
+            self._setup_carry()
+            # the reference's run-start build, as far as the steps can tell: reference positions := x0
+            self._load(x0, v0, 0, owner=self._carried, ref_user=x0)
+            ops.validate_snap(self.x_a, self.snap4, self.nbr_list._box_h, self._skin_now, 0, self.ctrl, self._gen.tensor)
+            integ.n_carried_runs = getattr(integ, "n_carried_runs", 0) + 1
+        else:
+            self._setup_deferred()
+            self._load(x0, v0)
         if self.mode == "external":
             self._external_force()
 
@@ -432,6 +491,26 @@ class _RunState:
             keep["event"] = torch.cuda.Event()
         d.side, d.builders, d.snap_event = keep["side"], keep["builders"], keep["event"]
         d.next = 0
+
+    def _setup_carry(self):
+        """List carry-over: the run starts on a force list built from OTHER positions than its reference positions
+        (x0), so it runs on the decoupled step kernel (``snap4`` set) -- with nothing scheduled ahead of time: no
+        trigger, no side builds.  When the force list runs out of its own guarantee the halt word fires and only the
+        force list is renewed (``_rebuild_internal``); the reference's rebuilds are events the step kernel takes itself."""
+        d = self._defer = _Deferred()
+        d.lead = d.adopt = 0
+        d.theta = 0.0  # (trigger_frac 0: chx_launch_lj_steps never raises the trigger word)
+        d.window = self.integ.launch_window
+        d.disabled = True
+        keep = self.integ.__dict__.setdefault("_defer_scratch", {})
+        if keep.get("key") != (self.n, str(self.dev)):
+            keep.clear()
+            keep["key"] = (self.n, str(self.dev))
+            keep["side"] = torch.cuda.Stream(device=self.dev)
+            keep["builders"] = [None, None]
+            keep["event"] = torch.cuda.Event()
+        d.side, d.builders, d.snap_event = keep["side"], keep["builders"], keep["event"]
+        d.next = 1 if d.builders[0] is self._carried else 0  # (a rebuild must not write into the list being walked)
 
     def _next_builder(self):
         d = self._defer
@@ -524,7 +603,7 @@ class _RunState:
             prof["confirm_s"] += t_c - t_p
             prof["adopt_s"] += _t.perf_counter() - t_c
 
-    def _rebuild_internal(self, step: int):
+    def _rebuild_internal(self, step: int, speculative: bool = True):
         """The force list ran out of its guarantee before its successor was ready (the halt word fired at ``step``
         on the list's own positions): build the next one here and now, from the halted state.  No reference event is
         involved; one that is booked for this very step stays booked (``ctrl_keep``)."""
@@ -533,12 +612,18 @@ class _RunState:
         x_user, v_user = self.state_user()
         ref_user = self._unpack(self.ref4)
         b = self._next_builder()
-        b._adopt_positions = True
-        try:
-            b.build(x_user.clone(), b.box_vectors)
-        finally:
-            b._adopt_positions = False
+        # (like the halting scheme's rebuild: enqueue the build, carry on, read its status block once it has arrived --
+        # a builder that has built before for this box; its first build goes the synchronous way)
+        spec = (speculative and _SPECULATIVE_REBUILD and b.__dict__.get("_perm") is not None
+                and b._build_speculative(x_user.clone(), publish=False))
+        if not spec:
+            b._adopt_positions = True
+            try:
+                b.build(x_user.clone(), b.box_vectors)
+            finally:
+                b._adopt_positions = False
         self._load(x_user, v_user, step, owner=b, ref_user=ref_user, ctrl_keep=3)
+        self._unsettled = (x_user, v_user, step, self.kicks_next, b, ref_user) if spec else None
         self._snap_is_ref = False
         d.n_internal_halts += 1
 
@@ -818,24 +903,34 @@ class _RunState:
         if pend is None:
             return True
         self._unsettled = None
+        # (the list that was built: the caller's, or -- force list renewed on its own -- one of the private builders)
+        owner = pend[4] if len(pend) > 4 else self.nbr_list
         if self.mode == "fused" and self._windowed():
             # the build's status block reaches the host with the pack launch of the load that followed the build;
             # a step launch of that load's generation has begun => it is there.  Otherwise wait for the stream.
             if int(self._gen.host[0]) < self._gen_step0:
                 torch.cuda.current_stream().synchronize()
-            ok = self.nbr_list._confirm_build(wait=False)
+            ok = owner._confirm_build(wait=False)
         else:
-            ok = self.nbr_list._confirm_build()
+            ok = owner._confirm_build()
         if ok:
             return True
-        x_user, v_user, step, kicks = pend
+        x_user, v_user, step, kicks = pend[:4]
         torch.cuda.synchronize()
         if self._defer is not None:
             # whatever ran on the rejected list is void, its reference events included: the device log tells how many
             # rebuilds the reference had made BEFORE this step (the host-made ones are not in it)
             self._abandon_side_build()
             self._restore_event_count(step)
-        self._load(x_user, v_user, step, ctrl_keep=1 if self._defer is not None else 0)
+        if len(pend) > 4:
+            # (a renewal of the force list alone: the reference's bookkeeping was none of its business.  The counters are
+            # back where they were (above); an event the launch before `step` had booked for `step` -- its criterion,
+            # chiron/integrators.py:241, on the very arrays saved here -- is booked again)
+            self._load(x_user, v_user, step, owner=owner, ref_user=pend[5], ctrl_keep=1)
+            if step > 0 and bool(ops.nl_check(x_user, pend[5], self.nbr_list._box_h, self._skin_now).item()):
+                self.ctrl[10 + (step & 1)].fill_(step)
+        else:
+            self._load(x_user, v_user, step, ctrl_keep=1 if self._defer is not None else 0)
         self.kicks_next = kicks
         self._unsettled_step = step
         return False
@@ -958,6 +1053,8 @@ class _RunState:
         even, odd = (self.x_a, self.x_b) if self.parity == 0 else (self.x_b, self.x_a)
         ops.langevin_fused_chunk(self.params, even, odd, step, 1, 1, 0)
         self._final_state = self.state_user() if with_state else None
+        # (list carry-over: the reference positions the caller's list will be rebuilt from, should anybody read it)
+        self._final_ref = self._unpack(self.ref4) if with_state and self._carried is not None else None
         ev = torch.cuda.Event()
         ev.record()
         ev.synchronize()
@@ -989,7 +1086,7 @@ class _RunState:
                             continue
                         limit = min(limit, d.s_adopt)
                     else:
-                        watch = True
+                        watch = not d.disabled
                 c = min(chunk, limit - enq)
                 sent = self._enqueue_window(enq, c, watch)
                 enq += sent
@@ -1030,6 +1127,13 @@ class _RunState:
             # the skin check fired while producing x_halt: steps < halt ran, the launches queued behind are no-ops
             # and the rebuild is enqueued behind them
             self._kick_sent = False
+            # (diagnostic: launches of steps >= halt that were already enqueued -- what the device drains as no-ops)
+            self.integ.noop_launches = getattr(self.integ, "noop_launches", 0) + max(0, enq - halt)
+            if halt == 0:
+                # (only a carried force list that does not cover x0 halts launch 0: nothing has run, the run's first
+                # step still owes its single leading kick)
+                self.kicks_next = 1
+                self.integ.n_carry_rejected = getattr(self.integ, "n_carry_rejected", 0) + 1
             self.parity = (self._gen_parity0 + halt - self._gen_step0) & 1
             self._close_generation()
             self._halt_rebuild(halt, speculative=True)
@@ -1053,20 +1157,37 @@ class _RunState:
         self._abandon_side_build()
         gen = getattr(self, "_gen", None)
         n_dev = int(gen.host[8]) if gen is not None else 0
-        if n_dev <= 0:
+        # list carry-over: the run-start build (chiron/integrators.py:169) was not carried out on the caller's list
+        missed = 1 if self._carried is not None else 0
+        if n_dev <= 0 and not missed:
             return
         if n_dev > _EV_LOG_CAP:
             log.warning("more reference rebuild events in one run() than the device log holds; rebuild_steps is truncated")
-        self.n_rebuilds += n_dev
-        self.rebuild_log = (list(self._host_events), self.ev_log[:min(n_dev, _EV_LOG_CAP)].clone())
-        last_dev = int(gen.host[9])
+        last_dev = -1
+        if n_dev > 0:
+            self.n_rebuilds += n_dev
+            self.rebuild_log = (list(self._host_events), self.ev_log[:min(n_dev, _EV_LOG_CAP)].clone())
+            last_dev = int(gen.host[9])
         last_host = self._host_events[-1] if self._host_events else -1
-        if last_dev > last_host:
-            self.nbr_list._defer_build(self._unpack(self.ref4), n_dev)
+        if last_dev > last_host or (missed and last_host < 0):
+            # (ref4: the positions of the last event -- or x0, the run-start build's, when there was none)
+            ref_user, self._final_ref = getattr(self, "_final_ref", None), None
+            self.nbr_list._defer_build(ref_user if ref_user is not None else self._unpack(self.ref4), n_dev + missed)
         else:  # the host's own rebuild was the latest: the public list is current
-            self.nbr_list.n_builds += n_dev
+            self.nbr_list.n_builds += n_dev + missed
         for k in ("n_side_builds", "n_adoptions", "n_internal_halts", "late_triggers"):
             setattr(self.integ, k, getattr(self.integ, k, 0) + getattr(d, k))
+
+    def offer_carry(self, state) -> None:
+        """End of ``run()``: leave the force list the run ended on, and the identity of the positions it returned, for
+        a next ``run()`` that continues from exactly there (``LangevinIntegrator._take_carry``)."""
+        self.integ._carry = None
+        if not (_CARRY[0] and self.mode == "fused" and self.is_verlet and self._windowed() and self.fl is not None
+                and getattr(self, "_unsettled", None) is None):
+            return
+        lst, x = self.nbr_list, state.positions
+        self.integ._carry = dict(owner=self._owner, public=lst, x=x, x_version=x._version, cs_md=lst._cs_md, skin=lst._skin,
+                                 box_token=getattr(lst, "_box_token", None))
 
     def _halt_rebuild(self, halt: int, speculative: bool):
         """The halt word fired at ``halt``.  Halting scheme: that IS the reference's rebuild.  Deferred scheme: the
@@ -1076,7 +1197,7 @@ class _RunState:
         if self._defer is None or self._snap_is_ref:
             self._rebuild(halt, speculative=speculative)
         else:
-            self._rebuild_internal(halt)
+            self._rebuild_internal(halt, speculative)
 
     # -- other paths -------------------------------------------------------
     def _external_force(self):

@@ -269,6 +269,7 @@ class NeighborListNsqrd(PairsBase):
     def build(self, positions, box_vectors):
         """chiron/neighbors.py:628-729"""
         positions = _strip_positions(positions)
+        self.__dict__.pop("_deferred", None)  # (a rebuild still pending from an earlier run() is superseded)
         private = getattr(self, "_adopt_positions", False)  # the integrator's own rebuild inside run()
         if (private and box_vectors is not None and box_vectors is getattr(self, "box_vectors", None)
                 and getattr(self, "_box_h", None) is not None):
@@ -350,6 +351,7 @@ class NeighborListNsqrd(PairsBase):
         g, chunks = self._fl_geometry(n)
         if getattr(self, "_scratch", None) is None:
             self._scratch = {}
+        self.__dict__.pop("_deferred", None)  # (a rebuild still pending from an earlier run() is superseded)
         self.ref_positions = positions  # a fresh tensor nobody else holds
         self._cutoff_and_skin = cs
         nl, first, n_nbr, sorted_ids, fl, deg, status = ops.nl_build_cell_fl(
@@ -434,7 +436,7 @@ class NeighborListNsqrd(PairsBase):
         (``LangevinIntegrator``: deferred rebuilds).  None when the one-pass cell build does not apply."""
         if not (self.is_built and self._use_cell_list and getattr(self, "_box_h", None) is not None and self._box_h.periodic
                 and getattr(self, "_fl_geo", None) is not None and self._cs_md is not None
-                and self.__dict__.get("_perm") is not None):
+                and (self.__dict__.get("_perm") is not None or "_deferred" in self.__dict__)):
             return None
         b = self.__class__.__new__(self.__class__)
         b._use_cell_list = True
@@ -451,6 +453,27 @@ class NeighborListNsqrd(PairsBase):
         b.is_built = True
         # background builds: workgroups of the wave-per-particle kernel in flight (0 = one wavefront per row)
         b._bg_blocks = int(os.environ.get("CHX_DEFER_BG_BLOCKS", "512"))
+        return b
+
+    def _detach_for_carry(self):
+        """The list as it stands -- rows, force list, the cell-ordered positions it was built from -- handed over to a
+        private list object the integrator keeps (``LangevinIntegrator``: list carry-over between ``run()`` calls).
+        The arrays of a build are never written again, so both objects may go on reading them; the work arrays go
+        with the private object (the next build of this list allocates its own: it must not overwrite the positions
+        the carried force list is validated against).  None when the last build was not a confirmed one-pass cell
+        build."""
+        sc = self.__dict__.get("_scratch")
+        fl = self.__dict__.get("_force_list")
+        if (sc is None or sc.get("arrays") is None or fl is None or self.__dict__.get("_perm") is None
+                or getattr(self, "_spec", None) is not None or fl.perm is not self._perm):
+            return None
+        b = self._clone_builder()
+        if b is None or sc["arrays"][4].shape[0] != self._perm.shape[0]:
+            return None
+        for name in self._DEFERRED_ATTRS:
+            b.__dict__[name] = self.__dict__[name]
+        b._scratch, self._scratch = sc, None
+        b._last_max_n = getattr(self, "_last_max_n", None)
         return b
 
     _DEFERRED_ATTRS = ("ref_positions", "n_neighbors", "_nl", "_nl_mask", "_first", "_perm", "_force_list")

@@ -272,6 +272,17 @@ def repack_langevin(x4_old, v_old, ref4_old, perm_old, perm_new, inv_ws, x4_new,
     )
 
 
+def validate_snap(x4, snap4, box: Box, skin: float, step: int, ctrl, host_ctrl=None) -> None:
+    """Halt launch ``step`` unless every particle is within skin/2 of the positions its force list was built from
+    (include/chx.h: chx_validate_snap)."""
+    _require_device(x4, snap4, ctrl)
+    check(
+        _lib.load().chx_validate_snap(_ptr(x4), _ptr(snap4), x4.shape[0], box, C.c_float(skin), int(step), _ptr(ctrl),
+                                      C.c_void_p(host_ctrl.data_ptr()) if host_ctrl is not None else None, _stream()),
+        "chx_validate_snap",
+    )
+
+
 def nl_calculate(xyz, nl, nl_mask, box: Box, cutoff: float):
     xyz = _f32(xyz)
     _require_device(xyz, nl, nl_mask)

@@ -45,7 +45,8 @@ typedef void* chx_stream_t;
  *      chx_pack_langevin is the one supported producer); x4[p].w belongs to the kernel (path length); the words of a
  *      force-list chunk are interleaved over the lanes (see "Force list" below); chx_mc_t::state is
  *      CHX_MC_STATE_WORDS = 16 ints (two slots) and chx_mc_t::energy 4 doubles -- the struct's SIZE did not change,
- *      so chx_sizeof_mc_t() cannot tell; this version number does. */
+ *      so chx_sizeof_mc_t() cannot tell; this version number does.  Added in round 3 without touching any existing
+ *      signature: chx_repack_langevin, chx_validate_snap, chx_set_poll_sleep_ns, chx_poll_stats. */
 #define CHX_ABI_VERSION 2
 
 /* high bit of a force-list entry: neighbor has the HIGHER original particle id */
@@ -212,6 +213,15 @@ int chx_pack_langevin(const float* x3, const float* v3, const float* mass, const
 int chx_repack_langevin(const float* x4_old, const float* v_old, const float* ref4_old, const uint32_t* perm_old,
                         const uint32_t* perm_new, uint32_t* inv_ws, int32_t n, float* x4_new, float* v_new,
                         float* ref4_new, float* mass_new, int32_t* ctrl_reset, int32_t ctrl_keep, chx_stream_t stream);
+
+/* List carry-over (LangevinIntegrator: a run() that starts on the force list its predecessor ended on instead of
+ * building one): halt launch `step` -- ctrl[3] = min(ctrl[3], step), and the same into host_ctrl[3] when given -- unless
+ * every particle of x4 (n,4; internal order of that list) is within skin/2 of the position the list was built from
+ * (snap4, same order; minimum image), the guarantee under which a list of radius cutoff + skin holds every pair inside
+ * the cutoff (chiron/neighbors.py:872-907 states it for the reference positions).  Enqueued behind chx_pack_langevin
+ * (which resets ctrl) and in front of the first step launch. */
+int chx_validate_snap(const float* x4, const float* snap4, int32_t n, chx_box_t box, float skin, int32_t step,
+                      int32_t* ctrl, int32_t* host_ctrl, chx_stream_t stream);
 
 /* LJPotential.compute_energy / compute_force over the neighbor list:
  * E = sum over listed pairs with d < cutoff of 4 eps ((s/d)^12 - (s/d)^6)

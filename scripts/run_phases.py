@@ -26,6 +26,10 @@ def wrap(obj, name, tag, when="after"):
     setattr(obj, name, f)
 
 wrap(N.NeighborListNsqrd, "_build_speculative", "1 build enqueued")
+wrap(I.LangevinIntegrator, "_take_carry", "0 carry decided")
+wrap(I._RunState, "_setup_carry", "1a carry set up", "before")
+wrap(I._RunState, "_load", "1b _load entered", "before")
+wrap(I._RunState, "_open_generation", "1c generation opened")
 wrap(I._RunState, "__init__", "2 state packed (pack enqueued)")
 wrap(I._RunState, "_enqueue_window", "3 first steps enqueued", "before")
 wrap(I._RunState, "final_kick", "4 kick done (device drained)")

@@ -1,5 +1,5 @@
 # GPU test suite under the tuning overrides (lanes per particle, pruning cadence, launch queue and its poll policy, build
-# kernel, host control-block scheme, deferred rebuilds): every combination must pass
+# kernel, host control-block scheme, deferred rebuilds, list carry-over): every combination must pass
 cd $GRAFT_REPO_ROOT
 for env in "CHX_SYNC_REBUILD=1" "CHX_LAUNCH_WINDOW=0" "CHX_LAUNCH_WINDOW=1" "CHX_LAUNCH_WINDOW=3 CHX_FL_G=2" "CHX_HOST_CTRL=0" "CHX_MC_DECIDE_LAUNCH=1" \
            "CHX_BUILD_KERNEL=cell" "CHX_BUILD_KERNEL=cell CHX_BUILD_SPLIT=3" "CHX_BUILD_KERNEL=particle" \
@@ -7,7 +7,7 @@ for env in "CHX_SYNC_REBUILD=1" "CHX_LAUNCH_WINDOW=0" "CHX_LAUNCH_WINDOW=1" "CHX
            "CHX_PRUNE_EVERY=7 CHX_INNER_SKIN=0.02" "CHX_PRUNE_EVERY=50 CHX_INNER_SKIN=0.3" \
            "CHX_POLL=spin" "CHX_POLL_SLEEP_NS=50000" "CHX_DEFERRED_REBUILD=1" "CHX_DEFERRED_REBUILD=1 CHX_DEFER_BG_BLOCKS=0" \
            "CHX_DEFERRED_REBUILD=1 CHX_DEFER_LEAD=8 CHX_DEFER_ADOPT=12 CHX_LAUNCH_WINDOW=3" "CHX_DEFERRED_REBUILD=1 CHX_FL_G=8" \
-           "CHX_PIN_CPUS=0"; do
+           "CHX_PIN_CPUS=0" "CHX_LIST_CARRY=0" "CHX_LIST_CARRY_MAX_STEPS=100000"; do
   echo "== $env"
   env $env timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
 done

@@ -2092,3 +2092,195 @@ def test_deferred_rebuilds_survive_a_list_that_runs_out_early(ca, O, monkeypatch
     assert torch.minimum(dx, (dx - L).abs()).max().item() < 2e-4
     dref = (nbr_c.ref_positions - nbr_b.ref_positions).abs()
     assert torch.minimum(dref, (dref - L).abs()).max().item() < 2e-4
+
+
+# ---------------------------------------------------------------------------
+# list carry-over between run() calls
+# ---------------------------------------------------------------------------
+def _carry_segments(ca, O, carry, segments, steps, n=4096, dt_fs=2.0, seed=67, tamper=None):
+    """`segments` consecutive run(steps) calls on one integrator and one list, each continuing from the state the
+    previous one returned.  Returns per-segment records and the final objects."""
+    import os
+
+    from chiron_amd import integrators
+
+    if os.environ.get("CHX_LAUNCH_WINDOW") == "0" or os.environ.get("CHX_HOST_CTRL") == "0":
+        pytest.skip("list carry-over rides on the bounded launch queue, which this run switches off")
+    if os.environ.get("CHX_DEFERRED_REBUILD") == "1":
+        pytest.skip("with deferred rebuilds switched on every run() builds its list on entry")
+    u = ca.unit
+    x, box = O.lj_lattice(n, 0.1, SIGMA, seed=seed)
+    pot = lj_pot(ca, n)
+    state = make_state(ca, x, box)
+    thermo = ca.states.ThermodynamicState(pot, temperature=300 * u.kelvin)
+    nbr = ca.neighbors.NeighborListCell(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+                                        skin=SKIN * u.nanometer, n_max_neighbors=180)
+    integ = ca.integrators.LangevinIntegrator(timestep=dt_fs * u.femtoseconds, collision_rate=1.0 / u.picoseconds)
+    old = integrators._CARRY[0]
+    integrators._CARRY[0] = carry
+    recs = []
+    try:
+        for k in range(segments):
+            if tamper is not None:
+                tamper(k, state, integ, nbr)
+            key_before = state.current_PRNG_key
+            x_in, v_in = state.positions.clone(), None if state._velocities is None else state.velocities.clone()
+            state, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr)
+            recs.append(dict(key=key_before, x_in=x_in, v_in=v_in, rebuild_steps=list(integ.rebuild_steps),
+                             n_rebuilds=integ.n_rebuilds, x=state.positions.clone(), v=state.velocities.clone()))
+    finally:
+        integrators._CARRY[0] = old
+    return x, box, pot, state, nbr, integ, recs
+
+
+def _mi_max(a, b, L):
+    d = (a - b).abs()
+    return torch.minimum(d, (d - L).abs()).max().item()
+
+
+def test_list_carry_over_keeps_the_reference_events_and_the_public_list(ca, O):
+    """A run() that continues the trajectory of the previous one starts on the force list that one ended on: no list
+    build on entry.  What the reference's run-start build means to the steps -- reference positions := x0
+    (chiron/integrators.py:169, chiron/neighbors.py:671) -- still happens, so every segment has the reference's
+    rebuild events at the reference's steps, the trajectory is the halting scheme's up to summation order, and the
+    caller's list, resolved when somebody reads it, is the one the reference would hold: built from the positions of
+    the last rebuild (or x0).  Checked against the same segments run with a list build on every entry, and against
+    the C oracle on the same Philox streams."""
+    from oracle import c_oracle as CO
+    import chiron_amd.rng as R
+
+    segments, steps, n = 10, 60, 4096
+    x, box, pot, a, nbr_a, integ_a, ra = _carry_segments(ca, O, True, segments, steps)
+    _, _, _, b, nbr_b, integ_b, rb = _carry_segments(ca, O, False, segments, steps)
+    L = float(box[0, 0])
+    assert getattr(integ_a, "n_carried_runs", 0) == segments - 1 and getattr(integ_a, "n_carry_rejected", 0) == 0
+    assert getattr(integ_b, "n_carried_runs", 0) == 0
+    # the force list ran out of its own guarantee at least once along the way and was renewed without a reference event
+    assert getattr(integ_a, "n_internal_halts", 0) >= 1
+    for k in range(segments):
+        assert ra[k]["rebuild_steps"] == rb[k]["rebuild_steps"] and ra[k]["n_rebuilds"] == rb[k]["n_rebuilds"], k
+        assert _mi_max(ra[k]["x"], rb[k]["x"], L) < 2e-4 and (ra[k]["v"] - rb[k]["v"]).abs().max().item() < 2e-2, k
+    # the caller's list: pending after a carried run, counted as the reference counts its builds
+    assert "_deferred" in nbr_a.__dict__ and "n_neighbors" not in nbr_a.__dict__
+    assert nbr_a.is_built and nbr_a.n_builds == nbr_b.n_builds
+    ref = nbr_a.ref_positions  # (first access: builds)
+    assert "_deferred" not in nbr_a.__dict__
+    assert _mi_max(ref, nbr_b.ref_positions, L) < 2e-4
+    if not ra[-1]["rebuild_steps"]:  # no event in the last segment: the list is the run-start build's, from x0
+        assert torch.equal(ref, ra[-1]["x_in"])
+    mask, nl, nnbr = CO.nl_build_fixed(ref.cpu().numpy(), box, CUTOFF + SKIN, int(nbr_a.n_max_neighbors))
+    assert np.array_equal(nbr_a.n_neighbors.cpu().numpy(), nnbr) and np.array_equal(u32(nbr_a.neighbor_list), nl)
+    e_list = float(pot.compute_energy(a.positions, nbr_a))
+    e64 = CO.lj_cell_f64(a.positions.cpu().numpy(), box, SIGMA, EPS, CUTOFF)[0]
+    assert abs(e_list - e64) <= 2e-5 * abs(e64) + 1e-3
+    # the C oracle, segment by segment: a list build (reference positions := x0) on every entry, the segment's own key
+    mass = np.full(n, 39.948, f32)
+    kT, ca_, cb_ = O.langevin_constants(300.0, 0.002, 1.0)
+    _, run_key = R.split(ra[0]["key"])
+    xo = x
+    vo = O.initial_velocities(mass, kT, O.philox_normals3(n, 0, O.STREAM_VELOCITY, tuple(run_key)))
+    for k in range(segments):
+        _, run_key = R.split(ra[k]["key"])
+        xo, vo, st = CO.langevin_run_cell_omp(xo, vo, box, mass, SIGMA, EPS, CUTOFF, SKIN, 0.002, ca_, cb_, kT, steps, None,
+                                              tuple(run_key), threads=CO.effective_cores())
+        assert st["rebuilds"] == ra[k]["n_rebuilds"], k
+        do = np.abs(ra[k]["x"].cpu().numpy() - xo)
+        assert np.minimum(do, np.abs(do - L)).max() < 5e-4, k
+        # (each segment starts from the product's own state: the comparison does not accumulate)
+        xo, vo = ra[k]["x"].cpu().numpy(), ra[k]["v"].cpu().numpy()
+
+
+def test_list_carry_over_is_declined_for_positions_from_elsewhere(ca, O):
+    """The offer is taken only by a run() that gets the very tensor the previous one returned, unwritten, with the same
+    list object; anything else builds its list on entry as the reference does."""
+    def tamper(k, state, integ, nbr):
+        if k == 1:  # a copy of the positions (what a Monte Carlo move or another replica hands over)
+            state.positions = state.positions.clone()
+        if k == 2:  # written in place since
+            state.positions.add_(0.0)
+        if k == 3:  # the offer is for ONE next run: consumed or dropped, never kept
+            assert integ.__dict__.get("_carry") is not None
+    x, box, pot, a, nbr, integ, recs = _carry_segments(ca, O, True, 5, 20, n=2048, tamper=tamper)
+    assert integ.n_carried_runs == 2  # segments 3 and 4
+    assert "_deferred" in nbr.__dict__
+    # a longer run than the carry-over serves takes the ordinary path, and finds the caller's list current afterwards
+    u = ca.unit
+    thermo = ca.states.ThermodynamicState(pot, temperature=300 * u.kelvin)
+    from chiron_amd import integrators
+
+    out, nbr = integ.run(a, thermo, number_of_steps=integrators._CARRY_MAX_STEPS + 1, nbr_list=nbr)
+    assert integ.n_carried_runs == 2 and "_deferred" not in nbr.__dict__ and "n_neighbors" in nbr.__dict__
+    # another list object: declined as well
+    nbr2 = ca.neighbors.NeighborListCell(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+                                         skin=SKIN * u.nanometer, n_max_neighbors=180)
+    nbr2.build_from_state(out)
+    out2, nbr2 = integ.run(out, thermo, number_of_steps=20, nbr_list=nbr2)
+    assert integ.n_carried_runs == 2
+
+
+def test_list_carry_over_device_check_rejects_a_list_that_does_not_cover_x0(ca, O):
+    """Should the host-side conditions ever let through positions the carried force list does not cover (here: forced,
+    by moving particles in place and forging the version stamp), the device check halts launch 0, the list is renewed
+    from x0 before anything has run, and the run is the one a list build on entry gives -- first kick included."""
+    moved = {}
+
+    def tamper(k, state, integ, nbr):
+        if k == 1:
+            xs = state.positions
+            xs[:64] += 0.31  # > skin / 2
+            moved["x"] = xs.clone()
+            offer = integ.__dict__.get("_carry")
+            if offer is not None:
+                offer["x_version"] = xs._version
+    x, box, pot, a, nbr_a, integ_a, ra = _carry_segments(ca, O, True, 2, 40, n=2048, tamper=tamper)
+    assert integ_a.n_carried_runs == 1 and integ_a.n_carry_rejected == 1
+    _, _, _, b, nbr_b, integ_b, rb = _carry_segments(ca, O, False, 2, 40, n=2048, tamper=tamper)
+    L = float(box[0, 0])
+    assert torch.equal(ra[1]["x_in"], rb[1]["x_in"])
+    assert ra[1]["rebuild_steps"] == rb[1]["rebuild_steps"]
+    assert _mi_max(ra[1]["x"], rb[1]["x"], L) < 2e-5 and (ra[1]["v"] - rb[1]["v"]).abs().max().item() < 2e-3
+    assert _mi_max(nbr_a.ref_positions, nbr_b.ref_positions, L) < 2e-5 and nbr_a.n_builds == nbr_b.n_builds
+
+
+def test_list_carry_over_survives_a_rejected_force_list_renewal(ca, O, monkeypatch):
+    """A renewal of the force list is enqueued without waiting for its status block; should the block later say that a
+    capacity overflowed (here: the confirmation of the first renewal is made to fail), the launches since are void, the
+    list is rebuilt the synchronous way, the state goes back to the renewal step with the reference's bookkeeping as it
+    was there, and the run ends as the halting scheme's does."""
+    import os
+
+    from chiron_amd import neighbors
+
+    if os.environ.get("CHX_SYNC_REBUILD") == "1":
+        pytest.skip("every rebuild waits for its status block in this run: nothing is enqueued unconfirmed")
+    calls = {"n": 0}
+    orig = neighbors.NeighborListNsqrd._confirm_build
+
+    def confirm(self, wait=True):
+        spec = getattr(self, "_spec", None)
+        if spec is not None and getattr(self, "_box_token", 0) is None and calls["n"] == 0:  # a private builder's first
+            calls["n"] += 1
+            orig(self, wait=True)
+            self.n_builds -= 1
+            self._adopt_positions = True
+            try:
+                self.build(self.ref_positions, self.box_vectors)
+            finally:
+                self._adopt_positions = False
+            return False
+        return orig(self, wait)
+
+    monkeypatch.setattr(neighbors.NeighborListNsqrd, "_confirm_build", confirm)
+    from chiron_amd import integrators
+
+    monkeypatch.setattr(integrators, "_CARRY_MAX_STEPS", 256)  # (segments long enough for renewals inside them)
+    segments, steps = 8, 100
+    x, box, pot, a, nbr_a, integ_a, ra = _carry_segments(ca, O, True, segments, steps)
+    monkeypatch.setattr(neighbors.NeighborListNsqrd, "_confirm_build", orig)
+    assert calls["n"] == 1 and integ_a.n_internal_halts >= 2
+    _, _, _, b, nbr_b, integ_b, rb = _carry_segments(ca, O, False, segments, steps)
+    L = float(box[0, 0])
+    for k in range(segments):
+        assert ra[k]["rebuild_steps"] == rb[k]["rebuild_steps"], k
+        assert _mi_max(ra[k]["x"], rb[k]["x"], L) < 2e-4, k
+    assert nbr_a.n_builds == nbr_b.n_builds and _mi_max(nbr_a.ref_positions, nbr_b.ref_positions, L) < 2e-4

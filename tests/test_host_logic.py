@@ -366,6 +366,8 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
         assert needle in msg, msg
 
     failed(lib.chx_nl_build_nsq(None, -1, 8, box, f(1.0), None, None, None, None), "chx_nl_build_nsq")
+    failed(lib.chx_validate_snap(None, None, 8, box, f(0.5), 0, None, None, None), "null pointer")
+    failed(lib.chx_validate_snap(ctypes.c_void_p(64), ctypes.c_void_p(64), 8, box, f(0.0), 0, ctypes.c_void_p(64), None, None), "skin")
     failed(lib.chx_nl_build_nsq(None, 4, 8, box, f(1.0), None, None, None, None), "null pointer")
     failed(lib.chx_nl_build_nsq(ctypes.c_void_p(64), 4, 8, _lib.Box(1, 0.0, 1.0, 1.0), f(1.0), ctypes.c_void_p(64),
                                 ctypes.c_void_p(64), ctypes.c_void_p(64), None), "box lengths")
@@ -689,6 +691,73 @@ def test_integrator_copies_drop_per_process_device_state():
     m2 = copy.deepcopy(move)
     assert m2.integrator is not move.integrator and "_gen_ring" not in m2.integrator.__dict__
     assert move.integrator._gen_ring is marker
+
+
+def test_list_carry_over_offer_is_taken_only_by_the_run_that_continues_the_trajectory():
+    """Host side of the list carry-over (LangevinIntegrator._take_carry): the offer a run() leaves is taken by the next
+    one only for the same list object, the very position tensor that run returned (unwritten since), the same box
+    values, cutoff and skin, a short enough run and no reporter -- and it is an offer for ONE call."""
+    import torch
+
+    from chiron_amd import integrators
+    from chiron_amd.integrators import LangevinIntegrator
+    from chiron_amd.neighbors import NeighborListNsqrd, OrthogonalPeriodicSpace
+
+    class State:
+        pass
+
+    class Owner:
+        _last_max_n = 40
+
+    def setup():
+        nbr = NeighborListNsqrd(OrthogonalPeriodicSpace(), cutoff=1.0 * unit.nanometer, skin=0.5 * unit.nanometer,
+                                n_max_neighbors=180)
+        nbr.is_built, nbr._cs_md, nbr._box_token = True, 1.5, object()
+        st = State()
+        st.positions, st._box_token = torch.zeros((8, 3)), nbr._box_token
+        integ = LangevinIntegrator()
+        owner = Owner()
+        integ._carry = dict(owner=owner, public=nbr, x=st.positions, x_version=st.positions._version, cs_md=1.5,
+                            skin=nbr._skin, box_token=nbr._box_token)
+        return integ, nbr, st, owner
+
+    integ, nbr, st, owner = setup()
+    assert integ._take_carry(st, nbr, 20) is owner
+    assert integ.__dict__.get("_carry") is None and integ._take_carry(st, nbr, 20) is None  # consumed
+    for spoil in ("steps", "zero", "copy", "written", "box", "skin", "list", "reporter", "traj", "capacity", "switch"):
+        integ, nbr, st, owner = setup()
+        steps, other = 20, nbr
+        if spoil == "steps":
+            steps = integrators._CARRY_MAX_STEPS + 1
+        elif spoil == "zero":
+            steps = 0
+        elif spoil == "copy":
+            st.positions = st.positions.clone()
+        elif spoil == "written":
+            st.positions.add_(1.0)
+        elif spoil == "box":
+            st._box_token = object()
+        elif spoil == "skin":
+            nbr.skin = 0.5 * unit.nanometer  # (a new object, and is_built / _cs_md are void with it)
+        elif spoil == "list":
+            other = NeighborListNsqrd(OrthogonalPeriodicSpace())
+        elif spoil == "reporter":
+            integ.reporter = object()
+        elif spoil == "traj":
+            integ.save_traj_in_memory = True
+        elif spoil == "capacity":
+            owner._last_max_n = 170  # > 0.85 * n_max_neighbors: the reference's growth rule must see every build
+        elif spoil == "switch":
+            integrators._CARRY[0] = False
+        try:
+            assert integ._take_carry(st, other, steps) is None, spoil
+        finally:
+            integrators._CARRY[0] = True
+        assert integ.__dict__.get("_carry") is None, spoil
+    # an offer that names the caller's own list needs that list's last confirmed cell build: none here
+    integ, nbr, st, owner = setup()
+    integ._carry["owner"] = nbr
+    assert integ._take_carry(st, nbr, 20) is None
 
 
 def test_cell_build_refuses_a_grid_axis_beyond_its_packed_coordinates():
