@@ -252,9 +252,17 @@ class LangevinIntegrator:
             to_report = (-(step + base)) % self.report_interval  # steps until the next reporting step
             return min(number_of_steps, step + to_report + 1)
 
-        # (host work that does not depend on the steps goes in front of them: behind them the device would wait for it)
-        # the reference returns the key its loop ended with (:216); the counter-based stream folds the step count in
-        key_out = chain_key if isinstance(key, JaxKey) else fold_in(key, number_of_steps)
+        # Host work that does not depend on the steps' results -- the key the reference returns (:216: the one its loop
+        # ended with; the counter-based stream folds the step count in) and the copy of the box for the returned state --
+        # is done while the last launches are still queued, right before the host waits for them (_enqueue_kick); behind
+        # the wait the device would idle through it, in front of the first launch as well.
+        tail = {}
+
+        def host_tail():
+            tail["key"] = chain_key if isinstance(key, JaxKey) else fold_in(key, number_of_steps)
+            tail["box"] = sampler_state._box_copy()
+
+        st._host_tail = host_tail
         done = 0
         while done < number_of_steps:
             stop = next_stop(done)
@@ -279,9 +287,11 @@ class LangevinIntegrator:
             st._settle()
 
         st.finish()
-        updated_sampler_state = sampler_state._copy_with(*st.final_state_user())  # :210-218
+        if not tail:
+            host_tail()
+        updated_sampler_state = sampler_state._copy_with(*st.final_state_user(), box_copy=tail["box"])  # :210-218
         st.offer_carry(updated_sampler_state)
-        updated_sampler_state.current_PRNG_key = key_out
+        updated_sampler_state.current_PRNG_key = tail["key"]
         self.n_rebuilds = st.n_rebuilds
         self._rebuild_log = st.rebuild_log
         return updated_sampler_state, st.nbr_list
@@ -1055,8 +1065,11 @@ class _RunState:
         self._final_state = self.state_user() if with_state else None
         # (list carry-over: the reference positions the caller's list will be rebuilt from, should anybody read it)
         self._final_ref = self._unpack(self.ref4) if with_state and self._carried is not None else None
+        work, self._host_tail = getattr(self, "_host_tail", None), None
+        if work is not None:
+            work()  # (see LangevinIntegrator.run: the launches above are still queued; its device copy is behind them)
         ev = torch.cuda.Event()
-        ev.record()
+        ev.record()  # (the last thing on the stream: a caller's device-wide synchronize then finds nothing pending)
         ev.synchronize()
 
     def _advance_windowed(self, done: int, stop: int, final: bool = False) -> int:

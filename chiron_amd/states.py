@@ -95,16 +95,23 @@ class SamplerState:
             setattr(new, name, value)
         return new
 
-    def _copy_with(self, positions: torch.Tensor, velocities: torch.Tensor) -> "SamplerState":
+    def _copy_with(self, positions: torch.Tensor, velocities: torch.Tensor, box_copy=None) -> "SamplerState":
         """``deepcopy(self)`` followed by assigning fresh md-unit fp32 device arrays (what
-        chiron/integrators.py:210-214 does), without cloning the two arrays that are replaced."""
+        chiron/integrators.py:210-214 does), without cloning the two arrays that are replaced.
+        ``box_copy``: a copy of the box values the caller has made already (``_box_copy``: the integrator takes it
+        while its steps run instead of behind them)."""
         new = SamplerState.__new__(SamplerState)
         new.__dict__.update(self.__dict__)
         if self._box_vectors is not None:
-            new._box_vectors = unit.Quantity(self._box_vectors._value.clone(), self._box_vectors.unit)
+            new._box_vectors = box_copy if box_copy is not None else self._box_copy()
         new._positions = unit.Quantity(positions, self._distance_unit)
         new._velocities = unit.Quantity(velocities, self._velocity_unit())
         return new
+
+    def _box_copy(self):
+        if self._box_vectors is None:
+            return None
+        return unit.Quantity(self._box_vectors._value.clone(), self._box_vectors.unit)
 
     def _velocity_unit(self):
         """distance / time (unit arithmetic is exact-rational Python: once per pair of units, not per run() call)"""

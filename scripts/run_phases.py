@@ -34,11 +34,17 @@ wrap(I._RunState, "__init__", "2 state packed (pack enqueued)")
 wrap(I._RunState, "_enqueue_window", "3 first steps enqueued", "before")
 wrap(I._RunState, "final_kick", "4 kick done (device drained)")
 wrap(I._RunState, "state_user", "5 state unpacked (enqueued)")
+wrap(I._RunState, "finish", "5a finish() done")
+wrap(I._RunState, "offer_carry", "5c carry offered")
+from chiron_amd import states as S
+wrap(S.SamplerState, "_copy_with", "5b state copied")
+if len(sys.argv) > 3:
+    I._CARRY[0] = sys.argv[3] != "0"
 state, nbr = integ.run(state, thermo, number_of_steps=0, nbr_list=nbr)
 t0 = time.perf_counter()
 while time.perf_counter() - t0 < 3.0:
     state, nbr = integ.run(state, thermo, number_of_steps=2000, nbr_list=nbr)
-rows = []
+rows = {}
 for _ in range(400):
     torch.cuda.synchronize()
     marks.clear()
@@ -47,8 +53,7 @@ for _ in range(400):
     tb = time.perf_counter()
     torch.cuda.synchronize()
     tc = time.perf_counter()
-    rows.append([marks.get(k, ta) - ta for k in sorted(marks)] + [tb - ta, tc - ta])
-    keys = sorted(marks)
-r = 1e6 * np.median(np.array(rows), axis=0)
-for k, v in zip(keys + ["6 run() returned", "7 device idle"], r):
-    print(f"  {k:36s} {v:8.1f} us")
+    for k, v in list(marks.items()) + [("6 run() returned", tb), ("7 device idle", tc)]:
+        rows.setdefault(k, []).append(v - ta)
+for k in sorted(rows):  # (a mark that only some calls pass -- a list renewal -- shows with its count)
+    print(f"  {k:36s} {1e6 * np.median(rows[k]):8.1f} us   (n = {len(rows[k])})")
