@@ -25,6 +25,11 @@ def wrap(obj, name, tag, when="after"):
         return r
     setattr(obj, name, f)
 
+from chiron_amd import ops as OPS, utils as U
+wrap(U, "get_list_of_mass", "0a masses listed")
+wrap(N.NeighborListNsqrd, "_build_speculative", "0c _build_speculative entered", "before")
+wrap(OPS, "cell_grid", "0d cell grid known")
+wrap(OPS, "nl_build_cell_fl", "0e build call entered", "before")
 wrap(N.NeighborListNsqrd, "_build_speculative", "1 build enqueued")
 wrap(I.LangevinIntegrator, "_take_carry", "0 carry decided")
 wrap(I._RunState, "_setup_carry", "1a carry set up", "before")
