@@ -1279,13 +1279,13 @@ int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, in
         int last = hc[0];
         bool timing = false;
         timespec t0{};
-        if (poll.sleep_ns > 0) g_poll_stats[0] += 1;
+        if (poll.sleep_ns > 0) __atomic_fetch_add(&g_poll_stats[0], 1, __ATOMIC_RELAXED);
         for (unsigned spins = 0;; ++spins) {
           if ((long long)hc[3] <= s) return CHX_OK;
           if (watch && hc[12] != 0x7FFFFFFF) return CHX_OK;
           const int begun = hc[0];  // newest launch that has begun; begun+1 .. s-1 are still waiting
           if (s - begun <= low) {
-            if (poll.sleep_ns > 0 && s - begun <= 2) g_poll_stats[2] += 1;  // overslept: the queue is all but dry
+            if (poll.sleep_ns > 0 && s - begun <= 2) __atomic_fetch_add(&g_poll_stats[2], 1, __ATOMIC_RELAXED);  // overslept: the queue is all but dry
             break;
           }
           if (poll.sleep_ns > 0) {
@@ -1294,8 +1294,8 @@ int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, in
             clock_gettime(CLOCK_MONOTONIC, &n0);
             nanosleep(&nap, nullptr);
             clock_gettime(CLOCK_MONOTONIC, &n1);
-            g_poll_stats[1] += 1;
-            g_poll_stats[3] += (n1.tv_sec - n0.tv_sec) * 1000000000LL + (n1.tv_nsec - n0.tv_nsec);
+            __atomic_fetch_add(&g_poll_stats[1], 1, __ATOMIC_RELAXED);  // (several launching threads may share the counters)
+            __atomic_fetch_add(&g_poll_stats[3], (n1.tv_sec - n0.tv_sec) * 1000000000LL + (n1.tv_nsec - n0.tv_nsec), __ATOMIC_RELAXED);
           } else {
             cpu_relax();
           }
