@@ -355,7 +355,10 @@ class NeighborListNsqrd(PairsBase):
         self.ref_positions = positions  # a fresh tensor nobody else holds
         self._cutoff_and_skin = cs
         nl, first, n_nbr, sorted_ids, fl, deg, status = ops.nl_build_cell_fl(
-            positions, self._box_h, cs, m, ncell, nc, g, chunks, self._scratch, max_blocks=getattr(self, "_bg_blocks", 0))
+            positions, self._box_h, cs, m, ncell, nc, g, chunks, self._scratch,
+            # (a build on a side stream shares the chip with the step launches: fewer workgroups; on the step stream
+            # itself -- a renewal of the force list at a halt -- nothing else runs: one wavefront per row)
+            max_blocks=getattr(self, "_bg_blocks", 0) if stream is not None else 0)
         host = getattr(self, "_status_host", None)
         if host is None:
             host = self._status_host = torch.empty((8,), dtype=torch.int32, pin_memory=True)
