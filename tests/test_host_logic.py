@@ -760,6 +760,28 @@ def test_list_carry_over_offer_is_taken_only_by_the_run_that_continues_the_traje
     assert integ._take_carry(st, nbr, 20) is None
 
 
+def test_launch_window_poll_policy_and_its_diagnostics_are_host_calls():
+    """``chx_set_poll_sleep_ns`` (how the launch window waits; 0 = busy-wait) returns the previous setting, and
+    ``chx_poll_stats`` reads / resets the window's counters: both are plain host calls (no GPU needed)."""
+    import ctypes
+
+    from chiron_amd import _lib
+
+    lib = _lib.load()
+    old = lib.chx_set_poll_sleep_ns(0)
+    try:
+        assert lib.chx_set_poll_sleep_ns(7000) == 0
+        assert lib.chx_set_poll_sleep_ns(-5) == 7000  # (negative: clamped to busy-waiting)
+        assert lib.chx_set_poll_sleep_ns(old) == 0
+    finally:
+        lib.chx_set_poll_sleep_ns(old)
+    st = (ctypes.c_int64 * 4)(1, 2, 3, 4)
+    assert lib.chx_poll_stats(st, 1) == 0
+    assert all(v >= 0 for v in st)
+    assert lib.chx_poll_stats(st, 0) == 0 and list(st) == [0, 0, 0, 0]  # (nothing has polled since the reset)
+    assert lib.chx_poll_stats(None, 0) == 0
+
+
 def test_cell_build_refuses_a_grid_axis_beyond_its_packed_coordinates():
     """The cell kernels carry a cell's grid coordinates in 10 bits per axis; a caller-supplied grid with a longer
     axis would alias cells silently (advisor finding, round 2).  Refused before any launch."""
