@@ -2284,3 +2284,42 @@ def test_list_carry_over_survives_a_rejected_force_list_renewal(ca, O, monkeypat
         assert ra[k]["rebuild_steps"] == rb[k]["rebuild_steps"], k
         assert _mi_max(ra[k]["x"], rb[k]["x"], L) < 2e-4, k
     assert nbr_a.n_builds == nbr_b.n_builds and _mi_max(nbr_a.ref_positions, nbr_b.ref_positions, L) < 2e-4
+
+
+def test_list_carry_over_with_injected_noise_follows_the_oracle_step_for_step(ca, O):
+    """The carried path against the NumPy oracle at the tolerance of a single run (injected noise, no chaos to hide
+    behind): five 12-step segments under a thin skin, so that reference rebuild events AND renewals of the carried
+    force list fall inside them; the oracle builds its list on every entry (chiron/integrators.py:169)."""
+    import os
+
+    from chiron_amd import integrators
+
+    if os.environ.get("CHX_LAUNCH_WINDOW") == "0" or os.environ.get("CHX_HOST_CTRL") == "0":
+        pytest.skip("list carry-over rides on the bounded launch queue, which this run switches off")
+    if os.environ.get("CHX_DEFERRED_REBUILD") == "1":
+        pytest.skip("with deferred rebuilds switched on every run() builds its list on entry")
+    n, steps, segments, skin = 2500, 12, 5, 0.05
+    x, box, pot, state, thermo, nbr, integ = _langevin_setup(ca, O, n, 0.3, 43, skin, 4.0)
+    rng = np.random.default_rng(23)
+    mass = np.full(n, 39.948, f32)
+    kT = O.R_KJ * 300.0
+    v0 = O.initial_velocities(mass, kT, rng.normal(size=(n, 3)).astype(f32))
+    state.velocities = v0
+    xo, vo = x, v0
+    old = integrators._CARRY[0]
+    integrators._CARRY[0] = True
+    events = 0
+    try:
+        for k in range(segments):
+            noise = rng.normal(size=(steps, n, 3)).astype(f32)
+            state, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr, noise=noise)
+            xo, vo, rebuilds, _ = O.langevin_run(xo, vo, box, mass, SIGMA, EPS, CUTOFF, skin, 180, 0.004, 1.0, 300.0, steps,
+                                                 lambda s: noise[s])
+            assert integ.n_rebuilds == rebuilds, k
+            events += rebuilds
+            assert np.abs(state.positions.cpu().numpy() - xo).max() < 5e-6, k
+            assert np.abs(state.velocities.cpu().numpy() - vo).max() < 5e-4 * max(1.0, np.abs(vo).max()), k
+    finally:
+        integrators._CARRY[0] = old
+    assert integ.n_carried_runs == segments - 1 and getattr(integ, "n_carry_rejected", 0) == 0
+    assert events >= 2 and integ.n_internal_halts >= 1  # both kinds of rebuild happened inside carried segments
