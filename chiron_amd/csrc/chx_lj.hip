@@ -1012,10 +1012,14 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
 // SLICES lanes share one particle: 64 (a whole wavefront) for the small systems this path is meant
 // for -- at N = 512 a lane then evaluates 8 pairs instead of 32, and the launch is a dependent-issue
 // chain, not a throughput problem -- and 16 beyond.
-template <int SLICES>
+// DIRECT (the small-system instantiation, SLICES = 64): no LDS tiles.  A lane's candidates j = sl, sl + 64, ... are
+// read straight from the position buffer, eight coalesced loads in flight per lane -- at N = 512 that is the whole row
+// behind ONE exposed round trip, where the tiled form pays one per tile plus two barriers each; same pairs in the same
+// order in every lane, so the same bits.
+template <int SLICES, bool DIRECT>
 __global__ __launch_bounds__(256) void k_ap_step(StepArgs a, long long step, int n_kicks, int do_aoa, int use_cutoff) {
   constexpr int PPB = 256 / SLICES;
-  __shared__ float4 tile[AP_TILE];
+  __shared__ float4 tile[DIRECT ? 1 : AP_TILE];
   __shared__ float sF[3 * PPB];
   const int p0 = blockIdx.x * PPB;
   const StepParticle tk = load_step_particle<false, false>(a, step, do_aoa, p0, threadIdx.x, PPB);
@@ -1025,40 +1029,57 @@ __global__ __launch_bounds__(256) void k_ap_step(StepArgs a, long long step, int
   const bool valid = i < a.n;
   const float4 xi = a.x_cur[valid ? i : 0];
   float fx = 0.f, fy = 0.f, fz = 0.f;
-  for (int j0 = 0; j0 < a.n; j0 += AP_TILE) {
-    __syncthreads();
-    const int jj = j0 + threadIdx.x;
-    if (jj < a.n) tile[threadIdx.x] = a.x_cur[jj];
-    __syncthreads();
-    const int cnt = (a.n - j0) < AP_TILE ? (a.n - j0) : AP_TILE;
-    if (valid) {
-      for (int u = sl; u < cnt; u += SLICES) {
-        const int j = j0 + u;
-        if (j == i) continue;
-        const float4 xj = tile[u];
-        const bool hi = j > i;
-        float rx, ry, rz;
-        bool bad;  // branch-free minimum image, general formula for |d| >= L (same bits where both apply)
-        displacement_oriented_fast(a.box, hi, xi.x, xi.y, xi.z, xj.x, xj.y, xj.z, rx, ry, rz, bad);
-        if (__builtin_expect(bad, 0)) displacement_oriented(a.box, hi, xi.x, xi.y, xi.z, xj.x, xj.y, xj.z, rx, ry, rz);
-        const float r2 = norm2(rx, ry, rz);
-        if (!use_cutoff || r2 <= a.lj.T) {
-          float e, fs;
-          lj_pair(r2, a.lj.sig2, a.lj.eps4, a.lj.eps24, e, fs);
-          if (!hi) fs = -fs;
-          fx += fs * rx;
-          fy += fs * ry;
-          fz += fs * rz;
+  auto pair = [&](int j, const float4& xj) {
+    const bool hi = j > i;
+    float rx, ry, rz;
+    bool bad;  // branch-free minimum image, general formula for |d| >= L (same bits where both apply)
+    displacement_oriented_fast(a.box, hi, xi.x, xi.y, xi.z, xj.x, xj.y, xj.z, rx, ry, rz, bad);
+    if (__builtin_expect(bad, 0)) displacement_oriented(a.box, hi, xi.x, xi.y, xi.z, xj.x, xj.y, xj.z, rx, ry, rz);
+    const float r2 = norm2(rx, ry, rz);
+    if (!use_cutoff || r2 <= a.lj.T) {
+      float e, fs;
+      lj_pair(r2, a.lj.sig2, a.lj.eps4, a.lj.eps24, e, fs);
+      if (!hi) fs = -fs;
+      fx += fs * rx;
+      fy += fs * ry;
+      fz += fs * rz;
+    }
+  };
+  if (DIRECT) {
+    constexpr int B = 8;  // loads in flight per lane
+    for (int j0 = sl; j0 < a.n; j0 += B * SLICES) {
+      float4 xj[B];
+#pragma unroll
+      for (int k = 0; k < B; ++k) {
+        const int j = j0 + k * SLICES;
+        xj[k] = a.x_cur[j < a.n ? j : 0];
+      }
+      if (valid) {
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+          const int j = j0 + k * SLICES;
+          if (j < a.n && j != i) pair(j, xj[k]);
+        }
+      }
+    }
+  } else {
+    for (int j0 = 0; j0 < a.n; j0 += AP_TILE) {
+      __syncthreads();
+      const int jj = j0 + threadIdx.x;
+      if (jj < a.n) tile[threadIdx.x] = a.x_cur[jj];
+      __syncthreads();
+      const int cnt = (a.n - j0) < AP_TILE ? (a.n - j0) : AP_TILE;
+      if (valid) {
+        for (int u = sl; u < cnt; u += SLICES) {
+          const int j = j0 + u;
+          if (j == i) continue;
+          pair(j, tile[u]);
         }
       }
     }
   }
-#pragma unroll
-  for (int o = SLICES / 2; o > 0; o >>= 1) {
-    fx += __shfl_xor(fx, o, CHX_WAVE);
-    fy += __shfl_xor(fy, o, CHX_WAVE);
-    fz += __shfl_xor(fz, o, CHX_WAVE);
-  }
+  // (DPP swizzles inside a row of 16 lanes, shuffles across rows: the force-list kernels' reduction)
+  fx = group_sum<SLICES>(fx), fy = group_sum<SLICES>(fy), fz = group_sum<SLICES>(fz);
   if (sl == 0) {
     sF[3 * il] = fx;
     sF[3 * il + 1] = fy;
@@ -1321,10 +1342,10 @@ int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, in
       a.ref4 = nullptr;  // no skin check on these paths
       a.snap4 = nullptr;
       if (a.n <= 2048) {
-        hipLaunchKernelGGL((k_ap_step<64>), dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, st, a, (long long)(step0 + i), nk,
+        hipLaunchKernelGGL((k_ap_step<64, true>), dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, st, a, (long long)(step0 + i), nk,
                            do_aoa, use_cutoff);
       } else {
-        hipLaunchKernelGGL((k_ap_step<16>), dim3((unsigned)((a.n + 15) / 16)), dim3(256), 0, st, a, (long long)(step0 + i), nk,
+        hipLaunchKernelGGL((k_ap_step<16, false>), dim3((unsigned)((a.n + 15) / 16)), dim3(256), 0, st, a, (long long)(step0 + i), nk,
                            do_aoa, use_cutoff);
       }
       continue;
