@@ -141,11 +141,23 @@ def make_system(workload: str, temperature_K: float, chunk: int, build: str):
     PRNG.set_seed(1234)
     state = SamplerState(fluid.positions, PRNG.get_random_key(), box_vectors=fluid.box_vectors)
     thermo = ThermodynamicState(pot, temperature=temperature_K * unit.kelvin)
+    nbr, integ = make_list_and_integrator(workload, chunk, build)
+    return fluid, pot, state, thermo, nbr, integ
+
+
+def make_list_and_integrator(workload: str, chunk: int = 32, build: str = "cell"):
+    """The neighbor list and the integrator of a workload as every leg of the bench uses them (also what the
+    production-state parity tests start their branches with: tests/test_gpu_production_state.py)."""
+    from chiron_amd import unit
+    from chiron_amd.integrators import LangevinIntegrator
+    from chiron_amd.neighbors import NeighborListCell, NeighborListNsqrd, OrthogonalPeriodicSpace
+
+    _, rho = WORKLOADS[workload]
     cls = NeighborListCell if build == "cell" else NeighborListNsqrd
     m0 = 180 if rho <= 0.2 else 400
-    nbr = cls(OrthogonalPeriodicSpace(), cutoff=cutoff, skin=SKIN_NM * unit.nanometer, n_max_neighbors=m0)
+    nbr = cls(OrthogonalPeriodicSpace(), cutoff=3.0 * SIGMA_NM * unit.nanometer, skin=SKIN_NM * unit.nanometer, n_max_neighbors=m0)
     integ = LangevinIntegrator(timestep=1.0 * unit.femtoseconds, collision_rate=1.0 / unit.picoseconds, chunk_size=chunk)
-    return fluid, pot, state, thermo, nbr, integ
+    return nbr, integ
 
 
 def two_replica_overlap(args, steps: int):

@@ -294,6 +294,10 @@ class LangevinIntegrator:
         updated_sampler_state.current_PRNG_key = tail["key"]
         self.n_rebuilds = st.n_rebuilds
         self._rebuild_log = st.rebuild_log
+        if getattr(self, "keep_run_state", False):
+            # (tests / audits: the device-resident state the last launch of the run saw -- force list, pruned inner
+            # list, control block, positions in internal order.  Off by default: it pins the run's buffers.)
+            self._last_run_state = st
         return updated_sampler_state, st.nbr_list
 
     def _take_carry(self, sampler_state, nbr_list, number_of_steps: int):

@@ -24,6 +24,7 @@ def lib():
         assert _lib.orc_source_hash().decode().endswith(build_oracle.source_hash()), "liboracle.so is stale"
         _lib.orc_full_rows_cell.restype = C.c_int
         _lib.orc_lj_cell_f64.restype = C.c_int
+        _lib.orc_lj_cell_f64_ex.restype = C.c_int
         _lib.orc_nl_build_fixed.restype = C.c_int
         _lib.orc_lj_nl.restype = C.c_float
         _lib.orc_langevin_run.restype = C.c_int
@@ -156,4 +157,26 @@ def lj_cell_f64(x, box, sigma, eps, cutoff, threads=0, cap0=64):
             return float(stats[0]), f, float(stats[1]), float(stats[2]), int(stats[3])
         if rc < 0:
             raise MemoryError("orc_lj_cell_f64")
+        cap = rc + 16
+
+
+def lj_cell_f64_ex(x, box, sigma, eps, cutoff, threads=0, cap0=64, geom32=True):
+    """lj_cell_f64 plus per-particle noise scales:
+    (E, force64 (n,3), sum|e_ij|, fabs (n,3) = sum_j |f_ij,c|, fterm (n,3) = sum_j (|repulsive| + |attractive|)_c, n_pairs).
+    geom32: pair vectors in the reference's fp32 arithmetic (chiron/neighbors.py:69-79; what the kernels reproduce bit
+    for bit), Lennard-Jones values and sums in fp64 -- see oracle.c for why the clustered fluid needs it."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n, cap = x.shape[0], int(cap0)
+    f = np.zeros((n, 3), np.float64)
+    fa = np.zeros((n, 3), np.float64)
+    ft = np.zeros((n, 3), np.float64)
+    stats = np.zeros(4, np.float64)
+    while True:
+        rc = lib().orc_lj_cell_f64_ex(_p(x, C.c_float), n, _box(box), C.c_float(sigma), C.c_float(eps), C.c_float(cutoff), cap,
+                                      _p(f, C.c_double), _p(fa, C.c_double), _p(ft, C.c_double), _p(stats, C.c_double),
+                                      int(threads), int(bool(geom32)))
+        if rc == 0:
+            return float(stats[0]), f, float(stats[1]), fa, ft, int(stats[3])
+        if rc < 0:
+            raise MemoryError("orc_lj_cell_f64_ex")
         cap = rc + 16

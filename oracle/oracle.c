@@ -399,8 +399,17 @@ int orc_full_rows_cell(const float* x, int n, orc_box box, float cs, int cap, ui
  * far above the tolerance); the VALUES are fp64 on the same coordinates with an fp64 minimum image.
  * force64 (n,3); stats[0] = E, [1] = sum over pairs |e_ij|, [2] = max_i max_c sum_j |f_ij,c|, [3] = pairs.
  * Returns 0, or the required row capacity if `cap` was too small. */
-int orc_lj_cell_f64(const float* x, int n, orc_box box, float sigma, float eps, float rc, int cap, double* force64,
-                    double* stats, int threads) {
+/* geom32 != 0: the pair vectors are the REFERENCE's fp32 ones (x_i - x_j, mod(r + L/2, L) - L/2 in fp32,
+ * chiron/neighbors.py:69-79 -- the kernels reproduce them bit for bit), and only the Lennard-Jones arithmetic and the
+ * sums are fp64.  At r ~ sigma the fp32 minimum image alone (one rounding at magnitude L/2) moves a pair force by up to
+ * 13 ulp(L/2) / (2 r) ~ 2e-5 (L = 23 nm) .. 4e-5 (L = 47 nm) of its size, more than SURVEY 8(c)'s 1e-5: on a clustered
+ * fluid the tolerance against pure fp64 geometry measures the reference's formula, not the kernel.
+ * fabs_out (n,3) or NULL: per particle and component, sum_j |f_ij,c|.
+ * fterm_out (n,3) or NULL: sum_j (|repulsive| + |attractive|) = sum_j 24 eps (2 s^12 + s^6) / d^2 |r_c| -- the scale of
+ * the particle's fp32 rounding noise: near d = 2^(1/6) sigma the two terms cancel in f_ij while their rounding errors
+ * do not. */
+int orc_lj_cell_f64_ex(const float* x, int n, orc_box box, float sigma, float eps, float rc, int cap, double* force64,
+                       double* fabs_out, double* fterm_out, double* stats, int threads, int geom32) {
 #ifdef _OPENMP
   if (threads > 0) omp_set_num_threads(threads);
 #endif
@@ -413,25 +422,44 @@ int orc_lj_cell_f64(const float* x, int n, orc_box box, float sigma, float eps, 
   double e_tot = 0.0, e_abs = 0.0, f_abs_max = 0.0, pairs = 0.0;
 #pragma omp parallel for schedule(static) reduction(+ : e_tot, e_abs, pairs) reduction(max : f_abs_max)
   for (int i = 0; i < n; ++i) {
-    double f[3] = {0, 0, 0}, fa[3] = {0, 0, 0};
+    double f[3] = {0, 0, 0}, fa[3] = {0, 0, 0}, ft[3] = {0, 0, 0};
     const uint32_t* row = rows + (size_t)i * cap;
     for (int k = 0; k < deg[i]; ++k) {
       const int j = (int)row[k];
       double r[3], d2 = 0.0;
-      for (int c = 0; c < 3; ++c) {
-        r[c] = (double)x[3 * i + c] - (double)x[3 * j + c];
-        if (box.periodic) r[c] -= L[c] * nearbyint(r[c] / L[c]);
-        d2 += r[c] * r[c];
+      if (geom32) {
+        /* the reference's orientation: lower id minus higher id (chiron/neighbors.py:773-779) */
+        float r32[3];
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        (void)disp(&box, x + 3 * lo, x + 3 * hi, r32);
+        for (int c = 0; c < 3; ++c) { r[c] = (i < j) ? (double)r32[c] : -(double)r32[c]; d2 += r[c] * r[c]; }
+      } else {
+        for (int c = 0; c < 3; ++c) {
+          r[c] = (double)x[3 * i + c] - (double)x[3 * j + c];
+          if (box.periodic) r[c] -= L[c] * nearbyint(r[c] / L[c]);
+          d2 += r[c] * r[c];
+        }
       }
       const double s2 = (double)sigma * (double)sigma / d2, s6 = s2 * s2 * s2;
       const double e = 4.0 * (double)eps * (s6 * s6 - s6);
       const double fs = 24.0 * (double)eps * (2.0 * s6 * s6 - s6) / d2;
-      for (int c = 0; c < 3; ++c) { f[c] += fs * r[c]; fa[c] += fabs(fs * r[c]); }
+      const double ts = 24.0 * (double)eps * (2.0 * s6 * s6 + s6) / d2;
+      for (int c = 0; c < 3; ++c) { f[c] += fs * r[c]; fa[c] += fabs(fs * r[c]); ft[c] += ts * fabs(r[c]); }
       if (i < j) { e_tot += e; e_abs += fabs(e); pairs += 1.0; }
     }
-    for (int c = 0; c < 3; ++c) { force64[3 * (size_t)i + c] = f[c]; if (fa[c] > f_abs_max) f_abs_max = fa[c]; }
+    for (int c = 0; c < 3; ++c) {
+      force64[3 * (size_t)i + c] = f[c];
+      if (fabs_out) fabs_out[3 * (size_t)i + c] = fa[c];
+      if (fterm_out) fterm_out[3 * (size_t)i + c] = ft[c];
+      if (fa[c] > f_abs_max) f_abs_max = fa[c];
+    }
   }
   if (stats) { stats[0] = e_tot; stats[1] = e_abs; stats[2] = f_abs_max; stats[3] = pairs; }
   free(rows); free(deg);
   return 0;
+}
+
+int orc_lj_cell_f64(const float* x, int n, orc_box box, float sigma, float eps, float rc, int cap, double* force64,
+                    double* stats, int threads) {
+  return orc_lj_cell_f64_ex(x, n, box, sigma, eps, rc, cap, force64, NULL, NULL, stats, threads, 0);
 }

@@ -430,6 +430,37 @@ def test_c_oracle_full_size_checkers_against_the_numpy_oracle():
         assert abs(e - e64) <= 1e-12 * eabs64 and abs(eabs - eabs64) <= 1e-12 * eabs64
         assert np.abs(f - f64).max() <= 1e-11 * max(1.0, fmax64)
         assert pairs > n  # a fluid, not a gas of isolated particles
+        # the variant the production-state GPU tests use: same routine with the per-particle noise scale ...
+        e_x, f_x, eabs_x, fa_x, _, pairs_x = CO.lj_cell_f64_ex(x, box, sigma, eps, cutoff, threads=2, cap0=4, geom32=False)
+        assert e_x == e and eabs_x == eabs and pairs_x == pairs and np.array_equal(f_x, f) and fa_x.max() == fabs
+        # ... and with the REFERENCE's fp32 pair vectors (chiron/neighbors.py:69-79) under fp64 Lennard-Jones values:
+        # restated here with the NumPy oracle's displacement over all pairs
+        e_g, f_g, eabs_g, fa_g, ft_g, pairs_g = CO.lj_cell_f64_ex(x, box, sigma, eps, cutoff, threads=2, cap0=4, geom32=True)
+        assert pairs_g == pairs
+        ii, jj = np.triu_indices(n, k=1)
+        r32, d32 = O.periodic_displacement(x[ii], x[jj], box)
+        sel = d32 < np.float32(cutoff)
+        assert int(sel.sum()) == pairs
+        r = r32[sel].astype(np.float64)
+        d2 = (r * r).sum(axis=1)
+        s6 = (float(f32(sigma)) ** 2 / d2) ** 3
+        fs = 24.0 * float(f32(eps)) * (2.0 * s6 * s6 - s6) / d2
+        want_f = np.zeros((n, 3))
+        want_a = np.zeros((n, 3))
+        want_t = np.zeros((n, 3))
+        ts = 24.0 * float(f32(eps)) * (2.0 * s6 * s6 + s6) / d2
+        np.add.at(want_t, ii[sel], ts[:, None] * np.abs(r))
+        np.add.at(want_t, jj[sel], ts[:, None] * np.abs(r))
+        np.add.at(want_f, ii[sel], fs[:, None] * r)
+        np.add.at(want_f, jj[sel], -fs[:, None] * r)
+        np.add.at(want_a, ii[sel], np.abs(fs[:, None] * r))
+        np.add.at(want_a, jj[sel], np.abs(fs[:, None] * r))
+        assert np.abs(f_g - want_f).max() <= 1e-11 * max(1.0, want_a.max())
+        assert np.abs(fa_g - want_a).max() <= 1e-11 * max(1.0, want_a.max())
+        assert np.abs(ft_g - want_t).max() <= 1e-11 * max(1.0, want_t.max()) and (ft_g >= fa_g * (1 - 1e-12)).all()
+        assert abs(e_g - (4.0 * float(f32(eps)) * (s6 * s6 - s6)).sum()) <= 1e-11 * eabs_g
+        # the two geometries differ by the fp32 minimum image's own rounding, far below any tolerance at this scale
+        assert np.abs(f_g - f).max() <= 1e-4 * max(1.0, fabs)
 
 
 def test_c_oracle_binary_cannot_go_stale(tmp_path, monkeypatch):
