@@ -56,7 +56,6 @@ class LangevinParams(C.Structure):
         ("prune_phase", C.c_int64),
         ("host_ctrl", C.c_void_p),
         ("snap4", C.c_void_p),
-        ("trigger_frac", C.c_float),
         ("ev_log_cap", C.c_int32),
         ("ev_log", C.c_void_p),
     ]
@@ -99,6 +98,26 @@ class McParams(C.Structure):
 # indices into the chx_mc_t state block (include/chx.h)
 MC_CUR, MC_ACCEPTED, MC_PROPOSED, MC_HALT, MC_KEY0, MC_KEY1, MC_SLOT_WORDS, MC_STATE_WORDS = 0, 1, 2, 3, 4, 5, 8, 16
 
+class BuildRiders(C.Structure):
+    """chx_build_riders_t (include/chx.h): work that rides on the launches of chx_nl_build_cell_fl."""
+
+    _fields_ = [
+        ("xyz_copy_out", C.c_void_p),
+        ("v3", C.c_void_p),
+        ("mass", C.c_void_p),
+        ("ref3", C.c_void_p),
+        ("x4_out", C.c_void_p),
+        ("v_out", C.c_void_p),
+        ("mass_out", C.c_void_p),
+        ("ref4_out", C.c_void_p),
+        ("ctrl_reset", C.c_void_p),
+        ("ctrl_keep", C.c_int32),
+        ("publish_host_dst8", C.c_void_p),
+    ]
+
+
+BUILD_STATUS_WORDS = 8  # include/chx.h: chx_nl_build_cell_fl, status8
+
 _P = C.c_void_p
 _I32 = C.c_int32
 _I64 = C.c_int64
@@ -123,11 +142,10 @@ SIGNATURES = {
     ),
     "chx_nl_build_cell_fl": (
         C.c_int,
-        [_P, _I32, _I32, Box, _F, C.POINTER(_I32), _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _I32, _P],
+        [_P, _I32, _I32, Box, _F, C.POINTER(_I32), _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, C.POINTER(BuildRiders), _P],
     ),
     "chx_nl_finish_padding": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),
     "chx_pack_langevin": (C.c_int, [_P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _I32, _P, _P, _P]),
-    "chx_repack_langevin": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _I32, _P]),
     "chx_validate_snap": (C.c_int, [_P, _P, _I32, Box, _F, _I32, _P, _P, _P]),
     "chx_nl_calculate": (C.c_int, [_P, _P, _P, _I32, _I32, Box, _F, _P, _P, _P, _P, _P]),
     "chx_nl_check": (C.c_int, [_P, _P, _I32, Box, _F, _P, _P]),
@@ -149,7 +167,7 @@ SIGNATURES = {
     "chx_langevin_chunk": (C.c_int, [C.POINTER(LangevinParams), _I64, _I32, _I32, _P]),
     "chx_langevin_resume": (C.c_int, [C.POINTER(LangevinParams), _P]),
     "chx_langevin_fused_chunk": (C.c_int, [C.POINTER(LangevinParams), _P, _P, _I64, _I32, _I32, _I32, _P]),
-    "chx_langevin_fused_run": (C.c_int, [C.POINTER(LangevinParams), _P, _P, _I64, _I32, _I32, _I32, _I32, C.POINTER(C.c_int32), _P]),
+    "chx_langevin_fused_run": (C.c_int, [C.POINTER(LangevinParams), _P, _P, _I64, _I32, _I32, _I32, C.POINTER(C.c_int32), _P]),
     "chx_set_poll_sleep_ns": (_I64, [_I64]),
     "chx_poll_stats": (C.c_int, [C.POINTER(_I64), _I32]),
     "chx_ctrl_reset": (C.c_int, [_P, _P]),
@@ -168,7 +186,7 @@ SIGNATURES = {
     ),
 }
 
-ABI_VERSION = 2  # include/chx.h: CHX_ABI_VERSION (history there)
+ABI_VERSION = 3  # include/chx.h: CHX_ABI_VERSION (history there)
 
 _lib: Optional[C.CDLL] = None
 

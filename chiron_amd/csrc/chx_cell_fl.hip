@@ -167,8 +167,9 @@ __device__ __forceinline__ void build_row_of_particle(
     n_nbr[i] = count_h;
     first_out[i] = mn;
     if (WRITE_FL) deg[w] = count_f < fcap ? count_f : fcap;
-    // only the rare failure cases touch the shared status words here (one hot address serialises
-    // atomics chip-wide); the maxima the host needs are reduced by k_nl_summary
+    // only the rare failure cases touch the shared status words here (one hot address serialises atomics chip-wide:
+    // spreading the maxima over 64 slots with a read-before-atomic filter still cost the build 60 us at N = 32768,
+    // measured in round 4); the maxima the host needs are reduced from n_nbr / deg by k_build_epilogue
     if (count_h > CHX_CELL_CAP - 40) atomicOr(&status[0], 1);
     if (WRITE_FL && count_f > fcap) {
       atomicAdd(&status[4], 1);
@@ -179,11 +180,6 @@ __device__ __forceinline__ void build_row_of_particle(
 }
 
 // one wavefront per PARTICLE (the general kernel: any row length up to the on-chip candidate buffer)
-// STRIDE: grid-stride over the rows -- a launch with fewer wavefronts than rows (the background builds of the deferred
-// scheme, which leave most wave slots to the step kernels running beside them) walks several rows per wave.  A
-// template parameter: the loop around the row costs the ordinary one-wave-per-row launch 13 % (46 -> 52 us at
-// N = 32768, rocprofv3, round 3).
-template <bool STRIDE>
 __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
     const float4* __restrict__ xs4, int n, int m, Box3 box, float T, CellGrid g,
     const int32_t* __restrict__ cell_of, const int32_t* __restrict__ cell_start,
@@ -192,16 +188,9 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
     int32_t* __restrict__ status) {
   __shared__ uint32_t cand_all[4][CHX_CELL_CAP];
   const int w0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (!STRIDE) {
-    if (w0 >= n) return;
-    build_row_of_particle<true>(w0, cand_all[threadIdx.x >> 6], xs4, n, m, box, T, g, cell_start, sorted_ids, nl, first_out,
-                                n_nbr, fg, fcap, fl, deg, status);
-  } else {
-    const int waves = (int)((gridDim.x * blockDim.x) >> 6);
-    for (int w = w0; w < n; w += waves)
-      build_row_of_particle<true>(w, cand_all[threadIdx.x >> 6], xs4, n, m, box, T, g, cell_start, sorted_ids, nl, first_out,
-                                  n_nbr, fg, fcap, fl, deg, status);
-  }
+  if (w0 >= n) return;
+  build_row_of_particle<true>(w0, cand_all[threadIdx.x >> 6], xs4, n, m, box, T, g, cell_start, sorted_ids, nl, first_out,
+                              n_nbr, fg, fcap, fl, deg, status);
 }
 
 // One wavefront per CELL: the (about ten at the BASELINE density) particles of a cell share their 27-cell
@@ -410,11 +399,15 @@ __global__ __launch_bounds__(256) void k_nl_build_cellwise_fl(
   }
 }
 
-// status[1] = max n_nbr, status[2] = #rows with n_nbr == m, status[3] = max full degree
-__global__ __launch_bounds__(256) void k_nl_summary(const int32_t* __restrict__ n_nbr,
-                                                    const int32_t* __restrict__ deg, int n, int m,
-                                                    int32_t* __restrict__ status) {
+// The chain's last launch: status[1] = max n_nbr, status[2] = #rows with n_nbr == m, status[3] = max full degree,
+// reduced from the arrays the build has written (a few dozen workgroups, one atomic each), and -- by whichever workgroup
+// finishes last (ticket in status[7]) -- status[0..7] copied into host-mapped memory with system scope, so the host can
+// read the block after waiting for the stream, or once it knows a later launch has begun: no publish launch.
+__global__ __launch_bounds__(256) void k_build_epilogue(const int32_t* __restrict__ n_nbr, const int32_t* __restrict__ deg,
+                                                        int n, int m, int32_t* __restrict__ status,
+                                                        int32_t* __restrict__ host_dst8) {
   __shared__ int32_t red[3][4];
+  __shared__ int last_block;
   int mx = 0, eq = 0, md = 0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const int c = n_nbr[i];
@@ -446,6 +439,13 @@ __global__ __launch_bounds__(256) void k_nl_summary(const int32_t* __restrict__ 
     atomicMax(&status[1], mx);
     if (eq) atomicAdd(&status[2], eq);
     atomicMax(&status[3], md);
+    __threadfence();
+    last_block = atomicAdd(&status[7], 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last_block && host_dst8 != nullptr && threadIdx.x < 8) {
+    const int v = threadIdx.x == 7 ? 0 : __hip_atomic_load(&status[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&host_dst8[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -454,7 +454,8 @@ extern "C" int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_
                                     int32_t* cell_count, int32_t* cell_start, uint32_t* sorted_ids,
                                     int32_t* status8, uint32_t* nl_rows_out, uint32_t* first_out,
                                     int32_t* n_nbr_out, int32_t g, int32_t chunks, uint32_t* fl_out,
-                                    int32_t* deg_out, float* xs4_out, int32_t max_blocks, chx_stream_t stream) {
+                                    int32_t* deg_out, float* xs4_out, const chx_build_riders_t* riders,
+                                    chx_stream_t stream) {
   CHX_REQUIRE(n >= 1 && m >= 1, "need n >= 1, m >= 1");
   CHX_REQUIRE(xyz && nc_h && cell_of && cell_count && cell_start && sorted_ids && status8 &&
                   nl_rows_out && first_out && n_nbr_out && fl_out && deg_out && xs4_out,
@@ -464,8 +465,26 @@ extern "C" int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_
   CHX_REQUIRE(chunks >= 1 && (int64_t)chunks * CHX_FL_QUAD * g < (1 << 20), "bad force-list capacity");
   hipStream_t st = chx_stream(stream);
   CellGrid grid;
+  BinRiders rd = {};
+  int32_t* publish_host = nullptr;
+  if (riders != nullptr) {
+    rd.xyz_copy = riders->xyz_copy_out;
+    if (riders->x4_out != nullptr) {
+      CHX_REQUIRE(riders->v3 && riders->mass && riders->v_out && riders->mass_out, "pack rider: null pointer");
+      rd.v3 = riders->v3;
+      rd.mass = riders->mass;
+      rd.ref3 = riders->ref3;
+      rd.x4 = reinterpret_cast<float4*>(riders->x4_out);
+      rd.v = riders->v_out;
+      rd.mass_out = riders->mass_out;
+      rd.ref4 = reinterpret_cast<float4*>(riders->ref4_out);
+    }
+    rd.ctrl = riders->ctrl_reset;
+    rd.ctrl_keep = riders->ctrl_keep;
+    publish_host = riders->publish_host_dst8;
+  }
   int rc = chx_cell_prepare(xyz, n, box, cutoff_plus_skin, nc_h, cell_of, cell_count, cell_start,
-                            sorted_ids, status8, 8, &grid, st, xs4_out);  // (the cell sort also emits xs4)
+                            sorted_ids, status8, 8, &grid, st, xs4_out, &rd);  // (the cell sort also emits xs4)
   if (rc != CHX_OK) return rc;
   const float T = chx_cutoff_threshold_h(cutoff_plus_skin);
   const unsigned wb = (unsigned)(((int64_t)n * CHX_WAVE + 255) / 256);
@@ -477,15 +496,9 @@ extern "C" int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_
   static const int forced = [] { const char* e = getenv("CHX_BUILD_KERNEL"); return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'c' ? 2 : 0)); }();
   const bool per_particle = forced == 1 || (forced == 0 && (int64_t)grid.ncx * grid.ncy * grid.ncz < 8192);
   if (per_particle) {
-    if (max_blocks > 0 && (unsigned)max_blocks < wb) {
-      hipLaunchKernelGGL((k_nl_build_cell_fl<true>), dim3((unsigned)max_blocks), dim3(256), 0, st, xs4, n, m, make_box3(box), T,
-                         grid, cell_of, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, chunks * CHX_FL_QUAD * g,
-                         fl_out, deg_out, status8);
-    } else {
-      hipLaunchKernelGGL((k_nl_build_cell_fl<false>), dim3(wb), dim3(256), 0, st, xs4, n, m, make_box3(box), T, grid,
-                         cell_of, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, chunks * CHX_FL_QUAD * g,
-                         fl_out, deg_out, status8);
-    }
+    hipLaunchKernelGGL(k_nl_build_cell_fl, dim3(wb), dim3(256), 0, st, xs4, n, m, make_box3(box), T, grid,
+                       cell_of, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, chunks * CHX_FL_QUAD * g,
+                       fl_out, deg_out, status8);
   } else {
     const int ncell = grid.ncx * grid.ncy * grid.ncz;
     static const int split_env = [] { const char* e = getenv("CHX_BUILD_SPLIT"); return e ? atoi(e) : 0; }();
@@ -497,7 +510,7 @@ extern "C" int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_
                        fl_out, deg_out, status8);
   }
   const unsigned sb = (unsigned)((n + 255) / 256 < 64 ? (n + 255) / 256 : 64);
-  hipLaunchKernelGGL(k_nl_summary, dim3(sb), dim3(256), 0, st, n_nbr_out, deg_out, n, m, status8);
+  hipLaunchKernelGGL(k_build_epilogue, dim3(sb), dim3(256), 0, st, n_nbr_out, deg_out, n, m, status8, publish_host);
   return chx_check_launch("chx_nl_build_cell_fl");
 }
 
@@ -541,7 +554,7 @@ __global__ void k_pack_langevin(const float* __restrict__ x3, const float* __res
   if (blockIdx.x == 0) {
     const int t = threadIdx.x;
     if (ctrl != nullptr && t < CHX_CTRL_WORDS) {
-      // (deferred rebuilds: the reference's event counters / booked events survive a repack into another order)
+      // (carried-over force list: the reference's event counters / booked events survive a renewal of the list)
       const bool keep = ((ctrl_keep & 1) && (t == 8 || t == 9)) || ((ctrl_keep & 2) && (t == 10 || t == 11));
       if (!keep) ctrl[t] = chx_ctrl_reset_word(t);
     }
@@ -576,54 +589,6 @@ extern "C" int chx_pack_langevin(const float* x3, const float* v3, const float* 
                      reinterpret_cast<float4*>(ref4_out), ctrl_reset, (int)ctrl_keep, publish_src8,
                      publish_host_dst8);
   return chx_check_launch("chx_pack_langevin");
-}
-
-// ---------------------------------------------------------------------------
-// deferred rebuilds: the state changes its internal order on the device (include/chx.h: chx_repack_langevin)
-// ---------------------------------------------------------------------------
-__global__ void k_repack_invert(const uint32_t* __restrict__ perm_old, int n, uint32_t* __restrict__ inv) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q < n) inv[perm_old[q]] = (uint32_t)q;
-}
-
-__global__ void k_repack_langevin(const float4* __restrict__ x_old, const float* __restrict__ v_old,
-                                  const float4* __restrict__ ref_old, const uint32_t* __restrict__ inv,
-                                  const uint32_t* __restrict__ perm_new, int n, float4* __restrict__ x_new,
-                                  float* __restrict__ v_new, float4* __restrict__ ref_new, float* __restrict__ mass_new,
-                                  int32_t* __restrict__ ctrl, int ctrl_keep) {
-  if (blockIdx.x == 0 && ctrl != nullptr && threadIdx.x < CHX_CTRL_WORDS) {
-    const int t = threadIdx.x;
-    const bool keep = ((ctrl_keep & 1) && (t == 8 || t == 9)) || ((ctrl_keep & 2) && (t == 10 || t == 11));
-    if (!keep) ctrl[t] = chx_ctrl_reset_word(t);
-  }
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const uint32_t q = inv[perm_new[p]];
-  const float4 x = x_old[q];
-  const float4 r = ref_old[q];
-  x_new[p] = make_float4(x.x, x.y, x.z, 0.f);  // (.w, the path length, starts over: the first launch refreshes the inner list)
-  v_new[3 * (size_t)p] = v_old[3 * (size_t)q];
-  v_new[3 * (size_t)p + 1] = v_old[3 * (size_t)q + 1];
-  v_new[3 * (size_t)p + 2] = v_old[3 * (size_t)q + 2];
-  ref_new[p] = r;
-  mass_new[p] = r.w;
-}
-
-extern "C" int chx_repack_langevin(const float* x4_old, const float* v_old, const float* ref4_old,
-                                   const uint32_t* perm_old, const uint32_t* perm_new, uint32_t* inv_ws, int32_t n,
-                                   float* x4_new, float* v_new, float* ref4_new, float* mass_new, int32_t* ctrl_reset,
-                                   int32_t ctrl_keep, chx_stream_t stream) {
-  CHX_REQUIRE(n >= 1, "n < 1");
-  CHX_REQUIRE(x4_old && v_old && ref4_old && perm_old && perm_new && inv_ws && x4_new && v_new && ref4_new && mass_new,
-              "null pointer");
-  CHX_REQUIRE(x4_old != x4_new && v_old != v_new && ref4_old != ref4_new, "outputs must not alias the inputs");
-  hipStream_t st = chx_stream(stream);
-  const unsigned blocks = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_repack_invert, dim3(blocks), dim3(256), 0, st, perm_old, n, inv_ws);
-  hipLaunchKernelGGL(k_repack_langevin, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(x4_old), v_old,
-                     reinterpret_cast<const float4*>(ref4_old), inv_ws, perm_new, n, reinterpret_cast<float4*>(x4_new),
-                     v_new, reinterpret_cast<float4*>(ref4_new), mass_new, ctrl_reset, (int)ctrl_keep);
-  return chx_check_launch("chx_repack_langevin");
 }
 
 // ---------------------------------------------------------------------------

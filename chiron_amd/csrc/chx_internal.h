@@ -10,11 +10,32 @@ struct CellGrid {
   float sx, sy, sz;  // nc / L
 };
 
+// Riders of the binning pass (all optional; the integrator's rebuild chain: one launch sequence instead of
+// copy / zero / pack launches of their own):
+//   xyz_copy  (n,3): a copy of the input positions (the list's private reference positions);
+//   v3 .. ref4: the Langevin state packed into the cell order the binning produces (what chx_pack_langevin does):
+//               x4[p] = (xyz[id], 0), v[p] = v3[id], mass_out[p] = mass[id], ref4[p] = ((ref3 ? ref3 : xyz)[id], mass[id])
+//               with id = sorted_ids[p]; on when x4 != NULL;
+//   ctrl:      what chx_ctrl_reset writes (ctrl_keep as in chx_pack_langevin).
+struct BinRiders {
+  float* xyz_copy;
+  const float* v3;
+  const float* mass;
+  const float* ref3;
+  float4* x4;
+  float* v;
+  float* mass_out;
+  float4* ref4;
+  int32_t* ctrl;
+  int ctrl_keep;
+};
 // Bin particles into cells (chx_neighbors.hip): cell_of, cell_start, sorted_ids [, xs4_out]; zeroes status.
+// cell_count must be all zero on entry (ncell + 1 words) and is all zero again when the chain has run.
 int chx_cell_prepare(const float* xyz, int n, chx_box_t box, float cutoff_plus_skin,
                      const int32_t* nc_h, int32_t* cell_of, int32_t* cell_count, int32_t* cell_start,
                      uint32_t* sorted_ids, int32_t* status, int status_len, CellGrid* g_out,
-                     hipStream_t st, float* xs4_out = nullptr);  // xs4_out: positions in cell order, .w = cell index
+                     hipStream_t st, float* xs4_out = nullptr,  // xs4_out: positions in cell order, .w = cell index
+                     const BinRiders* riders = nullptr);
 
 // ctrl != NULL: the kernel is part of a Langevin chunk and turns into a no-op
 // (setting ctrl[1]) when ctrl[0] says the skin check fired.
@@ -54,7 +75,7 @@ static inline int chx_lj_fl_blocks(int n, int g) { return (int)(((int64_t)n * g 
 // (i even ? x_even : x_odd) and writes the other buffer.  do_aoa == 0: force + kicks only.
 int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, int64_t step0,
                         int n_steps, int kicks_first, int do_aoa, hipStream_t st, int window = 0,
-                        int32_t* n_enqueued = nullptr, int watch_trigger = 0);
+                        int32_t* n_enqueued = nullptr);
 int chx_launch_lj_allpairs(const float* x, int stride, int n, chx_box_t box, float sigma,
                            float epsilon, float cutoff, float* f3, float* energy, double* ws,
                            int32_t* ctrl, hipStream_t st);

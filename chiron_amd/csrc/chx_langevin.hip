@@ -310,7 +310,7 @@ extern "C" int chx_langevin_fused_chunk(const chx_langevin_t* p, float* x_even, 
 }
 
 extern "C" int chx_langevin_fused_run(const chx_langevin_t* p, float* x_even, float* x_odd, int64_t step0,
-                                      int32_t n_steps, int32_t kicks_first, int32_t window, int32_t watch_trigger,
+                                      int32_t n_steps, int32_t kicks_first, int32_t window,
                                       int32_t* n_enqueued_out, chx_stream_t stream) {
   CHX_REQUIRE(p && n_enqueued_out, "null pointer");
   *n_enqueued_out = 0;
@@ -327,10 +327,10 @@ extern "C" int chx_langevin_fused_run(const chx_langevin_t* p, float* x_even, fl
   CHX_REQUIRE(step0 >= 0 && step0 + n_steps < (1ll << 31) - 1, "step index out of range");
   int rc = debug_check_ref4(p, chx_stream(stream), "chx_langevin_fused_run");
   if (rc != CHX_OK) return rc;
-  CHX_REQUIRE(!p->snap4 || (p->ref4 && p->skin > 0.f), "deferred rebuilds need ref4 and a skin");
+  CHX_REQUIRE(!p->snap4 || (p->ref4 && p->skin > 0.f), "snap4 (decoupled force list) needs ref4 and a skin");
   CHX_REQUIRE(!p->ev_log || p->ev_log_cap > 0, "ev_log without a capacity");
   rc = chx_launch_lj_steps(p, x_even, x_odd, step0, n_steps, kicks_first, 1, chx_stream(stream), window,
-                           n_enqueued_out, watch_trigger);
+                           n_enqueued_out);
   if (rc != CHX_OK) return rc;
   return chx_check_launch("chx_langevin_fused_run");
 }

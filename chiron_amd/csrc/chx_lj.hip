@@ -12,12 +12,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
-#include <sched.h>
-#include <sys/prctl.h>
-#include <time.h>
 
 #include "chx_common.h"
 #include "chx_internal.h"
+#include "chx_step.h"
 
 // ---------------------------------------------------------------------------
 // force list construction
@@ -187,13 +185,6 @@ extern "C" int64_t chx_lj_ws_count(int32_t n) {
 // ---------------------------------------------------------------------------
 // list kernel
 // ---------------------------------------------------------------------------
-struct LJParams {
-  float T;      // r2 <= T  <=>  d < cutoff
-  float sig2;   // sigma^2
-  float eps4;   // 4 eps
-  float eps24;  // 24 eps
-};
-
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one).  Give every
 // XCD a contiguous range of logical blocks: particles are in cell order, so each private 4 MB L2
 // then caches one spatial slab of positions instead of all of them.  Bijective for any grid size;
@@ -606,39 +597,6 @@ __global__ __launch_bounds__(256) void k_lj_fl(const float4* __restrict__ x4,
 // run because the skin check fired (INT_MAX when clear): every later launch of the
 // chunk is a no-op and the host rebuilds the list at exactly the reference's step.
 // ---------------------------------------------------------------------------
-struct StepArgs {
-  int n;
-  const float4* x_cur;
-  float* x_next;  // (n,4)
-  float* v;       // (n,3)
-  float4* ref4;   // written only at a reference rebuild event of the deferred scheme (snap4 set)
-  const float* mass;
-  const uint32_t* perm;
-  const uint32_t* fl;
-  const int32_t* deg;
-  int chunks;
-  Box3 box;
-  LJParams lj;
-  int wrap;
-  float T_half_skin;
-  float hdt, a, b, kT;
-  uint32_t k0, k1;
-  const float* noise;
-  long long noise_step0;
-  int32_t* ctrl;
-  // dynamically pruned inner list (NULL: always run on the full force list)
-  uint32_t* fli;
-  int32_t* degi;
-  int32_t* host_ctrl;   // host-mapped copy of the control block (chx_langevin_t::host_ctrl), or NULL
-  float T_inner;        // r2 <= T_inner: kept by the pruning pass  ((cutoff + inner skin)^2, padded up)
-  float half_inner;     // a particle whose path since the pass is longer than this invalidates the inner list
-  // deferred rebuilds (chx_langevin_t::snap4; nullptr = the halting scheme)
-  const float4* snap4;  // positions the force list was built from
-  float T_trigger;      // |x - snap|^2 > T_trigger: time to build the next list
-  int32_t* ev_log;
-  int ev_cap;
-};
-
 // operands of one particle's integrate work
 struct StepParticle {
   bool live;
@@ -842,11 +800,6 @@ __device__ __forceinline__ bool step_epilogue(const StepArgs& a, const StepParti
         if (d2s > a.T_half_skin) {
           atomicMin(&a.ctrl[3], (int)(step + 1));
           if (a.host_ctrl) __hip_atomic_store(&a.host_ctrl[3], (int)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        if (d2s > a.T_trigger) {
-          const int old = atomicMin(&a.ctrl[12], (int)(step + 1));
-          if (old > (int)(step + 1) && a.host_ctrl)  // (first raiser of this step: the host hears of it at once)
-            __hip_atomic_store(&a.host_ctrl[12], (int)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
       if ((HOT || a.fli) && path > a.half_inner) stale = true;
@@ -1110,7 +1063,7 @@ static int launch_lj_fl_g(const float4* x4, const uint32_t* fl, const int32_t* d
   return CHX_OK;
 }
 
-static LJParams make_lj(float sigma, float epsilon, float cutoff) {
+LJParams chx_make_lj(float sigma, float epsilon, float cutoff) {
   LJParams lj;
   lj.T = chx_cutoff_threshold_h(cutoff);
   lj.sig2 = sigma * sigma;
@@ -1125,7 +1078,7 @@ int chx_launch_lj_fl(const float* x4, const uint32_t* fl, const int32_t* deg, in
                      const chx_fl_select_t* select) {
   const float4* xx = reinterpret_cast<const float4*>(x4);
   const Box3 b3 = make_box3(box);
-  const LJParams lj = make_lj(sigma, epsilon, cutoff);
+  const LJParams lj = chx_make_lj(sigma, epsilon, cutoff);
   FlSelect sel = {nullptr, nullptr, nullptr, 0, 0};
   if (select) {
     sel.state = select->state;
@@ -1180,196 +1133,30 @@ static void launch_step_g(const StepArgs& a, long long step, int n_kicks, int do
   if (dbg) (void)hipStreamSynchronize(st);
 }
 
-// ---------------------------------------------------------------------------
-// How the launch window waits for the device when its queue is full.
-//   sleep (default): nanosleep between polls, with the thread's timer slack lowered once so that a 5 us nap is
-//                    not rounded up to the kernel's default 50 us; the queue refills in bursts (see the loop).
-//   spin  (CHX_POLL=spin): busy-wait with the architecture's relax hint -- one core at 100 % per rank.
-// Eight ranks on one host share its CPU quota with eight HIP helper threads.
-// ---------------------------------------------------------------------------
-struct PollPolicy {
-  long sleep_ns;  // 0: spin
-};
-static inline void cpu_relax() {
-#if defined(__x86_64__) || defined(__i386__)
-  __builtin_ia32_pause();
-#elif defined(__aarch64__)
-  asm volatile("yield" ::: "memory");
-#else
-  sched_yield();
-#endif
-}
-// (run-time switchable: chx_set_poll_sleep_ns -- the launch-regime probe of chiron_amd/_device.py spins for its
-// measurement, where a voluntary context switch of the launching thread can only be a collision with the runtime)
-// diagnostics of the sleeping window (chx_poll_stats): waits, naps, wake-ups that found the queue (nearly) empty, ns asleep
-static int64_t g_poll_stats[4] = {0, 0, 0, 0};
-extern "C" int chx_poll_stats(int64_t* out4_h, int32_t reset) {
-  if (out4_h)
-    for (int i = 0; i < 4; ++i) out4_h[i] = __atomic_load_n(&g_poll_stats[i], __ATOMIC_RELAXED);
-  if (reset)
-    for (int i = 0; i < 4; ++i) __atomic_store_n(&g_poll_stats[i], 0, __ATOMIC_RELAXED);
-  return CHX_OK;
-}
-static long g_poll_sleep_ns = [] {
-  const char* e = getenv("CHX_POLL");
-  if (e && (e[0] == 's' && e[1] == 'p')) return 0L;  // "spin"
-  const char* n = getenv("CHX_POLL_SLEEP_NS");
-  long v = n ? atol(n) : 5000L;
-  return v < 0 ? 0L : v;
-}();
-extern "C" int64_t chx_set_poll_sleep_ns(int64_t ns) {
-  const long old = __atomic_exchange_n(&g_poll_sleep_ns, (long)(ns < 0 ? 0 : ns), __ATOMIC_RELAXED);
-  return (int64_t)old;
-}
-static PollPolicy poll_policy() {
-  const long ns = __atomic_load_n(&g_poll_sleep_ns, __ATOMIC_RELAXED);
-  if (ns > 0) {
-    static thread_local bool slack_set = false;
-    if (!slack_set) {
-      (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);  // this thread only; 1 us
-      slack_set = true;
-    }
+// one fused step launch on the force list (the host loop lives in chx_launch_window.hip)
+int chx_launch_step(const StepArgs& a, int g, long long step, int n_kicks, int do_aoa, bool prune, int epoch, hipStream_t st) {
+  switch (g) {
+    case 1: launch_step_g<1>(a, step, n_kicks, do_aoa, prune, epoch, st); break;
+    case 2: launch_step_g<2>(a, step, n_kicks, do_aoa, prune, epoch, st); break;
+    case 4: launch_step_g<4>(a, step, n_kicks, do_aoa, prune, epoch, st); break;
+    case 8: launch_step_g<8>(a, step, n_kicks, do_aoa, prune, epoch, st); break;
+    case 16: launch_step_g<16>(a, step, n_kicks, do_aoa, prune, epoch, st); break;
+    case 32: launch_step_g<32>(a, step, n_kicks, do_aoa, prune, epoch, st); break;
+    case 64: launch_step_g<64>(a, step, n_kicks, do_aoa, prune, epoch, st); break;
+    default:
+      chx_set_error("chx_launch_step: unsupported g = %d", g);
+      return CHX_ERR_INVALID;
   }
-  return PollPolicy{ns};
+  return CHX_OK;
 }
 
-// launch i of the chunk reads (i even ? x_even : x_odd) and writes the other buffer
-// window > 0 (needs p->host_ctrl, readable by the host at the same address): launch step s only once fewer than
-// `window` earlier launches are still waiting to begin, and stop at the first step the halt word rules out;
-// *n_enqueued = launches made.  What the host polls is the copy of the control block every launch stores into
-// host_ctrl when it begins (word 0 = its step index, word 3 = the halt word).
-int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, int64_t step0,
-                        int n_steps, int kicks_first, int do_aoa, hipStream_t st, int window, int32_t* n_enqueued,
-                        int watch_trigger) {
-  if (n_enqueued) *n_enqueued = 0;
-  StepArgs a;
-  a.n = p->n;
-  a.v = p->v;
-  a.ref4 = reinterpret_cast<float4*>(p->ref4);
-  a.mass = p->mass;
-  a.perm = p->perm;
-  a.fl = p->fl;
-  a.deg = p->deg;
-  a.chunks = p->fl_chunks;
-  a.box = make_box3(p->box);
-  a.lj = make_lj(p->sigma, p->epsilon, p->cutoff);
-  a.wrap = p->wrap;
-  a.T_half_skin = chx_cutoff_threshold_h(p->skin * 0.5f);
-  a.hdt = p->half_dt;
-  a.a = p->a;
-  a.b = p->b;
-  a.kT = p->kT;
-  a.k0 = p->k0;
-  a.k1 = p->k1;
-  a.noise = p->noise;
-  a.noise_step0 = p->noise_step0;
-  a.ctrl = p->ctrl;
-  a.host_ctrl = p->fl != nullptr ? p->host_ctrl : nullptr;
-  const bool use_inner = p->fl_inner && p->deg_inner && p->prune_every > 0 && p->inner_skin > 0.f;  // (ref_inner4: unused)
-  a.fli = use_inner ? p->fl_inner : nullptr;
-  a.degi = use_inner ? p->deg_inner : nullptr;
-  {
-    // keep |r| < cutoff + inner_skin (padded up), distrust the table once a particle has moved
-    // inner_skin / 2 (padded down): the paddings dwarf fp32 rounding
-    const float rk = (p->cutoff + p->inner_skin) * 1.00001f;
-    const float hm = 0.5f * p->inner_skin * 0.9999f;
-    a.T_inner = rk * rk;
-    a.half_inner = hm;
+// one fused step launch without a neighbor list: all-pairs force + BAOAB (k_ap_step)
+void chx_launch_ap_step(const StepArgs& a, long long step, int n_kicks, int do_aoa, int use_cutoff, hipStream_t st) {
+  if (a.n <= 2048) {
+    hipLaunchKernelGGL((k_ap_step<64, true>), dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, st, a, step, n_kicks, do_aoa, use_cutoff);
+  } else {
+    hipLaunchKernelGGL((k_ap_step<16, false>), dim3((unsigned)((a.n + 15) / 16)), dim3(256), 0, st, a, step, n_kicks, do_aoa, use_cutoff);
   }
-  // deferred rebuilds need both position sets and the force-list path
-  const bool deferred = p->snap4 != nullptr && p->fl != nullptr && p->ref4 != nullptr;
-  a.snap4 = deferred ? reinterpret_cast<const float4*>(p->snap4) : nullptr;
-  a.T_trigger = (deferred && p->trigger_frac > 0.f) ? chx_cutoff_threshold_h(p->skin * 0.5f * p->trigger_frac) : INFINITY;
-  a.ev_log = deferred ? p->ev_log : nullptr;
-  a.ev_cap = deferred ? p->ev_log_cap : 0;
-  const bool throttle = window > 0 && a.host_ctrl != nullptr;
-  const bool watch = throttle && deferred && watch_trigger != 0;
-  const PollPolicy poll = poll_policy();
-  for (int i = 0; i < n_steps; ++i) {
-    if (throttle) {
-      const long long s = step0 + i;
-      const volatile int32_t* hc = a.host_ctrl;
-      if ((long long)hc[3] <= s) return CHX_OK;  // the skin check has fired: launches from s on would be no-ops
-      if (watch && hc[12] != 0x7FFFFFFF) return CHX_OK;  // the caller schedules the next force list from here
-      if (s - hc[0] > window) {
-        // The queue is full.  Spinning here keeps one core at 100 % per rank for nothing: the device needs
-        // ~5 us per queued launch.  The sleeping policy therefore lets the queue drain to `low` launches before
-        // it refills it in one burst (the host enqueues a launch in ~2.5 us, so the burst outruns the device),
-        // sleeping in between; the spinning policy (CHX_POLL=spin) refills launch by launch.
-        const int low = poll.sleep_ns > 0 ? window - window / 2 : window;
-        int last = hc[0];
-        bool timing = false;
-        timespec t0{};
-        if (poll.sleep_ns > 0) __atomic_fetch_add(&g_poll_stats[0], 1, __ATOMIC_RELAXED);
-        for (unsigned spins = 0;; ++spins) {
-          if ((long long)hc[3] <= s) return CHX_OK;
-          if (watch && hc[12] != 0x7FFFFFFF) return CHX_OK;
-          const int begun = hc[0];  // newest launch that has begun; begun+1 .. s-1 are still waiting
-          if (s - begun <= low) {
-            if (poll.sleep_ns > 0 && s - begun <= 2) __atomic_fetch_add(&g_poll_stats[2], 1, __ATOMIC_RELAXED);  // overslept: the queue is all but dry
-            break;
-          }
-          if (poll.sleep_ns > 0) {
-            const timespec nap = {0, poll.sleep_ns};
-            timespec n0, n1;
-            clock_gettime(CLOCK_MONOTONIC, &n0);
-            nanosleep(&nap, nullptr);
-            clock_gettime(CLOCK_MONOTONIC, &n1);
-            __atomic_fetch_add(&g_poll_stats[1], 1, __ATOMIC_RELAXED);  // (several launching threads may share the counters)
-            __atomic_fetch_add(&g_poll_stats[3], (n1.tv_sec - n0.tv_sec) * 1000000000LL + (n1.tv_nsec - n0.tv_nsec), __ATOMIC_RELAXED);
-          } else {
-            cpu_relax();
-          }
-          if (poll.sleep_ns > 0 || (spins & 0xFFFF) == 0xFFFF) {  // a stream that makes no progress for a minute is not coming back
-            timespec t1;
-            clock_gettime(CLOCK_MONOTONIC, &t1);
-            if (begun != last || !timing) last = begun, t0 = t1, timing = true;
-            else if (t1.tv_sec - t0.tv_sec > 60) {
-              chx_set_error("chx_langevin_fused_run: no step launch has begun for 60 s (step %lld, newest begun %d)", s, begun);
-              return CHX_ERR_LAUNCH;
-            }
-          }
-        }
-      }
-    }
-    if (n_enqueued) *n_enqueued = i + 1;
-    a.x_cur = reinterpret_cast<const float4*>((i & 1) ? x_odd : x_even);
-    a.x_next = (i & 1) ? x_even : x_odd;
-    const int nk = i == 0 ? kicks_first : 2;
-    if (p->fl == nullptr) {  // no neighbor list: all-pairs force + BAOAB in one launch
-      const int use_cutoff = p->cutoff >= 0.0f ? 1 : 0;
-      if (!use_cutoff) a.lj = make_lj(p->sigma, p->epsilon, 1.0f);
-      a.ref4 = nullptr;  // no skin check on these paths
-      a.snap4 = nullptr;
-      if (a.n <= 2048) {
-        hipLaunchKernelGGL((k_ap_step<64, true>), dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, st, a, (long long)(step0 + i), nk,
-                           do_aoa, use_cutoff);
-      } else {
-        hipLaunchKernelGGL((k_ap_step<16, false>), dim3((unsigned)((a.n + 15) / 16)), dim3(256), 0, st, a, (long long)(step0 + i), nk,
-                           do_aoa, use_cutoff);
-      }
-      continue;
-    }
-    // refreshes of the inner list sit at fixed step indices (counted from prune_phase), not at chunk
-    // boundaries: a trajectory does not depend on how its steps are batched into calls
-    // (the force-only launch that ends a run is included: it may be the first one after a rebuild)
-    const bool since = use_inner && (step0 + i >= p->prune_phase);
-    const bool prune = since && ((step0 + i - p->prune_phase) % p->prune_every == 0);
-    const int epoch = since ? (int)((step0 + i - p->prune_phase) / p->prune_every) : -1;
-    switch (p->g) {
-      case 1: launch_step_g<1>(a, step0 + i, nk, do_aoa, prune, epoch, st); break;
-      case 2: launch_step_g<2>(a, step0 + i, nk, do_aoa, prune, epoch, st); break;
-      case 4: launch_step_g<4>(a, step0 + i, nk, do_aoa, prune, epoch, st); break;
-      case 8: launch_step_g<8>(a, step0 + i, nk, do_aoa, prune, epoch, st); break;
-      case 16: launch_step_g<16>(a, step0 + i, nk, do_aoa, prune, epoch, st); break;
-      case 32: launch_step_g<32>(a, step0 + i, nk, do_aoa, prune, epoch, st); break;
-      case 64: launch_step_g<64>(a, step0 + i, nk, do_aoa, prune, epoch, st); break;
-      default:
-        chx_set_error("chx_launch_lj_steps: unsupported g = %d", p->g);
-        return CHX_ERR_INVALID;
-    }
-  }
-  return CHX_OK;
 }
 
 extern "C" int chx_lj_fl_energy_force(const float* x4, const uint32_t* fl, const int32_t* deg,
@@ -1468,7 +1255,7 @@ extern "C" int chx_lj_nl_energy_force(const float* xyz, const uint32_t* nl, cons
     return CHX_ERR_LAUNCH;
   }
   const Box3 b3 = make_box3(box);
-  const LJParams lj = make_lj(sigma, epsilon, cutoff);
+  const LJParams lj = chx_make_lj(sigma, epsilon, cutoff);
   const unsigned blocks = (unsigned)(((int64_t)n * CHX_WAVE + 255) / 256);  // <= chx_lj_ws_count(n)
   if (force_out && energy_out) {
     hipLaunchKernelGGL((k_lj_nl<true, true>), dim3(blocks), dim3(256), 0, st, xyz, nl, n_nbr, n, m, b3, lj, force_out, ws);
@@ -1563,7 +1350,7 @@ int chx_launch_lj_allpairs(const float* x, int stride, int n, chx_box_t box, flo
                            int32_t* ctrl, hipStream_t st) {
   const Box3 b3 = make_box3(box);
   const int use_cutoff = cutoff >= 0.0f ? 1 : 0;
-  const LJParams lj = make_lj(sigma, epsilon, use_cutoff ? cutoff : 1.0f);
+  const LJParams lj = chx_make_lj(sigma, epsilon, use_cutoff ? cutoff : 1.0f);
   const unsigned blocks = (unsigned)((n + 15) / 16);
   if (f3 && energy) {
     hipLaunchKernelGGL((k_lj_allpairs<true, true>), dim3(blocks), dim3(256), 0, st, x, stride, n, b3,

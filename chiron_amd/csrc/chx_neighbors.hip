@@ -113,18 +113,21 @@ __device__ __forceinline__ int cell_coord(float x, float L, float s, int nc) {
   return c >= nc ? nc - 1 : c;
 }
 
-__global__ void k_zero_i32(int32_t* __restrict__ p, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = 0;
-}
-
+// (cell_count is all zero on entry: the previous chain's k_cell_sort left it so -- no zeroing launch in front)
 __global__ void k_cell_assign(const float* __restrict__ xyz, int n, Box3 box, CellGrid g,
-                              int32_t* __restrict__ cell_of, int32_t* __restrict__ cell_count) {
+                              int32_t* __restrict__ cell_of, int32_t* __restrict__ cell_count,
+                              float* __restrict__ xyz_copy) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  int cx = cell_coord(xyz[3 * (size_t)i], box.lx, g.sx, g.ncx);
-  int cy = cell_coord(xyz[3 * (size_t)i + 1], box.ly, g.sy, g.ncy);
-  int cz = cell_coord(xyz[3 * (size_t)i + 2], box.lz, g.sz, g.ncz);
+  const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+  if (xyz_copy != nullptr) {  // the list's private copy of its reference positions rides along
+    xyz_copy[3 * (size_t)i] = x;
+    xyz_copy[3 * (size_t)i + 1] = y;
+    xyz_copy[3 * (size_t)i + 2] = z;
+  }
+  int cx = cell_coord(x, box.lx, g.sx, g.ncx);
+  int cy = cell_coord(y, box.ly, g.sy, g.ncy);
+  int cz = cell_coord(z, box.lz, g.sz, g.ncz);
   int c = (cz * g.ncy + cy) * g.ncx + cx;
   cell_of[i] = c;
   atomicAdd(&cell_count[c], 1);
@@ -137,10 +140,17 @@ __global__ void k_cell_assign(const float* __restrict__ xyz, int n, Box3 box, Ce
 // latency per trip -- took 30 us for the 27 000 cells of N = 262 144.)
 __global__ __launch_bounds__(1024) void k_cell_scan(int32_t* __restrict__ cell_count,
                                                     int32_t* __restrict__ cell_start, int ncell,
-                                                    int32_t* __restrict__ status, int status_len) {
+                                                    int32_t* __restrict__ status, int status_len,
+                                                    int32_t* __restrict__ ctrl, int ctrl_keep) {
   __shared__ int32_t wtot[16];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   if (t < status_len) status[t] = 0;  // (the build kernels behind this one accumulate into it: no memset launch)
+  // rider of the integrator's rebuild chain: the control-block reset of chx_ctrl_reset (ctrl_keep: chx_pack_langevin)
+  if (ctrl != nullptr && t >= 512 && t < 512 + CHX_CTRL_WORDS) {
+    const int w = t - 512;
+    const bool keep = ((ctrl_keep & 1) && (w == 8 || w == 9)) || ((ctrl_keep & 2) && (w == 10 || w == 11));
+    if (!keep) ctrl[w] = chx_ctrl_reset_word(w);
+  }
   const int seg = ((ncell + 15) / 16 + CHX_WAVE - 1) & ~(CHX_WAVE - 1);
   const int s0 = wv * seg < ncell ? wv * seg : ncell;
   const int s1 = s0 + seg < ncell ? s0 + seg : ncell;
@@ -205,23 +215,40 @@ __global__ void k_cell_scatter(const int32_t* __restrict__ cell_of, int n,
 #define CHX_SORT_PER_LANE 4
 // xs4 != NULL: also emit the positions in cell order, .w = the cell's packed grid coordinates as int bits (what the one-pass build reads:
 // its candidate loads are then coalesced and it needs no dependent cell_of[sorted_ids[w]] round trip).
-__device__ __forceinline__ void cell_emit_sorted(const float* __restrict__ xyz, float4* __restrict__ xs4, int at, uint32_t id, int c) {
-  xs4[at] = make_float4(xyz[3 * (size_t)id], xyz[3 * (size_t)id + 1], xyz[3 * (size_t)id + 2], __int_as_float(c));
+__device__ __forceinline__ void cell_emit_sorted(const float* __restrict__ xyz, float4* __restrict__ xs4, int at, uint32_t id, int c,
+                                                 const BinRiders& rd) {
+  const float x = xyz[3 * (size_t)id], y = xyz[3 * (size_t)id + 1], z = xyz[3 * (size_t)id + 2];
+  xs4[at] = make_float4(x, y, z, __int_as_float(c));
+  if (rd.x4 != nullptr) {  // the Langevin state in the new internal order (what chx_pack_langevin writes)
+    const float m = rd.mass[id];
+    rd.x4[at] = make_float4(x, y, z, 0.f);
+    rd.v[3 * (size_t)at] = rd.v3[3 * (size_t)id];
+    rd.v[3 * (size_t)at + 1] = rd.v3[3 * (size_t)id + 1];
+    rd.v[3 * (size_t)at + 2] = rd.v3[3 * (size_t)id + 2];
+    rd.mass_out[at] = m;
+    if (rd.ref4 != nullptr) {
+      if (rd.ref3 != nullptr) rd.ref4[at] = make_float4(rd.ref3[3 * (size_t)id], rd.ref3[3 * (size_t)id + 1], rd.ref3[3 * (size_t)id + 2], m);
+      else rd.ref4[at] = make_float4(x, y, z, m);
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void k_cell_sort(const int32_t* __restrict__ cell_start, int ncell,
                                                    uint32_t* __restrict__ sorted_ids, const float* __restrict__ xyz,
-                                                   float4* __restrict__ xs4, int ncx, int ncy) {
+                                                   float4* __restrict__ xs4, int ncx, int ncy,
+                                                   int32_t* __restrict__ cell_count, BinRiders rd) {
   const int lane = lane_id();
   const int ci = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (ci >= ncell) return;
+  // the scatter's cursors are done with: leave the counters zeroed for the next build (no zeroing launch there)
+  if (lane == 0) cell_count[ci] = 0;
   // what goes into xs4[].w: the cell's grid coordinates, 10 bits each (chx_cell_grid_h keeps every axis <= 1024 cells),
   // so the build kernel's rows need no integer divisions to find their 27 neighbours
   const int c = (ci % ncx) | (((ci / ncx) % ncy) << 10) | ((ci / (ncx * ncy)) << 20);
   const int s = cell_start[ci], e = cell_start[ci + 1];
   const int np = e - s;
   if (np <= 1) {
-    if (xs4 != nullptr && np == 1 && lane == 0) cell_emit_sorted(xyz, xs4, s, sorted_ids[s], c);
+    if (xs4 != nullptr && np == 1 && lane == 0) cell_emit_sorted(xyz, xs4, s, sorted_ids[s], c, rd);
     return;
   }
   if (np > CHX_WAVE * CHX_SORT_PER_LANE) {
@@ -238,7 +265,7 @@ __global__ __launch_bounds__(256) void k_cell_sort(const int32_t* __restrict__ c
     }
     if (xs4 != nullptr) {
       __threadfence_block();  // lane 0's stores, read back by the whole wavefront
-      for (int t = lane; t < np; t += CHX_WAVE) cell_emit_sorted(xyz, xs4, s + t, sorted_ids[s + t], c);
+      for (int t = lane; t < np; t += CHX_WAVE) cell_emit_sorted(xyz, xs4, s + t, sorted_ids[s + t], c, rd);
     }
     return;
   }
@@ -268,7 +295,7 @@ __global__ __launch_bounds__(256) void k_cell_sort(const int32_t* __restrict__ c
   for (int k = 0; k < CHX_SORT_PER_LANE; ++k) {
     if (k * CHX_WAVE + lane < np) {
       sorted_ids[s + rank[k]] = mine[k];
-      if (xs4 != nullptr) cell_emit_sorted(xyz, xs4, s + rank[k], mine[k], c);
+      if (xs4 != nullptr) cell_emit_sorted(xyz, xs4, s + rank[k], mine[k], c, rd);
     }
   }
 }
@@ -358,7 +385,7 @@ __global__ __launch_bounds__(256) void k_nl_build_cell(
 int chx_cell_prepare(const float* xyz, int n, chx_box_t box, float cutoff_plus_skin,
                      const int32_t* nc_h, int32_t* cell_of, int32_t* cell_count, int32_t* cell_start,
                      uint32_t* sorted_ids, int32_t* status, int status_len, CellGrid* g_out,
-                     hipStream_t st, float* xs4_out) {
+                     hipStream_t st, float* xs4_out, const BinRiders* riders) {
   CHX_REQUIRE(box.periodic && box.lx > 0 && box.ly > 0 && box.lz > 0, "periodic box required");
   CHX_REQUIRE(nc_h[0] >= 3 && nc_h[1] >= 3 && nc_h[2] >= 3, "need >= 3 cells per axis");
   // k_cell_sort packs a cell's grid coordinates into 10 bits per axis (xs4.w) and the build kernels decode them
@@ -377,16 +404,18 @@ int chx_cell_prepare(const float* xyz, int n, chx_box_t box, float cutoff_plus_s
   g.sx = (float)nc_h[0] / box.lx; g.sy = (float)nc_h[1] / box.ly; g.sz = (float)nc_h[2] / box.lz;
   *g_out = g;
   CHX_REQUIRE(status_len >= 0 && status_len <= 1024, "status block too long");
-  // (a kernel, not hipMemsetAsync: the runtime's fill path can block the calling thread on a signal of its own, and
-  // a rebuild inside the Langevin loop must not put the host to sleep -- DESIGN.md section 6)
-  hipLaunchKernelGGL(k_zero_i32, dim3((unsigned)((ncell + 1 + 255) / 256)), dim3(256), 0, st, cell_count, ncell + 1);
+  BinRiders rd = {};
+  if (riders) rd = *riders;
+  CHX_REQUIRE(!rd.x4 || (xs4_out && rd.v3 && rd.mass && rd.v && rd.mass_out), "pack rider: null pointer");
+  // (no zeroing launch: cell_count arrives zeroed -- the caller's allocation, then k_cell_sort of the previous chain)
   const unsigned pb = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_cell_assign, dim3(pb), dim3(256), 0, st, xyz, n, b3, g, cell_of, cell_count);
-  hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, st, cell_count, cell_start, ncell, status, status_len);
+  hipLaunchKernelGGL(k_cell_assign, dim3(pb), dim3(256), 0, st, xyz, n, b3, g, cell_of, cell_count, rd.xyz_copy);
+  hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, st, cell_count, cell_start, ncell, status, status_len, rd.ctrl,
+                     rd.ctrl_keep);
   hipLaunchKernelGGL(k_cell_scatter, dim3(pb), dim3(256), 0, st, cell_of, n, cell_start, cell_count,
                      sorted_ids);
   hipLaunchKernelGGL(k_cell_sort, dim3((unsigned)(((int64_t)ncell * CHX_WAVE + 255) / 256)), dim3(256), 0, st,
-                     cell_start, ncell, sorted_ids, xyz, reinterpret_cast<float4*>(xs4_out), g.ncx, g.ncy);
+                     cell_start, ncell, sorted_ids, xyz, reinterpret_cast<float4*>(xs4_out), g.ncx, g.ncy, cell_count, rd);
   return CHX_OK;
 }
 

@@ -35,23 +35,16 @@ log = logging.getLogger("chiron_amd")
 _INT_MAX = 2**31 - 1
 _TRACE_RUN = __import__("os").environ.get("CHX_TRACE_RUN") == "1"
 _SPECULATIVE_REBUILD = __import__("os").environ.get("CHX_SYNC_REBUILD") != "1"
-# Deferred rebuilds (include/chx.h: chx_langevin_t::snap4): the force list follows a schedule of its own, built on a
-# second stream ahead of time, and the reference's rebuild events are taken on the device.  OFF by default: measured in
-# round 3 (profiles/r03_deferred_rebuild.md) it breaks even at N = 32 768 and loses 3 % at N = 262 144 -- the build's
-# kernels are not hidden by the step kernels beside them, they share the chip with them, and the earlier switch costs
-# 28 % more builds.  CHX_DEFERRED_REBUILD=1 turns it on (a list, so that tests / A-B scripts can flip it in-process).
-_DEFERRED = [__import__("os").environ.get("CHX_DEFERRED_REBUILD", "0") == "1"]
 _EV_LOG_CAP = 4096
-# List carry-over: a short run() that continues the trajectory of the previous one (same integrator, same list object,
-# the very position tensor that run returned, untouched) starts on the force list its predecessor ended on instead of
-# building one -- the reference's run-start build (chiron/integrators.py:169) shrinks to "reference positions := x0" and
-# the caller's list is rebuilt from x0 only if somebody reads it.  CHX_LIST_CARRY=0 switches it off;
-# runs longer than CHX_LIST_CARRY_MAX_STEPS keep the build on entry: a carried list is older, so it runs out of its
-# guarantee sooner, and from ~100 steps on the renewals cost what the build would have (measured, round 3).
-_CARRY = [__import__("os").environ.get("CHX_LIST_CARRY", "1") != "0"]
-_CARRY_MAX_STEPS = int(__import__("os").environ.get("CHX_LIST_CARRY_MAX_STEPS", "64"))
-_PROFILE_DEFER = __import__("os").environ.get("CHX_PROFILE_DEFER") == "1"  # host seconds per phase -> integ.defer_profile
-
+# List carry-over (LangevinIntegrator(list_carry=...)): a short run() that continues the trajectory of the previous one
+# (same integrator, same list object, the very position tensor that run returned, untouched) starts on the force list its
+# predecessor ended on instead of building one -- the reference's run-start build (chiron/integrators.py:169) shrinks to
+# "reference positions := x0" and the caller's list is rebuilt from x0 only if somebody reads it.
+# The environment only supplies the DEFAULTS of the two constructor arguments (CHX_LIST_CARRY=0 / CHX_LIST_CARRY_MAX_STEPS):
+# runs longer than the limit keep the build on entry, because a carried list is older, runs out of its guarantee sooner,
+# and from ~100 steps on the renewals cost what the build would have (measured, round 3).
+_CARRY_DEFAULT = __import__("os").environ.get("CHX_LIST_CARRY", "1") != "0"
+_CARRY_MAX_STEPS_DEFAULT = int(__import__("os").environ.get("CHX_LIST_CARRY_MAX_STEPS", "64"))
 
 def langevin_constants(timestep, collision_rate):
     """(half_dt, a, b) in fp32 exactly as chiron/integrators.py:132-137 forms them."""
@@ -67,8 +60,12 @@ class LangevinIntegrator:
     """Langevin dynamics with the BAOAB splitting (Leimkuhler & Matthews 2013).
 
     Same constructor and ``run`` signature as chiron/integrators.py:25-105.
-    ``chunk_size`` (steps enqueued per launch batch) and ``launch_window`` (launches kept queued ahead of the
-    device) are the only additions; neither changes a trajectory.
+    Additions (none changes the steps a trajectory takes): ``chunk_size`` (steps enqueued per C call),
+    ``launch_window`` (launches kept queued ahead of the device) and ``list_carry`` / ``list_carry_max_steps``: a
+    ``run()`` of at most that many steps that continues the previous call's trajectory starts on the force list that
+    call ended on instead of building one; the caller's list object is then brought up to the reference's state (rebuilt
+    from the run's last reference positions) lazily, the first time one of its arrays is read.  ``list_carry=False``
+    builds on every entry, exactly like chiron/integrators.py:169.
     """
 
     def __init__(
@@ -81,6 +78,8 @@ class LangevinIntegrator:
         save_traj_in_memory: bool = False,
         chunk_size: int = 32,
         launch_window: Optional[int] = None,
+        list_carry: Optional[bool] = None,
+        list_carry_max_steps: Optional[int] = None,
     ) -> None:
         self.kB = unit.BOLTZMANN_CONSTANT_kB * unit.AVOGADRO_CONSTANT_NA
         self.timestep = timestep
@@ -94,11 +93,13 @@ class LangevinIntegrator:
         self.refresh_velocities = refresh_velocities
         self._move_iteration = 0
         self.chunk_size = max(1, int(chunk_size))
-        # step launches the host keeps queued ahead of the device on the neighbor-list path (0: the older scheme, two
-        # whole chunks ahead).  After the skin check fires everything still queued is dead time in front of the rebuild.
+        # step launches the host keeps queued ahead of the device on the neighbor-list path.  After the skin check fires
+        # everything still queued is dead time in front of the rebuild.
         if launch_window is None:
             launch_window = int(os.environ.get("CHX_LAUNCH_WINDOW", "12"))
-        self.launch_window = max(0, int(launch_window))
+        self.launch_window = max(1, int(launch_window))
+        self.list_carry = _CARRY_DEFAULT if list_carry is None else bool(list_carry)
+        self.list_carry_max_steps = _CARRY_MAX_STEPS_DEFAULT if list_carry_max_steps is None else max(0, int(list_carry_max_steps))
         self.n_rebuilds = 0  # neighbor-list rebuilds triggered inside the last run()
 
     # Per-process device resources a run() leaves on the integrator for the next one: host-mapped pinned slots the
@@ -144,24 +145,6 @@ class LangevinIntegrator:
         temperature = thermodynamic_state.temperature
         x0 = sampler_state.positions
 
-        # The list build of chiron/integrators.py:169 goes to the device FIRST: nothing below depends on it until the
-        # state is packed, and the first step launch has to wait for its ~80 us of device time -- every microsecond of
-        # host work done before it is enqueued is a microsecond the device idles at the start of a run() (measured,
-        # round 3: 35 us of a 276 us 20-step run).  A list this integrator has built before for the same box is
-        # rebuilt without waiting for its status block (validated after the first chunk, see _RunState._settle).
-        is_lj = isinstance(potential, LJPotential)
-        spec0 = False
-        carried = self._take_carry(sampler_state, nbr_list, number_of_steps) if is_lj else None
-        if carried is not None:
-            pass  # (no build: _RunState validates the carried force list against x0 on the device)
-        elif (nbr_list is not None and is_lj and _SPECULATIVE_REBUILD and isinstance(nbr_list, NeighborListNsqrd)
-                and getattr(nbr_list, "_box_token", None) is not None
-                and nbr_list._box_token is getattr(sampler_state, "_box_token", None)
-                and isinstance(x0, torch.Tensor) and x0.is_cuda and x0.dtype == torch.float32):
-            spec0 = nbr_list._build_speculative(x0.clone(), publish=False)  # (_RunState._load copies the status)
-
-        key = sampler_state.new_PRNG_key  # :124
-
         # unit arithmetic is slow Python (exact rationals) and the mass upload a host->device copy:
         # both are functions of objects that rarely change between run() calls
         cache = self.__dict__.setdefault("_run_cache", {})
@@ -177,7 +160,7 @@ class LangevinIntegrator:
         if cache.get(m_key, (None,))[0] is not mass._value:
             cache[m_key] = (mass._value, as_tensor(mass.value_in_unit_system(unit.md_unit_system)))
         mass_unitless = cache[m_key][1]
-        if len(cache[m_key]) < 3:  # lightest particle: the speed cap behind the deferred rebuilds' lead time
+        if len(cache[m_key]) < 3:  # lightest particle: the speed scale of the pruned inner list's skin
             cache[m_key] = cache[m_key] + (float(np.min(np.asarray(mass.value_in_unit_system(unit.md_unit_system)))),)
         self._m_min = cache[m_key][2]
         c_key = ("dt",)
@@ -185,13 +168,39 @@ class LangevinIntegrator:
             cache[c_key] = (id(self.timestep), id(self.collision_rate), langevin_constants(self.timestep, self.collision_rate),
                             self.timestep, self.collision_rate)
         half_dt, a, b = cache[c_key][2]
-
         # velocity (re)initialisation rules, :140-160
-        if (
-            self.refresh_velocities
-            or sampler_state._velocities is None
-            or sampler_state._velocities.shape[0] != sampler_state.positions.shape[0]
-        ):
+        needs_velocities = (self.refresh_velocities or sampler_state._velocities is None
+                            or sampler_state._velocities.shape[0] != sampler_state.positions.shape[0])
+
+        # The list build of chiron/integrators.py:169 goes to the device FIRST: nothing below depends on it until the
+        # first step is launched, and that launch has to wait for the build's ~65 us of device time -- every microsecond
+        # of host work done before it is enqueued is a microsecond the device idles at the start of a run().  A list this
+        # integrator has built before for the same box is rebuilt without waiting for its status block (validated after
+        # the first launches, see _RunState._settle), and the build's own launches copy x0 for the list, pack the state
+        # into the integrator's buffers and reset the control block (chx_build_riders_t) -- when the velocities are there
+        # already; a run that has to draw them first packs behind the build instead.
+        is_lj = isinstance(potential, LJPotential)
+        spec0 = packed0 = False
+        carried = self._take_carry(sampler_state, nbr_list, number_of_steps) if is_lj else None
+        if carried is not None:
+            pass  # (no build: _RunState validates the carried force list against x0 on the device)
+        elif (nbr_list is not None and is_lj and _SPECULATIVE_REBUILD and isinstance(nbr_list, NeighborListNsqrd)
+                and getattr(nbr_list, "_box_token", None) is not None
+                and nbr_list._box_token is getattr(sampler_state, "_box_token", None)
+                and isinstance(x0, torch.Tensor) and x0.is_cuda and x0.dtype == torch.float32):
+            pack = ctrl = None
+            v_in = None if needs_velocities else sampler_state.velocities
+            if (v_in is not None and v_in.is_cuda and v_in.dtype == torch.float32 and v_in.is_contiguous()
+                    and mass_unitless.device == x0.device):
+                buf = _RunState.device_buffers(self, x0.shape[0], x0.device)
+                pack = (v_in, mass_unitless, None, buf["x_a"], buf["v"], buf["mass"], buf["ref4"])
+                ctrl = buf["ctrl"]
+            spec0 = nbr_list._build_speculative(x0, publish=False, pack=pack, ctrl=ctrl, copy_positions=True)
+            packed0 = bool(spec0) and pack is not None
+
+        key = sampler_state.new_PRNG_key  # :124
+
+        if needs_velocities:
             sampler_state.velocities = initialize_velocities(temperature, potential.topology, key)
         v0 = sampler_state.velocities
 
@@ -229,7 +238,7 @@ class LangevinIntegrator:
                 chain_key, subkey = split(chain_key)
                 ops.jax_normal(subkey, (n_atoms, 3), out=noise[s_])
         st = _RunState(self, potential, nbr_list, x0, v0, mass_unitless, kbT_unitless, half_dt, a, b, key, noise, mode,
-                       carry=carried)
+                       carry=carried, packed=packed0 and mode == "fused")
         if spec0:
             st._unsettled = (nbr_list.ref_positions, v0, 0, 1)
 
@@ -274,7 +283,7 @@ class LangevinIntegrator:
             elapsed_step = last + base
             if done == stop and elapsed_step % self.report_interval == 0:  # :197-205
                 if has_reporter:
-                    # (deferred rebuilds: the list the steps run on is the one that is valid for these positions; the
+                    # (carried-over list: the list the steps run on is the one that is valid for these positions; the
                     # caller's list is brought up to the reference's last rebuild when the run ends)
                     self._report(st.positions_user(), potential, st.report_list(), last, self._move_iteration, elapsed_step)
                 if self.save_traj_in_memory:
@@ -311,9 +320,9 @@ class LangevinIntegrator:
         from .neighbors import NeighborListNsqrd
 
         offer, self._carry = self.__dict__.get("_carry"), None
-        if offer is None or not _CARRY[0] or _DEFERRED[0] or not (0 < number_of_steps <= _CARRY_MAX_STEPS):
+        if offer is None or not self.list_carry or not (0 < number_of_steps <= self.list_carry_max_steps):
             return None
-        if not (self.launch_window > 0 and _HOST_CTRL_IN_KERNEL[0] and isinstance(nbr_list, NeighborListNsqrd)):
+        if not isinstance(nbr_list, NeighborListNsqrd):
             return None
         if (hasattr(self, "reporter") and self.reporter is not None) or self.save_traj_in_memory:
             return None
@@ -332,14 +341,14 @@ class LangevinIntegrator:
                 return None
         max_n = getattr(owner, "_last_max_n", None)
         if max_n is None or max_n > 0.85 * int(nbr_list.n_max_neighbors):  # (the reference's growth rule needs to see
-            return None                                                   # every build's row counts: _setup_deferred)
+            return None                                                   # every build's row counts)
         return owner
 
     @property
     def rebuild_steps(self):
         """Step indices (within the last ``run``) at which the reference rebuilt its neighbor list
         (chiron/integrators.py:241-242), in order: the ones the host carried out and the ones the step kernel took
-        on the device (deferred rebuilds)."""
+        on the device (carried-over force list)."""
         host_events, dev_log = getattr(self, "_rebuild_log", ([], None))
         dev = [] if dev_log is None else [int(v) for v in dev_log.cpu().tolist()]
         return sorted(list(host_events) + dev)
@@ -365,29 +374,15 @@ class LangevinIntegrator:
         self.reporter.report(d)
 
 
-# how the host gets to see the control block of a chunk: copied by every step launch itself (default), or by a
-# publish launch behind the chunk (CHX_HOST_CTRL=0; a list so that A/B scripts can flip it in-process)
-_HOST_CTRL_IN_KERNEL = [os.environ.get("CHX_HOST_CTRL", "1") != "0"]
+class _Decoupled:
+    """Bookkeeping of a run whose force list was built from OTHER positions than the reference's reference positions
+    (list carry-over, ``_RunState._setup_carry``): the private list builders that take turns when the force list is
+    renewed, and the number of renewals."""
 
-
-class _Pending:
-    __slots__ = ("s0", "n", "parity0", "host", "event")
-
-
-class _Deferred:
-    """Schedule of the force list when it is decoupled from the reference's rebuilds (_RunState._setup_deferred).
-    phase 0: cruising (the launch loop watches the trigger word); 1: triggered, snapshot due at ``s_snap``;
-    2: the side stream is building, switch due at ``s_adopt``."""
-
-    __slots__ = ("lead", "adopt", "theta", "window", "side", "builders", "snap_event", "next", "phase", "s_snap", "s_adopt",
-                 "builder", "disabled", "n_side_builds", "n_adoptions", "n_internal_halts", "late_triggers")
+    __slots__ = ("builders", "next", "n_internal_halts")
 
     def __init__(self):
-        self.phase = 0
-        self.s_snap = self.s_adopt = -1
-        self.builder = None
-        self.disabled = False
-        self.n_side_builds = self.n_adoptions = self.n_internal_halts = self.late_triggers = 0
+        self.n_internal_halts = 0
 
 
 class _Slot:
@@ -405,8 +400,30 @@ class _Slot:
 class _RunState:
     """Device-resident state of one ``run`` call in the kernels' internal layout."""
 
+    @staticmethod
+    def device_buffers(integ, n: int, dev) -> dict:
+        """Device arrays kept on the integrator between run() calls (every launch of a run is enqueued behind the
+        previous run's on the same stream): the control block, the rebuild-event log, the energy workspace and the
+        Langevin state in internal order -- positions (two buffers: a step reads one and writes the other), velocities,
+        masses, reference positions.  Everything a run() returns is a fresh copy, never one of these."""
+        keep = integ.__dict__.setdefault("_dev_scratch", {})
+        sk = (n, str(dev))
+        if keep.get("key") != sk:
+            keep.clear()
+            keep["key"] = sk
+            f32 = dict(dtype=torch.float32, device=dev)
+            keep["ctrl"] = torch.zeros((CTRL_WORDS,), dtype=torch.int32, device=dev)
+            keep["ev_log"] = torch.zeros((_EV_LOG_CAP,), dtype=torch.int32, device=dev)
+            keep["ws"] = torch.empty((int(ops._lib.load().chx_lj_ws_count(n)),), dtype=torch.float64, device=dev)
+            keep["x_a"], keep["x_b"] = torch.empty((n, 4), **f32), torch.empty((n, 4), **f32)
+            keep["v"], keep["mass"], keep["ref4"] = torch.empty((n, 3), **f32), torch.empty((n,), **f32), torch.empty((n, 4), **f32)
+        return keep
+
     def __init__(self, integ, potential, nbr_list, x0, v0, mass, kT, half_dt, a, b, key: PRNGKey, noise, mode: str,
-                 carry=None):
+                 carry=None, packed: bool = False):
+        """``packed``: the list build that preceded this call (``NeighborListNsqrd._build_speculative`` with the pack
+        rider) has already written the state into the integrator's buffers in the new list's order and reset the
+        control block."""
         from .neighbors import NeighborListNsqrd, PairListNsqrd
 
         self.integ = integ
@@ -421,28 +438,20 @@ class _RunState:
         if self.noise is not None and (self.noise.dim() != 3 or tuple(self.noise.shape[1:]) != (self.n, 3)):
             raise ValueError(f"noise must have shape (steps, {self.n}, 3), got {tuple(self.noise.shape)}")
         self.mass_user = mass
-        # small device scratch kept on the integrator between run() calls (every launch of a run is
-        # enqueued behind the previous run's on the same stream; _load resets the control block)
-        keep = integ.__dict__.setdefault("_dev_scratch", {})
-        sk = (self.n, str(self.dev))
-        if keep.get("key") != sk:
-            keep.clear()
-            keep["key"] = sk
-            keep["ctrl"] = torch.zeros((CTRL_WORDS,), dtype=torch.int32, device=self.dev)
-            keep["ev_log"] = torch.zeros((_EV_LOG_CAP,), dtype=torch.int32, device=self.dev)
-            keep["ws"] = torch.empty((int(ops._lib.load().chx_lj_ws_count(self.n)),), dtype=torch.float64, device=self.dev)
+        keep = self.device_buffers(integ, self.n, self.dev)
         self.ctrl, self.ws, self.ev_log = keep["ctrl"], keep["ws"], keep["ev_log"]
         self.is_verlet = isinstance(nbr_list, NeighborListNsqrd)
         self.is_pairlist = isinstance(nbr_list, PairListNsqrd)
+        self.x_a, self.x_b, self.v, self.mass = keep["x_a"], keep["x_b"], keep["v"], keep["mass"]
+        self.ref4 = keep["ref4"] if self.is_verlet else None  # (the skin check's reference positions: Verlet lists only)
         self.n_rebuilds = 0
         self.kicks_next = 1  # the first step of a run applies only its leading kick
-        self.depth = 2  # chunks kept in flight ahead of the host
         self._defer = None
         self._final_state = None
         self.rebuild_log = ([], None)
         self._snap_is_ref = False
         self._host_events = []  # steps of the reference rebuilds the HOST carried out (halting scheme)
-        self._carried = carry if (carry is not None and mode == "fused" and self.is_verlet and self._windowed()) else None
+        self._carried = carry if (carry is not None and mode == "fused" and self.is_verlet) else None
         if self._carried is not None:
             self._setup_carry()
             # the reference's run-start build, as far as the steps can tell: reference positions := x0
@@ -450,80 +459,28 @@ class _RunState:
             ops.validate_snap(self.x_a, self.snap4, self.nbr_list._box_h, self._skin_now, 0, self.ctrl, self._gen.tensor)
             integ.n_carried_runs = getattr(integ, "n_carried_runs", 0) + 1
         else:
-            self._setup_deferred()
-            self._load(x0, v0)
+            self._load(x0, v0, packed=packed)
         if self.mode == "external":
             self._external_force()
 
-    # -- deferred rebuilds ---------------------------------------------------
-    def _setup_deferred(self):
-        """Decide whether this run decouples the force list's rebuild schedule from the reference's
-        (include/chx.h: chx_langevin_t::snap4; DESIGN.md section 4) and with which constants.
+    def pack_rider(self, v_user: torch.Tensor, ref_user=None):
+        """(v3, mass, ref3, x4_out, v_out, mass_out, ref4_out) for ``NeighborListNsqrd._build_speculative(pack=...)``:
+        the rebuild's own launches write the state into the buffers the steps read (no pack launch behind the build)."""
+        return (v_user, self.mass_user, ref_user, self.x_a, self.v, self.mass, self.ref4)
 
-        The schedule is a function of the trajectory alone: a particle farther than ``theta * skin/2`` from the
-        positions the force list was built from raises the trigger word at step t; the next list is built from the
-        positions of step ``t + lead`` (on a second stream) and takes over at step ``t + lead + adopt``.  ``lead``
-        covers the launches already queued when the host hears of the trigger, ``adopt`` the build's duration, and
-        ``theta`` leaves the fastest particles (5.5 sigma_v) enough room to reach neither skin/2 before the switch.
-        Where that room does not exist -- thin skins, long time steps, lists that last a few dozen steps -- or the
-        public list is close to its row capacity (the reference's growth rule, chiron/neighbors.py:709-727, looks at
-        every rebuild's row counts, which a deferred public rebuild never sees), the halting scheme stays."""
-        self._defer = None
-        if not (_DEFERRED[0] and self.mode == "fused" and self._windowed() and self.is_verlet):
-            return
-        lst = self.nbr_list
-        skin = float(lst.skin.value_in_unit_system(unit.md_unit_system))
-        lead = int(os.environ.get("CHX_DEFER_LEAD", "16"))
-        adopt = int(os.environ.get("CHX_DEFER_ADOPT", "32" if self.n < (1 << 17) else "48"))
-        if lead < 5 or adopt < 1 or skin <= 0.0:
-            return
-        m_min = getattr(self.integ, "_m_min", None)
-        if not m_min or m_min <= 0.0:
-            return
-        v_cap = 5.5 * float(np.sqrt(self.kT / m_min))           # nm / ps
-        margin = (lead + adopt + 4) * 2.0 * self.half_dt * v_cap  # nm travelled between trigger and switch, at most
-        theta = 1.0 - margin / (0.5 * skin)
-        env_theta = os.environ.get("CHX_DEFER_THETA")
-        if env_theta is not None:
-            theta = float(env_theta)
-        if not (0.25 <= theta < 1.0):
-            return
-        max_n = getattr(lst, "_last_max_n", None)
-        if max_n is None or max_n > 0.85 * int(lst.n_max_neighbors):
-            return
-        if lst._clone_builder() is None:
-            return
-        d = self._defer = _Deferred()
-        d.lead, d.adopt, d.theta = lead, adopt, float(theta)
-        d.window = max(1, min(self.integ.launch_window, lead - 4))
-        keep = self.integ.__dict__.setdefault("_defer_scratch", {})
-        if keep.get("key") != (self.n, str(self.dev)):
-            keep.clear()
-            keep["key"] = (self.n, str(self.dev))
-            keep["side"] = torch.cuda.Stream(device=self.dev)
-            keep["builders"] = [None, None]
-            keep["event"] = torch.cuda.Event()
-        d.side, d.builders, d.snap_event = keep["side"], keep["builders"], keep["event"]
-        d.next = 0
-
+    # -- list carry-over -------------------------------------------------------
     def _setup_carry(self):
         """List carry-over: the run starts on a force list built from OTHER positions than its reference positions
-        (x0), so it runs on the decoupled step kernel (``snap4`` set) -- with nothing scheduled ahead of time: no
-        trigger, no side builds.  When the force list runs out of its own guarantee the halt word fires and only the
-        force list is renewed (``_rebuild_internal``); the reference's rebuilds are events the step kernel takes itself."""
-        d = self._defer = _Deferred()
-        d.lead = d.adopt = 0
-        d.theta = 0.0  # (trigger_frac 0: chx_launch_lj_steps never raises the trigger word)
-        d.window = self.integ.launch_window
-        d.disabled = True
+        (x0), so it runs on the decoupled step kernel (``snap4`` set: include/chx.h).  When the force list runs out of
+        its own guarantee the halt word fires and only the force list is renewed (``_rebuild_internal``); the
+        reference's rebuilds are events the step kernel takes itself."""
+        d = self._defer = _Decoupled()
         keep = self.integ.__dict__.setdefault("_defer_scratch", {})
         if keep.get("key") != (self.n, str(self.dev)):
             keep.clear()
             keep["key"] = (self.n, str(self.dev))
-            keep["side"] = torch.cuda.Stream(device=self.dev)
             keep["builders"] = [None, None]
-            keep["event"] = torch.cuda.Event()
-        d.side, d.builders, d.snap_event = keep["side"], keep["builders"], keep["event"]
+        d.builders = keep["builders"]
         d.next = 1 if d.builders[0] is self._carried else 0  # (a rebuild must not write into the list being walked)
 
     def _next_builder(self):
@@ -539,104 +496,26 @@ class _RunState:
         d.next ^= 1
         return b
 
-    def _start_side_build(self, step: int):
-        """Launch ``step`` is next: snapshot the positions it will read and build the next force list from them on
-        the side stream.  Nothing waits: the step stream carries on with the current list."""
-        d = self._defer
-        if _PROFILE_DEFER:
-            import time as _t
-
-            t_p = _t.perf_counter()
-        x_snap = self.positions_user()  # (a fresh tensor, allocated and written on the step stream)
-        d.snap_event.record()
-        d.side.wait_event(d.snap_event)
-        b = self._next_builder()
-        with ops.launch_stream(d.side):
-            ok = b._build_speculative(x_snap, publish=True, stream=d.side)
-        if not ok:  # (cannot happen for a clone of a cell-built list)
-            raise RuntimeError("deferred rebuild: the side build did not take the one-pass cell path")
-        d.builder, d.phase, d.s_adopt = b, 2, step + d.adopt
-        d.n_side_builds += 1
-        if _PROFILE_DEFER:
-            prof = self.integ.__dict__.setdefault("defer_profile", {"snapshot_build_s": 0.0, "confirm_s": 0.0, "adopt_s": 0.0})
-            prof["snapshot_build_s"] += _t.perf_counter() - t_p
-
-    def _abandon_side_build(self):
-        """A build in flight that will not be used: nothing may free or reuse its arrays before it is done."""
-        d = self._defer
-        if d is not None and d.phase == 2 and d.builder is not None:
-            ev = getattr(d.builder, "_spec_event", None)
-            if ev is not None:
-                torch.cuda.current_stream().wait_event(ev)
-            d.builder._spec = None
-        if d is not None:
-            d.phase, d.builder = 0, None
-
-    def _adopt(self, step: int):
-        """Launch ``step`` is the first on the list the side stream has built: the state changes into that list's
-        order ON THE DEVICE (two small launches, no round trip through user order), the launch parameters are pointed
-        at the new list, and a new generation of launches begins.  The reference's bookkeeping -- reference positions,
-        booked events, counters -- travels with the state."""
-        d = self._defer
-        b = d.builder
-        if _PROFILE_DEFER:
-            import time as _t
-
-            t_p = _t.perf_counter()
-        b._confirm_build()  # (host wait for the side build -- long done; a capacity overflow rebuilds synchronously)
-        if _PROFILE_DEFER:
-            t_c = _t.perf_counter()
-        fl = b.force_list
-        keep = self.integ.__dict__["_defer_scratch"]
-        alt = keep.get("alt")
-        if alt is None or alt["v"].shape != self.v.shape:
-            alt = keep["alt"] = dict(v=torch.empty_like(self.v), ref4=torch.empty_like(self.ref4),
-                                     mass=torch.empty_like(self.mass),
-                                     inv=torch.empty((self.n,), dtype=torch.int32, device=self.dev))
-        x_src, x_dst = (self.x_a, self.x_b) if self.parity == 0 else (self.x_b, self.x_a)
-        ops.repack_langevin(x_src, self.v, self.ref4, self.perm, fl.perm, alt["inv"], x_dst, alt["v"], alt["ref4"], alt["mass"],
-                            ctrl=self.ctrl, ctrl_keep=3)
-        self.v, alt["v"] = alt["v"], self.v
-        self.ref4, alt["ref4"] = alt["ref4"], self.ref4
-        self.mass, alt["mass"] = alt["mass"], self.mass
-        self.parity ^= 1
-        self.fl, self.perm, self._owner = fl, fl.perm, b
-        self._close_generation()
-        self._open_generation(step)
-        p = self.params
-        p.g, p.fl_chunks = fl.g, fl.chunks
-        p.v, p.ref4, p.mass = self.v.data_ptr(), self.ref4.data_ptr(), self.mass.data_ptr()
-        p.perm, p.fl, p.deg = fl.perm.data_ptr(), fl.fl.data_ptr(), fl.deg.data_ptr()
-        p.host_ctrl = self._gen.tensor.data_ptr()
-        self._point_params_at_list(p, b, step)
-        self._snap_is_ref = False
-        d.phase, d.builder = 0, None
-        d.n_adoptions += 1
-        if _PROFILE_DEFER:
-            prof = self.integ.__dict__.setdefault("defer_profile", {"snapshot_build_s": 0.0, "confirm_s": 0.0, "adopt_s": 0.0})
-            prof["confirm_s"] += t_c - t_p
-            prof["adopt_s"] += _t.perf_counter() - t_c
-
     def _rebuild_internal(self, step: int, speculative: bool = True):
-        """The force list ran out of its guarantee before its successor was ready (the halt word fired at ``step``
-        on the list's own positions): build the next one here and now, from the halted state.  No reference event is
-        involved; one that is booked for this very step stays booked (``ctrl_keep``)."""
+        """The carried force list ran out of its guarantee (the halt word fired at ``step`` on the list's own
+        positions): build the next one here and now, from the halted state.  No reference event is involved; one that
+        is booked for this very step stays booked (``ctrl_keep``)."""
         d = self._defer
-        self._abandon_side_build()
         x_user, v_user = self.state_user()
         ref_user = self._unpack(self.ref4)
         b = self._next_builder()
         # (like the halting scheme's rebuild: enqueue the build, carry on, read its status block once it has arrived --
         # a builder that has built before for this box; its first build goes the synchronous way)
         spec = (speculative and _SPECULATIVE_REBUILD and b.__dict__.get("_perm") is not None
-                and b._build_speculative(x_user.clone(), publish=False))
+                and b._build_speculative(x_user.clone(), publish=False, pack=self.pack_rider(v_user, ref_user), ctrl=self.ctrl,
+                                         ctrl_keep=3))
         if not spec:
             b._adopt_positions = True
             try:
                 b.build(x_user.clone(), b.box_vectors)
             finally:
                 b._adopt_positions = False
-        self._load(x_user, v_user, step, owner=b, ref_user=ref_user, ctrl_keep=3)
+        self._load(x_user, v_user, step, owner=b, ref_user=ref_user, ctrl_keep=3, packed=bool(spec))
         self._unsettled = (x_user, v_user, step, self.kicks_next, b, ref_user) if spec else None
         self._snap_is_ref = False
         d.n_internal_halts += 1
@@ -687,12 +566,14 @@ class _RunState:
             return 0.0, 0
         return inner, every
 
-    def _load(self, x_user: torch.Tensor, v_user: torch.Tensor, step: int = 0, owner=None, ref_user=None, ctrl_keep: int = 0):
-        """(Re)pack user-order arrays into the internal order of the current force list.
+    def _load(self, x_user: torch.Tensor, v_user: torch.Tensor, step: int = 0, owner=None, ref_user=None, ctrl_keep: int = 0,
+              packed: bool = False):
+        """(Re)pack user-order arrays into the internal order of the current force list (``packed``: the build's own
+        launches have done that, and reset the control block) and point the launch parameters at that list.
 
         ``owner``: the list object whose force list the steps run on from here (default: the caller's ``nbr_list``;
-        with deferred rebuilds one of the integrator's private builders).  ``ref_user``: the reference's reference
-        positions when they are not the owner's (deferred rebuilds: the public list's positions travel separately).
+        on a carried-over list one of the integrator's private builders).  ``ref_user``: the reference's reference
+        positions when they are not the owner's (list carry-over: the public list's positions travel separately).
         ``ctrl_keep``: what survives the control-block reset (ops.pack_langevin)."""
         owner = self.nbr_list if owner is None else owner
         self._owner = owner
@@ -700,24 +581,13 @@ class _RunState:
         perm = self.fl.perm if self.fl is not None else None
         self.perm = perm
         n = self.n
-        # one launch: positions (current buffer when parity == 0), velocities, masses, reference positions
-        prev = (self.x_a, self.v, self.mass, self.ref4) if getattr(self, "x_a", None) is not None else None
-        # riders on the pack launch: the control-block reset and, after a speculative build, the copy of its status
-        # block to the host (one launch instead of three)
-        pub = owner._take_publish() if self.mode == "fused" and hasattr(owner, "_take_publish") else None
-        if ref_user is None and self.is_verlet:
-            ref_user = owner.ref_positions
-        self.x_a, self.v, self.mass, self.ref4 = ops.pack_langevin(
-            x_user, v_user, self.mass_user, ref_user if self.is_verlet else None, perm, self.is_verlet,
-            out=prev,  # a rebuild writes into the buffers of the previous load (the state was copied out first)
-            ctrl=self.ctrl, publish=pub, ctrl_keep=ctrl_keep)
-        if pub is not None:
-            owner._published(record=not self._windowed())  # (the launch window tells without an event)
-        if self.mode in ("fused", "pairs"):  # one launch per step, positions ping-pong between two buffers
-            if getattr(self, "x_b", None) is None:
-                self.x_b = torch.empty_like(self.x_a)  # fully written before it is read
-        else:
-            self.x_b = None
+        if not packed:
+            # one launch: positions (the buffer that is current at parity 0), velocities, masses, reference positions,
+            # written into the integrator's buffers (a rebuild has copied the state out first), and the control-block reset
+            if ref_user is None and self.is_verlet:
+                ref_user = owner.ref_positions
+            ops.pack_langevin(x_user, v_user, self.mass_user, ref_user if self.is_verlet else None, perm, self.is_verlet,
+                              out=(self.x_a, self.v, self.mass, self.ref4), ctrl=self.ctrl, ctrl_keep=ctrl_keep)
         self.parity = 0
         if self.mode == "external":
             self.f = torch.zeros((n, 3), dtype=torch.float32, device=self.dev)
@@ -734,7 +604,7 @@ class _RunState:
                 if sk is None or sk[0] is not self.nbr_list.skin:
                     sk = self._skin_md = (self.nbr_list.skin, float(self.nbr_list.skin.value_in_unit_system(unit.md_unit_system)))
                 skin = sk[1]
-        if self.mode == "fused" and self._windowed():
+        if self.mode == "fused":
             self._open_generation(step)
         p = LangevinParams()
         p.n = n
@@ -762,7 +632,7 @@ class _RunState:
         p.ctrl = self.ctrl.data_ptr()
         p.ws = self.ws.data_ptr()
         p.external_force = 1 if self.mode == "external" else 0
-        if self.mode == "fused" and self._windowed():
+        if self.mode == "fused":
             p.host_ctrl = self._gen.tensor.data_ptr()
         self._skin_now = skin
         self._point_params_at_list(p, owner, step)
@@ -770,7 +640,7 @@ class _RunState:
 
     def _point_params_at_list(self, p, owner, step: int):
         """The fields of the launch parameters that belong to the force list the steps run on: the pruned inner list
-        (restarted at ``step``) and, with deferred rebuilds, the positions the list was built from."""
+        (restarted at ``step``) and, on a carried-over list, the positions the list was built from."""
         n, skin = self.n, self._skin_now
         if self.fl is not None and self.is_verlet:
             inner, every = self._inner_list_settings(skin)
@@ -790,19 +660,15 @@ class _RunState:
             # the positions the force list was built from, in its own order: the build's cell-ordered copy
             scratch = getattr(owner, "_scratch", None)
             xs4 = scratch["arrays"][4] if scratch and scratch.get("arrays") is not None else None
-            if xs4 is None or xs4.shape[0] != n:  # (cannot happen: the scheme is only set up on cell-built lists)
-                raise RuntimeError("deferred rebuild: the force list's owner holds no cell-ordered positions")
+            if xs4 is None or xs4.shape[0] != n:  # (cannot happen: a list is only carried over from a cell build)
+                raise RuntimeError("list carry-over: the force list's owner holds no cell-ordered positions")
             self.snap4 = xs4
             p.snap4 = xs4.data_ptr()
-            p.trigger_frac = d.theta
             p.ev_log, p.ev_log_cap = self.ev_log.data_ptr(), _EV_LOG_CAP
             if owner is self.nbr_list:
                 self._snap_is_ref = True  # (a load on the public list: its positions are the reference's)
 
     # -- host-visible control block of the launch window ---------------------------------------
-    def _windowed(self) -> bool:
-        return self.integ.launch_window > 0 and _HOST_CTRL_IN_KERNEL[0]
-
     def _open_generation(self, step: int):
         """A *generation* = the step launches between two loads of the state (list rebuilds).  All of them copy
         the control block into one host-mapped slot (chx_langevin_t::host_ctrl), and no launch of another
@@ -890,18 +756,19 @@ class _RunState:
         if prof:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        self._abandon_side_build()  # (deferred scheme: a next list in the making is obsolete now)
         x_user, v_user = self.state_user()
-        spec = speculative and _SPECULATIVE_REBUILD and self.nbr_list._build_speculative(x_user, publish=False)
+        keep_events = 1 if self._defer is not None else 0
+        spec = speculative and _SPECULATIVE_REBUILD and self.nbr_list._build_speculative(
+            x_user, publish=False, pack=self.pack_rider(v_user), ctrl=self.ctrl, ctrl_keep=keep_events)
         if not spec:
             self.nbr_list._adopt_positions = True  # x_user is a fresh tensor nobody else holds
             try:
                 self.nbr_list.build(x_user, self.nbr_list.box_vectors)
             finally:
                 self.nbr_list._adopt_positions = False
-        # (deferred scheme: the device's event counters carry on; an event it booked for this very step is the one
+        # (carried-over list: the device's event counters carry on; an event it booked for this very step is the one
         # being carried out here)
-        self._load(x_user, v_user, step, ctrl_keep=1 if self._defer is not None else 0)
+        self._load(x_user, v_user, step, ctrl_keep=keep_events, packed=bool(spec))
         self._unsettled = (x_user, v_user, step, self.kicks_next) if spec else None
         self.n_rebuilds += 1
         self._host_events.append(step)
@@ -919,7 +786,7 @@ class _RunState:
         self._unsettled = None
         # (the list that was built: the caller's, or -- force list renewed on its own -- one of the private builders)
         owner = pend[4] if len(pend) > 4 else self.nbr_list
-        if self.mode == "fused" and self._windowed():
+        if self.mode == "fused":
             # the build's status block reaches the host with the pack launch of the load that followed the build;
             # a step launch of that load's generation has begun => it is there.  Otherwise wait for the stream.
             if int(self._gen.host[0]) < self._gen_step0:
@@ -934,7 +801,6 @@ class _RunState:
         if self._defer is not None:
             # whatever ran on the rejected list is void, its reference events included: the device log tells how many
             # rebuilds the reference had made BEFORE this step (the host-made ones are not in it)
-            self._abandon_side_build()
             self._restore_event_count(step)
         if len(pend) > 4:
             # (a renewal of the force list alone: the reference's bookkeeping was none of its business.  The counters are
@@ -960,100 +826,10 @@ class _RunState:
         fix = torch.tensor([len(kept), kept[-1] if kept else -1], dtype=torch.int32, device=self.dev)
         self.ctrl[8:10].copy_(fix)
 
-    # -- fused neighbor-list path -------------------------------------------
-    def _enqueue_fused(self, s0: int, n: int, do_aoa: int = 1) -> _Pending:
-        even, odd = (self.x_a, self.x_b) if self.parity == 0 else (self.x_b, self.x_a)
-        # pinned read-back slots are allocated once per integrator (pinning memory can take milliseconds);
-        # a slot is reused only after the chunk that owned it has been waited for
-        ring = getattr(self.integ, "_pinned_ring", None)
-        if ring is None or len(ring) < self.depth + 3:
-            ring = self.integ._pinned_ring = [torch.empty((CTRL_WORDS,), dtype=torch.int32, pin_memory=True)
-                                              for _ in range(self.depth + 3)]
-            self.integ._ring_next = 0
-        host = ring[self.integ._ring_next % len(ring)]
-        self.integ._ring_next += 1
-        # every launch of the chunk copies the control block into this slot when it starts (and a halting thread
-        # stores the halt word there directly): no separate publish launch per chunk
-        in_kernel = _HOST_CTRL_IN_KERNEL[0]
-        self.params.host_ctrl = host.data_ptr() if in_kernel else None
-        ops.langevin_fused_chunk(self.params, even, odd, s0, n, self.kicks_next, do_aoa)
-        if not in_kernel:
-            ops.publish(self.ctrl, host, CTRL_WORDS)  # the older scheme: one publish launch per chunk
-        rec = _Pending()
-        rec.s0, rec.n, rec.parity0 = s0, n, self.parity
-        if do_aoa:
-            self.parity ^= n & 1
-            self.kicks_next = 2
-        rec.host = host
-        rec.event = torch.cuda.Event()
-        rec.event.record()
-        return rec
-
-    def _bank_inner_stats(self):
-        """Fold the device counters (reset with every load) into the integrator's totals."""
-        self.integ.full_list_launches = getattr(self.integ, "full_list_launches", 0) + getattr(self, "_seen_full", 0)
-        self.integ.prune_passes = getattr(self.integ, "prune_passes", 0) + getattr(self, "_seen_prune", 0)
-        self._seen_full = self._seen_prune = 0
-
-    def _advance_fused(self, done: int, stop: int, final: bool = False) -> int:
-        chunk = self.integ.chunk_size
-        pending = collections.deque()
-        nxt = done
-        self._kick_rec = None
-        while done < stop:
-            while len(pending) < self.depth and nxt < stop:
-                c = min(chunk, stop - nxt)
-                pending.append(self._enqueue_fused(nxt, c))
-                nxt += c
-            if final and nxt == stop and self._kick_rec is None:
-                # every step of the run is enqueued: the trailing half-kick (chiron/integrators.py:195) rides right
-                # behind them instead of waiting for the host to read the last chunk's control block.  Like every
-                # launch of a chunk it turns into a no-op if the skin check fires first (step index = stop).
-                keep = self.kicks_next
-                self.kicks_next = 1
-                self._kick_rec = self._enqueue_fused(stop, 1, do_aoa=0)
-                self.kicks_next = keep
-            rec = pending.popleft()
-            if _TRACE_RUN:
-                import time as _t
-
-                t_w = _t.perf_counter()
-                rec.event.synchronize()
-                t_w = _t.perf_counter() - t_w
-                if t_w > 5e-3:
-                    print(f"[chx trace] waited {1e3*t_w:.1f} ms for chunk s0={rec.s0} n={rec.n} halt={int(rec.host[3])} "
-                          f"pending={len(pending)}", flush=True)
-            else:
-                rec.event.synchronize()
-            if not self._settle():
-                # the speculative rebuild before this chunk overflowed a capacity: redo from its step
-                pending.clear()
-                self._kick_rec = None
-                done = nxt = self._unsettled_step
-                continue
-            halt = int(rec.host[3])
-            self._seen_full, self._seen_prune = int(rec.host[6]), int(rec.host[7])  # counters since the last load
-            if halt <= rec.s0 + rec.n:
-                # skin check fired while producing x_halt: steps < halt ran, everything queued behind is a
-                # no-op; the rebuild is enqueued behind those launches, nothing waits for them
-                pending.clear()
-                self._kick_rec = None  # (it ran as a no-op)
-                self.parity = rec.parity0 ^ ((halt - rec.s0) & 1)
-                self._bank_inner_stats()
-                self._rebuild(halt, speculative=True)
-                done = nxt = halt
-            else:
-                done = rec.s0 + rec.n
-        if not self._settle():  # a rebuild at the very last step: nothing ran on its list yet
-            self._kick_rec = None
-        return done
-
     # -- fused neighbor-list path, bounded launch queue --------------------------------------------
-    def _enqueue_window(self, s0: int, n: int, watch: bool = False) -> int:
+    def _enqueue_window(self, s0: int, n: int) -> int:
         even, odd = (self.x_a, self.x_b) if self.parity == 0 else (self.x_b, self.x_a)
-        d = self._defer
-        window = self.integ.launch_window if d is None or d.disabled else d.window
-        sent = ops.langevin_fused_run(self.params, even, odd, s0, n, self.kicks_next, window, watch)
+        sent = ops.langevin_fused_run(self.params, even, odd, s0, n, self.kicks_next, max(1, int(self.integ.launch_window)))
         if sent:
             self.parity ^= sent & 1
             self.kicks_next = 2
@@ -1079,43 +855,16 @@ class _RunState:
     def _advance_windowed(self, done: int, stop: int, final: bool = False) -> int:
         """Steps [done, stop) through ``chx_langevin_fused_run``: the C loop keeps at most ``launch_window``
         launches queued ahead of the device and returns early when it sees the halt word, so a rebuild starts
-        behind a handful of no-op launches instead of up to two chunks of them.
-
-        With deferred rebuilds (``self._defer``) the halt word is the exception: the loop also returns when it sees
-        the trigger word, and this method then takes the snapshot for the next force list at step trigger + lead and
-        switches to that list at snapshot + adopt -- both fixed by the trajectory, whatever the chunking."""
+        behind a handful of no-op launches."""
         chunk = self.integ.chunk_size
         enq = done  # first step not enqueued yet
         self._kick_sent = False
-        d = self._defer
         while True:
             while enq < stop:
-                limit, watch = stop, False
-                if d is not None:
-                    if d.phase == 1:
-                        if enq >= d.s_snap:
-                            self._start_side_build(enq)
-                            continue
-                        limit = min(limit, d.s_snap)
-                    elif d.phase == 2:
-                        if enq >= d.s_adopt:
-                            self._adopt(enq)
-                            continue
-                        limit = min(limit, d.s_adopt)
-                    else:
-                        watch = not d.disabled
-                c = min(chunk, limit - enq)
-                sent = self._enqueue_window(enq, c, watch)
+                c = min(chunk, stop - enq)
+                sent = self._enqueue_window(enq, c)
                 enq += sent
                 if sent < c:
-                    if watch and int(self._gen.host[3]) > enq and int(self._gen.host[12]) != _INT_MAX:
-                        # a particle has used up theta of the force list's skin: schedule the next list
-                        trig = int(self._gen.host[12])
-                        d.phase, d.s_snap = 1, trig + d.lead
-                        if d.s_snap < enq:  # (the host was held up for longer than `lead` launches)
-                            d.s_snap = enq
-                            d.late_triggers += 1
-                        continue
                     break  # the launch loop saw the halt word
                 pend = getattr(self, "_unsettled", None)
                 if pend is not None and enq - pend[2] >= max(chunk, self.integ.launch_window + 1):
@@ -1158,20 +907,19 @@ class _RunState:
         return stop
 
     def report_list(self):
-        """The list a report's energy is evaluated with (chiron/integrators.py:278): the caller's list in the halting
-        scheme -- rebuilt at every reference event, as in the reference -- and the force list's owner otherwise (same
-        cutoff, same skin, valid for the current positions)."""
+        """The list a report's energy is evaluated with (chiron/integrators.py:278): the caller's list -- rebuilt at
+        every reference event, as in the reference -- or, on a carried-over force list, that list's owner (same cutoff,
+        same skin, valid for the current positions)."""
         return self.nbr_list if self._defer is None else self._owner
 
     def finish(self):
-        """End of ``run()`` (the stream is idle): the reference's rebuild count, and -- deferred scheme -- the public
+        """End of ``run()`` (the stream is idle): the reference's rebuild count, and -- carried-over list -- the public
         list, which the reference would have rebuilt at every event.  Here it is rebuilt once, from the positions of
         the LAST event, and only when somebody reads it (NeighborListNsqrd._defer_build)."""
         self.rebuild_log = (list(self._host_events), None)
         d = self._defer
         if d is None:
             return
-        self._abandon_side_build()
         gen = getattr(self, "_gen", None)
         n_dev = int(gen.host[8]) if gen is not None else 0
         # list carry-over: the run-start build (chiron/integrators.py:169) was not carried out on the caller's list
@@ -1192,14 +940,13 @@ class _RunState:
             self.nbr_list._defer_build(ref_user if ref_user is not None else self._unpack(self.ref4), n_dev + missed)
         else:  # the host's own rebuild was the latest: the public list is current
             self.nbr_list.n_builds += n_dev + missed
-        for k in ("n_side_builds", "n_adoptions", "n_internal_halts", "late_triggers"):
-            setattr(self.integ, k, getattr(self.integ, k, 0) + getattr(d, k))
+        self.integ.n_internal_halts = getattr(self.integ, "n_internal_halts", 0) + d.n_internal_halts
 
     def offer_carry(self, state) -> None:
         """End of ``run()``: leave the force list the run ended on, and the identity of the positions it returned, for
         a next ``run()`` that continues from exactly there (``LangevinIntegrator._take_carry``)."""
         self.integ._carry = None
-        if not (_CARRY[0] and self.mode == "fused" and self.is_verlet and self._windowed() and self.fl is not None
+        if not (self.integ.list_carry and self.mode == "fused" and self.is_verlet and self.fl is not None
                 and getattr(self, "_unsettled", None) is None):
             return
         lst, x = self.nbr_list, state.positions
@@ -1207,10 +954,10 @@ class _RunState:
                                  box_token=getattr(lst, "_box_token", None))
 
     def _halt_rebuild(self, halt: int, speculative: bool):
-        """The halt word fired at ``halt``.  Halting scheme: that IS the reference's rebuild.  Deferred scheme: the
-        force list has run out of its own guarantee; when its positions are still the reference's (no switch since
-        the last rebuild the host made) the two coincide and the reference's rebuild is carried out here, otherwise
-        only the force list is renewed."""
+        """The halt word fired at ``halt``.  Ordinarily that IS the reference's rebuild.  On a carried-over force
+        list it means the list has run out of its own guarantee; when its positions are the reference's (the host has
+        rebuilt since the run began) the two coincide and the reference's rebuild is carried out here, otherwise only
+        the force list is renewed."""
         if self._defer is None or self._snap_is_ref:
             self._rebuild(halt, speculative=speculative)
         else:
@@ -1229,9 +976,7 @@ class _RunState:
         """Run steps [done, stop); returns the new step count (== stop).  ``final``: ``stop`` is the end of the
         run (the fused path then enqueues the trailing kick behind the last chunk, see ``final_kick``)."""
         if self.mode == "fused":
-            if self._windowed():
-                return self._advance_windowed(done, stop, final)
-            return self._advance_fused(done, stop, final)
+            return self._advance_windowed(done, stop, final)
         if self.mode == "pairs":
             # all-pairs force + BAOAB in one launch per step (k_ap_step); no skin check exists on this
             # path (PairListNsqrd.check only looks at N), so nothing halts and nothing is read back
@@ -1256,7 +1001,7 @@ class _RunState:
 
     def final_kick(self, n_steps: int):
         """Trailing half-kick of the last step (chiron/integrators.py:195)."""
-        if self.mode == "fused" and self._windowed():
+        if self.mode == "fused":
             if not getattr(self, "_kick_sent", False):
                 self._enqueue_kick(n_steps)
             if int(self._gen.host[3]) <= n_steps:
@@ -1270,24 +1015,6 @@ class _RunState:
             self._kick_sent = False
             self._close_generation()
             self._retire_all()  # (_enqueue_kick waited for the stream)
-        elif self.mode == "fused":
-            rec = getattr(self, "_kick_rec", None)  # already in flight behind the last chunk?
-            self._kick_rec = None
-            if rec is None:
-                self.kicks_next = 1
-                rec = self._enqueue_fused(n_steps, 1, do_aoa=0)
-            rec.event.synchronize()
-            if int(rec.host[3]) <= n_steps:
-                # The skin check fired in the run's very last step and its word reached the host only with this
-                # launch's own copy of the control block (see chx_langevin_t::host_ctrl): the kick above ran as a
-                # no-op.  Rebuild exactly as _advance_fused does for a halt at the end of a chunk, then kick.
-                self._bank_inner_stats()
-                self._rebuild(n_steps, speculative=False)
-                self.kicks_next = 1
-                rec = self._enqueue_fused(n_steps, 1, do_aoa=0)
-                rec.event.synchronize()
-            self._seen_full, self._seen_prune = int(rec.host[6]), int(rec.host[7])
-            self._bank_inner_stats()
         elif self.mode == "pairs":
             even, odd = (self.x_a, self.x_b) if self.parity == 0 else (self.x_b, self.x_a)
             ops.langevin_fused_chunk(self.params, even, odd, n_steps, 1, 1, 0)  # force + one kick, positions stay

@@ -322,26 +322,30 @@ class NeighborListNsqrd(PairsBase):
         self.n_builds += 1
 
     # -- unsynchronised rebuild (integrator only) ---------------------------------------------
-    def _build_speculative(self, positions: torch.Tensor, publish: bool = True, stream=None) -> bool:
+    def _build_speculative(self, positions: torch.Tensor, publish: bool = True, pack=None, ctrl=None, ctrl_keep: int = 0,
+                           copy_positions: bool = False) -> bool:
         """Rebuild from ``positions`` WITHOUT waiting for the build's status block.
 
         The reference synchronises inside every build (chiron/neighbors.py:709) to decide whether
         ``n_max_neighbors`` has to grow.  Between two rebuilds of one trajectory it almost never does,
-        so the integrator enqueues the build, publishes the status block to pinned host memory and
-        carries on with the arrays it got; ``_confirm_build`` reads the block later (by then it has
+        so the integrator enqueues the build -- whose last launch stores the status block in pinned host memory --
+        and carries on with the arrays it got; ``_confirm_build`` reads the block later (by then it has
         long arrived) and, if a capacity did overflow, redoes the build through ``build()`` -- the
         caller then discards whatever it ran on the speculative list.  The overflowing kernel bounds
         its writes, so a speculative list is always safe to walk.  Returns False (nothing enqueued)
-        when this fast path does not apply.  ``publish=False``: the caller copies the status block to the host
-        itself (``_take_publish`` / ``_published``: the integrator lets its pack launch do it).  ``stream``: the
-        ``torch.cuda.Stream`` the kernels are being launched on when that is not torch's current one
-        (``ops.launch_stream``): the completion event is recorded there.
+        when this fast path does not apply.  ``publish=True`` records an event behind the build that
+        ``_confirm_build`` waits for; with ``publish=False`` the caller has its own way of knowing that the build has run
+        (the integrator: a later launch has begun) and confirms with ``_confirm_build(wait=False)``.
+        Riders of the build's launches (include/chx.h: chx_build_riders_t): ``pack`` = (v3, mass, ref3 or None, x4_out,
+        v_out, mass_out, ref4_out) -- the Langevin state packed into the new internal order; ``ctrl`` / ``ctrl_keep`` --
+        the integrator's control block, reset; ``copy_positions`` -- ``positions`` is somebody else's tensor: the list
+        keeps a copy made by the binning launch instead of the tensor itself.
         """
         if not (self.is_built and self._use_cell_list and getattr(self, "_box_h", None) is not None
                 and self._box_h.periodic and getattr(self, "_fl_geo", None) is not None and self._cs_md is not None):
             return False
         n = positions.shape[0]
-        if self._fl_geo[0] != n or positions.dtype != torch.float32 or not positions.is_cuda:
+        if self._fl_geo[0] != n or positions.dtype != torch.float32 or not positions.is_cuda or not positions.is_contiguous():
             return False
         cs = self._cs_md
         ncell, nc = ops.cell_grid(self._box_h, cs, n)
@@ -352,28 +356,26 @@ class NeighborListNsqrd(PairsBase):
         if getattr(self, "_scratch", None) is None:
             self._scratch = {}
         self.__dict__.pop("_deferred", None)  # (a rebuild still pending from an earlier run() is superseded)
-        self.ref_positions = positions  # a fresh tensor nobody else holds
-        self._cutoff_and_skin = cs
-        nl, first, n_nbr, sorted_ids, fl, deg, status = ops.nl_build_cell_fl(
-            positions, self._box_h, cs, m, ncell, nc, g, chunks, self._scratch,
-            # (a build on a side stream shares the chip with the step launches: fewer workgroups; on the step stream
-            # itself -- a renewal of the force list at a halt -- nothing else runs: one wavefront per row)
-            max_blocks=getattr(self, "_bg_blocks", 0) if stream is not None else 0)
         host = getattr(self, "_status_host", None)
         if host is None:
             host = self._status_host = torch.empty((8,), dtype=torch.int32, pin_memory=True)
+        riders = {"publish": host}
+        if copy_positions:
+            riders["copy"] = torch.empty_like(positions)
+        if pack is not None:
+            riders["pack"] = pack
+        if ctrl is not None:
+            riders["ctrl"], riders["ctrl_keep"] = ctrl, ctrl_keep
+        self.ref_positions = riders["copy"] if copy_positions else positions  # (else: a fresh tensor nobody else holds)
+        self._cutoff_and_skin = cs
+        nl, first, n_nbr, sorted_ids, fl, deg, status = ops.nl_build_cell_fl(
+            positions, self._box_h, cs, m, ncell, nc, g, chunks, self._scratch, riders=riders)
         ev = getattr(self, "_spec_event", None)
         if ev is None:
             ev = self._spec_event = torch.cuda.Event()  # (one event, recorded again by every speculative build)
         if publish:
-            ops.publish(status, host, 8)
-            if stream is not None:
-                ev.record(stream)
-            else:
-                ev.record()
-            self._pending_publish, self._spec_recorded = None, True
-        else:
-            self._pending_publish = (status, host)
+            ev.record()
+        self._spec_recorded = bool(publish)
         self._spec = (ev, m, g, chunks)
         self._nl, self._nl_mask, self._first = nl, None, first
         self.n_neighbors = n_nbr
@@ -381,20 +383,6 @@ class NeighborListNsqrd(PairsBase):
         self._force_list = ops.ForceList.prebuilt(fl, deg, sorted_ids, g, chunks, getattr(self, "_last_maxdeg", 0))
         self.n_builds += 1
         return True
-
-    def _take_publish(self):
-        """(status block, pinned host block) a ``_build_speculative(publish=False)`` left for the caller to copy,
-        or None; the caller reports back with ``_published`` once the copying launch is enqueued."""
-        pub = getattr(self, "_pending_publish", None)
-        self._pending_publish = None
-        return pub
-
-    def _published(self, record: bool = True):
-        """``record=False``: the caller has its own way of knowing when the copy has landed and will confirm with
-        ``_confirm_build(wait=False)``."""
-        self._spec_recorded = record
-        if record:
-            self._spec_event.record()
 
     def _confirm_build(self, wait: bool = True) -> bool:
         """True if the last ``_build_speculative`` produced the list ``build()`` would have; otherwise
@@ -404,11 +392,6 @@ class NeighborListNsqrd(PairsBase):
             return True
         self._spec = None
         ev, m, g, chunks = spec
-        pub = self._take_publish()
-        if pub is not None:  # nobody copied the status block yet
-            ops.publish(pub[0], pub[1], 8)
-            ev.record()
-            self._spec_recorded, wait = True, True
         if wait:
             if getattr(self, "_spec_recorded", True):
                 ev.synchronize()
@@ -432,11 +415,11 @@ class NeighborListNsqrd(PairsBase):
             self._adopt_positions = False
         return False
 
-    # -- deferred rebuilds (integrator only) ----------------------------------------------------
+    # -- list carry-over (integrator only) ------------------------------------------------------
     def _clone_builder(self):
         """A private list builder with this list's geometry and capacities and buffers of its own: what the integrator
-        builds its NEXT force list with, on another stream, while the steps still run on the current one
-        (``LangevinIntegrator``: deferred rebuilds).  None when the one-pass cell build does not apply."""
+        renews a carried-over force list with (``LangevinIntegrator``: list carry-over) without touching the caller's
+        list.  None when the one-pass cell build does not apply."""
         if not (self.is_built and self._use_cell_list and getattr(self, "_box_h", None) is not None and self._box_h.periodic
                 and getattr(self, "_fl_geo", None) is not None and self._cs_md is not None
                 and (self.__dict__.get("_perm") is not None or "_deferred" in self.__dict__)):
@@ -454,8 +437,6 @@ class NeighborListNsqrd(PairsBase):
         b._scratch = None
         b.n_builds = 0
         b.is_built = True
-        # background builds: workgroups of the wave-per-particle kernel in flight (0 = one wavefront per row)
-        b._bg_blocks = int(os.environ.get("CHX_DEFER_BG_BLOCKS", "512"))
         return b
 
     def _detach_for_carry(self):
@@ -494,11 +475,18 @@ class NeighborListNsqrd(PairsBase):
     def __getattr__(self, name):
         # (reached only when normal lookup fails: costs nothing on the hot path)
         if name in NeighborListNsqrd._DEFERRED_ATTRS and "_deferred" in self.__dict__:
-            pos = self.__dict__.pop("_deferred")
+            pos = self.__dict__["_deferred"]
             builds = self.n_builds
             self._adopt_positions = True  # a tensor nobody else holds
             try:
+                # (build() drops the `_deferred` entry itself; if it raises -- out of memory, a box that no longer
+                # fits -- the pending positions are put back, so a later read tries again instead of finding a list
+                # that claims to be built and holds no arrays)
                 self.build(pos, self.box_vectors)
+            except BaseException:
+                self.__dict__["_deferred"] = pos
+                self.n_builds = builds
+                raise
             finally:
                 self._adopt_positions = False
             self.n_builds = builds  # already counted by _defer_build
@@ -572,7 +560,7 @@ class NeighborListNsqrd(PairsBase):
                 new._scratch = None  # kernel work arrays are not part of the list
             elif k in ("_spec", "_status_host"):
                 setattr(new, k, None)
-            elif k in ("_spec_event", "_pending_publish"):
+            elif k in ("_spec_event",):
                 continue  # plumbing of the speculative rebuild: the copy starts without any
             elif isinstance(v, torch.Tensor):
                 setattr(new, k, v.clone())

@@ -43,36 +43,9 @@ _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _CUR_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
 
 
-_stream_tls = __import__("threading").local()
-
-
-class launch_stream:
-    """``with launch_stream(side): ...``: kernels launched by this module inside the block go to ``side`` (a
-    ``torch.cuda.Stream``) while torch's CURRENT stream -- and with it the stream the caching allocator books new
-    tensors on -- stays what it was.  The deferred list rebuild uses it: the arrays of the next force list are
-    allocated on the step stream, where they will live, and only the build's kernels run on the side stream (events
-    order the two); allocating under ``torch.cuda.stream(side)`` instead would tie the blocks to the side stream's
-    pool and let them be reused there while the step stream still reads them."""
-
-    def __init__(self, stream):
-        self.raw = None if stream is None else C.c_void_p(stream.cuda_stream)
-
-    def __enter__(self):
-        self.prev = getattr(_stream_tls, "raw", None)
-        _stream_tls.raw = self.raw
-        return self
-
-    def __exit__(self, *exc):
-        _stream_tls.raw = self.prev
-        return False
-
-
 def _stream():
     """torch's current HIP stream as a raw handle.  ``torch.cuda.current_stream()`` builds a Python
     Stream object (~9 us, a dozen times per integrator call); the raw accessor is a plain C call."""
-    over = getattr(_stream_tls, "raw", None)
-    if over is not None:
-        return over
     if _RAW_STREAM is not None and _CUR_DEVICE is not None:
         return C.c_void_p(_RAW_STREAM(_CUR_DEVICE()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -167,7 +140,7 @@ def nl_build_cell(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: int, 
     mask = torch.empty((n, m), dtype=torch.int32, device=dev)
     n_nbr = torch.empty((n,), dtype=torch.int32, device=dev)
     cell_of = torch.empty((n,), dtype=torch.int32, device=dev)
-    cell_count = torch.empty((ncell + 1,), dtype=torch.int32, device=dev)
+    cell_count = torch.zeros((ncell + 1,), dtype=torch.int32, device=dev)  # (zero on entry: include/chx.h)
     cell_start = torch.empty((ncell + 1,), dtype=torch.int32, device=dev)
     sorted_ids = torch.empty((n,), dtype=torch.int32, device=dev)
     status = torch.empty((4,), dtype=torch.int32, device=dev)
@@ -182,12 +155,16 @@ def nl_build_cell(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: int, 
 
 
 def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: int, ncell: int, nc, g: int, chunks: int,
-                     scratch: Optional[dict] = None, max_blocks: int = 0):
+                     scratch: Optional[dict] = None, riders: Optional[dict] = None):
     """One-pass cell build (half-list rows without padding + force list).
 
-    Returns (nl_rows, first, n_nbr, sorted_ids, fl, deg, status8); nothing is synchronised here.
+    Returns (nl_rows, first, n_nbr, sorted_ids, fl, deg, status); nothing is synchronised here.
     ``scratch`` (a dict the caller keeps between builds) lets the kernel-internal work arrays be
     reused: the arrays that become part of the list are always fresh.
+    ``riders`` (include/chx.h: chx_build_riders_t): ``copy`` -- a (n,3) tensor that receives a copy of ``xyz``;
+    ``pack`` -- (v3, mass, ref3 or None, x4_out, v_out, mass_out, ref4_out or None): the Langevin state packed into
+    the new internal order; ``ctrl`` / ``ctrl_keep`` -- control block to reset; ``publish`` -- pinned host tensor that
+    receives status[0..7] from the chain's last launch.
     """
     xyz = _f32(xyz)
     _require_device(xyz)
@@ -205,17 +182,42 @@ def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: in
         cell_of, cell_count, cell_start, status, xs4 = scratch["arrays"]
     else:
         cell_of = torch.empty((n,), **i32)
-        cell_count = torch.empty((ncell + 1,), **i32)
+        cell_count = torch.zeros((ncell + 1,), **i32)  # (zero on entry, left zeroed by every build: include/chx.h)
         cell_start = torch.empty((ncell + 1,), **i32)
-        status = torch.empty((8,), **i32)
+        status = torch.empty((_lib.BUILD_STATUS_WORDS,), **i32)
         xs4 = torch.empty((n, 4), dtype=torch.float32, device=dev)
         if scratch is not None:
             scratch["key"], scratch["arrays"] = key, (cell_of, cell_count, cell_start, status, xs4)
+    rd = None
+    if riders:
+        rd = _lib.BuildRiders()
+        cp = riders.get("copy")
+        if cp is not None:
+            _require_device(cp)
+            rd.xyz_copy_out = cp.data_ptr()
+        pk = riders.get("pack")
+        if pk is not None:
+            v3, mass, ref3, x4_out, v_out, mass_out, ref4_out = pk
+            _require_device(v3, mass, x4_out, v_out, mass_out)
+            if v3.dtype != torch.float32 or not v3.is_contiguous() or mass.dtype != torch.float32 or not mass.is_contiguous():
+                raise _lib.ChxError("pack rider: velocities and masses must be contiguous fp32 tensors")
+            rd.v3, rd.mass = v3.data_ptr(), mass.data_ptr()
+            rd.ref3 = ref3.data_ptr() if ref3 is not None else None
+            rd.x4_out, rd.v_out, rd.mass_out = x4_out.data_ptr(), v_out.data_ptr(), mass_out.data_ptr()
+            rd.ref4_out = ref4_out.data_ptr() if ref4_out is not None else None
+        ct = riders.get("ctrl")
+        if ct is not None:
+            rd.ctrl_reset, rd.ctrl_keep = ct.data_ptr(), int(riders.get("ctrl_keep", 0))
+        pb = riders.get("publish")
+        if pb is not None:
+            if not pb.is_pinned():
+                raise _lib.ChxError("publish needs a pinned (host-mapped) destination tensor")
+            rd.publish_host_dst8 = pb.data_ptr()
     check(
         _lib.load().chx_nl_build_cell_fl(
             _ptr(xyz), n, m, box, C.c_float(cutoff_plus_skin), nc, _ptr(cell_of), _ptr(cell_count), _ptr(cell_start),
             _ptr(sorted_ids), _ptr(status), _ptr(nl), _ptr(first), _ptr(n_nbr), g, chunks, _ptr(fl), _ptr(deg),
-            _ptr(xs4), int(max_blocks), _stream(),
+            _ptr(xs4), C.byref(rd) if rd is not None else None, _stream(),
         ),
         "chx_nl_build_cell_fl",
     )
@@ -258,18 +260,6 @@ def pack_langevin(x3, v3, mass, ref3, perm, want_ref: bool, out=None, ctrl=None,
         "chx_pack_langevin",
     )
     return x4, v, m_int, ref4
-
-
-def repack_langevin(x4_old, v_old, ref4_old, perm_old, perm_new, inv_ws, x4_new, v_new, ref4_new, mass_new, ctrl=None,
-                    ctrl_keep: int = 0) -> None:
-    """Internal order of the current force list -> order of the next one, on the device (include/chx.h)."""
-    _require_device(x4_old, v_old, ref4_old, perm_old, perm_new, inv_ws, x4_new, v_new, ref4_new, mass_new)
-    check(
-        _lib.load().chx_repack_langevin(_ptr(x4_old), _ptr(v_old), _ptr(ref4_old), _ptr(perm_old), _ptr(perm_new), _ptr(inv_ws),
-                                        x4_old.shape[0], _ptr(x4_new), _ptr(v_new), _ptr(ref4_new), _ptr(mass_new), _ptr(ctrl),
-                                        int(ctrl_keep), _stream()),
-        "chx_repack_langevin",
-    )
 
 
 def validate_snap(x4, snap4, box: Box, skin: float, step: int, ctrl, host_ctrl=None) -> None:
@@ -548,17 +538,16 @@ _tls = __import__("threading").local()  # (MultiStateSampler may drive two repli
 
 
 def langevin_fused_run(params: LangevinParams, x_even: torch.Tensor, x_odd: torch.Tensor, step0: int,
-                       n_steps: int, kicks_first: int, window: int, watch_trigger: bool = False) -> int:
+                       n_steps: int, kicks_first: int, window: int) -> int:
     """``langevin_fused_chunk`` with a bounded launch queue (include/chx.h: chx_langevin_fused_run).
-    Returns the number of launches made: fewer than ``n_steps`` when the host saw the halt word (or, with
-    ``watch_trigger``, the trigger word of the deferred rebuilds)."""
+    Returns the number of launches made: fewer than ``n_steps`` when the host saw the halt word."""
     _require_device(x_even, x_odd)
     out = getattr(_tls, "n_enqueued", None)
     if out is None:
         out = _tls.n_enqueued = C.c_int32(0)
     check(
         _lib.load().chx_langevin_fused_run(C.byref(params), _ptr(x_even), _ptr(x_odd), step0, n_steps, kicks_first, window,
-                                           1 if watch_trigger else 0, C.byref(out), _stream()),
+                                           C.byref(out), _stream()),
         "chx_langevin_fused_run",
     )
     return out.value

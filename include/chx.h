@@ -46,8 +46,15 @@ typedef void* chx_stream_t;
  *      force-list chunk are interleaved over the lanes (see "Force list" below); chx_mc_t::state is
  *      CHX_MC_STATE_WORDS = 16 ints (two slots) and chx_mc_t::energy 4 doubles -- the struct's SIZE did not change,
  *      so chx_sizeof_mc_t() cannot tell; this version number does.  Added in round 3 without touching any existing
- *      signature: chx_repack_langevin, chx_validate_snap, chx_set_poll_sleep_ns, chx_poll_stats. */
-#define CHX_ABI_VERSION 2
+ *      signature: chx_repack_langevin, chx_validate_snap, chx_set_poll_sleep_ns, chx_poll_stats.
+ *   3  round 4 -- INCOMPATIBLE with 2: the deferred-rebuild scheme of round 3 is gone (measured: no gain,
+ *      profiles/r04_internal_skin.md) and with it chx_repack_langevin, chx_langevin_t::trigger_frac (ev_log_cap
+ *      moves into its slot, so the struct's SIZE does not change: this version number tells), control word [12], the
+ *      watch_trigger argument of
+ *      chx_langevin_fused_run and the max_blocks argument of chx_nl_build_cell_fl.  Both cell builds now expect
+ *      cell_count zeroed on entry and leave it zeroed; chx_nl_build_cell_fl takes a chx_build_riders_t* (copy of the
+ *      positions, packed Langevin state, control-block reset, status publish: see there). */
+#define CHX_ABI_VERSION 3
 
 /* high bit of a force-list entry: neighbor has the HIGHER original particle id */
 #define CHX_FL_HI 0x80000000u
@@ -101,8 +108,8 @@ int64_t chx_cell_grid_h(chx_box_t box, float cutoff_plus_skin, int32_t n, int32_
 
 /* New (the reference has no cell list, chiron/neighbors.py:529-530): O(N)
  * build that produces BIT-IDENTICAL nl/nl_mask/n_nbr to chx_nl_build_nsq.
- * Workspace (caller-allocated): cell_of[n] i32, cell_count[ncell+1] i32,
- * cell_start[ncell+1] i32, sorted_ids[n] u32 (out: particle ids in cell
+ * Workspace (caller-allocated): cell_of[n] i32, cell_count[ncell+1] i32 (ALL ZERO on
+ * entry, all zero again afterwards: ABI 3), cell_start[ncell+1] i32, sorted_ids[n] u32 (out: particle ids in cell
  * order, ascending id inside a cell), status[4] i32 (out: [0]!=0 -> a row
  * overflowed the on-chip candidate buffer, results invalid, rebuild with
  * chx_nl_build_nsq). */
@@ -119,20 +126,37 @@ int chx_nl_build_cell(const float* xyz, int32_t n, int32_t m, chx_box_t box, flo
  * (chiron/neighbors.py:603-620) and mask (:623) if somebody reads them, and (b) the
  * force list (layout above, internal order = sorted_ids, g lanes, capacity chunks*4*g
  * entries per particle, unused slots = 0) and deg_out[n] are emitted directly, in scan
- * order, without atomics.  status8 (out): [0] != 0 -> a half row overflowed the on-chip
- * candidate buffer (nothing valid); [1] max n_nbr; [2] number of rows with n_nbr == m
- * (the reference's growth trigger, :709); [3] max full degree; [4] rows whose full
- * degree exceeded the capacity (force list invalid, retry with more chunks).
+ * order, without atomics.
+ * Workspace contracts (ABI 3): cell_count (ncell + 1 ints) must be ALL ZERO on entry -- the caller zeroes it once, when
+ * it allocates it -- and is all zero again when the launches have run (the chain needs no zeroing launch of its own);
+ * status8 (out): [0] != 0 -> a half row overflowed the on-chip candidate buffer (nothing valid); [1] max n_nbr;
+ * [2] number of rows with n_nbr == m (the reference's growth trigger, :709); [3] max full degree; [4] rows whose full
+ * degree exceeded the capacity (force list invalid, retry with more chunks); [5], [6] reserved; [7] scratch.
  * xs4_out (n,4): the positions in internal (cell) order, x4[p] = xyz[sorted_ids[p]].
- * max_blocks > 0: a BACKGROUND build -- the wave-per-particle kernel is launched with at most that many workgroups
- * (of four wavefronts) and walks the rows grid-stride, so that step kernels running on another stream beside it keep
- * most of the wave slots (deferred rebuilds, chx_langevin_t::snap4); 0: one wavefront per row.  Same bits either way. */
+ * riders (may be NULL; every member optional): work that rides on the chain's launches instead of costing launches of
+ * its own when the build is a list rebuild inside the Langevin loop (chiron/integrators.py:239-242) -- six launches
+ * where round 3 used ten. */
+typedef struct {
+  float* xyz_copy_out;        /* (n,3): a copy of xyz (the list's private reference positions, chiron/neighbors.py:671) */
+  /* the Langevin state packed into the new internal order, exactly what chx_pack_langevin(xyz, v3, mass, ref3 or xyz,
+   * sorted_ids, ...) would write afterwards; on when x4_out != NULL (then v3, mass, v_out, mass_out are required): */
+  const float* v3;            /* (n,3) velocities, user order */
+  const float* mass;          /* (n)   masses, user order */
+  const float* ref3;          /* (n,3) reference positions of the skin check, user order; NULL = xyz itself */
+  float* x4_out;              /* (n,4) (xyz, 0) */
+  float* v_out;               /* (n,3) */
+  float* mass_out;            /* (n) */
+  float* ref4_out;            /* (n,4) (ref xyz, mass), or NULL */
+  int32_t* ctrl_reset;        /* CHX_CTRL_WORDS ints: what chx_ctrl_reset writes ... */
+  int32_t ctrl_keep;          /* ... except the words chx_pack_langevin's ctrl_keep names */
+  int32_t* publish_host_dst8; /* HOST-MAPPED: status[0..7] is stored there (system scope) by the chain's last launch */
+} chx_build_riders_t;
 int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_box_t box, float cutoff_plus_skin,
                          const int32_t* nc_h, int32_t* cell_of, int32_t* cell_count,
                          int32_t* cell_start, uint32_t* sorted_ids, int32_t* status8,
                          uint32_t* nl_rows_out, uint32_t* first_out, int32_t* n_nbr_out, int32_t g,
                          int32_t chunks, uint32_t* fl_out, int32_t* deg_out, float* xs4_out,
-                         int32_t max_blocks, chx_stream_t stream);
+                         const chx_build_riders_t* riders, chx_stream_t stream);
 int chx_nl_finish_padding(uint32_t* nl_inout, const uint32_t* first, const int32_t* n_nbr, int32_t n,
                           int32_t m, int32_t* nl_mask_out, chx_stream_t stream);
 
@@ -196,23 +220,13 @@ int chx_unpack_langevin(const float* x4, const float* v, const uint32_t* perm, i
  * ref4[p] = (ref3[perm[p]], mass_out[p]) (ref4_out may be NULL).  Optional riders, so that a list rebuild inside
  * the Langevin loop costs one launch here instead of three: ctrl_reset != NULL -> what chx_ctrl_reset writes, except
  * that ctrl_keep bit 0 leaves the reference-event counters ([8], [9]) and bit 1 the event words ([10], [11]) as they
- * are (deferred rebuilds: a repack into the order of the next force list must not lose a rebuild event that is booked
- * for the very next launch, nor the count so far);
+ * are (carried-over force list: a renewal of the list must not lose a rebuild event that is booked for the very next
+ * launch, nor the count so far);
  * publish_src8 / publish_host_dst8 != NULL -> what chx_publish(src, dst, 8) does (the build's status block). */
 int chx_pack_langevin(const float* x3, const float* v3, const float* mass, const float* ref3,
                       const uint32_t* perm, int32_t n, float* x4_out, float* v_out, float* mass_out,
                       float* ref4_out, int32_t* ctrl_reset, int32_t ctrl_keep, const int32_t* publish_src8,
                       int32_t* publish_host_dst8, chx_stream_t stream);
-
-/* Deferred rebuilds (chx_langevin_t::snap4): move the Langevin state from the internal order of the current force
- * list (perm_old: internal -> original id) into the order of the next one (perm_new) on the device, two launches and
- * no round trip through user order: x4_new[p] = (x4_old[q].xyz, 0), v_new[p] = v_old[q], ref4_new[p] = ref4_old[q]
- * (xyz and the mass in .w), mass_new[p] = ref4_old[q].w with q = the old internal index of original id perm_new[p].
- * inv_ws: n uint32 of scratch.  The outputs must not alias the inputs.  ctrl_reset / ctrl_keep: as in
- * chx_pack_langevin. */
-int chx_repack_langevin(const float* x4_old, const float* v_old, const float* ref4_old, const uint32_t* perm_old,
-                        const uint32_t* perm_new, uint32_t* inv_ws, int32_t n, float* x4_new, float* v_new,
-                        float* ref4_new, float* mass_new, int32_t* ctrl_reset, int32_t ctrl_keep, chx_stream_t stream);
 
 /* List carry-over (LangevinIntegrator: a run() that starts on the force list its predecessor ended on instead of
  * building one): halt launch `step` -- ctrl[3] = min(ctrl[3], step), and the same into host_ctrl[3] when given -- unless
@@ -279,7 +293,7 @@ typedef struct {
   float* f;              /* (n,3) forces, internal order               (in/out) */
   float* ref4;           /* (n,4) positions at the reference's last list build, or NULL (no list); .w = the particle's
                             MASS (chx_pack_langevin writes it: the fused step kernel takes the mass from here).  Read
-                            only, except with snap4 set (deferred rebuilds, below): the kernel then rewrites the xyz
+                            only, except with snap4 set (decoupled force list, below): the kernel then rewrites the xyz
                             of every row at a reference rebuild event */
   const float* mass;     /* (n)   masses, internal order */
   const uint32_t* perm;  /* (n)   internal -> original id (RNG counter / noise row), NULL = identity */
@@ -298,10 +312,9 @@ typedef struct {
                             must not run (INT32_MAX when clear), [4],[5] inner list stale (by step
                             parity; the value is the refresh epoch the word was raised in),
                             [6] launches that ran on the full list, [7] refreshes of the inner list;
-                            deferred rebuilds (snap4 set): [8] reference rebuild events since the block was reset,
+                            decoupled force list (snap4 set): [8] reference rebuild events since the block was reset,
                             [9] step of the last one, [10],[11] event words by step parity (value s = "launch s starts
-                            with a reference rebuild"; -1 when clear), [12] first step whose positions passed the
-                            trigger distance from snap4 (INT32_MAX when clear), [13..15] reserved */
+                            with a reference rebuild"; -1 when clear), [12..15] reserved */
   double* ws;            /* energy workspace, >= chx_lj_ws_count(n) */
   int32_t external_force; /* != 0: do not launch the LJ force kernel (the caller fills f
                              between single-step chunks: IdealGasPotential and other potentials) */
@@ -327,24 +340,21 @@ typedef struct {
    * the copy is the step index of the newest launch that has begun (not ctrl[0]); words 6 and 7 are also stored
    * whenever they change.  NULL = off. */
   int32_t* host_ctrl;    /* CHX_CTRL_WORDS ints */
-  /* Deferred list rebuilds (fused neighbor-list path; snap4 == NULL = off: the halting scheme described at
+  /* Decoupled force list (fused neighbor-list path; snap4 == NULL = off: the ordinary scheme described at
    * chx_langevin_fused_chunk).  The reference rebuilds its list -- and takes new reference positions -- whenever a
    * particle has moved skin/2 from them (chiron/integrators.py:239-242, chiron/neighbors.py:868); what the FORCE needs
-   * is only a list that still holds every pair inside the cutoff.  With snap4 set the two are decoupled:
+   * is only a list that still holds every pair inside the cutoff.  With snap4 set the two are decoupled (what the list
+   * carry-over between short run() calls runs on):
    *   - fl / deg were built from the positions snap4 (same cutoff + skin) and stay exhaustive while no particle is
    *     farther than skin/2 from its snap4 row: THAT check raises the halt word ctrl[3] as before;
    *   - the reference's own check against ref4 no longer halts anything: the launch that sees it fire for the
    *     positions of step s+1 stores s+1 in the event word of that parity, and launch s+1 starts by copying its input
    *     positions into ref4 (the reference's new reference positions, from which the caller can build the PUBLIC list
    *     whenever somebody wants to see it), counting the event in ctrl[8] / ctrl[9] and logging its step in
-   *     ev_log[(count - 1) % ev_log_cap] (optional);
-   *   - a particle farther than trigger_frac * skin/2 from snap4 raises ctrl[12] (first such step, like the halt word):
-   *     the caller's cue to build the next force list from a snapshot taken a fixed number of steps later, on another
-   *     stream, and to switch to it a fixed number of steps after that -- before the halt distance is reached.
-   * Rebuild events, reference positions and interacting pairs are exactly those of the halting scheme; trajectories
+   *     ev_log[(count - 1) % ev_log_cap] (optional).
+   * Rebuild events, reference positions and interacting pairs are exactly those of the ordinary scheme; trajectories
    * differ from it only through the summation order of the forces (the internal order follows snap4, not ref4). */
   const float* snap4;     /* (n,4) positions the force list was built from, internal order (.w is not read) */
-  float trigger_frac;     /* in (0, 1]; <= 0: never raise ctrl[12] */
   int32_t ev_log_cap;
   int32_t* ev_log;
 } chx_langevin_t;
@@ -407,14 +417,18 @@ int chx_langevin_fused_chunk(const chx_langevin_t* p_h, float* x_even, float* x_
  * next call, or for the caller's wait on the stream, to find.  Why: after a halt everything still queued is dead
  * time in front of the list rebuild (about 2 us per no-op launch), so the queue should be as short as the host's
  * launch latency allows rather than a fixed number of chunks.
- * watch_trigger != 0 (deferred rebuilds): also stop enqueuing as soon as the trigger word host_ctrl[12] is set. */
+ * Side effect on the CALLING THREAD: with the sleeping poll policy (the default, chx_set_poll_sleep_ns) the first call
+ * lowers the thread's timer slack to 1 us (prctl(PR_SET_TIMERSLACK); a 5 us nap is otherwise rounded up to the
+ * kernel's default 50 us) and leaves it there -- the embedding application's thread keeps that slack.
+ * CHX_POLL_TIMERSLACK=0 in the environment leaves the slack alone (naps then last ~55 us: use a window >= 24). */
 int chx_langevin_fused_run(const chx_langevin_t* p_h, float* x_even, float* x_odd, int64_t step0,
-                           int32_t n_steps, int32_t kicks_first, int32_t window, int32_t watch_trigger,
+                           int32_t n_steps, int32_t kicks_first, int32_t window,
                            int32_t* n_enqueued_out, chx_stream_t stream);
 
 /* How chx_langevin_fused_run waits when its launch queue is full: sleep_ns > 0 -- nanosleep that long between polls
  * (default 5000, or CHX_POLL_SLEEP_NS; the queue refills in bursts of window / 2 launches); 0 -- busy-wait
- * (CHX_POLL=spin).  Host-side setting of the calling process; returns the previous value. */
+ * (CHX_POLL=spin).  A PROCESS-GLOBAL host-side setting (every thread that launches through chx_langevin_fused_run
+ * sees a change at its next full queue); returns the previous value. */
 int64_t chx_set_poll_sleep_ns(int64_t sleep_ns);
 /* Diagnostics of the sleeping window since the last reset: out4_h = {waits on a full queue, naps, wake-ups that found
  * two or fewer launches still queued (the nap outlasted the queue), nanoseconds spent in nanosleep}. */

@@ -28,7 +28,7 @@ torch.cuda.synchronize()
 for k in ks:
     for rep in range(2):
         for carry in (False, True):
-            integrators._CARRY[0] = carry
+            integ.list_carry = carry
             integ.n_carried_runs = integ.n_carry_rejected = integ.n_internal_halts = 0
             state, nbr = integ.run(state, thermo, number_of_steps=k, nbr_list=nbr)
             torch.cuda.synchronize()
@@ -43,4 +43,4 @@ for k in ks:
             print(f"{wl} run({k}) carry-over {'on ' if carry else 'off'}: median {1e6 * med:7.1f} us per call = {k / med:9.0f} steps/s"
                   f"   (carried {integ.n_carried_runs}, rejected {integ.n_carry_rejected}, force-list renewals {integ.n_internal_halts},"
                   f" reference rebuilds in the last call {integ.n_rebuilds})", flush=True)
-integrators._CARRY[0] = True
+integ.list_carry = True

@@ -44,7 +44,7 @@ wrap(I._RunState, "offer_carry", "5c carry offered")
 from chiron_amd import states as S
 wrap(S.SamplerState, "_copy_with", "5b state copied")
 if len(sys.argv) > 3:
-    I._CARRY[0] = sys.argv[3] != "0"
+    integ.list_carry = sys.argv[3] != "0"
 state, nbr = integ.run(state, thermo, number_of_steps=0, nbr_list=nbr)
 t0 = time.perf_counter()
 while time.perf_counter() - t0 < 3.0:

@@ -1,15 +1,14 @@
 # GPU test suite under the tuning overrides (lanes per particle, pruning cadence, launch queue and its poll policy, build
-# kernel, host control-block scheme, deferred rebuilds, list carry-over): every combination must pass
-# usage: bash scripts/test_matrix.sh [first] [count]   (26 combinations take ~24 min: two gpurun calls of 13)
+# kernel, list carry-over): every combination must pass
+# usage: bash scripts/test_matrix.sh [first] [count]
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 first=${1:-0}; count=${2:-100}; k=0
-for env in "CHX_SYNC_REBUILD=1" "CHX_LAUNCH_WINDOW=0" "CHX_LAUNCH_WINDOW=1" "CHX_LAUNCH_WINDOW=3 CHX_FL_G=2" "CHX_HOST_CTRL=0" "CHX_MC_DECIDE_LAUNCH=1" \
+for env in "CHX_SYNC_REBUILD=1" "CHX_LAUNCH_WINDOW=1" "CHX_LAUNCH_WINDOW=3 CHX_FL_G=2" "CHX_LAUNCH_WINDOW=500" "CHX_MC_DECIDE_LAUNCH=1" \
            "CHX_BUILD_KERNEL=cell" "CHX_BUILD_KERNEL=cell CHX_BUILD_SPLIT=3" "CHX_BUILD_KERNEL=particle" \
            "CHX_FL_G=1" "CHX_FL_G=8" "CHX_FL_G=16" "CHX_FL_G=64" "CHX_PRUNE_EVERY=0" "CHX_PRUNE_EVERY=1" \
            "CHX_PRUNE_EVERY=7 CHX_INNER_SKIN=0.02" "CHX_PRUNE_EVERY=50 CHX_INNER_SKIN=0.3" \
-           "CHX_POLL=spin" "CHX_POLL_SLEEP_NS=50000" "CHX_DEFERRED_REBUILD=1" "CHX_DEFERRED_REBUILD=1 CHX_DEFER_BG_BLOCKS=0" \
-           "CHX_DEFERRED_REBUILD=1 CHX_DEFER_LEAD=8 CHX_DEFER_ADOPT=12 CHX_LAUNCH_WINDOW=3" "CHX_DEFERRED_REBUILD=1 CHX_FL_G=8" \
+           "CHX_POLL=spin" "CHX_POLL_SLEEP_NS=50000" "CHX_POLL_TIMERSLACK=0" \
            "CHX_PIN_CPUS=0" "CHX_LIST_CARRY=0" "CHX_LIST_CARRY_MAX_STEPS=100000"; do
   k=$((k + 1))
   if [ $k -le $first ] || [ $k -gt $((first + count)) ]; then continue; fi

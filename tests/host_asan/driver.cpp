@@ -108,8 +108,8 @@ int main() {
   int32_t grid[3] = {3, 3, 3};
   EXPECT_INVALID(chx_nl_build_cell(F, -1, 4, ok_box, 1.5f, grid, I, I, I, U, I, U, I, I, nullptr));
   EXPECT_INVALID(chx_nl_build_cell(nullptr, 4, 4, ok_box, 1.5f, grid, I, I, I, U, I, U, I, I, nullptr));
-  EXPECT_INVALID(chx_nl_build_cell_fl(F, -1, 4, ok_box, 1.5f, grid, I, I, I, U, I, U, U, I, 8, 2, U, I, F, 0, nullptr));
-  EXPECT_INVALID(chx_nl_build_cell_fl(F, 4, 4, ok_box, 1.5f, grid, I, I, I, U, I, U, U, I, 3, 2, U, I, F, 0, nullptr));  // g not 2^k
+  EXPECT_INVALID(chx_nl_build_cell_fl(F, -1, 4, ok_box, 1.5f, grid, I, I, I, U, I, U, U, I, 8, 2, U, I, F, nullptr, nullptr));
+  EXPECT_INVALID(chx_nl_build_cell_fl(F, 4, 4, ok_box, 1.5f, grid, I, I, I, U, I, U, U, I, 3, 2, U, I, F, nullptr, nullptr));  // g not 2^k
   EXPECT_INVALID(chx_nl_finish_padding(U, U, I, -1, 4, I, nullptr));
   EXPECT_INVALID(chx_nl_calculate(F, U, I, -1, 4, ok_box, 1.0f, I, I, F, F, nullptr));
   EXPECT_INVALID(chx_nl_check(F, F, -1, ok_box, 0.5f, I, nullptr));
@@ -160,23 +160,23 @@ int main() {
   EXPECT_INVALID(chx_langevin_fused_chunk(&lp, F, F, 0, 1, 1, 1, nullptr));  // g = 3 is not a supported lane count
   // the bounded launch queue: needs the force-list path, a host-visible control block, a window and an out pointer
   int32_t sent = -1;
-  EXPECT_INVALID(chx_langevin_fused_run(nullptr, F, F, 0, 1, 1, 4, 0, &sent, nullptr));
-  EXPECT_INVALID(chx_langevin_fused_run(&lp, F, F, 0, 1, 1, 4, 0, nullptr, nullptr));
-  EXPECT_INVALID(chx_langevin_fused_run(&lp, F, F, 0, 1, 1, 4, 0, &sent, nullptr));  // host_ctrl == NULL
+  EXPECT_INVALID(chx_langevin_fused_run(nullptr, F, F, 0, 1, 1, 4, &sent, nullptr));
+  EXPECT_INVALID(chx_langevin_fused_run(&lp, F, F, 0, 1, 1, 4, nullptr, nullptr));
+  EXPECT_INVALID(chx_langevin_fused_run(&lp, F, F, 0, 1, 1, 4, &sent, nullptr));  // host_ctrl == NULL
   lp.host_ctrl = I;
-  EXPECT_INVALID(chx_langevin_fused_run(&lp, F, F, 0, 1, 1, 0, 0, &sent, nullptr));  // window < 1
-  EXPECT_INVALID(chx_langevin_fused_run(&lp, F, F, 0, -1, 1, 4, 0, &sent, nullptr));
+  EXPECT_INVALID(chx_langevin_fused_run(&lp, F, F, 0, 1, 1, 0, &sent, nullptr));  // window < 1
+  EXPECT_INVALID(chx_langevin_fused_run(&lp, F, F, 0, -1, 1, 4, &sent, nullptr));
   {
     // the halt word already rules out the first step: nothing is launched (so the bad lane count is never reached)
     int32_t hc[CHX_CTRL_WORDS] = {6, 0, 0, 7, -2, -2, 0, 0, 0, -1, -1, -1, 0x7FFFFFFF, 0, 0, 0};
     lp.host_ctrl = hc;
     sent = -1;
-    int rc = chx_langevin_fused_run(&lp, F, F, 7, 5, 2, 4, 0, &sent, nullptr);
+    int rc = chx_langevin_fused_run(&lp, F, F, 7, 5, 2, 4, &sent, nullptr);
     (void)rc;  // (without a device the trailing hipGetLastError may complain; what matters is that nothing was launched)
     EXPECT(sent == 0);
     // a free window and no halt: the first launch is attempted and rejected for its lane count
     hc[3] = 0x7fffffff;
-    EXPECT_INVALID(chx_langevin_fused_run(&lp, F, F, 7, 5, 2, 4, 0, &sent, nullptr));
+    EXPECT_INVALID(chx_langevin_fused_run(&lp, F, F, 7, 5, 2, 4, &sent, nullptr));
     lp.host_ctrl = I;
   }
   EXPECT_INVALID(chx_mc_displace_chunk(nullptr, 0, 1, nullptr));

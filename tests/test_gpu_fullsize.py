@@ -233,18 +233,15 @@ def test_c4_langevin_is_independent_of_launch_batching(ca, O):
 
 
 @pytest.mark.parametrize("n", [N3, N4], ids=["c3-32768", "c4-262144"])
-def test_launch_window_and_chunked_scheme_agree_at_full_size(ca, O, n, monkeypatch):
-    """The metric configuration's loop, both ways: the bounded launch queue (chx_langevin_fused_run, the default) and
-    the older two-chunks-in-flight scheme end in the same bits -- positions, velocities, rebuild count, rebuilt list --
-    at N = 32,768 (lanes per particle 4, per-particle build kernel) and N = 262,144 (two lanes, cell-wise build kernel).
-    Thin skin: several rebuilds inside a short run."""
-    import os
-
-    if os.environ.get("CHX_LAUNCH_WINDOW") == "0":
-        pytest.skip("the launch window is switched off (CHX_LAUNCH_WINDOW=0): both runs would take the chunked scheme")
+def test_launch_window_width_does_not_change_the_trajectory_at_full_size(ca, O, n, monkeypatch):
+    """The metric configuration's loop at two extremes of the bounded launch queue (chx_langevin_fused_run): the default
+    window (12 launches ahead of the device, the halt seen within a handful of no-op launches) and a window as long as
+    the run (everything enqueued at once, every halt drained as dozens of no-op launches) end in the same bits --
+    positions, velocities, rebuild count, rebuilt list -- at N = 32,768 (lanes per particle 4, per-particle build
+    kernel) and N = 262,144 (two lanes, cell-wise build kernel).  Thin skin: several rebuilds inside a short run."""
     orig = ca.integrators.LangevinIntegrator.__init__
     res = []
-    for window in (None, 0):
+    for window in (None, 4096):
         def init(self, *a, _w=window, **k):
             orig(self, *a, **k)
             if _w is not None:
@@ -253,11 +250,12 @@ def test_launch_window_and_chunked_scheme_agree_at_full_size(ca, O, n, monkeypat
         res.append(_run_langevin(ca, O, n, 32, 160 if n == N3 else 96, 0.06))
     monkeypatch.setattr(ca.integrators.LangevinIntegrator, "__init__", orig)
     (a, nbr_a, integ_a), (b, nbr_b, integ_b) = res
-    assert integ_a.launch_window > 0 and integ_b.launch_window == 0
+    assert integ_a.launch_window < 64 and integ_b.launch_window == 4096
     assert integ_a.n_rebuilds == integ_b.n_rebuilds >= 1
     assert torch.equal(a.positions, b.positions) and torch.equal(a.velocities, b.velocities)
     assert torch.equal(nbr_a.ref_positions, nbr_b.ref_positions) and torch.equal(nbr_a.n_neighbors, nbr_b.n_neighbors)
     assert (integ_a.prune_passes, integ_a.full_list_launches) == (integ_b.prune_passes, integ_b.full_list_launches)
+    assert getattr(integ_b, "noop_launches", 0) > getattr(integ_a, "noop_launches", 0)  # the long queue drains more dead launches
 
 
 def test_c3_mc_device_loop_equals_host_loop(ca, O, monkeypatch):

@@ -1763,7 +1763,7 @@ def test_reference_mcmc_workflows_on_a_harmonic_oscillator(ca, O):
         assert np.abs(s2.positions.cpu().numpy() - x).max() < 2e-6 * 20
 
 
-@pytest.mark.parametrize("window", [0, 1, 16])
+@pytest.mark.parametrize("window", [1, 16, 256])
 @pytest.mark.parametrize("where", ["end-of-run", "end-of-chunk", "mid-chunk"])
 def test_langevin_halt_at_chunk_and_run_boundaries_matches_oracle(ca, O, where, window):
     """The skin check firing in the LAST step of a run (the rebuild then happens after the loop's last A-O-A and
@@ -1793,7 +1793,7 @@ def test_langevin_halt_at_chunk_and_run_boundaries_matches_oracle(ca, O, where, 
         steps, chunk = h + 9, h + 3           # (control: in the middle of a chunk)
     _, _, pot, state, thermo, nbr, integ = _langevin_setup(ca, O, n, 0.3, 43, skin, 4.0, "NeighborListNsqrd", 250)
     integ.chunk_size = chunk
-    integ.launch_window = window  # 0: two chunks in flight; else the bounded launch queue (chx_langevin_fused_run)
+    integ.launch_window = window  # launches kept queued ahead of the device (chx_langevin_fused_run); 256: the whole run
     state.velocities = v0
     out, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr, noise=noise[:steps])
     xo, vo, rebuilds, (nl_mask, nl, n_max) = oracle(steps)
@@ -1810,11 +1810,11 @@ def test_langevin_halt_at_chunk_and_run_boundaries_matches_oracle(ca, O, where, 
 def test_langevin_launch_window_does_not_change_the_trajectory(ca, O, reports):
     """The bounded launch queue (LangevinIntegrator.launch_window -> chx_langevin_fused_run) only changes how far the
     host runs ahead of the device: trajectory, rebuild count, pruning counters and the rebuilt list are the same
-    bits for every window, for the older two-chunks-in-flight scheme (window 0), with the Philox stream and
+    bits for every window (256: everything is enqueued at once), with the Philox stream and
     with the run cut into report segments.  Thin skin + large time step: a rebuild every few steps."""
     n, skin, steps = 2500, 0.05, 150
     ref = None
-    for window, chunk in ((0, 32), (1, 32), (2, 5), (16, 32), (64, 7), (16, 1)):
+    for window, chunk in ((256, 32), (1, 32), (2, 5), (16, 32), (64, 7), (16, 1)):
         x, box, pot, state, thermo, nbr, integ = _langevin_setup(ca, O, n, 0.3, 43, skin, 4.0)
         integ.chunk_size, integ.launch_window = chunk, window
         if reports:
@@ -1911,8 +1911,8 @@ def test_deep_copied_integrator_and_sampler_run_on_fresh_slots(ca, O):
     out1, nbr1 = integ.run(state, thermo, number_of_steps=150, nbr_list=nbr)
     import os
 
-    windowed = os.environ.get("CHX_LAUNCH_WINDOW") != "0" and os.environ.get("CHX_HOST_CTRL") != "0"
-    ring_name = "_gen_ring" if windowed else "_pinned_ring"  # (the chunked scheme keeps plain pinned read-back slots)
+    windowed = True
+    ring_name = "_gen_ring"
     assert integ.n_rebuilds >= 1 and ring_name in integ.__dict__  # the loop ran and left its host-mapped slots
     clone = copy.deepcopy(integ)
     assert ring_name not in clone.__dict__ and "_dev_scratch" not in clone.__dict__
@@ -1937,177 +1937,15 @@ def test_deep_copied_integrator_and_sampler_run_on_fresh_slots(ca, O):
 
 
 # ---------------------------------------------------------------------------
-# deferred list rebuilds (opt-in: CHX_DEFERRED_REBUILD=1; include/chx.h: chx_langevin_t::snap4)
-# ---------------------------------------------------------------------------
-def _deferred_run(ca, O, deferred, steps, chunk=32, window=None, n=4096, dt_fs=2.0, seed=61, reporter=None, interval=100):
-    import os
-
-    from chiron_amd import integrators
-
-    if os.environ.get("CHX_LAUNCH_WINDOW") == "0" or os.environ.get("CHX_HOST_CTRL") == "0":
-        pytest.skip("deferred rebuilds ride on the bounded launch queue, which this run switches off")
-
-    u = ca.unit
-    x, box = O.lj_lattice(n, 0.1, SIGMA, seed=seed)
-    pot = lj_pot(ca, n)
-    state = make_state(ca, x, box)
-    thermo = ca.states.ThermodynamicState(pot, temperature=300 * u.kelvin)
-    nbr = ca.neighbors.NeighborListCell(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
-                                        skin=SKIN * u.nanometer, n_max_neighbors=180)
-    kw = {} if window is None else {"launch_window": window}
-    integ = ca.integrators.LangevinIntegrator(timestep=dt_fs * u.femtoseconds, collision_rate=1.0 / u.picoseconds,
-                                              chunk_size=chunk, reporter=reporter, report_interval=interval, **kw)
-    old = integrators._DEFERRED[0]
-    integrators._DEFERRED[0] = deferred
-    try:
-        key_before = state.current_PRNG_key
-        out, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr)
-    finally:
-        integrators._DEFERRED[0] = old
-    return x, box, pot, out, nbr, integ, key_before
-
-
-def test_deferred_rebuilds_keep_the_reference_events_and_the_public_list(ca, O):
-    """With the force list on a schedule of its own -- built ahead of time on a side stream, switched in by a device
-    repack -- the REFERENCE's rebuilds become events the step kernel takes itself.  Same events at the same steps as
-    the halting scheme and as the C oracle (chiron/integrators.py:239-242), same trajectory up to the summation order
-    of the forces, and the caller's list ends as the reference's would: built from the positions of the last event."""
-    from oracle import c_oracle as CO
-    import chiron_amd.rng as R
-
-    steps, n = 700, 4096
-    x, box, pot, a, nbr_a, integ_a, key0 = _deferred_run(ca, O, True, steps)
-    _, _, _, b, nbr_b, integ_b, _ = _deferred_run(ca, O, False, steps)
-    assert integ_a.n_adoptions >= 2 and integ_a.n_side_builds >= integ_a.n_adoptions  # the scheme really ran
-    assert integ_a.n_internal_halts == 0 and integ_a.late_triggers == 0
-    assert integ_a.n_rebuilds == integ_b.n_rebuilds >= 3
-    assert integ_a.rebuild_steps == integ_b.rebuild_steps and len(integ_a.rebuild_steps) == integ_a.n_rebuilds
-    dx = (a.positions - b.positions).abs()
-    L = float(box[0, 0])
-    dx = torch.minimum(dx, (dx - L).abs())
-    assert dx.max().item() < 2e-4 and (a.velocities - b.velocities).abs().max().item() < 2e-2
-    # the caller's list: resolved on first access, from the positions of the LAST event
-    assert "_deferred" in nbr_a.__dict__ and "n_neighbors" not in nbr_a.__dict__
-    assert nbr_a.is_built and nbr_a.n_builds == nbr_b.n_builds
-    ref = nbr_a.ref_positions  # (first access: builds)
-    assert "_deferred" not in nbr_a.__dict__
-    dref = (ref - nbr_b.ref_positions).abs()
-    assert torch.minimum(dref, (dref - L).abs()).max().item() < 2e-4
-    mask, nl, nnbr = CO.nl_build_fixed(ref.cpu().numpy(), box, CUTOFF + SKIN, int(nbr_a.n_max_neighbors))
-    assert np.array_equal(nbr_a.n_neighbors.cpu().numpy(), nnbr) and np.array_equal(u32(nbr_a.neighbor_list), nl)
-    # its energy is the energy of the final frame (the list is valid for it: no event since)
-    e_list = float(pot.compute_energy(a.positions, nbr_a))
-    e64 = CO.lj_cell_f64(a.positions.cpu().numpy(), box, SIGMA, EPS, CUTOFF)[0]
-    assert abs(e_list - e64) <= 2e-5 * abs(e64) + 1e-3
-    # the C oracle on the same Philox stream: same number of rebuilds, same trajectory within chaos-free tolerance
-    _, run_key = R.split(key0)
-    mass = np.full(n, 39.948, f32)
-    kT, ca_, cb_ = O.langevin_constants(300.0, 0.002, 1.0)
-    v0 = O.initial_velocities(mass, kT, O.philox_normals3(n, 0, O.STREAM_VELOCITY, tuple(run_key)))
-    xo, vo, st = CO.langevin_run_cell_omp(x, v0, box, mass, SIGMA, EPS, CUTOFF, SKIN, 0.002, ca_, cb_, kT, steps, None,
-                                          tuple(run_key), threads=CO.effective_cores())
-    assert st["rebuilds"] == integ_a.n_rebuilds
-    do = np.abs(a.positions.cpu().numpy() - xo)
-    assert np.minimum(do, np.abs(do - L)).max() < 5e-4
-
-
-def test_deferred_rebuilds_do_not_depend_on_launch_batching(ca, O):
-    """Snapshot and switch steps are functions of the trajectory (trigger step + lead, + adopt): chunk sizes, launch
-    windows (capped at lead - 4 while the trigger is watched) and report stops give the same bits."""
-    steps = 500
-    runs = [_deferred_run(ca, O, True, steps, chunk=32), _deferred_run(ca, O, True, steps, chunk=5),
-            _deferred_run(ca, O, True, steps, chunk=32, window=3), _deferred_run(ca, O, True, steps, chunk=17, window=64)]
-    from chiron_amd.reporters import LangevinDynamicsReporter
-
-    rep = LangevinDynamicsReporter("deferred_probe", buffer_size=1)
-    runs.append(_deferred_run(ca, O, True, steps, chunk=32, reporter=rep, interval=70))
-    ref = runs[0]
-    assert ref[5].n_adoptions >= 1
-    for r in runs[1:]:
-        assert torch.equal(r[3].positions, ref[3].positions) and torch.equal(r[3].velocities, ref[3].velocities)
-        assert r[5].rebuild_steps == ref[5].rebuild_steps and r[5].n_adoptions == ref[5].n_adoptions
-    # the reported energies are energies of the reported frames (evaluated on the list the steps run on)
-    from oracle import c_oracle as CO
-
-    frames, energy = np.asarray(rep.get_property("positions")), np.asarray(rep.get_property("potential_energy"), dtype=np.float64).ravel()
-    assert len(frames) == len(energy) >= 7
-    for k in (0, len(frames) // 2, len(frames) - 1):
-        e64 = CO.lj_cell_f64(frames[k], ref[1], SIGMA, EPS, CUTOFF)[0]
-        assert abs(energy[k] - e64) <= 2e-5 * abs(e64) + 1e-3
-
-
-def test_deferred_rebuilds_fall_back_when_the_list_is_short_lived(ca, O):
-    """Thin skin: there is no room between trigger and switch (theta < 0.25), the run takes the halting scheme."""
-    from chiron_amd import integrators
-
-    n, steps, skin = 2500, 40, 0.05
-    x, box, pot, state, thermo, nbr, integ = _langevin_setup(ca, O, n, 0.3, 43, skin, 4.0)
-    old = integrators._DEFERRED[0]
-    integrators._DEFERRED[0] = True
-    try:
-        out, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr)
-    finally:
-        integrators._DEFERRED[0] = old
-    assert integ.n_rebuilds >= 1 and getattr(integ, "n_adoptions", 0) == 0
-    assert "_deferred" not in nbr.__dict__ and len(integ.rebuild_steps) == integ.n_rebuilds
-
-
-def test_deferred_rebuilds_survive_a_list_that_runs_out_early(ca, O, monkeypatch):
-    """The schedule's prediction can fail (here it is made to: the trigger fires at 98 % of the skin, far too late for
-    lead + adopt steps): the halt word then fires on the force list's OWN positions.  While those are still the
-    reference's (no switch yet) the halt IS the reference's rebuild and the host carries it out, abandoning the build in
-    flight; after a switch only the force list is renewed, on the spot, and a reference event booked for that very
-    step stays booked.  Either way: the halting scheme's events, trajectory and final list."""
-    monkeypatch.setenv("CHX_DEFER_THETA", "0.98")
-    steps = 600
-    x, box, pot, a, nbr_a, integ_a, _ = _deferred_run(ca, O, True, steps)
-    monkeypatch.delenv("CHX_DEFER_THETA")
-    _, _, _, b, nbr_b, integ_b, _ = _deferred_run(ca, O, False, steps)
-    assert integ_a.n_rebuilds == integ_b.n_rebuilds >= 3 and integ_a.rebuild_steps == integ_b.rebuild_steps
-    # the first generation's halt coincides with the reference's first rebuild: carried out by the host
-    host_events, dev_log = integ_a._rebuild_log
-    assert len(host_events) >= 1 and host_events[0] == integ_b.rebuild_steps[0]
-    L = float(box[0, 0])
-    dx = (a.positions - b.positions).abs()
-    assert torch.minimum(dx, (dx - L).abs()).max().item() < 2e-4
-    ref = nbr_a.ref_positions
-    dref = (ref - nbr_b.ref_positions).abs()
-    assert torch.minimum(dref, (dref - L).abs()).max().item() < 2e-4
-    assert nbr_a.n_builds == nbr_b.n_builds
-    # ... and after a switch: the first switch is allowed to happen on schedule, every later trigger comes too late
-    from chiron_amd import integrators
-
-    orig_adopt = integrators._RunState._adopt
-
-    def adopt_then_sabotage(self, step):
-        orig_adopt(self, step)
-        self._defer.theta = 0.985
-        self.params.trigger_frac = 0.985
-
-    monkeypatch.setattr(integrators._RunState, "_adopt", adopt_then_sabotage)
-    _, _, _, c, nbr_c, integ_c, _ = _deferred_run(ca, O, True, steps)
-    assert integ_c.n_adoptions >= 1 and integ_c.n_internal_halts >= 1
-    assert integ_c.n_rebuilds == integ_b.n_rebuilds and integ_c.rebuild_steps == integ_b.rebuild_steps
-    dx = (c.positions - b.positions).abs()
-    assert torch.minimum(dx, (dx - L).abs()).max().item() < 2e-4
-    dref = (nbr_c.ref_positions - nbr_b.ref_positions).abs()
-    assert torch.minimum(dref, (dref - L).abs()).max().item() < 2e-4
-
-
-# ---------------------------------------------------------------------------
 # list carry-over between run() calls
 # ---------------------------------------------------------------------------
-def _carry_segments(ca, O, carry, segments, steps, n=4096, dt_fs=2.0, seed=67, tamper=None):
+def _carry_segments(ca, O, carry, segments, steps, n=4096, dt_fs=2.0, seed=67, tamper=None, max_steps=None):
     """`segments` consecutive run(steps) calls on one integrator and one list, each continuing from the state the
     previous one returned.  Returns per-segment records and the final objects."""
     import os
 
     from chiron_amd import integrators
 
-    if os.environ.get("CHX_LAUNCH_WINDOW") == "0" or os.environ.get("CHX_HOST_CTRL") == "0":
-        pytest.skip("list carry-over rides on the bounded launch queue, which this run switches off")
-    if os.environ.get("CHX_DEFERRED_REBUILD") == "1":
-        pytest.skip("with deferred rebuilds switched on every run() builds its list on entry")
     u = ca.unit
     x, box = O.lj_lattice(n, 0.1, SIGMA, seed=seed)
     pot = lj_pot(ca, n)
@@ -2115,11 +1953,10 @@ def _carry_segments(ca, O, carry, segments, steps, n=4096, dt_fs=2.0, seed=67, t
     thermo = ca.states.ThermodynamicState(pot, temperature=300 * u.kelvin)
     nbr = ca.neighbors.NeighborListCell(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
                                         skin=SKIN * u.nanometer, n_max_neighbors=180)
-    integ = ca.integrators.LangevinIntegrator(timestep=dt_fs * u.femtoseconds, collision_rate=1.0 / u.picoseconds)
-    old = integrators._CARRY[0]
-    integrators._CARRY[0] = carry
+    integ = ca.integrators.LangevinIntegrator(timestep=dt_fs * u.femtoseconds, collision_rate=1.0 / u.picoseconds,
+                                              list_carry=carry, **({} if max_steps is None else {"list_carry_max_steps": max_steps}))
     recs = []
-    try:
+    if True:
         for k in range(segments):
             if tamper is not None:
                 tamper(k, state, integ, nbr)
@@ -2128,8 +1965,6 @@ def _carry_segments(ca, O, carry, segments, steps, n=4096, dt_fs=2.0, seed=67, t
             state, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr)
             recs.append(dict(key=key_before, x_in=x_in, v_in=v_in, rebuild_steps=list(integ.rebuild_steps),
                              n_rebuilds=integ.n_rebuilds, x=state.positions.clone(), v=state.velocities.clone()))
-    finally:
-        integrators._CARRY[0] = old
     return x, box, pot, state, nbr, integ, recs
 
 
@@ -2208,7 +2043,7 @@ def test_list_carry_over_is_declined_for_positions_from_elsewhere(ca, O):
     thermo = ca.states.ThermodynamicState(pot, temperature=300 * u.kelvin)
     from chiron_amd import integrators
 
-    out, nbr = integ.run(a, thermo, number_of_steps=integrators._CARRY_MAX_STEPS + 1, nbr_list=nbr)
+    out, nbr = integ.run(a, thermo, number_of_steps=integ.list_carry_max_steps + 1, nbr_list=nbr)
     assert integ.n_carried_runs == 2 and "_deferred" not in nbr.__dict__ and "n_neighbors" in nbr.__dict__
     # another list object: declined as well
     nbr2 = ca.neighbors.NeighborListCell(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
@@ -2271,11 +2106,9 @@ def test_list_carry_over_survives_a_rejected_force_list_renewal(ca, O, monkeypat
         return orig(self, wait)
 
     monkeypatch.setattr(neighbors.NeighborListNsqrd, "_confirm_build", confirm)
-    from chiron_amd import integrators
-
-    monkeypatch.setattr(integrators, "_CARRY_MAX_STEPS", 256)  # (segments long enough for renewals inside them)
     segments, steps = 8, 100
-    x, box, pot, a, nbr_a, integ_a, ra = _carry_segments(ca, O, True, segments, steps)
+    # (list_carry_max_steps = 256: segments long enough for renewals inside them)
+    x, box, pot, a, nbr_a, integ_a, ra = _carry_segments(ca, O, True, segments, steps, max_steps=256)
     monkeypatch.setattr(neighbors.NeighborListNsqrd, "_confirm_build", orig)
     assert calls["n"] == 1 and integ_a.n_internal_halts >= 2
     _, _, _, b, nbr_b, integ_b, rb = _carry_segments(ca, O, False, segments, steps)
@@ -2294,10 +2127,6 @@ def test_list_carry_over_with_injected_noise_follows_the_oracle_step_for_step(ca
 
     from chiron_amd import integrators
 
-    if os.environ.get("CHX_LAUNCH_WINDOW") == "0" or os.environ.get("CHX_HOST_CTRL") == "0":
-        pytest.skip("list carry-over rides on the bounded launch queue, which this run switches off")
-    if os.environ.get("CHX_DEFERRED_REBUILD") == "1":
-        pytest.skip("with deferred rebuilds switched on every run() builds its list on entry")
     n, steps, segments, skin = 2500, 12, 5, 0.05
     x, box, pot, state, thermo, nbr, integ = _langevin_setup(ca, O, n, 0.3, 43, skin, 4.0)
     rng = np.random.default_rng(23)
@@ -2306,10 +2135,9 @@ def test_list_carry_over_with_injected_noise_follows_the_oracle_step_for_step(ca
     v0 = O.initial_velocities(mass, kT, rng.normal(size=(n, 3)).astype(f32))
     state.velocities = v0
     xo, vo = x, v0
-    old = integrators._CARRY[0]
-    integrators._CARRY[0] = True
+    integ.list_carry = True
     events = 0
-    try:
+    if True:
         for k in range(segments):
             noise = rng.normal(size=(steps, n, 3)).astype(f32)
             state, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr, noise=noise)
@@ -2319,7 +2147,5 @@ def test_list_carry_over_with_injected_noise_follows_the_oracle_step_for_step(ca
             events += rebuilds
             assert np.abs(state.positions.cpu().numpy() - xo).max() < 5e-6, k
             assert np.abs(state.velocities.cpu().numpy() - vo).max() < 5e-4 * max(1.0, np.abs(vo).max()), k
-    finally:
-        integrators._CARRY[0] = old
     assert integ.n_carried_runs == segments - 1 and getattr(integ, "n_carry_rejected", 0) == 0
     assert events >= 2 and integ.n_internal_halts >= 1  # both kinds of rebuild happened inside carried segments

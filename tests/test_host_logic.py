@@ -281,12 +281,12 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/chx.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
-    assert lib.chx_version() == _lib.ABI_VERSION == 2
+    assert lib.chx_version() == _lib.ABI_VERSION == 3
     # struct layouts agree with the header (x86-64 SysV)
     assert ctypes.sizeof(_lib.Box) == 16
     assert ctypes.sizeof(_lib.LangevinParams) == 248 == lib.chx_sizeof_langevin_t()
     assert _lib.LangevinParams.host_ctrl.offset == 216 and _lib.LangevinParams.snap4.offset == 224
-    assert _lib.LangevinParams.trigger_frac.offset == 232 and _lib.LangevinParams.ev_log.offset == 240
+    assert _lib.LangevinParams.ev_log_cap.offset == 232 and _lib.LangevinParams.ev_log.offset == 240
     assert _lib.LangevinParams.fl_inner.offset == 176 and _lib.LangevinParams.prune_phase.offset == 208
     # struct-by-value marshalling rule of include/chx.h: no float scalars before a box that follows
     # five or more integer/pointer arguments (mis-marshalled by this image's libffi)
@@ -379,27 +379,20 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
                            ctypes.c_void_p(64), None), "power of two")
     failed(lib.chx_langevin_fused_chunk(None, None, None, 0, 1, 1, 1, None), "null params")
     sent = ctypes.c_int32(-1)
-    failed(lib.chx_langevin_fused_run(None, None, None, 0, 1, 1, 4, 0, ctypes.byref(sent), None), "null pointer")
+    failed(lib.chx_langevin_fused_run(None, None, None, 0, 1, 1, 4, ctypes.byref(sent), None), "null pointer")
     lp = _lib.LangevinParams()
     lp.n = 4
     lp.v = lp.mass = lp.ctrl = lp.fl = lp.deg = 64
     lp.fl_chunks = 1
-    failed(lib.chx_langevin_fused_run(ctypes.byref(lp), ctypes.c_void_p(64), ctypes.c_void_p(128), 0, 1, 1, 4, 0,
+    failed(lib.chx_langevin_fused_run(ctypes.byref(lp), ctypes.c_void_p(64), ctypes.c_void_p(128), 0, 1, 1, 4,
                                       ctypes.byref(sent), None), "host_ctrl")
     hc = (ctypes.c_int32 * _lib.CTRL_WORDS)(6, 0, 0, 7, -2, -2, 0, 0, 0, -1, -1, -1, 2**31 - 1, 0, 0, 0)
     lp.host_ctrl = ctypes.addressof(hc)
-    failed(lib.chx_langevin_fused_run(ctypes.byref(lp), ctypes.c_void_p(64), ctypes.c_void_p(128), 0, 1, 1, 0, 0,
+    failed(lib.chx_langevin_fused_run(ctypes.byref(lp), ctypes.c_void_p(64), ctypes.c_void_p(128), 0, 1, 1, 0,
                                       ctypes.byref(sent), None), "window")
     # the halt word (7) already rules out step 7: the launch loop stops before its first launch
-    lib.chx_langevin_fused_run(ctypes.byref(lp), ctypes.c_void_p(64), ctypes.c_void_p(128), 7, 5, 2, 4, 0, ctypes.byref(sent), None)
+    lib.chx_langevin_fused_run(ctypes.byref(lp), ctypes.c_void_p(64), ctypes.c_void_p(128), 7, 5, 2, 4, ctypes.byref(sent), None)
     assert sent.value == 0
-    # deferred rebuilds: a set trigger word stops a watching loop before its first launch, and only a watching one
-    hc[3], hc[12] = 2**31 - 1, 3
-    lp.snap4 = lp.ref4 = 64
-    lp.skin = 0.5
-    lib.chx_langevin_fused_run(ctypes.byref(lp), ctypes.c_void_p(64), ctypes.c_void_p(128), 7, 5, 2, 4, 1, ctypes.byref(sent), None)
-    assert sent.value == 0
-    lp.snap4 = None
     failed(lib.chx_mc_displace_chunk(None, 0, 1, None), "null parameter block")
     failed(lib.chx_lj_nl_energy_force(None, None, None, 8, 0, box, f(1), f(1), f(1), None, None, None, None), "m >= 1")
     failed(lib.chx_baoab_step(None, None, None, None, -3, box, 1, f(1), f(1), f(1), f(1), None, f(1), 0, 0, 0, None,
@@ -409,7 +402,7 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
     p.n = 0
     failed(lib.chx_mc_displace_chunk(ctypes.byref(p), 0, 1, None), "n <= 0")
     # the threshold helper and the grid helper are pure host functions
-    assert lib.chx_version() == _lib.ABI_VERSION == 2
+    assert lib.chx_version() == _lib.ABI_VERSION == 3
 
 
 def test_sampler_state_copy_with_and_box_token():
@@ -728,7 +721,7 @@ def test_list_carry_over_offer_is_taken_only_by_the_run_that_continues_the_traje
         integ, nbr, st, owner = setup()
         steps, other = 20, nbr
         if spoil == "steps":
-            steps = integrators._CARRY_MAX_STEPS + 1
+            steps = integ.list_carry_max_steps + 1
         elif spoil == "zero":
             steps = 0
         elif spoil == "copy":
@@ -748,11 +741,8 @@ def test_list_carry_over_offer_is_taken_only_by_the_run_that_continues_the_traje
         elif spoil == "capacity":
             owner._last_max_n = 170  # > 0.85 * n_max_neighbors: the reference's growth rule must see every build
         elif spoil == "switch":
-            integrators._CARRY[0] = False
-        try:
-            assert integ._take_carry(st, other, steps) is None, spoil
-        finally:
-            integrators._CARRY[0] = True
+            integ.list_carry = False  # (LangevinIntegrator(list_carry=False))
+        assert integ._take_carry(st, other, steps) is None, spoil
         assert integ.__dict__.get("_carry") is None, spoil
     # an offer that names the caller's own list needs that list's last confirmed cell build: none here
     integ, nbr, st, owner = setup()
@@ -795,7 +785,7 @@ def test_cell_build_refuses_a_grid_axis_beyond_its_packed_coordinates():
     p = ctypes.c_void_p(64)
     rc = lib.chx_nl_build_cell(p, 8, 8, box, ctypes.c_float(1.5), nc, p, p, p, p, p, p, p, p, None)
     assert rc < 0 and "1024 cells per axis" in lib.chx_last_error().decode()
-    rc = lib.chx_nl_build_cell_fl(p, 8, 8, box, ctypes.c_float(1.5), nc, p, p, p, p, p, p, p, p, 4, 1, p, p, p, 0, None)
+    rc = lib.chx_nl_build_cell_fl(p, 8, 8, box, ctypes.c_float(1.5), nc, p, p, p, p, p, p, p, p, 4, 1, p, p, p, None, None)
     assert rc < 0 and "1024 cells per axis" in lib.chx_last_error().decode()
     # the helper itself never hands out such a grid
     total = lib.chx_cell_grid_h(_lib.Box(1, 4000.0, 4000.0, 4000.0), ctypes.c_float(1.5), 1 << 30, nc)
