@@ -58,6 +58,9 @@ class LangevinParams(C.Structure):
         ("snap4", C.c_void_p),
         ("ev_log_cap", C.c_int32),
         ("ev_log", C.c_void_p),
+        ("final_x3", C.c_void_p),
+        ("final_v3", C.c_void_p),
+        ("final_ref3", C.c_void_p),
     ]
 
 
@@ -132,6 +135,7 @@ SIGNATURES = {
     "chx_sizeof_langevin_t": (_I64, []),
     "chx_sizeof_mc_t": (_I64, []),
     "chx_cutoff_threshold_h": (_F, [_F]),
+    "chx_philox4x32_h": (None, [_U32, _U32, _U32, _U32, _U32, _U32, C.POINTER(_U32)]),
     "chx_displacement": (C.c_int, [_P, _P, _I64, Box, _P, _P, _P]),
     "chx_wrap": (C.c_int, [_P, _P, _I64, Box, _P]),
     "chx_nl_build_nsq": (C.c_int, [_P, _I32, _I32, Box, _F, _P, _P, _P, _P]),
@@ -143,6 +147,11 @@ SIGNATURES = {
     "chx_nl_build_cell_fl": (
         C.c_int,
         [_P, _I32, _I32, Box, _F, C.POINTER(_I32), _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, C.POINTER(BuildRiders), _P],
+    ),
+    "chx_cell_bin_fl": (C.c_int, [_P, _I32, Box, _F, C.POINTER(_I32), _P, _P, _P, _P, _P, _P, C.POINTER(BuildRiders), _P]),
+    "chx_nl_rows_cell_fl": (
+        C.c_int,
+        [_I32, _I32, Box, _F, C.POINTER(_I32), _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P],
     ),
     "chx_nl_finish_padding": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),
     "chx_pack_langevin": (C.c_int, [_P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _I32, _P, _P, _P]),

@@ -449,46 +449,64 @@ __global__ __launch_bounds__(256) void k_build_epilogue(const int32_t* __restric
   }
 }
 
-extern "C" int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_box_t box,
-                                    float cutoff_plus_skin, const int32_t* nc_h, int32_t* cell_of,
-                                    int32_t* cell_count, int32_t* cell_start, uint32_t* sorted_ids,
-                                    int32_t* status8, uint32_t* nl_rows_out, uint32_t* first_out,
-                                    int32_t* n_nbr_out, int32_t g, int32_t chunks, uint32_t* fl_out,
-                                    int32_t* deg_out, float* xs4_out, const chx_build_riders_t* riders,
-                                    chx_stream_t stream) {
+static int riders_to_bin(const chx_build_riders_t* riders, BinRiders* rd) {
+  *rd = BinRiders{};
+  if (riders == nullptr) return CHX_OK;
+  rd->xyz_copy = riders->xyz_copy_out;
+  if (riders->x4_out != nullptr) {
+    CHX_REQUIRE(riders->v3 && riders->mass && riders->v_out && riders->mass_out, "pack rider: null pointer");
+    rd->v3 = riders->v3;
+    rd->mass = riders->mass;
+    rd->ref3 = riders->ref3;
+    rd->x4 = reinterpret_cast<float4*>(riders->x4_out);
+    rd->v = riders->v_out;
+    rd->mass_out = riders->mass_out;
+    rd->ref4 = reinterpret_cast<float4*>(riders->ref4_out);
+  }
+  rd->ctrl = riders->ctrl_reset;
+  rd->ctrl_keep = riders->ctrl_keep;
+  return CHX_OK;
+}
+
+// first half of chx_nl_build_cell_fl: the binning launches (and their riders)
+extern "C" int chx_cell_bin_fl(const float* xyz, int32_t n, chx_box_t box, float cutoff_plus_skin, const int32_t* nc_h,
+                               int32_t* cell_of, int32_t* cell_count, int32_t* cell_start, uint32_t* sorted_ids,
+                               int32_t* status8, float* xs4_out, const chx_build_riders_t* riders, chx_stream_t stream) {
+  CHX_REQUIRE(n >= 1, "need n >= 1");
+  CHX_REQUIRE(xyz && nc_h && cell_of && cell_count && cell_start && sorted_ids && status8 && xs4_out, "null pointer");
+  BinRiders rd;
+  int rc = riders_to_bin(riders, &rd);
+  if (rc != CHX_OK) return rc;
+  CellGrid grid;
+  rc = chx_cell_prepare(xyz, n, box, cutoff_plus_skin, nc_h, cell_of, cell_count, cell_start, sorted_ids, status8, 8, &grid,
+                        chx_stream(stream), xs4_out, &rd);  // (the cell sort also emits xs4)
+  if (rc != CHX_OK) return rc;
+  return chx_check_launch("chx_cell_bin_fl");
+}
+
+// second half: the rows (half list + force list) from the binned particles, the summary and its publish
+extern "C" int chx_nl_rows_cell_fl(int32_t n, int32_t m, chx_box_t box, float cutoff_plus_skin, const int32_t* nc_h,
+                                   const int32_t* cell_of, const int32_t* cell_start, const uint32_t* sorted_ids,
+                                   int32_t* status8, const float* xs4, uint32_t* nl_rows_out, uint32_t* first_out,
+                                   int32_t* n_nbr_out, int32_t g, int32_t chunks, uint32_t* fl_out, int32_t* deg_out,
+                                   int32_t* publish_host_dst8, chx_stream_t stream) {
   CHX_REQUIRE(n >= 1 && m >= 1, "need n >= 1, m >= 1");
-  CHX_REQUIRE(xyz && nc_h && cell_of && cell_count && cell_start && sorted_ids && status8 &&
-                  nl_rows_out && first_out && n_nbr_out && fl_out && deg_out && xs4_out,
+  CHX_REQUIRE(nc_h && cell_of && cell_start && sorted_ids && status8 && xs4 && nl_rows_out && first_out && n_nbr_out &&
+                  fl_out && deg_out,
               "null pointer");
   CHX_REQUIRE(g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64,
               "g must be a power of two <= 64");
   CHX_REQUIRE(chunks >= 1 && (int64_t)chunks * CHX_FL_QUAD * g < (1 << 20), "bad force-list capacity");
+  CHX_REQUIRE(box.periodic && box.lx > 0 && box.ly > 0 && box.lz > 0, "periodic box required");
+  CHX_REQUIRE(nc_h[0] >= 3 && nc_h[1] >= 3 && nc_h[2] >= 3 && nc_h[0] <= 1024 && nc_h[1] <= 1024 && nc_h[2] <= 1024,
+              "need 3 .. 1024 cells per axis");
   hipStream_t st = chx_stream(stream);
   CellGrid grid;
-  BinRiders rd = {};
-  int32_t* publish_host = nullptr;
-  if (riders != nullptr) {
-    rd.xyz_copy = riders->xyz_copy_out;
-    if (riders->x4_out != nullptr) {
-      CHX_REQUIRE(riders->v3 && riders->mass && riders->v_out && riders->mass_out, "pack rider: null pointer");
-      rd.v3 = riders->v3;
-      rd.mass = riders->mass;
-      rd.ref3 = riders->ref3;
-      rd.x4 = reinterpret_cast<float4*>(riders->x4_out);
-      rd.v = riders->v_out;
-      rd.mass_out = riders->mass_out;
-      rd.ref4 = reinterpret_cast<float4*>(riders->ref4_out);
-    }
-    rd.ctrl = riders->ctrl_reset;
-    rd.ctrl_keep = riders->ctrl_keep;
-    publish_host = riders->publish_host_dst8;
-  }
-  int rc = chx_cell_prepare(xyz, n, box, cutoff_plus_skin, nc_h, cell_of, cell_count, cell_start,
-                            sorted_ids, status8, 8, &grid, st, xs4_out, &rd);  // (the cell sort also emits xs4)
-  if (rc != CHX_OK) return rc;
+  grid.ncx = nc_h[0]; grid.ncy = nc_h[1]; grid.ncz = nc_h[2];
+  grid.sx = (float)nc_h[0] / box.lx; grid.sy = (float)nc_h[1] / box.ly; grid.sz = (float)nc_h[2] / box.lz;
   const float T = chx_cutoff_threshold_h(cutoff_plus_skin);
   const unsigned wb = (unsigned)(((int64_t)n * CHX_WAVE + 255) / 256);
-  float4* xs4 = reinterpret_cast<float4*>(xs4_out);
+  const float4* xs = reinterpret_cast<const float4*>(xs4);
   // One wavefront per particle, or -- when there are enough cells to fill the chip with one wavefront each -- one
   // per cell, the cell's particles sharing their candidate scan (measured: N = 262144 / 27000 cells 355 -> 263 us;
   // N = 32768 / 3375 cells 51 -> 83 us, or 51 -> 51 with four wavefronts per cell: too few, too long wavefronts
@@ -496,7 +514,7 @@ extern "C" int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_
   static const int forced = [] { const char* e = getenv("CHX_BUILD_KERNEL"); return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'c' ? 2 : 0)); }();
   const bool per_particle = forced == 1 || (forced == 0 && (int64_t)grid.ncx * grid.ncy * grid.ncz < 8192);
   if (per_particle) {
-    hipLaunchKernelGGL(k_nl_build_cell_fl, dim3(wb), dim3(256), 0, st, xs4, n, m, make_box3(box), T, grid,
+    hipLaunchKernelGGL(k_nl_build_cell_fl, dim3(wb), dim3(256), 0, st, xs, n, m, make_box3(box), T, grid,
                        cell_of, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, chunks * CHX_FL_QUAD * g,
                        fl_out, deg_out, status8);
   } else {
@@ -505,13 +523,36 @@ extern "C" int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_
     int split = split_env > 0 ? split_env : (8192 + ncell - 1) / ncell;  // (only > 1 when the kernel is forced)
     split = split < 1 ? 1 : (split > 16 ? 16 : split);
     const unsigned cb = (unsigned)(((int64_t)ncell * split * CHX_WAVE + 255) / 256);
-    hipLaunchKernelGGL(k_nl_build_cellwise_fl, dim3(cb), dim3(256), 0, st, xs4, n, m, make_box3(box), T, grid, ncell,
+    hipLaunchKernelGGL(k_nl_build_cellwise_fl, dim3(cb), dim3(256), 0, st, xs, n, m, make_box3(box), T, grid, ncell,
                        split, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, chunks * CHX_FL_QUAD * g,
                        fl_out, deg_out, status8);
   }
   const unsigned sb = (unsigned)((n + 255) / 256 < 64 ? (n + 255) / 256 : 64);
-  hipLaunchKernelGGL(k_build_epilogue, dim3(sb), dim3(256), 0, st, n_nbr_out, deg_out, n, m, status8, publish_host);
-  return chx_check_launch("chx_nl_build_cell_fl");
+  hipLaunchKernelGGL(k_build_epilogue, dim3(sb), dim3(256), 0, st, n_nbr_out, deg_out, n, m, status8, publish_host_dst8);
+  return chx_check_launch("chx_nl_rows_cell_fl");
+}
+
+extern "C" int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_box_t box,
+                                    float cutoff_plus_skin, const int32_t* nc_h, int32_t* cell_of,
+                                    int32_t* cell_count, int32_t* cell_start, uint32_t* sorted_ids,
+                                    int32_t* status8, uint32_t* nl_rows_out, uint32_t* first_out,
+                                    int32_t* n_nbr_out, int32_t g, int32_t chunks, uint32_t* fl_out,
+                                    int32_t* deg_out, float* xs4_out, const chx_build_riders_t* riders,
+                                    chx_stream_t stream) {
+  // (argument checks of both halves up front: nothing is launched for a call that the second half would refuse)
+  CHX_REQUIRE(n >= 1 && m >= 1, "need n >= 1, m >= 1");
+  CHX_REQUIRE(xyz && nc_h && cell_of && cell_count && cell_start && sorted_ids && status8 &&
+                  nl_rows_out && first_out && n_nbr_out && fl_out && deg_out && xs4_out,
+              "null pointer");
+  CHX_REQUIRE(g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64,
+              "g must be a power of two <= 64");
+  CHX_REQUIRE(chunks >= 1 && (int64_t)chunks * CHX_FL_QUAD * g < (1 << 20), "bad force-list capacity");
+  int rc = chx_cell_bin_fl(xyz, n, box, cutoff_plus_skin, nc_h, cell_of, cell_count, cell_start, sorted_ids, status8, xs4_out,
+                           riders, stream);
+  if (rc != CHX_OK) return rc;
+  return chx_nl_rows_cell_fl(n, m, box, cutoff_plus_skin, nc_h, cell_of, cell_start, sorted_ids, status8, xs4_out,
+                             nl_rows_out, first_out, n_nbr_out, g, chunks, fl_out, deg_out,
+                             riders ? riders->publish_host_dst8 : nullptr, stream);
 }
 
 // padding (chiron/neighbors.py:603-620) and list mask (:623) for rows that hold only their real entries

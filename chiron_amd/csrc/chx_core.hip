@@ -326,3 +326,17 @@ extern "C" int chx_jax_normal(uint32_t k0, uint32_t k1, int64_t count, float* ou
                      out);
   return chx_check_launch("chx_jax_normal");
 }
+
+// Philox4x32-10 on the host (same constants and round structure as chx_common.h: philox4x32)
+extern "C" void chx_philox4x32_h(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                 uint32_t* out4_h) {
+  if (!out4_h) return;
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+    k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+  }
+  out4_h[0] = c0, out4_h[1] = c1, out4_h[2] = c2, out4_h[3] = c3;
+}

@@ -115,6 +115,10 @@ int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, in
   a.snap4 = deferred ? reinterpret_cast<const float4*>(p->snap4) : nullptr;
   a.ev_log = deferred ? p->ev_log : nullptr;
   a.ev_cap = deferred ? p->ev_log_cap : 0;
+  // (only the force-only launch that ends a run writes the user-order copies)
+  a.x3_out = do_aoa ? nullptr : p->final_x3;
+  a.v3_out = do_aoa ? nullptr : p->final_v3;
+  a.ref3_out = do_aoa ? nullptr : p->final_ref3;
   const bool throttle = window > 0 && a.host_ctrl != nullptr;
   const PollPolicy poll = poll_policy();
   for (int i = 0; i < n_steps; ++i) {

@@ -701,9 +701,9 @@ __device__ __forceinline__ StepParticle load_step_operands(const StepArgs& a, lo
       t.m = t.ref.w;
     }
     if (DEFER && do_aoa) t.snap = a.snap4[t.pp];
-    // (a reference rebuild event of the deferred scheme copies the input positions into ref4 even in the force-only
-    // launch that ends a run)
-    if (do_aoa || DEFER) t.x = a.x_cur[t.pp];
+    // (a reference rebuild event of the decoupled scheme copies the input positions into ref4 even in the force-only
+    // launch that ends a run; so does that launch's user-order copy of the final state)
+    if (do_aoa || DEFER || (!HOT && a.x3_out != nullptr)) t.x = a.x_cur[t.pp];
     if (do_aoa) {
       // the path travelled since the last pruning pass rides in x4.w; a pruning launch starts it over
       t.path0 = PRUNE ? 0.f : t.x.w;
@@ -779,6 +779,17 @@ __device__ __forceinline__ bool step_epilogue(const StepArgs& a, const StepParti
     store_wt3(a.v + 3 * (size_t)tk.pp, vn[0], vn[1], vn[2]);
     // the reference's rebuild (its side effect on the state): reference positions := this launch's input positions
     if (ev) store_wt4(a.ref4 + tk.pp, make_float4(tk.x.x, tk.x.y, tk.x.z, tk.m));
+    if (!HOT && !do_aoa && (a.x3_out != nullptr || a.v3_out != nullptr || a.ref3_out != nullptr)) {
+      // the run's last launch: the state it leaves, in USER order (what chx_unpack_langevin would copy out behind it)
+      const size_t o = 3 * (size_t)(a.perm ? a.perm[tk.pp] : (uint32_t)tk.pp);
+      if (a.v3_out != nullptr) a.v3_out[o] = vn[0], a.v3_out[o + 1] = vn[1], a.v3_out[o + 2] = vn[2];
+      if (a.x3_out != nullptr) a.x3_out[o] = tk.x.x, a.x3_out[o + 1] = tk.x.y, a.x3_out[o + 2] = tk.x.z;
+      if (a.ref3_out != nullptr) {
+        a.ref3_out[o] = ev ? tk.x.x : tk.ref.x;
+        a.ref3_out[o + 1] = ev ? tk.x.y : tk.ref.y;
+        a.ref3_out[o + 2] = ev ? tk.x.z : tk.ref.z;
+      }
+    }
     if (do_aoa) {
       // x4.w: path length since the last pruning pass (a sum of per-step displacements bounds the displacement)
       const float path = tk.path0 + __builtin_sqrtf((sqi[0] + sqi[1]) + sqi[2]);

@@ -43,6 +43,10 @@ struct StepArgs {
   const float4* snap4;  // positions the force list was built from
   int32_t* ev_log;
   int ev_cap;
+  // the run's last (force-only) launch also writes the state in user order (chx_langevin_t::final_x3 ...); NULL = off
+  float* x3_out;
+  float* v3_out;
+  float* ref3_out;
 };
 
 // One fused [pair force + BAOAB + wrap + skin check] launch on the force list with g lanes per particle (k_lj_step);

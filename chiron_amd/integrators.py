@@ -827,9 +827,10 @@ class _RunState:
         self.ctrl[8:10].copy_(fix)
 
     # -- fused neighbor-list path, bounded launch queue --------------------------------------------
-    def _enqueue_window(self, s0: int, n: int) -> int:
+    def _enqueue_window(self, s0: int, n: int, unthrottled: bool = False) -> int:
         even, odd = (self.x_a, self.x_b) if self.parity == 0 else (self.x_b, self.x_a)
-        sent = ops.langevin_fused_run(self.params, even, odd, s0, n, self.kicks_next, max(1, int(self.integ.launch_window)))
+        window = (1 << 20) if unthrottled else max(1, int(self.integ.launch_window))
+        sent = ops.langevin_fused_run(self.params, even, odd, s0, n, self.kicks_next, window)
         if sent:
             self.parity ^= sent & 1
             self.kicks_next = 2
@@ -837,17 +838,27 @@ class _RunState:
 
     def _enqueue_kick(self, step: int, with_state: bool = False):
         """Force + trailing half-kick (chiron/integrators.py:195) as launch ``step``: a no-op if the skin check
-        has fired by then, like every launch of the generation.  ``with_state``: the copy of positions and velocities
-        back to user order that ends a run() is enqueued right behind it, before the host waits (it is void, and
-        taken again, in the rare case that the kick turns out to have been a no-op)."""
+        has fired by then, like every launch of the generation.  ``with_state``: the launch also writes positions and
+        velocities in user order -- what run() returns -- instead of a copy-out launch behind it (void, and taken
+        again, in the rare case that the kick turns out to have been a no-op)."""
         even, odd = (self.x_a, self.x_b) if self.parity == 0 else (self.x_b, self.x_a)
-        ops.langevin_fused_chunk(self.params, even, odd, step, 1, 1, 0)
-        self._final_state = self.state_user() if with_state else None
-        # (list carry-over: the reference positions the caller's list will be rebuilt from, should anybody read it)
-        self._final_ref = self._unpack(self.ref4) if with_state and self._carried is not None else None
+        p = self.params
+        if with_state:
+            f32 = dict(dtype=torch.float32, device=self.dev)
+            x3, v3 = torch.empty((self.n, 3), **f32), torch.empty((self.n, 3), **f32)
+            # (list carry-over: the reference positions the caller's list will be rebuilt from, should anybody read it)
+            r3 = torch.empty((self.n, 3), **f32) if self._carried is not None else None
+            p.final_x3, p.final_v3 = x3.data_ptr(), v3.data_ptr()
+            p.final_ref3 = r3.data_ptr() if r3 is not None else None
+        try:
+            ops.langevin_fused_chunk(p, even, odd, step, 1, 1, 0)
+        finally:
+            p.final_x3 = p.final_v3 = p.final_ref3 = None
+        self._final_state = (x3, v3) if with_state else None
+        self._final_ref = r3 if with_state else None
         work, self._host_tail = getattr(self, "_host_tail", None), None
         if work is not None:
-            work()  # (see LangevinIntegrator.run: the launches above are still queued; its device copy is behind them)
+            work()  # (see LangevinIntegrator.run: the launches above are still queued)
         ev = torch.cuda.Event()
         ev.record()  # (the last thing on the stream: a caller's device-wide synchronize then finds nothing pending)
         ev.synchronize()
@@ -862,8 +873,19 @@ class _RunState:
         while True:
             while enq < stop:
                 c = min(chunk, stop - enq)
-                sent = self._enqueue_window(enq, c)
+                # The last launches of a segment go out without throttling: the window exists to keep the no-op launches
+                # behind a halt few (a list lasts ~200 steps, so one segment tail in seven holds a halt, which then
+                # drains up to `chunk` no-ops instead of ~8: +50 us), while a throttled tail makes EVERY segment end with
+                # the host asleep in the window and the closing launches -- kick, copy-out -- enqueued late, behind an
+                # idle device (measured, round 4: 7-13 us gaps in front of each at the end of a 20-step run()).
+                sent = self._enqueue_window(enq, c, unthrottled=(stop - enq <= chunk))
                 enq += sent
+                work = getattr(self, "_host_tail", None)
+                if work is not None and sent > 0:
+                    # host work of the run's END that does not depend on the steps (the key and the box the returned
+                    # state carries) is done here, with a queue of launches in front of the device
+                    self._host_tail = None
+                    work()
                 if sent < c:
                     break  # the launch loop saw the halt word
                 pend = getattr(self, "_unsettled", None)

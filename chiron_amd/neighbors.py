@@ -348,7 +348,10 @@ class NeighborListNsqrd(PairsBase):
         if self._fl_geo[0] != n or positions.dtype != torch.float32 or not positions.is_cuda or not positions.is_contiguous():
             return False
         cs = self._cs_md
-        ncell, nc = ops.cell_grid(self._box_h, cs, n)
+        gc = self.__dict__.get("_grid_cache")  # (the grid is a function of the box object, cutoff + skin and n)
+        if gc is None or gc[0] is not self._box_h or gc[1] != cs or gc[2] != n:
+            gc = self._grid_cache = (self._box_h, cs, n) + tuple(ops.cell_grid(self._box_h, cs, n))
+        ncell, nc = gc[3], gc[4]
         if ncell <= 0:
             return False
         m = int(self.n_max_neighbors)
@@ -558,7 +561,7 @@ class NeighborListNsqrd(PairsBase):
                 new._force_list = None  # rebuilt lazily; it is a pure function of the list
             elif k == "_scratch":
                 new._scratch = None  # kernel work arrays are not part of the list
-            elif k in ("_spec", "_status_host"):
+            elif k in ("_spec", "_status_host", "_grid_cache"):
                 setattr(new, k, None)
             elif k in ("_spec_event",):
                 continue  # plumbing of the speculative rebuild: the copy starts without any

@@ -171,12 +171,7 @@ def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: in
     n = xyz.shape[0]
     dev = xyz.device
     i32 = dict(dtype=torch.int32, device=dev)
-    nl = torch.empty((n, m), **i32)
-    first = torch.empty((n,), **i32)
-    n_nbr = torch.empty((n,), **i32)
     sorted_ids = torch.empty((n,), **i32)
-    fl = torch.empty((chunks, n, FL_QUAD * g), **i32)
-    deg = torch.empty((n,), **i32)
     key = (n, ncell, str(dev))
     if scratch is not None and scratch.get("key") == key:
         cell_of, cell_count, cell_start, status, xs4 = scratch["arrays"]
@@ -189,6 +184,7 @@ def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: in
         if scratch is not None:
             scratch["key"], scratch["arrays"] = key, (cell_of, cell_count, cell_start, status, xs4)
     rd = None
+    publish = None
     if riders:
         rd = _lib.BuildRiders()
         cp = riders.get("copy")
@@ -212,14 +208,26 @@ def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: in
         if pb is not None:
             if not pb.is_pinned():
                 raise _lib.ChxError("publish needs a pinned (host-mapped) destination tensor")
-            rd.publish_host_dst8 = pb.data_ptr()
+            publish = C.c_void_p(pb.data_ptr())
+    lib = _lib.load()
+    stream = _stream()
+    cs = C.c_float(cutoff_plus_skin)
+    # the binning launches go to the device FIRST; the arrays the rows go into are allocated while they run (at the entry
+    # of a short run() the device idles until the first launch is made: include/chx.h, chx_cell_bin_fl)
     check(
-        _lib.load().chx_nl_build_cell_fl(
-            _ptr(xyz), n, m, box, C.c_float(cutoff_plus_skin), nc, _ptr(cell_of), _ptr(cell_count), _ptr(cell_start),
-            _ptr(sorted_ids), _ptr(status), _ptr(nl), _ptr(first), _ptr(n_nbr), g, chunks, _ptr(fl), _ptr(deg),
-            _ptr(xs4), C.byref(rd) if rd is not None else None, _stream(),
-        ),
-        "chx_nl_build_cell_fl",
+        lib.chx_cell_bin_fl(_ptr(xyz), n, box, cs, nc, _ptr(cell_of), _ptr(cell_count), _ptr(cell_start), _ptr(sorted_ids),
+                            _ptr(status), _ptr(xs4), C.byref(rd) if rd is not None else None, stream),
+        "chx_cell_bin_fl",
+    )
+    nl = torch.empty((n, m), **i32)
+    first = torch.empty((n,), **i32)
+    n_nbr = torch.empty((n,), **i32)
+    fl = torch.empty((chunks, n, FL_QUAD * g), **i32)
+    deg = torch.empty((n,), **i32)
+    check(
+        lib.chx_nl_rows_cell_fl(n, m, box, cs, nc, _ptr(cell_of), _ptr(cell_start), _ptr(sorted_ids), _ptr(status), _ptr(xs4),
+                                _ptr(nl), _ptr(first), _ptr(n_nbr), g, chunks, _ptr(fl), _ptr(deg), publish, stream),
+        "chx_nl_rows_cell_fl",
     )
     return nl, first, n_nbr, sorted_ids, fl, deg, status
 

@@ -33,7 +33,37 @@ STREAM_UNIFORM = 3
 STREAM_SPLIT = 0x5EED
 
 
+_fast = None  # (callable, out buffer) once libchx is loaded: chx_philox4x32_h, 1 us instead of 7
+
+
+def _bind_fast():
+    """The library's host Philox (include/chx.h: chx_philox4x32_h) in place of the Python loop below: key handling
+    (split / fold_in / uniform) sits on the entry and exit path of every short run() call.  Same bits (tested)."""
+    global _fast
+    import ctypes
+
+    from . import _lib
+
+    try:
+        fn = _lib.load().chx_philox4x32_h
+    except Exception:  # (no library: the pure-Python rounds below are the definition anyway)
+        _fast = False
+        return
+    _fast = (fn, (ctypes.c_uint32 * 4)())
+
+
 def philox4x32(counter: Tuple[int, int, int, int], key: Tuple[int, int]) -> Tuple[int, int, int, int]:
+    if _fast is None:
+        _bind_fast()
+    if _fast:
+        fn, out = _fast
+        fn(int(counter[0]) & _MASK, int(counter[1]) & _MASK, int(counter[2]) & _MASK, int(counter[3]) & _MASK,
+           int(key[0]) & _MASK, int(key[1]) & _MASK, out)
+        return out[0], out[1], out[2], out[3]
+    return philox4x32_py(counter, key)
+
+
+def philox4x32_py(counter: Tuple[int, int, int, int], key: Tuple[int, int]) -> Tuple[int, int, int, int]:
     c0, c1, c2, c3 = (int(c) & _MASK for c in counter)
     k0, k1 = (int(k) & _MASK for k in key)
     for _ in range(10):

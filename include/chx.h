@@ -53,7 +53,9 @@ typedef void* chx_stream_t;
  *      watch_trigger argument of
  *      chx_langevin_fused_run and the max_blocks argument of chx_nl_build_cell_fl.  Both cell builds now expect
  *      cell_count zeroed on entry and leave it zeroed; chx_nl_build_cell_fl takes a chx_build_riders_t* (copy of the
- *      positions, packed Langevin state, control-block reset, status publish: see there). */
+ *      positions, packed Langevin state, control-block reset, status publish: see there).  chx_langevin_t grew
+ *      final_x3 / final_v3 / final_ref3 (the run's last launch writes the state in user order).  Added:
+ *      chx_philox4x32_h. */
 #define CHX_ABI_VERSION 3
 
 /* high bit of a force-list entry: neighbor has the HIGHER original particle id */
@@ -75,6 +77,11 @@ const char* chx_source_hash(void);
  * (ctypes, cgo, JNI) assert their own layout against these at load time. */
 int64_t chx_sizeof_langevin_t(void);
 int64_t chx_sizeof_mc_t(void);
+
+/* Philox4x32-10 on the host (the generator every device stream of this library draws from; Random123 known answers in
+ * the tests): out4_h = philox(counter (c0..c3), key (k0, k1)).  Key handling of the bindings (split, fold_in, uniform)
+ * is built on it. */
+void chx_philox4x32_h(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out4_h);
 
 /* Largest fp32 t with sqrtf(t) < c (host helper, exact).  `d < c` on the
  * reference's d = sqrt(r2) is then equivalent to `r2 <= T` (neighbors.py:600-602,
@@ -157,6 +164,19 @@ int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_box_t box, 
                          uint32_t* nl_rows_out, uint32_t* first_out, int32_t* n_nbr_out, int32_t g,
                          int32_t chunks, uint32_t* fl_out, int32_t* deg_out, float* xs4_out,
                          const chx_build_riders_t* riders, chx_stream_t stream);
+/* The same build in two calls, for a caller that wants the binning launches on the device before it has allocated the
+ * arrays the rows go into (the integrator's run() entry: the device idles until the first launch is made):
+ * chx_cell_bin_fl = the binning launches with the riders (publish_host_dst8 is ignored here), chx_nl_rows_cell_fl = the
+ * row kernel and the summary, which publishes status8 to publish_host_dst8 when that is given.  Same arguments, same
+ * contracts, same bits as the one call. */
+int chx_cell_bin_fl(const float* xyz, int32_t n, chx_box_t box, float cutoff_plus_skin, const int32_t* nc_h,
+                    int32_t* cell_of, int32_t* cell_count, int32_t* cell_start, uint32_t* sorted_ids,
+                    int32_t* status8, float* xs4_out, const chx_build_riders_t* riders, chx_stream_t stream);
+int chx_nl_rows_cell_fl(int32_t n, int32_t m, chx_box_t box, float cutoff_plus_skin, const int32_t* nc_h,
+                        const int32_t* cell_of, const int32_t* cell_start, const uint32_t* sorted_ids,
+                        int32_t* status8, const float* xs4, uint32_t* nl_rows_out, uint32_t* first_out,
+                        int32_t* n_nbr_out, int32_t g, int32_t chunks, uint32_t* fl_out, int32_t* deg_out,
+                        int32_t* publish_host_dst8, chx_stream_t stream);
 int chx_nl_finish_padding(uint32_t* nl_inout, const uint32_t* first, const int32_t* n_nbr, int32_t n,
                           int32_t m, int32_t* nl_mask_out, chx_stream_t stream);
 
@@ -357,6 +377,15 @@ typedef struct {
   const float* snap4;     /* (n,4) positions the force list was built from, internal order (.w is not read) */
   int32_t ev_log_cap;
   int32_t* ev_log;
+  /* Optional outputs of the FORCE-ONLY launch that ends a run (chx_langevin_fused_chunk with do_aoa == 0; ignored by
+   * every other launch): the final state in USER order, written by that launch itself instead of by a
+   * chx_unpack_langevin launch behind it -- final_x3[perm[p]] = x[p].xyz, final_v3[perm[p]] = v[p] after the trailing
+   * kick (chiron/integrators.py:195, :210-214), final_ref3[perm[p]] = ref4[p].xyz as the launch leaves it (decoupled
+   * force list: the reference positions the caller's list is to be rebuilt from).  Each may be NULL.  Void when the
+   * launch turned out to be a no-op (halt word <= its step): the caller checks the halt word as for any launch. */
+  float* final_x3;
+  float* final_v3;
+  float* final_ref3;
 } chx_langevin_t;
 
 #define CHX_CTRL_WORDS 16

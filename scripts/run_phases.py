@@ -37,6 +37,9 @@ wrap(I._RunState, "_load", "1b _load entered", "before")
 wrap(I._RunState, "_open_generation", "1c generation opened")
 wrap(I._RunState, "__init__", "2 state packed (pack enqueued)")
 wrap(I._RunState, "_enqueue_window", "3 first steps enqueued", "before")
+wrap(I._RunState, "_enqueue_window", "3a first window call returned")
+wrap(I._RunState, "_enqueue_kick", "3b kick being enqueued", "before")
+wrap(torch.cuda.Event, "synchronize", "3c waiting for the device", "before")
 wrap(I._RunState, "final_kick", "4 kick done (device drained)")
 wrap(I._RunState, "state_user", "5 state unpacked (enqueued)")
 wrap(I._RunState, "finish", "5a finish() done")

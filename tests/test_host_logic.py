@@ -94,6 +94,21 @@ def test_prng_keys():
     assert philox4x32((0, 0, 0, 0), (0, 0)) == (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)
 
 
+def test_host_philox_c_helper_and_python_rounds_agree():
+    """chiron_amd.rng.philox4x32 goes through the library's host helper (include/chx.h: chx_philox4x32_h) once it is
+    loaded; the Python rounds stay the definition.  Same bits on the Random123 vectors and on random blocks."""
+    from chiron_amd import rng
+
+    rng.philox4x32((0, 0, 0, 0), (0, 0))
+    assert rng._fast, "libchx is built in this tree: the C helper must have been bound"
+    r = np.random.default_rng(3)
+    for _ in range(500):
+        c = tuple(int(v) for v in r.integers(0, 2**32, 4))
+        k = tuple(int(v) for v in r.integers(0, 2**32, 2))
+        assert rng.philox4x32(c, k) == rng.philox4x32_py(c, k)
+    assert rng.philox4x32_py((0xFFFFFFFF,) * 4, (0xFFFFFFFF, 0xFFFFFFFF)) == (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)
+
+
 def test_host_philox_matches_oracle():
     from oracle import chiron_oracle as O
 
@@ -284,7 +299,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.chx_version() == _lib.ABI_VERSION == 3
     # struct layouts agree with the header (x86-64 SysV)
     assert ctypes.sizeof(_lib.Box) == 16
-    assert ctypes.sizeof(_lib.LangevinParams) == 248 == lib.chx_sizeof_langevin_t()
+    assert ctypes.sizeof(_lib.LangevinParams) == 272 == lib.chx_sizeof_langevin_t()
     assert _lib.LangevinParams.host_ctrl.offset == 216 and _lib.LangevinParams.snap4.offset == 224
     assert _lib.LangevinParams.ev_log_cap.offset == 232 and _lib.LangevinParams.ev_log.offset == 240
     assert _lib.LangevinParams.fl_inner.offset == 176 and _lib.LangevinParams.prune_phase.offset == 208
