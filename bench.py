@@ -76,6 +76,12 @@ def parse():
     ap.add_argument("--clock-warmup-s", type=float, default=3.0,
                     help="seconds of untimed stepping in front of the --warmup steps: the card's graphics clock takes "
                          "0-2 s of load to leave its idle level (scripts/mode_probe.py), 10 %% in steps/s")
+    ap.add_argument("--requalify", type=int, default=1,
+                    help="launcher (--gpus N without a torchrun environment): every rank measures its stand-alone rate "
+                         "before it joins the process group and the launcher replaces ranks below 0.97 x the median by "
+                         "fresh processes (at most twice); 0 = start the ranks as they come")
+    ap.add_argument("--qualify-seconds", type=float, default=1.0,
+                    help="stand-alone stepping in front of the three rate windows of the requalification")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend of the real run (nccl = RCCL over xGMI; gloo only for rehearsals)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -87,28 +93,137 @@ def parse():
     return ap.parse_args()
 
 
+QUALIFY_RATIO = 0.97      # a rank whose stand-alone rate is below this fraction of the ranks' median is replaced
+QUALIFY_MAX_REPLACEMENTS = 2  # per rank
+
+
+class _RankChild:
+    """One rank of the launcher: a fresh child interpreter of this script plus the two pipes of the requalification
+    protocol (child -> parent: its stand-alone rate; parent -> child: "go")."""
+
+    def __init__(self, args, rank: int, port: int, attempt: int, qualify: bool):
+        import subprocess
+
+        self.rank, self.attempt, self.rate = rank, attempt, None
+        env = dict(os.environ)
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CHX_BENCH_ATTEMPT=str(attempt))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this host driver
+        fds = ()
+        self.report_r = self.go_w = None
+        if qualify:
+            self.report_r, report_w = os.pipe()
+            go_r, self.go_w = os.pipe()
+            env["CHX_BENCH_QUALIFY_FDS"] = f"{report_w},{go_r}"
+            fds = (report_w, go_r)
+        self.proc = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, pass_fds=fds)
+        for fd in fds:
+            os.close(fd)
+
+    def read_rate(self, timeout_s: float):
+        """The child's stand-alone steps/s (one line on the report pipe), or None if it died / timed out."""
+        import select
+
+        buf = b""
+        t_end = time.time() + timeout_s
+        while time.time() < t_end and b"\n" not in buf:
+            if self.proc.poll() is not None and not select.select([self.report_r], [], [], 0)[0]:
+                return None
+            if select.select([self.report_r], [], [], 0.1)[0]:
+                chunk = os.read(self.report_r, 256)
+                if not chunk:
+                    return None
+                buf += chunk
+        try:
+            self.rate = float(buf.split(b"\n")[0])
+        except ValueError:
+            self.rate = None
+        return self.rate
+
+    def release(self, summary: dict):
+        os.write(self.go_w, (json.dumps(summary) + "\n").encode())
+        os.close(self.go_w)
+        os.close(self.report_r)
+
+    def discard(self):
+        """Replace, never re-exec: the child is told to go away and a FRESH interpreter takes its rank."""
+        self.proc.terminate()
+        try:
+            self.proc.wait(timeout=20)
+        except Exception:  # pragma: no cover
+            self.proc.kill()
+        for fd in (self.go_w, self.report_r):
+            try:
+                os.close(fd)
+            except OSError:
+                pass
+
+
+def requalify(children, spawn, ratio: float = QUALIFY_RATIO, max_replacements: int = QUALIFY_MAX_REPLACEMENTS,
+              timeout_s: float = 300.0):
+    """Rate-based rank requalification (round-3 review item 4).  One fresh process in eight launches 3-12 % slower for
+    its whole life (the HIP runtime's slow launch regime, profiles/r03_launch_regime.md), and behind a barrier the
+    slowest of N ranks sets the pace.  The regime shows in a rank's own stand-alone rate within a second, so every child
+    measures that rate BEFORE it joins the process group and parks; the parent replaces any rank below `ratio` x the
+    median of the ranks' rates with a fresh child (at most `max_replacements` times per rank), then releases all of them.
+    `children`: list of objects with .rank / .read_rate(timeout) / .discard(); `spawn(rank, attempt)` makes a new one.
+    Returns (children, log) with log = [{"rank", "attempt", "rate", "median", "replaced"}...]."""
+    log = []
+    rates = {c.rank: c.read_rate(timeout_s) for c in children}
+    attempts = {c.rank: 0 for c in children}
+    by_rank = {c.rank: c for c in children}
+    for _ in range(max_replacements):
+        known = sorted(v for v in rates.values() if v)
+        if not known:
+            break
+        median = known[len(known) // 2] if len(known) > 2 else known[-1]  # (two ranks: the faster one is the yardstick)
+        slow = [r for r, v in rates.items() if v and v < ratio * median and attempts[r] < max_replacements]
+        for r, v in rates.items():
+            log.append({"rank": r, "attempt": attempts[r], "rate": v, "median": median, "replaced": r in slow})
+        if not slow:
+            return [by_rank[r] for r in sorted(by_rank)], log
+        for r in slow:
+            by_rank[r].discard()
+            attempts[r] += 1
+            by_rank[r] = spawn(r, attempts[r])
+        for r in slow:
+            rates[r] = by_rank[r].read_rate(timeout_s)
+    known = sorted(v for v in rates.values() if v)
+    median = (known[len(known) // 2] if len(known) > 2 else known[-1]) if known else None
+    for r, v in rates.items():
+        log.append({"rank": r, "attempt": attempts[r], "rate": v, "median": median, "replaced": False})
+    return [by_rank[r] for r in sorted(by_rank)], log
+
+
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` started by hand (no RANK in the environment): become a launcher.
 
     Starts N fresh child interpreters of this script, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
-    MASTER_ADDR / MASTER_PORT as torchrun would set them), relays their output -- rank 0 prints the JSON
-    line -- and returns non-zero if any rank failed.  The launcher itself never initialises the GPU and
-    no process that has touched the GPU is ever re-exec'ed: children are ordinary subprocesses.
-    Replica loop being sharded: chiron/multistate.py:497-531.
+    MASTER_ADDR / MASTER_PORT as torchrun would set them), requalifies them by their stand-alone rate (`requalify`),
+    relays their output -- rank 0 prints the JSON line -- and returns non-zero if any rank failed.  The launcher
+    itself never initialises the GPU and no process that has touched the GPU is ever re-exec'ed: children are ordinary
+    subprocesses, and a replaced rank is a NEW subprocess.  Under torchrun there is no parent of ours and the ranks run
+    as they are started.  Replica loop being sharded: chiron/multistate.py:497-531.
     """
     import socket
-    import subprocess
 
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ)
-        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this host driver
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    qualify = bool(args.requalify)
+    spawn = lambda r, attempt: _RankChild(args, r, port, attempt, qualify)
+    children = [spawn(r, 0) for r in range(args.gpus)]
+    if qualify:
+        children, qlog = requalify(children, spawn)
+        replaced = [e for e in qlog if e["replaced"]]
+        summary = {"ratio": QUALIFY_RATIO, "replaced": [[e["rank"], e["attempt"], e["rate"]] for e in replaced],
+                   "final_rates": {str(c.rank): c.rate for c in children}}
+        for r, a, v in summary["replaced"]:
+            print(f"bench.py launcher: rank {r} (attempt {a}) ran {v:.0f} steps/s stand-alone, below {QUALIFY_RATIO} x the "
+                  f"median: replaced by a fresh process", file=sys.stderr, flush=True)
+        for c in children:
+            c.release(summary)
+    procs = [c.proc for c in children]
     rc = 0
     pending = dict(enumerate(procs))
     while pending:
@@ -124,6 +239,27 @@ def launch_ranks(args) -> int:
                     q.terminate()
         time.sleep(0.05)
     return rc
+
+
+def qualification_phase(measure):
+    """Child side of `requalify`: report this process's stand-alone rate and park until the parent says go.  Returns the
+    parent's summary (a dict), or None when this process was not started by the launcher with the protocol on.
+    `measure()` -> steps/s; it runs BEFORE the process joins any process group."""
+    spec = os.environ.get("CHX_BENCH_QUALIFY_FDS")
+    if not spec:
+        return None
+    report_w, go_r = (int(v) for v in spec.split(","))
+    rate = measure()
+    os.write(report_w, f"{rate:.3f}\n".encode())
+    os.close(report_w)
+    buf = b""
+    while b"\n" not in buf:
+        chunk = os.read(go_r, 4096)
+        if not chunk:  # the parent went away
+            raise SystemExit("bench.py: the launcher closed the requalification pipe")
+        buf += chunk
+    os.close(go_r)
+    return json.loads(buf.split(b"\n")[0])
 
 
 def make_system(workload: str, temperature_K: float, chunk: int, build: str):
@@ -417,7 +553,7 @@ def short_run_block(integ, thermo, state, nbr, k: int, calls: int = 200):
 def mc_block(args, trials: int = 4096):
     """The Metropolis half of the north star at the metric's configuration: MonteCarloDisplacementMove on the C3 fluid
     (chiron/mcmc.py:243-306, :357-463, :680-787) through the device-resident trial loop -- propose + skin check, energy
-    over the force list, decision at the head of the next proposal launch: two launches per trial, no host round trip.
+    over the force list, next proposal -- one launch per trial (k_mc_trial), no host round trip.
     The displacement is small enough (0.001 nm) that most trials are accepted and the list lasts; rebuild trials count."""
     import torch
 
@@ -438,7 +574,7 @@ def mc_block(args, trials: int = 4096):
         torch.cuda.synchronize()
         rates.append(trials / (time.perf_counter() - t0))
     st = move.statistics
-    return {"move": "MonteCarloDisplacementMove, sigma = 0.001 nm, all particles, device-resident trial loop (two launches per trial)",
+    return {"move": "MonteCarloDisplacementMove, sigma = 0.001 nm, all particles, device-resident trial loop (one launch per trial)",
             "n_particles": fluid.n_particles, "trials_per_s": round(sorted(rates)[1], 1), "trials_per_s_windows": [round(r, 1) for r in rates],
             "trials_per_window": trials, "acceptance": round(st["n_accepted"] / max(1, st["n_proposed"]), 4),
             "list_rebuilds_last_window": nbr.n_builds - builds0}
@@ -666,6 +802,13 @@ def dry_run(args, rank: int, world: int) -> None:
     from chiron_amd.states import ThermodynamicState
 
     torch.set_num_threads(1)
+
+    def fake_rate():
+        # rehearsal of the requalification protocol: CHX_BENCH_FAKE_RATES="rank:attempt=relative;..." (default 1.0)
+        table = dict(item.split("=") for item in os.environ.get("CHX_BENCH_FAKE_RATES", "").split(";") if "=" in item)
+        return 100000.0 * float(table.get(f"{rank}:{os.environ.get('CHX_BENCH_ATTEMPT', '0')}", "1.0"))
+
+    qual = qualification_phase(fake_rate)  # (before the process group exists: a replaced rank never joined anything)
     use_dist = world > 1 or "MASTER_ADDR" in os.environ
     if use_dist:
         dist.init_process_group(args.dry_run_backend, rank=rank, world_size=world)
@@ -703,7 +846,8 @@ def dry_run(args, rank: int, world: int) -> None:
             "config": {"workload": "dry run: no kernels, synthetic energies", "replicas": world,
                        "group_world_size": dist.get_world_size() if use_dist else 1, "ranks": ranks,
                        "replica_exchanges": exchanges, "exchange_interval_steps": args.exchange_interval,
-                       "state_of_replica": [int(v) for v in rex.state_of_replica]},
+                       "state_of_replica": [int(v) for v in rex.state_of_replica],
+                       "attempt": int(os.environ.get("CHX_BENCH_ATTEMPT", "0")), "requalification": qual},
         }), flush=True)
     if use_dist:
         dist.barrier()
@@ -743,6 +887,34 @@ def main():
     torch.set_num_threads(1)
     import torch.distributed as dist
 
+    # Requalification (launcher of this script only; `requalify`): this rank's stand-alone rate, measured BEFORE it
+    # joins the process group -- a rank that has drawn the runtime's slow launch regime is replaced by a fresh process
+    # by the parent while it is parked here, having joined nothing.
+    prebuilt, qual = None, None
+    if os.environ.get("CHX_BENCH_QUALIFY_FDS"):
+        from chiron_amd import _lib as _lib0
+
+        _lib0.load()
+        prebuilt = list(make_system(args.workload, 300.0 * (1.05 ** rank), args.chunk, args.build))
+
+        def measure():
+            fluid0, pot0, st0, th0, nb0, ig0 = prebuilt
+            ig0.list_carry = False
+            t_q = time.perf_counter()
+            while time.perf_counter() - t_q < args.qualify_seconds:
+                st0, nb0 = ig0.run(st0, th0, number_of_steps=2000, nbr_list=nb0)
+                torch.cuda.synchronize()
+            rates_q = []
+            for _ in range(3):
+                t_w = time.perf_counter()
+                st0, nb0 = ig0.run(st0, th0, number_of_steps=10000, nbr_list=nb0)
+                torch.cuda.synchronize()
+                rates_q.append(10000.0 / (time.perf_counter() - t_w))
+            prebuilt[2], prebuilt[4] = st0, nb0
+            return sorted(rates_q)[1]
+
+        qual = qualification_phase(measure)
+
     # under a launcher (RANK set) the process group is always created, also for one rank, so that the
     # RCCL path (init, barrier, all-reduce, all-gather) can be exercised on a single-GPU box
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
@@ -761,7 +933,7 @@ def main():
 
     _lib.load()
     temperature = 300.0 * (1.05 ** rank)
-    fluid, pot, state, thermo, nbr, integ = make_system(args.workload, temperature, args.chunk, args.build)
+    fluid, pot, state, thermo, nbr, integ = prebuilt or make_system(args.workload, temperature, args.chunk, args.build)
     n = fluid.n_particles
     ladder = [ThermodynamicState(pot, temperature=300.0 * (1.05 ** r) * unit.kelvin) for r in range(world)]
     rex = ReplicaExchange(ladder, PRNGKey(2024, 7), rank=rank, world_size=world)
@@ -943,6 +1115,7 @@ def main():
             "roofline_pair_force": roof_force,
         }
         out["config"]["list_carry_over"] = False
+        out["config"]["requalification"] = qual
         if world == 1:
             try:
                 state, nbr, out["short_run"] = short_run_block(integ, rex.my_state, state, nbr, args.steps if args.steps <= 64 else 20)

@@ -75,8 +75,8 @@ class McParams(C.Structure):
         ("g", C.c_int32),
         ("fl_chunks", C.c_int32),
         ("reserved", C.c_int32),
-        ("x_a", C.c_void_p),
-        ("x_b", C.c_void_p),
+        ("cur4", C.c_void_p),
+        ("prop4", C.c_void_p),
         ("ref4", C.c_void_p),
         ("perm", C.c_void_p),
         ("subset_mask", C.c_void_p),
@@ -95,6 +95,11 @@ class McParams(C.Structure):
         ("accept_log", C.c_void_p),
         ("energy_log", C.c_void_p),
         ("ws", C.c_void_p),
+        ("k0", C.c_uint32),
+        ("k1", C.c_uint32),
+        ("keytab", C.c_void_p),
+        ("keytab_h", C.c_void_p),
+        ("chain_out_h", C.c_void_p),
     ]
 
 
@@ -187,6 +192,7 @@ SIGNATURES = {
         C.c_int,
         [_P, _P, _I64, _P, _P, _P, _U32, _U32, _U32, _F, _P, _P, _P],
     ),
+    "chx_mc_key_chain_h": (C.c_int, [_U32, _U32, _I32, C.POINTER(_U32), C.POINTER(_U32)]),
     "chx_mc_displace_chunk": (C.c_int, [_P, _I64, _I32, _P]),
     "chx_lj_nl_energy_force": (C.c_int, [_P, _P, _P, _I32, _I32, Box, _F, _F, _F, _P, _P, _P, _P]),
     "chx_baoab_step": (

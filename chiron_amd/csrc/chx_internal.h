@@ -39,21 +39,9 @@ int chx_cell_prepare(const float* xyz, int n, chx_box_t box, float cutoff_plus_s
 
 // ctrl != NULL: the kernel is part of a Langevin chunk and turns into a no-op
 // (setting ctrl[1]) when ctrl[0] says the skin check fired.
-//
-// select != NULL (device-resident Monte Carlo): the positions are read from x4 or from
-// select->x4_alt, whichever state[CHX_MC_CUR] ^ flip names, and the launch is a no-op once
-// *halt <= trial; with energy == NULL the per-block partials stay in ws.
-struct chx_fl_select_t {
-  const int32_t* state;  // the slot of this trial (CHX_MC_CUR is read from it)
-  const int32_t* halt;   // the shared halt word
-  const float* x4_alt;
-  int flip;
-  long long trial;
-};
 int chx_launch_lj_fl(const float* x4, const uint32_t* fl, const int32_t* deg, int n, int g, int chunks,
                      chx_box_t box, float sigma, float epsilon, float cutoff, float* f3,
-                     float* energy, double* ws, int32_t* ctrl, hipStream_t st,
-                     const chx_fl_select_t* select = nullptr);
+                     float* energy, double* ws, int32_t* ctrl, hipStream_t st);
 // Force-list addressing: a row is stored in chunks of W = CHX_FL_QUAD * g entries, fl[chunk][particle][W], and lane q
 // of the g lanes that own a particle reads the four words 4q..4q+3 of a chunk with one 16-byte load.  Inside a chunk the
 // row is INTERLEAVED over the lanes: row entry e (0 <= e < W, in the row's order) sits in word 4 (e % g) + e / g, so

@@ -1,28 +1,44 @@
-// libchx: device-resident MonteCarloDisplacementMove loop on the force list.
+// libchx: device-resident MonteCarloDisplacementMove loop on the force list -- ONE launch per trial.
 //
 // The reference (chiron/mcmc.py:243-306 -> :357-463 -> :680-787) runs one trial as
 //   key = split; x' = wrap(x + sigma N(0,1)); [rebuild list if skin check]; u' = beta U(x');
 //   key = split; accept iff -(u'-u) >= 0 or uniform(key) < exp(-(u'-u))
-// with a host round trip per trial.  Here a whole chunk of trials is enqueued at once:
-// two launches per trial (decision of the previous trial + proposal + skin check; list-kernel energy), the
-// accepted configuration changes hands by flipping a buffer index in device memory, the
-// PRNG chain key lives on the device and advances by the same two splits per trial, and
-// the first trial whose proposal violates the skin halts the chunk (every later launch is
-// a no-op) so the host can run exactly that trial through the rebuild path.
+// with a host round trip per trial.  Here a whole chunk of trials is enqueued at once and trial t is one launch
+// (k_mc_trial; rounds 1-3 used two: a proposal launch and an energy launch):
+//   head   the decision of trial t-1, taken by every workgroup from the per-block energy partials launch t-1 left
+//          (redundantly and identically: a launch of its own would cost more than the arithmetic);
+//   body   the energy of the proposal x'_t over the force list (the pair-force kernel's row loop, chx_lj_row.h);
+//   tail   the NEXT proposal.  The chain key advances by two splits per trial whatever the decisions are, so the
+//          displacement d_{t+1} of every particle is known now; what is not known is which configuration it will be
+//          added to -- x_t (trial t rejected) or x'_t (accepted).  The launch writes BOTH candidates,
+//          wrap(x_t + d_{t+1}) and wrap(x'_t + d_{t+1}), next to the pair (x_t, x'_t) itself, and launch t+1 picks by
+//          the decision it takes at its head: the energy loop gathers its neighbours from ONE array, like the
+//          pair-force kernel, and no launch reads what it writes (the buffers alternate with the trial's parity).
+// Because the key chain does not depend on decisions, the HOST works it out for the whole chunk (a few hundred
+// microseconds for 4096 trials, chx_mc_key_chain_h) and uploads one row per trial -- its proposal key and the uniform
+// of its decision: five Philox blocks per wavefront and launch on the device cost 1.7 us of a 9 us launch (v_mul_hi_u32
+// is a quarter-rate instruction; measured, round 4), one scalar load costs nothing.
+// The first trial whose proposal violates the list's skin (chiron/neighbors.py:868) halts the chunk -- every later
+// launch is a no-op -- so the host can run exactly that trial through the reference's rebuild branch.
 #include "chx_common.h"
 #include "chx_internal.h"
+#include "chx_lj_row.h"
 
 #include <limits.h>
 #include <stdlib.h>
 
 struct McArgs {
   int n;
-  float4* xa;
-  float4* xb;
+  float4* cur4;   // [parity][copy][n]: the configuration before the parity's trial (which copy: the decision)
+  float4* prop4;  // [parity][copy][n]: the two candidates for the trial's proposal
   const float4* ref4;
   const uint32_t* perm;
   const float* subset;
+  const uint32_t* fl;
+  const int32_t* deg;
+  int chunks;
   Box3 box;
+  LJParams lj;
   float T_half_skin;
   float sigma_d;
   double beta;
@@ -30,107 +46,196 @@ struct McArgs {
   double* energy;
   int32_t* accept_log;
   float* energy_log;
-  const double* ws;
-  int nblocks;  // list-kernel partials in ws
+  double* ws;   // two halves of ws_half doubles: launch t writes half t & 1 and reads the other (the partials of t - 1)
+  int ws_half;
+  int nblocks;  // per-block energy partials per half
+  const uint4* keyrow;  // key table row of the launch's own trial: {proposal key (2 words), uniform of its decision (fp32 bits), 0}
 };
 
-__device__ __forceinline__ void mc_split(uint32_t k0, uint32_t k1, uint32_t& c0, uint32_t& c1,
-                                         uint32_t& s0, uint32_t& s1) {
-  const uint4 o = philox4x32(make_uint4(0u, 0u, 0u, CHX_STREAM_SPLIT), k0, k1);
-  c0 = o.x;
-  c1 = o.y;
-  s0 = o.z;
-  s1 = o.w;
-}
-
-// One launch of the trial loop.  DECIDE: take the decision of trial `trial - 1` from the partials its energy launch
-// left in ws -- EVERY workgroup does, redundantly and identically (fixed summation order, one thread's arithmetic),
-// because the proposal below needs the outcome and a launch boundary costs more than this; workgroup 0 records it.
-// PROPOSE: propose trial `trial`.  The chain state (current buffer, counters, key; energies) lives in two slots that
-// take turns by trial parity: the state BEFORE trial t's proposal sits in slot t & 1, so a launch reads one slot
-// and (workgroup 0) writes the other, and no workgroup reads what another one of the same launch writes.
-template <bool DECIDE, bool PROPOSE>
-__global__ __launch_bounds__(256) void k_mc_step(McArgs a, long long trial, int log_slot) {
-  if ((long long)a.state[CHX_MC_HALT] <= trial - (DECIDE ? 1 : 0)) return;  // (the halt word is shared: slot 0)
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  // both candidates for "the current configuration" are requested before the decision is known
-  float4 xa_p = make_float4(0.f, 0.f, 0.f, 0.f), xb_p = xa_p;
-  if (PROPOSE && p < a.n) {
-    xa_p = a.xa[p];
-    xb_p = a.xb[p];
-  }
-  const int32_t* in = a.state + CHX_MC_SLOT_WORDS * (int)((DECIDE ? trial - 1 : trial) & 1);
-  int cur = in[CHX_MC_CUR];
-  uint32_t key0 = (uint32_t)in[CHX_MC_KEY0], key1 = (uint32_t)in[CHX_MC_KEY1];
-  if (DECIDE) {
-    __shared__ int32_t sh[3];
-    double s = 0.0;
-    for (int i = threadIdx.x; i < a.nblocks; i += 256) s += a.ws[i];
-    s = block_sum<256>(s);
-    if (threadIdx.x == 0) {
-      const double* e_in = a.energy + 2 * (int)((trial - 1) & 1);
-      const float e_prop = (float)s;  // the potential energy is an fp32 number (k_sum_ws)
-      uint32_t c0, c1, p0, p1, d0, d1, u0, u1;
-      mc_split(key0, key1, c0, c1, p0, p1);  // proposal key
-      mc_split(c0, c1, d0, d1, u0, u1);      // acceptance key
-      const double U = (double)u32_to_uniform(philox4x32(make_uint4(0u, 0u, 0u, CHX_STREAM_UNIFORM), u0, u1).x);
-      const double up = a.beta * (double)e_prop;
-      const double uc = a.beta * e_in[0];
-      const double lp = -up + uc;  // log_proposal_ratio  :770
-      int acc = 0;
-      if (!isnan(up)) acc = (-lp <= 0.0 || U < exp(lp)) ? 1 : 0;  // :428-429, :544-545
-      const int new_cur = cur ^ acc;
-      sh[0] = new_cur;
-      sh[1] = (int32_t)d0;
-      sh[2] = (int32_t)d1;
-      if (blockIdx.x == 0) {
-        int32_t* out = a.state + CHX_MC_SLOT_WORDS * (int)(trial & 1);
-        double* e_out = a.energy + 2 * (int)(trial & 1);
-        const double e_cur = acc ? (double)e_prop : e_in[0];
-        out[CHX_MC_CUR] = new_cur;
-        out[CHX_MC_ACCEPTED] = in[CHX_MC_ACCEPTED] + acc;
-        out[CHX_MC_PROPOSED] = in[CHX_MC_PROPOSED] + 1;
-        out[CHX_MC_KEY0] = (int32_t)d0;
-        out[CHX_MC_KEY1] = (int32_t)d1;
-        e_out[0] = e_cur;
-        e_out[1] = (double)e_prop;
-        if (a.accept_log) a.accept_log[log_slot] = acc;
-        if (a.energy_log) a.energy_log[log_slot] = (float)e_cur;
-      }
-    }
-    __syncthreads();
-    cur = sh[0];
-    key0 = (uint32_t)sh[1];
-    key1 = (uint32_t)sh[2];
-  }
-  if (!PROPOSE || p >= a.n) return;
-  const bool cur_b = (cur & 1) != 0;
-  const float4 xi = cur_b ? xb_p : xa_p;
-  float4* xo = cur_b ? a.xa : a.xb;
-  uint32_t c0, c1, k0, k1;
-  mc_split(key0, key1, c0, c1, k0, k1);
-  const uint32_t o = a.perm ? a.perm[p] : (uint32_t)p;
+// sigma N(0,1) [* mask] of one particle (chiron/mcmc.py:733-748; k: the proposal key of the trial, o: original particle id)
+__device__ __forceinline__ void mc_displacement(const McArgs& a, uint32_t o, uint32_t k0, uint32_t k1, float& dx, float& dy,
+                                                float& dz) {
   float z0, z1, z2;
   philox_normals3(o, 0u, CHX_STREAM_MC_DISPLACE, k0, k1, z0, z1, z2);
-  // normal * sigma [* mask] then x + d   (chiron/mcmc.py:733-748)
-  float dx = fmul(z0, a.sigma_d), dy = fmul(z1, a.sigma_d), dz = fmul(z2, a.sigma_d);
+  dx = fmul(z0, a.sigma_d), dy = fmul(z1, a.sigma_d), dz = fmul(z2, a.sigma_d);
   if (a.subset) {
     const float mk = a.subset[o];
     dx = fmul(dx, mk);
     dy = fmul(dy, mk);
     dz = fmul(dz, mk);
   }
-  float xn = fadd(xi.x, dx), yn = fadd(xi.y, dy), zn = fadd(xi.z, dz);
-  if (a.box.periodic) {  // :751-755
+}
+// x + d, wrapped (:748-755)
+__device__ __forceinline__ float4 mc_displaced(const McArgs& a, float4 x, float dx, float dy, float dz) {
+  float xn = fadd(x.x, dx), yn = fadd(x.y, dy), zn = fadd(x.z, dz);
+  if (a.box.periodic) {
     xn = wrap1(xn, a.box.lx);
     yn = wrap1(yn, a.box.ly);
     zn = wrap1(zn, a.box.lz);
   }
-  xo[p] = make_float4(xn, yn, zn, 0.0f);
-  const float4 r0 = a.ref4[p];
+  return make_float4(xn, yn, zn, 0.0f);
+}
+
+// this thread's share of the energy partials launch `trial - 1` left
+__device__ __forceinline__ double mc_partials(const McArgs& a, long long trial) {
+  const double* ws_in = a.ws + (size_t)a.ws_half * (int)((trial - 1) & 1);
+  double part = 0.0;
+  for (int i = threadIdx.x; i < a.nblocks; i += 256) part += ws_in[i];
+  return part;
+}
+
+// The decision of trial `trial - 1` (chiron/mcmc.py:428-436, :531-548) from those partials and the trial's uniform: one
+// thread's arithmetic in a fixed summation order, so every workgroup that calls this arrives at the same bits;
+// workgroup 0 records it in the slot of `trial`.
+__device__ __forceinline__ int mc_decide(const McArgs& a, long long trial, int log_slot, double part, float uniform) {
+  __shared__ int32_t sh_acc;
+  const int b = (int)(trial & 1);
+  const int32_t* in = a.state + CHX_MC_SLOT_WORDS * (b ^ 1);
+  const double s = block_sum<256>(part);
+  if (threadIdx.x == 0) {
+    const double* e_in = a.energy + 2 * (b ^ 1);
+    const float e_prop = (float)s;  // the potential energy is an fp32 number (k_sum_ws)
+    const double U = (double)uniform;
+    const double up = a.beta * (double)e_prop;
+    const double uc = a.beta * e_in[0];
+    const double lp = -up + uc;  // log_proposal_ratio  :770
+    int acc = 0;
+    if (!isnan(up)) acc = (-lp <= 0.0 || U < exp(lp)) ? 1 : 0;  // :428-429, :544-545
+    sh_acc = acc;
+    if (blockIdx.x == 0) {
+      int32_t* out = a.state + CHX_MC_SLOT_WORDS * b;
+      double* e_out = a.energy + 2 * b;
+      const double e_cur = acc ? (double)e_prop : e_in[0];
+      out[CHX_MC_CUR] = acc;  // which copy of cur4[trial & 1] holds the configuration before trial `trial`
+      out[CHX_MC_ACCEPTED] = in[CHX_MC_ACCEPTED] + acc;
+      out[CHX_MC_PROPOSED] = in[CHX_MC_PROPOSED] + 1;
+      e_out[0] = e_cur;
+      e_out[1] = (double)e_prop;
+      if (a.accept_log) a.accept_log[log_slot] = acc;
+      if (a.energy_log) a.energy_log[log_slot] = (float)e_cur;
+    }
+  }
+  __syncthreads();
+  return sh_acc;
+}
+
+// the chunk's last launch: the decision of its last trial, one workgroup (a.keyrow: the row of `trial`)
+__global__ __launch_bounds__(256) void k_mc_decide(McArgs a, long long trial, int log_slot) {
+  const double part = mc_partials(a, trial);
+  const float uniform = __uint_as_float(a.keyrow[-1].z);
+  if ((long long)a.state[CHX_MC_HALT] <= trial - 1) return;
+  (void)mc_decide(a, trial, log_slot, part, uniform);
+}
+
+// the chunk's first launch: the configuration before trial `trial` sits in copy state.CUR of cur4[trial & 1]; make
+// both copies hold it and both candidates hold its proposal, so that the first trial launch needs no decision
+__global__ __launch_bounds__(256) void k_mc_prologue(McArgs a, long long trial) {
+  if ((long long)a.state[CHX_MC_HALT] <= trial) return;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.n) return;
+  const int b = (int)(trial & 1);
+  const int sel = a.state[CHX_MC_SLOT_WORDS * b + CHX_MC_CUR] & 1;
+  float4* cur = a.cur4 + (size_t)2 * b * a.n;
+  float4* prop = a.prop4 + (size_t)2 * b * a.n;
+  const float4 xc = cur[(size_t)sel * a.n + p];
+  const uint4 row = a.keyrow[0];
+  const uint32_t o = a.perm ? a.perm[p] : (uint32_t)p;
+  float dx, dy, dz;
+  mc_displacement(a, o, row.x, row.y, dx, dy, dz);
+  const float4 xp = mc_displaced(a, xc, dx, dy, dz);
+  cur[(size_t)(1 - sel) * a.n + p] = xc;
+  prop[p] = xp;
+  prop[(size_t)a.n + p] = xp;
+}
+
+// Trial `trial` in one launch (see the head of this file).  Reads the buffers of parity trial & 1, writes the other.
+// DECIDE = false: the chunk's first trial (the prologue made both copies equal: nothing to decide).
+// The launch is a chain of dependent round trips, not a throughput problem (like k_lj_step), so everything that does
+// not depend on the decision is requested before it: the row's index quad and length, both copies of the particle's
+// own x_t / x'_t, its reference position, the energy partials, the key rows.  Behind the decision only the neighbour
+// gathers, the particle's next displacement (one Philox block, computed while the gathers are in flight), the pair
+// arithmetic and the stores remain.
+template <int G, bool DECIDE>
+__global__ __launch_bounds__(256) void k_mc_trial(McArgs a, long long trial, int log_slot, unsigned nblocks) {
+  const int b = (int)(trial & 1);
+  const unsigned blk = xcd_block(blockIdx.x, nblocks);
+  const int tid = blk * 256 + threadIdx.x;
+  const int p = tid / G;
+  const int q = tid % G;
+  const bool valid = p < a.n;
+  const int pc = valid ? p : 0;
+  // ---- loads that do not wait for anything (relaxed wavefront-scope atomics: not sunk below the branches) ----
+  const uint4* col = reinterpret_cast<const uint4*>(a.fl) + (size_t)pc * G + q;
+  const uint4 e4 = pinned_load16(col);
+  const int d_raw = pinned_load4(a.deg + pc);
+  const float4* cur_b = a.cur4 + (size_t)2 * b * a.n;
+  const float4* prop_b = a.prop4 + (size_t)2 * b * a.n;
+  const uint4 xp0 = pinned_load16(prop_b + pc), xp1 = DECIDE ? pinned_load16(prop_b + a.n + pc) : xp0;
+  const uint4 xc0 = pinned_load16(cur_b + pc), xc1 = DECIDE ? pinned_load16(cur_b + a.n + pc) : xc0;
+  const uint4 r0b = pinned_load16(a.ref4 + pc);
+  const uint32_t o = a.perm ? (uint32_t)pinned_load4(reinterpret_cast<const int32_t*>(a.perm) + pc) : (uint32_t)pc;
+  const double part = DECIDE ? mc_partials(a, trial) : 0.0;
+  const float uniform = DECIDE ? __uint_as_float(a.keyrow[-1].z) : 0.f;  // (the uniform of trial - 1's decision)
+  const uint4 next = a.keyrow[1];                                         // (.xy: the proposal key of trial + 1)
+  if ((long long)a.state[CHX_MC_HALT] <= trial - (DECIDE ? 1 : 0)) return;  // (the halt word is shared: slot 0)
+  // ---- the decision of trial - 1: every workgroup, same bits ----
+  const int sel = DECIDE ? mc_decide(a, trial, log_slot, part, uniform) : 0;
+  // ---- energy of x'_t over the force list: the pair-force kernel's row loop and its reduction, bit for bit ----
+  const float4* prop = prop_b + (size_t)sel * a.n;  // x'_t
+  const uint4 xpb = sel ? xp1 : xp0, xcb = sel ? xc1 : xc0;
+  RowLoads rl = lj_row_adopt<G>(prop, col, pc, xpb, d_raw, e4);  // (the neighbour gathers are in flight from here)
+  // this particle's next displacement sigma N(0,1) [* mask] (chiron/mcmc.py:733-748), under the gathers' latency
+  float dx, dy, dz;
+  mc_displacement(a, o, next.x, next.y, dx, dy, dz);
+  float4 xp;
+  float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
+  lj_row_finish<G>(rl, prop, a.fl, a.n, q, valid, a.box, a.box.periodic != 0, a.lj, xp, fx, fy, fz, en);
+  en = group_sum<G>(en);
+  double mine = (valid && q == 0) ? 0.5 * (double)en : 0.0;  // every pair is visited from both ends
+  mine = block_sum<256>(mine);
+  if (threadIdx.x == 0) a.ws[(size_t)a.ws_half * b + blk] = mine;  // (never the half the heads of this launch are reading)
+  if (!valid || q != 0) return;
+  // ---- skin check of this trial's proposal (chiron/neighbors.py:868): the first violating trial halts the chunk ----
   float rx, ry, rz;
-  displacement(a.box, xn, yn, zn, r0.x, r0.y, r0.z, rx, ry, rz);
-  if (norm2(rx, ry, rz) > a.T_half_skin) atomicMin(&a.state[CHX_MC_HALT], (int)trial);  // neighbors.py:868
+  displacement(a.box, xp.x, xp.y, xp.z, __uint_as_float(r0b.x), __uint_as_float(r0b.y), __uint_as_float(r0b.z), rx, ry, rz);
+  if (norm2(rx, ry, rz) > a.T_half_skin) atomicMin(&a.state[CHX_MC_HALT], (int)trial);
+  // ---- the next trial's candidates (chiron/mcmc.py:733-755 on either outcome of this trial) ----
+  const float4 xc = make_float4(__uint_as_float(xcb.x), __uint_as_float(xcb.y), __uint_as_float(xcb.z), 0.0f);
+  const float4 xpc = make_float4(xp.x, xp.y, xp.z, 0.0f);
+  float4* cur_n = a.cur4 + (size_t)2 * (b ^ 1) * a.n;
+  float4* prop_n = a.prop4 + (size_t)2 * (b ^ 1) * a.n;
+  cur_n[p] = xc;                 // trial t rejected: the configuration stays
+  cur_n[(size_t)a.n + p] = xpc;  // accepted: the proposal becomes the configuration
+  prop_n[p] = mc_displaced(a, xc, dx, dy, dz);
+  prop_n[(size_t)a.n + p] = mc_displaced(a, xpc, dx, dy, dz);
+}
+
+template <int G>
+static void launch_trial(const McArgs& a, long long t, bool decide, int log_slot, hipStream_t st) {
+  const unsigned blocks = (unsigned)(((int64_t)a.n * G + 255) / 256);
+  if (decide) hipLaunchKernelGGL((k_mc_trial<G, true>), dim3(blocks), dim3(256), 0, st, a, t, log_slot, blocks);
+  else hipLaunchKernelGGL((k_mc_trial<G, false>), dim3(blocks), dim3(256), 0, st, a, t, log_slot, blocks);
+}
+
+extern "C" int chx_mc_key_chain_h(uint32_t k0, uint32_t k1, int32_t n_trials, uint32_t* keytab_h, uint32_t* chain_out_h) {
+  CHX_REQUIRE(n_trials >= 0, "n_trials < 0");
+  uint32_t o[4];
+  for (int i = 0; i <= n_trials; ++i) {
+    if (chain_out_h) chain_out_h[2 * i] = k0, chain_out_h[2 * i + 1] = k1;
+    chx_philox4x32_h(0u, 0u, 0u, CHX_STREAM_SPLIT, k0, k1, o);  // key, subkey = split(key): the proposal key (mcmc.py:724)
+    const uint32_t c0 = o[0], c1 = o[1], p0 = o[2], p1 = o[3];
+    chx_philox4x32_h(0u, 0u, 0u, CHX_STREAM_SPLIT, c0, c1, o);  // key, subkey = split(key): the acceptance key (:531)
+    const uint32_t u0 = o[2], u1 = o[3];
+    k0 = o[0], k1 = o[1];
+    if (keytab_h) {
+      chx_philox4x32_h(0u, 0u, 0u, CHX_STREAM_UNIFORM, u0, u1, o);
+      const float U = ((float)(o[0] >> 9) + 0.5f) * (1.0f / 8388608.0f);  // u32_to_uniform (chx_common.h), exact in fp32
+      uint32_t ub;
+      __builtin_memcpy(&ub, &U, 4);
+      keytab_h[4 * i] = p0, keytab_h[4 * i + 1] = p1, keytab_h[4 * i + 2] = ub, keytab_h[4 * i + 3] = 0u;
+    }
+  }
+  return CHX_OK;
 }
 
 extern "C" int chx_mc_displace_chunk(const chx_mc_t* p, int64_t trial0, int32_t n_trials,
@@ -139,20 +244,35 @@ extern "C" int chx_mc_displace_chunk(const chx_mc_t* p, int64_t trial0, int32_t 
   CHX_REQUIRE(p->n > 0, "n <= 0");
   CHX_REQUIRE(n_trials >= 0, "n_trials < 0");
   CHX_REQUIRE(trial0 >= 0 && trial0 + n_trials < (int64_t)INT_MAX, "trial index out of range");
-  CHX_REQUIRE(p->x_a && p->x_b && p->ref4 && p->fl && p->deg && p->state && p->energy && p->ws,
+  CHX_REQUIRE(p->cur4 && p->prop4 && p->ref4 && p->fl && p->deg && p->state && p->energy && p->ws,
               "null pointer");
+  CHX_REQUIRE(p->keytab && p->keytab_h, "null key table");
   CHX_REQUIRE(p->fl_chunks >= 1, "fl_chunks < 1");
+  CHX_REQUIRE(p->g == 1 || p->g == 2 || p->g == 4 || p->g == 8 || p->g == 16 || p->g == 32 || p->g == 64,
+              "g must be a power of two <= 64");
   CHX_REQUIRE(!p->box.periodic || (p->box.lx > 0 && p->box.ly > 0 && p->box.lz > 0),
               "box lengths must be > 0");
+  if (n_trials == 0) return CHX_OK;
   hipStream_t st = chx_stream(stream);
+  // the key chain of the chunk: rows 0 .. n_trials (the last one feeds the candidates the last launch writes)
+  int rc = chx_mc_key_chain_h(p->k0, p->k1, n_trials, p->keytab_h, p->chain_out_h);
+  if (rc != CHX_OK) return rc;
+  if (hipMemcpyAsync(p->keytab, p->keytab_h, sizeof(uint32_t) * 4 * (size_t)(n_trials + 1), hipMemcpyHostToDevice, st) != hipSuccess) {
+    chx_set_error("chx_mc_displace_chunk: key table upload failed");
+    return CHX_ERR_LAUNCH;
+  }
   McArgs a;
   a.n = p->n;
-  a.xa = reinterpret_cast<float4*>(p->x_a);
-  a.xb = reinterpret_cast<float4*>(p->x_b);
+  a.cur4 = reinterpret_cast<float4*>(p->cur4);
+  a.prop4 = reinterpret_cast<float4*>(p->prop4);
   a.ref4 = reinterpret_cast<const float4*>(p->ref4);
   a.perm = p->perm;
   a.subset = p->subset_mask;
+  a.fl = p->fl;
+  a.deg = p->deg;
+  a.chunks = p->fl_chunks;
   a.box = make_box3(p->box);
+  a.lj = chx_make_lj(p->sigma, p->epsilon, p->cutoff);
   a.T_half_skin = chx_cutoff_threshold_h(p->skin * 0.5f);
   a.sigma_d = p->sigma_d;
   a.beta = p->beta;
@@ -161,29 +281,26 @@ extern "C" int chx_mc_displace_chunk(const chx_mc_t* p, int64_t trial0, int32_t 
   a.accept_log = p->accept_log;
   a.energy_log = p->energy_log;
   a.ws = p->ws;
+  a.ws_half = (int)chx_lj_ws_count(p->n);
   a.nblocks = chx_lj_fl_blocks(p->n, p->g);
-  chx_fl_select_t sel;
-  sel.halt = p->state + CHX_MC_HALT;
-  sel.x4_alt = p->x_b;
-  sel.flip = 1;  // the proposed configuration sits in the buffer that is NOT current
-  const unsigned pb = (unsigned)((p->n + 255) / 256);
-  // CHX_MC_DECIDE_LAUNCH=1: every decision a one-block launch of its own (three launches per trial; A/B, tests)
-  static const bool decide_launch = [] { const char* e = getenv("CHX_MC_DECIDE_LAUNCH"); return e && e[0] == '1'; }();
+  const uint4* tab = reinterpret_cast<const uint4*>(p->keytab);
+  a.keyrow = tab;
+  hipLaunchKernelGGL(k_mc_prologue, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0, st, a, (long long)trial0);
   for (int i = 0; i < n_trials; ++i) {
     const long long t = trial0 + i;
-    if (i == 0 || decide_launch) {
-      hipLaunchKernelGGL((k_mc_step<false, true>), dim3(pb), dim3(256), 0, st, a, t, 0);
-    } else {
-      hipLaunchKernelGGL((k_mc_step<true, true>), dim3(pb), dim3(256), 0, st, a, t, i - 1);  // decides trial t - 1
-    }
-    sel.state = p->state + CHX_MC_SLOT_WORDS * (int)(t & 1);
-    sel.trial = t;
-    int rc = chx_launch_lj_fl(p->x_a, p->fl, p->deg, p->n, p->g, p->fl_chunks, p->box, p->sigma,
-                              p->epsilon, p->cutoff, nullptr, nullptr, p->ws, nullptr, st, &sel);
-    if (rc != CHX_OK) return rc;
-    if (i == n_trials - 1 || decide_launch) {
-      hipLaunchKernelGGL((k_mc_step<true, false>), dim3(1), dim3(256), 0, st, a, t + 1, i);  // decides trial t
+    const bool decide = i > 0;  // (decides trial t - 1, logged at i - 1)
+    a.keyrow = tab + i;
+    switch (p->g) {
+      case 1: launch_trial<1>(a, t, decide, i - 1, st); break;
+      case 2: launch_trial<2>(a, t, decide, i - 1, st); break;
+      case 4: launch_trial<4>(a, t, decide, i - 1, st); break;
+      case 8: launch_trial<8>(a, t, decide, i - 1, st); break;
+      case 16: launch_trial<16>(a, t, decide, i - 1, st); break;
+      case 32: launch_trial<32>(a, t, decide, i - 1, st); break;
+      default: launch_trial<64>(a, t, decide, i - 1, st); break;
     }
   }
+  a.keyrow = tab + n_trials;
+  hipLaunchKernelGGL(k_mc_decide, dim3(1), dim3(256), 0, st, a, (long long)(trial0 + n_trials), n_trials - 1);
   return chx_check_launch("chx_mc_displace_chunk");
 }

@@ -292,9 +292,20 @@ class MonteCarloDisplacementMove(MCMove):
         n = sampler_state.number_of_particles
         key = sampler_state._current_PRNG_key
         ctx = {"fl": fl, "nbr_list": nbr_list}
-        ctx["x_a"] = fl.pack(sampler_state.positions, 4)
-        ctx["x_b"] = torch.empty_like(ctx["x_a"])
+        # configurations and proposal candidates, (parity, copy, n, 4) each (include/chx.h: chx_mc_t): the chain enters at
+        # trial `trial`, so the current configuration goes into copy 0 of parity trial & 1
+        ctx["cur4"] = torch.empty((2, 2, n, 4), dtype=torch.float32, device=dev)
+        ctx["prop4"] = torch.empty((2, 2, n, 4), dtype=torch.float32, device=dev)
+        ctx["cur4"][trial & 1, 0].copy_(fl.pack(sampler_state.positions, 4))
         ctx["ref4"] = fl.pack(nbr_list.ref_positions, 4)
+        ctx["ws"] = torch.empty((2 * int(_lib.load().chx_lj_ws_count(n)),), dtype=torch.float64, device=dev)
+        # the chunk's key chain is worked out on the host by chx_mc_displace_chunk (the chain does not depend on decisions):
+        # device table, pinned staging, and the chain key before every trial of the chunk for the host's own use
+        rows = self._DEVICE_CHUNK + 1
+        ctx["keytab"] = torch.empty((rows, 4), dtype=torch.int32, device=dev)
+        ctx["keytab_h"] = torch.empty((rows, 4), dtype=torch.int32, pin_memory=True)
+        ctx["chain"] = np.zeros((rows, 2), dtype=np.uint32)
+        ctx["key"] = (int(key[0]) & 0xFFFFFFFF, int(key[1]) & 0xFFFFFFFF)
         # two state slots that take turns by trial parity (include/chx.h: chx_mc_displace_chunk): the chain enters the
         # device loop at trial `trial`, so its state goes into slot trial & 1; the halt word is shared (slot 0)
         slot = _lib.MC_SLOT_WORDS * (trial & 1)
@@ -311,7 +322,7 @@ class MonteCarloDisplacementMove(MCMove):
         beta = float(thermodynamic_state.beta * (unit.Quantity(1.0, unit.kilojoule_per_mole) / unit.AVOGADRO_CONSTANT_NA))
         p = _lib.McParams()
         p.n, p.g, p.fl_chunks = n, fl.g, fl.chunks
-        p.x_a, p.x_b, p.ref4 = ctx["x_a"].data_ptr(), ctx["x_b"].data_ptr(), ctx["ref4"].data_ptr()
+        p.cur4, p.prop4, p.ref4 = ctx["cur4"].data_ptr(), ctx["prop4"].data_ptr(), ctx["ref4"].data_ptr()
         p.perm = None if fl.perm is None else fl.perm.data_ptr()
         p.subset_mask = None if mask is None else mask.data_ptr()
         p.fl, p.deg = fl.fl.data_ptr(), fl.deg.data_ptr()
@@ -321,7 +332,9 @@ class MonteCarloDisplacementMove(MCMove):
         p.beta = beta
         p.state, p.energy = ctx["state"].data_ptr(), ctx["energy"].data_ptr()
         p.accept_log, p.energy_log = ctx["accept_log"].data_ptr(), ctx["energy_log"].data_ptr()
-        p.ws = fl.ws.data_ptr()
+        p.ws = ctx["ws"].data_ptr()
+        p.keytab, p.keytab_h = ctx["keytab"].data_ptr(), ctx["keytab_h"].data_ptr()
+        p.chain_out_h = ctx["chain"].ctypes.data
         ctx["params"] = p
         return ctx
 
@@ -361,11 +374,13 @@ class MonteCarloDisplacementMove(MCMove):
                 m = min(m, self.autotune_interval - self._number_of_attempts_made % self.autotune_interval)
             sigma_md = float(self.displacement_sigma.value_in_unit_system(unit.md_unit_system))
             ctx["params"].sigma_d = sigma_md
+            ctx["params"].k0, ctx["params"].k1 = ctx["key"]  # chain key before trial i
             ops.mc_displace_chunk(ctx["params"], i, m)
             st = ctx["state"].cpu().numpy()  # waits for the chunk
             halt = int(st[_lib.MC_HALT])
             halted = halt < i + m
             done = (halt if halted else i + m) - i
+            ctx["key"] = (int(ctx["chain"][done, 0]), int(ctx["chain"][done, 1]))  # chain key before trial i + done
             if done > 0:
                 acc = ctx["accept_log"][:done].cpu().numpy()
                 elog = ctx["energy_log"][:done].cpu().numpy()
@@ -378,10 +393,9 @@ class MonteCarloDisplacementMove(MCMove):
                 # trial `halt` trips the skin check: run it on the reference's rebuild branch
                 # (i == halt now: the chain state sits in slot i & 1)
                 so = _lib.MC_SLOT_WORDS * (i & 1)
-                cur = ctx["x_b"] if (int(st[so + _lib.MC_CUR]) & 1) else ctx["x_a"]
+                cur = ctx["cur4"][i & 1, int(st[so + _lib.MC_CUR]) & 1]
                 sampler_state.positions = ctx["fl"].unpack(cur)
-                sampler_state._current_PRNG_key = PRNGKey(int(st[so + _lib.MC_KEY0]) & 0xFFFFFFFF,
-                                                          int(st[so + _lib.MC_KEY1]) & 0xFFFFFFFF)
+                sampler_state._current_PRNG_key = PRNGKey(*ctx["key"])
                 self._current_reduced_potential = thermodynamic_state.reduced_potential_from_energy(energy, sampler_state)
                 sampler_state, thermodynamic_state, nbr_list = self._step(sampler_state, thermodynamic_state, nbr_list)
                 energy = float(pot.compute_energy(sampler_state.positions, nbr_list))
@@ -394,10 +408,9 @@ class MonteCarloDisplacementMove(MCMove):
         if ctx is not None:
             st = ctx["state"].cpu().numpy()
             so = _lib.MC_SLOT_WORDS * (i & 1)  # i == total trials done: the chain state sits in slot i & 1
-            cur = ctx["x_b"] if (int(st[so + _lib.MC_CUR]) & 1) else ctx["x_a"]
+            cur = ctx["cur4"][i & 1, int(st[so + _lib.MC_CUR]) & 1]
             sampler_state.positions = ctx["fl"].unpack(cur)
-            sampler_state._current_PRNG_key = PRNGKey(int(st[so + _lib.MC_KEY0]) & 0xFFFFFFFF,
-                                                      int(st[so + _lib.MC_KEY1]) & 0xFFFFFFFF)
+            sampler_state._current_PRNG_key = PRNGKey(*ctx["key"])
         self._current_reduced_potential = thermodynamic_state.reduced_potential_from_energy(energy, sampler_state)
         self._move_iteration += 1
         return sampler_state, thermodynamic_state, nbr_list

@@ -54,8 +54,10 @@ typedef void* chx_stream_t;
  *      chx_langevin_fused_run and the max_blocks argument of chx_nl_build_cell_fl.  Both cell builds now expect
  *      cell_count zeroed on entry and leave it zeroed; chx_nl_build_cell_fl takes a chx_build_riders_t* (copy of the
  *      positions, packed Langevin state, control-block reset, status publish: see there).  chx_langevin_t grew
- *      final_x3 / final_v3 / final_ref3 (the run's last launch writes the state in user order).  Added:
- *      chx_philox4x32_h. */
+ *      final_x3 / final_v3 / final_ref3 (the run's last launch writes the state in user order).  chx_mc_t: x_a / x_b
+ *      became cur4 / prop4 (four configurations each) and ws doubled -- the Monte Carlo loop is one launch per trial.
+ *      Added: chx_philox4x32_h, chx_cell_bin_fl, chx_nl_rows_cell_fl, chx_mc_key_chain_h (chx_mc_t grew k0, k1,
+ *      keytab, keytab_h, chain_out_h: the chunk's key chain is computed on the host). */
 #define CHX_ABI_VERSION 3
 
 /* high bit of a force-list entry: neighbor has the HIGHER original particle id */
@@ -491,34 +493,43 @@ int chx_metropolis_select(float* x_cur, const float* x_prop, int64_t count,
                           uint32_t k0, uint32_t k1, uint32_t ctr, float uniform_h,
                           int32_t* accepted_out, int32_t* counters, chx_stream_t stream);
 
-/* Device-resident MonteCarloDisplacementMove loop on the force list: n_trials
- * consecutive propose / energy / Metropolis trials (chiron/mcmc.py:243-306, :357-463,
- * :680-787) enqueued back to back, TWO launches per trial and no host round trip (the decision of trial t is taken
- * at the head of the launch that proposes trial t+1 -- by every workgroup, redundantly and identically, from the
- * energy launch's per-block partials: a launch of its own would cost more than the arithmetic; the chunk's last
- * decision is a one-block launch):
- *   propose  x' = wrap(x + sigma_d N(0,1) [* mask]) into the spare buffer + skin check
- *            against ref4 (chiron/neighbors.py:868); the proposal key is the subkey of
- *            split(chain key) -- what SamplerState.new_PRNG_key would hand out
- *   energy   list kernel on x' (per-block fp64 partials, fixed order)
- *   decide   U' = fp32(sum partials); accept iff !isnan(beta U') and
- *            (beta U' - beta U <= 0 or uniform < exp(-(beta U' - beta U))) with the uniform
- *            drawn from the next subkey of the chain (:428-436, :531-548); on accept the
- *            buffers swap roles (state[CHX_MC_CUR] ^= 1) and U <- U'.  The chain key
- *            advances by two splits per trial, exactly like the host path.
- * When the skin check fires in trial t the kernels store t in state[CHX_MC_HALT] and every
- * launch of trial >= t is a no-op: the caller runs that trial through the rebuild path and
- * resumes.  state is CHX_MC_STATE_WORDS ints: TWO slots of CHX_MC_SLOT_WORDS words (indices below, slot s at
- * offset s * CHX_MC_SLOT_WORDS) that take turns by trial parity -- a launch reads one and writes the other, so no
+/* Device-resident MonteCarloDisplacementMove loop on the force list: n_trials consecutive propose / energy /
+ * Metropolis trials (chiron/mcmc.py:243-306, :357-463, :680-787) enqueued back to back, ONE launch per trial (ABI 3;
+ * two until round 3) and no host round trip.  Launch t
+ *   decides   trial t-1 at its head -- every workgroup, redundantly and identically, from the per-block energy partials
+ *             launch t-1 left: U' = fp32(sum partials); accept iff !isnan(beta U') and (beta U' - beta U <= 0 or
+ *             uniform < exp(-(beta U' - beta U))) with the uniform drawn from the acceptance subkey of the chain
+ *             (:428-436, :531-548); a launch of its own would cost more than the arithmetic (the chunk's last decision
+ *             is a one-block launch);
+ *   evaluates the energy of the proposal x'_t over the force list (the pair-force kernel's row loop and reduction:
+ *             per-block fp64 partials, fixed order) and checks x'_t against the skin (chiron/neighbors.py:868);
+ *   proposes  trial t+1: the chain key advances by two splits per trial whatever is decided, so every particle's next
+ *             displacement sigma_d N(0,1) [* mask] is known; the launch writes BOTH candidates wrap(x_t + d) and
+ *             wrap(x'_t + d) next to the pair (x_t, x'_t), and launch t+1 picks by its decision.  The proposal key is
+ *             the subkey of split(chain key) -- what SamplerState.new_PRNG_key would hand out.
+ * For the same reason the key chain is worked out on the HOST, by this call, from (k0, k1) = the chain key before trial0
+ * (chx_mc_key_chain_h): one row per trial -- proposal key, uniform of the decision -- goes into keytab_h (host-mapped or
+ * pinned, 4 (n_trials + 1) uint32) and from there to keytab (device, same size) with an asynchronous copy on `stream`;
+ * chain_out_h (2 (n_trials + 1) uint32, may be NULL) receives the chain key BEFORE each trial trial0 + i, i = 0 ..
+ * n_trials, so the caller knows the key at the halt trial or at the chunk's end.  The KEY words of the state slots are
+ * NOT maintained by the kernels (ABI 3).  keytab_h must not be rewritten before the chunk's launches have run.
+ * cur4 and prop4 are (2, 2, n, 4) floats each: [parity][copy][particle]; launch t reads parity t & 1 and writes the
+ * other.  On entry copy state[CHX_MC_CUR] of cur4[trial0 & 1] holds the current configuration (internal order); after
+ * the chunk copy state[CHX_MC_CUR] (of slot T & 1) of cur4[T & 1] does, T = the halt trial if the chunk halted, else
+ * trial0 + n_trials.
+ * When the skin check fires in trial t the launch stores t in state[CHX_MC_HALT] and every launch of trial > t is a
+ * no-op (trial t is never decided): the caller runs that trial through the rebuild path and resumes.  state is
+ * CHX_MC_STATE_WORDS ints: TWO slots of CHX_MC_SLOT_WORDS words (indices below, slot s at offset
+ * s * CHX_MC_SLOT_WORDS) that take turns by trial parity -- a launch reads one and writes the other, so no
  * workgroup reads what another one of the same launch writes.  On entry slot (trial0 & 1) holds the chain state; after
- * the chunk slot (T & 1) does, T = the halt trial if the chunk halted, else trial0 + n_trials.  The halt word is
- * shared: always state[CHX_MC_HALT] of slot 0.  energy follows the same rule: [2 s] = current potential energy
- * (kJ/mol) of slot s, [2 s + 1] = last proposed.  accept_log / energy_log (n_trials entries each, may be NULL) record
- * the decision and the current energy after every trial, indexed by trial - trial0.  Asynchronous. */
-#define CHX_MC_CUR 0       /* which buffer (0: x_a, 1: x_b) holds the current configuration */
+ * the chunk slot (T & 1) does.  The halt word is shared: always state[CHX_MC_HALT] of slot 0.  energy follows the same
+ * rule: [2 s] = current potential energy (kJ/mol) of slot s, [2 s + 1] = last proposed.  accept_log / energy_log
+ * (n_trials entries each, may be NULL) record the decision and the current energy after every trial, indexed by
+ * trial - trial0.  ws: 2 * chx_lj_ws_count(n) doubles (the partials alternate between two halves).  Asynchronous. */
+#define CHX_MC_CUR 0       /* which copy (0 / 1) of cur4[parity] holds the current configuration */
 #define CHX_MC_ACCEPTED 1  /* running counters */
 #define CHX_MC_PROPOSED 2
-#define CHX_MC_HALT 3      /* first trial that did not run; INT32_MAX when clear */
+#define CHX_MC_HALT 3      /* first trial whose proposal violated the skin; INT32_MAX when clear */
 #define CHX_MC_KEY0 4      /* PRNG chain key */
 #define CHX_MC_KEY1 5
 #define CHX_MC_SLOT_WORDS 8
@@ -528,8 +539,8 @@ typedef struct chx_mc_t {
   int32_t g;               /* lanes per particle of the force list */
   int32_t fl_chunks;
   int32_t reserved;
-  float* x_a;              /* (n,4) internal order */
-  float* x_b;              /* (n,4) internal order */
+  float* cur4;             /* (2,2,n,4) configurations, internal order (see above) */
+  float* prop4;            /* (2,2,n,4) proposal candidates */
   const float* ref4;       /* (n,4) positions the list was built from, internal order */
   const uint32_t* perm;    /* internal -> original id */
   const float* subset_mask;/* per ORIGINAL id 0/1 factors, or NULL */
@@ -545,10 +556,19 @@ typedef struct chx_mc_t {
   double* energy;          /* 4 doubles: [2 s] current, [2 s + 1] proposed, of slot s */
   int32_t* accept_log;
   float* energy_log;
-  double* ws;              /* chx_lj_ws_count(n) doubles */
+  double* ws;              /* 2 * chx_lj_ws_count(n) doubles */
+  uint32_t k0, k1;         /* chain key before trial0 */
+  uint32_t* keytab;        /* device, 4 (n_trials + 1) words */
+  uint32_t* keytab_h;      /* pinned host staging of the same size, filled by the call */
+  uint32_t* chain_out_h;   /* host, 2 (n_trials + 1) words, or NULL */
 } chx_mc_t;
 int chx_mc_displace_chunk(const chx_mc_t* p_h, int64_t trial0, int32_t n_trials,
                           chx_stream_t stream);
+/* The key chain of n_trials consecutive trials from the chain key (k0, k1), on the host: per trial two splits
+ * (chiron/mcmc.py:724 proposal, :531 acceptance).  keytab_h row i (4 words) = {proposal key of trial i (2), fp32 bits of
+ * the uniform of its decision, 0}, rows 0 .. n_trials; chain_out_h entry i (2 words) = chain key before trial i, entries
+ * 0 .. n_trials.  Either may be NULL. */
+int chx_mc_key_chain_h(uint32_t k0, uint32_t k1, int32_t n_trials, uint32_t* keytab_h, uint32_t* chain_out_h);
 
 #ifdef __cplusplus
 }

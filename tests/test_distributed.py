@@ -190,6 +190,78 @@ def test_bench_launcher_starts_n_ranks_gloo_dry_run():
     assert sorted(line["config"]["state_of_replica"]) == [0, 1]
 
 
+def test_bench_launcher_requalifies_slow_ranks_before_the_group_forms():
+    """Rate-based rank requalification (round-3 review item 4): every rank reports its stand-alone rate before it joins
+    the process group; the launcher replaces a rank below 0.97 x the median with a FRESH process (never a re-exec), at
+    most twice, then releases all ranks.  Fake rates: rank 1 is slow on its first attempt (0.90), rank 3 on its first
+    two (0.80, 0.95) -- both get replaced until they pass; rank 2 at 0.98 is inside the tolerance and stays."""
+    fake = "1:0=0.90;3:0=0.80;3:1=0.95;2:0=0.98"
+    res, lines = _run_bench(["--gpus", "4", "--steps", "2000", "--warmup", "0", "--dry-run-backend", "gloo"],
+                            env_extra={"CHX_BENCH_FAKE_RATES": fake})
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert len(lines) == 1
+    cfg = lines[0]["config"]
+    assert cfg["group_world_size"] == 4 and cfg["ranks"] == [0, 1, 2, 3]
+    q = cfg["requalification"]
+    assert sorted((r, a) for r, a, _ in q["replaced"]) == [(1, 0), (3, 0), (3, 1)]
+    assert q["final_rates"] == {"0": 100000.0, "1": 100000.0, "2": 98000.0, "3": 100000.0}
+    assert res.stderr.count("replaced by a fresh process") == 3
+    # a rank that stays slow is kept after two replacements (the run must not hang on an unlucky host)
+    res, lines = _run_bench(["--gpus", "3", "--steps", "1000", "--warmup", "0", "--dry-run-backend", "gloo"],
+                            env_extra={"CHX_BENCH_FAKE_RATES": "2:0=0.5;2:1=0.5;2:2=0.5"})
+    assert res.returncode == 0 and len(lines) == 1
+    q = lines[0]["config"]["requalification"]
+    assert [(r, a) for r, a, _ in q["replaced"]] == [(2, 0), (2, 1)] and q["final_rates"]["2"] == 50000.0
+    # switched off: ranks start as they come, nothing is reported
+    res, lines = _run_bench(["--gpus", "2", "--steps", "1000", "--warmup", "0", "--dry-run-backend", "gloo", "--requalify", "0"],
+                            env_extra={"CHX_BENCH_FAKE_RATES": "1:0=0.5"})
+    assert res.returncode == 0 and lines[0]["config"]["requalification"] is None
+
+
+def test_requalify_decisions_on_fake_children():
+    """The parent's decision rule by itself (bench.requalify): median of the ranks, 0.97 threshold, at most two
+    replacements per rank, two ranks measured against the faster one, dead children (no rate) left alone."""
+    import sys
+
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+
+    class Child:
+        def __init__(self, rank, attempt, table):
+            self.rank, self.attempt, self.table, self.gone = rank, attempt, table, False
+            self.rate = None
+
+        def read_rate(self, timeout):
+            self.rate = self.table.get((self.rank, self.attempt), 100.0)
+            return self.rate
+
+        def discard(self):
+            self.gone = True
+
+    def run(n, table):
+        made = []
+
+        def spawn(r, a):
+            c = Child(r, a, table)
+            made.append(c)
+            return c
+
+        first = [spawn(r, 0) for r in range(n)]
+        final, log = bench.requalify(first, spawn)
+        return first, final, made, log
+
+    first, final, made, log = run(8, {(5, 0): 96.0, (5, 1): 99.0})
+    assert [c.attempt for c in final] == [0, 0, 0, 0, 0, 1, 0, 0] and first[5].gone and not any(c.gone for c in final)
+    assert len(made) == 9 and sum(e["replaced"] for e in log) == 1
+    first, final, made, log = run(8, {(r, 0): 97.5 for r in range(8)})  # uniformly "slow": nobody is below the median
+    assert len(made) == 8
+    first, final, made, log = run(2, {(0, 0): 90.0})  # two ranks: the faster one is the yardstick
+    assert final[0].attempt == 1 and final[1].attempt == 0
+    first, final, made, log = run(4, {(2, 0): None})  # a child that never reported: not replaced here (it fails loudly later)
+    assert len(made) == 4
+
+
 def test_bench_launcher_eight_ranks_gloo_dry_run_and_torchrun():
     """The configuration the driver measures at round end, C5: eight ranks.  (a) `python bench.py --gpus 8` as its own
     launcher; (b) under the driver's own command line, `python -m torch.distributed.run --nproc-per-node 8 ... bench.py

@@ -109,6 +109,29 @@ def test_host_philox_c_helper_and_python_rounds_agree():
     assert rng.philox4x32_py((0xFFFFFFFF,) * 4, (0xFFFFFFFF, 0xFFFFFFFF)) == (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)
 
 
+def test_mc_key_chain_helper_matches_the_host_key_handling():
+    """chx_mc_key_chain_h (include/chx.h): the chain the device Monte Carlo loop runs on -- per trial two splits
+    (chiron/mcmc.py:724, :531), the proposal key and the uniform of the decision -- equals what the host loop gets from
+    chiron_amd.rng.split / uniform, trial by trial."""
+    import ctypes
+
+    from chiron_amd import _lib, rng
+
+    lib = _lib.load()
+    n = 40
+    tab = (ctypes.c_uint32 * (4 * (n + 1)))()
+    chain = (ctypes.c_uint32 * (2 * (n + 1)))()
+    assert lib.chx_mc_key_chain_h(2024, 7, n, tab, chain) == 0
+    key = rng.PRNGKey(2024, 7)
+    for i in range(n + 1):
+        assert (chain[2 * i], chain[2 * i + 1]) == tuple(key)
+        key, sub = rng.split(key)  # SamplerState.new_PRNG_key: the proposal key
+        assert (tab[4 * i], tab[4 * i + 1]) == tuple(sub)
+        key, acc = rng.split(key)  # the acceptance key
+        assert np.frombuffer(np.uint32(tab[4 * i + 2]).tobytes(), np.float32)[0] == np.float32(rng.uniform(acc))
+    assert lib.chx_mc_key_chain_h(1, 2, -1, None, None) < 0
+
+
 def test_host_philox_matches_oracle():
     from oracle import chiron_oracle as O
 
@@ -311,7 +334,7 @@ def test_library_exports_every_declared_symbol():
             ints = sum(1 for a in args[:i] if a not in (ctypes.c_float, ctypes.c_double))
             floats = i - ints
             assert floats == 0 or ints < 5, name
-    assert ctypes.sizeof(_lib.McParams) == 160
+    assert ctypes.sizeof(_lib.McParams) == 192
     assert _lib.McParams.beta.offset == 112 and _lib.McParams.ws.offset == 152
 
 
