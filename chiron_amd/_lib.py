@@ -121,6 +121,9 @@ class BuildRiders(C.Structure):
         ("ctrl_reset", C.c_void_p),
         ("ctrl_keep", C.c_int32),
         ("publish_host_dst8", C.c_void_p),
+        ("cand_list", C.c_void_p),
+        ("cand_len", C.c_void_p),
+        ("cand_cap", C.c_int32),
     ]
 
 
@@ -156,7 +159,7 @@ SIGNATURES = {
     "chx_cell_bin_fl": (C.c_int, [_P, _I32, Box, _F, C.POINTER(_I32), _P, _P, _P, _P, _P, _P, C.POINTER(BuildRiders), _P]),
     "chx_nl_rows_cell_fl": (
         C.c_int,
-        [_I32, _I32, Box, _F, C.POINTER(_I32), _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P],
+        [_I32, _I32, Box, _F, C.POINTER(_I32), _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P],
     ),
     "chx_nl_finish_padding": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),
     "chx_pack_langevin": (C.c_int, [_P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _I32, _P, _P, _P]),

@@ -14,103 +14,37 @@
 
 #include "chx_common.h"
 #include "chx_internal.h"
+#include "chx_cell.h"
 
 #define CHX_CELL_CAP 1024  // half-row candidates kept on chip per row
 
 
-// set bits of a ballot below this lane (v_mbcnt: two instructions instead of mask, and, two popcounts)
-__device__ __forceinline__ int lanes_below(unsigned long long ballot) {
-  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ballot, 0u));
-}
-
-// The 27 cells around cell (cx,cy,cz) are at most 18 contiguous index ranges of the cell-ordered arrays (the three
-// x-neighbours of a (y,z) row are adjacent except across the periodic seam).  Lane r < 18 fetches the bounds of
-// range r -- all 18 in one round trip -- and a wave-wide prefix sum flattens them into one candidate index space
-// [0, total): rng_s[r] = first array index of range r, rng_o[r] = flat index of its first candidate (LDS, per wave).
-__device__ __forceinline__ int cell_ranges(const CellGrid& g, int cx, int cy, int cz, const int32_t* __restrict__ cell_start,
-                                           int lane, int* rng_s, int* rng_o) {
-  int rs = 0, re = 0;
-  if (lane < 18) {
-    const int combo = lane >> 1, sub = lane & 1;
-    int zz = cz + combo / 3 - 1, yy = cy + combo % 3 - 1;  // periodic wrap without a division
-    zz = zz < 0 ? zz + g.ncz : (zz >= g.ncz ? zz - g.ncz : zz);
-    yy = yy < 0 ? yy + g.ncy : (yy >= g.ncy ? yy - g.ncy : yy);
-    const int row = (zz * g.ncy + yy) * g.ncx;
-    int a0 = 0, a1 = 0;
-    if (g.ncx == 3) {
-      if (sub == 0) { a0 = row; a1 = row + 3; }
-    } else if (cx == 0) {
-      if (sub == 0) { a0 = row + g.ncx - 1; a1 = row + g.ncx; } else { a0 = row; a1 = row + 2; }
-    } else if (cx == g.ncx - 1) {
-      if (sub == 0) { a0 = row + cx - 1; a1 = row + cx + 1; } else { a0 = row; a1 = row + 1; }
-    } else {
-      if (sub == 0) { a0 = row + cx - 1; a1 = row + cx + 2; }
-    }
-    if (a1 > a0) {
-      rs = cell_start[a0];
-      re = cell_start[a1];
-    }
-  }
-  const int len = re - rs;
-  int incl = len;
-#pragma unroll
-  for (int o = 1; o < 32; o <<= 1) {
-    const int v = __shfl_up(incl, o, CHX_WAVE);
-    if (lane >= o) incl += v;
-  }
-  const int total = __shfl(incl, 17, CHX_WAVE);
-  if (lane < 18) {
-    rng_s[lane] = rs;
-    rng_o[lane] = incl - len;
-  }
-  __threadfence_block();
-  return total;
-}
-
 // One wavefront builds the rows of ONE particle (cell-order index w): scans the 27 surrounding cells, writes the
 // force-list row in scan order (WRITE_FL) and the half row rank-sorted ascending, as jnp.where(mask, size=M) returns
 // it.  cand = this wave's CHX_CELL_CAP words of LDS.
+// the per-cell candidate lists k_cell_sort may have written (chx_cell.h); list == NULL: none
+struct CandLists {
+  const uint32_t* list;
+  const int32_t* len;
+  int cap;
+};
+
 template <bool WRITE_FL>
 __device__ __forceinline__ void build_row_of_particle(
     int w, uint32_t* cand, const float4* __restrict__ xs4, int n, int m, const Box3& box, float T, const CellGrid& g,
     const int32_t* __restrict__ cell_start, const uint32_t* __restrict__ sorted_ids, uint32_t* __restrict__ nl,
     uint32_t* __restrict__ first_out, int32_t* __restrict__ n_nbr, int fg, int fcap, uint32_t* __restrict__ fl,
-    int32_t* __restrict__ deg, int32_t* __restrict__ status) {
+    int32_t* __restrict__ deg, int32_t* __restrict__ status, const CandLists& cl) {
   const int lane = lane_id();
   const uint32_t i = sorted_ids[w];
   const float4 xw = xs4[w];  // positions in cell order: candidate loads below are coalesced
   const float xi = xw.x, yi = xw.y, zi = xw.z;
   const int c = __float_as_int(xw.w);  // packed by k_cell_sort: 10 bits per axis
   const int cx = c & 1023, cy = (c >> 10) & 1023, cz = c >> 20;
-  int* rng_s = reinterpret_cast<int*>(cand) + CHX_CELL_CAP - 40;  // tail of this wave's LDS slice
-  int* rng_o = rng_s + 20;
-  const int total = cell_ranges(g, cx, cy, cz, cell_start, lane, rng_s, rng_o);
   int count_h = 0, count_f = 0;
-  int r = 0;  // range holding this lane's candidate; candidates only move forward
-  // candidate of the NEXT iteration is requested before the current one is processed, so the
-  // loop's global loads overlap instead of forming a chain of dependent round trips
-  int k_n = 0;
-  uint32_t j_n = 0;
-  float4 x_n = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (lane < total) {
-    while (r < 17 && rng_o[r + 1] <= lane) ++r;
-    k_n = rng_s[r] + (lane - rng_o[r]);
-    j_n = sorted_ids[k_n];
-    x_n = xs4[k_n];
-  }
-  for (int t0 = 0; t0 < total; t0 += CHX_WAVE) {
-    const int t = t0 + lane;
+  // one batch of 64 candidates: candidate index k (into the cell-ordered arrays), its original id j, its position
+  auto test_batch = [&](int t, int total, int k, uint32_t j, const float4& xk) __attribute__((always_inline)) {
     bool ok = false, hi = false;
-    const uint32_t j = j_n;
-    const int k = k_n;
-    const float4 xk = x_n;
-    if (t + CHX_WAVE < total) {
-      const int tn = t + CHX_WAVE;
-      while (r < 17 && rng_o[r + 1] <= tn) ++r;
-      k_n = rng_s[r] + (tn - rng_o[r]);
-      j_n = sorted_ids[k_n];
-      x_n = xs4[k_n];
-    }
     if (t < total) {
       hi = j > i;
       float rx, ry, rz;  // x_i - x_j for row i of the half list, x_j - x_i for row j
@@ -134,6 +68,62 @@ __device__ __forceinline__ void build_row_of_particle(
       if (okh && slot < CHX_CELL_CAP - 40) cand[slot] = j;
       count_h += __popcll(bh);
     }
+  };
+  const int c_lin = (cz * g.ncy + cy) * g.ncx + cx;
+  const int listed_total = cl.list != nullptr ? cl.len[c_lin] : 0x7FFFFFFF;
+  if (listed_total <= cl.cap) {
+    // The cell's neighbourhood is written out as a list of candidate indices (k_cell_sort, once per cell): read it with
+    // coalesced loads.  Indices two batches ahead and the gathers of the next batch are requested before the current
+    // batch is processed, so the loop's loads overlap instead of forming a chain of dependent round trips.
+    const int total = listed_total;
+    const uint32_t* lst = cl.list + (size_t)c_lin * cl.cap;
+    uint32_t k_n = lane < total ? lst[lane] : 0u;
+    uint32_t k_nn = lane + CHX_WAVE < total ? lst[lane + CHX_WAVE] : 0u;
+    uint32_t j_n = sorted_ids[k_n];
+    float4 x_n = xs4[k_n];
+    for (int t0 = 0; t0 < total; t0 += CHX_WAVE) {
+      const int t = t0 + lane;
+      const uint32_t j = j_n;
+      const int k = (int)k_n;
+      const float4 xk = x_n;
+      if (t0 + CHX_WAVE < total) {  // (wave-uniform)
+        k_n = k_nn;
+        j_n = sorted_ids[k_n];
+        x_n = xs4[k_n];
+        k_nn = t + 2 * CHX_WAVE < total ? lst[t + 2 * CHX_WAVE] : 0u;
+      }
+      test_batch(t, total, k, j, xk);
+    }
+  } else {
+    // no list for this cell (none written, or the neighbourhood is longer than a list holds): work the neighbourhood's
+    // index ranges out here and search them batch by batch
+    int* rng_s = reinterpret_cast<int*>(cand) + CHX_CELL_CAP - 40;  // tail of this wave's LDS slice
+    int* rng_o = rng_s + 20;
+    const int total = cell_ranges(g, cx, cy, cz, cell_start, lane, rng_s, rng_o);
+    int r = 0;  // range holding this lane's candidate; candidates only move forward
+    int k_n = 0;
+    uint32_t j_n = 0;
+    float4 x_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < total) {
+      while (r < 17 && rng_o[r + 1] <= lane) ++r;
+      k_n = rng_s[r] + (lane - rng_o[r]);
+      j_n = sorted_ids[k_n];
+      x_n = xs4[k_n];
+    }
+    for (int t0 = 0; t0 < total; t0 += CHX_WAVE) {
+      const int t = t0 + lane;
+      const uint32_t j = j_n;
+      const int k = k_n;
+      const float4 xk = x_n;
+      if (t + CHX_WAVE < total) {
+        const int tn = t + CHX_WAVE;
+        while (r < 17 && rng_o[r + 1] <= tn) ++r;
+        k_n = rng_s[r] + (tn - rng_o[r]);
+        j_n = sorted_ids[k_n];
+        x_n = xs4[k_n];
+      }
+      test_batch(t, total, k, j, xk);
+    }
   }
   // force-list row: the force kernel gathers whole chunks (and chunk 0 speculatively), so the
   // unused slots of the chunks it can touch must hold a valid index; later chunks are never read
@@ -151,12 +141,21 @@ __device__ __forceinline__ void build_row_of_particle(
   // half row: rank sort -> ascending ids, as jnp.where(mask, size=M) returns them
   uint32_t* nl_row = nl + (size_t)i * m;
   uint32_t mn = 0xFFFFFFFFu;
-  for (int t = lane; t < kept; t += CHX_WAVE) {
-    const uint32_t v = cand[t];
-    mn = v < mn ? v : mn;
+  if (kept <= CHX_WAVE) {
+    // the common case: the row fits one value per lane -- ranks from lane broadcasts (v_readlane), no LDS traffic
+    const uint32_t v = lane < kept ? cand[lane] : 0xFFFFFFFFu;
+    mn = v;
     int rank = 0;
-    for (int u = 0; u < kept; ++u) rank += cand[u] < v ? 1 : 0;
-    if (rank < m) nl_row[rank] = v;
+    for (int u = 0; u < kept; ++u) rank += (uint32_t)__builtin_amdgcn_readlane((int)v, u) < v ? 1 : 0;
+    if (lane < kept && rank < m) nl_row[rank] = v;
+  } else {
+    for (int t = lane; t < kept; t += CHX_WAVE) {
+      const uint32_t v = cand[t];
+      mn = v < mn ? v : mn;
+      int rank = 0;
+      for (int u = 0; u < kept; ++u) rank += cand[u] < v ? 1 : 0;
+      if (rank < m) nl_row[rank] = v;
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -185,12 +184,12 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
     const int32_t* __restrict__ cell_of, const int32_t* __restrict__ cell_start,
     const uint32_t* __restrict__ sorted_ids, uint32_t* __restrict__ nl, uint32_t* __restrict__ first_out,
     int32_t* __restrict__ n_nbr, int fg, int fcap, uint32_t* __restrict__ fl, int32_t* __restrict__ deg,
-    int32_t* __restrict__ status) {
+    int32_t* __restrict__ status, CandLists cl) {
   __shared__ uint32_t cand_all[4][CHX_CELL_CAP];
   const int w0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (w0 >= n) return;
   build_row_of_particle<true>(w0, cand_all[threadIdx.x >> 6], xs4, n, m, box, T, g, cell_start, sorted_ids, nl, first_out,
-                              n_nbr, fg, fcap, fl, deg, status);
+                              n_nbr, fg, fcap, fl, deg, status, cl);
 }
 
 // One wavefront per CELL: the (about ten at the BASELINE density) particles of a cell share their 27-cell
@@ -394,7 +393,7 @@ __global__ __launch_bounds__(256) void k_nl_build_cellwise_fl(
       const int ii = __builtin_ctzll(redo);
       redo &= redo - 1;
       build_row_of_particle<false>(hb + ii, cand, xs4, n, m, box, T, g, cell_start, sorted_ids, nl, first_out, n_nbr, fg, fcap,
-                                   fl, deg, status);
+                                   fl, deg, status, CandLists{nullptr, nullptr, 0});
     }
   }
 }
@@ -479,7 +478,9 @@ extern "C" int chx_cell_bin_fl(const float* xyz, int32_t n, chx_box_t box, float
   if (rc != CHX_OK) return rc;
   CellGrid grid;
   rc = chx_cell_prepare(xyz, n, box, cutoff_plus_skin, nc_h, cell_of, cell_count, cell_start, sorted_ids, status8, 8, &grid,
-                        chx_stream(stream), xs4_out, &rd);  // (the cell sort also emits xs4)
+                        chx_stream(stream), xs4_out, &rd,  // (the cell sort also emits xs4 and the candidate lists)
+                        riders ? riders->cand_list : nullptr, riders ? riders->cand_len : nullptr,
+                        riders ? riders->cand_cap : 0);
   if (rc != CHX_OK) return rc;
   return chx_check_launch("chx_cell_bin_fl");
 }
@@ -489,8 +490,10 @@ extern "C" int chx_nl_rows_cell_fl(int32_t n, int32_t m, chx_box_t box, float cu
                                    const int32_t* cell_of, const int32_t* cell_start, const uint32_t* sorted_ids,
                                    int32_t* status8, const float* xs4, uint32_t* nl_rows_out, uint32_t* first_out,
                                    int32_t* n_nbr_out, int32_t g, int32_t chunks, uint32_t* fl_out, int32_t* deg_out,
-                                   int32_t* publish_host_dst8, chx_stream_t stream) {
+                                   int32_t* publish_host_dst8, const uint32_t* cand_list, const int32_t* cand_len,
+                                   int32_t cand_cap, chx_stream_t stream) {
   CHX_REQUIRE(n >= 1 && m >= 1, "need n >= 1, m >= 1");
+  CHX_REQUIRE((cand_list == nullptr) == (cand_len == nullptr) && cand_cap >= 0, "candidate lists need both arrays");
   CHX_REQUIRE(nc_h && cell_of && cell_start && sorted_ids && status8 && xs4 && nl_rows_out && first_out && n_nbr_out &&
                   fl_out && deg_out,
               "null pointer");
@@ -514,9 +517,10 @@ extern "C" int chx_nl_rows_cell_fl(int32_t n, int32_t m, chx_box_t box, float cu
   static const int forced = [] { const char* e = getenv("CHX_BUILD_KERNEL"); return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'c' ? 2 : 0)); }();
   const bool per_particle = forced == 1 || (forced == 0 && (int64_t)grid.ncx * grid.ncy * grid.ncz < 8192);
   if (per_particle) {
+    const CandLists cl = {cand_cap > 0 ? cand_list : nullptr, cand_len, cand_cap};
     hipLaunchKernelGGL(k_nl_build_cell_fl, dim3(wb), dim3(256), 0, st, xs, n, m, make_box3(box), T, grid,
                        cell_of, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, chunks * CHX_FL_QUAD * g,
-                       fl_out, deg_out, status8);
+                       fl_out, deg_out, status8, cl);
   } else {
     const int ncell = grid.ncx * grid.ncy * grid.ncz;
     static const int split_env = [] { const char* e = getenv("CHX_BUILD_SPLIT"); return e ? atoi(e) : 0; }();
@@ -552,7 +556,8 @@ extern "C" int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_
   if (rc != CHX_OK) return rc;
   return chx_nl_rows_cell_fl(n, m, box, cutoff_plus_skin, nc_h, cell_of, cell_start, sorted_ids, status8, xs4_out,
                              nl_rows_out, first_out, n_nbr_out, g, chunks, fl_out, deg_out,
-                             riders ? riders->publish_host_dst8 : nullptr, stream);
+                             riders ? riders->publish_host_dst8 : nullptr, riders ? riders->cand_list : nullptr,
+                             riders ? riders->cand_len : nullptr, riders ? riders->cand_cap : 0, stream);
 }
 
 // padding (chiron/neighbors.py:603-620) and list mask (:623) for rows that hold only their real entries

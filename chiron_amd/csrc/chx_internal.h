@@ -35,7 +35,9 @@ int chx_cell_prepare(const float* xyz, int n, chx_box_t box, float cutoff_plus_s
                      const int32_t* nc_h, int32_t* cell_of, int32_t* cell_count, int32_t* cell_start,
                      uint32_t* sorted_ids, int32_t* status, int status_len, CellGrid* g_out,
                      hipStream_t st, float* xs4_out = nullptr,  // xs4_out: positions in cell order, .w = cell index
-                     const BinRiders* riders = nullptr);
+                     const BinRiders* riders = nullptr,
+                     // optional per-cell candidate index lists (chx_cell.h): ncell * cand_cap words and ncell lengths
+                     uint32_t* cand_list = nullptr, int32_t* cand_len = nullptr, int cand_cap = 0);
 
 // ctrl != NULL: the kernel is part of a Langevin chunk and turns into a no-op
 // (setting ctrl[1]) when ctrl[0] says the skin check fired.

@@ -9,6 +9,7 @@
 
 #include "chx_common.h"
 #include "chx_internal.h"
+#include "chx_cell.h"
 
 // ---------------------------------------------------------------------------
 // shared row epilogue: padding (chiron/neighbors.py:603-620) and mask (:623)
@@ -236,10 +237,22 @@ __device__ __forceinline__ void cell_emit_sorted(const float* __restrict__ xyz, 
 __global__ __launch_bounds__(256) void k_cell_sort(const int32_t* __restrict__ cell_start, int ncell,
                                                    uint32_t* __restrict__ sorted_ids, const float* __restrict__ xyz,
                                                    float4* __restrict__ xs4, int ncx, int ncy,
-                                                   int32_t* __restrict__ cell_count, BinRiders rd) {
+                                                   int32_t* __restrict__ cell_count, BinRiders rd, CellGrid g,
+                                                   uint32_t* __restrict__ cand_list, int32_t* __restrict__ cand_len,
+                                                   int cand_cap) {
   const int lane = lane_id();
-  const int ci = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (ci >= ncell) return;
+  int ci = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (ci >= ncell) {
+    // The second half of the grid (launched only when the lists are wanted): one wavefront per cell writes the candidate
+    // indices of the cell's 27-cell neighbourhood, once for all of its rows (chx_cell.h).  Wavefronts of their own, not a
+    // second job of the sorting wavefronts: either job is a short chain of dependent steps, and a few thousand wavefronts
+    // leave the chip mostly idle -- side by side the two chains cost the longer one, in sequence their sum (measured).
+    ci -= ncell;
+    if (cand_list == nullptr || ci >= ncell || cell_start[ci + 1] <= cell_start[ci]) return;  // (an empty cell has no rows)
+    const CellRangeLoads ranges = cell_candidates_begin(g, ci % ncx, (ci / ncx) % ncy, ci / (ncx * ncy), cell_start, lane);
+    cell_candidates_finish(ranges, ci, lane, cand_list, cand_len, cand_cap);
+    return;
+  }
   // the scatter's cursors are done with: leave the counters zeroed for the next build (no zeroing launch there)
   if (lane == 0) cell_count[ci] = 0;
   // what goes into xs4[].w: the cell's grid coordinates, 10 bits each (chx_cell_grid_h keeps every axis <= 1024 cells),
@@ -385,7 +398,8 @@ __global__ __launch_bounds__(256) void k_nl_build_cell(
 int chx_cell_prepare(const float* xyz, int n, chx_box_t box, float cutoff_plus_skin,
                      const int32_t* nc_h, int32_t* cell_of, int32_t* cell_count, int32_t* cell_start,
                      uint32_t* sorted_ids, int32_t* status, int status_len, CellGrid* g_out,
-                     hipStream_t st, float* xs4_out, const BinRiders* riders) {
+                     hipStream_t st, float* xs4_out, const BinRiders* riders, uint32_t* cand_list, int32_t* cand_len,
+                     int cand_cap) {
   CHX_REQUIRE(box.periodic && box.lx > 0 && box.ly > 0 && box.lz > 0, "periodic box required");
   CHX_REQUIRE(nc_h[0] >= 3 && nc_h[1] >= 3 && nc_h[2] >= 3, "need >= 3 cells per axis");
   // k_cell_sort packs a cell's grid coordinates into 10 bits per axis (xs4.w) and the build kernels decode them
@@ -414,8 +428,12 @@ int chx_cell_prepare(const float* xyz, int n, chx_box_t box, float cutoff_plus_s
                      rd.ctrl_keep);
   hipLaunchKernelGGL(k_cell_scatter, dim3(pb), dim3(256), 0, st, cell_of, n, cell_start, cell_count,
                      sorted_ids);
-  hipLaunchKernelGGL(k_cell_sort, dim3((unsigned)(((int64_t)ncell * CHX_WAVE + 255) / 256)), dim3(256), 0, st,
-                     cell_start, ncell, sorted_ids, xyz, reinterpret_cast<float4*>(xs4_out), g.ncx, g.ncy, cell_count, rd);
+  const bool lists = cand_list && cand_len && cand_cap > 0;
+  // (with the lists: twice the wavefronts, the second half writes them -- k_cell_sort)
+  const int64_t sort_waves = (int64_t)ncell * (lists ? 2 : 1);
+  hipLaunchKernelGGL(k_cell_sort, dim3((unsigned)((sort_waves * CHX_WAVE + 255) / 256)), dim3(256), 0, st,
+                     cell_start, ncell, sorted_ids, xyz, reinterpret_cast<float4*>(xs4_out), g.ncx, g.ncy, cell_count, rd, g,
+                     lists ? cand_list : nullptr, cand_len, cand_cap);
   return CHX_OK;
 }
 

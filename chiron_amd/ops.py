@@ -175,18 +175,29 @@ def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: in
     key = (n, ncell, str(dev))
     if scratch is not None and scratch.get("key") == key:
         cell_of, cell_count, cell_start, status, xs4 = scratch["arrays"]
+        cand = scratch.get("cand")
     else:
         cell_of = torch.empty((n,), **i32)
         cell_count = torch.zeros((ncell + 1,), **i32)  # (zero on entry, left zeroed by every build: include/chx.h)
         cell_start = torch.empty((ncell + 1,), **i32)
         status = torch.empty((_lib.BUILD_STATUS_WORDS,), **i32)
         xs4 = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        # per-cell candidate index lists for the per-particle row kernel (grids below 8192 cells: beyond that the
+        # cell-wise kernel shares the neighbourhood scan among a cell's rows itself): capacity = 1.5 x the mean
+        # neighbourhood, a longer one keeps the range search (include/chx.h: chx_build_riders_t::cand_list)
+        cand = None
+        if ncell < 8192 and os.environ.get("CHX_BUILD_LISTS", "1") != "0":
+            cap = min(8192, (int(1.5 * 27.0 * n / ncell) + 64 + 63) // 64 * 64)
+            cand = (torch.empty((ncell, cap), **i32), torch.empty((ncell,), **i32), cap)
         if scratch is not None:
-            scratch["key"], scratch["arrays"] = key, (cell_of, cell_count, cell_start, status, xs4)
+            scratch["key"], scratch["arrays"], scratch["cand"] = key, (cell_of, cell_count, cell_start, status, xs4), cand
     rd = None
     publish = None
-    if riders:
+    if riders or cand is not None:
+        riders = riders or {}
         rd = _lib.BuildRiders()
+        if cand is not None:
+            rd.cand_list, rd.cand_len, rd.cand_cap = cand[0].data_ptr(), cand[1].data_ptr(), cand[2]
         cp = riders.get("copy")
         if cp is not None:
             _require_device(cp)
@@ -226,7 +237,9 @@ def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: in
     deg = torch.empty((n,), **i32)
     check(
         lib.chx_nl_rows_cell_fl(n, m, box, cs, nc, _ptr(cell_of), _ptr(cell_start), _ptr(sorted_ids), _ptr(status), _ptr(xs4),
-                                _ptr(nl), _ptr(first), _ptr(n_nbr), g, chunks, _ptr(fl), _ptr(deg), publish, stream),
+                                _ptr(nl), _ptr(first), _ptr(n_nbr), g, chunks, _ptr(fl), _ptr(deg), publish,
+                                _ptr(cand[0]) if cand is not None else None, _ptr(cand[1]) if cand is not None else None,
+                                cand[2] if cand is not None else 0, stream),
         "chx_nl_rows_cell_fl",
     )
     return nl, first, n_nbr, sorted_ids, fl, deg, status

@@ -159,6 +159,13 @@ typedef struct {
   int32_t* ctrl_reset;        /* CHX_CTRL_WORDS ints: what chx_ctrl_reset writes ... */
   int32_t ctrl_keep;          /* ... except the words chx_pack_langevin's ctrl_keep names */
   int32_t* publish_host_dst8; /* HOST-MAPPED: status[0..7] is stored there (system scope) by the chain's last launch */
+  /* Optional workspace that makes the per-particle row kernel ~30 % faster: the binning writes every cell's 27-cell
+   * neighbourhood out once as a list of candidate indices (cand_list: ncell * cand_cap words, cand_len: ncell ints),
+   * which the ~10 rows of the cell then read instead of each working the neighbourhood's index ranges out and searching
+   * them.  A neighbourhood longer than cand_cap keeps the search; same bits either way.  NULL / 0 = off. */
+  uint32_t* cand_list;
+  int32_t* cand_len;
+  int32_t cand_cap;
 } chx_build_riders_t;
 int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_box_t box, float cutoff_plus_skin,
                          const int32_t* nc_h, int32_t* cell_of, int32_t* cell_count,
@@ -178,7 +185,8 @@ int chx_nl_rows_cell_fl(int32_t n, int32_t m, chx_box_t box, float cutoff_plus_s
                         const int32_t* cell_of, const int32_t* cell_start, const uint32_t* sorted_ids,
                         int32_t* status8, const float* xs4, uint32_t* nl_rows_out, uint32_t* first_out,
                         int32_t* n_nbr_out, int32_t g, int32_t chunks, uint32_t* fl_out, int32_t* deg_out,
-                        int32_t* publish_host_dst8, chx_stream_t stream);
+                        int32_t* publish_host_dst8, const uint32_t* cand_list, const int32_t* cand_len,
+                        int32_t cand_cap, chx_stream_t stream);
 int chx_nl_finish_padding(uint32_t* nl_inout, const uint32_t* first, const int32_t* n_nbr, int32_t n,
                           int32_t m, int32_t* nl_mask_out, chx_stream_t stream);
 
