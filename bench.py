@@ -141,9 +141,15 @@ class _RankChild:
         return self.rate
 
     def release(self, summary: dict):
-        os.write(self.go_w, (json.dumps(summary) + "\n").encode())
-        os.close(self.go_w)
-        os.close(self.report_r)
+        try:
+            os.write(self.go_w, (json.dumps(summary) + "\n").encode())
+        except OSError:  # the child is gone (it failed before it parked): the launcher's wait loop reports its exit code
+            pass
+        for fd in (self.go_w, self.report_r):
+            try:
+                os.close(fd)
+            except OSError:
+                pass
 
     def discard(self):
         """Replace, never re-exec: the child is told to go away and a FRESH interpreter takes its rank."""

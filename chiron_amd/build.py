@@ -87,31 +87,50 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(f"libchx.so is current (source hash {source_hash()[:16]})")
         return OUT
+    import fcntl
     from concurrent.futures import ThreadPoolExecutor
 
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     objdir = os.path.join(HERE, "_obj")
     os.makedirs(objdir, exist_ok=True)
+    # One builder at a time (several ranks may call build() at once): the others wait here and then find the library
+    # current.  Temporary files carry the pid besides, so that even builders that cannot share the lock (another
+    # filesystem view) never write through each other's half-made files.
+    lock = open(os.path.join(objdir, ".build.lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and not needs_build():
+            return OUT
+        return _build_locked(hipcc, objdir, force, verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(hipcc: str, objdir: str, force: bool, verbose: bool) -> str:
+    from concurrent.futures import ThreadPoolExecutor
+
     cflags = [f for f in FLAGS if f != "-shared"]
     tree = source_hash()
+    tag = f".{os.getpid()}.tmp"
 
     def compile_one(src):
         # (the hash string is compiled into chx_core.hip only: every other unit is independent of the tree's hash)
         extra = [f'-DCHX_SOURCE_HASH="{tree}"'] if os.path.basename(src) == "chx_core.hip" else []
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + "." + _object_key(src, cflags + extra) + ".o")
         if force or not os.path.exists(obj):
-            cmd = [hipcc] + cflags + extra + ["-c", src, "-o", obj + ".tmp"]
+            cmd = [hipcc] + cflags + extra + ["-c", src, "-o", obj + tag]
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)
-            os.replace(obj + ".tmp", obj)
+            os.replace(obj + tag, obj)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as pool:
         objs = list(pool.map(compile_one, sources()))
-    for stale in set(glob.glob(os.path.join(objdir, "*.o"))) - set(objs):
+    for stale in set(glob.glob(os.path.join(objdir, "*.o"))) - set(objs):  # (under the lock: nobody is about to link them)
         os.remove(stale)
-    tmp = OUT + ".tmp"
+    tmp = OUT + tag
     cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", tmp]
     if verbose:
         print(" ".join(cmd))

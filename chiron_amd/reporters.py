@@ -102,8 +102,9 @@ class _SimulationReporter:
 class LangevinDynamicsReporter(_SimulationReporter):
     _name = "langevin_reporter"
 
-    def __init__(self, name: str = None, buffer_size: int = 1, topology=None):
-        super().__init__(name or self._name, buffer_size)
+    def __init__(self, file_name: str = None, buffer_size: int = 1, topology=None, name: str = None):
+        # (first parameter named as in chiron/reporters.py:303-308; `name=` was this package's spelling until round 3)
+        super().__init__(file_name or name or self._name, buffer_size)
         self.topology = topology
         self.xtc_file_path = None
         self._default_properties = ["positions", "box_vectors", "u_kn", "state_index", "step"]
@@ -116,10 +117,11 @@ class LangevinDynamicsReporter(_SimulationReporter):
 class MCReporter(_SimulationReporter):
     _name = "mc_reporter"
 
-    def __init__(self, name=None, buffer_size: int = 1):
-        if isinstance(name, int):  # the reference is also called as MCReporter(1)
-            name, buffer_size = None, name
-        super().__init__(name or self._name, buffer_size)
+    def __init__(self, file_name=None, buffer_size: int = 1, name=None):
+        # (chiron/reporters.py:278)
+        if isinstance(file_name, int):  # the reference is also called as MCReporter(1)
+            file_name, buffer_size = None, file_name
+        super().__init__(file_name or name or self._name, buffer_size)
 
     @classmethod
     def get_name(cls):
@@ -129,8 +131,9 @@ class MCReporter(_SimulationReporter):
 class MultistateReporter(_SimulationReporter):
     _name = "multistate_reporter"
 
-    def __init__(self, name: str = None, buffer_size: int = 1):
-        super().__init__(name or self._name, buffer_size)
+    def __init__(self, file_name: str = None, buffer_size: int = 1, name: str = None):
+        # (chiron/reporters.py:220-224)
+        super().__init__(file_name or name or self._name, buffer_size)
         self._default_properties = ["positions", "box_vectors", "u_kn", "state_index", "step"]
 
     @classmethod

@@ -1,0 +1,49 @@
+#!/bin/bash
+# Round 4's evidence in one GPU call (GPU box only):  bash scripts/r04_profiles.sh
+#  (1) the driver's own bench command, plain and under rocprofv3 --kernel-trace --stats -> profiles/r04_bench_driver_cmd_*
+#  (2) one --stats pass of scripts/kernel_bench.py per quoted system state (equilibrated snapshot on disk) ->
+#      profiles/r04_kernel_states.md: every roofline fraction recomputes from one row
+#  (3) the PMC passes over the hot kernels (separate --pmc runs) -> profiles/pmc_traffic.json, r04_pmc_hot_kernels.md
+#  (4) the default bench line -> profiles/r04_bench_default.json
+set -o pipefail
+export TMPDIR=/tmp
+R=$PWD
+out=$R/gpurun_out/r04_prof
+mkdir -p "$out"
+echo "== (1) driver command" | tee "$out/progress.log"
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$out/bench_plain.log" 2> "$out/bench_plain.err" || exit 1
+rm -rf /tmp/r04_drv
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/r04_drv -- python3 "$R/bench.py" --gpus 1 --steps 20 --warmup 5 > "$out/bench_prof.log" 2> "$out/bench_prof.err") || exit 1
+python3 scripts/stats_to_md.py /tmp/r04_drv r04_driver_cmd "$out/bench_prof.log" "$out/bench_plain.log" \
+  "Round 4: rocprofv3 --kernel-trace --stats of the driver's own command (python3 bench.py --gpus 1 --steps 20 --warmup 5)" || exit 1
+echo "== (2) per-state kernel passes" | tee -a "$out/progress.log"
+export KB_SNAPSHOT_DIR=/tmp/kb_snap_r04
+rm -rf "$KB_SNAPSHOT_DIR"
+{
+  echo "# Round 4: one system state per row -- rocprofv3 --kernel-trace --stats of \`scripts/kernel_bench.py <workload>\`"
+  echo
+  sed -n '2,12p' scripts/state_roofline.py | sed 's/^"""//; s/"""$//'
+  echo
+  echo "| state | kernel | lanes / particle | P_nl | algorithmic bytes | launches | rocprofv3 avg (us) | GB/s | fraction of 8 TB/s | HIP-event time in the same pass (us) |"
+  echo "|---|---|---|---|---|---|---|---|---|---|"
+} > "$out/r04_kernel_states.md"
+for spec in "c3 20000" "c4 20000" "c3_liquid 4000" "c4_liquid 1000"; do
+  set -- $spec
+  wl=$1; export KB_WARM=$2
+  echo "   $wl (equilibrated $KB_WARM steps)" | tee -a "$out/progress.log"
+  GS=auto KB_REPS=2 python3 scripts/kernel_bench.py $wl > "$out/kb_${wl}_equil.log" 2>&1 || exit 1
+  rm -rf /tmp/r04_kb_$wl
+  (cd /tmp && GS=auto KB_SPIN_S=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/r04_kb_$wl -- python3 "$R/scripts/kernel_bench.py" $wl > "$out/kb_${wl}.log" 2>&1) || exit 1
+  python3 scripts/state_roofline.py /tmp/r04_kb_$wl "$out/kb_${wl}.log" $wl >> "$out/r04_kernel_states.md" || exit 1
+done
+cp "$out/r04_kernel_states.md" profiles/r04_kernel_states.md
+echo "== (3) PMC passes" | tee -a "$out/progress.log"
+KB_WARM=20000 bash scripts/pmc_collect.sh "$out/pmc" c3 c4 || exit 1
+cp "$out/pmc/pmc_traffic.json" profiles/pmc_traffic.json
+cp "$out/pmc/pmc_hot_kernels.md" profiles/r04_pmc_hot_kernels.md
+echo "== (4) default bench line" | tee -a "$out/progress.log"
+python3 bench.py > "$out/bench_default.json" 2> "$out/bench_default.err" || exit 1
+cp "$out/bench_default.json" profiles/r04_bench_default.json
+mkdir -p "$out/profiles"
+cp profiles/r04_* profiles/pmc_traffic.json "$out/profiles/"
+echo "== done" | tee -a "$out/progress.log"

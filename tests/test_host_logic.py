@@ -855,6 +855,13 @@ def test_reporter_npz_round_trip(tmp_path):
         rep.report({"positions": torch.zeros(4, 3), "potential_energy": np.float32(9), "step": 5, "box_vectors": np.eye(3, dtype=np.float32)})
         again = LangevinDynamicsReporter.load(rep.save())
         assert again["positions"].shape[0] == 6 and int(again["step"][-1]) == 5
+        # the reference's keyword (chiron/reporters.py:220-224, :278, :303-308): file_name=; positional and the old name= too
+        from chiron_amd.reporters import MultistateReporter
+
+        for cls in (LangevinDynamicsReporter, MCReporter, MultistateReporter):
+            assert str(cls(file_name="by_keyword", buffer_size=3).log_file_path).endswith("by_keyword.npz")
+            assert str(cls("positional").log_file_path).endswith("positional.npz")
+            assert str(cls(name="old_spelling").log_file_path).endswith("old_spelling.npz")
         mc = MCReporter(1)
         mc.report({"n_accepted": 3})
         assert MCReporter.load(mc.save(tmp_path / "mc.npz"))["n_accepted"].tolist() == [3]
