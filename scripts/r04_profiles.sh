@@ -6,23 +6,29 @@
 #  (3) the PMC passes over the hot kernels (separate --pmc runs) -> profiles/pmc_traffic.json, r04_pmc_hot_kernels.md
 #  (4) the default bench line -> profiles/r04_bench_default.json
 set -o pipefail
+PARTS=${PARTS:-"1 2 3 4"}   # which of the four parts to run
+has() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
 export TMPDIR=/tmp
 R=$PWD
 out=$R/gpurun_out/r04_prof
 mkdir -p "$out"
-echo "== (1) driver command" | tee "$out/progress.log"
+echo "== parts: $PARTS" | tee "$out/progress.log"
+if has 1; then
+echo "== (1) driver command" | tee -a "$out/progress.log"
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$out/bench_plain.log" 2> "$out/bench_plain.err" || exit 1
 rm -rf /tmp/r04_drv
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/r04_drv -- python3 "$R/bench.py" --gpus 1 --steps 20 --warmup 5 > "$out/bench_prof.log" 2> "$out/bench_prof.err") || exit 1
 python3 scripts/stats_to_md.py /tmp/r04_drv r04_driver_cmd "$out/bench_prof.log" "$out/bench_plain.log" \
   "Round 4: rocprofv3 --kernel-trace --stats of the driver's own command (python3 bench.py --gpus 1 --steps 20 --warmup 5)" || exit 1
+fi
+if has 2; then
 echo "== (2) per-state kernel passes" | tee -a "$out/progress.log"
 export KB_SNAPSHOT_DIR=/tmp/kb_snap_r04
 rm -rf "$KB_SNAPSHOT_DIR"
 {
   echo "# Round 4: one system state per row -- rocprofv3 --kernel-trace --stats of \`scripts/kernel_bench.py <workload>\`"
   echo
-  sed -n '2,12p' scripts/state_roofline.py | sed 's/^"""//; s/"""$//'
+  python3 -c "import re; print(re.search(r'^\"\"\"(.*?)\"\"\"', open('scripts/state_roofline.py').read(), re.S).group(1))"
   echo
   echo "| state | kernel | lanes / particle | P_nl | algorithmic bytes | launches | rocprofv3 avg (us) | GB/s | fraction of 8 TB/s | HIP-event time in the same pass (us) |"
   echo "|---|---|---|---|---|---|---|---|---|---|"
@@ -37,13 +43,18 @@ for spec in "c3 20000" "c4 20000" "c3_liquid 4000" "c4_liquid 1000"; do
   python3 scripts/state_roofline.py /tmp/r04_kb_$wl "$out/kb_${wl}.log" $wl >> "$out/r04_kernel_states.md" || exit 1
 done
 cp "$out/r04_kernel_states.md" profiles/r04_kernel_states.md
+fi
+if has 3; then
 echo "== (3) PMC passes" | tee -a "$out/progress.log"
 KB_WARM=20000 bash scripts/pmc_collect.sh "$out/pmc" c3 c4 || exit 1
 cp "$out/pmc/pmc_traffic.json" profiles/pmc_traffic.json
 cp "$out/pmc/pmc_hot_kernels.md" profiles/r04_pmc_hot_kernels.md
+fi
+if has 4; then
 echo "== (4) default bench line" | tee -a "$out/progress.log"
 python3 bench.py > "$out/bench_default.json" 2> "$out/bench_default.err" || exit 1
 cp "$out/bench_default.json" profiles/r04_bench_default.json
+fi
 mkdir -p "$out/profiles"
 cp profiles/r04_* profiles/pmc_traffic.json "$out/profiles/"
 echo "== done" | tee -a "$out/progress.log"

@@ -5,9 +5,9 @@ bytes (pair force 24 N + 16 P_nl; fused step + 72 N) and the 8 TB/s H
 
 The pass runs kernel_bench.py on ONE state (the fluid equilibrated for KB_WARM steps, loaded from the on-disk snapshot,
 list built from it), so every k_lj_fl launch in the directory is a launch on that state and the fraction recomputes
-from this one row: frac = bytes / (avg_us * 1e-6) / 8e12.  The step kernel's row carries the caveat of kernel_bench.py:
-its skin check is disabled, the list ages while it is timed, and the pruned rows grow shorter than a live run's -- the
-live figure is the one in the bench line / the driver-command table."""
+from this one row: frac = bytes / (avg_us * 1e-6) / 8e12.  (The pass also launches the fused step kernel, but with its
+skin check disabled: the list ages while it is timed and the pruned rows grow shorter than a live run's -- no row is
+printed for it; its live figure is `roofline` in the bench line and the driver-command table.)"""
 import csv, glob, os, re, sys
 
 prof, log, wl = sys.argv[1:4]
@@ -26,7 +26,7 @@ for path in glob.glob(os.path.join(prof, "**", "*kernel_stats.csv"), recursive=T
 force = [(k, v) for k, v in rows.items() if k.startswith("void k_lj_fl<") and "true, false>" in k]
 step = [(k, v) for k, v in rows.items() if k.startswith("void k_lj_step<") and ", true, false, false>" in k]
 bf, bs = 24 * n + 16 * p_nl, 96 * n + 16 * p_nl
-for kind, found, b in (("pair force `k_lj_fl`", force, bf), ("fused step `k_lj_step` (aged list: see header)", step, bs)):
+for kind, found, b in (("pair force `k_lj_fl`", force, bf),):
     for name, (calls, avg) in found:
         print(f"| {wl} (N = {n}, rho* = {rho}) | {kind} | {g} | {p_nl} | {b} | {calls} | {avg:.2f} | {b / (avg * 1e-6) / 1e9:.0f} | "
               f"**{b / (avg * 1e-6) / 8e12:.3f}** | {ev_force:.2f} |" if kind.startswith("pair") else

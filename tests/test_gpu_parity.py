@@ -1844,18 +1844,90 @@ def test_both_cell_build_kernels_write_the_same_bits(tmp_path):
     import sys
 
     got = {}
-    for kern in ("particle", "cell"):
-        path = tmp_path / f"{kern}.npz"
-        env = dict(os.environ, CHX_BUILD_KERNEL=kern)
+    # (round 4: the per-particle kernel reads per-cell candidate index lists written by the binning -- chx_cell.h --
+    # unless CHX_BUILD_LISTS=0, or a cell's neighbourhood is longer than a list holds: the "dense" system; a third dump
+    # runs it on the older range search)
+    for kern, lists in (("particle", "1"), ("cell", "1"), ("particle", "0")):
+        path = tmp_path / f"{kern}{lists}.npz"
+        env = dict(os.environ, CHX_BUILD_KERNEL=kern, CHX_BUILD_LISTS=lists)
         r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_dump_cell_build.py"), str(path)],
                            env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        got[kern] = np.load(path)
-    a, b = got["particle"], got["cell"]
-    assert sorted(a.files) == sorted(b.files) and len(a.files) >= 30
-    for key in a.files:
-        assert np.array_equal(a[key], b[key]), key
+        got[kern + lists] = np.load(path)
+    a = got["particle1"]
+    assert len(a.files) >= 30
+    for other in ("cell1", "particle0"):
+        b = got[other]
+        assert sorted(a.files) == sorted(b.files)
+        for key in a.files:
+            assert np.array_equal(a[key], b[key]), (other, key)
     assert int(a["grow_m"][0]) > 12  # the growth loop really ran (rows longer than the initial capacity)
+
+
+def test_build_riders_and_split_entry_points_write_the_same_bits(ca, O):
+    """Round 4's rebuild chain at the C ABI (include/chx.h): (a) chx_cell_bin_fl + chx_nl_rows_cell_fl == the one call
+    chx_nl_build_cell_fl; (b) the riders -- a copy of the positions, the Langevin state packed into the new internal
+    order, the control-block reset, the status block published to host-mapped memory -- write exactly what the separate
+    launches they replace write (clone, chx_pack_langevin with its ctrl rider, chx_publish)."""
+    import ctypes as C
+
+    from chiron_amd import _lib, ops
+
+    lib = _lib.load()
+    n, m = 5000, 180
+    x, box = O.lj_lattice(n, 0.1, SIGMA, seed=5)
+    rng = np.random.default_rng(1)
+    x = O.periodic_wrap((x + rng.normal(0, 0.05, x.shape)).astype(f32), box)
+    xt, vt = dev(x), dev(rng.normal(size=(n, 3)))
+    mass = dev(rng.uniform(10.0, 50.0, size=n))
+    ref = dev(O.periodic_wrap((x + rng.normal(0, 0.01, x.shape)).astype(f32), box))
+    bh = ops.make_box(dev(box), True)
+    cs = CUTOFF + SKIN
+    ncell, nc = ops.cell_grid(bh, cs, n)
+    assert ncell > 0
+    g, chunks = 4, 6
+    plain = ops.nl_build_cell_fl(xt, bh, cs, m, ncell, nc, g, chunks, {})
+    want_pack = ops.pack_langevin(xt, vt, mass, ref, plain[3], True)
+    for ref3 in (ref, None):
+        f32k = dict(dtype=torch.float32, device="cuda")
+        outs = (torch.zeros((n, 4), **f32k), torch.zeros((n, 3), **f32k), torch.zeros((n,), **f32k), torch.zeros((n, 4), **f32k))
+        ctrl = torch.full((_lib.CTRL_WORDS,), 77, dtype=torch.int32, device="cuda")
+        host = torch.full((8,), -1, dtype=torch.int32).pin_memory()
+        copy = torch.zeros_like(xt)
+        riders = {"copy": copy, "pack": (vt, mass, ref3) + outs, "ctrl": ctrl, "ctrl_keep": 1, "publish": host}
+        got = ops.nl_build_cell_fl(xt, bh, cs, m, ncell, nc, g, chunks, {}, riders=riders)
+        torch.cuda.synchronize()
+        # rows (real entries), first, counts, order, force list (the chunks a row may touch), degrees
+        real = torch.arange(m, device="cuda")[None, :] < plain[2][:, None]
+        used = torch.clamp((plain[5] + 4 * g - 1) // (4 * g), min=1)
+        keep = torch.arange(chunks, device="cuda")[:, None] < used[None, :]
+        assert torch.equal(plain[0][real], got[0][real]) and torch.equal(plain[4][keep], got[4][keep])
+        for k in (1, 2, 3, 5):
+            assert torch.equal(plain[k], got[k]), k
+        assert torch.equal(copy, xt)
+        st = got[6].cpu().numpy()
+        assert np.array_equal(host.numpy()[:7], st[:7]) and host.numpy()[7] == 0 and st[0] == 0 and st[1] == int(plain[2].max())
+        want = want_pack if ref3 is not None else ops.pack_langevin(xt, vt, mass, xt, plain[3], True)
+        for a, b in zip(want, outs):
+            assert torch.equal(a, b)
+        reset = [0, 0, 0, 2**31 - 1, -2, -2, 0, 0, 77, 77, -1, -1, 2**31 - 1, 0, 0, 0]  # ctrl_keep bit 0: words 8, 9 stay
+        assert ctrl.cpu().tolist() == reset
+    # the one-call form, straight through ctypes, against the two halves ops.nl_build_cell_fl makes
+    i32 = dict(dtype=torch.int32, device="cuda")
+    arrs = dict(cell_of=torch.empty((n,), **i32), cell_count=torch.zeros((ncell + 1,), **i32), cell_start=torch.empty((ncell + 1,), **i32),
+                ids=torch.empty((n,), **i32), status=torch.empty((8,), **i32), nl=torch.empty((n, m), **i32), first=torch.empty((n,), **i32),
+                n_nbr=torch.empty((n,), **i32), fl=torch.empty((chunks, n, 4 * g), **i32), deg=torch.empty((n,), **i32),
+                xs4=torch.empty((n, 4), dtype=torch.float32, device="cuda"))
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rc = lib.chx_nl_build_cell_fl(p(xt), n, m, bh, C.c_float(cs), nc, p(arrs["cell_of"]), p(arrs["cell_count"]), p(arrs["cell_start"]),
+                                  p(arrs["ids"]), p(arrs["status"]), p(arrs["nl"]), p(arrs["first"]), p(arrs["n_nbr"]), g, chunks,
+                                  p(arrs["fl"]), p(arrs["deg"]), p(arrs["xs4"]), None, None)
+    assert rc == 0, lib.chx_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(arrs["ids"], plain[3]) and torch.equal(arrs["n_nbr"], plain[2]) and torch.equal(arrs["deg"], plain[5])
+    assert torch.equal(arrs["first"], plain[1]) and int(arrs["cell_count"].abs().sum()) == 0  # (left zeroed for the next build)
+    real = torch.arange(m, device="cuda")[None, :] < plain[2][:, None]
+    assert torch.equal(arrs["nl"][real], plain[0][real])
 
 
 def test_langevin_run_after_an_interrupted_run(ca, O, monkeypatch):
