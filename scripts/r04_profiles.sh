@@ -6,7 +6,7 @@
 #  (3) the PMC passes over the hot kernels (separate --pmc runs) -> profiles/pmc_traffic.json, r04_pmc_hot_kernels.md
 #  (4) the default bench line -> profiles/r04_bench_default.json
 set -o pipefail
-PARTS=${PARTS:-"1 2 3 4"}   # which of the four parts to run
+PARTS=${PARTS:-"1 2 3 4 5"}   # which of the five parts to run
 has() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
 export TMPDIR=/tmp
 R=$PWD
@@ -54,6 +54,25 @@ if has 4; then
 echo "== (4) default bench line" | tee -a "$out/progress.log"
 python3 bench.py > "$out/bench_default.json" 2> "$out/bench_default.err" || exit 1
 cp "$out/bench_default.json" profiles/r04_bench_default.json
+fi
+if has 5; then
+echo "== (5) the live C3 loop alone under the profiler" | tee -a "$out/progress.log"
+# (the metric kernel on nothing but the production loop: 3 s of warm-up and five 20 000-step windows with their rebuilds
+# and refreshes; the driver-command table of part 1 averages the same kernel over every leg of bench.py, two replicas
+# sharing the card included)
+python3 scripts/steps_rate.py c3 20000 5 > "$out/live_plain.log" 2>&1 || exit 1
+rm -rf /tmp/r04_live
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/r04_live -- python3 "$R/scripts/steps_rate.py" c3 20000 5 > "$out/live_prof.log" 2>&1) || exit 1
+{
+  echo "# Round 4: the live C3 Langevin loop alone under rocprofv3 --kernel-trace --stats (\`scripts/steps_rate.py c3 20000 5\`)"
+  echo
+  echo "Un-profiled, same box: \`$(grep median "$out/live_plain.log")\`; under the profiler: \`$(grep median "$out/live_prof.log")\`."
+  echo "Algorithmic bytes of a step at this state: 96 N + 16 P_nl = 12.96 MB (N = 32 768, P_nl = 613 k): fraction of 8 TB/s = 12.96e6 / (avg us x 1e-6) / 8e12."
+  echo
+  echo '```'
+  python3 scripts/kernel_stats.py /tmp/r04_live k_
+  echo '```'
+} > profiles/r04_c3_live_loop_kernel_stats.md
 fi
 mkdir -p "$out/profiles"
 cp profiles/r04_* profiles/pmc_traffic.json "$out/profiles/"
