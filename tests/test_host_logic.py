@@ -867,3 +867,52 @@ def test_reporter_npz_round_trip(tmp_path):
         assert MCReporter.load(mc.save(tmp_path / "mc.npz"))["n_accepted"].tolist() == [3]
     finally:
         BaseReporter.set_directory(None)
+
+
+def test_list_carry_is_a_constructor_argument_and_the_environment_only_its_default():
+    """Round-3 review item 10: the list carry-over (a semantic deviation from chiron/integrators.py:169 -- the caller's
+    list is rebuilt lazily) is chosen by an argument a caller can see; CHX_LIST_CARRY / CHX_LIST_CARRY_MAX_STEPS only
+    supply the defaults."""
+    import subprocess
+    import sys
+
+    from chiron_amd import integrators
+
+    a = integrators.LangevinIntegrator()
+    assert a.list_carry is integrators._CARRY_DEFAULT and a.list_carry_max_steps == integrators._CARRY_MAX_STEPS_DEFAULT
+    b = integrators.LangevinIntegrator(list_carry=False, list_carry_max_steps=7, launch_window=0)
+    assert b.list_carry is False and b.list_carry_max_steps == 7 and b.launch_window == 1  # (a window of 0 launches cannot make progress)
+    assert integrators.LangevinIntegrator(list_carry=True).list_carry is True
+    code = ("from chiron_amd import integrators as I; i = I.LangevinIntegrator(); "
+            "j = I.LangevinIntegrator(list_carry=True, list_carry_max_steps=9); print(i.list_carry, i.list_carry_max_steps, j.list_carry, j.list_carry_max_steps)")
+    env = dict(os.environ, CHX_LIST_CARRY="0", CHX_LIST_CARRY_MAX_STEPS="5")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split() == ["False", "5", "True", "9"]
+
+
+def test_sampler_state_box_copies_come_from_a_pool_and_stay_independent():
+    """SamplerState._box_copy (round 4): the box a returned state carries is a private copy (the reference deep-copies
+    the state, chiron/integrators.py:210), made 32 at a time instead of one clone launch per run(); copies are
+    independent memory, the states of one trajectory share the pool, a new box starts a new one, a deep copy none."""
+    import copy
+
+    from chiron_amd.states import SamplerState
+
+    box = unit.Quantity(np.eye(3, dtype=np.float32) * 3.0, unit.nanometer)
+    s = SamplerState(unit.Quantity(np.zeros((4, 3), np.float32), unit.nanometer), PRNGKey(1, 2), box_vectors=box)
+    t, pools, ptrs = s, set(), set()
+    for _ in range(70):
+        t = t._copy_with(torch.zeros(4, 3), torch.zeros(4, 3))
+        pools.add(id(t.__dict__["_box_pool"][1]))
+        ptrs.add(t.box_vectors.data_ptr())
+        assert torch.equal(t.box_vectors, s.box_vectors) and t.box_vectors.data_ptr() != s.box_vectors.data_ptr()
+    assert len(pools) == 3 and len(ptrs) == 70  # 70 copies out of three pools of 32, every one its own memory
+    a, b = s._box_copy(), s._box_copy()
+    a._value.mul_(2.0)
+    assert torch.equal(b._value, s.box_vectors) and not torch.equal(a._value, b._value)
+    d = copy.deepcopy(t)
+    assert "_box_pool" not in d.__dict__ and torch.equal(d.box_vectors, t.box_vectors)
+    s.box_vectors = np.eye(3, dtype=np.float32) * 5.0
+    assert float(s._box_copy()._value[0, 0]) == 5.0
