@@ -29,7 +29,11 @@ struct CandLists {
   int cap;
 };
 
-template <bool WRITE_FL>
+// WRITE_HALF == false: the half row is only COUNTED (n_nbr: the capacity checks of the build need it), not stored or
+// sorted -- the integrator's rebuilds, whose half rows nobody reads (chx_nl_rows_cell_fl: nl_rows_out == NULL); cand
+// is then CHX_RANGE_WORDS words (the range table of a cell without a candidate list).
+#define CHX_RANGE_WORDS 64
+template <bool WRITE_FL, bool WRITE_HALF = true>
 __device__ __forceinline__ void build_row_of_particle(
     int w, uint32_t* cand, const float4* __restrict__ xs4, int n, int m, const Box3& box, float T, const CellGrid& g,
     const int32_t* __restrict__ cell_start, const uint32_t* __restrict__ sorted_ids, uint32_t* __restrict__ nl,
@@ -63,7 +67,9 @@ __device__ __forceinline__ void build_row_of_particle(
     }
     const bool okh = ok && hi;
     const unsigned long long bh = __ballot(okh);
-    if (bh) {
+    if (!WRITE_HALF) {
+      count_h += __popcll(bh);
+    } else if (bh) {
       const int slot = count_h + lanes_below(bh);
       if (okh && slot < CHX_CELL_CAP - 40) cand[slot] = j;
       count_h += __popcll(bh);
@@ -97,7 +103,7 @@ __device__ __forceinline__ void build_row_of_particle(
   } else {
     // no list for this cell (none written, or the neighbourhood is longer than a list holds): work the neighbourhood's
     // index ranges out here and search them batch by batch
-    int* rng_s = reinterpret_cast<int*>(cand) + CHX_CELL_CAP - 40;  // tail of this wave's LDS slice
+    int* rng_s = reinterpret_cast<int*>(cand) + (WRITE_HALF ? CHX_CELL_CAP : CHX_RANGE_WORDS) - 40;  // tail of the LDS slice
     int* rng_o = rng_s + 20;
     const int total = cell_ranges(g, cx, cy, cz, cell_start, lane, rng_s, rng_o);
     int r = 0;  // range holding this lane's candidate; candidates only move forward
@@ -135,6 +141,18 @@ __device__ __forceinline__ void build_row_of_particle(
     end = end < fcap ? end : fcap;
     // (the row's own index: a zero-length pair keeps the force kernel on its fast path)
     for (int sl = used + lane; sl < end; sl += CHX_WAVE) fl[chx_fl_addr(w, sl, n, fg)] = (uint32_t)w;
+  }
+  if (!WRITE_HALF) {
+    if (lane == 0) {
+      n_nbr[i] = count_h;
+      if (WRITE_FL) deg[w] = count_f < fcap ? count_f : fcap;
+      if (WRITE_FL && count_f > fcap) {
+        atomicAdd(&status[4], 1);
+        atomicMax(&status[3], count_f);
+      }
+    }
+    __threadfence_block();  // (the range table in cand is reused by the caller's next row)
+    return;
   }
   const int kept = count_h < CHX_CELL_CAP - 40 ? count_h : CHX_CELL_CAP - 40;
   __threadfence_block();
@@ -179,17 +197,18 @@ __device__ __forceinline__ void build_row_of_particle(
 }
 
 // one wavefront per PARTICLE (the general kernel: any row length up to the on-chip candidate buffer)
+template <bool WRITE_HALF>
 __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
     const float4* __restrict__ xs4, int n, int m, Box3 box, float T, CellGrid g,
     const int32_t* __restrict__ cell_of, const int32_t* __restrict__ cell_start,
     const uint32_t* __restrict__ sorted_ids, uint32_t* __restrict__ nl, uint32_t* __restrict__ first_out,
     int32_t* __restrict__ n_nbr, int fg, int fcap, uint32_t* __restrict__ fl, int32_t* __restrict__ deg,
     int32_t* __restrict__ status, CandLists cl) {
-  __shared__ uint32_t cand_all[4][CHX_CELL_CAP];
+  __shared__ uint32_t cand_all[4][WRITE_HALF ? CHX_CELL_CAP : CHX_RANGE_WORDS];
   const int w0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (w0 >= n) return;
-  build_row_of_particle<true>(w0, cand_all[threadIdx.x >> 6], xs4, n, m, box, T, g, cell_start, sorted_ids, nl, first_out,
-                              n_nbr, fg, fcap, fl, deg, status, cl);
+  build_row_of_particle<true, WRITE_HALF>(w0, cand_all[threadIdx.x >> 6], xs4, n, m, box, T, g, cell_start, sorted_ids, nl,
+                                          first_out, n_nbr, fg, fcap, fl, deg, status, cl);
 }
 
 // One wavefront per CELL: the (about ten at the BASELINE density) particles of a cell share their 27-cell
@@ -208,12 +227,15 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
 __device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
+template <bool WRITE_HALF>
 __global__ __launch_bounds__(256) void k_nl_build_cellwise_fl(
     const float4* __restrict__ xs4, int n, int m, Box3 box, float T, CellGrid g, int ncell, int split,
     const int32_t* __restrict__ cell_start, const uint32_t* __restrict__ sorted_ids, uint32_t* __restrict__ nl,
     uint32_t* __restrict__ first_out, int32_t* __restrict__ n_nbr, int fg, int fcap, uint32_t* __restrict__ fl,
     int32_t* __restrict__ deg, int32_t* __restrict__ status) {
-  __shared__ uint32_t cand_all[4][CHX_CELL_CAP];  // sort staging (first CHX_ROW_SORT_CAP words) + ranges (tail)
+  // sort staging (first CHX_ROW_SORT_CAP words) + ranges (tail)
+  constexpr int SLICE = WRITE_HALF ? CHX_CELL_CAP : CHX_RANGE_WORDS;
+  __shared__ uint32_t cand_all[4][SLICE];
   const int lane = lane_id();
   // `split` wavefronts share a cell, each taking a contiguous slice of its particles (few cells = few wavefronts:
   // the launch then lives on latency, and more, shorter waves beat fewer candidate fetches)
@@ -228,7 +250,7 @@ __global__ __launch_bounds__(256) void k_nl_build_cellwise_fl(
   }
   if (h1 <= h0) return;
   uint32_t* cand = cand_all[threadIdx.x >> 6];
-  int* rng_s = reinterpret_cast<int*>(cand) + CHX_CELL_CAP - 40;
+  int* rng_s = reinterpret_cast<int*>(cand) + SLICE - 40;
   int* rng_o = rng_s + 20;
   const int cx = c % g.ncx, cy = (c / g.ncx) % g.ncy, cz = c / (g.ncx * g.ncy);
   const int total = cell_ranges(g, cx, cy, cz, cell_start, lane, rng_s, rng_o);
@@ -244,7 +266,7 @@ __global__ __launch_bounds__(256) void k_nl_build_cellwise_fl(
     // Half-row hits wait for their rank sort on chip when the pass has few enough particles (the BASELINE density:
     // ~10 per cell): row ii owns CHX_LDS_ROW_WORDS words of this wave's LDS slice, nothing is written to `nl`
     // unsorted and read back.  Denser cells keep the older scheme (unsorted to the row of `nl`, sorted in place).
-    const bool lds_rows = nh <= CHX_LDS_ROWS;
+    const bool lds_rows = WRITE_HALF && nh <= CHX_LDS_ROWS;
     int r = 0, k_n = 0;
     uint32_t j_n = 0;
     float4 x_n = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -292,7 +314,9 @@ __global__ __launch_bounds__(256) void k_nl_build_cellwise_fl(
           }
           const bool okh = ok && hi;
           const unsigned long long bh = __ballot(okh);
-          {
+          if (!WRITE_HALF) {
+            ch = lane == ii ? ch + __popcll(bh) : ch;  // counted only
+          } else {
             const int base = rl_i(ch, ii);
             const int slot = base + lanes_below(bh);
             if (ON_CHIP) {
@@ -312,6 +336,7 @@ __global__ __launch_bounds__(256) void k_nl_build_cellwise_fl(
     // XCD's whole L2 once per cell: measured 3x slower than the per-particle kernel.)
     __threadfence_block();
     unsigned long long redo = 0;  // rows the general routine has to rebuild (it uses this wave's whole LDS slice)
+    if (!WRITE_HALF && lane < nh) n_nbr[ih] = ch;
     for (int ii = 0; ii < nh; ++ii) {
       const int count_f = rl_i(cf, ii), count_h = rl_i(ch, ii);
       const int w = hb + ii;
@@ -333,7 +358,9 @@ __global__ __launch_bounds__(256) void k_nl_build_cellwise_fl(
           atomicMax(&status[3], count_f);
         }
       }
-      if (count_h > m || count_h > (lds_rows ? CHX_LDS_ROW_WORDS : CHX_ROW_SORT_CAP)) {
+      if (!WRITE_HALF) {
+        // (nothing stored, nothing to sort)
+      } else if (count_h > m || count_h > (lds_rows ? CHX_LDS_ROW_WORDS : CHX_ROW_SORT_CAP)) {
         redo |= 1ull << ii;  // too long to sort this way (and not stored completely)
       } else if (lds_rows) {
         uint32_t* nl_row = nl + (size_t)i * m;
@@ -392,7 +419,7 @@ __global__ __launch_bounds__(256) void k_nl_build_cellwise_fl(
       // cell_ranges inside rewrites the same values into the tail of cand)
       const int ii = __builtin_ctzll(redo);
       redo &= redo - 1;
-      build_row_of_particle<false>(hb + ii, cand, xs4, n, m, box, T, g, cell_start, sorted_ids, nl, first_out, n_nbr, fg, fcap,
+      build_row_of_particle<false, true>(hb + ii, cand, xs4, n, m, box, T, g, cell_start, sorted_ids, nl, first_out, n_nbr, fg, fcap,
                                    fl, deg, status, CandLists{nullptr, nullptr, 0});
     }
   }
@@ -494,9 +521,9 @@ extern "C" int chx_nl_rows_cell_fl(int32_t n, int32_t m, chx_box_t box, float cu
                                    int32_t cand_cap, chx_stream_t stream) {
   CHX_REQUIRE(n >= 1 && m >= 1, "need n >= 1, m >= 1");
   CHX_REQUIRE((cand_list == nullptr) == (cand_len == nullptr) && cand_cap >= 0, "candidate lists need both arrays");
-  CHX_REQUIRE(nc_h && cell_of && cell_start && sorted_ids && status8 && xs4 && nl_rows_out && first_out && n_nbr_out &&
-                  fl_out && deg_out,
-              "null pointer");
+  CHX_REQUIRE(nc_h && cell_of && cell_start && sorted_ids && status8 && xs4 && n_nbr_out && fl_out && deg_out, "null pointer");
+  CHX_REQUIRE((nl_rows_out == nullptr) == (first_out == nullptr), "half rows: nl_rows_out and first_out go together");
+  const bool half = nl_rows_out != nullptr;  // else: the half rows are counted (n_nbr_out), not written
   CHX_REQUIRE(g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64,
               "g must be a power of two <= 64");
   CHX_REQUIRE(chunks >= 1 && (int64_t)chunks * CHX_FL_QUAD * g < (1 << 20), "bad force-list capacity");
@@ -518,18 +545,18 @@ extern "C" int chx_nl_rows_cell_fl(int32_t n, int32_t m, chx_box_t box, float cu
   const bool per_particle = forced == 1 || (forced == 0 && (int64_t)grid.ncx * grid.ncy * grid.ncz < 8192);
   if (per_particle) {
     const CandLists cl = {cand_cap > 0 ? cand_list : nullptr, cand_len, cand_cap};
-    hipLaunchKernelGGL(k_nl_build_cell_fl, dim3(wb), dim3(256), 0, st, xs, n, m, make_box3(box), T, grid,
-                       cell_of, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, chunks * CHX_FL_QUAD * g,
-                       fl_out, deg_out, status8, cl);
+    hipLaunchKernelGGL(half ? k_nl_build_cell_fl<true> : k_nl_build_cell_fl<false>, dim3(wb), dim3(256), 0, st, xs, n, m,
+                       make_box3(box), T, grid, cell_of, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g,
+                       chunks * CHX_FL_QUAD * g, fl_out, deg_out, status8, cl);
   } else {
     const int ncell = grid.ncx * grid.ncy * grid.ncz;
     static const int split_env = [] { const char* e = getenv("CHX_BUILD_SPLIT"); return e ? atoi(e) : 0; }();
     int split = split_env > 0 ? split_env : (8192 + ncell - 1) / ncell;  // (only > 1 when the kernel is forced)
     split = split < 1 ? 1 : (split > 16 ? 16 : split);
     const unsigned cb = (unsigned)(((int64_t)ncell * split * CHX_WAVE + 255) / 256);
-    hipLaunchKernelGGL(k_nl_build_cellwise_fl, dim3(cb), dim3(256), 0, st, xs, n, m, make_box3(box), T, grid, ncell,
-                       split, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, chunks * CHX_FL_QUAD * g,
-                       fl_out, deg_out, status8);
+    hipLaunchKernelGGL(half ? k_nl_build_cellwise_fl<true> : k_nl_build_cellwise_fl<false>, dim3(cb), dim3(256), 0, st, xs,
+                       n, m, make_box3(box), T, grid, ncell, split, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out,
+                       g, chunks * CHX_FL_QUAD * g, fl_out, deg_out, status8);
   }
   const unsigned sb = (unsigned)((n + 255) / 256 < 64 ? (n + 255) / 256 : 64);
   hipLaunchKernelGGL(k_build_epilogue, dim3(sb), dim3(256), 0, st, n_nbr_out, deg_out, n, m, status8, publish_host_dst8);
@@ -545,9 +572,10 @@ extern "C" int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_
                                     chx_stream_t stream) {
   // (argument checks of both halves up front: nothing is launched for a call that the second half would refuse)
   CHX_REQUIRE(n >= 1 && m >= 1, "need n >= 1, m >= 1");
-  CHX_REQUIRE(xyz && nc_h && cell_of && cell_count && cell_start && sorted_ids && status8 &&
-                  nl_rows_out && first_out && n_nbr_out && fl_out && deg_out && xs4_out,
+  CHX_REQUIRE(xyz && nc_h && cell_of && cell_count && cell_start && sorted_ids && status8 && n_nbr_out && fl_out && deg_out &&
+                  xs4_out,
               "null pointer");
+  CHX_REQUIRE((nl_rows_out == nullptr) == (first_out == nullptr), "half rows: nl_rows_out and first_out go together");
   CHX_REQUIRE(g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64,
               "g must be a power of two <= 64");
   CHX_REQUIRE(chunks >= 1 && (int64_t)chunks * CHX_FL_QUAD * g < (1 << 20), "bad force-list capacity");

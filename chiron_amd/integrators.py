@@ -35,6 +35,11 @@ log = logging.getLogger("chiron_amd")
 _INT_MAX = 2**31 - 1
 _TRACE_RUN = __import__("os").environ.get("CHX_TRACE_RUN") == "1"
 _SPECULATIVE_REBUILD = __import__("os").environ.get("CHX_SYNC_REBUILD") != "1"
+# The list builds inside run() write the force list (what the step kernels read) and only COUNT the reference-format
+# half rows (the counts feed the reference's capacity checks, chiron/neighbors.py:709-727); the rows themselves are a
+# function of the list's reference positions and are written when somebody reads `neighbor_list` (NeighborListNsqrd.
+# __getattr__).  CHX_RUN_HALF_ROWS=1: write them with every build, as the reference does (A/B, tests).
+_RUN_HALF_ROWS = __import__("os").environ.get("CHX_RUN_HALF_ROWS") == "1"
 _EV_LOG_CAP = 4096
 # List carry-over (LangevinIntegrator(list_carry=...)): a short run() that continues the trajectory of the previous one
 # (same integrator, same list object, the very position tensor that run returned, untouched) starts on the force list its
@@ -195,7 +200,8 @@ class LangevinIntegrator:
                 buf = _RunState.device_buffers(self, x0.shape[0], x0.device)
                 pack = (v_in, mass_unitless, None, buf["x_a"], buf["v"], buf["mass"], buf["ref4"])
                 ctrl = buf["ctrl"]
-            spec0 = nbr_list._build_speculative(x0, publish=False, pack=pack, ctrl=ctrl, copy_positions=True)
+            spec0 = nbr_list._build_speculative(x0, publish=False, pack=pack, ctrl=ctrl, copy_positions=True,
+                                                half_rows=_RUN_HALF_ROWS)
             packed0 = bool(spec0) and pack is not None
 
         key = sampler_state.new_PRNG_key  # :124
@@ -508,7 +514,7 @@ class _RunState:
         # a builder that has built before for this box; its first build goes the synchronous way)
         spec = (speculative and _SPECULATIVE_REBUILD and b.__dict__.get("_perm") is not None
                 and b._build_speculative(x_user.clone(), publish=False, pack=self.pack_rider(v_user, ref_user), ctrl=self.ctrl,
-                                         ctrl_keep=3))
+                                         ctrl_keep=3, half_rows=_RUN_HALF_ROWS))
         if not spec:
             b._adopt_positions = True
             try:
@@ -759,7 +765,8 @@ class _RunState:
         x_user, v_user = self.state_user()
         keep_events = 1 if self._defer is not None else 0
         spec = speculative and _SPECULATIVE_REBUILD and self.nbr_list._build_speculative(
-            x_user, publish=False, pack=self.pack_rider(v_user), ctrl=self.ctrl, ctrl_keep=keep_events)
+            x_user, publish=False, pack=self.pack_rider(v_user), ctrl=self.ctrl, ctrl_keep=keep_events,
+            half_rows=_RUN_HALF_ROWS)
         if not spec:
             self.nbr_list._adopt_positions = True  # x_user is a fresh tensor nobody else holds
             try:

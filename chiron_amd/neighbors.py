@@ -270,6 +270,7 @@ class NeighborListNsqrd(PairsBase):
         """chiron/neighbors.py:628-729"""
         positions = _strip_positions(positions)
         self.__dict__.pop("_deferred", None)  # (a rebuild still pending from an earlier run() is superseded)
+        self.__dict__.pop("_half_rows_pending", None)  # (so are half rows an integrator rebuild left for later)
         private = getattr(self, "_adopt_positions", False)  # the integrator's own rebuild inside run()
         if (private and box_vectors is not None and box_vectors is getattr(self, "box_vectors", None)
                 and getattr(self, "_box_h", None) is not None):
@@ -323,7 +324,7 @@ class NeighborListNsqrd(PairsBase):
 
     # -- unsynchronised rebuild (integrator only) ---------------------------------------------
     def _build_speculative(self, positions: torch.Tensor, publish: bool = True, pack=None, ctrl=None, ctrl_keep: int = 0,
-                           copy_positions: bool = False) -> bool:
+                           copy_positions: bool = False, half_rows: bool = True) -> bool:
         """Rebuild from ``positions`` WITHOUT waiting for the build's status block.
 
         The reference synchronises inside every build (chiron/neighbors.py:709) to decide whether
@@ -339,7 +340,9 @@ class NeighborListNsqrd(PairsBase):
         Riders of the build's launches (include/chx.h: chx_build_riders_t): ``pack`` = (v3, mass, ref3 or None, x4_out,
         v_out, mass_out, ref4_out) -- the Langevin state packed into the new internal order; ``ctrl`` / ``ctrl_keep`` --
         the integrator's control block, reset; ``copy_positions`` -- ``positions`` is somebody else's tensor: the list
-        keeps a copy made by the binning launch instead of the tensor itself.
+        keeps a copy made by the binning launch instead of the tensor itself.  ``half_rows=False``: the reference-format
+        half rows (``neighbor_list``) are counted, not written -- the integrator's step kernels read the force list only;
+        the rows are built from the same positions the first time somebody reads them (``__getattr__``).
         """
         if not (self.is_built and self._use_cell_list and getattr(self, "_box_h", None) is not None
                 and self._box_h.periodic and getattr(self, "_fl_geo", None) is not None and self._cs_md is not None):
@@ -372,7 +375,7 @@ class NeighborListNsqrd(PairsBase):
         self.ref_positions = riders["copy"] if copy_positions else positions  # (else: a fresh tensor nobody else holds)
         self._cutoff_and_skin = cs
         nl, first, n_nbr, sorted_ids, fl, deg, status = ops.nl_build_cell_fl(
-            positions, self._box_h, cs, m, ncell, nc, g, chunks, self._scratch, riders=riders)
+            positions, self._box_h, cs, m, ncell, nc, g, chunks, self._scratch, riders=riders, half_rows=half_rows)
         ev = getattr(self, "_spec_event", None)
         if ev is None:
             ev = self._spec_event = torch.cuda.Event()  # (one event, recorded again by every speculative build)
@@ -380,7 +383,12 @@ class NeighborListNsqrd(PairsBase):
             ev.record()
         self._spec_recorded = bool(publish)
         self._spec = (ev, m, g, chunks)
-        self._nl, self._nl_mask, self._first = nl, None, first
+        if half_rows:
+            self._nl, self._nl_mask, self._first = nl, None, first
+        else:  # (read through __getattr__: built on first use)
+            for name in self._HALF_ROW_ATTRS:
+                self.__dict__.pop(name, None)
+            self.__dict__["_half_rows_pending"] = True
         self.n_neighbors = n_nbr
         self._perm = sorted_ids
         self._force_list = ops.ForceList.prebuilt(fl, deg, sorted_ids, g, chunks, getattr(self, "_last_maxdeg", 0))
@@ -458,12 +466,16 @@ class NeighborListNsqrd(PairsBase):
         if b is None or sc["arrays"][4].shape[0] != self._perm.shape[0]:
             return None
         for name in self._DEFERRED_ATTRS:
-            b.__dict__[name] = self.__dict__[name]
+            if name in self.__dict__:
+                b.__dict__[name] = self.__dict__[name]
+        if self.__dict__.get("_half_rows_pending"):
+            b.__dict__["_half_rows_pending"] = True
         b._scratch, self._scratch = sc, None
         b._last_max_n = getattr(self, "_last_max_n", None)
         return b
 
     _DEFERRED_ATTRS = ("ref_positions", "n_neighbors", "_nl", "_nl_mask", "_first", "_perm", "_force_list")
+    _HALF_ROW_ATTRS = ("_nl", "_nl_mask", "_first")  # what a build with half_rows=False leaves for the first reader
 
     def _defer_build(self, ref_positions: torch.Tensor, n_events: int) -> None:
         """The reference rebuilt this list ``n_events`` times inside ``run()`` and the last rebuild was from
@@ -472,11 +484,26 @@ class NeighborListNsqrd(PairsBase):
         reference; ``n_builds`` counts the reference's rebuilds."""
         for name in self._DEFERRED_ATTRS:
             self.__dict__.pop(name, None)
+        self.__dict__.pop("_half_rows_pending", None)
         self.__dict__["_deferred"] = ref_positions
         self.n_builds += int(n_events)
 
     def __getattr__(self, name):
         # (reached only when normal lookup fails: costs nothing on the hot path)
+        if name in NeighborListNsqrd._HALF_ROW_ATTRS and self.__dict__.get("_half_rows_pending"):
+            # The integrator's last rebuild wrote the force list and the row counts only.  The half rows are a pure
+            # function of (reference positions, box, cutoff + skin, n_max_neighbors): the synchronous build from the same
+            # positions writes what that rebuild would have (and redoes the force list, bit for bit the same).
+            self._confirm_build()
+            if self.__dict__.get("_half_rows_pending"):  # (a rejected speculative build has already been redone in full)
+                builds = self.n_builds
+                self._adopt_positions = True  # the list's own tensor
+                try:
+                    self.build(self.ref_positions, self.box_vectors)
+                finally:
+                    self._adopt_positions = False
+                self.n_builds = builds
+            return self.__dict__[name]
         if name in NeighborListNsqrd._DEFERRED_ATTRS and "_deferred" in self.__dict__:
             pos = self.__dict__["_deferred"]
             builds = self.n_builds

@@ -155,10 +155,12 @@ def nl_build_cell(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: int, 
 
 
 def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: int, ncell: int, nc, g: int, chunks: int,
-                     scratch: Optional[dict] = None, riders: Optional[dict] = None):
+                     scratch: Optional[dict] = None, riders: Optional[dict] = None, half_rows: bool = True):
     """One-pass cell build (half-list rows without padding + force list).
 
     Returns (nl_rows, first, n_nbr, sorted_ids, fl, deg, status); nothing is synchronised here.
+    ``half_rows=False``: the half rows are counted (n_nbr, which the capacity checks need) but not written or sorted
+    -- nl_rows and first come back as None (the integrator's rebuilds: the step kernels read the force list only).
     ``scratch`` (a dict the caller keeps between builds) lets the kernel-internal work arrays be
     reused: the arrays that become part of the list are always fresh.
     ``riders`` (include/chx.h: chx_build_riders_t): ``copy`` -- a (n,3) tensor that receives a copy of ``xyz``;
@@ -230,14 +232,14 @@ def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: in
                             _ptr(status), _ptr(xs4), C.byref(rd) if rd is not None else None, stream),
         "chx_cell_bin_fl",
     )
-    nl = torch.empty((n, m), **i32)
-    first = torch.empty((n,), **i32)
+    nl = torch.empty((n, m), **i32) if half_rows else None
+    first = torch.empty((n,), **i32) if half_rows else None
     n_nbr = torch.empty((n,), **i32)
     fl = torch.empty((chunks, n, FL_QUAD * g), **i32)
     deg = torch.empty((n,), **i32)
     check(
         lib.chx_nl_rows_cell_fl(n, m, box, cs, nc, _ptr(cell_of), _ptr(cell_start), _ptr(sorted_ids), _ptr(status), _ptr(xs4),
-                                _ptr(nl), _ptr(first), _ptr(n_nbr), g, chunks, _ptr(fl), _ptr(deg), publish,
+                                _ptr(nl) if half_rows else None, _ptr(first) if half_rows else None, _ptr(n_nbr), g, chunks, _ptr(fl), _ptr(deg), publish,
                                 _ptr(cand[0]) if cand is not None else None, _ptr(cand[1]) if cand is not None else None,
                                 cand[2] if cand is not None else 0, stream),
         "chx_nl_rows_cell_fl",

@@ -142,6 +142,9 @@ int chx_nl_build_cell(const float* xyz, int32_t n, int32_t m, chx_box_t box, flo
  * [2] number of rows with n_nbr == m (the reference's growth trigger, :709); [3] max full degree; [4] rows whose full
  * degree exceeded the capacity (force list invalid, retry with more chunks); [5], [6] reserved; [7] scratch.
  * xs4_out (n,4): the positions in internal (cell) order, x4[p] = xyz[sorted_ids[p]].
+ * nl_rows_out == NULL together with first_out == NULL (both builds below, accepted since round 4): the half rows are
+ * COUNTED -- n_nbr_out and status8[1], [2] as above -- but not written or sorted: a list rebuild inside the Langevin loop,
+ * whose step kernels read the force list only (the rows are a function of xyz and can be produced by a later call).
  * riders (may be NULL; every member optional): work that rides on the chain's launches instead of costing launches of
  * its own when the build is a list rebuild inside the Langevin loop (chiron/integrators.py:239-242) -- six launches
  * where round 3 used ten. */

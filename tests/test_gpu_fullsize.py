@@ -241,16 +241,15 @@ def test_launch_window_width_does_not_change_the_trajectory_at_full_size(ca, O, 
     kernel) and N = 262,144 (two lanes, cell-wise build kernel).  Thin skin: several rebuilds inside a short run."""
     orig = ca.integrators.LangevinIntegrator.__init__
     res = []
-    for window in (None, 4096):
+    for window in (12, 4096):  # (12 = the default; set explicitly so that a CHX_LAUNCH_WINDOW override does not move it)
         def init(self, *a, _w=window, **k):
             orig(self, *a, **k)
-            if _w is not None:
-                self.launch_window = _w
+            self.launch_window = _w
         monkeypatch.setattr(ca.integrators.LangevinIntegrator, "__init__", init)
         res.append(_run_langevin(ca, O, n, 32, 160 if n == N3 else 96, 0.06))
     monkeypatch.setattr(ca.integrators.LangevinIntegrator, "__init__", orig)
     (a, nbr_a, integ_a), (b, nbr_b, integ_b) = res
-    assert integ_a.launch_window < 64 and integ_b.launch_window == 4096
+    assert integ_a.launch_window == 12 and integ_b.launch_window == 4096
     assert integ_a.n_rebuilds == integ_b.n_rebuilds >= 1
     assert torch.equal(a.positions, b.positions) and torch.equal(a.velocities, b.velocities)
     assert torch.equal(nbr_a.ref_positions, nbr_b.ref_positions) and torch.equal(nbr_a.n_neighbors, nbr_b.n_neighbors)

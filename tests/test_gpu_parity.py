@@ -1930,6 +1930,80 @@ def test_build_riders_and_split_entry_points_write_the_same_bits(ca, O):
     assert torch.equal(arrs["nl"][real], plain[0][real])
 
 
+def test_build_without_half_rows_counts_them_and_writes_the_same_force_list(ca, O):
+    """include/chx.h (round 4): nl_rows_out == first_out == NULL -- the rebuilds inside LangevinIntegrator.run() -- counts
+    the half rows (n_nbr, status[1], [2]: the reference's capacity checks, chiron/neighbors.py:709-727) without writing
+    them; force list, degrees, order and status must be the bits of the full build.  Both row kernels (one wavefront
+    per particle below 8192 cells, one per cell above), and a capacity smaller than the rows (counted all the same)."""
+    from chiron_amd import ops
+
+    for n, rho, m in ((5000, 0.1, 180), (6000, 0.8, 40), (262144 // 2, 0.05, 180)):
+        x, box = O.lj_lattice(n, rho, SIGMA, seed=5)
+        x = O.periodic_wrap((x + np.random.default_rng(1).normal(0, 0.05, x.shape)).astype(f32), box)
+        xt = dev(x)
+        bh = ops.make_box(dev(box), True)
+        cs = CUTOFF + SKIN
+        ncell, nc = ops.cell_grid(bh, cs, n)
+        assert ncell > 0 and (n < 100000 or ncell >= 8192)  # (the large system takes the cell-wise kernel)
+        rho_n = n / float(np.prod(np.diag(box)))
+        g = 4
+        chunks = ops.fl_chunks_for(int(1.8 * rho_n * 4.19 * cs ** 3) + 24, g)
+        sc_a, sc_b = {}, {}
+        full = ops.nl_build_cell_fl(xt, bh, cs, m, ncell, nc, g, chunks, sc_a)
+        host = torch.full((8,), -1, dtype=torch.int32).pin_memory()
+        part = ops.nl_build_cell_fl(xt, bh, cs, m, ncell, nc, g, chunks, sc_b, riders={"publish": host}, half_rows=False)
+        torch.cuda.synchronize()
+        assert part[0] is None and part[1] is None
+        for k in (2, 3, 5):
+            assert torch.equal(full[k], part[k]), (n, k)
+        used = torch.clamp((full[5] + 4 * g - 1) // (4 * g), min=1)
+        keep = torch.arange(chunks, device="cuda")[:, None] < used[None, :]
+        assert torch.equal(full[4][keep], part[4][keep])
+        sa, sb = full[6].cpu().numpy(), part[6].cpu().numpy()
+        assert np.array_equal(sa[:5], sb[:5]) and np.array_equal(host.numpy()[:5], sb[:5]) and sa[0] == 0 and sa[4] == 0
+        assert sa[1] == int(full[2].max()) and sa[2] == int((full[2] == m).sum())
+        if m == 40:
+            assert sa[1] > m  # rows longer than the capacity: counted all the same
+
+
+def test_half_rows_left_out_by_a_run_are_built_when_read(ca, O):
+    """LangevinIntegrator.run() rebuilds write the force list and count the half rows (integrators._RUN_HALF_ROWS);
+    `neighbor_list` / `neighbor_mask` read afterwards must be what NeighborListNsqrd.build() gives from the list's
+    reference positions (chiron/integrators.py:241-242: the list the caller gets back is the last rebuild's), n_builds
+    must not move when they are read, and a deep copy taken before the read must give the same."""
+    import copy
+
+    n, skin, steps = 2500, 0.05, 120
+    x, box, pot, state, thermo, nbr, integ = _langevin_setup(ca, O, n, 0.3, 43, skin, 4.0)
+    integ.list_carry = False
+    state, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr)
+    assert ca.integrators._RUN_HALF_ROWS or nbr.__dict__.get("_half_rows_pending")
+    builds = nbr.n_builds
+    assert builds >= 2  # (rebuilt inside the run)
+    twin = copy.deepcopy(nbr)
+    ref_pos = nbr.ref_positions.clone()
+    counts = nbr.n_neighbors.clone()
+    fl_before = nbr.force_list
+    deg_before, perm_before = fl_before.deg.clone(), fl_before.perm.clone()
+    got_nl, got_mask = nbr.neighbor_list.clone(), nbr.neighbor_mask.clone()
+    assert nbr.n_builds == builds and not nbr.__dict__.get("_half_rows_pending")
+    assert torch.equal(nbr.ref_positions, ref_pos) and torch.equal(nbr.n_neighbors, counts)
+    assert torch.equal(nbr.force_list.deg, deg_before) and torch.equal(nbr.force_list.perm, perm_before)
+    fresh = ca.neighbors.NeighborListNsqrd(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=nbr.cutoff, skin=nbr.skin,
+                                           n_max_neighbors=nbr.n_max_neighbors)
+    fresh.build(ref_pos, nbr.box_vectors)
+    assert torch.equal(fresh.neighbor_list, got_nl) and torch.equal(fresh.neighbor_mask, got_mask)
+    assert torch.equal(fresh.n_neighbors, counts)
+    assert torch.equal(twin.neighbor_list, got_nl) and torch.equal(twin.n_neighbors, counts)
+    # and the trajectory does not care whether somebody looked: the next run from here equals the one of an untouched twin
+    x2, box2, pot2, state2, thermo2, nbr2, integ2 = _langevin_setup(ca, O, n, 0.3, 43, skin, 4.0)
+    integ2.list_carry = False
+    state2, nbr2 = integ2.run(state2, thermo2, number_of_steps=steps, nbr_list=nbr2)
+    a, nbr = integ.run(state, thermo, number_of_steps=40, nbr_list=nbr)
+    b, nbr2 = integ2.run(state2, thermo2, number_of_steps=40, nbr_list=nbr2)
+    assert torch.equal(a.positions, b.positions) and torch.equal(a.velocities, b.velocities)
+
+
 def test_langevin_run_after_an_interrupted_run(ca, O, monkeypatch):
     """A run() that dies half-way (here: its first rebuild raises) leaves its generation of step launches open --
     the host-mapped control slot, launches possibly still queued.  The integrator must come back clean: the next
