@@ -124,6 +124,8 @@ class BuildRiders(C.Structure):
         ("cand_list", C.c_void_p),
         ("cand_len", C.c_void_p),
         ("cand_cap", C.c_int32),
+        ("cell_slots", C.c_void_p),
+        ("cell_slot_cap", C.c_int32),
     ]
 
 
@@ -142,6 +144,7 @@ SIGNATURES = {
     "chx_source_hash": (C.c_char_p, []),
     "chx_sizeof_langevin_t": (_I64, []),
     "chx_sizeof_mc_t": (_I64, []),
+    "chx_sizeof_build_riders_t": (_I64, []),
     "chx_cutoff_threshold_h": (_F, [_F]),
     "chx_philox4x32_h": (None, [_U32, _U32, _U32, _U32, _U32, _U32, C.POINTER(_U32)]),
     "chx_displacement": (C.c_int, [_P, _P, _I64, Box, _P, _P, _P]),
@@ -254,7 +257,8 @@ def load() -> C.CDLL:
     if lib.chx_version() != ABI_VERSION:
         raise ChxError(f"libchx ABI version {lib.chx_version()} != {ABI_VERSION} (include/chx.h: CHX_ABI_VERSION)")
     # the structs are mirrored by hand above: a layout drift would corrupt kernel arguments silently
-    for name, mirror in (("chx_sizeof_langevin_t", LangevinParams), ("chx_sizeof_mc_t", McParams)):
+    for name, mirror in (("chx_sizeof_langevin_t", LangevinParams), ("chx_sizeof_mc_t", McParams),
+                         ("chx_sizeof_build_riders_t", BuildRiders)):
         if getattr(lib, name)() != C.sizeof(mirror):
             raise ChxError(f"{name}() = {getattr(lib, name)()} but ctypes mirror {mirror.__name__} is {C.sizeof(mirror)} bytes")
     # a library built from other sources than the ones beside it is refused (CHX_LIB: deliberate A/B runs).  A

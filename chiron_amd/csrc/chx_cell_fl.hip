@@ -491,6 +491,9 @@ static int riders_to_bin(const chx_build_riders_t* riders, BinRiders* rd) {
   }
   rd->ctrl = riders->ctrl_reset;
   rd->ctrl_keep = riders->ctrl_keep;
+  CHX_REQUIRE(riders->cell_slot_cap >= 0 && (riders->cell_slots != nullptr || riders->cell_slot_cap == 0), "cell slots: bad capacity");
+  rd->cell_slots = riders->cell_slots;
+  rd->cell_slot_cap = riders->cell_slot_cap;
   return CHX_OK;
 }
 

@@ -35,6 +35,7 @@ static const char g_source_hash[] = "CHX_SOURCE_HASH=" CHX_SOURCE_HASH;
 extern "C" const char* chx_source_hash(void) { return g_source_hash + 16; }
 extern "C" int64_t chx_sizeof_langevin_t(void) { return (int64_t)sizeof(chx_langevin_t); }
 extern "C" int64_t chx_sizeof_mc_t(void) { return (int64_t)sizeof(chx_mc_t); }
+extern "C" int64_t chx_sizeof_build_riders_t(void) { return (int64_t)sizeof(chx_build_riders_t); }
 
 // Largest fp32 t with sqrtf(t) < c.  Host sqrtf is correctly rounded and
 // monotone, as is the device __fsqrt_rn, so the equivalence is exact.

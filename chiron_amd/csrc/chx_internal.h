@@ -28,6 +28,10 @@ struct BinRiders {
   float4* ref4;
   int32_t* ctrl;
   int ctrl_keep;
+  // per-cell id slots (include/chx.h: chx_build_riders_t::cell_slots): the counting launch stores every particle's id in
+  // slot (cell, arrival order) and the scatter launch is not needed
+  uint32_t* cell_slots;
+  int cell_slot_cap;
 };
 // Bin particles into cells (chx_neighbors.hip): cell_of, cell_start, sorted_ids [, xs4_out]; zeroes status.
 // cell_count must be all zero on entry (ncell + 1 words) and is all zero again when the chain has run.

@@ -115,9 +115,12 @@ __device__ __forceinline__ int cell_coord(float x, float L, float s, int nc) {
 }
 
 // (cell_count is all zero on entry: the previous chain's k_cell_sort left it so -- no zeroing launch in front)
+// slots != NULL: the arrival order the counting atomic returns is kept -- particle i goes to slots[c * slot_cap + order]
+// (an order beyond the capacity is dropped here and reported by k_cell_sort, which sees the cell's count) -- and no
+// scatter launch is needed: k_cell_sort reads a cell's ids from its slots.
 __global__ void k_cell_assign(const float* __restrict__ xyz, int n, Box3 box, CellGrid g,
                               int32_t* __restrict__ cell_of, int32_t* __restrict__ cell_count,
-                              float* __restrict__ xyz_copy) {
+                              float* __restrict__ xyz_copy, uint32_t* __restrict__ slots, int slot_cap) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
@@ -131,7 +134,8 @@ __global__ void k_cell_assign(const float* __restrict__ xyz, int n, Box3 box, Ce
   int cz = cell_coord(z, box.lz, g.sz, g.ncz);
   int c = (cz * g.ncy + cy) * g.ncx + cx;
   cell_of[i] = c;
-  atomicAdd(&cell_count[c], 1);
+  const int order = atomicAdd(&cell_count[c], 1);
+  if (slots != nullptr && order < slot_cap) slots[(size_t)c * slot_cap + order] = (uint32_t)i;
 }
 
 // single-block exclusive scan: cell_start[0..ncell] from cell_count; zeroes cell_count (reused as cursor).
@@ -239,7 +243,8 @@ __global__ __launch_bounds__(256) void k_cell_sort(const int32_t* __restrict__ c
                                                    float4* __restrict__ xs4, int ncx, int ncy,
                                                    int32_t* __restrict__ cell_count, BinRiders rd, CellGrid g,
                                                    uint32_t* __restrict__ cand_list, int32_t* __restrict__ cand_len,
-                                                   int cand_cap) {
+                                                   int cand_cap, const uint32_t* __restrict__ slots, int slot_cap,
+                                                   int32_t* __restrict__ status) {
   const int lane = lane_id();
   int ci = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (ci >= ncell) {
@@ -260,11 +265,22 @@ __global__ __launch_bounds__(256) void k_cell_sort(const int32_t* __restrict__ c
   const int c = (ci % ncx) | (((ci / ncx) % ncy) << 10) | ((ci / (ncx * ncy)) << 20);
   const int s = cell_start[ci], e = cell_start[ci + 1];
   const int np = e - s;
+  if (slots != nullptr) {
+    // the cell's ids wait in its slots (k_cell_assign), in arrival order: bring them to their place in sorted_ids for
+    // the paths below that sort in place.  More ids than slots: the build is void (status[5]; the caller repeats it
+    // without slots) -- the lost entries get a valid id, so that whatever still runs on this list reads valid memory.
+    const uint32_t* mine = slots + (size_t)ci * slot_cap;
+    if (np > slot_cap && lane == 0) atomicOr(&status[5], 1);
+    if (np <= 1 || np > CHX_WAVE * CHX_SORT_PER_LANE || np > slot_cap) {
+      for (int t = lane; t < np; t += CHX_WAVE) sorted_ids[s + t] = mine[t < slot_cap ? t : 0];
+      __threadfence_block();
+    }
+  }
   if (np <= 1) {
     if (xs4 != nullptr && np == 1 && lane == 0) cell_emit_sorted(xyz, xs4, s, sorted_ids[s], c, rd);
     return;
   }
-  if (np > CHX_WAVE * CHX_SORT_PER_LANE) {
+  if (np > CHX_WAVE * CHX_SORT_PER_LANE || (slots != nullptr && np > slot_cap)) {
     if (lane == 0) {
       for (int a = s + 1; a < e; ++a) {
         const uint32_t v = sorted_ids[a];
@@ -287,7 +303,8 @@ __global__ __launch_bounds__(256) void k_cell_sort(const int32_t* __restrict__ c
 #pragma unroll
   for (int k = 0; k < CHX_SORT_PER_LANE; ++k) {
     const int t = k * CHX_WAVE + lane;
-    mine[k] = t < np ? sorted_ids[s + t] : 0xFFFFFFFFu;  // ids are distinct and < 2^32 - 1
+    // ids are distinct and < 2^32 - 1
+    mine[k] = t < np ? (slots != nullptr ? slots[(size_t)ci * slot_cap + t] : sorted_ids[s + t]) : 0xFFFFFFFFu;
     rank[k] = 0;
   }
   const int rounds = (np + CHX_WAVE - 1) / CHX_WAVE;
@@ -423,17 +440,20 @@ int chx_cell_prepare(const float* xyz, int n, chx_box_t box, float cutoff_plus_s
   CHX_REQUIRE(!rd.x4 || (xs4_out && rd.v3 && rd.mass && rd.v && rd.mass_out), "pack rider: null pointer");
   // (no zeroing launch: cell_count arrives zeroed -- the caller's allocation, then k_cell_sort of the previous chain)
   const unsigned pb = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_cell_assign, dim3(pb), dim3(256), 0, st, xyz, n, b3, g, cell_of, cell_count, rd.xyz_copy);
+  const bool slotted = rd.cell_slots != nullptr && rd.cell_slot_cap > 0 && status_len >= 8;
+  hipLaunchKernelGGL(k_cell_assign, dim3(pb), dim3(256), 0, st, xyz, n, b3, g, cell_of, cell_count, rd.xyz_copy,
+                     slotted ? rd.cell_slots : nullptr, rd.cell_slot_cap);
   hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, st, cell_count, cell_start, ncell, status, status_len, rd.ctrl,
                      rd.ctrl_keep);
-  hipLaunchKernelGGL(k_cell_scatter, dim3(pb), dim3(256), 0, st, cell_of, n, cell_start, cell_count,
-                     sorted_ids);
+  if (!slotted)
+    hipLaunchKernelGGL(k_cell_scatter, dim3(pb), dim3(256), 0, st, cell_of, n, cell_start, cell_count, sorted_ids);
   const bool lists = cand_list && cand_len && cand_cap > 0;
   // (with the lists: twice the wavefronts, the second half writes them -- k_cell_sort)
   const int64_t sort_waves = (int64_t)ncell * (lists ? 2 : 1);
   hipLaunchKernelGGL(k_cell_sort, dim3((unsigned)((sort_waves * CHX_WAVE + 255) / 256)), dim3(256), 0, st,
                      cell_start, ncell, sorted_ids, xyz, reinterpret_cast<float4*>(xs4_out), g.ncx, g.ncy, cell_count, rd, g,
-                     lists ? cand_list : nullptr, cand_len, cand_cap);
+                     lists ? cand_list : nullptr, cand_len, cand_cap, slotted ? rd.cell_slots : nullptr, rd.cell_slot_cap,
+                     status);
   return CHX_OK;
 }
 

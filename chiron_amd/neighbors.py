@@ -241,7 +241,7 @@ class NeighborListNsqrd(PairsBase):
             ncell, nc = ops.cell_grid(self._box_h, cs, n)
             if ncell > 0:
                 g, chunks = self._fl_geometry(n)
-                for _ in range(4):
+                for _ in range(5):
                     if getattr(self, "_scratch", None) is None:
                         self._scratch = {}
                     nl, first, n_nbr, sorted_ids, fl, deg, status = ops.nl_build_cell_fl(
@@ -249,6 +249,9 @@ class NeighborListNsqrd(PairsBase):
                     st = status.cpu().tolist()  # the build's only host sync (the reference syncs at :709)
                     if _DEBUG_BUILD:
                         print(f"[chx build] n={n} m={m} g={g} chunks={chunks} status={st}", flush=True)
+                    if st[5]:  # a cell held more particles than its id slots: the same build without the slots
+                        self._scratch["no_slots"] = True
+                        continue
                     if st[0]:
                         log.debug("cell build overflowed its on-chip candidate buffer; using the O(N^2) kernel")
                         break
@@ -411,7 +414,9 @@ class NeighborListNsqrd(PairsBase):
         st = self._status_host.tolist()
         # [0] on-chip candidate overflow, [1] max n_neighbors, [2] rows with exactly m entries (the
         # reference's growth trigger), [3] max force-list degree, [4] force-list rows that did not fit
-        if st[0] == 0 and st[2] == 0 and st[4] == 0 and st[1] <= m:
+        if st[5] and self._scratch is not None:  # (a cell overflowed its id slots: the build below goes without them)
+            self._scratch["no_slots"] = True
+        if st[0] == 0 and st[2] == 0 and st[4] == 0 and st[5] == 0 and st[1] <= m:
             self._last_maxdeg = st[3]
             self._last_max_n = st[1]
             self._force_list.maxdeg = st[3]

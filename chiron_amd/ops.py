@@ -178,6 +178,7 @@ def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: in
     if scratch is not None and scratch.get("key") == key:
         cell_of, cell_count, cell_start, status, xs4 = scratch["arrays"]
         cand = scratch.get("cand")
+        slots = scratch.get("slots")
     else:
         cell_of = torch.empty((n,), **i32)
         cell_count = torch.zeros((ncell + 1,), **i32)  # (zero on entry, left zeroed by every build: include/chx.h)
@@ -191,15 +192,26 @@ def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: in
         if ncell < 8192 and os.environ.get("CHX_BUILD_LISTS", "1") != "0":
             cap = min(8192, (int(1.5 * 27.0 * n / ncell) + 64 + 63) // 64 * 64)
             cand = (torch.empty((ncell, cap), **i32), torch.empty((ncell,), **i32), cap)
+        # per-cell id slots (include/chx.h: chx_build_riders_t::cell_slots): the chain needs no scatter launch.  Twice the
+        # mean occupancy + 32; a cell beyond that voids the build (status[5]) and the caller turns the slots off
+        slots = None
+        slot_cap = int(os.environ.get("CHX_BUILD_SLOT_CAP", "0")) or (int(2.0 * n / ncell) + 32 + 63) // 64 * 64  # (env: tests)
+        if slot_cap <= 1024 and os.environ.get("CHX_BUILD_SLOTS", "1") != "0" and not (scratch or {}).get("no_slots"):
+            slots = (torch.empty((ncell, slot_cap), **i32), slot_cap)
         if scratch is not None:
             scratch["key"], scratch["arrays"], scratch["cand"] = key, (cell_of, cell_count, cell_start, status, xs4), cand
+            scratch["slots"] = slots
+    if slots is not None and scratch is not None and scratch.get("no_slots"):
+        slots = scratch["slots"] = None
     rd = None
     publish = None
-    if riders or cand is not None:
+    if riders or cand is not None or slots is not None:
         riders = riders or {}
         rd = _lib.BuildRiders()
         if cand is not None:
             rd.cand_list, rd.cand_len, rd.cand_cap = cand[0].data_ptr(), cand[1].data_ptr(), cand[2]
+        if slots is not None:
+            rd.cell_slots, rd.cell_slot_cap = slots[0].data_ptr(), slots[1]
         cp = riders.get("copy")
         if cp is not None:
             _require_device(cp)

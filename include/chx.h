@@ -79,6 +79,7 @@ const char* chx_source_hash(void);
  * (ctypes, cgo, JNI) assert their own layout against these at load time. */
 int64_t chx_sizeof_langevin_t(void);
 int64_t chx_sizeof_mc_t(void);
+int64_t chx_sizeof_build_riders_t(void);
 
 /* Philox4x32-10 on the host (the generator every device stream of this library draws from; Random123 known answers in
  * the tests): out4_h = philox(counter (c0..c3), key (k0, k1)).  Key handling of the bindings (split, fold_in, uniform)
@@ -140,7 +141,8 @@ int chx_nl_build_cell(const float* xyz, int32_t n, int32_t m, chx_box_t box, flo
  * it allocates it -- and is all zero again when the launches have run (the chain needs no zeroing launch of its own);
  * status8 (out): [0] != 0 -> a half row overflowed the on-chip candidate buffer (nothing valid); [1] max n_nbr;
  * [2] number of rows with n_nbr == m (the reference's growth trigger, :709); [3] max full degree; [4] rows whose full
- * degree exceeded the capacity (force list invalid, retry with more chunks); [5], [6] reserved; [7] scratch.
+ * degree exceeded the capacity (force list invalid, retry with more chunks); [5] != 0 -> a cell overflowed its id
+ * slots (chx_build_riders_t::cell_slots; nothing valid, retry without); [6] reserved; [7] scratch.
  * xs4_out (n,4): the positions in internal (cell) order, x4[p] = xyz[sorted_ids[p]].
  * nl_rows_out == NULL together with first_out == NULL (both builds below, accepted since round 4): the half rows are
  * COUNTED -- n_nbr_out and status8[1], [2] as above -- but not written or sorted: a list rebuild inside the Langevin loop,
@@ -169,6 +171,12 @@ typedef struct {
   uint32_t* cand_list;
   int32_t* cand_len;
   int32_t cand_cap;
+  /* Optional workspace that saves the chain one launch (five instead of six): ncell * cell_slot_cap words in which the
+   * counting launch keeps every particle's id under (its cell, its arrival order), so that the per-cell sort finds a
+   * cell's ids without a scatter launch in between.  A cell with more particles than cell_slot_cap voids the build:
+   * status8[5] != 0, repeat it with cell_slots = NULL (the list written is safe to walk, not correct).  NULL / 0 = off. */
+  uint32_t* cell_slots;
+  int32_t cell_slot_cap;
 } chx_build_riders_t;
 int chx_nl_build_cell_fl(const float* xyz, int32_t n, int32_t m, chx_box_t box, float cutoff_plus_skin,
                          const int32_t* nc_h, int32_t* cell_of, int32_t* cell_count,

@@ -9,7 +9,7 @@ for env in "CHX_SYNC_REBUILD=1" "CHX_LAUNCH_WINDOW=1" "CHX_LAUNCH_WINDOW=3 CHX_F
            "CHX_FL_G=1" "CHX_FL_G=8" "CHX_FL_G=16" "CHX_FL_G=64" "CHX_PRUNE_EVERY=0" "CHX_PRUNE_EVERY=1" \
            "CHX_PRUNE_EVERY=7 CHX_INNER_SKIN=0.02" "CHX_PRUNE_EVERY=50 CHX_INNER_SKIN=0.3" \
            "CHX_POLL=spin" "CHX_POLL_SLEEP_NS=50000" "CHX_POLL_TIMERSLACK=0" \
-           "CHX_PIN_CPUS=0" "CHX_LIST_CARRY=0" "CHX_LIST_CARRY_MAX_STEPS=100000" "CHX_BUILD_LISTS=0" "CHX_RUN_HALF_ROWS=1"; do
+           "CHX_PIN_CPUS=0" "CHX_LIST_CARRY=0" "CHX_LIST_CARRY_MAX_STEPS=100000" "CHX_BUILD_LISTS=0" "CHX_RUN_HALF_ROWS=1" "CHX_BUILD_SLOTS=0"; do
   k=$((k + 1))
   if [ $k -le $first ] || [ $k -gt $((first + count)) ]; then continue; fi
   echo "== $env" | tee -a gpurun_out/test_matrix.log

@@ -2004,6 +2004,53 @@ def test_half_rows_left_out_by_a_run_are_built_when_read(ca, O):
     assert torch.equal(a.positions, b.positions) and torch.equal(a.velocities, b.velocities)
 
 
+def test_cell_slot_overflow_voids_the_build_and_the_retry_goes_without_slots(ca, O, monkeypatch):
+    """include/chx.h, chx_build_riders_t::cell_slots (round 4: the binning keeps every particle's id in a per-cell slot
+    array and needs no scatter launch).  A cell with more particles than slots sets status[5]; the synchronous build
+    repeats itself without slots, the integrator's speculative rebuild is rejected and redone -- same list, same
+    trajectory as with the slots off."""
+    u = ca.unit
+    n = 6000
+    x, box = O.lj_lattice(n, 0.8, SIGMA, seed=5)
+    x = O.periodic_wrap((x + np.random.default_rng(1).normal(0, 0.03, x.shape)).astype(f32), box)
+
+    def build(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        nbr = ca.neighbors.NeighborListCell(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
+                                            skin=SKIN * u.nanometer, n_max_neighbors=180)
+        nbr.build(dev(x), dev(box))
+        for k in env:
+            monkeypatch.delenv(k)
+        return nbr
+
+    plain = build(CHX_BUILD_SLOTS="0")
+    assert plain._scratch.get("slots") is None
+    roomy = build()
+    assert roomy._scratch["slots"] is not None and not roomy._scratch.get("no_slots")
+    tight = build(CHX_BUILD_SLOT_CAP="8")
+    assert tight._scratch.get("no_slots") and tight._scratch["slots"] is None
+    for other in (roomy, tight):
+        assert torch.equal(plain.neighbor_list, other.neighbor_list) and torch.equal(plain.n_neighbors, other.n_neighbors)
+        assert torch.equal(plain.force_list.perm, other.force_list.perm) and torch.equal(plain.force_list.deg, other.force_list.deg)
+    # the integrator's speculative rebuilds: slots too small from the second build on
+    res = []
+    for shrink in (False, True):
+        xs, boxs, pot, state, thermo, nbr, integ = _langevin_setup(ca, O, 2500, 0.3, 43, 0.05, 4.0)
+        integ.list_carry = False
+        state, nbr = integ.run(state, thermo, number_of_steps=0, nbr_list=nbr)
+        if shrink:
+            ncell = nbr._scratch["slots"][0].shape[0]
+            nbr._scratch["slots"] = (torch.empty((ncell, 1), dtype=torch.int32, device="cuda"), 1)
+        state, nbr = integ.run(state, thermo, number_of_steps=90, nbr_list=nbr)
+        assert bool(nbr._scratch.get("no_slots")) == shrink
+        res.append((state, nbr, integ.n_rebuilds))
+    (a, na, ra), (b, nb, rb) = res
+    assert ra == rb >= 1
+    assert torch.equal(a.positions, b.positions) and torch.equal(a.velocities, b.velocities)
+    assert torch.equal(na.neighbor_list, nb.neighbor_list)
+
+
 def test_langevin_run_after_an_interrupted_run(ca, O, monkeypatch):
     """A run() that dies half-way (here: its first rebuild raises) leaves its generation of step launches open --
     the host-mapped control slot, launches possibly still queued.  The integrator must come back clean: the next

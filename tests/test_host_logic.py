@@ -533,6 +533,7 @@ def test_build_is_keyed_on_a_source_hash_not_on_mtimes(monkeypatch):
     assert lib.chx_source_hash().decode() == have
     assert lib.chx_sizeof_langevin_t() == __import__("ctypes").sizeof(_lib.LangevinParams)
     assert lib.chx_sizeof_mc_t() == __import__("ctypes").sizeof(_lib.McParams)
+    assert lib.chx_sizeof_build_riders_t() == __import__("ctypes").sizeof(_lib.BuildRiders) == 128
     monkeypatch.setattr(_lib, "_lib", None)
     with pytest.raises(_lib.ChxError, match="built from other sources"):
         _lib.load()
