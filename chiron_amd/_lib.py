@@ -88,7 +88,7 @@ class McParams(C.Structure):
         ("sigma", C.c_float),
         ("epsilon", C.c_float),
         ("cutoff", C.c_float),
-        ("reserved2", C.c_float),
+        ("inner_skin", C.c_float),
         ("beta", C.c_double),
         ("state", C.c_void_p),
         ("energy", C.c_void_p),
@@ -100,11 +100,15 @@ class McParams(C.Structure):
         ("keytab", C.c_void_p),
         ("keytab_h", C.c_void_p),
         ("chain_out_h", C.c_void_p),
+        ("fli", C.c_void_p),
+        ("cnti", C.c_void_p),
+        ("refi4", C.c_void_p),
     ]
 
 
 # indices into the chx_mc_t state block (include/chx.h)
 MC_CUR, MC_ACCEPTED, MC_PROPOSED, MC_HALT, MC_KEY0, MC_KEY1, MC_SLOT_WORDS, MC_STATE_WORDS = 0, 1, 2, 3, 4, 5, 8, 16
+MC_REFRESH, MC_REFRESHES = 6, 7  # slot 0: inner-list bookkeeping of the kernels
 
 class BuildRiders(C.Structure):
     """chx_build_riders_t (include/chx.h): work that rides on the launches of chx_nl_build_cell_fl."""

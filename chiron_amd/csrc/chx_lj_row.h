@@ -76,9 +76,11 @@ struct PruneOut {
 };
 
 // two list entries (u, u+1) of one lane; xj*: the gathered neighbor positions as (x,y) and (z,w)
-template <int MODE, bool PRUNE>
+// (ACT0: the first entry may be a padding slot as well -- the Monte Carlo kernel's per-lane inner list, chx_mc.hip)
+template <int MODE, bool PRUNE, bool ACT0 = false>
 __device__ __forceinline__ void lj_pair2(const float4& xi, f2 xy0, f2 zw0, f2 xy1, f2 zw1, uint32_t e0, uint32_t e1,
-                                         bool act1, const Box3& box, const LJParams& lj, float T_inner, RowAcc& A) {
+                                         bool act1, const Box3& box, const LJParams& lj, float T_inner, RowAcc& A,
+                                         bool act0 = true) {
   // orientation: r = x_lo - x_hi by ORIGINAL id = +-(xi - xj); multiplying by +-1 is exact
   const f2 sgn = {(e0 & CHX_FL_HI) ? 1.0f : -1.0f, (e1 & CHX_FL_HI) ? 1.0f : -1.0f};
   const f2 dx = xi.x - pk_xx(xy0, xy1);
@@ -107,7 +109,7 @@ __device__ __forceinline__ void lj_pair2(const float4& xi, f2 xy0, f2 zw0, f2 xy
     A.keep0 |= r2.x <= T_inner;
     A.keep1 = act1 && (A.keep1 || r2.y <= T_inner);
   }
-  const bool in0 = r2.x <= lj.T;
+  const bool in0 = (ACT0 ? act0 : true) && r2.x <= lj.T;
   const bool in1 = act1 && r2.y <= lj.T;
   const f2 inv = {__builtin_amdgcn_rcpf(r2.x), __builtin_amdgcn_rcpf(r2.y)};
   const f2 s2 = inv * lj.sig2;

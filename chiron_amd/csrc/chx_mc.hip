@@ -50,7 +50,166 @@ struct McArgs {
   int ws_half;
   int nblocks;  // per-block energy partials per half
   const uint4* keyrow;  // key table row of the launch's own trial: {proposal key (2 words), uniform of its decision (fp32 bits), 0}
+  // the inner list (see "Inner list" below); fli == NULL: off
+  uint32_t* fli;    // same geometry as fl
+  int32_t* cnti;    // (n, G): entries of a lane's even words | odd words << 16
+  float4* refi4;    // (n,4): the proposal the inner list was taken at
+  float T_inner;       // r2 <= T_inner: listed (cutoff + inner skin)
+  float T_inner_half;  // a candidate further than this from refi4 asks for a new inner list
 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// Inner list.  Two thirds of the force list's entries lie between the cutoff and cutoff + skin and contribute exact
+// zeros to every trial's energy.  A launch that is told to (state[CHX_MC_REFRESH] == its trial: the first of a chunk,
+// then on demand) walks the force list as before and, on the way, copies the entries within cutoff + inner skin of its
+// proposal into an inner list that the following launches walk instead, until a particle has strayed inner skin / 2
+// from where it stood then: every launch checks BOTH candidates it writes for the next trial against that position and
+// books a refresh for the next trial if one fails -- one trial ahead, so the launch that would misuse the list is the
+// one that renews it.
+// The energy has to come out in the BITS the force list gives (the host loop of MCMove and compute_energy use it, and a
+// decision is a comparison of those bits).  A lane adds its entries up in two accumulators, the even and the odd words
+// of its quads in chunk order, and an entry beyond the cutoff adds an exact zero: so the inner list is compacted PER
+// LANE AND PER WORD PARITY -- every kept entry stays with its lane and its accumulator, in its order -- and the sums
+// are the same additions without the zeros.  cnti holds the two lengths of a lane; unused words of the chunks a lane
+// walks hold the row's own index (gathered, never counted).
+// ---------------------------------------------------------------------------------------------------------------
+struct InnerOut {
+  uint32_t* lane;  // this lane's word 0 of chunk 0
+  size_t stride;   // words between consecutive chunks
+  int ne, no;
+};
+__device__ __forceinline__ void inner_put(InnerOut& o, bool odd, uint32_t ent) {
+  const int s = odd ? o.no++ : o.ne++;
+  o.lane[(size_t)(s >> 1) * o.stride + (size_t)(2 * (s & 1) + (odd ? 1 : 0))] = ent;
+}
+
+// the force-list walk of lj_row_loop (same calls, same order: same energy bits) that also fills the lane's inner list
+template <int G, int MODE>
+__device__ __forceinline__ void mc_refresh_loop(const float4* __restrict__ x4, const uint4* __restrict__ col, size_t stride,
+                                                int d, int nc, int q, const float4& xi, uint4 e4, float4 (&xj)[4],
+                                                const Box3& box, const LJParams& lj, RowAcc& A, float T_inner,
+                                                InnerOut& o) {
+  constexpr int W = 4 * G;
+  int c = 0;
+  if (G > 1 || nc > 0) do {
+    const int k0 = c * W + q;
+    uint4 nx = make_uint4(0u, 0u, 0u, 0u);
+    if (c + 1 < nc) nx = col[(size_t)(c + 1) * stride];
+    if (k0 < d) {
+      lj_pair2<MODE, true>(xi, (f2){xj[0].x, xj[0].y}, (f2){xj[0].z, xj[0].w}, (f2){xj[1].x, xj[1].y},
+                           (f2){xj[1].z, xj[1].w}, e4.x, e4.y, k0 + G < d, box, lj, T_inner, A);
+      if (A.keep0) inner_put(o, false, e4.x);
+      if (A.keep1) inner_put(o, true, e4.y);
+    }
+    if (k0 + 2 * G < d) {
+      lj_pair2<MODE, true>(xi, (f2){xj[2].x, xj[2].y}, (f2){xj[2].z, xj[2].w}, (f2){xj[3].x, xj[3].y},
+                           (f2){xj[3].z, xj[3].w}, e4.z, e4.w, k0 + 3 * G < d, box, lj, T_inner, A);
+      if (A.keep0) inner_put(o, false, e4.z);
+      if (A.keep1) inner_put(o, true, e4.w);
+    }
+    if (c + 1 < nc) {
+      e4 = nx;
+      xj[0] = x4[e4.x & ~CHX_FL_HI];
+      xj[1] = x4[e4.y & ~CHX_FL_HI];
+      xj[2] = x4[e4.z & ~CHX_FL_HI];
+      xj[3] = x4[e4.w & ~CHX_FL_HI];
+    }
+  } while (++c < nc);
+}
+
+// the walk of a lane's inner list: ne even-word entries, no odd-word entries, nc = chunks that hold them
+template <int G, int MODE>
+__device__ __forceinline__ void mc_inner_loop(const float4* __restrict__ x4, const uint4* __restrict__ col, size_t stride,
+                                              int ne, int no, int nc, const float4& xi, uint4 e4, float4 (&xj)[4],
+                                              const Box3& box, const LJParams& lj, RowAcc& A) {
+  int c = 0;
+  do {  // (at least one pass, like lj_row_loop: chunk 0 is in flight already)
+    uint4 nx = make_uint4(0u, 0u, 0u, 0u);
+    if (c + 1 < nc) nx = col[(size_t)(c + 1) * stride];
+    const bool a0 = 2 * c < ne, a1 = 2 * c < no, a2 = 2 * c + 1 < ne, a3 = 2 * c + 1 < no;
+    if (a0 | a1)
+      lj_pair2<MODE, false, true>(xi, (f2){xj[0].x, xj[0].y}, (f2){xj[0].z, xj[0].w}, (f2){xj[1].x, xj[1].y},
+                                  (f2){xj[1].z, xj[1].w}, e4.x, e4.y, a1, box, lj, 0.f, A, a0);
+    if (a2 | a3)
+      lj_pair2<MODE, false, true>(xi, (f2){xj[2].x, xj[2].y}, (f2){xj[2].z, xj[2].w}, (f2){xj[3].x, xj[3].y},
+                                  (f2){xj[3].z, xj[3].w}, e4.z, e4.w, a3, box, lj, 0.f, A, a2);
+    if (c + 1 < nc) {
+      e4 = nx;
+      xj[0] = x4[e4.x & ~CHX_FL_HI];
+      xj[1] = x4[e4.y & ~CHX_FL_HI];
+      xj[2] = x4[e4.z & ~CHX_FL_HI];
+      xj[3] = x4[e4.w & ~CHX_FL_HI];
+    }
+  } while (++c < nc);
+}
+
+// general path of one lane (lj_row_finish's: one entry at a time through the general minimum image) over `nc` chunks of
+// `row`; entry (c, u) counts when act(c, u)
+template <typename Act>
+__device__ __forceinline__ void mc_general_lane(const float4* __restrict__ x4, const uint32_t* __restrict__ row, size_t stride_words,
+                                                int nc, const float4& xi, const Box3& box, const LJParams& lj, RowAcc& A, Act act) {
+  A.ax = A.ay = A.az = A.ae = f2_splat(0.f);
+  for (int c = 0; c < nc; ++c) {
+    for (int u = 0; u < 4; ++u) {
+      if (!act(c, u)) continue;
+      const uint32_t en_t = row[(size_t)c * stride_words + u];
+      const float4 xo = x4[en_t & ~CHX_FL_HI];
+      const bool hi = (en_t & CHX_FL_HI) != 0u;
+      float gx, gy, gz;
+      displacement_oriented(box, hi, xi.x, xi.y, xi.z, xo.x, xo.y, xo.z, gx, gy, gz);
+      const float g2 = norm2(gx, gy, gz);
+      if (g2 <= lj.T) {
+        float e, fs;
+        lj_pair(g2, lj.sig2, lj.eps4, lj.eps24, e, fs);
+        A.ae[u & 1] += e;  // same accumulator parity as the fast path
+      }
+    }
+  }
+}
+
+// energy share of one lane, lj_row_finish's bits.  REFRESH: over the force list (L: its loads), filling the inner list;
+// else over the inner list (L: the inner list's loads, d_raw = the lane's packed lengths).
+template <int G, bool REFRESH>
+__device__ __forceinline__ float mc_row_energy(RowLoads& L, const float4* __restrict__ x4, const uint32_t* __restrict__ list, int n,
+                                               int q, bool valid, const Box3& box, bool periodic, const LJParams& lj,
+                                               const McArgs& a, float4& xi_out) {
+  constexpr int W = 4 * G;
+  const int pc = L.pc;
+  const size_t stride = (size_t)n * G;  // uint4 units between consecutive chunks
+  const float4 xi = L.xi;
+  xi_out = xi;
+  RowAcc A;
+  A.ax = A.ay = A.az = A.ae = f2_splat(0.f);
+  A.bad = false;
+  A.keep0 = A.keep1 = false;
+  const uint32_t* row = list + ((size_t)pc * G + q) * 4;
+  if (REFRESH) {
+    const int d = valid ? L.d_raw : 0;
+    const int nc = (d + W - 1) / W;
+    InnerOut o = {a.fli + ((size_t)pc * G + q) * 4, stride * 4, 0, 0};
+    if (!periodic) mc_refresh_loop<G, LJ_OPEN>(x4, L.col, stride, d, nc, q, xi, L.e4, L.xj, box, lj, A, a.T_inner, o);
+    else mc_refresh_loop<G, LJ_SHIFT>(x4, L.col, stride, d, nc, q, xi, L.e4, L.xj, box, lj, A, a.T_inner, o);
+    if (valid) {
+      // whole chunks (at least chunk 0, which every launch gathers before it knows the lengths) must hold valid indices
+      int nci = ((o.ne > o.no ? o.ne : o.no) + 1) >> 1;
+      nci = nci < 1 ? 1 : nci;
+      const int ne = o.ne, no = o.no;
+      while (o.ne < 2 * nci) inner_put(o, false, (uint32_t)pc);
+      while (o.no < 2 * nci) inner_put(o, true, (uint32_t)pc);
+      a.cnti[(size_t)pc * G + q] = ne | (no << 16);
+    }
+    if (__builtin_expect(A.bad, 0))
+      mc_general_lane(x4, row, stride * 4, nc, xi, box, lj, A, [&](int c, int u) { return c * W + u * G + q < d; });
+  } else {
+    const int ne = valid ? (L.d_raw & 0xFFFF) : 0, no = valid ? ((L.d_raw >> 16) & 0xFFFF) : 0;
+    const int nc = ((ne > no ? ne : no) + 1) >> 1;
+    if (!periodic) mc_inner_loop<G, LJ_OPEN>(x4, L.col, stride, ne, no, nc, xi, L.e4, L.xj, box, lj, A);
+    else mc_inner_loop<G, LJ_SHIFT>(x4, L.col, stride, ne, no, nc, xi, L.e4, L.xj, box, lj, A);
+    if (__builtin_expect(A.bad, 0))
+      mc_general_lane(x4, row, stride * 4, nc, xi, box, lj, A, [&](int c, int u) { return 2 * c + (u >> 1) < ((u & 1) ? no : ne); });
+  }
+  return 0.f + (A.ae.x + A.ae.y);
+}
 
 // sigma N(0,1) [* mask] of one particle (chiron/mcmc.py:733-748; k: the proposal key of the trial, o: original particle id)
 __device__ __forceinline__ void mc_displacement(const McArgs& a, uint32_t o, uint32_t k0, uint32_t k1, float& dx, float& dy,
@@ -146,6 +305,7 @@ __global__ __launch_bounds__(256) void k_mc_prologue(McArgs a, long long trial) 
   cur[(size_t)(1 - sel) * a.n + p] = xc;
   prop[p] = xp;
   prop[(size_t)a.n + p] = xp;
+  if (p == 0 && a.fli != nullptr) a.state[CHX_MC_REFRESH] = (int)trial;  // the chunk's first trial takes the inner list
 }
 
 // Trial `trial` in one launch (see the head of this file).  Reads the buffers of parity trial & 1, writes the other.
@@ -155,7 +315,7 @@ __global__ __launch_bounds__(256) void k_mc_prologue(McArgs a, long long trial) 
 // own x_t / x'_t, its reference position, the energy partials, the key rows.  Behind the decision only the neighbour
 // gathers, the particle's next displacement (one Philox block, computed while the gathers are in flight), the pair
 // arithmetic and the stores remain.
-template <int G, bool DECIDE>
+template <int G, bool DECIDE, bool INNER>
 __global__ __launch_bounds__(256) void k_mc_trial(McArgs a, long long trial, int log_slot, unsigned nblocks) {
   const int b = (int)(trial & 1);
   const unsigned blk = xcd_block(blockIdx.x, nblocks);
@@ -177,23 +337,42 @@ __global__ __launch_bounds__(256) void k_mc_trial(McArgs a, long long trial, int
   const double part = DECIDE ? mc_partials(a, trial) : 0.0;
   const float uniform = DECIDE ? __uint_as_float(a.keyrow[-1].z) : 0.f;  // (the uniform of trial - 1's decision)
   const uint4 next = a.keyrow[1];                                         // (.xy: the proposal key of trial + 1)
+  // (inner list: its first quad, the lane's lengths and the position it was taken at -- requested whether this launch
+  // turns out to walk it or to renew it)
+  const uint4* coli = INNER ? reinterpret_cast<const uint4*>(a.fli) + (size_t)pc * G + q : col;
+  const uint4 e4i = INNER ? pinned_load16(coli) : e4;
+  const int cnt_raw = INNER ? pinned_load4(a.cnti + (size_t)pc * G + q) : 0;
+  const uint4 rib = INNER ? pinned_load16(a.refi4 + pc) : r0b;
+  const bool refresh = INNER && (long long)a.state[CHX_MC_REFRESH] == trial;  // (launch-uniform)
   if ((long long)a.state[CHX_MC_HALT] <= trial - (DECIDE ? 1 : 0)) return;  // (the halt word is shared: slot 0)
   // ---- the decision of trial - 1: every workgroup, same bits ----
   const int sel = DECIDE ? mc_decide(a, trial, log_slot, part, uniform) : 0;
   // ---- energy of x'_t over the force list: the pair-force kernel's row loop and its reduction, bit for bit ----
   const float4* prop = prop_b + (size_t)sel * a.n;  // x'_t
   const uint4 xpb = sel ? xp1 : xp0, xcb = sel ? xc1 : xc0;
-  RowLoads rl = lj_row_adopt<G>(prop, col, pc, xpb, d_raw, e4);  // (the neighbour gathers are in flight from here)
+  // (the neighbour gathers are in flight from here.  Gathering the first chunk from BOTH candidates ahead of the
+  // decision -- so that the two chains run side by side -- was measured in round 4: 116 k -> 110-113 k trials/s, the
+  // four extra scattered loads per lane cost more than the decision's latency)
+  const bool walk_inner = INNER && !refresh;
+  RowLoads rl = lj_row_adopt<G>(prop, walk_inner ? coli : col, pc, xpb, walk_inner ? cnt_raw : d_raw, walk_inner ? e4i : e4);
   // this particle's next displacement sigma N(0,1) [* mask] (chiron/mcmc.py:733-748), under the gathers' latency
   float dx, dy, dz;
   mc_displacement(a, o, next.x, next.y, dx, dy, dz);
   float4 xp;
-  float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
-  lj_row_finish<G>(rl, prop, a.fl, a.n, q, valid, a.box, a.box.periodic != 0, a.lj, xp, fx, fy, fz, en);
+  float en = 0.f;
+  if (!INNER) {
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    lj_row_finish<G>(rl, prop, a.fl, a.n, q, valid, a.box, a.box.periodic != 0, a.lj, xp, fx, fy, fz, en);
+  } else if (refresh) {
+    en = mc_row_energy<G, true>(rl, prop, a.fl, a.n, q, valid, a.box, a.box.periodic != 0, a.lj, a, xp);
+  } else {
+    en = mc_row_energy<G, false>(rl, prop, a.fli, a.n, q, valid, a.box, a.box.periodic != 0, a.lj, a, xp);
+  }
   en = group_sum<G>(en);
   double mine = (valid && q == 0) ? 0.5 * (double)en : 0.0;  // every pair is visited from both ends
   mine = block_sum<256>(mine);
   if (threadIdx.x == 0) a.ws[(size_t)a.ws_half * b + blk] = mine;  // (never the half the heads of this launch are reading)
+  if (INNER && refresh && blockIdx.x == 0 && threadIdx.x == 0) a.state[CHX_MC_REFRESHES] += 1;  // (statistics)
   if (!valid || q != 0) return;
   // ---- skin check of this trial's proposal (chiron/neighbors.py:868): the first violating trial halts the chunk ----
   float rx, ry, rz;
@@ -206,15 +385,35 @@ __global__ __launch_bounds__(256) void k_mc_trial(McArgs a, long long trial, int
   float4* prop_n = a.prop4 + (size_t)2 * (b ^ 1) * a.n;
   cur_n[p] = xc;                 // trial t rejected: the configuration stays
   cur_n[(size_t)a.n + p] = xpc;  // accepted: the proposal becomes the configuration
-  prop_n[p] = mc_displaced(a, xc, dx, dy, dz);
-  prop_n[(size_t)a.n + p] = mc_displaced(a, xpc, dx, dy, dz);
+  const float4 c0 = mc_displaced(a, xc, dx, dy, dz), c1 = mc_displaced(a, xpc, dx, dy, dz);
+  prop_n[p] = c0;
+  prop_n[(size_t)a.n + p] = c1;
+  if (INNER) {
+    // the inner list's guarantee, one trial ahead: whichever candidate becomes the next proposal must lie within
+    // inner skin / 2 of where this particle stood when the list was taken (this launch's own proposal if it renews it)
+    float rfx = __uint_as_float(rib.x), rfy = __uint_as_float(rib.y), rfz = __uint_as_float(rib.z);
+    if (refresh) {
+      rfx = xp.x, rfy = xp.y, rfz = xp.z;
+      a.refi4[p] = xpc;
+    }
+    float ux, uy, uz, wx, wy, wz;
+    displacement(a.box, c0.x, c0.y, c0.z, rfx, rfy, rfz, ux, uy, uz);
+    displacement(a.box, c1.x, c1.y, c1.z, rfx, rfy, rfz, wx, wy, wz);
+    if (norm2(ux, uy, uz) > a.T_inner_half || norm2(wx, wy, wz) > a.T_inner_half)
+      atomicMax(&a.state[CHX_MC_REFRESH], (int)trial + 1);
+  }
 }
 
 template <int G>
 static void launch_trial(const McArgs& a, long long t, bool decide, int log_slot, hipStream_t st) {
   const unsigned blocks = (unsigned)(((int64_t)a.n * G + 255) / 256);
-  if (decide) hipLaunchKernelGGL((k_mc_trial<G, true>), dim3(blocks), dim3(256), 0, st, a, t, log_slot, blocks);
-  else hipLaunchKernelGGL((k_mc_trial<G, false>), dim3(blocks), dim3(256), 0, st, a, t, log_slot, blocks);
+  if (a.fli != nullptr) {
+    if (decide) hipLaunchKernelGGL((k_mc_trial<G, true, true>), dim3(blocks), dim3(256), 0, st, a, t, log_slot, blocks);
+    else hipLaunchKernelGGL((k_mc_trial<G, false, true>), dim3(blocks), dim3(256), 0, st, a, t, log_slot, blocks);
+  } else {
+    if (decide) hipLaunchKernelGGL((k_mc_trial<G, true, false>), dim3(blocks), dim3(256), 0, st, a, t, log_slot, blocks);
+    else hipLaunchKernelGGL((k_mc_trial<G, false, false>), dim3(blocks), dim3(256), 0, st, a, t, log_slot, blocks);
+  }
 }
 
 extern "C" int chx_mc_key_chain_h(uint32_t k0, uint32_t k1, int32_t n_trials, uint32_t* keytab_h, uint32_t* chain_out_h) {
@@ -283,6 +482,22 @@ extern "C" int chx_mc_displace_chunk(const chx_mc_t* p, int64_t trial0, int32_t 
   a.ws = p->ws;
   a.ws_half = (int)chx_lj_ws_count(p->n);
   a.nblocks = chx_lj_fl_blocks(p->n, p->g);
+  a.fli = nullptr;
+  a.cnti = nullptr;
+  a.refi4 = nullptr;
+  a.T_inner = a.T_inner_half = 0.f;
+  if (p->fli != nullptr && p->inner_skin > 0.f) {
+    CHX_REQUIRE(p->cnti && p->refi4, "inner list: null pointer");
+    CHX_REQUIRE((int64_t)p->fl_chunks * 2 < 32768, "inner list: too many chunks for the packed lane lengths");
+    a.fli = p->fli;
+    a.cnti = p->cnti;
+    a.refi4 = reinterpret_cast<float4*>(p->refi4);
+    a.T_inner = chx_cutoff_threshold_h(p->cutoff + p->inner_skin);
+    // (1e-4 nm inside the half skin: the triangle inequality behind the guarantee is exact, the fp32 displacements
+    // it is checked with are not)
+    const float half = p->inner_skin * 0.5f - 1.0e-4f;
+    a.T_inner_half = half > 0.f ? chx_cutoff_threshold_h(half) : 0.f;
+  }
   const uint4* tab = reinterpret_cast<const uint4*>(p->keytab);
   a.keyrow = tab;
   hipLaunchKernelGGL(k_mc_prologue, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0, st, a, (long long)trial0);

@@ -22,6 +22,10 @@ from .rng import JaxKey, PRNGKey
 from .rng import uniform as host_uniform
 from .states import SamplerState, ThermodynamicState
 
+# Inner skin (nm) of the inner list the device-resident displacement loop walks between refreshes (include/chx.h:
+# chx_mc_t::fli; same energies and decisions with or without it, bit for bit).  CHX_MC_INNER_SKIN=0 turns it off.
+_MC_INNER_SKIN = float(os.environ.get("CHX_MC_INNER_SKIN", "0.1"))
+
 
 class MCMCMove:
     def __init__(self, number_of_moves: int, reporter=None, report_interval: Optional[int] = 100):
@@ -335,6 +339,13 @@ class MonteCarloDisplacementMove(MCMove):
         p.ws = ctx["ws"].data_ptr()
         p.keytab, p.keytab_h = ctx["keytab"].data_ptr(), ctx["keytab_h"].data_ptr()
         p.chain_out_h = ctx["chain"].ctypes.data
+        # inner list of the trial launches (include/chx.h: chx_mc_t::fli): workspace only, the kernels fill it
+        if _MC_INNER_SKIN > 0.0 and 2 * fl.chunks < 32768:
+            ctx["fli"] = torch.empty_like(fl.fl)
+            ctx["cnti"] = torch.empty((n, fl.g), dtype=torch.int32, device=dev)
+            ctx["refi4"] = torch.empty((n, 4), dtype=torch.float32, device=dev)
+            p.fli, p.cnti, p.refi4 = ctx["fli"].data_ptr(), ctx["cnti"].data_ptr(), ctx["refi4"].data_ptr()
+            p.inner_skin = _MC_INNER_SKIN
         ctx["params"] = p
         return ctx
 
@@ -377,6 +388,8 @@ class MonteCarloDisplacementMove(MCMove):
             ctx["params"].k0, ctx["params"].k1 = ctx["key"]  # chain key before trial i
             ops.mc_displace_chunk(ctx["params"], i, m)
             st = ctx["state"].cpu().numpy()  # waits for the chunk
+            self.inner_list_refreshes = getattr(self, "inner_list_refreshes", 0) + int(st[_lib.MC_REFRESHES]) - ctx.get("refreshes", 0)
+            ctx["refreshes"] = int(st[_lib.MC_REFRESHES])
             halt = int(st[_lib.MC_HALT])
             halted = halt < i + m
             done = (halt if halted else i + m) - i

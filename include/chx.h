@@ -535,7 +535,7 @@ int chx_metropolis_select(float* x_cur, const float* x_prop, int64_t count,
  * cur4 and prop4 are (2, 2, n, 4) floats each: [parity][copy][particle]; launch t reads parity t & 1 and writes the
  * other.  On entry copy state[CHX_MC_CUR] of cur4[trial0 & 1] holds the current configuration (internal order); after
  * the chunk copy state[CHX_MC_CUR] (of slot T & 1) of cur4[T & 1] does, T = the halt trial if the chunk halted, else
- * trial0 + n_trials.
+ * trial0 + n_trials.  state[CHX_MC_REFRESH] (slot 0) belongs to the kernels (inner list, chx_mc_t::fli).
  * When the skin check fires in trial t the launch stores t in state[CHX_MC_HALT] and every launch of trial > t is a
  * no-op (trial t is never decided): the caller runs that trial through the rebuild path and resumes.  state is
  * CHX_MC_STATE_WORDS ints: TWO slots of CHX_MC_SLOT_WORDS words (indices below, slot s at offset
@@ -551,6 +551,8 @@ int chx_metropolis_select(float* x_cur, const float* x_prop, int64_t count,
 #define CHX_MC_HALT 3      /* first trial whose proposal violated the skin; INT32_MAX when clear */
 #define CHX_MC_KEY0 4      /* PRNG chain key */
 #define CHX_MC_KEY1 5
+#define CHX_MC_REFRESH 6   /* slot 0 only: the trial whose launch renews the inner list (chx_mc_t::fli) */
+#define CHX_MC_REFRESHES 7 /* slot 0 only: launches that have renewed it so far (statistics) */
 #define CHX_MC_SLOT_WORDS 8
 #define CHX_MC_STATE_WORDS 16
 typedef struct chx_mc_t {
@@ -569,7 +571,7 @@ typedef struct chx_mc_t {
   float skin;
   float sigma_d;           /* displacement sigma (nm) */
   float sigma, epsilon, cutoff;
-  float reserved2;
+  float inner_skin;        /* nm; > 0 with fli != NULL: the trial launches walk an inner list (below) */
   double beta;             /* mol/kJ */
   int32_t* state;          /* CHX_MC_STATE_WORDS ints (two slots, see above) */
   double* energy;          /* 4 doubles: [2 s] current, [2 s + 1] proposed, of slot s */
@@ -580,6 +582,15 @@ typedef struct chx_mc_t {
   uint32_t* keytab;        /* device, 4 (n_trials + 1) words */
   uint32_t* keytab_h;      /* pinned host staging of the same size, filled by the call */
   uint32_t* chain_out_h;   /* host, 2 (n_trials + 1) words, or NULL */
+  /* Inner list (optional workspace, contents private to the kernels; NULL = off).  Most entries of the force list lie
+   * between cutoff and cutoff + skin and add exact zeros to a trial's energy: the chunk's first trial launch (and later
+   * ones on demand) copies the entries within cutoff + inner_skin of its proposal into fli, and the launches after it walk
+   * those until a particle has strayed inner_skin / 2 from where it stood then (every launch checks the candidates it
+   * writes for the next trial, which then renews the list).  Compacted per lane and per accumulator, so the energies --
+   * and with them every decision -- are the force list's, bit for bit. */
+  uint32_t* fli;           /* as many words as fl */
+  int32_t* cnti;           /* n * g ints */
+  float* refi4;            /* (n,4) */
 } chx_mc_t;
 int chx_mc_displace_chunk(const chx_mc_t* p_h, int64_t trial0, int32_t n_trials,
                           chx_stream_t stream);

@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-for r in 1 2 3; do for h in 0 1; do CHX_BUILD_SLOTS=$h timeout -k 10 200 python scripts/run_phases.py 20 c3 0 > gpurun_out/phases_s$h.$r.log 2>&1; echo "slots=$h $(grep 'device idle' gpurun_out/phases_s$h.$r.log) $(grep 'kick done' gpurun_out/phases_s$h.$r.log)"; done; done
+timeout -k 10 600 python -m pytest tests -m gpu -x -q -k "mc or MC or mcmc" > gpurun_out/t_mc.log 2>&1; tail -5 gpurun_out/t_mc.log; grep -n "^E " gpurun_out/t_mc.log | head -20
+for s in 0 0.1 0.05; do echo "inner skin $s"; CHX_MC_INNER_SKIN=$s timeout -k 10 200 python scripts/mc_rate.py 2>&1 | tail -3; done

@@ -1075,6 +1075,7 @@ def _mc_run(ca, O, host_loop, monkeypatch, *, n=500, skin=SKIN, sigma_d=0.002, m
         attempts=move.number_of_attemps_made, u=float(move._current_reduced_potential),
         sigma=move.displacement_sigma.value_in_unit_system(u.md_unit_system),
         ref=nbr.ref_positions.cpu().numpy(), n_nbr=nbr.n_neighbors.cpu().numpy(),
+        refreshes=getattr(move, "inner_list_refreshes", 0),
         reports={k: rep.get_property(k) for k in ("step", "iteration", "number_of_attempts_made", "potential_energy",
                                                   "displacement_sigma", "acceptance_probability")},
     )
@@ -1109,6 +1110,35 @@ def test_mc_device_loop_equals_host_loop(ca, O, monkeypatch, kw):
         assert np.array_equal(np.asarray(devr["reports"][k], dtype=np.float64), np.asarray(v, dtype=np.float64)), k
     if kw.get("skin") == 0.05:
         assert not np.array_equal(host["ref"], O.lj_lattice(500, 0.1, SIGMA, seed=71)[0])  # the list was rebuilt
+
+
+@pytest.mark.parametrize("kw", [dict(sigma_d=0.003, moves=400), dict(sigma_d=0.03, moves=150),
+                                dict(skin=0.05, sigma_d=0.008, moves=300), dict(subset=[0, 3, 17, 499], sigma_d=0.02, moves=200)],
+                         ids=["small-moves", "mixed-decisions", "rebuilds", "subset"])
+def test_mc_inner_list_changes_no_bit(ca, O, monkeypatch, kw):
+    """The trial launches of the device-resident displacement loop walk an inner list (include/chx.h: chx_mc_t::fli --
+    the force-list entries within cutoff + inner skin of the proposal it was taken at, compacted per lane and per
+    accumulator) and renew it when a particle has strayed inner skin / 2.  Energies, decisions, reports, key chain and
+    rebuild trials must be those of the loop without it, and of the host loop, for a wide skin (renewed rarely), a
+    narrow one (every few trials) and none."""
+    runs = {}
+    for tag, s_in in (("off", 0.0), ("wide", 0.1), ("narrow", 0.02)):
+        monkeypatch.setattr(ca.mcmc, "_MC_INNER_SKIN", s_in)
+        runs[tag] = _mc_run(ca, O, False, monkeypatch, **kw)
+    host = _mc_run(ca, O, True, monkeypatch, **kw)
+    trials = host["attempts"]
+    assert runs["off"]["refreshes"] == 0
+    assert 1 <= runs["wide"]["refreshes"] <= runs["narrow"]["refreshes"] <= trials
+    if kw["sigma_d"] == 0.003:
+        assert runs["wide"]["refreshes"] < trials // 8 < runs["narrow"]["refreshes"]  # rarely / every few trials
+    assert host["stats"]["n_accepted"] > 0
+    if kw["sigma_d"] == 0.03:
+        assert host["stats"]["n_accepted"] < host["stats"]["n_proposed"]
+    for tag, r in runs.items():
+        assert r["stats"] == host["stats"] and r["key"] == host["key"], tag
+        assert np.array_equal(r["x"], host["x"]) and np.array_equal(r["ref"], host["ref"]), tag
+        for k, v in host["reports"].items():
+            assert np.array_equal(np.asarray(r["reports"][k], dtype=np.float64), np.asarray(v, dtype=np.float64)), (tag, k)
 
 
 def _decisions_from_reports(rep):

@@ -334,7 +334,7 @@ def test_library_exports_every_declared_symbol():
             ints = sum(1 for a in args[:i] if a not in (ctypes.c_float, ctypes.c_double))
             floats = i - ints
             assert floats == 0 or ints < 5, name
-    assert ctypes.sizeof(_lib.McParams) == 192
+    assert ctypes.sizeof(_lib.McParams) == 216
     assert _lib.McParams.beta.offset == 112 and _lib.McParams.ws.offset == 152
 
 
