@@ -40,6 +40,8 @@ _SPECULATIVE_REBUILD = __import__("os").environ.get("CHX_SYNC_REBUILD") != "1"
 # function of the list's reference positions and are written when somebody reads `neighbor_list` (NeighborListNsqrd.
 # __getattr__).  CHX_RUN_HALF_ROWS=1: write them with every build, as the reference does (A/B, tests).
 _RUN_HALF_ROWS = __import__("os").environ.get("CHX_RUN_HALF_ROWS") == "1"
+_CARRY_VALIDATE = __import__("os").environ.get("CHX_CARRY_VALIDATE", "1") != "0"
+_PARAMS_CACHE = __import__("os").environ.get("CHX_PARAMS_CACHE", "1") != "0"
 _EV_LOG_CAP = 4096
 # List carry-over (LangevinIntegrator(list_carry=...)): a short run() that continues the trajectory of the previous one
 # (same integrator, same list object, the very position tensor that run returned, untouched) starts on the force list its
@@ -113,7 +115,7 @@ class LangevinIntegrator:
     # memory, and its numpy view no longer aliases it): it starts without and allocates its own on first use.
     # MultiStateSampler deep-copies its sampler, chiron/multistate.py:266-268.
     _PER_PROCESS_STATE = ("_gen_ring", "_gen_next", "_pinned_ring", "_ring_next", "_dev_scratch", "_inner_scratch",
-                          "_run_cache", "_defer_scratch", "_rebuild_log", "_carry")
+                          "_run_cache", "_defer_scratch", "_rebuild_log", "_carry", "_params_cache")
 
     def __getstate__(self):
         return {k: v for k, v in self.__dict__.items() if k not in self._PER_PROCESS_STATE}
@@ -321,8 +323,9 @@ class LangevinIntegrator:
         Offered by the previous ``run()`` (``_RunState.offer_carry``) and taken only when this call continues that
         trajectory: same list object, same box values, same cutoff and skin, and ``sampler_state.positions`` IS the
         tensor that run returned, not written to since -- positions from anywhere else (a Monte Carlo move, another
-        replica) take the ordinary path.  Whether the list really covers x0 is then checked on the device
-        (chx_validate_snap)."""
+        replica) take the ordinary path.  Such positions are covered by the list -- the run that returned them checked
+        them against it in its last launch and renewed it if need be (``_RunState.final_kick``) -- unless somebody wrote
+        to the tensor behind the version stamp's back: the device checks again (chx_validate_snap)."""
         from .neighbors import NeighborListNsqrd
 
         offer, self._carry = self.__dict__.get("_carry"), None
@@ -462,7 +465,14 @@ class _RunState:
             self._setup_carry()
             # the reference's run-start build, as far as the steps can tell: reference positions := x0
             self._load(x0, v0, 0, owner=self._carried, ref_user=x0)
-            ops.validate_snap(self.x_a, self.snap4, self.nbr_list._box_h, self._skin_now, 0, self.ctrl, self._gen.tensor)
+            # Does the carried list cover x0?  By the host's bookkeeping it does: x0 IS what the previous run returned
+            # (_take_carry: same tensor, same version), that run's last launch checked exactly these positions against the
+            # list's own (the halt word for step n_steps) and final_kick renewed the list if the check fired.  But a
+            # tensor's version stamp does not see writes through .data or a raw pointer, and the price of being wrong is a
+            # silently wrong force: the device checks again, one small launch in front of the first step (13 us of a
+            # 185 us run(20); CHX_CARRY_VALIDATE=0 leaves it out -- measured in round 4).
+            if _CARRY_VALIDATE:
+                ops.validate_snap(self.x_a, self.snap4, self.nbr_list._box_h, self._skin_now, 0, self.ctrl, self._gen.tensor)
             integ.n_carried_runs = getattr(integ, "n_carried_runs", 0) + 1
         else:
             self._load(x0, v0, packed=packed)
@@ -612,32 +622,52 @@ class _RunState:
                 skin = sk[1]
         if self.mode == "fused":
             self._open_generation(step)
-        p = LangevinParams()
-        p.n = n
+        # The parameter block is kept on the integrator between loads: most of its ~40 fields are functions of objects
+        # that outlive a run() -- the integrator's own device buffers, the box, the potential, the thermostat's constants --
+        # and filling a ctypes structure costs a fifth of a microsecond per field on the path to the first launch.  The
+        # cached block is reused when every one of those is the same object / value as when it was filled (the cache
+        # holds references, so an id cannot be recycled); what belongs to the list, the key and the generation is set
+        # every time.
+        pot = self.potential if self.mode != "external" else None
+        lj = (pot.sigma, pot.epsilon, pot.cutoff) if pot is not None else None
+        objs = (self.x_a, self.v, self.f, self.ref4, self.mass, self.ctrl, self.ws, box, self.noise)
+        vals = (n, self.mode, wrap, skin, self.half_dt, self.a, self.b, self.kT, lj,
+                self.is_pairlist and self.nbr_list.cutoff is None)
+        cached = self.integ.__dict__.get("_params_cache") if _PARAMS_CACHE else None
+        if (cached is not None and cached[1] == vals and len(cached[0]) == len(objs)
+                and all(u is w for u, w in zip(cached[0], objs))):
+            p = cached[2]
+            # (what _point_params_at_list and _enqueue_kick may have left from the previous load)
+            p.fl_inner = p.deg_inner = p.snap4 = p.ev_log = p.final_x3 = p.final_v3 = p.final_ref3 = None
+            p.inner_skin, p.prune_every, p.prune_phase, p.ev_log_cap = 0.0, 0, 0, 0
+        else:
+            p = LangevinParams()
+            p.n = n
+            p.x4 = self.x_a.data_ptr()
+            p.v = self.v.data_ptr()
+            p.f = self.f.data_ptr() if self.f is not None else None
+            p.ref4 = self.ref4.data_ptr() if self.ref4 is not None else None
+            p.mass = self.mass.data_ptr()
+            p.box = box
+            p.wrap = wrap
+            p.skin = skin
+            p.half_dt, p.a, p.b, p.kT = self.half_dt, self.a, self.b, self.kT
+            if self.mode != "external":
+                p.sigma, p.epsilon, p.cutoff = lj
+                if self.is_pairlist and self.nbr_list.cutoff is None:
+                    p.cutoff = -1.0
+            p.noise = self.noise.data_ptr() if self.noise is not None else None
+            p.noise_step0 = 0
+            p.ctrl = self.ctrl.data_ptr()
+            p.ws = self.ws.data_ptr()
+            p.external_force = 1 if self.mode == "external" else 0
+            self.integ._params_cache = (objs, vals, p)
         p.g = self.fl.g if self.fl is not None else 1
         p.fl_chunks = self.fl.chunks if self.fl is not None else 0
-        p.x4 = self.x_a.data_ptr()
-        p.v = self.v.data_ptr()
-        p.f = self.f.data_ptr() if self.f is not None else None
-        p.ref4 = self.ref4.data_ptr() if self.ref4 is not None else None
-        p.mass = self.mass.data_ptr()
         p.perm = perm.data_ptr() if perm is not None else None
         p.fl = self.fl.fl.data_ptr() if self.fl is not None else None
         p.deg = self.fl.deg.data_ptr() if self.fl is not None else None
-        p.box = box
-        p.wrap = wrap
-        p.skin = skin
-        p.half_dt, p.a, p.b, p.kT = self.half_dt, self.a, self.b, self.kT
-        if self.mode != "external":
-            p.sigma, p.epsilon, p.cutoff = self.potential.sigma, self.potential.epsilon, self.potential.cutoff
-            if self.is_pairlist and self.nbr_list.cutoff is None:
-                p.cutoff = -1.0
         p.k0, p.k1 = self.key[0], self.key[1]
-        p.noise = self.noise.data_ptr() if self.noise is not None else None
-        p.noise_step0 = 0
-        p.ctrl = self.ctrl.data_ptr()
-        p.ws = self.ws.data_ptr()
-        p.external_force = 1 if self.mode == "external" else 0
         if self.mode == "fused":
             p.host_ctrl = self._gen.tensor.data_ptr()
         self._skin_now = skin

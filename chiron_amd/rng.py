@@ -33,7 +33,7 @@ STREAM_UNIFORM = 3
 STREAM_SPLIT = 0x5EED
 
 
-_fast = None  # (callable, out buffer) once libchx is loaded: chx_philox4x32_h, 1 us instead of 7
+_fast = None  # (callable, output array type) once libchx is loaded: chx_philox4x32_h, 1 us instead of 7
 
 
 def _bind_fast():
@@ -49,14 +49,17 @@ def _bind_fast():
     except Exception:  # (no library: the pure-Python rounds below are the definition anyway)
         _fast = False
         return
-    _fast = (fn, (ctypes.c_uint32 * 4)())
+    # (no shared output buffer: ctypes releases the GIL for the call, and MultiStateSampler(concurrent_replicas > 1) splits
+    # keys from two threads at once -- a buffer kept here handed one thread the other's words, found in round 4)
+    _fast = (fn, ctypes.c_uint32 * 4)
 
 
 def philox4x32(counter: Tuple[int, int, int, int], key: Tuple[int, int]) -> Tuple[int, int, int, int]:
     if _fast is None:
         _bind_fast()
     if _fast:
-        fn, out = _fast
+        fn, out_t = _fast
+        out = out_t()
         fn(int(counter[0]) & _MASK, int(counter[1]) & _MASK, int(counter[2]) & _MASK, int(counter[3]) & _MASK,
            int(key[0]) & _MASK, int(key[1]) & _MASK, out)
         return out[0], out[1], out[2], out[3]

@@ -917,3 +917,30 @@ def test_sampler_state_box_copies_come_from_a_pool_and_stay_independent():
     assert "_box_pool" not in d.__dict__ and torch.equal(d.box_vectors, t.box_vectors)
     s.box_vectors = np.eye(3, dtype=np.float32) * 5.0
     assert float(s._box_copy()._value[0, 0]) == 5.0
+
+
+def test_host_philox_is_safe_to_call_from_several_threads():
+    """rng.philox4x32 goes through the library's host helper, and ctypes releases the GIL for the call: the words must
+    not travel through a buffer shared between threads (MultiStateSampler(concurrent_replicas=2) splits the keys of two
+    replicas at once; with a shared buffer one replica occasionally got the other's key -- round 4)."""
+    import threading
+
+    from chiron_amd import rng
+
+    want = {k: rng.philox4x32_py((k, 1, 2, 3), (k, 7)) for k in range(64)}
+    assert rng.philox4x32((5, 1, 2, 3), (5, 7)) == want[5]
+    assert rng._fast  # (the library's helper is what the threads below race on)
+    bad = []
+
+    def work(lane):
+        for rep in range(4000):
+            k = (lane * 17 + rep) % 64
+            if rng.philox4x32((k, 1, 2, 3), (k, 7)) != want[k]:
+                bad.append((lane, rep))
+
+    threads = [threading.Thread(target=work, args=(lane,)) for lane in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not bad, bad[:5]
