@@ -1127,18 +1127,21 @@ def test_mc_inner_list_changes_no_bit(ca, O, monkeypatch, kw):
         runs[tag] = _mc_run(ca, O, False, monkeypatch, **kw)
     host = _mc_run(ca, O, True, monkeypatch, **kw)
     trials = host["attempts"]
-    assert runs["off"]["refreshes"] == 0
-    assert 1 <= runs["wide"]["refreshes"] <= runs["narrow"]["refreshes"] <= trials
-    if kw["sigma_d"] == 0.003:
-        assert runs["wide"]["refreshes"] < trials // 8 < runs["narrow"]["refreshes"]  # rarely / every few trials
-    assert host["stats"]["n_accepted"] > 0
-    if kw["sigma_d"] == 0.03:
-        assert host["stats"]["n_accepted"] < host["stats"]["n_proposed"]
     for tag, r in runs.items():
         assert r["stats"] == host["stats"] and r["key"] == host["key"], tag
         assert np.array_equal(r["x"], host["x"]) and np.array_equal(r["ref"], host["ref"]), tag
         for k, v in host["reports"].items():
             assert np.array_equal(np.asarray(r["reports"][k], dtype=np.float64), np.asarray(v, dtype=np.float64)), (tag, k)
+    assert runs["off"]["refreshes"] == 0
+    # (every context of the device loop -- one per chunk and per trial that ran through the host's rebuild branch --
+    # opens with a refresh, so a run that rebuilds all the time counts about one per trial whatever the inner skin)
+    assert 1 <= runs["wide"]["refreshes"] <= 2 * trials and 1 <= runs["narrow"]["refreshes"] <= 2 * trials
+    print("inner-list refreshes (wide, narrow, trials):", runs["wide"]["refreshes"], runs["narrow"]["refreshes"], trials)
+    if kw["sigma_d"] == 0.003:
+        assert runs["wide"]["refreshes"] < trials // 8 < runs["narrow"]["refreshes"]  # rarely / every few trials
+    assert host["stats"]["n_accepted"] > 0
+    if kw["sigma_d"] == 0.03:
+        assert host["stats"]["n_accepted"] < host["stats"]["n_proposed"]
 
 
 def _decisions_from_reports(rep):
@@ -2007,7 +2010,8 @@ def test_half_rows_left_out_by_a_run_are_built_when_read(ca, O):
     x, box, pot, state, thermo, nbr, integ = _langevin_setup(ca, O, n, 0.3, 43, skin, 4.0)
     integ.list_carry = False
     state, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr)
-    assert ca.integrators._RUN_HALF_ROWS or nbr.__dict__.get("_half_rows_pending")
+    # (CHX_RUN_HALF_ROWS=1 / CHX_SYNC_REBUILD=1: every build writes the rows; the reads below must not care)
+    assert ca.integrators._RUN_HALF_ROWS or not ca.integrators._SPECULATIVE_REBUILD or nbr.__dict__.get("_half_rows_pending")
     builds = nbr.n_builds
     assert builds >= 2  # (rebuilt inside the run)
     twin = copy.deepcopy(nbr)

@@ -26,6 +26,9 @@ import numpy as np
 import pytest
 import torch
 
+# (scripts/test_matrix.sh runs this file under overrides of the pruning cadence: the assertions about the DEFAULT cadence step aside)
+_PRUNE_OVERRIDDEN = any(k in __import__("os").environ for k in ("CHX_PRUNE_EVERY", "CHX_INNER_SKIN"))
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -166,7 +169,8 @@ def _assert_forces_and_energy(CO, x, box, f_user, energy, stats=None):
 def test_final_frame_forces_energy_and_returned_list_match_the_oracle(prod, O, CO):
     n, box = prod.n, prod.box
     assert prod.integ.n_rebuilds >= (60 if prod.wl == "c3" else 25)  # a list lasts ~210 steps at 300 K, dt = 1 fs
-    assert getattr(prod.integ, "prune_passes", 0) >= prod.steps // 40  # the inner list was refreshed at its cadence
+    if not _PRUNE_OVERRIDDEN:
+        assert getattr(prod.integ, "prune_passes", 0) >= prod.steps // 40  # the inner list was refreshed at its cadence
     x = _np(prod.state.positions)
     v = _np(prod.state.velocities)
     kT = O.R_KJ * 300.0
@@ -221,7 +225,9 @@ def test_one_step_matches_oracle_at_refresh_post_rebuild_and_pre_rebuild_launche
     R = scout.rebuild_steps
     assert len(R) >= 2, R
     every = int(scout._last_run_state.params.prune_every)
-    assert every in (20, 24, 32)  # (the defaults: 32 below N = 2^17, 20 at N = 2^18)
+    if every <= 0:
+        pytest.skip("CHX_PRUNE_EVERY=0: no inner list, no refresh launches to look at")
+    assert _PRUNE_OVERRIDDEN or every in (20, 24, 32)  # (the defaults: 32 below N = 2^17, 20 at N = 2^18)
     r0, r1 = R[0], R[1]
     assert r0 + every + 1 < r1
     cases = {"first launch after a rebuild (epoch-0 refresh of the inner list)": r0,
@@ -243,6 +249,8 @@ def test_one_step_matches_oracle_at_refresh_post_rebuild_and_pre_rebuild_launche
 def test_one_step_matches_oracle_on_the_stale_list_fallback(prod, O, CO):
     """One hot particle (6 nm/ps, 24 sigma_v) outruns half the inner skin within ten steps: the launches from there to
     the next refresh walk the full list.  Step K sits inside that stretch."""
+    if _PRUNE_OVERRIDDEN:
+        pytest.skip("the scenario is laid out for the default pruning cadence and inner skin")
     start = copy.deepcopy(prod.state)
     v = start.velocities.clone()
     hot = 12345
