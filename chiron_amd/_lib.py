@@ -171,6 +171,7 @@ SIGNATURES = {
     "chx_nl_finish_padding": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),
     "chx_pack_langevin": (C.c_int, [_P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _I32, _P, _P, _P]),
     "chx_validate_snap": (C.c_int, [_P, _P, _I32, Box, _F, _I32, _P, _P, _P]),
+    "chx_pack_validate_langevin": (C.c_int, [Box, _F, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _I32, _P]),
     "chx_nl_calculate": (C.c_int, [_P, _P, _P, _I32, _I32, Box, _F, _P, _P, _P, _P, _P]),
     "chx_nl_check": (C.c_int, [_P, _P, _I32, Box, _F, _P, _P]),
     "chx_pl_build": (C.c_int, [_I32, _P, _P, _P]),

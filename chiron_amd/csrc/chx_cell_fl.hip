@@ -668,6 +668,74 @@ extern "C" int chx_pack_langevin(const float* x3, const float* v3, const float* 
   return chx_check_launch("chx_pack_langevin");
 }
 
+// The pack launch of a run that starts on a carried-over force list, with chx_validate_snap's question folded in: is every
+// particle within skin / 2 of the position its force list was built from (snap4, internal order)?  The answer has to
+// land in the halt word, which this very launch resets -- so the reset moves to whichever workgroup finishes LAST
+// (ticket in sync2[0]; a workgroup that saw a violation raises sync2[1] before it takes its ticket): that workgroup
+// writes the control block with the halt word already decided and leaves sync2 zeroed for the next call.
+__global__ void k_pack_validate_langevin(const float* __restrict__ x3, const float* __restrict__ v3,
+                                         const float* __restrict__ mass, const float* __restrict__ ref3,
+                                         const uint32_t* __restrict__ perm, int n, float4* __restrict__ x4,
+                                         float* __restrict__ v, float* __restrict__ mass_out, float4* __restrict__ ref4,
+                                         int32_t* __restrict__ ctrl, int ctrl_keep, const float4* __restrict__ snap4,
+                                         Box3 box, float T_half_skin, int step, int32_t* __restrict__ host_ctrl,
+                                         int32_t* __restrict__ sync2) {
+  __shared__ int sh_last;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  int bad = 0;
+  if (p < n) {
+    const size_t o = perm ? perm[p] : (uint32_t)p;
+    const float x = x3[3 * o], y = x3[3 * o + 1], z = x3[3 * o + 2];
+    x4[p] = make_float4(x, y, z, 0.f);
+    v[3 * (size_t)p] = v3[3 * o];
+    v[3 * (size_t)p + 1] = v3[3 * o + 1];
+    v[3 * (size_t)p + 2] = v3[3 * o + 2];
+    mass_out[p] = mass[o];
+    if (ref4) ref4[p] = make_float4(ref3[3 * o], ref3[3 * o + 1], ref3[3 * o + 2], mass[o]);
+    const float4 s = snap4[p];
+    float rx, ry, rz;
+    displacement(box, x, y, z, s.x, s.y, s.z, rx, ry, rz);
+    bad = !(norm2(rx, ry, rz) <= T_half_skin);  // (NaN positions fail the negated comparison: they halt too)
+  }
+  const int any_bad = __syncthreads_or(bad);
+  if (threadIdx.x == 0) {
+    if (any_bad) atomicOr(&sync2[1], 1);
+    __threadfence();
+    sh_last = atomicAdd(&sync2[0], 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!sh_last) return;
+  __threadfence();
+  const int t = threadIdx.x;
+  const int failed = __hip_atomic_load(&sync2[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t < CHX_CTRL_WORDS) {
+    const bool keep = ((ctrl_keep & 1) && (t == 8 || t == 9)) || ((ctrl_keep & 2) && (t == 10 || t == 11));
+    if (!keep) ctrl[t] = (t == 3 && failed) ? step : chx_ctrl_reset_word(t);
+  }
+  if (t == 64 && failed && host_ctrl != nullptr)
+    __hip_atomic_store(&host_ctrl[3], step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (t == 65) {
+    __hip_atomic_store(&sync2[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&sync2[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+extern "C" int chx_pack_validate_langevin(chx_box_t box, float skin, int32_t step, const float* snap4, int32_t* host_ctrl,
+                                          int32_t* sync2, const float* x3, const float* v3, const float* mass,
+                                          const float* ref3, const uint32_t* perm, int32_t n, float* x4_out, float* v_out,
+                                          float* mass_out, float* ref4_out, int32_t* ctrl_reset, int32_t ctrl_keep,
+                                          chx_stream_t stream) {
+  CHX_REQUIRE(n >= 1, "n < 1");
+  CHX_REQUIRE(x3 && v3 && mass && x4_out && v_out && mass_out && snap4 && sync2 && ctrl_reset, "null pointer");
+  CHX_REQUIRE(!ref4_out || ref3, "ref4_out without ref3");
+  CHX_REQUIRE(skin > 0.f && step >= 0, "need skin > 0 and step >= 0");
+  hipLaunchKernelGGL(k_pack_validate_langevin, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, chx_stream(stream), x3, v3,
+                     mass, ref3, perm, n, reinterpret_cast<float4*>(x4_out), v_out, mass_out,
+                     reinterpret_cast<float4*>(ref4_out), ctrl_reset, (int)ctrl_keep, reinterpret_cast<const float4*>(snap4),
+                     make_box3(box), chx_cutoff_threshold_h(skin * 0.5f), (int)step, host_ctrl, sync2);
+  return chx_check_launch("chx_pack_validate_langevin");
+}
+
 // ---------------------------------------------------------------------------
 // list carry-over: may launch `step` walk a force list that was built from other positions?  (include/chx.h:
 // chx_validate_snap)

@@ -422,6 +422,7 @@ class _RunState:
             keep["key"] = sk
             f32 = dict(dtype=torch.float32, device=dev)
             keep["ctrl"] = torch.zeros((CTRL_WORDS,), dtype=torch.int32, device=dev)
+            keep["sync2"] = torch.zeros((2,), dtype=torch.int32, device=dev)  # (chx_pack_validate_langevin's ticket and flag)
             keep["ev_log"] = torch.zeros((_EV_LOG_CAP,), dtype=torch.int32, device=dev)
             keep["ws"] = torch.empty((int(ops._lib.load().chx_lj_ws_count(n)),), dtype=torch.float64, device=dev)
             keep["x_a"], keep["x_b"] = torch.empty((n, 4), **f32), torch.empty((n, 4), **f32)
@@ -464,15 +465,13 @@ class _RunState:
         if self._carried is not None:
             self._setup_carry()
             # the reference's run-start build, as far as the steps can tell: reference positions := x0
-            self._load(x0, v0, 0, owner=self._carried, ref_user=x0)
             # Does the carried list cover x0?  By the host's bookkeeping it does: x0 IS what the previous run returned
             # (_take_carry: same tensor, same version), that run's last launch checked exactly these positions against the
             # list's own (the halt word for step n_steps) and final_kick renewed the list if the check fired.  But a
             # tensor's version stamp does not see writes through .data or a raw pointer, and the price of being wrong is a
-            # silently wrong force: the device checks again, one small launch in front of the first step (13 us of a
-            # 185 us run(20); CHX_CARRY_VALIDATE=0 leaves it out -- measured in round 4).
-            if _CARRY_VALIDATE:
-                ops.validate_snap(self.x_a, self.snap4, self.nbr_list._box_h, self._skin_now, 0, self.ctrl, self._gen.tensor)
+            # silently wrong force: the device checks again -- inside the pack launch (round 3: a launch of its own in
+            # front of the first step, 13 us of a 185 us run(20)).  CHX_CARRY_VALIDATE=0 leaves the check out.
+            self._load(x0, v0, 0, owner=self._carried, ref_user=x0, validate=_CARRY_VALIDATE)
             integ.n_carried_runs = getattr(integ, "n_carried_runs", 0) + 1
         else:
             self._load(x0, v0, packed=packed)
@@ -583,32 +582,22 @@ class _RunState:
         return inner, every
 
     def _load(self, x_user: torch.Tensor, v_user: torch.Tensor, step: int = 0, owner=None, ref_user=None, ctrl_keep: int = 0,
-              packed: bool = False):
+              packed: bool = False, validate: bool = False):
         """(Re)pack user-order arrays into the internal order of the current force list (``packed``: the build's own
         launches have done that, and reset the control block) and point the launch parameters at that list.
 
         ``owner``: the list object whose force list the steps run on from here (default: the caller's ``nbr_list``;
         on a carried-over list one of the integrator's private builders).  ``ref_user``: the reference's reference
         positions when they are not the owner's (list carry-over: the public list's positions travel separately).
-        ``ctrl_keep``: what survives the control-block reset (ops.pack_langevin)."""
+        ``ctrl_keep``: what survives the control-block reset (ops.pack_langevin).  ``validate`` (a run that starts on a
+        carried-over list): the pack launch also checks x_user against the positions the force list was built from and
+        leaves the verdict in the halt word it resets (chx_pack_validate_langevin)."""
         owner = self.nbr_list if owner is None else owner
         self._owner = owner
         self.fl = owner.force_list if self.mode == "fused" else None
         perm = self.fl.perm if self.fl is not None else None
         self.perm = perm
         n = self.n
-        if not packed:
-            # one launch: positions (the buffer that is current at parity 0), velocities, masses, reference positions,
-            # written into the integrator's buffers (a rebuild has copied the state out first), and the control-block reset
-            if ref_user is None and self.is_verlet:
-                ref_user = owner.ref_positions
-            ops.pack_langevin(x_user, v_user, self.mass_user, ref_user if self.is_verlet else None, perm, self.is_verlet,
-                              out=(self.x_a, self.v, self.mass, self.ref4), ctrl=self.ctrl, ctrl_keep=ctrl_keep)
-        self.parity = 0
-        if self.mode == "external":
-            self.f = torch.zeros((n, 3), dtype=torch.float32, device=self.dev)
-        else:
-            self.f = None
         box = Box(0, 0.0, 0.0, 0.0)
         wrap = 0
         skin = 0.0
@@ -620,7 +609,28 @@ class _RunState:
                 if sk is None or sk[0] is not self.nbr_list.skin:
                     sk = self._skin_md = (self.nbr_list.skin, float(self.nbr_list.skin.value_in_unit_system(unit.md_unit_system)))
                 skin = sk[1]
-        if self.mode == "fused":
+        check = None
+        self.parity = 0  # (the pack below writes the buffer that is current at parity 0)
+        if validate and not packed and self.mode == "fused":
+            # (the verdict also goes to the generation's host-mapped slot: the slot has to be the new one already)
+            self._open_generation(step)
+            scratch = getattr(owner, "_scratch", None)
+            xs4 = scratch["arrays"][4] if scratch and scratch.get("arrays") is not None else None
+            if xs4 is None or xs4.shape[0] != n:
+                raise RuntimeError("list carry-over: the force list's owner holds no cell-ordered positions")
+            check = (xs4, box, skin, step, self._gen.tensor, self.device_buffers(self.integ, n, self.dev)["sync2"])
+        if not packed:
+            # one launch: positions (the buffer that is current at parity 0), velocities, masses, reference positions,
+            # written into the integrator's buffers (a rebuild has copied the state out first), and the control-block reset
+            if ref_user is None and self.is_verlet:
+                ref_user = owner.ref_positions
+            ops.pack_langevin(x_user, v_user, self.mass_user, ref_user if self.is_verlet else None, perm, self.is_verlet,
+                              out=(self.x_a, self.v, self.mass, self.ref4), ctrl=self.ctrl, ctrl_keep=ctrl_keep, validate=check)
+        if self.mode == "external":
+            self.f = torch.zeros((n, 3), dtype=torch.float32, device=self.dev)
+        else:
+            self.f = None
+        if self.mode == "fused" and check is None:
             self._open_generation(step)
         # The parameter block is kept on the integrator between loads: most of its ~40 fields are functions of objects
         # that outlive a run() -- the integrator's own device buffers, the box, the potential, the thermostat's constants --

@@ -268,11 +268,14 @@ def nl_finish_padding(nl: torch.Tensor, first: torch.Tensor, n_nbr: torch.Tensor
     return mask
 
 
-def pack_langevin(x3, v3, mass, ref3, perm, want_ref: bool, out=None, ctrl=None, publish=None, ctrl_keep: int = 0):
+def pack_langevin(x3, v3, mass, ref3, perm, want_ref: bool, out=None, ctrl=None, publish=None, ctrl_keep: int = 0,
+                  validate=None):
     """User-order state -> internal order in one launch: (x4, v, mass_internal, ref4 or None).
     ``out`` = a previous result of the same shapes to write into.  Riders on the same launch: ``ctrl`` = control
     block to reset (``ctrl_reset``; ``ctrl_keep`` bit 0 / 1: leave the reference-event counters / booked events alone),
-    ``publish`` = (device block of 8 ints, pinned host block) to copy (``publish``)."""
+    ``publish`` = (device block of 8 ints, pinned host block) to copy (``publish``); ``validate`` = (snap4, box, skin, step,
+    host_ctrl tensor or None, sync2): the launch also answers chx_validate_snap's question and leaves the answer in the
+    reset control block's halt word (include/chx.h: chx_pack_validate_langevin; needs ``ctrl``)."""
     x3, v3, mass = _f32(x3), _f32(v3), _f32(mass)
     _require_device(x3, v3, mass, perm)
     n = x3.shape[0]
@@ -287,6 +290,19 @@ def pack_langevin(x3, v3, mass, ref3, perm, want_ref: bool, out=None, ctrl=None,
     if want_ref:
         ref3 = _f32(ref3)
         _require_device(ref3)
+    if validate is not None:
+        snap4, box, skin, step, host_ctrl, sync2 = validate
+        _require_device(snap4, sync2, ctrl)
+        if publish:
+            raise _lib.ChxError("pack_langevin: validate and publish do not combine")
+        check(
+            _lib.load().chx_pack_validate_langevin(
+                box, C.c_float(skin), int(step), _ptr(snap4), C.c_void_p(host_ctrl.data_ptr()) if host_ctrl is not None else None,
+                _ptr(sync2), _ptr(x3), _ptr(v3), _ptr(mass), _ptr(ref3) if want_ref else None, _ptr(perm), n, _ptr(x4), _ptr(v),
+                _ptr(m_int), _ptr(ref4), _ptr(ctrl), int(ctrl_keep), _stream()),
+            "chx_pack_validate_langevin",
+        )
+        return x4, v, m_int, ref4
     check(
         _lib.load().chx_pack_langevin(_ptr(x3), _ptr(v3), _ptr(mass), _ptr(ref3) if want_ref else None, _ptr(perm), n,
                                       _ptr(x4), _ptr(v), _ptr(m_int), _ptr(ref4), _ptr(ctrl), int(ctrl_keep),

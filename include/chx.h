@@ -264,6 +264,15 @@ int chx_unpack_langevin(const float* x4, const float* v, const uint32_t* perm, i
  * are (carried-over force list: a renewal of the list must not lose a rebuild event that is booked for the very next
  * launch, nor the count so far);
  * publish_src8 / publish_host_dst8 != NULL -> what chx_publish(src, dst, 8) does (the build's status block). */
+/* chx_pack_langevin (with its control-block reset) and chx_validate_snap (below) in ONE launch, for a run that starts on a
+ * carried-over force list: the halt word of the freshly reset control block is `step` if some particle is farther than
+ * skin / 2 from snap4 (the positions the force list was built from, internal order), as is host_ctrl[3] (HOST-MAPPED,
+ * may be NULL).  sync2: two ints of device memory, zero on entry (the caller zeroes them once), zero again afterwards.
+ * ctrl_reset is required.  Added in round 4. */
+int chx_pack_validate_langevin(chx_box_t box, float skin, int32_t step, const float* snap4, int32_t* host_ctrl,
+                               int32_t* sync2, const float* x3, const float* v3, const float* mass, const float* ref3,
+                               const uint32_t* perm, int32_t n, float* x4_out, float* v_out, float* mass_out,
+                               float* ref4_out, int32_t* ctrl_reset, int32_t ctrl_keep, chx_stream_t stream);
 int chx_pack_langevin(const float* x3, const float* v3, const float* mass, const float* ref3,
                       const uint32_t* perm, int32_t n, float* x4_out, float* v_out, float* mass_out,
                       float* ref4_out, int32_t* ctrl_reset, int32_t ctrl_keep, const int32_t* publish_src8,

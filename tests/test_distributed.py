@@ -218,6 +218,37 @@ def test_bench_launcher_requalifies_slow_ranks_before_the_group_forms():
     assert res.returncode == 0 and lines[0]["config"]["requalification"] is None
 
 
+def test_bench_single_gpu_run_is_chosen_among_fresh_candidates():
+    """`bench.py --gpus 1` started by hand: the process that runs the bench is chosen by the same rate-based
+    qualification (bench.launch_single) -- two fresh candidates measure their stand-alone rate in turn and park; one
+    below 0.97 x the better is replaced (at most twice); the earliest good one runs the bench, the others go.  Fake
+    rates: a slow first candidate (0.85) -> a third is needed to have two that agree, and the second one runs."""
+    args = ["--gpus", "1", "--steps", "500", "--warmup", "0", "--dry-run-backend", "gloo"]
+    res, lines = _run_bench(args, env_extra={"CHX_BENCH_FAKE_RATES": "0:0=0.85"})
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert len(lines) == 1
+    cfg = lines[0]["config"]
+    assert cfg["attempt"] == 1 and cfg["group_world_size"] == 1
+    assert cfg["requalification"] == {"ratio": 0.97, "candidates_steps_per_s": [85000.0, 100000.0, 100000.0], "chosen_attempt": 1}
+    assert "running the bench in attempt 1" in res.stderr
+    # two candidates that agree: the first runs, nothing is said
+    res, lines = _run_bench(args, env_extra={"CHX_BENCH_FAKE_RATES": "0:1=0.99"})
+    assert res.returncode == 0 and len(lines) == 1
+    assert lines[0]["config"]["requalification"]["chosen_attempt"] == 0 and lines[0]["config"]["attempt"] == 0
+    assert len(lines[0]["config"]["requalification"]["candidates_steps_per_s"]) == 2 and "running the bench in" not in res.stderr
+    # an unlucky host (every candidate different): four candidates at most, the best one runs
+    res, lines = _run_bench(args, env_extra={"CHX_BENCH_FAKE_RATES": "0:0=0.5;0:1=0.6;0:2=0.7;0:3=0.9"})
+    assert res.returncode == 0 and len(lines) == 1
+    assert lines[0]["config"]["requalification"]["chosen_attempt"] == 3
+    # switched off, or under a profiler (whose preloaded tool has initialised the GPU: no child may be started): in-process
+    for extra_args, extra_env in ((["--requalify", "0"], {}), ([], {"ROCPROFILER_TEST_MARKER": "1"})):
+        res, lines = _run_bench(args + extra_args, env_extra=dict(extra_env, CHX_BENCH_FAKE_RATES="0:0=0.5"))
+        assert res.returncode == 0 and len(lines) == 1 and lines[0]["config"]["requalification"] is None
+    # a candidate that dies before it reports: its exit code comes back, no line
+    res, lines = _run_bench(args, env_extra={"CHX_BENCH_FAKE_RATES": "0:0=not-a-number"})
+    assert res.returncode != 0 and not lines
+
+
 def test_requalify_decisions_on_fake_children():
     """The parent's decision rule by itself (bench.requalify): median of the ranks, 0.97 threshold, at most two
     replacements per rank, two ranks measured against the faster one, dead children (no rate) left alone."""
