@@ -331,6 +331,9 @@ def _count_inside(x4: torch.Tensor, p, q, hi, box, T: float) -> int:
 def test_inner_list_pair_set_audit_at_random_steps(prod, O, CO):
     from chiron_amd import ops
 
+    if os.environ.get("CHX_PRUNE_EVERY") == "0":
+        pytest.skip("CHX_PRUNE_EVERY=0: there is no inner list to audit")
+
     rng = np.random.default_rng(20260 + prod.n)
     span = 5000
     ks = sorted(int(k) for k in rng.integers(1, span, 50))
