@@ -1184,6 +1184,11 @@ def main():
             "roofline_pair_force": roof_force,
         }
         out["config"]["list_carry_over"] = False
+        from chiron_amd import integrators as _integ_mod
+
+        # (what a list build inside the timed run() writes: the force list the step kernels read, every time; the
+        # reference-format half rows on demand -- their counts always, the rows when `neighbor_list` is first read)
+        out["config"]["half_rows_inside_run"] = "written" if _integ_mod._RUN_HALF_ROWS else "counted; built on first read of neighbor_list"
         out["config"]["requalification"] = qual
         if world == 1:
             try:

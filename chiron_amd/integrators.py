@@ -115,7 +115,7 @@ class LangevinIntegrator:
     # memory, and its numpy view no longer aliases it): it starts without and allocates its own on first use.
     # MultiStateSampler deep-copies its sampler, chiron/multistate.py:266-268.
     _PER_PROCESS_STATE = ("_gen_ring", "_gen_next", "_pinned_ring", "_ring_next", "_dev_scratch", "_inner_scratch",
-                          "_run_cache", "_defer_scratch", "_rebuild_log", "_carry", "_params_cache")
+                          "_run_cache", "_defer_scratch", "_rebuild_log", "_carry", "_params_cache", "_mass_q")
 
     def __getstate__(self):
         return {k: v for k, v in self.__dict__.items() if k not in self._PER_PROCESS_STATE}
@@ -146,7 +146,15 @@ class LangevinIntegrator:
         from .utils import get_list_of_mass, initialize_velocities
 
         potential = thermodynamic_state.potential
-        mass = get_list_of_mass(potential.topology)
+        # (the Quantity around the topology's cached mass array costs 3.5 us to make: kept while the array is the same object)
+        topo = potential.topology
+        raw = topo.masses_amu() if hasattr(topo, "masses_amu") else None
+        held = self.__dict__.get("_mass_q")
+        if raw is not None and held is not None and held[0] is raw:
+            mass = held[1]
+        else:
+            mass = get_list_of_mass(topo)
+            self._mass_q = (raw, mass) if raw is not None else None
         self.box_vectors = sampler_state.box_vectors
         self.progress_bar = progress_bar
         temperature = thermodynamic_state.temperature

@@ -207,41 +207,73 @@ def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: in
     publish = None
     if riders or cand is not None or slots is not None:
         riders = riders or {}
-        rd = _lib.BuildRiders()
-        if cand is not None:
-            rd.cand_list, rd.cand_len, rd.cand_cap = cand[0].data_ptr(), cand[1].data_ptr(), cand[2]
-        if slots is not None:
-            rd.cell_slots, rd.cell_slot_cap = slots[0].data_ptr(), slots[1]
         cp = riders.get("copy")
+        pk = riders.get("pack")
+        ct = riders.get("ctrl")
+        pb = riders.get("publish")
+        # The rider block is kept with the work arrays: its members that point at things which outlive a build -- the
+        # candidate lists and id slots (this scratch), the integrator's own buffers (pack outputs, control block), the
+        # list's pinned status block -- are filled once and reused while they are the same objects (references held
+        # here, so an id cannot be recycled); what changes from build to build (the copy of the positions, the velocities
+        # to pack, ctrl_keep) is set every time.  ~4 us less Python in front of a run()'s first launch.
+        stable = (cand[0] if cand is not None else None, slots[0] if slots is not None else None,
+                  pk[1] if pk is not None else None, pk[3] if pk is not None else None, pk[4] if pk is not None else None,
+                  pk[5] if pk is not None else None, pk[6] if pk is not None else None, ct, pb)
+        kept = scratch.get("rd") if scratch is not None else None
+        if kept is not None and len(kept[0]) == len(stable) and all(u is w for u, w in zip(kept[0], stable)):
+            rd, publish = kept[1], kept[2]
+        else:
+            rd = _lib.BuildRiders()
+            if cand is not None:
+                rd.cand_list, rd.cand_len, rd.cand_cap = cand[0].data_ptr(), cand[1].data_ptr(), cand[2]
+            if slots is not None:
+                rd.cell_slots, rd.cell_slot_cap = slots[0].data_ptr(), slots[1]
+            if pk is not None:
+                _, mass, _, x4_out, v_out, mass_out, ref4_out = pk
+                _require_device(mass, x4_out, v_out, mass_out)
+                if mass.dtype != torch.float32 or not mass.is_contiguous():
+                    raise _lib.ChxError("pack rider: velocities and masses must be contiguous fp32 tensors")
+                rd.mass = mass.data_ptr()
+                rd.x4_out, rd.v_out, rd.mass_out = x4_out.data_ptr(), v_out.data_ptr(), mass_out.data_ptr()
+                rd.ref4_out = ref4_out.data_ptr() if ref4_out is not None else None
+            if ct is not None:
+                rd.ctrl_reset = ct.data_ptr()
+            if pb is not None:
+                if not pb.is_pinned():
+                    raise _lib.ChxError("publish needs a pinned (host-mapped) destination tensor")
+                publish = C.c_void_p(pb.data_ptr())
+            if scratch is not None:
+                scratch["rd"] = (stable, rd, publish)
         if cp is not None:
             _require_device(cp)
             rd.xyz_copy_out = cp.data_ptr()
-        pk = riders.get("pack")
+        else:
+            rd.xyz_copy_out = None
         if pk is not None:
-            v3, mass, ref3, x4_out, v_out, mass_out, ref4_out = pk
-            _require_device(v3, mass, x4_out, v_out, mass_out)
-            if v3.dtype != torch.float32 or not v3.is_contiguous() or mass.dtype != torch.float32 or not mass.is_contiguous():
+            v3, ref3 = pk[0], pk[2]
+            _require_device(v3)
+            if v3.dtype != torch.float32 or not v3.is_contiguous():
                 raise _lib.ChxError("pack rider: velocities and masses must be contiguous fp32 tensors")
-            rd.v3, rd.mass = v3.data_ptr(), mass.data_ptr()
+            rd.v3 = v3.data_ptr()
             rd.ref3 = ref3.data_ptr() if ref3 is not None else None
-            rd.x4_out, rd.v_out, rd.mass_out = x4_out.data_ptr(), v_out.data_ptr(), mass_out.data_ptr()
-            rd.ref4_out = ref4_out.data_ptr() if ref4_out is not None else None
-        ct = riders.get("ctrl")
-        if ct is not None:
-            rd.ctrl_reset, rd.ctrl_keep = ct.data_ptr(), int(riders.get("ctrl_keep", 0))
-        pb = riders.get("publish")
-        if pb is not None:
-            if not pb.is_pinned():
-                raise _lib.ChxError("publish needs a pinned (host-mapped) destination tensor")
-            publish = C.c_void_p(pb.data_ptr())
+        rd.ctrl_keep = int(riders.get("ctrl_keep", 0)) if ct is not None else 0
     lib = _lib.load()
     stream = _stream()
     cs = C.c_float(cutoff_plus_skin)
     # the binning launches go to the device FIRST; the arrays the rows go into are allocated while they run (at the entry
     # of a short run() the device idles until the first launch is made: include/chx.h, chx_cell_bin_fl)
+    # (the work arrays' pointers as ctypes objects, made once per set of arrays)
+    wp = scratch.get("wptr") if scratch is not None else None
+    if wp is None or wp[0] is not cell_of or wp[1] is not (cand[0] if cand is not None else None):
+        wp = (cell_of, cand[0] if cand is not None else None, _ptr(cell_of), _ptr(cell_count), _ptr(cell_start), _ptr(status),
+              _ptr(xs4), _ptr(cand[0]) if cand is not None else None, _ptr(cand[1]) if cand is not None else None)
+        if scratch is not None:
+            scratch["wptr"] = wp
+    p_cell_of, p_cell_count, p_cell_start, p_status, p_xs4, p_cand0, p_cand1 = wp[2:]
+    p_sorted = _ptr(sorted_ids)
     check(
-        lib.chx_cell_bin_fl(_ptr(xyz), n, box, cs, nc, _ptr(cell_of), _ptr(cell_count), _ptr(cell_start), _ptr(sorted_ids),
-                            _ptr(status), _ptr(xs4), C.byref(rd) if rd is not None else None, stream),
+        lib.chx_cell_bin_fl(_ptr(xyz), n, box, cs, nc, p_cell_of, p_cell_count, p_cell_start, p_sorted,
+                            p_status, p_xs4, C.byref(rd) if rd is not None else None, stream),
         "chx_cell_bin_fl",
     )
     nl = torch.empty((n, m), **i32) if half_rows else None
@@ -250,10 +282,9 @@ def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: in
     fl = torch.empty((chunks, n, FL_QUAD * g), **i32)
     deg = torch.empty((n,), **i32)
     check(
-        lib.chx_nl_rows_cell_fl(n, m, box, cs, nc, _ptr(cell_of), _ptr(cell_start), _ptr(sorted_ids), _ptr(status), _ptr(xs4),
+        lib.chx_nl_rows_cell_fl(n, m, box, cs, nc, p_cell_of, p_cell_start, p_sorted, p_status, p_xs4,
                                 _ptr(nl) if half_rows else None, _ptr(first) if half_rows else None, _ptr(n_nbr), g, chunks, _ptr(fl), _ptr(deg), publish,
-                                _ptr(cand[0]) if cand is not None else None, _ptr(cand[1]) if cand is not None else None,
-                                cand[2] if cand is not None else 0, stream),
+                                p_cand0, p_cand1, cand[2] if cand is not None else 0, stream),
         "chx_nl_rows_cell_fl",
     )
     return nl, first, n_nbr, sorted_ids, fl, deg, status
