@@ -49,7 +49,7 @@ struct McArgs {
   double* ws;   // two halves of ws_half doubles: launch t writes half t & 1 and reads the other (the partials of t - 1)
   int ws_half;
   int nblocks;  // per-block energy partials per half
-  const uint4* keyrow;  // key table row of the launch's own trial: {proposal key (2 words), uniform of its decision (fp32 bits), 0}
+  const uint4* keyrow;  // key table row of the launch's own trial: {proposal key (2 words), uniform of its decision and its logarithm (fp32 bits)}
   // the inner list (see "Inner list" below); fli == NULL: off
   uint32_t* fli;    // same geometry as fl
   int32_t* cnti;    // (n, G): entries of a lane's even words | odd words << 16
@@ -246,7 +246,11 @@ __device__ __forceinline__ double mc_partials(const McArgs& a, long long trial) 
 // The decision of trial `trial - 1` (chiron/mcmc.py:428-436, :531-548) from those partials and the trial's uniform: one
 // thread's arithmetic in a fixed summation order, so every workgroup that calls this arrives at the same bits;
 // workgroup 0 records it in the slot of `trial`.
-__device__ __forceinline__ int mc_decide(const McArgs& a, long long trial, int log_slot, double part, float uniform) {
+// (log_u: fp32 log of the uniform, made on the host with the key table: most decisions are then a comparison -- the
+// fp64 exponential sits on the launch's dependent chain, one thread computing it while 255 wait -- and the exponential is
+// only evaluated when log_prob and log(uniform) are closer than the fp32 rounding of the latter could explain, so every
+// decision is the one `uniform < exp(log_prob)` gives)
+__device__ __forceinline__ int mc_decide(const McArgs& a, long long trial, int log_slot, double part, float uniform, float log_u) {
   __shared__ int32_t sh_acc;
   const int b = (int)(trial & 1);
   const int32_t* in = a.state + CHX_MC_SLOT_WORDS * (b ^ 1);
@@ -259,7 +263,13 @@ __device__ __forceinline__ int mc_decide(const McArgs& a, long long trial, int l
     const double uc = a.beta * e_in[0];
     const double lp = -up + uc;  // log_proposal_ratio  :770
     int acc = 0;
-    if (!isnan(up)) acc = (-lp <= 0.0 || U < exp(lp)) ? 1 : 0;  // :428-429, :544-545
+    if (!isnan(up)) {  // :428-429, :544-545
+      const double lu = (double)log_u;
+      const double tol = 4.0e-7 * (fabs(lu) + 1.0);
+      if (-lp <= 0.0 || lp > lu + tol) acc = 1;
+      else if (lp < lu - tol) acc = 0;
+      else acc = U < exp(lp) ? 1 : 0;
+    }
     sh_acc = acc;
     if (blockIdx.x == 0) {
       int32_t* out = a.state + CHX_MC_SLOT_WORDS * b;
@@ -281,9 +291,9 @@ __device__ __forceinline__ int mc_decide(const McArgs& a, long long trial, int l
 // the chunk's last launch: the decision of its last trial, one workgroup (a.keyrow: the row of `trial`)
 __global__ __launch_bounds__(256) void k_mc_decide(McArgs a, long long trial, int log_slot) {
   const double part = mc_partials(a, trial);
-  const float uniform = __uint_as_float(a.keyrow[-1].z);
+  const float uniform = __uint_as_float(a.keyrow[-1].z), log_u = __uint_as_float(a.keyrow[-1].w);
   if ((long long)a.state[CHX_MC_HALT] <= trial - 1) return;
-  (void)mc_decide(a, trial, log_slot, part, uniform);
+  (void)mc_decide(a, trial, log_slot, part, uniform, log_u);
 }
 
 // the chunk's first launch: the configuration before trial `trial` sits in copy state.CUR of cur4[trial & 1]; make
@@ -335,7 +345,8 @@ __global__ __launch_bounds__(256) void k_mc_trial(McArgs a, long long trial, int
   const uint4 r0b = pinned_load16(a.ref4 + pc);
   const uint32_t o = a.perm ? (uint32_t)pinned_load4(reinterpret_cast<const int32_t*>(a.perm) + pc) : (uint32_t)pc;
   const double part = DECIDE ? mc_partials(a, trial) : 0.0;
-  const float uniform = DECIDE ? __uint_as_float(a.keyrow[-1].z) : 0.f;  // (the uniform of trial - 1's decision)
+  const float uniform = DECIDE ? __uint_as_float(a.keyrow[-1].z) : 0.f;  // (the uniform of trial - 1's decision ...
+  const float log_u = DECIDE ? __uint_as_float(a.keyrow[-1].w) : 0.f;    // ... and its logarithm)
   const uint4 next = a.keyrow[1];                                         // (.xy: the proposal key of trial + 1)
   // (inner list: its first quad, the lane's lengths and the position it was taken at -- requested whether this launch
   // turns out to walk it or to renew it)
@@ -346,7 +357,7 @@ __global__ __launch_bounds__(256) void k_mc_trial(McArgs a, long long trial, int
   const bool refresh = INNER && (long long)a.state[CHX_MC_REFRESH] == trial;  // (launch-uniform)
   if ((long long)a.state[CHX_MC_HALT] <= trial - (DECIDE ? 1 : 0)) return;  // (the halt word is shared: slot 0)
   // ---- the decision of trial - 1: every workgroup, same bits ----
-  const int sel = DECIDE ? mc_decide(a, trial, log_slot, part, uniform) : 0;
+  const int sel = DECIDE ? mc_decide(a, trial, log_slot, part, uniform, log_u) : 0;
   // ---- energy of x'_t over the force list: the pair-force kernel's row loop and its reduction, bit for bit ----
   const float4* prop = prop_b + (size_t)sel * a.n;  // x'_t
   const uint4 xpb = sel ? xp1 : xp0, xcb = sel ? xc1 : xc0;
@@ -431,7 +442,10 @@ extern "C" int chx_mc_key_chain_h(uint32_t k0, uint32_t k1, int32_t n_trials, ui
       const float U = ((float)(o[0] >> 9) + 0.5f) * (1.0f / 8388608.0f);  // u32_to_uniform (chx_common.h), exact in fp32
       uint32_t ub;
       __builtin_memcpy(&ub, &U, 4);
-      keytab_h[4 * i] = p0, keytab_h[4 * i + 1] = p1, keytab_h[4 * i + 2] = ub, keytab_h[4 * i + 3] = 0u;
+      const float LU = (float)log((double)U);  // (what mc_decide compares against before it falls back on exp)
+      uint32_t lb;
+      __builtin_memcpy(&lb, &LU, 4);
+      keytab_h[4 * i] = p0, keytab_h[4 * i + 1] = p1, keytab_h[4 * i + 2] = ub, keytab_h[4 * i + 3] = lb;
     }
   }
   return CHX_OK;

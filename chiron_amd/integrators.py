@@ -171,7 +171,7 @@ class LangevinIntegrator:
                     del cache[k]
             cache[kT_key] = (temperature, float((self.kB * temperature).value_in_unit_system(unit.md_unit_system)))
         kbT_unitless = cache[kT_key][1]
-        m_key = ("mass", id(potential.topology), str(x0.device))
+        m_key = ("mass", id(potential.topology), x0.device)  # (a torch.device hashes and compares; str() of it costs 1 us)
         if cache.get(m_key, (None,))[0] is not mass._value:
             cache[m_key] = (mass._value, as_tensor(mass.value_in_unit_system(unit.md_unit_system)))
         mass_unitless = cache[m_key][1]
@@ -424,7 +424,7 @@ class _RunState:
         Langevin state in internal order -- positions (two buffers: a step reads one and writes the other), velocities,
         masses, reference positions.  Everything a run() returns is a fresh copy, never one of these."""
         keep = integ.__dict__.setdefault("_dev_scratch", {})
-        sk = (n, str(dev))
+        sk = (n, dev)
         if keep.get("key") != sk:
             keep.clear()
             keep["key"] = sk
@@ -457,7 +457,7 @@ class _RunState:
             raise ValueError(f"noise must have shape (steps, {self.n}, 3), got {tuple(self.noise.shape)}")
         self.mass_user = mass
         keep = self.device_buffers(integ, self.n, self.dev)
-        self.ctrl, self.ws, self.ev_log = keep["ctrl"], keep["ws"], keep["ev_log"]
+        self.ctrl, self.ws, self.ev_log, self.sync2 = keep["ctrl"], keep["ws"], keep["ev_log"], keep["sync2"]
         self.is_verlet = isinstance(nbr_list, NeighborListNsqrd)
         self.is_pairlist = isinstance(nbr_list, PairListNsqrd)
         self.x_a, self.x_b, self.v, self.mass = keep["x_a"], keep["x_b"], keep["v"], keep["mass"]
@@ -499,9 +499,9 @@ class _RunState:
         reference's rebuilds are events the step kernel takes itself."""
         d = self._defer = _Decoupled()
         keep = self.integ.__dict__.setdefault("_defer_scratch", {})
-        if keep.get("key") != (self.n, str(self.dev)):
+        if keep.get("key") != (self.n, self.dev):
             keep.clear()
-            keep["key"] = (self.n, str(self.dev))
+            keep["key"] = (self.n, self.dev)
             keep["builders"] = [None, None]
         d.builders = keep["builders"]
         d.next = 1 if d.builders[0] is self._carried else 0  # (a rebuild must not write into the list being walked)
@@ -626,7 +626,7 @@ class _RunState:
             xs4 = scratch["arrays"][4] if scratch and scratch.get("arrays") is not None else None
             if xs4 is None or xs4.shape[0] != n:
                 raise RuntimeError("list carry-over: the force list's owner holds no cell-ordered positions")
-            check = (xs4, box, skin, step, self._gen.tensor, self.device_buffers(self.integ, n, self.dev)["sync2"])
+            check = (xs4, box, skin, step, self._gen.tensor, self.sync2)
         if not packed:
             # one launch: positions (the buffer that is current at parity 0), velocities, masses, reference positions,
             # written into the integrator's buffers (a rebuild has copied the state out first), and the control-block reset

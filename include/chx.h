@@ -605,7 +605,7 @@ int chx_mc_displace_chunk(const chx_mc_t* p_h, int64_t trial0, int32_t n_trials,
                           chx_stream_t stream);
 /* The key chain of n_trials consecutive trials from the chain key (k0, k1), on the host: per trial two splits
  * (chiron/mcmc.py:724 proposal, :531 acceptance).  keytab_h row i (4 words) = {proposal key of trial i (2), fp32 bits of
- * the uniform of its decision, 0}, rows 0 .. n_trials; chain_out_h entry i (2 words) = chain key before trial i, entries
+ * the uniform of its decision, fp32 bits of that uniform's logarithm}, rows 0 .. n_trials; chain_out_h entry i (2 words) = chain key before trial i, entries
  * 0 .. n_trials.  Either may be NULL. */
 int chx_mc_key_chain_h(uint32_t k0, uint32_t k1, int32_t n_trials, uint32_t* keytab_h, uint32_t* chain_out_h);
 

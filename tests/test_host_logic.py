@@ -128,7 +128,11 @@ def test_mc_key_chain_helper_matches_the_host_key_handling():
         key, sub = rng.split(key)  # SamplerState.new_PRNG_key: the proposal key
         assert (tab[4 * i], tab[4 * i + 1]) == tuple(sub)
         key, acc = rng.split(key)  # the acceptance key
-        assert np.frombuffer(np.uint32(tab[4 * i + 2]).tobytes(), np.float32)[0] == np.float32(rng.uniform(acc))
+        u32 = np.frombuffer(np.uint32(tab[4 * i + 2]).tobytes(), np.float32)[0]
+        assert u32 == np.float32(rng.uniform(acc))
+        # word 3: fp32 log of that uniform (the device decides by comparison and evaluates exp only near the boundary)
+        lu = np.frombuffer(np.uint32(tab[4 * i + 3]).tobytes(), np.float32)[0]
+        assert abs(float(lu) - np.log(np.float64(u32))) <= 1.2e-7 * (abs(np.log(np.float64(u32))) + 1e-30) + 1e-45
     assert lib.chx_mc_key_chain_h(1, 2, -1, None, None) < 0
 
 
