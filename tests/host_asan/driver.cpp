@@ -123,6 +123,40 @@ int main() {
   EXPECT_INVALID(chx_invert_perm(U, -1, U, nullptr));
   EXPECT_INVALID(chx_pack_langevin(F, F, F, F, U, -1, F, F, F, F, nullptr, 0, nullptr, nullptr, nullptr));
   EXPECT_INVALID(chx_pack_langevin(F, F, F, F, U, 4, F, F, F, F, nullptr, 0, I, nullptr, nullptr));  // publish without a destination
+  // round 4: the pack launch that also checks a carried-over list, the build's optional workspaces, the key table
+  EXPECT_INVALID(chx_pack_validate_langevin(ok_box, 0.4f, 0, F, nullptr, I, F, F, F, F, U, 0, F, F, F, F, I, 0, nullptr));      // n < 1
+  EXPECT_INVALID(chx_pack_validate_langevin(ok_box, 0.4f, 0, nullptr, nullptr, I, F, F, F, F, U, 4, F, F, F, F, I, 0, nullptr)); // no snap4
+  EXPECT_INVALID(chx_pack_validate_langevin(ok_box, 0.4f, 0, F, nullptr, nullptr, F, F, F, F, U, 4, F, F, F, F, I, 0, nullptr)); // no sync2
+  EXPECT_INVALID(chx_pack_validate_langevin(ok_box, 0.4f, 0, F, nullptr, I, F, F, F, F, U, 4, F, F, F, F, nullptr, 0, nullptr)); // no ctrl
+  EXPECT_INVALID(chx_pack_validate_langevin(ok_box, 0.0f, 0, F, nullptr, I, F, F, F, F, U, 4, F, F, F, F, I, 0, nullptr));       // skin
+  EXPECT_INVALID(chx_pack_validate_langevin(ok_box, 0.4f, -1, F, nullptr, I, F, F, F, F, U, 4, F, F, F, F, I, 0, nullptr));      // step
+  EXPECT_INVALID(chx_pack_validate_langevin(ok_box, 0.4f, 0, F, nullptr, I, F, F, F, nullptr, U, 4, F, F, F, F, I, 0, nullptr)); // ref4 without ref3
+  EXPECT(chx_sizeof_build_riders_t() == (int64_t)sizeof(chx_build_riders_t));
+  {
+    chx_build_riders_t rd;
+    memset(&rd, 0, sizeof(rd));
+    rd.cell_slot_cap = 64;  // a capacity without the slots
+    EXPECT_INVALID(chx_cell_bin_fl(F, 4, ok_box, 1.5f, grid, I, I, I, U, I, F, &rd, nullptr));
+    rd.cell_slot_cap = -1;
+    rd.cell_slots = U;
+    EXPECT_INVALID(chx_cell_bin_fl(F, 4, ok_box, 1.5f, grid, I, I, I, U, I, F, &rd, nullptr));
+    // half rows: nl_rows_out and first_out go together (both NULL = counted only)
+    EXPECT_INVALID(chx_nl_rows_cell_fl(4, 4, ok_box, 1.5f, grid, I, I, U, I, F, nullptr, U, I, 4, 2, U, I, nullptr, nullptr, nullptr, 0, nullptr));
+    EXPECT_INVALID(chx_nl_rows_cell_fl(4, 4, ok_box, 1.5f, grid, I, I, U, I, F, U, nullptr, I, 4, 2, U, I, nullptr, nullptr, nullptr, 0, nullptr));
+    EXPECT_INVALID(chx_nl_build_cell_fl(F, 4, 4, ok_box, 1.5f, grid, I, I, I, U, I, nullptr, U, I, 4, 2, U, I, F, nullptr, nullptr));
+  }
+  {
+    std::vector<uint32_t> tab(4 * 33), chain(2 * 33);
+    EXPECT(chx_mc_key_chain_h(2024u, 7u, 32, tab.data(), chain.data()) == CHX_OK);
+    for (int r = 0; r <= 32; ++r) {
+      float uf, lf;
+      memcpy(&uf, &tab[4 * r + 2], 4);
+      memcpy(&lf, &tab[4 * r + 3], 4);
+      EXPECT(uf > 0.f && uf < 1.f && lf < 0.f && fabs((double)lf - log((double)uf)) <= 1.2e-7 * fabs(log((double)uf)) + 1e-30);
+    }
+    EXPECT(chx_mc_key_chain_h(1u, 2u, 0, nullptr, nullptr) == CHX_OK);
+    EXPECT_INVALID(chx_mc_key_chain_h(1u, 2u, -1, tab.data(), chain.data()));
+  }
   EXPECT_INVALID(chx_unpack_langevin(F, F, U, -1, F, F, nullptr));
   EXPECT_INVALID(chx_unpack_langevin(F, nullptr, U, 4, F, F, nullptr));
   EXPECT(chx_unpack_langevin(nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr) == CHX_OK);
