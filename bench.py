@@ -276,11 +276,18 @@ def launch_single(args):
             c = spawn(attempt)
             rate = c.read_rate(300.0)
             log.append(rate)
-            if rate is None:  # died before it could report: its exit code is the answer
-                code = c.proc.wait()
-                for o in cands:
+            if rate is None:
+                try:  # (a child whose report pipe closed is on its way out: give it a moment to be reaped)
+                    code = c.proc.wait(timeout=10)
+                except Exception:
+                    code = None
+                for o in cands + [c]:
                     o.discard()
-                return code if code else 1
+                if code is None:  # alive but silent for five minutes: give up on the protocol, run in this process
+                    print("bench.py launcher: a candidate did not report its rate; running the bench in the launcher's own "
+                          "process", file=sys.stderr, flush=True)
+                    return None
+                return code if code else 1  # died before it could report: its exit code is the answer
             cands.append(c)
             best = max(o.rate for o in cands)
             if len(cands) >= 2 and sum(1 for o in cands if o.rate >= QUALIFY_RATIO * best) >= 2:
