@@ -384,35 +384,46 @@ __global__ __launch_bounds__(256) void k_mc_trial(McArgs a, long long trial, int
   mine = block_sum<256>(mine);
   if (threadIdx.x == 0) a.ws[(size_t)a.ws_half * b + blk] = mine;  // (never the half the heads of this launch are reading)
   if (INNER && refresh && blockIdx.x == 0 && threadIdx.x == 0) a.state[CHX_MC_REFRESHES] += 1;  // (statistics)
-  if (!valid || q != 0) return;
-  // ---- skin check of this trial's proposal (chiron/neighbors.py:868): the first violating trial halts the chunk ----
-  float rx, ry, rz;
-  displacement(a.box, xp.x, xp.y, xp.z, __uint_as_float(r0b.x), __uint_as_float(r0b.y), __uint_as_float(r0b.z), rx, ry, rz);
-  if (norm2(rx, ry, rz) > a.T_half_skin) atomicMin(&a.state[CHX_MC_HALT], (int)trial);
-  // ---- the next trial's candidates (chiron/mcmc.py:733-755 on either outcome of this trial) ----
+  if (!valid) return;
+  // ---- the tail: four jobs per particle, dealt to its G lanes (role = q, q + G, ...: one each with four lanes or more)
+  // so that a wavefront issues the tail's instructions once, not four times over for lane 0 --
+  //   role 0  skin check of this trial's proposal (chiron/neighbors.py:868: the first violating trial halts the chunk)
+  //           and the configuration should the trial be rejected;
+  //   role 1, 2  the next trial's candidates wrap(x_t + d), wrap(x'_t + d) (chiron/mcmc.py:733-755 on either outcome),
+  //           each checked against the inner list's guarantee one trial ahead: whichever becomes the next proposal must
+  //           lie within inner skin / 2 of where this particle stood when the list was taken (this launch's own
+  //           proposal if it renews it);
+  //   role 3  the configuration should the trial be accepted.
+  // One instruction stream for all roles: a base position (+ displacement, wrapped), one minimum-image distance against
+  // the role's reference and threshold, one 16-byte store to the role's slot. ----
   const float4 xc = make_float4(__uint_as_float(xcb.x), __uint_as_float(xcb.y), __uint_as_float(xcb.z), 0.0f);
   const float4 xpc = make_float4(xp.x, xp.y, xp.z, 0.0f);
   float4* cur_n = a.cur4 + (size_t)2 * (b ^ 1) * a.n;
   float4* prop_n = a.prop4 + (size_t)2 * (b ^ 1) * a.n;
-  cur_n[p] = xc;                 // trial t rejected: the configuration stays
-  cur_n[(size_t)a.n + p] = xpc;  // accepted: the proposal becomes the configuration
-  const float4 c0 = mc_displaced(a, xc, dx, dy, dz), c1 = mc_displaced(a, xpc, dx, dy, dz);
-  prop_n[p] = c0;
-  prop_n[(size_t)a.n + p] = c1;
-  if (INNER) {
-    // the inner list's guarantee, one trial ahead: whichever candidate becomes the next proposal must lie within
-    // inner skin / 2 of where this particle stood when the list was taken (this launch's own proposal if it renews it)
-    float rfx = __uint_as_float(rib.x), rfy = __uint_as_float(rib.y), rfz = __uint_as_float(rib.z);
-    if (refresh) {
-      rfx = xp.x, rfy = xp.y, rfz = xp.z;
-      a.refi4[p] = xpc;
-    }
-    float ux, uy, uz, wx, wy, wz;
-    displacement(a.box, c0.x, c0.y, c0.z, rfx, rfy, rfz, ux, uy, uz);
-    displacement(a.box, c1.x, c1.y, c1.z, rfx, rfy, rfz, wx, wy, wz);
-    if (norm2(ux, uy, uz) > a.T_inner_half || norm2(wx, wy, wz) > a.T_inner_half)
+  float rfx = __uint_as_float(rib.x), rfy = __uint_as_float(rib.y), rfz = __uint_as_float(rib.z);
+  if (INNER && refresh) rfx = xp.x, rfy = xp.y, rfz = xp.z;
+#pragma unroll
+  for (int role = q; role < 4; role += G) {
+    const bool cand = role == 1 || role == 2;
+    const float4 base = (role == 0 || role == 1) ? xc : xpc;
+    const float4 out = cand ? mc_displaced(a, base, dx, dy, dz) : base;
+    float4* dst = (cand ? prop_n : cur_n) + (size_t)((role == 2 || role == 3) ? a.n : 0) + p;
+    *dst = out;
+    if (role == 3 || (cand && !INNER)) continue;
+    // (role 0 measures the PROPOSAL against the list's reference positions; a candidate against the inner list's)
+    const float px = role == 0 ? xp.x : out.x, py = role == 0 ? xp.y : out.y, pz = role == 0 ? xp.z : out.z;
+    const float qx = role == 0 ? __uint_as_float(r0b.x) : rfx, qy = role == 0 ? __uint_as_float(r0b.y) : rfy,
+                qz = role == 0 ? __uint_as_float(r0b.z) : rfz;
+    float rx, ry, rz;
+    displacement(a.box, px, py, pz, qx, qy, qz, rx, ry, rz);
+    const float r2 = norm2(rx, ry, rz);
+    if (role == 0) {
+      if (r2 > a.T_half_skin) atomicMin(&a.state[CHX_MC_HALT], (int)trial);
+    } else if (r2 > a.T_inner_half) {
       atomicMax(&a.state[CHX_MC_REFRESH], (int)trial + 1);
+    }
   }
+  if (INNER && refresh && q == 0) a.refi4[p] = xpc;
 }
 
 template <int G>
