@@ -962,7 +962,8 @@ def test_multistate_sampler_on_lj_replicas(ca, O, swap):
     assert all(k_ > 0 for k_ in ke)
 
 
-def test_multistate_concurrent_replicas_give_the_serial_results(ca, O):
+@pytest.mark.parametrize("with_mc", [False, True], ids=["langevin", "langevin+mc"])
+def test_multistate_concurrent_replicas_give_the_serial_results(ca, O, with_mc):
     """``MultiStateSampler(concurrent_replicas=2)`` propagates two replicas side by side (two threads, two HIP streams:
     a step of a medium-size system leaves the card mostly idle).  Replicas are independent between mixing steps, so
     positions, velocities, PRNG keys, neighbor lists, state assignment and the whole u_kn history must be the serial
@@ -988,8 +989,10 @@ def test_multistate_concurrent_replicas_give_the_serial_results(ca, O):
             lists.append(ca.neighbors.NeighborListCell(ca.neighbors.OrthogonalPeriodicSpace(), cutoff=CUTOFF * u.nanometer,
                                                        skin=0.06 * u.nanometer, n_max_neighbors=180))
         move = LangevinDynamicsMove(timestep=4.0 * u.femtoseconds, number_of_steps=120)
-        ms = MultiStateSampler(MCMCSampler(MoveSchedule([("LangevinDynamicsMove", move)])), swap="neighbors",
-                               concurrent_replicas=workers)
+        schedule = [("LangevinDynamicsMove", move)]
+        if with_mc:  # (the device-resident Monte Carlo loop in both lanes at once: its key chain is made on the host)
+            schedule.append(("MC", ca.mcmc.MonteCarloDisplacementMove(displacement_sigma=0.004 * u.nanometer, number_of_moves=40)))
+        ms = MultiStateSampler(MCMCSampler(MoveSchedule(schedule)), swap="neighbors", concurrent_replicas=workers)
         ms.create(thermo, states, lists)
         ms.run(n_iterations=4, n_mcmc_iterations=1)
         torch.cuda.synchronize()
