@@ -66,6 +66,11 @@ struct McArgs {
 // from where it stood then: every launch checks BOTH candidates it writes for the next trial against that position and
 // books a refresh for the next trial if one fails -- one trial ahead, so the launch that would misuse the list is the
 // one that renews it.
+// The refresh word follows the rule of the state slots: launch t READS state[CHX_MC_REFRESH] of slot t & 1 and BOOKS
+// into the word of the other slot, so no workgroup tests a word that a workgroup of the same launch writes (a grid
+// that is not co-resident -- N = 262 144 with four lanes per particle, liquid density with eight -- runs its last
+// workgroups after its first have finished: with ONE word they would see the booking for t + 1, skip the refresh
+// they are part of and walk rows this launch has not written.  Round-4 review).
 // The energy has to come out in the BITS the force list gives (the host loop of MCMove and compute_energy use it, and a
 // decision is a comparison of those bits).  A lane adds its entries up in two accumulators, the even and the odd words
 // of its quads in chunk order, and an entry beyond the cutoff adds an exact zero: so the inner list is compacted PER
@@ -315,7 +320,10 @@ __global__ __launch_bounds__(256) void k_mc_prologue(McArgs a, long long trial) 
   cur[(size_t)(1 - sel) * a.n + p] = xc;
   prop[p] = xp;
   prop[(size_t)a.n + p] = xp;
-  if (p == 0 && a.fli != nullptr) a.state[CHX_MC_REFRESH] = (int)trial;  // the chunk's first trial takes the inner list
+  if (p == 0 && a.fli != nullptr) {
+    a.state[CHX_MC_SLOT_WORDS * b + CHX_MC_REFRESH] = (int)trial;  // the chunk's first trial takes the inner list
+    a.state[CHX_MC_SLOT_WORDS * (b ^ 1) + CHX_MC_REFRESH] = -1;    // (nothing booked for the trial after it yet)
+  }
 }
 
 // Trial `trial` in one launch (see the head of this file).  Reads the buffers of parity trial & 1, writes the other.
@@ -354,7 +362,9 @@ __global__ __launch_bounds__(256) void k_mc_trial(McArgs a, long long trial, int
   const uint4 e4i = INNER ? pinned_load16(coli) : e4;
   const int cnt_raw = INNER ? pinned_load4(a.cnti + (size_t)pc * G + q) : 0;
   const uint4 rib = INNER ? pinned_load16(a.refi4 + pc) : r0b;
-  const bool refresh = INNER && (long long)a.state[CHX_MC_REFRESH] == trial;  // (launch-uniform)
+  // (launch-uniform: the word of slot b is written by the prologue and by launch trial - 1 only; this launch books into
+  // the other slot's)
+  const bool refresh = INNER && (long long)a.state[CHX_MC_SLOT_WORDS * b + CHX_MC_REFRESH] == trial;
   if ((long long)a.state[CHX_MC_HALT] <= trial - (DECIDE ? 1 : 0)) return;  // (the halt word is shared: slot 0)
   // ---- the decision of trial - 1: every workgroup, same bits ----
   const int sel = DECIDE ? mc_decide(a, trial, log_slot, part, uniform, log_u) : 0;
@@ -420,7 +430,10 @@ __global__ __launch_bounds__(256) void k_mc_trial(McArgs a, long long trial, int
     if (role == 0) {
       if (r2 > a.T_half_skin) atomicMin(&a.state[CHX_MC_HALT], (int)trial);
     } else if (r2 > a.T_inner_half) {
-      atomicMax(&a.state[CHX_MC_REFRESH], (int)trial + 1);
+      // (every booking lane stores the same value: a relaxed store, not an atomic -- with sigma_d of a few hundredths of
+      // a nanometre most particles book, and read-modify-writes of one address serialise chip-wide)
+      __hip_atomic_store(&a.state[CHX_MC_SLOT_WORDS * (b ^ 1) + CHX_MC_REFRESH], (int)trial + 1, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if (INNER && refresh && q == 0) a.refi4[p] = xpc;

@@ -236,6 +236,8 @@ class MonteCarloDisplacementMove(MCMove):
         self.displacement_sigma = displacement_sigma
         self.atom_subset = atom_subset
         self.atom_subset_mask = None
+        self.inner_list_refreshes = 0  # launches of the device loop that renewed their inner list (diagnostics)
+        self._dev_ws = None            # the device loop's arrays (``_device_workspace``)
 
     # trials enqueued per host round trip of the device-resident loop
     _DEVICE_CHUNK = 256
@@ -287,6 +289,46 @@ class MonteCarloDisplacementMove(MCMove):
             self.atom_subset_mask = torch.as_tensor(mask, device=sampler_state.positions.device)
         return self.atom_subset_mask if self.atom_subset is not None else None
 
+    def _device_workspace(self, n: int, dev, fl):
+        """The device loop's arrays that do not depend on a context's contents: configurations, candidates, energy
+        partials, key table with its pinned staging, logs and the inner list's workspace.  Kept on the move, keyed by
+        the force list's geometry: a trial that trips the skin check opens a new context (``_device_context``), and with
+        a narrow skin that is every few trials -- a pinned host allocation (``hipHostMalloc``) and nine device
+        allocations per rebuild otherwise.  The previous context's launches have finished by then (the chunk's state
+        is read on the host before anything else happens)."""
+        key = (n, str(dev), fl.g, fl.chunks, tuple(fl.fl.shape), self._DEVICE_CHUNK)
+        ws = self._dev_ws
+        if ws is not None and ws["key"] == key:
+            return ws
+        rows = self._DEVICE_CHUNK + 1
+        ws = {"key": key}
+        ws["cur4"] = torch.empty((2, 2, n, 4), dtype=torch.float32, device=dev)
+        ws["prop4"] = torch.empty((2, 2, n, 4), dtype=torch.float32, device=dev)
+        ws["ws"] = torch.empty((2 * int(_lib.load().chx_lj_ws_count(n)),), dtype=torch.float64, device=dev)
+        # the chunk's key chain is worked out on the host by chx_mc_displace_chunk (the chain does not depend on decisions):
+        # device table, pinned staging, and the chain key before every trial of the chunk for the host's own use
+        ws["keytab"] = torch.empty((rows, 4), dtype=torch.int32, device=dev)
+        ws["keytab_h"] = torch.empty((rows, 4), dtype=torch.int32, pin_memory=True)
+        ws["chain"] = np.zeros((rows, 2), dtype=np.uint32)
+        ws["state"] = torch.zeros((_lib.MC_STATE_WORDS,), dtype=torch.int32, device=dev)
+        ws["energy"] = torch.zeros((4,), dtype=torch.float64, device=dev)
+        ws["accept_log"] = torch.zeros((self._DEVICE_CHUNK,), dtype=torch.int32, device=dev)
+        ws["energy_log"] = torch.zeros((self._DEVICE_CHUNK,), dtype=torch.float32, device=dev)
+        # inner list of the trial launches (include/chx.h: chx_mc_t::fli): workspace only, the kernels fill it; the
+        # lane lengths start at zero so that no launch can ever walk a length nobody wrote
+        if 2 * fl.chunks < 32768:
+            ws["fli"] = torch.zeros_like(fl.fl)
+            ws["cnti"] = torch.zeros((n, fl.g), dtype=torch.int32, device=dev)
+            ws["refi4"] = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+        self._dev_ws = ws
+        return ws
+
+    def __getstate__(self):
+        # (copies and pickles of a move do not share or duplicate the device workspace)
+        d = dict(self.__dict__)
+        d["_dev_ws"] = None
+        return d
+
     def _device_context(self, sampler_state, thermodynamic_state, nbr_list, energy: float, trial: int = 0):
         """Pack the configuration into the force list's internal order and fill ``chx_mc_t``; ``trial`` = index of
         the first trial the device loop will run from this context."""
@@ -295,20 +337,14 @@ class MonteCarloDisplacementMove(MCMove):
         dev = sampler_state.positions.device
         n = sampler_state.number_of_particles
         key = sampler_state._current_PRNG_key
+        ws = self._device_workspace(n, dev, fl)
         ctx = {"fl": fl, "nbr_list": nbr_list}
+        for name in ("cur4", "prop4", "ws", "keytab", "keytab_h", "chain", "state", "energy", "accept_log", "energy_log"):
+            ctx[name] = ws[name]
         # configurations and proposal candidates, (parity, copy, n, 4) each (include/chx.h: chx_mc_t): the chain enters at
         # trial `trial`, so the current configuration goes into copy 0 of parity trial & 1
-        ctx["cur4"] = torch.empty((2, 2, n, 4), dtype=torch.float32, device=dev)
-        ctx["prop4"] = torch.empty((2, 2, n, 4), dtype=torch.float32, device=dev)
         ctx["cur4"][trial & 1, 0].copy_(fl.pack(sampler_state.positions, 4))
         ctx["ref4"] = fl.pack(nbr_list.ref_positions, 4)
-        ctx["ws"] = torch.empty((2 * int(_lib.load().chx_lj_ws_count(n)),), dtype=torch.float64, device=dev)
-        # the chunk's key chain is worked out on the host by chx_mc_displace_chunk (the chain does not depend on decisions):
-        # device table, pinned staging, and the chain key before every trial of the chunk for the host's own use
-        rows = self._DEVICE_CHUNK + 1
-        ctx["keytab"] = torch.empty((rows, 4), dtype=torch.int32, device=dev)
-        ctx["keytab_h"] = torch.empty((rows, 4), dtype=torch.int32, pin_memory=True)
-        ctx["chain"] = np.zeros((rows, 2), dtype=np.uint32)
         ctx["key"] = (int(key[0]) & 0xFFFFFFFF, int(key[1]) & 0xFFFFFFFF)
         # two state slots that take turns by trial parity (include/chx.h: chx_mc_displace_chunk): the chain enters the
         # device loop at trial `trial`, so its state goes into slot trial & 1; the halt word is shared (slot 0)
@@ -316,10 +352,8 @@ class MonteCarloDisplacementMove(MCMove):
         st = np.zeros(_lib.MC_STATE_WORDS, dtype=np.uint32)
         st[_lib.MC_HALT] = 0x7FFFFFFF
         st[slot + _lib.MC_KEY0], st[slot + _lib.MC_KEY1] = key[0], key[1]
-        ctx["state"] = torch.from_numpy(st.view(np.int32)).to(dev)
-        ctx["energy"] = torch.from_numpy(np.array([energy, energy, energy, energy], dtype=np.float64)).to(dev)
-        ctx["accept_log"] = torch.zeros((self._DEVICE_CHUNK,), dtype=torch.int32, device=dev)
-        ctx["energy_log"] = torch.zeros((self._DEVICE_CHUNK,), dtype=torch.float32, device=dev)
+        ctx["state"].copy_(torch.from_numpy(st.view(np.int32)))
+        ctx["energy"].copy_(torch.from_numpy(np.array([energy, energy, energy, energy], dtype=np.float64)))
         mask = self._subset_mask(sampler_state)
         if thermodynamic_state.beta is None:
             thermodynamic_state.beta = 1.0 / (unit.BOLTZMANN_CONSTANT_kB * (thermodynamic_state.temperature * unit.kelvin))
@@ -339,11 +373,8 @@ class MonteCarloDisplacementMove(MCMove):
         p.ws = ctx["ws"].data_ptr()
         p.keytab, p.keytab_h = ctx["keytab"].data_ptr(), ctx["keytab_h"].data_ptr()
         p.chain_out_h = ctx["chain"].ctypes.data
-        # inner list of the trial launches (include/chx.h: chx_mc_t::fli): workspace only, the kernels fill it
-        if _MC_INNER_SKIN > 0.0 and 2 * fl.chunks < 32768:
-            ctx["fli"] = torch.empty_like(fl.fl)
-            ctx["cnti"] = torch.empty((n, fl.g), dtype=torch.int32, device=dev)
-            ctx["refi4"] = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        if _MC_INNER_SKIN > 0.0 and "fli" in ws:
+            ctx["fli"], ctx["cnti"], ctx["refi4"] = ws["fli"], ws["cnti"], ws["refi4"]
             p.fli, p.cnti, p.refi4 = ctx["fli"].data_ptr(), ctx["cnti"].data_ptr(), ctx["refi4"].data_ptr()
             p.inner_skin = _MC_INNER_SKIN
         ctx["params"] = p
@@ -388,7 +419,7 @@ class MonteCarloDisplacementMove(MCMove):
             ctx["params"].k0, ctx["params"].k1 = ctx["key"]  # chain key before trial i
             ops.mc_displace_chunk(ctx["params"], i, m)
             st = ctx["state"].cpu().numpy()  # waits for the chunk
-            self.inner_list_refreshes = getattr(self, "inner_list_refreshes", 0) + int(st[_lib.MC_REFRESHES]) - ctx.get("refreshes", 0)
+            self.inner_list_refreshes += int(st[_lib.MC_REFRESHES]) - ctx.get("refreshes", 0)
             ctx["refreshes"] = int(st[_lib.MC_REFRESHES])
             halt = int(st[_lib.MC_HALT])
             halted = halt < i + m

@@ -544,7 +544,8 @@ int chx_metropolis_select(float* x_cur, const float* x_prop, int64_t count,
  * cur4 and prop4 are (2, 2, n, 4) floats each: [parity][copy][particle]; launch t reads parity t & 1 and writes the
  * other.  On entry copy state[CHX_MC_CUR] of cur4[trial0 & 1] holds the current configuration (internal order); after
  * the chunk copy state[CHX_MC_CUR] (of slot T & 1) of cur4[T & 1] does, T = the halt trial if the chunk halted, else
- * trial0 + n_trials.  state[CHX_MC_REFRESH] (slot 0) belongs to the kernels (inner list, chx_mc_t::fli).
+ * trial0 + n_trials.  state[CHX_MC_REFRESH] of BOTH slots belongs to the kernels (inner list, chx_mc_t::fli: launch t
+ * reads the word of slot t & 1 and books the next refresh into the other slot's, like every other state word).
  * When the skin check fires in trial t the launch stores t in state[CHX_MC_HALT] and every launch of trial > t is a
  * no-op (trial t is never decided): the caller runs that trial through the rebuild path and resumes.  state is
  * CHX_MC_STATE_WORDS ints: TWO slots of CHX_MC_SLOT_WORDS words (indices below, slot s at offset
@@ -560,7 +561,7 @@ int chx_metropolis_select(float* x_cur, const float* x_prop, int64_t count,
 #define CHX_MC_HALT 3      /* first trial whose proposal violated the skin; INT32_MAX when clear */
 #define CHX_MC_KEY0 4      /* PRNG chain key */
 #define CHX_MC_KEY1 5
-#define CHX_MC_REFRESH 6   /* slot 0 only: the trial whose launch renews the inner list (chx_mc_t::fli) */
+#define CHX_MC_REFRESH 6   /* slot t & 1: == t when the launch of trial t renews the inner list (chx_mc_t::fli) */
 #define CHX_MC_REFRESHES 7 /* slot 0 only: launches that have renewed it so far (statistics) */
 #define CHX_MC_SLOT_WORDS 8
 #define CHX_MC_STATE_WORDS 16

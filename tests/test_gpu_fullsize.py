@@ -280,6 +280,59 @@ def test_c3_mc_device_loop_equals_host_loop(ca, O, monkeypatch):
     assert not np.array_equal(res[0][3], O.lj_lattice(N3, 0.1, SIGMA, seed=1234)[0])  # at least one rebuild happened
 
 
+@pytest.mark.parametrize("subset", [False, True], ids=["all-particles", "atom-subset"])
+def test_c4_mc_inner_list_on_a_grid_that_is_not_co_resident(ca, O, monkeypatch, subset):
+    """Round-4 review (high): the trial launch tested the refresh word that its own tail books the NEXT refresh into.
+    On a grid that is not co-resident -- N = 262,144 with four lanes per particle = 4096 workgroups, twice what the chip
+    holds -- the last workgroups of a refreshing launch start after the first have booked trial + 1, skip the refresh
+    and walk inner-list rows nobody has written for this list.  The booking fires whenever consecutive displacements
+    differ by more than inner skin / 2 = 0.05 nm: sigma_d = 0.03 nm does that in every trial.  Now launch t reads the
+    word of slot t & 1 and books into the other one.  Energies (every report), decisions, key chain and positions must
+    be those of the loop without an inner list, bit for bit.  (The round-4 binary also passes this test on the MI355X:
+    the word is read with a scalar load, and the scalar cache of a CU kept serving the value its first workgroup had
+    fetched -- an accident of the cache, not a guarantee, so the test guards the configuration, it does not reproduce
+    the fault.)"""
+    u = ca.unit
+    monkeypatch.setenv("CHX_FL_G", "4")
+    monkeypatch.setenv("CHX_MC_HOST_LOOP", "0")
+    x, box = O.lj_lattice(N4, 0.1, SIGMA, seed=1234)
+    pot = _pot(ca, N4)
+    thermo = ca.states.ThermodynamicState(pot, temperature=300 * u.kelvin)
+    ids = [int(i) for i in np.random.default_rng(5).choice(N4, 3000, replace=False)] if subset else None
+    runs = {}
+    for tag, s_in in (("off", 0.0), ("on", 0.1)):
+        monkeypatch.setattr(ca.mcmc, "_MC_INNER_SKIN", s_in)
+        ca.utils.PRNG.set_seed(1234)
+        state = ca.states.SamplerState(u.Quantity(x, u.nanometer), ca.utils.PRNG.get_random_key(),
+                                       box_vectors=u.Quantity(box, u.nanometer))
+        nbr = _nbr(ca)
+        nbr.build_from_state(state)
+        assert nbr.force_list.g == 4
+        from chiron_amd.reporters import MCReporter
+
+        rep = MCReporter("mc_c4_inner", 1)
+        move = ca.mcmc.MonteCarloDisplacementMove(displacement_sigma=(0.05 if subset else 0.03) * u.nanometer,
+                                                  number_of_moves=48, atom_subset=ids, reporter=rep, report_interval=1)
+        assert move._device_loop_applies(state, thermo, nbr)
+        s2, _, n2 = move.update(state, thermo, nbr)
+        runs[tag] = dict(x=s2.positions.cpu().numpy(), key=tuple(s2._current_PRNG_key), stats=dict(move.statistics),
+                         e=np.asarray(rep.get_property("potential_energy"), dtype=np.float64),
+                         # (current and PROPOSED energy of the last two trials: with every proposal rejected the
+                         # reports alone would repeat the starting energy whatever the launches summed)
+                         e_last=move._dev_ws["energy"].cpu().numpy().copy(),
+                         refreshes=move.inner_list_refreshes)
+    on, off = runs["on"], runs["off"]
+    assert off["refreshes"] == 0 and on["refreshes"] >= 24, on["refreshes"]  # (the booking fires in most trials)
+    assert len(off["e"]) == 48 and np.array_equal(on["e"], off["e"])
+    assert np.array_equal(on["e_last"], off["e_last"]) and np.isfinite(off["e_last"]).all()
+    if not subset:  # (every all-particle proposal of this size is rejected: the proposed energy is the only witness)
+        assert off["stats"]["n_accepted"] == 0 and off["e_last"][1] != off["e_last"][0] and off["e_last"][3] != off["e_last"][2]
+    assert on["stats"] == off["stats"] and on["key"] == off["key"]
+    assert np.array_equal(on["x"], off["x"])
+    if subset:
+        assert 0 < off["stats"]["n_accepted"]
+
+
 @pytest.mark.parametrize("n", [N3, N4], ids=["c3-32768", "c4-262144"])
 def test_step_kernel_step_63_matches_oracle_at_full_size(ca, O, CO, n):
     """The fused step kernel (k_lj_step, steady-state instantiation, pruned inner list, device Philox) at the
