@@ -930,6 +930,14 @@ def main():
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "RANK" not in os.environ and args.gpus > 1:
+        if under_a_profiler():
+            # (the tool library the profiler preloads has already initialised the GPU in THIS process: it must not become
+            # a launcher that starts child interpreters -- see under_a_profiler.  Round-4 review)
+            print("bench.py: --gpus N > 1 under a profiler: this process has the GPU initialised by the tool's preloaded "
+                  "library and may not start the ranks.  Profile one rank (`rocprofv3 ... -- python3 bench.py --gpus 1`), or "
+                  "start the ranks with an outer launcher (torch.distributed.run) and put the profiler inside it.",
+                  file=sys.stderr, flush=True)
+            raise SystemExit(2)
         # started by hand: become the launcher BEFORE anything can touch the GPU
         raise SystemExit(launch_ranks(args))
     if ("RANK" not in os.environ and args.gpus == 1 and args.requalify and os.environ.get("CHX_BENCH_CHILD") != "1"

@@ -33,32 +33,36 @@ STREAM_UNIFORM = 3
 STREAM_SPLIT = 0x5EED
 
 
-_fast = None  # (callable, output array type) once libchx is loaded: chx_philox4x32_h, 1 us instead of 7
+_fast = None  # (callable, output array type) once libchx HAS BEEN loaded by someone else: chx_philox4x32_h, 1 us instead of 7
 
 
 def _bind_fast():
     """The library's host Philox (include/chx.h: chx_philox4x32_h) in place of the Python loop below: key handling
-    (split / fold_in / uniform) sits on the entry and exit path of every short run() call.  Same bits (tested)."""
+    (split / fold_in / uniform) sits on the entry and exit path of every short run() call.  Same bits (tested).
+
+    Key handling is host arithmetic and must stay free of side effects: it never LOADS the library itself (loading
+    shares torch's HIP runtime and initialises the device context -- a launcher or a parent process that only hands
+    out keys must not have touched the GPU before it starts its ranks; round-4 review).  It binds to a library the
+    process has already loaded for its kernels, and until then -- or if that load failed -- every call uses the
+    pure-Python rounds, which are the definition anyway; nothing is latched, the next call looks again."""
     global _fast
     import ctypes
 
     from . import _lib
 
-    try:
-        fn = _lib.load().chx_philox4x32_h
-    except Exception:  # (no library: the pure-Python rounds below are the definition anyway)
-        _fast = False
-        return
+    lib = _lib._lib
+    if lib is None:
+        return None
     # (no shared output buffer: ctypes releases the GIL for the call, and MultiStateSampler(concurrent_replicas > 1) splits
     # keys from two threads at once -- a buffer kept here handed one thread the other's words, found in round 4)
-    _fast = (fn, ctypes.c_uint32 * 4)
+    _fast = (lib.chx_philox4x32_h, ctypes.c_uint32 * 4)
+    return _fast
 
 
 def philox4x32(counter: Tuple[int, int, int, int], key: Tuple[int, int]) -> Tuple[int, int, int, int]:
-    if _fast is None:
-        _bind_fast()
-    if _fast:
-        fn, out_t = _fast
+    fast = _fast or _bind_fast()
+    if fast:
+        fn, out_t = fast
         out = out_t()
         fn(int(counter[0]) & _MASK, int(counter[1]) & _MASK, int(counter[2]) & _MASK, int(counter[3]) & _MASK,
            int(key[0]) & _MASK, int(key[1]) & _MASK, out)

@@ -7,6 +7,8 @@ the PRNG key is a Philox key pair (see ``chiron_amd.rng``).
 """
 from __future__ import annotations
 
+import threading
+
 from typing import List, Optional, Union
 
 import numpy as np
@@ -113,21 +115,35 @@ class SamplerState:
         return new
 
     _BOX_POOL = 32
+    _box_pool_lock = threading.Lock()
 
     def _box_copy(self):
         """A private copy of the box values for a state that is about to be returned (chiron/integrators.py:210: the
         reference deep-copies the state).  Copies are made 32 at a time -- one small launch fills a pool of independent
         3x3 blocks, and the states of one trajectory (they share the pool through ``_copy_with``) take one each: a clone
         per ``run()`` put a copy kernel into every call's dependent launch chain (2-5 us of a 230 us run(20), measured
-        in round 4).  A new box (the setter renews ``_box_token``) starts a new pool."""
+        in round 4).  A new box (the setter renews ``_box_token``) starts a new pool, and so does a box that was edited
+        IN PLACE since the pool was filled (``state.box_vectors.mul_(s)``: the property hands out the tensor itself):
+        the pool remembers the version counter of the tensor it was filled from and its own -- a state's box is either
+        that tensor or a block of the pool, and an in-place write to either moves the counter -- so the copy always
+        carries the values the state holds NOW, as ``clone()`` did (round-4 review).  The blocks are dealt under a lock
+        (concurrent replicas derive their states from one pool)."""
         if self._box_vectors is None:
             return None
         box = self._box_vectors._value
-        pool = self.__dict__.get("_box_pool")
-        if pool is None or pool[0] is not self._box_token or pool[2] >= self._BOX_POOL:
-            pool = self.__dict__["_box_pool"] = [self._box_token, box.unsqueeze(0).repeat(self._BOX_POOL, 1, 1), 0]
-        out = pool[1][pool[2]]
-        pool[2] += 1
+        with SamplerState._box_pool_lock:
+            pool = self.__dict__.get("_box_pool")
+            fresh = pool is not None and pool[0] is self._box_token and pool[2] < self._BOX_POOL
+            if fresh:
+                if box is pool[3]:
+                    fresh = box._version == pool[4]
+                else:  # a block of the pool (a view of it shares its version counter), or a tensor from elsewhere
+                    fresh = box._base is pool[1] and pool[1]._version == pool[5]
+            if not fresh:
+                filled = box.unsqueeze(0).repeat(self._BOX_POOL, 1, 1)
+                pool = self.__dict__["_box_pool"] = [self._box_token, filled, 0, box, box._version, filled._version]
+            out = pool[1][pool[2]]
+            pool[2] += 1
         return unit.Quantity(out, self._box_vectors.unit)
 
     def _velocity_unit(self):

@@ -379,3 +379,21 @@ def test_gathered_energies_are_fp64_exact():
     assert got.dtype == np.float64 and got[0] == v
     e32 = np.float32(-7720.9896)
     assert rex.gather_energies(torch.tensor([e32], dtype=torch.float32))[0] == float(e32)
+
+
+def test_bench_refuses_to_become_a_multi_rank_launcher_under_a_profiler():
+    """Round-4 review: `rocprofv3 ... -- python3 bench.py --gpus N` (N > 1, no RANK) used to turn the profiled process --
+    whose GPU the tool's preloaded library has already initialised -- into a launcher that starts N child interpreters.
+    It must exit non-zero with advice instead, without starting anything (also for the CPU rehearsal mode)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["ROCPROFILER_REGISTER_FORCE_LOAD"] = "1"  # (what a rocprofv3-started process finds in its environment)
+    for extra in ([], ["--dry-run-backend", "gloo"]):
+        out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1"] + extra, cwd=root,
+                             env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 2, (out.returncode, out.stderr[-1500:])
+        assert "under a profiler" in out.stderr and "launcher" in out.stderr
+        assert out.stdout.strip() == ""  # no rank ran, no JSON line

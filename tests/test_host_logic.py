@@ -97,16 +97,43 @@ def test_prng_keys():
 def test_host_philox_c_helper_and_python_rounds_agree():
     """chiron_amd.rng.philox4x32 goes through the library's host helper (include/chx.h: chx_philox4x32_h) once it is
     loaded; the Python rounds stay the definition.  Same bits on the Random123 vectors and on random blocks."""
-    from chiron_amd import rng
+    from chiron_amd import _lib, rng
 
+    _lib.load()  # (rng never loads the library itself: it binds to one the process has loaded for its kernels)
     rng.philox4x32((0, 0, 0, 0), (0, 0))
-    assert rng._fast, "libchx is built in this tree: the C helper must have been bound"
+    assert rng._fast, "libchx is loaded: the C helper must have been bound"
     r = np.random.default_rng(3)
     for _ in range(500):
         c = tuple(int(v) for v in r.integers(0, 2**32, 4))
         k = tuple(int(v) for v in r.integers(0, 2**32, 2))
         assert rng.philox4x32(c, k) == rng.philox4x32_py(c, k)
     assert rng.philox4x32_py((0xFFFFFFFF,) * 4, (0xFFFFFFFF, 0xFFFFFFFF)) == (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)
+
+
+def test_key_handling_alone_neither_loads_the_library_nor_touches_the_gpu():
+    """Round-4 review: the first split / fold_in / PRNG.get_random_key of a process used to load libchx -- and with it
+    share torch's HIP runtime and initialise the device context -- as a hidden side effect.  A launcher that only
+    hands out keys must stay clear of the GPU.  In a fresh interpreter: key handling leaves chiron_amd._lib unloaded
+    and torch.cuda uninitialised, uses the Python rounds, and binds the C helper once something else has loaded the
+    library (nothing is latched)."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, torch\n"
+        "from chiron_amd import _lib, rng\n"
+        "from chiron_amd.utils import PRNG\n"
+        "PRNG.set_seed(1234); k = PRNG.get_random_key(); a = rng.split(k); b = rng.fold_in(k, 3); u = rng.uniform(k)\n"
+        "assert _lib._lib is None and not rng._fast, 'key handling loaded the library'\n"
+        "assert not torch.cuda.is_initialized(), 'key handling initialised the GPU'\n"
+        "assert 'libchx' not in open('/proc/self/maps').read()\n"
+        "_lib.load(); a2 = rng.split(k)\n"
+        "assert rng._fast and a2 == a and rng.fold_in(k, 3) == b and rng.uniform(k) == u\n"
+        "print('ok')\n"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
 
 
 def test_mc_key_chain_helper_matches_the_host_key_handling():
@@ -921,6 +948,19 @@ def test_sampler_state_box_copies_come_from_a_pool_and_stay_independent():
     assert "_box_pool" not in d.__dict__ and torch.equal(d.box_vectors, t.box_vectors)
     s.box_vectors = np.eye(3, dtype=np.float32) * 5.0
     assert float(s._box_copy()._value[0, 0]) == 5.0
+    # in-place edits of a state's box (the property hands out the tensor itself) are carried into the next copy, as
+    # with the clone() the pool replaced -- whether the state holds the tensor the pool was filled from or one of the
+    # pool's own blocks -- and an edit of one state's block does not leak into its siblings (round-4 review)
+    r1 = s._copy_with(torch.zeros(4, 3), torch.zeros(4, 3))
+    r2 = r1._copy_with(torch.zeros(4, 3), torch.zeros(4, 3))
+    r1.box_vectors.mul_(2.0)  # a block of the pool
+    r3 = r1._copy_with(torch.zeros(4, 3), torch.zeros(4, 3))
+    assert float(r3.box_vectors[0, 0]) == 10.0 and float(r2.box_vectors[0, 0]) == 5.0
+    r4 = r2._copy_with(torch.zeros(4, 3), torch.zeros(4, 3))
+    assert float(r4.box_vectors[0, 0]) == 5.0 and r4.box_vectors.data_ptr() != r2.box_vectors.data_ptr()
+    s.box_vectors[0, 0] = 7.0  # the tensor the first pool was filled from
+    assert float(s._copy_with(torch.zeros(4, 3), torch.zeros(4, 3)).box_vectors[0, 0]) == 7.0
+    assert float(r4._copy_with(torch.zeros(4, 3), torch.zeros(4, 3)).box_vectors[0, 0]) == 5.0
 
 
 def test_host_philox_is_safe_to_call_from_several_threads():
@@ -929,8 +969,9 @@ def test_host_philox_is_safe_to_call_from_several_threads():
     replicas at once; with a shared buffer one replica occasionally got the other's key -- round 4)."""
     import threading
 
-    from chiron_amd import rng
+    from chiron_amd import _lib, rng
 
+    _lib.load()
     want = {k: rng.philox4x32_py((k, 1, 2, 3), (k, 7)) for k in range(64)}
     assert rng.philox4x32((5, 1, 2, 3), (5, 7)) == want[5]
     assert rng._fast  # (the library's helper is what the threads below race on)
