@@ -195,6 +195,9 @@ SIGNATURES = {
     "chx_langevin_fused_run": (C.c_int, [C.POINTER(LangevinParams), _P, _P, _I64, _I32, _I32, _I32, C.POINTER(C.c_int32), _P]),
     "chx_set_poll_sleep_ns": (_I64, [_I64]),
     "chx_poll_stats": (C.c_int, [C.POINTER(_I64), _I32]),
+    "chx_steps_join": (C.c_int, [_P]),
+    "chx_step_queue_info": (C.c_int, [C.POINTER(_I64), _P]),
+    "chx_step_queue_status": (C.c_char_p, []),
     "chx_ctrl_reset": (C.c_int, [_P, _P]),
     "chx_publish": (C.c_int, [_P, _P, _I32, _P]),
     "chx_mc_displace": (C.c_int, [_P, _P, _P, _I32, _F, Box, _U32, _U32, _U32, _P, _P]),
@@ -212,7 +215,7 @@ SIGNATURES = {
     ),
 }
 
-ABI_VERSION = 3  # include/chx.h: CHX_ABI_VERSION (history there)
+ABI_VERSION = 4  # include/chx.h: CHX_ABI_VERSION (history there)
 
 _lib: Optional[C.CDLL] = None
 

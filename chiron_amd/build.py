@@ -16,6 +16,10 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libchx.so")
+# the step kernels once more as a bare code object: what the step queue (csrc/chx_aql.hip) loads through the HSA runtime
+# and dispatches with its own AQL packets -- the device half of STEP_UNIT compiled by itself, same flags, same ISA
+STEP_UNIT = "chx_lj.hip"
+STEP_OUT = os.path.join(HERE, "libchx_step.hsaco")
 
 # -ffp-contract=off: the neighbor predicates and the BAOAB update must round once
 # per operation, like the reference's un-fused fp32 ops.
@@ -63,8 +67,17 @@ def binary_hash(path: str = OUT):
     return m.group(1).decode() if m else None
 
 
+def step_object_current() -> bool:
+    """libchx_step.hsaco carries no hash of its own: a stamp file beside it names the tree it was made from."""
+    try:
+        with open(STEP_OUT + ".hash") as fh:
+            return fh.read().strip() == source_hash() and os.path.exists(STEP_OUT)
+    except OSError:
+        return False
+
+
 def needs_build() -> bool:
-    return binary_hash() != source_hash()
+    return binary_hash() != source_hash() or not step_object_current()
 
 
 def _object_key(src: str, flags) -> str:
@@ -126,8 +139,24 @@ def _build_locked(hipcc: str, objdir: str, force: bool, verbose: bool) -> str:
             os.replace(obj + tag, obj)
         return obj
 
+    def compile_step_object(src):
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + "." + _object_key(src, cflags) + ".hsaco")
+        if force or not os.path.exists(obj):
+            cmd = [hipcc] + [f for f in cflags if f != "-fPIC"] + ["--cuda-device-only", "--no-gpu-bundle-output", src, "-o", obj + tag]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+            os.replace(obj + tag, obj)
+        return obj
+
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as pool:
+        step_job = pool.submit(compile_step_object, os.path.join(CSRC, STEP_UNIT))
         objs = list(pool.map(compile_one, sources()))
+        step_obj = step_job.result()
+    for stale in set(glob.glob(os.path.join(objdir, "*.hsaco"))) - {step_obj}:
+        os.remove(stale)
+    shutil.copyfile(step_obj, STEP_OUT + tag)
+    os.replace(STEP_OUT + tag, STEP_OUT)
     for stale in set(glob.glob(os.path.join(objdir, "*.o"))) - set(objs):  # (under the lock: nobody is about to link them)
         os.remove(stale)
     tmp = OUT + tag
@@ -138,4 +167,7 @@ def _build_locked(hipcc: str, objdir: str, force: bool, verbose: bool) -> str:
     os.replace(tmp, OUT)  # never truncate a library some process may have mapped
     if binary_hash(OUT) != tree:
         raise RuntimeError("libchx.so does not carry the hash of the tree it was built from")
+    with open(STEP_OUT + ".hash" + tag, "w") as fh:
+        fh.write(tree + "\n")
+    os.replace(STEP_OUT + ".hash" + tag, STEP_OUT + ".hash")
     return OUT

@@ -1,0 +1,27 @@
+// libchx: the step queue -- fused step launches dispatched as hand-written AQL packets on a private HSA queue
+// (chx_aql.hip).  Internal, not exported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct AqlKernel {
+  uint64_t object;  // kernel descriptor address in the loaded code object
+  uint32_t kernarg_size, group_size, private_size;
+};
+
+// true once the step queue is usable in this process (CHX_AQL=0 turns it off; a failed initialisation turns it off
+// for good and the launches go through hipLaunchKernelGGL as before)
+bool chx_aql_on();
+// the kernel whose demangled name starts with `prefix` ("void k_lj_step<4, true, false, false>"), or NULL
+const AqlKernel* chx_aql_kernel(const char* prefix);
+// release fence of a steady-state step launch whose outputs all leave as write-through stores: 0 = none, 1 = agent
+int chx_aql_hot_release();
+// One kernel dispatch packet behind everything enqueued so far on `st` (HIP launches included: the first packet after
+// a join waits for a marker launched on `st`) and on the step queue paired with it.  `release_agent`: the packet ends with
+// an agent-scope release (a launch that leaves plain stores behind); otherwise with the scope chx_aql_hot_release() names.
+int chx_aql_dispatch(hipStream_t st, const AqlKernel* k, unsigned blocks, const void* kernarg, size_t nbytes, bool release_agent);
+// Host wait until every packet dispatched for `st` has completed (no-op when none is outstanding).  Called by every
+// libchx entry point before it launches on `st` (chx_stream) and by the Python layer where it used to wait for the stream.
+void chx_aql_join(hipStream_t st);
+// number of step queues with packets outstanding (fast path of chx_stream)
+extern int chx_aql_open_count;

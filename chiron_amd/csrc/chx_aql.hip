@@ -1,0 +1,429 @@
+// libchx: the step queue.  The fused step kernels (k_lj_step, k_ap_step) are dispatched as hand-written AQL kernel
+// dispatch packets on a private user-mode HSA queue instead of through hipLaunchKernelGGL.
+//
+// Why (round 5, scripts/ub/aql_probe.hip, profiles/r05_aql_probe.md):
+//   * the host side of a dispatch is a 320-byte copy, a 64-byte packet and a doorbell write -- 0.02-1 us against the
+//     2.5 us of a HIP launch (5+ us in the HIP runtime's slow launch regime, profiles/r03_launch_regime.md, which then
+//     starves a 5 us step kernel): the device's rate no longer depends on the launching thread;
+//   * the packet header carries the fence scopes.  HIP gives every kernel agent-scope acquire + release fences; a
+//     steady-state step launch needs neither: its outputs leave as write-through (sc1) stores, and the hardware
+//     invalidates the vector L1 and the scalar cache at every dispatch whatever the acquire scope says (measured: 3000
+//     rewrite / re-read rounds over every CU, not one stale word with acquire = release = NONE and write-through
+//     stores; with plain stores and no release every word is stale -- the test has teeth).  Without the two cache
+//     operations a dependent launch boundary is 0.25 us shorter.  CHX_AQL_FENCE=agent keeps HIP's scopes.
+//
+// Ordering with the HIP stream the rest of libchx (and torch) launches on -- the Python layer thinks in ONE stream:
+//   HIP -> queue: the first packet after a join is preceded by a barrier-AND packet on a gate signal, and a one-thread
+//                 marker kernel launched on the HIP stream opens the gate: the packets run behind everything that was
+//                 enqueued on the stream before them;
+//   queue -> HIP: chx_aql_join() -- a barrier packet with a completion signal, and the host waits for it.  Every libchx
+//                 entry point joins before it launches on a stream (chx_stream), and the Python layer joins where it
+//                 used to wait for the stream.
+// The kernels come from libchx_step.hsaco, the device half of chx_lj.hip compiled on its own (chiron_amd/build.py): same
+// source, same flags, same ISA as the copies inside libchx.so.  The HSA runtime is the instance the process's HIP runtime
+// already uses (found through the loaded libamdhip64's directory, bound with dlsym: no second runtime, no link-time
+// dependency).
+#include <cxxabi.h>
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <hsa/amd_hsa_signal.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+#include <link.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "chx_aql.h"
+#include "chx_common.h"
+
+int chx_aql_open_count = 0;
+
+namespace {
+
+// ---- the HSA entry points, bound at run time ----
+#define CHX_HSA_FUNCS(X)                                                                                           \
+  X(hsa_init) X(hsa_shut_down) X(hsa_iterate_agents) X(hsa_agent_get_info) X(hsa_queue_create) X(hsa_queue_destroy)  \
+  X(hsa_queue_add_write_index_relaxed) X(hsa_queue_load_read_index_scacquire) X(hsa_signal_create)                   \
+  X(hsa_signal_store_relaxed) X(hsa_signal_store_screlease) X(hsa_signal_load_scacquire)                             \
+  X(hsa_signal_wait_scacquire) X(hsa_code_object_reader_create_from_file) X(hsa_executable_create_alt)              \
+  X(hsa_executable_load_agent_code_object) X(hsa_executable_freeze) X(hsa_executable_iterate_agent_symbols)         \
+  X(hsa_executable_symbol_get_info) X(hsa_amd_agent_iterate_memory_pools) X(hsa_amd_memory_pool_get_info)           \
+  X(hsa_amd_memory_pool_allocate) X(hsa_amd_agents_allow_access) X(hsa_amd_signal_create) X(hsa_status_string)
+struct Hsa {
+#define X(name) decltype(&::name) name = nullptr;
+  CHX_HSA_FUNCS(X)
+#undef X
+};
+Hsa H;
+
+struct LibSearch {
+  std::string dir;
+  std::string found_same_dir, found_any;
+};
+int phdr_cb(struct dl_phdr_info* info, size_t, void* data) {
+  LibSearch* s = static_cast<LibSearch*>(data);
+  if (!info->dlpi_name) return 0;
+  const std::string name = info->dlpi_name;
+  const size_t slash = name.rfind('/');
+  const std::string base = slash == std::string::npos ? name : name.substr(slash + 1);
+  if (base.rfind("libhsa-runtime64.so", 0) != 0) return 0;
+  if (s->found_any.empty()) s->found_any = name;
+  if (slash != std::string::npos && name.substr(0, slash) == s->dir && s->found_same_dir.empty()) s->found_same_dir = name;
+  return 0;
+}
+
+// the HSA runtime the process's HIP runtime is running on
+void* find_hsa() {
+  Dl_info info;
+  LibSearch s;
+  if (dladdr(reinterpret_cast<void*>(&hipGetLastError), &info) && info.dli_fname) {
+    const std::string f = info.dli_fname;
+    const size_t slash = f.rfind('/');
+    if (slash != std::string::npos) s.dir = f.substr(0, slash);
+    char real[4096];
+    if (realpath(s.dir.c_str(), real)) s.dir = real;
+  }
+  dl_iterate_phdr(phdr_cb, &s);
+  // (an object's recorded name may go through a symlinked directory: compare again on real paths)
+  if (s.found_same_dir.empty() && !s.dir.empty()) {
+    for (const char* cand : {"/libhsa-runtime64.so", "/libhsa-runtime64.so.1"}) {
+      void* h = dlopen((s.dir + cand).c_str(), RTLD_NOW | RTLD_NOLOAD);
+      if (h) return h;
+    }
+  }
+  const std::string pick = !s.found_same_dir.empty() ? s.found_same_dir : s.found_any;
+  if (pick.empty()) return nullptr;  // (no HSA runtime resident: the process has not initialised HIP -- not ours to start)
+  return dlopen(pick.c_str(), RTLD_NOW | RTLD_NOLOAD);
+}
+
+struct Gate {
+  hsa_signal_t sig;
+};
+
+struct Queue {
+  hsa_queue_t* q = nullptr;
+  char* ring = nullptr;  // kernarg slots in device memory, written by the host through the BAR
+  bool open = false;     // packets outstanding since the last join
+  hsa_signal_t done{};   // completion signal of the join barrier
+  Gate gates[4];
+  unsigned gate_next = 0;
+  uint64_t n_dispatched = 0, n_joins = 0, n_gates = 0;
+};
+
+constexpr uint32_t QSIZE = 1024;  // packets; the launch window keeps ~a dozen outstanding
+constexpr size_t SLOT = 512;      // bytes per kernarg slot (the step kernel's block: 320)
+
+std::mutex g_mu;
+int g_state = 0;  // 0 untried, 1 on, -1 off
+bool g_fence_none = true;
+hsa_agent_t g_gpu{}, g_cpu{};
+hsa_amd_memory_pool_t g_dev_pool{};
+bool g_have_gpu = false, g_have_cpu = false, g_have_pool = false;
+std::map<std::string, AqlKernel> g_kernels;  // demangled "void k_lj_step<4, true, false, false>" -> descriptor
+std::map<hipStream_t, Queue*> g_queues;
+char g_err[512] = "";
+volatile int g_queue_error = 0;
+
+void fail(const char* what, hsa_status_t s = HSA_STATUS_SUCCESS) {
+  const char* m = nullptr;
+  if (s != HSA_STATUS_SUCCESS && H.hsa_status_string) H.hsa_status_string(s, &m);
+  snprintf(g_err, sizeof(g_err), "step queue: %s%s%s", what, m ? ": " : "", m ? m : "");
+  if (getenv("CHX_AQL_VERBOSE")) fprintf(stderr, "[chx] %s\n", g_err);
+}
+
+struct AgentPick {
+  uint32_t want_bdf;
+  uint32_t want_domain;
+  bool have_want;
+  int n_gpu;
+  hsa_agent_t first_gpu;
+  hsa_agent_t match;
+  bool matched;
+};
+hsa_status_t agent_cb(hsa_agent_t a, void* data) {
+  AgentPick* p = static_cast<AgentPick*>(data);
+  hsa_device_type_t t;
+  if (H.hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+  if (t == HSA_DEVICE_TYPE_CPU && !g_have_cpu) g_cpu = a, g_have_cpu = true;
+  if (t != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
+  if (p->n_gpu++ == 0) p->first_gpu = a;
+  uint32_t bdf = 0, domain = 0;
+  H.hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf);
+  H.hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain);
+  if (p->have_want && !p->matched && bdf == p->want_bdf && domain == p->want_domain) p->match = a, p->matched = true;
+  return HSA_STATUS_SUCCESS;
+}
+hsa_status_t pool_cb(hsa_amd_memory_pool_t pool, void*) {
+  hsa_amd_segment_t seg;
+  H.hsa_amd_memory_pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_SEGMENT, &seg);
+  if (seg != HSA_AMD_SEGMENT_GLOBAL) return HSA_STATUS_SUCCESS;
+  uint32_t flags = 0;
+  bool alloc = false;
+  H.hsa_amd_memory_pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &flags);
+  H.hsa_amd_memory_pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_RUNTIME_ALLOC_ALLOWED, &alloc);
+  if (alloc && (flags & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_COARSE_GRAINED) && !g_have_pool) g_dev_pool = pool, g_have_pool = true;
+  return HSA_STATUS_SUCCESS;
+}
+hsa_status_t sym_cb(hsa_executable_t, hsa_agent_t, hsa_executable_symbol_t s, void*) {
+  hsa_symbol_kind_t kind;
+  H.hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_TYPE, &kind);
+  if (kind != HSA_SYMBOL_KIND_KERNEL) return HSA_STATUS_SUCCESS;
+  uint32_t len = 0;
+  H.hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_NAME_LENGTH, &len);
+  std::string name(len, '\0');
+  H.hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_NAME, &name[0]);
+  if (name.size() > 3 && name.compare(name.size() - 3, 3, ".kd") == 0) name.resize(name.size() - 3);
+  AqlKernel k{};
+  H.hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &k.object);
+  H.hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &k.kernarg_size);
+  H.hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &k.group_size);
+  H.hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &k.private_size);
+  int status = 0;
+  char* dem = abi::__cxa_demangle(name.c_str(), nullptr, nullptr, &status);
+  std::string key = (status == 0 && dem) ? dem : name;
+  free(dem);
+  const size_t paren = key.find('(');
+  if (paren != std::string::npos) key.resize(paren);
+  g_kernels[key] = k;
+  return HSA_STATUS_SUCCESS;
+}
+void queue_error_cb(hsa_status_t s, hsa_queue_t*, void*) {
+  fail("the queue reported an error", s);
+  fprintf(stderr, "[chx] %s\n", g_err);
+  g_queue_error = 1;
+}
+
+std::string own_dir() {
+  Dl_info info;
+  if (!dladdr(reinterpret_cast<void*>(&chx_aql_on), &info) || !info.dli_fname) return ".";
+  const std::string f = info.dli_fname;
+  const size_t slash = f.rfind('/');
+  return slash == std::string::npos ? "." : f.substr(0, slash);
+}
+
+bool init_locked() {
+  const char* e = getenv("CHX_AQL");
+  if (e && e[0] == '0') return fail("off (CHX_AQL=0)"), false;
+  const char* fe = getenv("CHX_AQL_FENCE");
+  g_fence_none = !(fe && (fe[0] == 'a' || fe[0] == 'A'));  // "agent": HIP's scopes on every packet
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fail("no HIP device"), false;
+  void* lib = find_hsa();
+  if (!lib) return fail("the HSA runtime of this process's HIP runtime was not found"), false;
+#define X(name)                                                      \
+  H.name = reinterpret_cast<decltype(H.name)>(dlsym(lib, #name));    \
+  if (!H.name) return fail("missing HSA entry point " #name), false;
+  CHX_HSA_FUNCS(X)
+#undef X
+  hsa_status_t s = H.hsa_init();  // (reference-counted: the runtime is up already)
+  if (s != HSA_STATUS_SUCCESS) return fail("hsa_init", s), false;
+  AgentPick pick{};
+  char bus[64] = "";
+  if (hipDeviceGetPCIBusId(bus, sizeof(bus), dev) == hipSuccess) {
+    unsigned dom = 0, b = 0, d = 0, f = 0;
+    if (sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f) == 4) {
+      pick.have_want = true;
+      pick.want_domain = dom;
+      pick.want_bdf = (b << 8) | (d << 3) | f;
+    }
+  }
+  H.hsa_iterate_agents(agent_cb, &pick);
+  if (pick.matched) g_gpu = pick.match, g_have_gpu = true;
+  else if (pick.n_gpu == 1) g_gpu = pick.first_gpu, g_have_gpu = true;
+  if (!g_have_gpu || !g_have_cpu) return fail("the HIP device was not found among the HSA agents"), false;
+  H.hsa_amd_agent_iterate_memory_pools(g_gpu, pool_cb, nullptr);
+  if (!g_have_pool) return fail("no device memory pool"), false;
+  // the step kernels' code object
+  const std::string path = own_dir() + "/libchx_step.hsaco";
+  const int fd = open(path.c_str(), O_RDONLY);
+  if (fd < 0) return fail("libchx_step.hsaco not found beside libchx.so"), false;
+  hsa_code_object_reader_t reader;
+  s = H.hsa_code_object_reader_create_from_file(fd, &reader);
+  if (s != HSA_STATUS_SUCCESS) return close(fd), fail("code object reader", s), false;
+  hsa_executable_t exe;
+  s = H.hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &exe);
+  if (s == HSA_STATUS_SUCCESS) s = H.hsa_executable_load_agent_code_object(exe, g_gpu, reader, nullptr, nullptr);
+  if (s == HSA_STATUS_SUCCESS) s = H.hsa_executable_freeze(exe, nullptr);
+  if (s != HSA_STATUS_SUCCESS) return close(fd), fail("loading libchx_step.hsaco", s), false;
+  H.hsa_executable_iterate_agent_symbols(exe, g_gpu, sym_cb, nullptr);
+  close(fd);
+  if (g_kernels.empty()) return fail("libchx_step.hsaco holds no kernels"), false;
+  return true;
+}
+
+Queue* queue_for(hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_queues.find(st);
+  if (it != g_queues.end()) return it->second;
+  Queue* Q = new Queue();
+  hsa_status_t s = H.hsa_queue_create(g_gpu, QSIZE, HSA_QUEUE_TYPE_SINGLE, queue_error_cb, nullptr, UINT32_MAX, UINT32_MAX, &Q->q);
+  if (s != HSA_STATUS_SUCCESS) return fail("hsa_queue_create", s), delete Q, nullptr;
+  s = H.hsa_amd_memory_pool_allocate(g_dev_pool, SLOT * QSIZE, 0, reinterpret_cast<void**>(&Q->ring));
+  if (s == HSA_STATUS_SUCCESS) s = H.hsa_amd_agents_allow_access(1, &g_cpu, nullptr, Q->ring);
+  if (s != HSA_STATUS_SUCCESS) return fail("kernarg ring in device memory", s), delete Q, nullptr;
+  s = H.hsa_signal_create(0, 0, nullptr, &Q->done);
+  for (Gate& g : Q->gates)
+    if (s == HSA_STATUS_SUCCESS) s = H.hsa_amd_signal_create(1, 0, nullptr, HSA_AMD_SIGNAL_AMD_GPU_ONLY, &g.sig);
+  if (s != HSA_STATUS_SUCCESS) return fail("signals", s), delete Q, nullptr;
+  g_queues[st] = Q;
+  return Q;
+}
+
+inline void* slot_of(Queue* Q, uint64_t widx) { return reinterpret_cast<char*>(Q->q->base_address) + 64 * (widx % QSIZE); }
+
+uint64_t reserve(Queue* Q) {
+  const uint64_t widx = H.hsa_queue_add_write_index_relaxed(Q->q, 1);
+  while (widx - H.hsa_queue_load_read_index_scacquire(Q->q) >= QSIZE - 1) {
+    if (g_queue_error) break;
+  }
+  return widx;
+}
+inline void publish(Queue* Q, uint64_t widx, uint16_t header) {
+  __atomic_store_n(reinterpret_cast<uint16_t*>(slot_of(Q, widx)), header, __ATOMIC_RELEASE);
+  H.hsa_signal_store_screlease(Q->q->doorbell_signal, (hsa_signal_value_t)widx);
+}
+void push_barrier(Queue* Q, hsa_signal_t dep, hsa_signal_t completion, int acquire, int release) {
+  const uint64_t widx = reserve(Q);
+  hsa_barrier_and_packet_t* pk = static_cast<hsa_barrier_and_packet_t*>(slot_of(Q, widx));
+  pk->reserved0 = 0;
+  pk->reserved1 = 0;
+  for (int i = 0; i < 5; ++i) pk->dep_signal[i] = hsa_signal_t{0};
+  pk->dep_signal[0] = dep;
+  pk->reserved2 = 0;
+  pk->completion_signal = completion;
+  publish(Q, widx, (uint16_t)((HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                              (acquire << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (release << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE)));
+}
+
+}  // namespace
+
+// the marker that opens a gate from the HIP stream: everything enqueued on the stream before it has completed
+__global__ void k_aql_gate_open(long long* value) {
+  __hip_atomic_store(value, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+bool chx_aql_on() {
+  int st = __atomic_load_n(&g_state, __ATOMIC_ACQUIRE);
+  if (st == 0) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_state == 0) __atomic_store_n(&g_state, init_locked() ? 1 : -1, __ATOMIC_RELEASE);
+    st = g_state;
+  }
+  return st == 1 && !g_queue_error;
+}
+
+const AqlKernel* chx_aql_kernel(const char* prefix) {
+  auto it = g_kernels.find(prefix);  // (filled once under the lock in init_locked, read-only afterwards)
+  return it == g_kernels.end() ? nullptr : &it->second;
+}
+
+int chx_aql_hot_release() { return g_fence_none ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT; }
+
+int chx_aql_dispatch(hipStream_t st, const AqlKernel* k, unsigned blocks, const void* kernarg, size_t nbytes, bool release_agent) {
+  if (nbytes > SLOT - 64 || nbytes < k->kernarg_size) {
+    chx_set_error("step queue: argument block of %zu bytes does not fit the kernel's %u", nbytes, k->kernarg_size);
+    return CHX_ERR_INVALID;
+  }
+  Queue* Q = queue_for(st);
+  if (!Q || g_queue_error) {
+    chx_set_error("%s", g_err);
+    return CHX_ERR_LAUNCH;
+  }
+  int acquire = g_fence_none ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT;
+  if (!Q->open) {
+    // first packet since the last join: behind everything the HIP stream holds
+    Gate& g = Q->gates[Q->gate_next++ % 4];
+    H.hsa_signal_store_relaxed(g.sig, 1);
+    long long* value = reinterpret_cast<long long*>(const_cast<int64_t*>(&reinterpret_cast<amd_signal_t*>(g.sig.handle)->value));
+    hipLaunchKernelGGL(k_aql_gate_open, dim3(1), dim3(1), 0, st, value);
+    push_barrier(Q, g.sig, hsa_signal_t{0}, HSA_FENCE_SCOPE_SYSTEM, HSA_FENCE_SCOPE_NONE);
+    Q->open = true;
+    Q->n_gates++;
+    __atomic_fetch_add(&chx_aql_open_count, 1, __ATOMIC_RELAXED);
+    acquire = HSA_FENCE_SCOPE_AGENT;
+  }
+  const uint64_t widx = reserve(Q);
+  // the argument block goes to device memory through the BAR; the read-back of its last word completes the posted
+  // writes before the doorbell can make the packet processor fetch them
+  char* ka = Q->ring + SLOT * (widx % QSIZE);
+  memcpy(ka, kernarg, nbytes);
+  __builtin_ia32_sfence();
+  (void)*reinterpret_cast<volatile uint32_t*>(ka + ((nbytes - 4) & ~(size_t)3));
+  hsa_kernel_dispatch_packet_t* pk = static_cast<hsa_kernel_dispatch_packet_t*>(slot_of(Q, widx));
+  pk->setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
+  pk->workgroup_size_x = 256, pk->workgroup_size_y = 1, pk->workgroup_size_z = 1;
+  pk->reserved0 = 0;
+  pk->grid_size_x = blocks * 256u, pk->grid_size_y = 1, pk->grid_size_z = 1;
+  pk->private_segment_size = k->private_size;
+  pk->group_segment_size = k->group_size;
+  pk->kernel_object = k->object;
+  pk->kernarg_address = ka;
+  pk->reserved2 = 0;
+  pk->completion_signal = hsa_signal_t{0};
+  const int release = release_agent ? HSA_FENCE_SCOPE_AGENT : chx_aql_hot_release();
+  publish(Q, widx, (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                              (acquire << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (release << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE)));
+  Q->n_dispatched++;
+  return CHX_OK;
+}
+
+void chx_aql_join(hipStream_t st) {
+  Queue* Q = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_queues.find(st);
+    if (it != g_queues.end()) Q = it->second;
+  }
+  if (!Q || !Q->open) return;
+  H.hsa_signal_store_relaxed(Q->done, 1);
+  push_barrier(Q, hsa_signal_t{0}, Q->done, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_SYSTEM);
+  timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  while (H.hsa_signal_wait_scacquire(Q->done, HSA_SIGNAL_CONDITION_LT, 1, 1000000ull, HSA_WAIT_STATE_ACTIVE) >= 1) {
+    if (g_queue_error) break;
+    timespec t1;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (t1.tv_sec - t0.tv_sec > 120) {
+      fail("the queue has not drained for 120 s");
+      fprintf(stderr, "[chx] %s\n", g_err);
+      g_queue_error = 1;
+      break;
+    }
+  }
+  Q->open = false;
+  Q->n_joins++;
+  __atomic_fetch_sub(&chx_aql_open_count, 1, __ATOMIC_RELAXED);
+}
+
+// ---- C ABI (include/chx.h) ----
+extern "C" int chx_steps_join(chx_stream_t stream) {
+  if (__atomic_load_n(&chx_aql_open_count, __ATOMIC_RELAXED) > 0) chx_aql_join(reinterpret_cast<hipStream_t>(stream));
+  return g_queue_error ? CHX_ERR_LAUNCH : CHX_OK;
+}
+extern "C" int chx_step_queue_info(int64_t* out8_h, chx_stream_t stream) {
+  const bool on = chx_aql_on();
+  if (out8_h) {
+    for (int i = 0; i < 8; ++i) out8_h[i] = 0;
+    out8_h[0] = on ? 1 : 0;
+    out8_h[1] = on ? (g_fence_none ? 0 : 1) : -1;  // release scope of a steady-state step packet: 0 none, 1 agent
+    out8_h[2] = (int64_t)g_kernels.size();
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_queues.find(reinterpret_cast<hipStream_t>(stream));
+    if (it != g_queues.end()) {
+      out8_h[3] = (int64_t)it->second->n_dispatched;
+      out8_h[4] = (int64_t)it->second->n_joins;
+      out8_h[5] = (int64_t)it->second->n_gates;
+      out8_h[6] = it->second->open ? 1 : 0;
+    }
+  }
+  return CHX_OK;
+}
+extern "C" const char* chx_step_queue_status(void) { return g_err; }

@@ -20,7 +20,17 @@ int chx_check_launch(const char* what);
     }                                      \
   } while (0)
 
-static inline hipStream_t chx_stream(chx_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+// The stream an entry point launches on.  Step launches may be outstanding on the step queue paired with it (chx_aql.h):
+// anything that goes to the HIP stream waits for them first, so that the caller's one-stream picture holds.
+extern int chx_aql_open_count;
+void chx_aql_join(hipStream_t st);
+static inline hipStream_t chx_stream(chx_stream_t s) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  if (__atomic_load_n(&chx_aql_open_count, __ATOMIC_RELAXED) > 0) chx_aql_join(st);
+  return st;
+}
+// (the step launches themselves: they go behind the outstanding ones)
+static inline hipStream_t chx_stream_steps(chx_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // word t of a freshly reset control block (include/chx.h: chx_langevin_t::ctrl, chx_ctrl_reset)
 __host__ __device__ __forceinline__ int chx_ctrl_reset_word(int t) {

@@ -275,6 +275,7 @@ static int debug_check_ref4(const chx_langevin_t* p, hipStream_t st, const char*
   static const bool dbg = getenv("CHX_DEBUG_SYNC") != nullptr;
   if (!dbg || !p->fl || !p->ref4) return CHX_OK;
   float row[4] = {0.f, 0.f, 0.f, 0.f};
+  chx_aql_join(st);
   if (hipStreamSynchronize(st) != hipSuccess ||
       hipMemcpy(row, p->ref4, sizeof(row), hipMemcpyDeviceToHost) != hipSuccess) {
     chx_set_error("%s: cannot read ref4[0] (debug check)", who);
@@ -301,10 +302,10 @@ extern "C" int chx_langevin_fused_chunk(const chx_langevin_t* p, float* x_even, 
   CHX_REQUIRE(kicks_first >= 0 && kicks_first <= 2, "kicks_first must be 0, 1 or 2");
   CHX_REQUIRE(step0 >= 0 && step0 + n_steps < (1ll << 31) - 1, "step index out of range");
   CHX_REQUIRE(do_aoa || n_steps <= 1, "force-only mode takes a single launch");
-  int rc = debug_check_ref4(p, chx_stream(stream), "chx_langevin_fused_chunk");
+  int rc = debug_check_ref4(p, chx_stream_steps(stream), "chx_langevin_fused_chunk");
   if (rc != CHX_OK) return rc;
   rc = chx_launch_lj_steps(p, x_even, x_odd, step0, n_steps, kicks_first, do_aoa,
-                               chx_stream(stream));
+                               chx_stream_steps(stream));
   if (rc != CHX_OK) return rc;
   return chx_check_launch("chx_langevin_fused_chunk");
 }
@@ -325,11 +326,11 @@ extern "C" int chx_langevin_fused_run(const chx_langevin_t* p, float* x_even, fl
   CHX_REQUIRE(n_steps >= 0, "n_steps < 0");
   CHX_REQUIRE(kicks_first >= 0 && kicks_first <= 2, "kicks_first must be 0, 1 or 2");
   CHX_REQUIRE(step0 >= 0 && step0 + n_steps < (1ll << 31) - 1, "step index out of range");
-  int rc = debug_check_ref4(p, chx_stream(stream), "chx_langevin_fused_run");
+  int rc = debug_check_ref4(p, chx_stream_steps(stream), "chx_langevin_fused_run");
   if (rc != CHX_OK) return rc;
   CHX_REQUIRE(!p->snap4 || (p->ref4 && p->skin > 0.f), "snap4 (decoupled force list) needs ref4 and a skin");
   CHX_REQUIRE(!p->ev_log || p->ev_log_cap > 0, "ev_log without a capacity");
-  rc = chx_launch_lj_steps(p, x_even, x_odd, step0, n_steps, kicks_first, 1, chx_stream(stream), window,
+  rc = chx_launch_lj_steps(p, x_even, x_odd, step0, n_steps, kicks_first, 1, chx_stream_steps(stream), window,
                            n_enqueued_out);
   if (rc != CHX_OK) return rc;
   return chx_check_launch("chx_langevin_fused_run");

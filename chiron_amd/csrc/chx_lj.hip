@@ -12,11 +12,13 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "chx_common.h"
 #include "chx_internal.h"
 #include "chx_step.h"
 #include "chx_lj_row.h"
+#include "chx_aql.h"
 
 // ---------------------------------------------------------------------------
 // force list construction
@@ -554,8 +556,10 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
   // ---- integrate: one particle per thread, packed into the first PPB threads of the block ----
   const bool stale = step_epilogue<HOT, DEFER>(a, tk, sF, step, n_kicks, do_aoa, is_event);
   // the inner list stays off until the next refresh (a new epoch) outdates the word
+  // (agent-scope stores = write-through: a steady-state launch dispatched through the step queue ends without a
+  // release fence, chx_aql.h, so nothing another XCD must see may stay behind as a dirty line of this XCD's L2)
   if (do_aoa && (HOT || a.fli) && epoch >= 0 && (stale || (!inner && !PRUNE && threadIdx.x == 0)))
-    ctrl_first[4 + (int)((step + 1) & 1)] = epoch;
+    __hip_atomic_store(&ctrl_first[4 + (int)((step + 1) & 1)], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (is_event) {  // the reference's rebuild count and the step it happened at (chiron/integrators.py:242)
       const int c = ctrl_first[8] + 1;
@@ -571,7 +575,7 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
     const int w = PRUNE ? 7 : 6;
     if (PRUNE || ((HOT || a.fli) && !inner)) {  // refreshes of the inner list / launches on the full list
       const int c = ctrl_first[w] + 1;
-      ctrl_first[w] = c;
+      __hip_atomic_store(&ctrl_first[w], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (a.host_ctrl != nullptr) __hip_atomic_store(&a.host_ctrl[w], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
@@ -730,9 +734,32 @@ int chx_launch_lj_fl(const float* x4, const uint32_t* fl, const int32_t* deg, in
   return CHX_ERR_INVALID;
 }
 
+// the step kernel's kernarg segment as the compiler lays it out (checked against the code object's metadata when the
+// step queue looks the kernel up: chx_aql_dispatch refuses a block shorter than the kernel's)
+struct StepKernarg {
+  int32_t* ctrl_first;
+  long long step;
+  int epoch;
+  int n_lead;
+  unsigned nblocks;
+  const float4* x_lead;
+  const uint32_t* sfl;
+  const int32_t* sdeg;
+  StepArgs a;
+  int n_kicks;
+  int do_aoa;
+};
+struct ApKernarg {
+  StepArgs a;
+  long long step;
+  int n_kicks;
+  int do_aoa;
+  int use_cutoff;
+};
+
 template <int G>
-static void launch_step_g(const StepArgs& a, long long step, int n_kicks, int do_aoa, bool prune, int epoch,
-                          hipStream_t st) {
+static int launch_step_g(const StepArgs& a, long long step, int n_kicks, int do_aoa, bool prune, int epoch,
+                         hipStream_t st) {
   const unsigned blocks = (unsigned)(((int64_t)a.n * G + 255) / 256);
   static const bool dbg = getenv("CHX_DEBUG_SYNC") != nullptr;  // serialise + narrate (fault hunting)
   if (dbg) fprintf(stderr, "[chx] k_lj_step<%d> step %lld kicks %d aoa %d prune %d epoch %d\n", G, step, n_kicks, do_aoa, (int)prune, epoch);
@@ -744,10 +771,37 @@ static void launch_step_g(const StepArgs& a, long long step, int n_kicks, int do
   const int32_t* sdeg = spec_inner ? a.degi : a.deg;
   // DEFER (deferred rebuilds, chx_langevin_t::snap4) is a template parameter, not a run-time switch: compiled into the
   // one kernel, its extra registers and branches cost the halting scheme's steady-state launch 2.5 % (measured, round 3)
+  const bool defer = a.snap4 != nullptr;
+  if (chx_aql_on()) {
+    // the step queue (chx_aql.h): the same kernel, dispatched as an AQL packet.  A steady-state launch leaves nothing
+    // but write-through stores behind (step_epilogue; the control words are stored at agent scope) and carries no
+    // release fence; a launch that refreshes the inner list or takes the general paths ends with an agent-scope release.
+    static const AqlKernel* table[2][2][2] = {{{nullptr, nullptr}, {nullptr, nullptr}}, {{nullptr, nullptr}, {nullptr, nullptr}}};
+    static bool looked[2][2][2] = {{{false, false}, {false, false}}, {{false, false}, {false, false}}};
+    const int ih = hot ? 1 : 0, ip = prune ? 1 : 0, id = defer ? 1 : 0;
+    if (!looked[ih][ip][id]) {
+      char name[96];
+      snprintf(name, sizeof(name), "void k_lj_step<%d, %s, %s, %s>", G, hot ? "true" : "false", prune ? "true" : "false",
+               defer ? "true" : "false");
+      table[ih][ip][id] = chx_aql_kernel(name);
+      looked[ih][ip][id] = true;
+    }
+    const AqlKernel* k = table[ih][ip][id];
+    if (k == nullptr) {  // (a code object from other sources than this library: refuse, do not mix launch paths)
+      chx_set_error("chx_launch_step: libchx_step.hsaco holds no k_lj_step<%d, %d, %d, %d>", G, ih, ip, id);
+      return CHX_ERR_LAUNCH;
+    }
+    {
+      StepKernarg ka;
+      std::memset(&ka, 0, sizeof(ka));
+      ka.ctrl_first = a.ctrl, ka.step = step, ka.epoch = epoch, ka.n_lead = a.n, ka.nblocks = blocks;
+      ka.x_lead = a.x_cur, ka.sfl = sfl, ka.sdeg = sdeg, ka.a = a, ka.n_kicks = n_kicks, ka.do_aoa = do_aoa;
+      return chx_aql_dispatch(st, k, blocks, &ka, sizeof(ka), !(hot && !prune && !defer));
+    }
+  }
 #define CHX_LAUNCH_STEP(HOT_, PRUNE_, DEFER_)                                                                             \
   hipLaunchKernelGGL((k_lj_step<G, HOT_, PRUNE_, DEFER_>), dim3(blocks), dim3(256), 0, st, a.ctrl, step, epoch, a.n, blocks, \
                      a.x_cur, sfl, sdeg, a, n_kicks, do_aoa)
-  const bool defer = a.snap4 != nullptr;
   if (defer) {
     if (hot && prune) CHX_LAUNCH_STEP(true, true, true);
     else if (hot) CHX_LAUNCH_STEP(true, false, true);
@@ -761,27 +815,40 @@ static void launch_step_g(const StepArgs& a, long long step, int n_kicks, int do
   }
 #undef CHX_LAUNCH_STEP
   if (dbg) (void)hipStreamSynchronize(st);
+  return CHX_OK;
 }
 
 // one fused step launch on the force list (the host loop lives in chx_launch_window.hip)
 int chx_launch_step(const StepArgs& a, int g, long long step, int n_kicks, int do_aoa, bool prune, int epoch, hipStream_t st) {
   switch (g) {
-    case 1: launch_step_g<1>(a, step, n_kicks, do_aoa, prune, epoch, st); break;
-    case 2: launch_step_g<2>(a, step, n_kicks, do_aoa, prune, epoch, st); break;
-    case 4: launch_step_g<4>(a, step, n_kicks, do_aoa, prune, epoch, st); break;
-    case 8: launch_step_g<8>(a, step, n_kicks, do_aoa, prune, epoch, st); break;
-    case 16: launch_step_g<16>(a, step, n_kicks, do_aoa, prune, epoch, st); break;
-    case 32: launch_step_g<32>(a, step, n_kicks, do_aoa, prune, epoch, st); break;
-    case 64: launch_step_g<64>(a, step, n_kicks, do_aoa, prune, epoch, st); break;
+    case 1: return launch_step_g<1>(a, step, n_kicks, do_aoa, prune, epoch, st);
+    case 2: return launch_step_g<2>(a, step, n_kicks, do_aoa, prune, epoch, st);
+    case 4: return launch_step_g<4>(a, step, n_kicks, do_aoa, prune, epoch, st);
+    case 8: return launch_step_g<8>(a, step, n_kicks, do_aoa, prune, epoch, st);
+    case 16: return launch_step_g<16>(a, step, n_kicks, do_aoa, prune, epoch, st);
+    case 32: return launch_step_g<32>(a, step, n_kicks, do_aoa, prune, epoch, st);
+    case 64: return launch_step_g<64>(a, step, n_kicks, do_aoa, prune, epoch, st);
     default:
       chx_set_error("chx_launch_step: unsupported g = %d", g);
       return CHX_ERR_INVALID;
   }
-  return CHX_OK;
 }
 
 // one fused step launch without a neighbor list: all-pairs force + BAOAB (k_ap_step)
 void chx_launch_ap_step(const StepArgs& a, long long step, int n_kicks, int do_aoa, int use_cutoff, hipStream_t st) {
+  if (chx_aql_on()) {
+    static const AqlKernel* small = chx_aql_kernel("void k_ap_step<64, true>");
+    static const AqlKernel* large = chx_aql_kernel("void k_ap_step<16, false>");
+    const AqlKernel* k = a.n <= 2048 ? small : large;
+    if (k == nullptr) chx_aql_join(st);  // (cannot happen with a code object built from this tree; keep the order at least)
+    if (k != nullptr) {
+      ApKernarg ka;
+      std::memset(&ka, 0, sizeof(ka));
+      ka.a = a, ka.step = step, ka.n_kicks = n_kicks, ka.do_aoa = do_aoa, ka.use_cutoff = use_cutoff;
+      const unsigned blocks = a.n <= 2048 ? (unsigned)((a.n + 3) / 4) : (unsigned)((a.n + 15) / 16);
+      if (chx_aql_dispatch(st, k, blocks, &ka, sizeof(ka), true) == CHX_OK) return;
+    }
+  }
   if (a.n <= 2048) {
     hipLaunchKernelGGL((k_ap_step<64, true>), dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, st, a, step, n_kicks, do_aoa, use_cutoff);
   } else {

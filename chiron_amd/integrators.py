@@ -53,6 +53,16 @@ _EV_LOG_CAP = 4096
 _CARRY_DEFAULT = __import__("os").environ.get("CHX_LIST_CARRY", "1") != "0"
 _CARRY_MAX_STEPS_DEFAULT = int(__import__("os").environ.get("CHX_LIST_CARRY_MAX_STEPS", "64"))
 
+def _wait_for_steps_and_stream(device_wide: bool = False) -> None:
+    """Host wait for everything this thread has enqueued: the step launches (they run on the step queue paired with the
+    stream, include/chx.h: chx_steps_join -- a wait for the stream alone does not cover them) and then the stream."""
+    ops.steps_join()
+    if device_wide:
+        torch.cuda.synchronize()
+    else:
+        torch.cuda.current_stream().synchronize()
+
+
 def langevin_constants(timestep, collision_rate):
     """(half_dt, a, b) in fp32 exactly as chiron/integrators.py:132-137 forms them."""
     dt = float(timestep.value_in_unit_system(unit.md_unit_system))
@@ -741,7 +751,7 @@ class _RunState:
         self.integ._gen_next += 1
         if slot.open or slot.dirty:
             if not (cur is not None and cur is not slot and int(cur.host[0]) >= cur.step0):
-                torch.cuda.current_stream().synchronize()  # (a run that ended in an exception, a zero-step run)
+                _wait_for_steps_and_stream()  # (a run that ended in an exception, a zero-step run)
             self._retire(slot)
         # what chx_ctrl_reset writes, with word 0 = "the launch before `step` has begun": nothing is queued
         slot.host[:] = (step - 1, 0, 0, _INT_MAX, -2, -2, 0, 0, 0, -1, -1, -1, _INT_MAX, 0, 0, 0)
@@ -808,7 +818,7 @@ class _RunState:
 
         prof = os.environ.get("CHX_PROFILE_REBUILD") == "1"
         if prof:
-            torch.cuda.synchronize()
+            _wait_for_steps_and_stream(device_wide=True)
             t0 = time.perf_counter()
         x_user, v_user = self.state_user()
         keep_events = 1 if self._defer is not None else 0
@@ -828,7 +838,7 @@ class _RunState:
         self.n_rebuilds += 1
         self._host_events.append(step)
         if prof:
-            torch.cuda.synchronize()
+            _wait_for_steps_and_stream(device_wide=True)
             self.integ.rebuild_seconds = getattr(self.integ, "rebuild_seconds", 0.0) + time.perf_counter() - t0
 
     def _settle(self) -> bool:
@@ -852,7 +862,7 @@ class _RunState:
         if ok:
             return True
         x_user, v_user, step, kicks = pend[:4]
-        torch.cuda.synchronize()
+        _wait_for_steps_and_stream(device_wide=True)
         if self._defer is not None:
             # whatever ran on the rejected list is void, its reference events included: the device log tells how many
             # rebuilds the reference had made BEFORE this step (the host-made ones are not in it)
@@ -914,9 +924,17 @@ class _RunState:
         work, self._host_tail = getattr(self, "_host_tail", None), None
         if work is not None:
             work()  # (see LangevinIntegrator.run: the launches above are still queued)
-        ev = torch.cuda.Event()
-        ev.record()  # (the last thing on the stream: a caller's device-wide synchronize then finds nothing pending)
-        ev.synchronize()
+        self._wait_for_launches()
+
+    def _wait_for_launches(self):
+        """Host wait until every launch of the run so far has run.  Through the step queue (the default) the step
+        launches are the last thing enqueued and the join is the whole wait -- the stream holds nothing behind the marker
+        that let them start; with plain HIP launches (CHX_AQL=0, or no queue) an event on the stream is."""
+        ops.steps_join()
+        if not ops.step_queue_on():
+            ev = torch.cuda.Event()
+            ev.record()  # (the last thing on the stream: a caller's device-wide synchronize then finds nothing pending)
+            ev.synchronize()
 
     def _advance_windowed(self, done: int, stop: int, final: bool = False) -> int:
         """Steps [done, stop) through ``chx_langevin_fused_run``: the C loop keeps at most ``launch_window``
@@ -953,9 +971,7 @@ class _RunState:
                     self._enqueue_kick(stop, with_state=True)  # (waits: everything up to here has run)
                     self._kick_sent = True
                 else:
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    ev.synchronize()
+                    self._wait_for_launches()
             if not self._settle():
                 # the speculative list these launches ran on was rejected (whatever they halted on or produced is
                 # void): the state is back at the rebuild step, on the list the synchronous build made

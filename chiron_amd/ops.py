@@ -635,6 +635,39 @@ def langevin_fused_run(params: LangevinParams, x_even: torch.Tensor, x_odd: torc
     return out.value
 
 
+def steps_join() -> None:
+    """Wait on the host until every step launch dispatched for the current stream has completed (include/chx.h:
+    chx_steps_join; returns at once when none is outstanding).  The step launches run on a queue of their own, so a
+    wait for the STREAM -- an event, ``stream.synchronize()``, a ``.cpu()`` -- does not cover them: whoever is about to
+    touch what they write with anything but a libchx call joins first (libchx calls join by themselves)."""
+    check(_lib.load().chx_steps_join(_stream()), "chx_steps_join")
+
+
+_queue_on = None
+
+
+def step_queue_on() -> bool:
+    """Do the fused step launches of this process go through the step queue?  (Decided once, at the first step launch or
+    here: include/chx.h.)"""
+    global _queue_on
+    if _queue_on is None:
+        out = (C.c_int64 * 8)()
+        check(_lib.load().chx_step_queue_info(out, None), "chx_step_queue_info")
+        _queue_on = bool(out[0])
+    return _queue_on
+
+
+def step_queue_info() -> dict:
+    """Diagnostics of the step queue paired with the current stream (include/chx.h: chx_step_queue_info)."""
+    out = (C.c_int64 * 8)()
+    lib = _lib.load()
+    check(lib.chx_step_queue_info(out, _stream()), "chx_step_queue_info")
+    status = lib.chx_step_queue_status()
+    return {"on": bool(out[0]), "hot_release": {0: "none", 1: "agent"}.get(int(out[1]), "off"), "kernels": int(out[2]),
+            "dispatched": int(out[3]), "joins": int(out[4]), "gates": int(out[5]), "open": bool(out[6]),
+            "status": status.decode() if status else ""}
+
+
 def ctrl_reset(ctrl: torch.Tensor) -> None:
     _require_device(ctrl)
     check(_lib.load().chx_ctrl_reset(_ptr(ctrl), _stream()), "chx_ctrl_reset")

@@ -58,7 +58,13 @@ typedef void* chx_stream_t;
  *      became cur4 / prop4 (four configurations each) and ws doubled -- the Monte Carlo loop is one launch per trial.
  *      Added: chx_philox4x32_h, chx_cell_bin_fl, chx_nl_rows_cell_fl, chx_mc_key_chain_h (chx_mc_t grew k0, k1,
  *      keytab, keytab_h, chain_out_h: the chunk's key chain is computed on the host). */
-#define CHX_ABI_VERSION 3
+/*   4  round 5 -- compatible with 3 for every existing signature.  Added: the STEP QUEUE.  chx_langevin_fused_chunk / _run
+ *      dispatch their step launches as AQL packets on a private HSA queue paired with `stream` (see chx_steps_join);
+ *      "asynchronous on `stream`" then means: behind everything enqueued on `stream` before the call, and every LATER
+ *      libchx call on `stream` runs behind them -- but a caller that enqueues work of its OWN on `stream` which reads
+ *      what the steps write must call chx_steps_join first.  CHX_AQL=0 in the environment restores plain HIP launches.
+ *      New entry points: chx_steps_join, chx_step_queue_info, chx_step_queue_status. */
+#define CHX_ABI_VERSION 4
 
 /* high bit of a force-list entry: neighbor has the HIGHER original particle id */
 #define CHX_FL_HI 0x80000000u
@@ -483,6 +489,25 @@ int chx_langevin_fused_chunk(const chx_langevin_t* p_h, float* x_even, float* x_
 int chx_langevin_fused_run(const chx_langevin_t* p_h, float* x_even, float* x_odd, int64_t step0,
                            int32_t n_steps, int32_t kicks_first, int32_t window,
                            int32_t* n_enqueued_out, chx_stream_t stream);
+
+/* The step queue.  The fused step kernels are dispatched as hand-written AQL kernel-dispatch packets on a user-mode HSA
+ * queue of the library's own, one per `stream` value, instead of through hipLaunchKernelGGL: the host side of a dispatch
+ * is a copy of the 320-byte argument block into device memory, a 64-byte packet and a doorbell write (the HIP runtime's
+ * launch path, and its slow regime, are out of the loop), and the packets of steady-state launches carry no cache
+ * fences (their outputs are write-through stores; CHX_AQL_FENCE=agent restores HIP's agent-scope acquire / release on
+ * every packet).  Ordering: the first packet after a join waits (barrier-AND packet on a signal that a marker kernel on
+ * `stream` sets) for everything enqueued on `stream` before it; chx_steps_join waits ON THE HOST until every packet
+ * dispatched for `stream` has completed (returns at once when none is outstanding).  Every libchx entry point that
+ * launches on a stream joins first, so libchx calls always see one ordered stream; only work the CALLER enqueues on
+ * `stream` by other means (its own kernels, copies, events) needs an explicit chx_steps_join in front when it depends on
+ * the steps.  The kernels are loaded from libchx_step.hsaco beside the library (same source, same flags as the copies
+ * inside it).  When the queue cannot be set up (file missing, HSA runtime not found, CHX_AQL=0) the launches go through
+ * HIP as in ABI 3; chx_step_queue_status() says why. */
+int chx_steps_join(chx_stream_t stream);
+/* out8_h = {queue usable (0 / 1), release scope of a steady-state packet (0 none, 1 agent, -1 off), kernels in the code
+ * object, packets dispatched for `stream`, joins, gates (HIP -> queue hand-overs), packets outstanding (0 / 1), 0}. */
+int chx_step_queue_info(int64_t* out8_h, chx_stream_t stream);
+const char* chx_step_queue_status(void);
 
 /* How chx_langevin_fused_run waits when its launch queue is full: sleep_ns > 0 -- nanosleep that long between polls
  * (default 5000, or CHX_POLL_SLEEP_NS; the queue refills in bursts of window / 2 launches); 0 -- busy-wait
