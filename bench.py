@@ -483,6 +483,10 @@ def time_kernels(fluid, pot, state, nbr, integ, reps: int, spin_s: float = 1.0, 
             start.record()
             for _ in range(count):
                 fn()
+            # (the step launches run on the step queue paired with the stream -- chx_steps_join, include/chx.h -- which an
+            # event on the stream does not see: the closing event is recorded once they have drained, so the bracket
+            # holds the launches plus one hand-over each way, ~5 us over 640 launches)
+            ops.steps_join()
             stop.record()
             torch.cuda.synchronize()
             samples.append(start.elapsed_time(stop) * 1e-3 / count)
@@ -574,11 +578,13 @@ def c2_block(chunk: int, steps: int = 20000):
         one_chunk()
     samples = []
     for _ in range(7):
+        ops.steps_join()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(20):
             one_chunk()
+        ops.steps_join()  # (see time_kernels)
         e1.record()
         torch.cuda.synchronize()
         samples.append(e0.elapsed_time(e1) * 1e-3 / (20 * 64))

@@ -17,11 +17,13 @@ from chiron_amd import unit
 def ev_time(fn, reps=200, warm=20):
     for _ in range(warm):
         fn()
+    ops.steps_join()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps):
         fn()
+    ops.steps_join()  # (step launches run on the step queue, which an event on the stream does not see: include/chx.h)
     b.record()
     torch.cuda.synchronize()
     return a.elapsed_time(b) * 1e3 / reps  # us
@@ -89,6 +91,7 @@ for wl in sys.argv[1:] or ["c3", "c4"]:
         while time.perf_counter() - t_w < spin:
             for _ in range(50):
                 one()
+            ops.steps_join()
             torch.cuda.synchronize()
         # the pair-force kernel is timed AFTER the clock warm-up above (which runs the STEP kernel on the state's own
         # buffers: x4 / fl, which the force launches read, are untouched): at the card's idle clock level the same

@@ -132,6 +132,13 @@ __global__ __launch_bounds__(256) void k_check(SArgs a) {
   if (threadIdx.x == 0 && s0 != a.val) atomicAdd(a.bad + 1, 1);
 }
 
+// ---- queue -> HIP stream hand-over without the host (mode "wait") ----
+__global__ void k_flag_set(int* flag, int value) { __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__global__ __launch_bounds__(256) void k_copy4(const float4* in, float4* out, int n) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < n) out[t] = in[t];
+}
+
 template __global__ void k_probe<0>(PArgs, long long);
 template __global__ void k_probe<1>(PArgs, long long);
 
@@ -338,6 +345,101 @@ int main(int argc, char** argv) {
   }
   if (!ks[0] || !ks[1]) return fprintf(stderr, "kernels not found\n"), 1;
   const size_t SLOT = 512;
+  if (argc > 3 && !strcmp(argv[3], "wait")) {
+    const Sym* kfl = nullptr;
+    for (const Sym& y : g_syms)
+      if (y.name.find("k_flag_set") != std::string::npos) kfl = &y;
+    if (!kfl || !g_have_dev) return fprintf(stderr, "wait: kernel or device pool missing\n"), 1;
+    char* ring = nullptr;
+    HK(hsa_amd_memory_pool_allocate(g_dev_pool, SLOT * QSIZE, 0, (void**)&ring));
+    HK(hsa_amd_agents_allow_access(1, &g_cpu, nullptr, ring));
+    hsa_signal_t done;
+    HK(hsa_signal_create(1, 0, nullptr, &done));
+    float4* y;
+    CK(hipMalloc(&y, sizeof(float4) * n));
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    auto push = [&](const Sym& k, unsigned nblk, const void* a, size_t sz, int acq, int rel, bool last) {
+      uint64_t widx = hsa_queue_add_write_index_relaxed(q, 1);
+      while (widx - hsa_queue_load_read_index_scacquire(q) >= QSIZE - 1) {
+      }
+      char* ka = ring + SLOT * (widx % QSIZE);
+      memcpy(ka, a, sz);
+      hsa_kernel_dispatch_packet_t* pk = reinterpret_cast<hsa_kernel_dispatch_packet_t*>(q->base_address) + (widx % QSIZE);
+      pk->setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
+      pk->workgroup_size_x = nblk == 0 ? 1 : 256, pk->workgroup_size_y = 1, pk->workgroup_size_z = 1;
+      pk->reserved0 = 0;
+      pk->grid_size_x = nblk == 0 ? 1 : nblk * 256, pk->grid_size_y = 1, pk->grid_size_z = 1;
+      pk->private_segment_size = k.priv;
+      pk->group_segment_size = k.group;
+      pk->kernel_object = k.object;
+      pk->kernarg_address = ka;
+      pk->reserved2 = 0;
+      pk->completion_signal = last ? done : hsa_signal_t{0};
+      const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                              (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+      __atomic_store_n(reinterpret_cast<uint16_t*>(pk), header, __ATOMIC_RELEASE);
+      hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)widx);
+    };
+    for (int kind = 0; kind < 3; ++kind) {
+      int* flag = nullptr;
+      hipError_t e = hipSuccess;
+      const char* kname = kind == 0 ? "hipMalloc word" : (kind == 1 ? "hipMallocSignalMemory" : "host join (reference)");
+      if (kind == 0) e = hipMalloc(&flag, 64);
+      else if (kind == 1) e = hipExtMallocWithFlags((void**)&flag, 8, hipMallocSignalMemory);
+      else e = hipMalloc(&flag, 64);
+      if (e != hipSuccess) {
+        printf("wait test, %s: allocation failed (%s)\n", kname, hipGetErrorString(e));
+        (void)hipGetLastError();
+        continue;
+      }
+      CK(hipMemset(flag, 0, 4));
+      const int steps = 200;
+      for (int rep = 0; rep < 5; ++rep) {
+        reset(s);
+        CK(hipMemset(y, 0, sizeof(float4) * n));
+        CK(hipDeviceSynchronize());
+        hsa_signal_store_relaxed(done, 1);
+        const int gen = rep + 1;
+        const double t0 = now_us();
+        for (int i = 0; i < steps; ++i) {
+          struct { PArgs a; long long step; } ka = {{n, 0, (i & 1) ? s.xb : s.xa, (i & 1) ? s.xa : s.xb, s.v, s.fl, s.ctrl}, i};
+          push(*ks[0], blocks, &ka, sizeof(ka), i == 0 ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE, false);
+        }
+        struct { int* f; int v; } fa = {flag, gen};
+        push(*kfl, 0, &fa, sizeof(fa), HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_SYSTEM, true);
+        const double t_enq = now_us();
+        hipError_t we = hipSuccess;
+        if (kind < 2) {
+          we = hipStreamWaitValue32(st, flag, (uint32_t)gen, hipStreamWaitValueGte, 0xFFFFFFFFu);
+          if (we != hipSuccess) {
+            printf("wait test, %s: hipStreamWaitValue32 failed (%s)\n", kname, hipGetErrorString(we));
+            (void)hipGetLastError();
+          }
+        } else {
+          while (hsa_signal_wait_scacquire(done, HSA_SIGNAL_CONDITION_LT, 1, 2000000000ull, HSA_WAIT_STATE_ACTIVE) >= 1) {
+          }
+        }
+        const float4* xfin = (steps & 1) ? s.xb : s.xa;
+        hipLaunchKernelGGL(k_copy4, dim3((n + 255) / 256), dim3(256), 0, st, xfin, y, n);
+        CK(hipStreamSynchronize(st));
+        const double t1 = now_us();
+        while (hsa_signal_wait_scacquire(done, HSA_SIGNAL_CONDITION_LT, 1, 2000000000ull, HSA_WAIT_STATE_ACTIVE) >= 1) {
+        }
+        std::vector<float4> hy(n), hx(n);
+        CK(hipMemcpy(hy.data(), y, sizeof(float4) * n, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hx.data(), xfin, sizeof(float4) * n, hipMemcpyDeviceToHost));
+        const bool same = memcmp(hy.data(), hx.data(), sizeof(float4) * n) == 0;
+        printf("wait test, %-22s rep %d: %d steps + hand-over + copy kernel: %.1f us (enqueue %.1f us)  copy saw the final state: %s\n", kname, rep,
+               steps, t1 - t0, t_enq - t0, same ? "yes" : "NO");
+        fflush(stdout);
+        if (we != hipSuccess) break;
+      }
+      CK(hipFree(flag));
+    }
+    printf("rc 0\n");
+    return 0;
+  }
   if (argc > 3 && !strcmp(argv[3], "stale")) {
     const Sym *kf = nullptr, *kc = nullptr;
     for (const Sym& y : g_syms) {

@@ -1,0 +1,92 @@
+"""The step queue (include/chx.h: chx_steps_join; csrc/chx_aql.hip): the fused step launches dispatched as AQL packets
+on a private HSA queue, steady-state packets without cache fences.  It must not change one bit of a trajectory."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_TRAJECTORY = r"""
+import hashlib, json, sys
+sys.path.insert(0, %r)
+import torch
+import bench
+from chiron_amd import ops
+fluid, pot, state, thermo, nbr, integ = bench.make_system(sys.argv[1], 300.0, 32, "cell")
+rebuilds = 0
+for k in (int(sys.argv[2]), 20, 7, 100, 1):   # a long run with rebuilds and refreshes, then short ones (carried lists)
+    state, nbr = integ.run(state, thermo, number_of_steps=k, nbr_list=nbr)
+    rebuilds += integ.n_rebuilds
+torch.cuda.synchronize()
+h = hashlib.sha256(state.positions.cpu().numpy().tobytes() + state.velocities.cpu().numpy().tobytes()
+                   + nbr.ref_positions.cpu().numpy().tobytes()).hexdigest()
+print("RESULT " + json.dumps({"hash": h, "rebuilds": rebuilds, "queue": ops.step_queue_info(),
+                              "carried": getattr(integ, "n_carried_runs", 0)}))
+""" % ROOT
+
+
+def _run(env_extra, workload, steps):
+    env = dict(os.environ)
+    for k in ("CHX_AQL", "CHX_AQL_FENCE"):
+        env.pop(k, None)
+    env.update(env_extra)
+    out = subprocess.run([sys.executable, "-c", _TRAJECTORY, workload, str(steps)], capture_output=True, text=True, timeout=600,
+                         env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    return json.loads(line[len("RESULT "):])
+
+
+@pytest.mark.parametrize("workload,steps", [("c3", 3000), ("c4", 600)], ids=["c3-32768", "c4-262144"])
+def test_step_queue_and_its_fence_modes_leave_every_bit_of_the_trajectory(workload, steps):
+    """One trajectory from the bench's own start -- thousands of steps with list rebuilds and inner-list refreshes, then
+    short runs on carried-over lists -- in three fresh processes: plain HIP launches (CHX_AQL=0), the step queue with
+    HIP's agent-scope fences on every packet (CHX_AQL_FENCE=agent), and the default (steady-state packets carry no
+    fences: their outputs are write-through stores, and what they read was written through or released).  A single
+    stale read anywhere -- an L1, scalar-cache or L2 line that survived a dispatch, a store still dirty in one XCD's L2
+    -- changes the hash."""
+    hip = _run({"CHX_AQL": "0"}, workload, steps)
+    fenced = _run({"CHX_AQL_FENCE": "agent"}, workload, steps)
+    bare = _run({}, workload, steps)
+    assert not hip["queue"]["on"] and hip["queue"]["dispatched"] == 0
+    assert fenced["queue"]["on"] and fenced["queue"]["hot_release"] == "agent"
+    assert bare["queue"]["on"] and bare["queue"]["hot_release"] == "none", bare["queue"]
+    total = steps + 20 + 7 + 100 + 1
+    assert bare["queue"]["dispatched"] >= total and bare["queue"]["gates"] >= 5 and not bare["queue"]["open"]
+    assert hip["rebuilds"] > 0 or workload == "c4"
+    assert hip["hash"] == fenced["hash"] == bare["hash"], (hip, fenced, bare)
+    assert hip["rebuilds"] == fenced["rebuilds"] == bare["rebuilds"] and hip["carried"] == bare["carried"]
+
+
+def test_step_queue_orders_with_the_stream_it_is_paired_with():
+    """chx_steps_join / the gate: a kernel enqueued on the stream BEFORE step launches is seen by them, and work the
+    caller enqueues AFTER a join sees what they wrote -- with torch's own ops on both sides, which never pass through
+    libchx (include/chx.h: only the caller's own work needs an explicit join)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from chiron_amd import ops
+
+    fluid, pot, state, thermo, nbr, integ = bench.make_system("c3", 300.0, 32, "cell")
+    if not ops.step_queue_on():
+        pytest.skip("the step queue is switched off (CHX_AQL=0)")
+    state, nbr = integ.run(state, thermo, number_of_steps=50, nbr_list=nbr)
+    info0 = ops.step_queue_info()
+    # a run() returns with the queue drained: reading its results needs no join
+    assert not info0["open"] and info0["dispatched"] >= 51
+    x1 = state.positions.clone()
+    # torch work in front (a big fill the steps' inputs do not depend on, then the inputs themselves rewritten): the
+    # gate must hold the first step packet until both have run
+    junk = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+    junk.fill_(1.0)
+    state2, nbr = integ.run(state, thermo, number_of_steps=30, nbr_list=nbr)
+    assert float(junk[-1].item()) == 1.0
+    info1 = ops.step_queue_info()
+    assert info1["gates"] > info0["gates"] and info1["joins"] > info0["joins"] and not info1["open"]
+    assert torch.isfinite(state2.positions).all() and not torch.equal(state2.positions, x1)

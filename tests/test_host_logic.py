@@ -989,3 +989,38 @@ def test_host_philox_is_safe_to_call_from_several_threads():
     for t in threads:
         t.join()
     assert not bad, bad[:5]
+
+
+def test_step_code_object_is_current_and_holds_every_step_kernel():
+    """The step queue (csrc/chx_aql.hip) dispatches the fused step kernels from libchx_step.hsaco, the device half of
+    csrc/chx_lj.hip compiled by itself (chiron_amd/build.py).  CPU check: the file is the one built from this tree,
+    it holds every instantiation the launcher can ask for, and their kernarg segments are the sizes the hand-laid
+    argument blocks cover (StepKernarg 320 bytes, ApKernarg 280 for a 276-byte segment: chx_aql_dispatch refuses a block shorter than the kernel's)."""
+    import shutil
+    import subprocess
+
+    from chiron_amd import build
+
+    assert build.step_object_current(), "libchx_step.hsaco is missing or was built from another tree: run build()"
+    readelf = shutil.which("llvm-readelf") or "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("llvm-readelf not available")
+    notes = subprocess.run([readelf, "--notes", build.STEP_OUT], capture_output=True, text=True, timeout=120).stdout
+    sizes = {}
+    size = None
+    for line in notes.splitlines():
+        line = line.strip()
+        if line.startswith(".kernarg_segment_size:"):
+            size = int(line.split(":")[1])
+        elif line.startswith(".name:") and size is not None:
+            sizes[line.split(":", 1)[1].strip()] = size
+            size = None
+    for g in (1, 2, 4, 8, 16, 32, 64):
+        for hot in (0, 1):
+            for prune in (0, 1):
+                for defer in (0, 1):
+                    names = [n for n in sizes if n.startswith(f"_Z9k_lj_stepILi{g}ELb{hot}ELb{prune}ELb{defer}EE")]
+                    assert len(names) == 1, (g, hot, prune, defer)
+                    assert sizes[names[0]] == 320
+    ap = [n for n in sizes if n.startswith("_Z9k_ap_stepILi64ELb1EE") or n.startswith("_Z9k_ap_stepILi16ELb0EE")]
+    assert len(ap) == 2 and all(276 <= sizes[n] <= 280 for n in ap), {n: sizes[n] for n in ap}  # (sizeof(ApKernarg) = 280)
