@@ -58,6 +58,11 @@ def parse():
     ap.add_argument("--chunk", type=int, default=32, help="steps enqueued per host round trip")
     ap.add_argument("--exchange-interval", type=int, default=1000, help="steps between replica-exchange attempts (1 ps at dt = 1 fs)")
     ap.add_argument("--kernel-reps", type=int, default=200)
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="repetitions of the contract's measurement (W untimed warm-up steps, then EXACTLY K timed steps between barrier + "
+                         "synchronize); `value` is K / the median time, every sample is in config.value_samples_steps_per_s.  0 = auto: "
+                         "5 when K <= 1000 (a single 200 us sample carries the host's jitter: the driver's K = 20 read 71.8 k in round 4 "
+                         "where the same binary's 300-call median read 94.5 k), else 1")
     ap.add_argument("--cpu-steps", type=int, default=-1, help="steps of the CPU baseline (-1 = auto, 0 = skip)")
     ap.add_argument("--extra-c4", type=int, default=1, help="also report the N=262,144 pair-force roofline (1 GPU runs)")
     ap.add_argument("--c4-equilibration", type=int, default=20000,
@@ -535,7 +540,10 @@ def time_kernels(fluid, pot, state, nbr, integ, reps: int, spin_s: float = 1.0, 
     p_nl = int(torch.minimum(nbr.n_neighbors, torch.tensor(nbr.n_max_neighbors, device=x4.device)).sum().item())
     fl.timing_samples_us = {"step": [round(v / per_call, 3) for v in step_samples], "force": force_samples,
                             "statistic": "median of 7 event-timed samples (per-launch averages over "
-                                         f"{max(2, reps // 10) * per_call} step / {reps} force launches each)"}
+                                         f"{max(2, reps // 10) * per_call} step / {reps} force launches each"
+                                         + ("; the step launches run on the step queue paired with the stream: the closing event "
+                                            "is recorded after chx_steps_join, so a sample also holds one hand-over each way"
+                                            if ops.step_queue_on() else "") + ")"}
     return t_step, t_force, p_nl, fl
 
 
@@ -1123,11 +1131,19 @@ def main():
             if settled or spent > 3.0 * args.clock_warmup_s:
                 break
         clock_warm_s = time.perf_counter() - t_c
-    # warm-up (untimed)
-    state, _ = propagate(state, args.warmup)
-    prune_before = (getattr(integ, "prune_passes", 0), getattr(integ, "full_list_launches", 0))
-    state, elapsed, per_rank, exchanges, rebuilds = timed(state, args.steps)
-    prune_after = (getattr(integ, "prune_passes", 0), getattr(integ, "full_list_launches", 0))
+    # The contract's measurement -- W untimed warm-up steps, then exactly K steps between barrier + synchronize, max over
+    # ranks -- `repeats` times over; the line reports the MEDIAN repetition (its time, its rebuild / refresh counts) and
+    # every repetition's rate beside it (config.value_samples_steps_per_s, first sample first).
+    repeats = args.repeats if args.repeats > 0 else (5 if args.steps <= 1000 else 1)
+    reps_ = []
+    for _ in range(repeats):
+        state, _ = propagate(state, args.warmup)  # warm-up (untimed)
+        prune_before = (getattr(integ, "prune_passes", 0), getattr(integ, "full_list_launches", 0))
+        state, elapsed, per_rank, exchanges, rebuilds = timed(state, args.steps)
+        prune_after = (getattr(integ, "prune_passes", 0), getattr(integ, "full_list_launches", 0))
+        reps_.append((elapsed, per_rank, exchanges, rebuilds, prune_before, prune_after))
+    value_samples = [round(world * args.steps / r[0], 2) for r in reps_]
+    elapsed, per_rank, exchanges, rebuilds, prune_before, prune_after = sorted(reps_, key=lambda r: r[0])[len(reps_) // 2]
     value = world * args.steps / elapsed
     sclk = {}  # (read only after the steady-state windows: a rocm-smi call idles the card for half a second)
 
@@ -1205,6 +1221,19 @@ def main():
             "roofline_pair_force": roof_force,
         }
         out["config"]["list_carry_over"] = False
+        out["config"]["value_statistic"] = (f"median of {repeats} repetitions of [{args.warmup} warm-up steps, then {args.steps} timed "
+                                            "steps between barrier + synchronize]" if repeats > 1 else "one timed region")
+        out["config"]["value_samples_steps_per_s"] = value_samples
+        out["config"]["value_first_sample_steps_per_s"] = value_samples[0]
+        try:
+            sq = ops.step_queue_info()
+            # (how the step launches reach the device: include/chx.h, "The step queue")
+            out["config"]["step_queue"] = ("AQL packets on a private HSA queue, steady-state packets without cache fences"
+                                           if sq["on"] and sq["hot_release"] == "none" else
+                                           ("AQL packets on a private HSA queue, agent-scope fences" if sq["on"] else
+                                            "off: hipLaunchKernelGGL (" + (sq["status"] or "CHX_AQL=0") + ")"))
+        except Exception as exc:  # pragma: no cover - diagnostics only
+            out["config"]["step_queue"] = repr(exc)
         from chiron_amd import integrators as _integ_mod
 
         # (what a list build inside the timed run() writes: the force list the step kernels read, every time; the

@@ -139,6 +139,14 @@ __global__ __launch_bounds__(256) void k_copy4(const float4* in, float4* out, in
   if (t < n) out[t] = in[t];
 }
 
+// ---- which XCD does block b of consecutive dispatches land on? (mode "xcc") ----
+__global__ __launch_bounds__(256) void k_xcc(int* out, int launch, int nblk) {
+  if (threadIdx.x == 0) {
+    const int id = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF;  // HW_REG_XCC_ID, bits 3:0
+    out[(size_t)launch * nblk + blockIdx.x] = id;
+  }
+}
+
 template __global__ void k_probe<0>(PArgs, long long);
 template __global__ void k_probe<1>(PArgs, long long);
 
@@ -438,6 +446,60 @@ int main(int argc, char** argv) {
       CK(hipFree(flag));
     }
     printf("rc 0\n");
+    return 0;
+  }
+  if (argc > 3 && !strcmp(argv[3], "xcc")) {
+    const Sym* kx = nullptr;
+    for (const Sym& y : g_syms)
+      if (y.name.find("k_xcc") != std::string::npos) kx = &y;
+    if (!kx || !g_have_dev) return fprintf(stderr, "xcc: kernel or device pool missing\n"), 1;
+    char* ring = nullptr;
+    HK(hsa_amd_memory_pool_allocate(g_dev_pool, SLOT * QSIZE, 0, (void**)&ring));
+    HK(hsa_amd_agents_allow_access(1, &g_cpu, nullptr, ring));
+    hsa_signal_t done;
+    HK(hsa_signal_create(1, 0, nullptr, &done));
+    const int L = 64, NB = 512;
+    int* out;
+    CK(hipMalloc(&out, sizeof(int) * L * NB));
+    CK(hipMemset(out, 0xFF, sizeof(int) * L * NB));
+    CK(hipDeviceSynchronize());
+    for (int i = 0; i < L; ++i) {
+      uint64_t widx = hsa_queue_add_write_index_relaxed(q, 1);
+      char* ka = ring + SLOT * (widx % QSIZE);
+      struct { int* o; int l; int nb; } a = {out, i, NB};
+      memcpy(ka, &a, sizeof(a));
+      hsa_kernel_dispatch_packet_t* pk = reinterpret_cast<hsa_kernel_dispatch_packet_t*>(q->base_address) + (widx % QSIZE);
+      pk->setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
+      pk->workgroup_size_x = 256, pk->workgroup_size_y = 1, pk->workgroup_size_z = 1;
+      pk->reserved0 = 0;
+      pk->grid_size_x = NB * 256, pk->grid_size_y = 1, pk->grid_size_z = 1;
+      pk->private_segment_size = kx->priv;
+      pk->group_segment_size = kx->group;
+      pk->kernel_object = kx->object;
+      pk->kernarg_address = ka;
+      pk->reserved2 = 0;
+      pk->completion_signal = i == L - 1 ? done : hsa_signal_t{0};
+      const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                              (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+      __atomic_store_n(reinterpret_cast<uint16_t*>(pk), header, __ATOMIC_RELEASE);
+      hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)widx);
+    }
+    while (hsa_signal_wait_scacquire(done, HSA_SIGNAL_CONDITION_LT, 1, 2000000000ull, HSA_WAIT_STATE_ACTIVE) >= 1) {
+    }
+    std::vector<int> h((size_t)L * NB);
+    CK(hipMemcpy(h.data(), out, sizeof(int) * L * NB, hipMemcpyDeviceToHost));
+    int exact = 0;
+    printf("XCD of block 0 in %d consecutive dispatches of %d blocks:", L, NB);
+    for (int i = 0; i < L; ++i) {
+      printf(" %d", h[(size_t)i * NB]);
+      bool rr = true;
+      for (int b = 0; b < NB; ++b) rr &= h[(size_t)i * NB + b] == (h[(size_t)i * NB] + b) % 8;
+      exact += rr;
+    }
+    printf("\nexact round-robin (block b on XCD (first + b) %% 8) in %d of %d dispatches\n", exact, L);
+    printf("first dispatch, blocks 0..31:");
+    for (int b = 0; b < 32; ++b) printf(" %d", h[b]);
+    printf("\nrc 0\n");
     return 0;
   }
   if (argc > 3 && !strcmp(argv[3], "stale")) {
