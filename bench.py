@@ -482,6 +482,7 @@ def time_kernels(fluid, pot, state, nbr, integ, reps: int, spin_s: float = 1.0, 
         for _ in range(7):
             if before_each is not None:
                 before_each()
+            ops.steps_join()  # (what before_each left on the step queue is not part of the sample)
             torch.cuda.synchronize()
             start = torch.cuda.Event(enable_timing=True)
             stop = torch.cuda.Event(enable_timing=True)

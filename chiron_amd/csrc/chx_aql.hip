@@ -64,44 +64,38 @@ struct Hsa {
 };
 Hsa H;
 
-struct LibSearch {
-  std::string dir;
-  std::string found_same_dir, found_any;
-};
+// every HSA runtime image resident in the process (a python process under rocprofv3 holds two: the system's, which the
+// profiler's preloaded tool brought along and which the HIP runtime then binds to, and the copy bundled with torch)
 int phdr_cb(struct dl_phdr_info* info, size_t, void* data) {
-  LibSearch* s = static_cast<LibSearch*>(data);
+  std::vector<std::string>* found = static_cast<std::vector<std::string>*>(data);
   if (!info->dlpi_name) return 0;
   const std::string name = info->dlpi_name;
   const size_t slash = name.rfind('/');
   const std::string base = slash == std::string::npos ? name : name.substr(slash + 1);
-  if (base.rfind("libhsa-runtime64.so", 0) != 0) return 0;
-  if (s->found_any.empty()) s->found_any = name;
-  if (slash != std::string::npos && name.substr(0, slash) == s->dir && s->found_same_dir.empty()) s->found_same_dir = name;
+  if (base.rfind("libhsa-runtime64.so", 0) == 0) found->push_back(name);
   return 0;
 }
 
-// the HSA runtime the process's HIP runtime is running on
+// The HSA runtime the process's HIP runtime is running on: the resident image that is INITIALISED.  Which image HIP's
+// calls bind to depends on the load order (the one next to libamdhip64 in a plain python process, the preloaded system
+// copy under a profiler); asking each image for the system timestamp tells without side effects -- an image nobody has
+// initialised answers HSA_STATUS_ERROR_NOT_INITIALIZED.  None initialised: the process has not started HIP, and the step
+// queue is not the one to start a runtime.
 void* find_hsa() {
-  Dl_info info;
-  LibSearch s;
-  if (dladdr(reinterpret_cast<void*>(&hipGetLastError), &info) && info.dli_fname) {
-    const std::string f = info.dli_fname;
-    const size_t slash = f.rfind('/');
-    if (slash != std::string::npos) s.dir = f.substr(0, slash);
-    char real[4096];
-    if (realpath(s.dir.c_str(), real)) s.dir = real;
+  std::vector<std::string> found;
+  dl_iterate_phdr(phdr_cb, &found);
+  void* live = nullptr;
+  for (const std::string& name : found) {
+    void* h = dlopen(name.c_str(), RTLD_NOW | RTLD_NOLOAD);
+    if (!h) continue;
+    auto get = reinterpret_cast<decltype(&::hsa_system_get_info)>(dlsym(h, "hsa_system_get_info"));
+    uint64_t t = 0;
+    const bool up = get != nullptr && get(HSA_SYSTEM_INFO_TIMESTAMP, &t) == HSA_STATUS_SUCCESS;
+    if (getenv("CHX_AQL_VERBOSE")) fprintf(stderr, "[chx] step queue: HSA runtime image %s: %s\n", name.c_str(), up ? "initialised" : "idle");
+    if (up && !live) live = h;
+    else dlclose(h);
   }
-  dl_iterate_phdr(phdr_cb, &s);
-  // (an object's recorded name may go through a symlinked directory: compare again on real paths)
-  if (s.found_same_dir.empty() && !s.dir.empty()) {
-    for (const char* cand : {"/libhsa-runtime64.so", "/libhsa-runtime64.so.1"}) {
-      void* h = dlopen((s.dir + cand).c_str(), RTLD_NOW | RTLD_NOLOAD);
-      if (h) return h;
-    }
-  }
-  const std::string pick = !s.found_same_dir.empty() ? s.found_same_dir : s.found_any;
-  if (pick.empty()) return nullptr;  // (no HSA runtime resident: the process has not initialised HIP -- not ours to start)
-  return dlopen(pick.c_str(), RTLD_NOW | RTLD_NOLOAD);
+  return live;
 }
 
 struct Gate {
