@@ -109,6 +109,13 @@ struct Queue {
   hsa_signal_t done{};   // completion signal of the join barrier
   Gate gates[4];
   unsigned gate_next = 0;
+  // The kernarg slot of packet w is reused by packet w + QSIZE, which is safe only once packet w has COMPLETED (its
+  // waves read the block while they run).  The queue's read index does not say that -- it says "consumed", and on an
+  // intercepted queue (rocprofv3) "copied out", long before the packet runs -- so the last packet of every quarter of
+  // the ring carries a completion signal, and the first packet of a quarter waits for the signal of that quarter's
+  // previous use: at most QSIZE - QSIZE / 4 packets are ever outstanding.
+  hsa_signal_t quarter[4];
+  bool quarter_used[4] = {false, false, false, false};
   uint64_t n_dispatched = 0, n_joins = 0, n_gates = 0;
 };
 
@@ -266,6 +273,8 @@ Queue* queue_for(hipStream_t st) {
   s = H.hsa_signal_create(0, 0, nullptr, &Q->done);
   for (Gate& g : Q->gates)
     if (s == HSA_STATUS_SUCCESS) s = H.hsa_amd_signal_create(1, 0, nullptr, HSA_AMD_SIGNAL_AMD_GPU_ONLY, &g.sig);
+  for (hsa_signal_t& qs : Q->quarter)
+    if (s == HSA_STATUS_SUCCESS) s = H.hsa_signal_create(0, 0, nullptr, &qs);
   if (s != HSA_STATUS_SUCCESS) return fail("signals", s), delete Q, nullptr;
   g_queues[st] = Q;
   return Q;
@@ -273,10 +282,38 @@ Queue* queue_for(hipStream_t st) {
 
 inline void* slot_of(Queue* Q, uint64_t widx) { return reinterpret_cast<char*>(Q->q->base_address) + 64 * (widx % QSIZE); }
 
-uint64_t reserve(Queue* Q) {
+bool wait_zero(hsa_signal_t sig, const char* what) {
+  timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  while (H.hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, 1, 1000000ull, HSA_WAIT_STATE_ACTIVE) >= 1) {
+    if (g_queue_error) return false;
+    timespec t1;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (t1.tv_sec - t0.tv_sec > 120) {
+      fail(what);
+      fprintf(stderr, "[chx] %s\n", g_err);
+      g_queue_error = 1;
+      return false;
+    }
+  }
+  return true;
+}
+
+// A slot of the packet ring (and with it a kernarg slot).  Returns the write index; *completion = the signal the packet
+// must carry (the quarter's, when the slot is the last of its quarter), else a null signal.
+uint64_t reserve(Queue* Q, hsa_signal_t* completion = nullptr) {
   const uint64_t widx = H.hsa_queue_add_write_index_relaxed(Q->q, 1);
+  const unsigned slot = (unsigned)(widx % QSIZE), quarter = slot / (QSIZE / 4);
+  if (slot % (QSIZE / 4) == 0 && Q->quarter_used[quarter]) (void)wait_zero(Q->quarter[quarter], "a quarter of the packet ring has not completed for 120 s");
   while (widx - H.hsa_queue_load_read_index_scacquire(Q->q) >= QSIZE - 1) {
     if (g_queue_error) break;
+  }
+  if (completion) *completion = hsa_signal_t{0};
+  if (slot % (QSIZE / 4) == QSIZE / 4 - 1) {
+    H.hsa_signal_store_relaxed(Q->quarter[quarter], 1);
+    Q->quarter_used[quarter] = true;
+    if (completion) *completion = Q->quarter[quarter];
+    else Q->quarter_used[quarter] = false;  // (a barrier packet of ours in that slot: see push_barrier)
   }
   return widx;
 }
@@ -285,7 +322,16 @@ inline void publish(Queue* Q, uint64_t widx, uint16_t header) {
   H.hsa_signal_store_screlease(Q->q->doorbell_signal, (hsa_signal_value_t)widx);
 }
 void push_barrier(Queue* Q, hsa_signal_t dep, hsa_signal_t completion, int acquire, int release) {
-  const uint64_t widx = reserve(Q);
+  hsa_signal_t quarter_sig{0};
+  const uint64_t widx = reserve(Q, &quarter_sig);
+  if (quarter_sig.handle != 0) {
+    // the last slot of a quarter went to a barrier packet: it carries the quarter's signal unless it has one of its own
+    // (the join's: the join then waits for everything, and the quarter counts as completed)
+    if (completion.handle == 0) completion = quarter_sig;
+    else {
+      H.hsa_signal_store_relaxed(quarter_sig, 0);
+    }
+  }
   hsa_barrier_and_packet_t* pk = static_cast<hsa_barrier_and_packet_t*>(slot_of(Q, widx));
   pk->reserved0 = 0;
   pk->reserved1 = 0;
@@ -344,7 +390,8 @@ int chx_aql_dispatch(hipStream_t st, const AqlKernel* k, unsigned blocks, const 
     __atomic_fetch_add(&chx_aql_open_count, 1, __ATOMIC_RELAXED);
     acquire = HSA_FENCE_SCOPE_AGENT;
   }
-  const uint64_t widx = reserve(Q);
+  hsa_signal_t quarter_sig{0};
+  const uint64_t widx = reserve(Q, &quarter_sig);
   // the argument block goes to device memory through the BAR; the read-back of its last word completes the posted
   // writes before the doorbell can make the packet processor fetch them
   char* ka = Q->ring + SLOT * (widx % QSIZE);
@@ -361,7 +408,7 @@ int chx_aql_dispatch(hipStream_t st, const AqlKernel* k, unsigned blocks, const 
   pk->kernel_object = k->object;
   pk->kernarg_address = ka;
   pk->reserved2 = 0;
-  pk->completion_signal = hsa_signal_t{0};
+  pk->completion_signal = quarter_sig;
   const int release = release_agent ? HSA_FENCE_SCOPE_AGENT : chx_aql_hot_release();
   publish(Q, widx, (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                               (acquire << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (release << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE)));
@@ -379,19 +426,7 @@ void chx_aql_join(hipStream_t st) {
   if (!Q || !Q->open) return;
   H.hsa_signal_store_relaxed(Q->done, 1);
   push_barrier(Q, hsa_signal_t{0}, Q->done, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_SYSTEM);
-  timespec t0;
-  clock_gettime(CLOCK_MONOTONIC, &t0);
-  while (H.hsa_signal_wait_scacquire(Q->done, HSA_SIGNAL_CONDITION_LT, 1, 1000000ull, HSA_WAIT_STATE_ACTIVE) >= 1) {
-    if (g_queue_error) break;
-    timespec t1;
-    clock_gettime(CLOCK_MONOTONIC, &t1);
-    if (t1.tv_sec - t0.tv_sec > 120) {
-      fail("the queue has not drained for 120 s");
-      fprintf(stderr, "[chx] %s\n", g_err);
-      g_queue_error = 1;
-      break;
-    }
-  }
+  (void)wait_zero(Q->done, "the queue has not drained for 120 s");
   Q->open = false;
   Q->n_joins++;
   __atomic_fetch_sub(&chx_aql_open_count, 1, __ATOMIC_RELAXED);
