@@ -105,21 +105,27 @@ struct Gate {
 struct Queue {
   hsa_queue_t* q = nullptr;
   char* ring = nullptr;  // kernarg slots in device memory, written by the host through the BAR
+  uint32_t size = 0;     // packets in the ring: what the runtime made of the request (an intercepted queue may differ)
   bool open = false;     // packets outstanding since the last join
   hsa_signal_t done{};   // completion signal of the join barrier
   Gate gates[4];
   unsigned gate_next = 0;
-  // The kernarg slot of packet w is reused by packet w + QSIZE, which is safe only once packet w has COMPLETED (its
-  // waves read the block while they run).  The queue's read index does not say that -- it says "consumed", and on an
-  // intercepted queue (rocprofv3) "copied out", long before the packet runs -- so the last packet of every quarter of
-  // the ring carries a completion signal, and the first packet of a quarter waits for the signal of that quarter's
-  // previous use: at most QSIZE - QSIZE / 4 packets are ever outstanding.
-  hsa_signal_t quarter[4];
-  bool quarter_used[4] = {false, false, false, false};
+  // Run-ahead bound.  The ring is cut into segments of SEG packets; the last packet of a segment carries that segment's
+  // completion signal, and the first packet of segment k waits until segment k - AHEAD has completed: at most
+  // AHEAD * SEG packets are ever outstanding.  Two reasons: (1) the kernarg slot of packet w is reused by packet
+  // w + size, which is safe only once packet w has COMPLETED (its waves read the block while they run) -- the queue's
+  // read index does not say that: it says "consumed", and on an intercepted queue (rocprofv3) "copied out", long before
+  // the packet runs; (2) a profiler's interceptor expands every packet into several on the real queue (counter
+  // collection: about five), and its overflow path did not survive a caller that runs hundreds of packets ahead
+  // (round 5: segmentation faults inside the runtime's doorbell handler with --pmc, and with --kernel-trace on 47 us
+  // kernels).  The integrator's launch window keeps a dozen packets outstanding: it never waits here.
+  static constexpr unsigned SEG = 32, AHEAD = 4, MAXSEG = 128;
+  hsa_signal_t seg_sig[MAXSEG];
+  bool seg_used[MAXSEG];
   uint64_t n_dispatched = 0, n_joins = 0, n_gates = 0;
 };
 
-constexpr uint32_t QSIZE = 1024;  // packets; the launch window keeps ~a dozen outstanding
+constexpr uint32_t QSIZE = 1024;  // packets asked for; the launch window keeps ~a dozen outstanding
 constexpr size_t SLOT = 512;      // bytes per kernarg slot (the step kernel's block: 320)
 
 std::mutex g_mu;
@@ -267,20 +273,27 @@ Queue* queue_for(hipStream_t st) {
   Queue* Q = new Queue();
   hsa_status_t s = H.hsa_queue_create(g_gpu, QSIZE, HSA_QUEUE_TYPE_SINGLE, queue_error_cb, nullptr, UINT32_MAX, UINT32_MAX, &Q->q);
   if (s != HSA_STATUS_SUCCESS) return fail("hsa_queue_create", s), delete Q, nullptr;
-  s = H.hsa_amd_memory_pool_allocate(g_dev_pool, SLOT * QSIZE, 0, reinterpret_cast<void**>(&Q->ring));
+  Q->size = Q->q->size;
+  if (Q->size < 16 || (Q->size & (Q->size - 1)) != 0) return fail("the queue's size is not a power of two >= 16"), delete Q, nullptr;
+  if (getenv("CHX_AQL_VERBOSE")) fprintf(stderr, "[chx] step queue: %u packets (asked for %u), ring at %p\n", Q->size, QSIZE, Q->q->base_address);
+  s = H.hsa_amd_memory_pool_allocate(g_dev_pool, SLOT * (size_t)Q->size, 0, reinterpret_cast<void**>(&Q->ring));
   if (s == HSA_STATUS_SUCCESS) s = H.hsa_amd_agents_allow_access(1, &g_cpu, nullptr, Q->ring);
   if (s != HSA_STATUS_SUCCESS) return fail("kernarg ring in device memory", s), delete Q, nullptr;
   s = H.hsa_signal_create(0, 0, nullptr, &Q->done);
   for (Gate& g : Q->gates)
     if (s == HSA_STATUS_SUCCESS) s = H.hsa_amd_signal_create(1, 0, nullptr, HSA_AMD_SIGNAL_AMD_GPU_ONLY, &g.sig);
-  for (hsa_signal_t& qs : Q->quarter)
-    if (s == HSA_STATUS_SUCCESS) s = H.hsa_signal_create(0, 0, nullptr, &qs);
+  const unsigned nseg = Q->size / Queue::SEG;
+  if (nseg > Queue::MAXSEG || nseg < 2 * Queue::AHEAD) return fail("unexpected queue size"), delete Q, nullptr;
+  for (unsigned i = 0; i < nseg; ++i) {
+    Q->seg_used[i] = false;
+    if (s == HSA_STATUS_SUCCESS) s = H.hsa_signal_create(0, 0, nullptr, &Q->seg_sig[i]);
+  }
   if (s != HSA_STATUS_SUCCESS) return fail("signals", s), delete Q, nullptr;
   g_queues[st] = Q;
   return Q;
 }
 
-inline void* slot_of(Queue* Q, uint64_t widx) { return reinterpret_cast<char*>(Q->q->base_address) + 64 * (widx % QSIZE); }
+inline void* slot_of(Queue* Q, uint64_t widx) { return reinterpret_cast<char*>(Q->q->base_address) + 64 * (widx % Q->size); }
 
 bool wait_zero(hsa_signal_t sig, const char* what) {
   timespec t0;
@@ -300,20 +313,26 @@ bool wait_zero(hsa_signal_t sig, const char* what) {
 }
 
 // A slot of the packet ring (and with it a kernarg slot).  Returns the write index; *completion = the signal the packet
-// must carry (the quarter's, when the slot is the last of its quarter), else a null signal.
-uint64_t reserve(Queue* Q, hsa_signal_t* completion = nullptr) {
+// must carry (its segment's, when the slot is the last of a segment), else a null signal.
+uint64_t reserve(Queue* Q, hsa_signal_t* completion) {
   const uint64_t widx = H.hsa_queue_add_write_index_relaxed(Q->q, 1);
-  const unsigned slot = (unsigned)(widx % QSIZE), quarter = slot / (QSIZE / 4);
-  if (slot % (QSIZE / 4) == 0 && Q->quarter_used[quarter]) (void)wait_zero(Q->quarter[quarter], "a quarter of the packet ring has not completed for 120 s");
-  while (widx - H.hsa_queue_load_read_index_scacquire(Q->q) >= QSIZE - 1) {
+  const unsigned QS = Q->size, nseg = QS / Queue::SEG;
+  const unsigned slot = (unsigned)(widx % QS), seg = slot / Queue::SEG;
+  if (slot % Queue::SEG == 0) {
+    const unsigned back = (seg + nseg - Queue::AHEAD) % nseg;
+    if (Q->seg_used[back]) {
+      (void)wait_zero(Q->seg_sig[back], "the step queue has made no progress for 120 s");
+      Q->seg_used[back] = false;
+    }
+  }
+  while (widx - H.hsa_queue_load_read_index_scacquire(Q->q) >= QS - 1) {
     if (g_queue_error) break;
   }
-  if (completion) *completion = hsa_signal_t{0};
-  if (slot % (QSIZE / 4) == QSIZE / 4 - 1) {
-    H.hsa_signal_store_relaxed(Q->quarter[quarter], 1);
-    Q->quarter_used[quarter] = true;
-    if (completion) *completion = Q->quarter[quarter];
-    else Q->quarter_used[quarter] = false;  // (a barrier packet of ours in that slot: see push_barrier)
+  *completion = hsa_signal_t{0};
+  if (slot % Queue::SEG == Queue::SEG - 1) {
+    H.hsa_signal_store_relaxed(Q->seg_sig[seg], 1);
+    Q->seg_used[seg] = true;
+    *completion = Q->seg_sig[seg];
   }
   return widx;
 }
@@ -322,15 +341,13 @@ inline void publish(Queue* Q, uint64_t widx, uint16_t header) {
   H.hsa_signal_store_screlease(Q->q->doorbell_signal, (hsa_signal_value_t)widx);
 }
 void push_barrier(Queue* Q, hsa_signal_t dep, hsa_signal_t completion, int acquire, int release) {
-  hsa_signal_t quarter_sig{0};
-  const uint64_t widx = reserve(Q, &quarter_sig);
-  if (quarter_sig.handle != 0) {
-    // the last slot of a quarter went to a barrier packet: it carries the quarter's signal unless it has one of its own
-    // (the join's: the join then waits for everything, and the quarter counts as completed)
-    if (completion.handle == 0) completion = quarter_sig;
-    else {
-      H.hsa_signal_store_relaxed(quarter_sig, 0);
-    }
+  hsa_signal_t seg_sig{0};
+  const uint64_t widx = reserve(Q, &seg_sig);
+  if (seg_sig.handle != 0) {
+    // the last slot of a segment went to a barrier packet: it carries the segment's signal unless it has one of its own
+    // (the join's: the join then waits for everything, and the segment counts as completed)
+    if (completion.handle == 0) completion = seg_sig;
+    else H.hsa_signal_store_relaxed(seg_sig, 0);
   }
   hsa_barrier_and_packet_t* pk = static_cast<hsa_barrier_and_packet_t*>(slot_of(Q, widx));
   pk->reserved0 = 0;
@@ -390,11 +407,11 @@ int chx_aql_dispatch(hipStream_t st, const AqlKernel* k, unsigned blocks, const 
     __atomic_fetch_add(&chx_aql_open_count, 1, __ATOMIC_RELAXED);
     acquire = HSA_FENCE_SCOPE_AGENT;
   }
-  hsa_signal_t quarter_sig{0};
-  const uint64_t widx = reserve(Q, &quarter_sig);
+  hsa_signal_t seg_sig{0};
+  const uint64_t widx = reserve(Q, &seg_sig);
   // the argument block goes to device memory through the BAR; the read-back of its last word completes the posted
   // writes before the doorbell can make the packet processor fetch them
-  char* ka = Q->ring + SLOT * (widx % QSIZE);
+  char* ka = Q->ring + SLOT * (widx % Q->size);
   memcpy(ka, kernarg, nbytes);
   __builtin_ia32_sfence();
   (void)*reinterpret_cast<volatile uint32_t*>(ka + ((nbytes - 4) & ~(size_t)3));
@@ -408,7 +425,7 @@ int chx_aql_dispatch(hipStream_t st, const AqlKernel* k, unsigned blocks, const 
   pk->kernel_object = k->object;
   pk->kernarg_address = ka;
   pk->reserved2 = 0;
-  pk->completion_signal = quarter_sig;
+  pk->completion_signal = seg_sig;
   const int release = release_agent ? HSA_FENCE_SCOPE_AGENT : chx_aql_hot_release();
   publish(Q, widx, (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                               (acquire << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (release << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE)));
