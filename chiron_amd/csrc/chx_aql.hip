@@ -131,6 +131,7 @@ constexpr size_t SLOT = 512;      // bytes per kernarg slot (the step kernel's b
 std::mutex g_mu;
 int g_state = 0;  // 0 untried, 1 on, -1 off
 bool g_fence_none = true;
+int g_device = -1;  // the HIP device the queue's agent is (the one current when the queue was set up)
 hsa_agent_t g_gpu{}, g_cpu{};
 hsa_amd_memory_pool_t g_dev_pool{};
 bool g_have_gpu = false, g_have_cpu = false, g_have_pool = false;
@@ -223,6 +224,7 @@ bool init_locked() {
   g_fence_none = !(fe && (fe[0] == 'a' || fe[0] == 'A'));  // "agent": HIP's scopes on every packet
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return fail("no HIP device"), false;
+  g_device = dev;
   void* lib = find_hsa();
   if (!lib) return fail("the HSA runtime of this process's HIP runtime was not found"), false;
 #define X(name)                                                      \
@@ -374,7 +376,11 @@ bool chx_aql_on() {
     if (g_state == 0) __atomic_store_n(&g_state, init_locked() ? 1 : -1, __ATOMIC_RELEASE);
     st = g_state;
   }
-  return st == 1 && !g_queue_error;
+  if (st != 1 || g_queue_error) return false;
+  // (one process, one GPU is the deployment -- a rank per card; a thread that has made ANOTHER device current launches
+  // through HIP as before: the queue belongs to the card it was opened on)
+  int dev = -1;
+  return hipGetDevice(&dev) == hipSuccess && dev == g_device;
 }
 
 const AqlKernel* chx_aql_kernel(const char* prefix) {

@@ -643,18 +643,15 @@ def steps_join() -> None:
     check(_lib.load().chx_steps_join(_stream()), "chx_steps_join")
 
 
-_queue_on = None
+_sq_probe = (C.c_int64 * 8)()
 
 
 def step_queue_on() -> bool:
-    """Do the fused step launches of this process go through the step queue?  (Decided once, at the first step launch or
-    here: include/chx.h.)"""
-    global _queue_on
-    if _queue_on is None:
-        out = (C.c_int64 * 8)()
-        check(_lib.load().chx_step_queue_info(out, None), "chx_step_queue_info")
-        _queue_on = bool(out[0])
-    return _queue_on
+    """Do the fused step launches of the calling thread go through the step queue?  (The queue belongs to the device it
+    was opened on; asked every time -- a ctypes call -- because the answer depends on the thread's current device.)"""
+    out = (C.c_int64 * 8)()
+    check(_lib.load().chx_step_queue_info(out, None), "chx_step_queue_info")
+    return bool(out[0])
 
 
 def step_queue_info() -> dict:

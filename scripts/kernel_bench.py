@@ -89,9 +89,10 @@ for wl in sys.argv[1:] or ["c3", "c4"]:
         spin = float(os.environ.get("KB_SPIN_S", "0"))
         t_w = time.perf_counter()
         while time.perf_counter() - t_w < spin:
-            for _ in range(50):
-                one()
-            ops.steps_join()
+            # (the state-neutral pair-force kernel, as bench.py's time_kernels does: the step kernel would age the list,
+            # and under a profiler its intercepted queue does not keep the card at its loaded clock)
+            for _ in range(200):
+                force_launch()
             torch.cuda.synchronize()
         # the pair-force kernel is timed AFTER the clock warm-up above (which runs the STEP kernel on the state's own
         # buffers: x4 / fl, which the force launches read, are untouched): at the card's idle clock level the same
