@@ -1,4 +1,5 @@
-# GPU test suite under the tuning overrides (lanes per particle, pruning cadence, launch queue and its poll policy, build
+# GPU test suite under the tuning overrides (step queue off / with HIP's fence scopes -- every other row runs with the
+# default: steady-state packets without cache fences --, lanes per particle, pruning cadence, launch queue and its poll policy, build
 # kernel / candidate lists / id slots / half rows, list carry-over and its device check, Monte Carlo inner list): every
 # combination must pass (tests that exercise a feature the override switches off skip themselves)
 # usage: bash scripts/test_matrix.sh [first] [count]     -> gpurun_out/test_matrix_<first>.log
@@ -7,7 +8,7 @@ mkdir -p gpurun_out
 first=${1:-0}; count=${2:-100}; k=0
 log=gpurun_out/test_matrix_$first.log
 : > $log
-for env in "CHX_SYNC_REBUILD=1" "CHX_LAUNCH_WINDOW=1" "CHX_LAUNCH_WINDOW=3 CHX_FL_G=2" "CHX_LAUNCH_WINDOW=500" "CHX_MC_DECIDE_LAUNCH=1" \
+for env in "CHX_AQL=0" "CHX_AQL_FENCE=agent" "CHX_AQL=0 CHX_LAUNCH_WINDOW=3" "CHX_AQL_FENCE=agent CHX_FL_G=8" "CHX_SYNC_REBUILD=1" "CHX_LAUNCH_WINDOW=1" "CHX_LAUNCH_WINDOW=3 CHX_FL_G=2" "CHX_LAUNCH_WINDOW=500" "CHX_MC_DECIDE_LAUNCH=1" \
            "CHX_BUILD_KERNEL=cell" "CHX_BUILD_KERNEL=cell CHX_BUILD_SPLIT=3" "CHX_BUILD_KERNEL=particle" \
            "CHX_FL_G=1" "CHX_FL_G=8" "CHX_FL_G=16" "CHX_FL_G=64" "CHX_PRUNE_EVERY=0" "CHX_PRUNE_EVERY=1" \
            "CHX_PRUNE_EVERY=7 CHX_INNER_SKIN=0.02" "CHX_PRUNE_EVERY=50 CHX_INNER_SKIN=0.3" \
