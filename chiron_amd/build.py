@@ -20,6 +20,13 @@ OUT = os.path.join(HERE, "libchx.so")
 # and dispatches with its own AQL packets -- the device half of STEP_UNIT compiled by itself, same flags, same ISA
 STEP_UNIT = "chx_lj.hip"
 STEP_OUT = os.path.join(HERE, "libchx_step.hsaco")
+# ... and the device halves of the units whose kernels ride on the queue while a run() is in progress (unpack, the list
+# build chain, pack: csrc/chx_launch.h): libchx_k_<unit>.hsaco, loaded when present
+QUEUE_UNITS = {"chx_core.hip": "core", "chx_neighbors.hip": "neighbors", "chx_cell_fl.hip": "cell_fl"}
+
+
+def queue_object(unit: str) -> str:
+    return os.path.join(HERE, f"libchx_k_{QUEUE_UNITS[unit]}.hsaco")
 
 # -ffp-contract=off: the neighbor predicates and the BAOAB update must round once
 # per operation, like the reference's un-fused fp32 ops.
@@ -71,7 +78,8 @@ def step_object_current() -> bool:
     """libchx_step.hsaco carries no hash of its own: a stamp file beside it names the tree it was made from."""
     try:
         with open(STEP_OUT + ".hash") as fh:
-            return fh.read().strip() == source_hash() and os.path.exists(STEP_OUT)
+            return (fh.read().strip() == source_hash() and os.path.exists(STEP_OUT)
+                    and all(os.path.exists(queue_object(u)) for u in QUEUE_UNITS))
     except OSError:
         return False
 
@@ -151,12 +159,15 @@ def _build_locked(hipcc: str, objdir: str, force: bool, verbose: bool) -> str:
 
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as pool:
         step_job = pool.submit(compile_step_object, os.path.join(CSRC, STEP_UNIT))
+        queue_jobs = {u: pool.submit(compile_step_object, os.path.join(CSRC, u)) for u in QUEUE_UNITS}
         objs = list(pool.map(compile_one, sources()))
         step_obj = step_job.result()
-    for stale in set(glob.glob(os.path.join(objdir, "*.hsaco"))) - {step_obj}:
+        queue_objs = {u: j.result() for u, j in queue_jobs.items()}
+    for stale in set(glob.glob(os.path.join(objdir, "*.hsaco"))) - {step_obj} - set(queue_objs.values()):
         os.remove(stale)
-    shutil.copyfile(step_obj, STEP_OUT + tag)
-    os.replace(STEP_OUT + tag, STEP_OUT)
+    for src_obj, dst in [(step_obj, STEP_OUT)] + [(o, queue_object(u)) for u, o in queue_objs.items()]:
+        shutil.copyfile(src_obj, dst + tag)
+        os.replace(dst + tag, dst)
     for stale in set(glob.glob(os.path.join(objdir, "*.o"))) - set(objs):  # (under the lock: nobody is about to link them)
         os.remove(stale)
     tmp = OUT + tag

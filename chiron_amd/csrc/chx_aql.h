@@ -25,3 +25,16 @@ int chx_aql_dispatch(hipStream_t st, const AqlKernel* k, unsigned blocks, const 
 void chx_aql_join(hipStream_t st);
 // number of step queues with packets outstanding (fast path of chx_stream)
 extern int chx_aql_open_count;
+
+// ---- any libchx kernel through the queue (round 5, second half: the whole of run() rides on it) ----
+// Packets are outstanding for `st` and the queue takes other kernels than the steps (CHX_AQL_SCOPE=steps: it does not):
+// a launch that goes to the queue now stays behind them without a join.
+bool chx_aql_active(hipStream_t st);
+// the kernel whose host-side stub is `host_fn` (hipKernelNameRefByPtr -> the code objects' symbol table), or NULL
+const AqlKernel* chx_aql_kernel_of(const void* host_fn, hipStream_t st);
+// One packet for any grid; `explicit_bytes` of packed arguments (the implicit arguments of code object v5 -- block
+// counts, group sizes, grid dimensions -- are appended when the kernel's segment asks for them); agent-scope release.
+int chx_aql_dispatch_any(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, const void* kernarg, size_t explicit_bytes);
+// open the queue for `st` (gate behind the stream's work) without dispatching anything: what follows on the queue-capable
+// entry points then rides on the queue
+int chx_aql_open(hipStream_t st);

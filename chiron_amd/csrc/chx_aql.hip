@@ -107,6 +107,7 @@ struct Queue {
   char* ring = nullptr;  // kernarg slots in device memory, written by the host through the BAR
   uint32_t size = 0;     // packets in the ring: what the runtime made of the request (an intercepted queue may differ)
   bool open = false;     // packets outstanding since the last join
+  bool fresh = false;    // the gate is up and no kernel packet has followed it yet
   hsa_signal_t done{};   // completion signal of the join barrier
   Gate gates[4];
   unsigned gate_next = 0;
@@ -126,11 +127,12 @@ struct Queue {
 };
 
 constexpr uint32_t QSIZE = 1024;  // packets asked for; the launch window keeps ~a dozen outstanding
-constexpr size_t SLOT = 512;      // bytes per kernarg slot (the step kernel's block: 320)
+constexpr size_t SLOT = 1024;     // bytes per kernarg slot (the step kernel's block: 320; any kernel's + 256 implicit)
 
 std::mutex g_mu;
 int g_state = 0;  // 0 untried, 1 on, -1 off
 bool g_fence_none = true;
+bool g_scope_run = true;  // every queue-capable launch rides on an open queue (CHX_AQL_SCOPE=steps: the step launches only)
 int g_device = -1;  // the HIP device the queue's agent is (the one current when the queue was set up)
 hsa_agent_t g_gpu{}, g_cpu{};
 hsa_amd_memory_pool_t g_dev_pool{};
@@ -201,6 +203,7 @@ hsa_status_t sym_cb(hsa_executable_t, hsa_agent_t, hsa_executable_symbol_t s, vo
   const size_t paren = key.find('(');
   if (paren != std::string::npos) key.resize(paren);
   g_kernels[key] = k;
+  g_kernels[name] = k;  // (the mangled symbol too: what hipKernelNameRefByPtr hands out)
   return HSA_STATUS_SUCCESS;
 }
 void queue_error_cb(hsa_status_t s, hsa_queue_t*, void*) {
@@ -220,6 +223,8 @@ std::string own_dir() {
 bool init_locked() {
   const char* e = getenv("CHX_AQL");
   if (e && e[0] == '0') return fail("off (CHX_AQL=0)"), false;
+  const char* sc = getenv("CHX_AQL_SCOPE");
+  g_scope_run = !(sc && (sc[0] == 's' || sc[0] == 'S'));
   const char* fe = getenv("CHX_AQL_FENCE");
   g_fence_none = !(fe && (fe[0] == 'a' || fe[0] == 'A'));  // "agent": HIP's scopes on every packet
   int dev = 0;
@@ -250,20 +255,36 @@ bool init_locked() {
   if (!g_have_gpu || !g_have_cpu) return fail("the HIP device was not found among the HSA agents"), false;
   H.hsa_amd_agent_iterate_memory_pools(g_gpu, pool_cb, nullptr);
   if (!g_have_pool) return fail("no device memory pool"), false;
-  // the step kernels' code object
-  const std::string path = own_dir() + "/libchx_step.hsaco";
-  const int fd = open(path.c_str(), O_RDONLY);
-  if (fd < 0) return fail("libchx_step.hsaco not found beside libchx.so"), false;
-  hsa_code_object_reader_t reader;
-  s = H.hsa_code_object_reader_create_from_file(fd, &reader);
-  if (s != HSA_STATUS_SUCCESS) return close(fd), fail("code object reader", s), false;
+  // the kernels' code objects: libchx_step.hsaco (the step kernels: required) and libchx_k_*.hsaco (the other
+  // translation units' device halves: optional, each one makes its kernels dispatchable through the queue)
   hsa_executable_t exe;
   s = H.hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &exe);
-  if (s == HSA_STATUS_SUCCESS) s = H.hsa_executable_load_agent_code_object(exe, g_gpu, reader, nullptr, nullptr);
-  if (s == HSA_STATUS_SUCCESS) s = H.hsa_executable_freeze(exe, nullptr);
-  if (s != HSA_STATUS_SUCCESS) return close(fd), fail("loading libchx_step.hsaco", s), false;
+  if (s != HSA_STATUS_SUCCESS) return fail("hsa_executable_create_alt", s), false;
+  const std::string dir = own_dir();
+  std::vector<std::string> files = {dir + "/libchx_step.hsaco"};
+  for (const char* unit : {"core", "langevin", "neighbors", "cell_fl", "mc"}) files.push_back(dir + "/libchx_k_" + unit + ".hsaco");
+  int loaded = 0;
+  for (size_t i = 0; i < files.size(); ++i) {
+    const int fd = open(files[i].c_str(), O_RDONLY);
+    if (fd < 0) {
+      if (i == 0) return fail("libchx_step.hsaco not found beside libchx.so"), false;
+      continue;
+    }
+    hsa_code_object_reader_t reader;
+    s = H.hsa_code_object_reader_create_from_file(fd, &reader);
+    if (s == HSA_STATUS_SUCCESS) s = H.hsa_executable_load_agent_code_object(exe, g_gpu, reader, nullptr, nullptr);
+    close(fd);
+    if (s != HSA_STATUS_SUCCESS) {
+      if (i == 0) return fail("loading libchx_step.hsaco", s), false;
+      if (getenv("CHX_AQL_VERBOSE")) fprintf(stderr, "[chx] step queue: %s not loaded\n", files[i].c_str());
+      continue;
+    }
+    ++loaded;
+  }
+  s = H.hsa_executable_freeze(exe, nullptr);
+  if (s != HSA_STATUS_SUCCESS) return fail("hsa_executable_freeze", s), false;
   H.hsa_executable_iterate_agent_symbols(exe, g_gpu, sym_cb, nullptr);
-  close(fd);
+  if (getenv("CHX_AQL_VERBOSE")) fprintf(stderr, "[chx] step queue: %d code objects, %zu kernel names\n", loaded, g_kernels.size());
   if (g_kernels.empty()) return fail("libchx_step.hsaco holds no kernels"), false;
   return true;
 }
@@ -390,9 +411,27 @@ const AqlKernel* chx_aql_kernel(const char* prefix) {
 
 int chx_aql_hot_release() { return g_fence_none ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT; }
 
-int chx_aql_dispatch(hipStream_t st, const AqlKernel* k, unsigned blocks, const void* kernarg, size_t nbytes, bool release_agent) {
-  if (nbytes > SLOT - 64 || nbytes < k->kernarg_size) {
-    chx_set_error("step queue: argument block of %zu bytes does not fit the kernel's %u", nbytes, k->kernarg_size);
+namespace {
+
+// the HIP -> queue hand-over: behind everything the stream holds
+void open_gate(Queue* Q, hipStream_t st) {
+  Gate& g = Q->gates[Q->gate_next++ % 4];
+  H.hsa_signal_store_relaxed(g.sig, 1);
+  long long* value = reinterpret_cast<long long*>(const_cast<int64_t*>(&reinterpret_cast<amd_signal_t*>(g.sig.handle)->value));
+  hipLaunchKernelGGL(k_aql_gate_open, dim3(1), dim3(1), 0, st, value);
+  push_barrier(Q, g.sig, hsa_signal_t{0}, HSA_FENCE_SCOPE_SYSTEM, HSA_FENCE_SCOPE_NONE);
+  Q->open = true;
+  Q->fresh = true;
+  Q->n_gates++;
+  __atomic_fetch_add(&chx_aql_open_count, 1, __ATOMIC_RELAXED);
+}
+
+int dispatch_core(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, const void* kernarg, size_t nbytes, int release) {
+  // (the segment may be shorter than the caller's block -- trailing padding of a by-value struct -- never longer)
+  const size_t seg = k->kernarg_size;
+  if (nbytes + 256 > SLOT || nbytes > seg + 8) {
+    // more explicit bytes than the kernel declares (+ alignment slack): the packed block does not belong to this kernel
+    chx_set_error("step queue: argument block of %zu bytes does not fit the kernel's segment of %zu", nbytes, seg);
     return CHX_ERR_INVALID;
   }
   Queue* Q = queue_for(st);
@@ -401,41 +440,99 @@ int chx_aql_dispatch(hipStream_t st, const AqlKernel* k, unsigned blocks, const 
     return CHX_ERR_LAUNCH;
   }
   int acquire = g_fence_none ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT;
-  if (!Q->open) {
-    // first packet since the last join: behind everything the HIP stream holds
-    Gate& g = Q->gates[Q->gate_next++ % 4];
-    H.hsa_signal_store_relaxed(g.sig, 1);
-    long long* value = reinterpret_cast<long long*>(const_cast<int64_t*>(&reinterpret_cast<amd_signal_t*>(g.sig.handle)->value));
-    hipLaunchKernelGGL(k_aql_gate_open, dim3(1), dim3(1), 0, st, value);
-    push_barrier(Q, g.sig, hsa_signal_t{0}, HSA_FENCE_SCOPE_SYSTEM, HSA_FENCE_SCOPE_NONE);
-    Q->open = true;
-    Q->n_gates++;
-    __atomic_fetch_add(&chx_aql_open_count, 1, __ATOMIC_RELAXED);
-    acquire = HSA_FENCE_SCOPE_AGENT;
-  }
+  if (!Q->open) open_gate(Q, st);
+  if (Q->fresh) acquire = HSA_FENCE_SCOPE_AGENT, Q->fresh = false;  // first packet since the last join
   hsa_signal_t seg_sig{0};
   const uint64_t widx = reserve(Q, &seg_sig);
   // the argument block goes to device memory through the BAR; the read-back of its last word completes the posted
   // writes before the doorbell can make the packet processor fetch them
   char* ka = Q->ring + SLOT * (widx % Q->size);
   memcpy(ka, kernarg, nbytes);
+  size_t end = nbytes;
+  if (seg > ((nbytes + 7) & ~(size_t)7)) {
+    // implicit arguments (code object v5): block counts, group sizes, remainders, global offsets, grid dimensions
+    const size_t ib = (nbytes + 7) & ~(size_t)7;
+    char im[256];
+    memset(im, 0, sizeof(im));
+    const uint32_t bc[3] = {grid.x, grid.y, grid.z};
+    memcpy(im, bc, 12);
+    const uint16_t gs[3] = {(uint16_t)block.x, (uint16_t)block.y, (uint16_t)block.z};
+    memcpy(im + 12, gs, 6);
+    const uint16_t dims = (uint16_t)(grid.z * block.z > 1 ? 3 : (grid.y * block.y > 1 ? 2 : 1));
+    memcpy(im + 64, &dims, 2);
+    size_t want = seg - ib;
+    if (want > sizeof(im)) want = sizeof(im);
+    if (ib + want > SLOT) want = SLOT - ib;
+    memcpy(ka + ib, im, want);
+    end = ib + want;
+  }
   __builtin_ia32_sfence();
-  (void)*reinterpret_cast<volatile uint32_t*>(ka + ((nbytes - 4) & ~(size_t)3));
+  (void)*reinterpret_cast<volatile uint32_t*>(ka + ((end - 4) & ~(size_t)3));
   hsa_kernel_dispatch_packet_t* pk = static_cast<hsa_kernel_dispatch_packet_t*>(slot_of(Q, widx));
-  pk->setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
-  pk->workgroup_size_x = 256, pk->workgroup_size_y = 1, pk->workgroup_size_z = 1;
+  const int ndim = grid.z * block.z > 1 ? 3 : (grid.y * block.y > 1 ? 2 : 1);
+  pk->setup = (uint16_t)(ndim << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS);
+  pk->workgroup_size_x = (uint16_t)block.x, pk->workgroup_size_y = (uint16_t)block.y, pk->workgroup_size_z = (uint16_t)block.z;
   pk->reserved0 = 0;
-  pk->grid_size_x = blocks * 256u, pk->grid_size_y = 1, pk->grid_size_z = 1;
+  pk->grid_size_x = grid.x * block.x, pk->grid_size_y = grid.y * block.y, pk->grid_size_z = grid.z * block.z;
   pk->private_segment_size = k->private_size;
   pk->group_segment_size = k->group_size;
   pk->kernel_object = k->object;
   pk->kernarg_address = ka;
   pk->reserved2 = 0;
   pk->completion_signal = seg_sig;
-  const int release = release_agent ? HSA_FENCE_SCOPE_AGENT : chx_aql_hot_release();
   publish(Q, widx, (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                               (acquire << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (release << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE)));
   Q->n_dispatched++;
+  return CHX_OK;
+}
+
+std::mutex g_name_mu;
+std::map<const void*, const AqlKernel*> g_by_host_fn;
+
+}  // namespace
+
+int chx_aql_dispatch(hipStream_t st, const AqlKernel* k, unsigned blocks, const void* kernarg, size_t nbytes, bool release_agent) {
+  if (nbytes < k->kernarg_size) {
+    chx_set_error("step queue: argument block of %zu bytes is shorter than the kernel's %u", nbytes, k->kernarg_size);
+    return CHX_ERR_INVALID;
+  }
+  return dispatch_core(st, k, dim3(blocks), dim3(256), kernarg, k->kernarg_size, release_agent ? HSA_FENCE_SCOPE_AGENT : chx_aql_hot_release());
+}
+
+int chx_aql_dispatch_any(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, const void* kernarg, size_t explicit_bytes) {
+  return dispatch_core(st, k, grid, block, kernarg, explicit_bytes, HSA_FENCE_SCOPE_AGENT);
+}
+
+bool chx_aql_active(hipStream_t st) {
+  if (!g_scope_run || __atomic_load_n(&chx_aql_open_count, __ATOMIC_RELAXED) <= 0 || g_queue_error) return false;
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_queues.find(st);
+  return it != g_queues.end() && it->second->open;
+}
+
+const AqlKernel* chx_aql_kernel_of(const void* host_fn, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_name_mu);
+  auto it = g_by_host_fn.find(host_fn);
+  if (it != g_by_host_fn.end()) return it->second;
+  const char* name = hipKernelNameRefByPtr(host_fn, st);
+  const AqlKernel* k = nullptr;
+  if (name != nullptr) {
+    auto f = g_kernels.find(name);
+    if (f != g_kernels.end()) k = &f->second;
+  }
+  if (k == nullptr && getenv("CHX_AQL_VERBOSE")) fprintf(stderr, "[chx] step queue: no code object holds %s\n", name ? name : "(unnamed kernel)");
+  g_by_host_fn[host_fn] = k;
+  return k;
+}
+
+int chx_aql_open(hipStream_t st) {
+  if (!chx_aql_on() || !g_scope_run) return CHX_OK;
+  Queue* Q = queue_for(st);
+  if (!Q || g_queue_error) {
+    chx_set_error("%s", g_err);
+    return CHX_ERR_LAUNCH;
+  }
+  if (!Q->open) open_gate(Q, st);
   return CHX_OK;
 }
 

@@ -13,6 +13,7 @@
 #include <type_traits>
 
 #include "chx_common.h"
+#include "chx_launch.h"
 #include "chx_internal.h"
 #include "chx_cell.h"
 
@@ -508,7 +509,7 @@ extern "C" int chx_cell_bin_fl(const float* xyz, int32_t n, chx_box_t box, float
   if (rc != CHX_OK) return rc;
   CellGrid grid;
   rc = chx_cell_prepare(xyz, n, box, cutoff_plus_skin, nc_h, cell_of, cell_count, cell_start, sorted_ids, status8, 8, &grid,
-                        chx_stream(stream), xs4_out, &rd,  // (the cell sort also emits xs4 and the candidate lists)
+                        chx_stream_q(stream), xs4_out, &rd,  // (the cell sort also emits xs4 and the candidate lists)
                         riders ? riders->cand_list : nullptr, riders ? riders->cand_len : nullptr,
                         riders ? riders->cand_cap : 0);
   if (rc != CHX_OK) return rc;
@@ -533,7 +534,7 @@ extern "C" int chx_nl_rows_cell_fl(int32_t n, int32_t m, chx_box_t box, float cu
   CHX_REQUIRE(box.periodic && box.lx > 0 && box.ly > 0 && box.lz > 0, "periodic box required");
   CHX_REQUIRE(nc_h[0] >= 3 && nc_h[1] >= 3 && nc_h[2] >= 3 && nc_h[0] <= 1024 && nc_h[1] <= 1024 && nc_h[2] <= 1024,
               "need 3 .. 1024 cells per axis");
-  hipStream_t st = chx_stream(stream);
+  hipStream_t st = chx_stream_q(stream);  // (CHX_LAUNCH below: rides on the step queue while a run() is in progress)
   CellGrid grid;
   grid.ncx = nc_h[0]; grid.ncy = nc_h[1]; grid.ncz = nc_h[2];
   grid.sx = (float)nc_h[0] / box.lx; grid.sy = (float)nc_h[1] / box.ly; grid.sz = (float)nc_h[2] / box.lz;
@@ -548,21 +549,21 @@ extern "C" int chx_nl_rows_cell_fl(int32_t n, int32_t m, chx_box_t box, float cu
   const bool per_particle = forced == 1 || (forced == 0 && (int64_t)grid.ncx * grid.ncy * grid.ncz < 8192);
   if (per_particle) {
     const CandLists cl = {cand_cap > 0 ? cand_list : nullptr, cand_len, cand_cap};
-    hipLaunchKernelGGL(half ? k_nl_build_cell_fl<true> : k_nl_build_cell_fl<false>, dim3(wb), dim3(256), 0, st, xs, n, m,
-                       make_box3(box), T, grid, cell_of, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g,
-                       chunks * CHX_FL_QUAD * g, fl_out, deg_out, status8, cl);
+    CHX_LAUNCH(half ? k_nl_build_cell_fl<true> : k_nl_build_cell_fl<false>, dim3(wb), dim3(256), st, xs, n, m, make_box3(box), T,
+               grid, cell_of, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, chunks * CHX_FL_QUAD * g, fl_out,
+               deg_out, status8, cl);
   } else {
     const int ncell = grid.ncx * grid.ncy * grid.ncz;
     static const int split_env = [] { const char* e = getenv("CHX_BUILD_SPLIT"); return e ? atoi(e) : 0; }();
     int split = split_env > 0 ? split_env : (8192 + ncell - 1) / ncell;  // (only > 1 when the kernel is forced)
     split = split < 1 ? 1 : (split > 16 ? 16 : split);
     const unsigned cb = (unsigned)(((int64_t)ncell * split * CHX_WAVE + 255) / 256);
-    hipLaunchKernelGGL(half ? k_nl_build_cellwise_fl<true> : k_nl_build_cellwise_fl<false>, dim3(cb), dim3(256), 0, st, xs,
-                       n, m, make_box3(box), T, grid, ncell, split, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out,
-                       g, chunks * CHX_FL_QUAD * g, fl_out, deg_out, status8);
+    CHX_LAUNCH(half ? k_nl_build_cellwise_fl<true> : k_nl_build_cellwise_fl<false>, dim3(cb), dim3(256), st, xs, n, m,
+               make_box3(box), T, grid, ncell, split, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g,
+               chunks * CHX_FL_QUAD * g, fl_out, deg_out, status8);
   }
   const unsigned sb = (unsigned)((n + 255) / 256 < 64 ? (n + 255) / 256 : 64);
-  hipLaunchKernelGGL(k_build_epilogue, dim3(sb), dim3(256), 0, st, n_nbr_out, deg_out, n, m, status8, publish_host_dst8);
+  CHX_LAUNCH(k_build_epilogue, dim3(sb), dim3(256), st, n_nbr_out, deg_out, n, m, status8, publish_host_dst8);
   return chx_check_launch("chx_nl_rows_cell_fl");
 }
 
@@ -661,10 +662,9 @@ extern "C" int chx_pack_langevin(const float* x3, const float* v3, const float* 
   CHX_REQUIRE(n == 0 || (x3 && v3 && mass && x4_out && v_out && mass_out), "null pointer");
   CHX_REQUIRE(!ref4_out || ref3, "ref4_out without ref3");
   const unsigned blocks = n > 0 ? (unsigned)((n + 255) / 256) : 1u;
-  hipLaunchKernelGGL(k_pack_langevin, dim3(blocks), dim3(256), 0, chx_stream(stream), x3, v3, mass,
-                     ref3, perm, n, reinterpret_cast<float4*>(x4_out), v_out, mass_out,
-                     reinterpret_cast<float4*>(ref4_out), ctrl_reset, (int)ctrl_keep, publish_src8,
-                     publish_host_dst8);
+  CHX_LAUNCH(k_pack_langevin, dim3(blocks), dim3(256), chx_stream_q(stream), x3, v3, mass, ref3, perm, n,
+             reinterpret_cast<float4*>(x4_out), v_out, mass_out, reinterpret_cast<float4*>(ref4_out), ctrl_reset, (int)ctrl_keep,
+             publish_src8, publish_host_dst8);
   return chx_check_launch("chx_pack_langevin");
 }
 
@@ -729,10 +729,10 @@ extern "C" int chx_pack_validate_langevin(chx_box_t box, float skin, int32_t ste
   CHX_REQUIRE(x3 && v3 && mass && x4_out && v_out && mass_out && snap4 && sync2 && ctrl_reset, "null pointer");
   CHX_REQUIRE(!ref4_out || ref3, "ref4_out without ref3");
   CHX_REQUIRE(skin > 0.f && step >= 0, "need skin > 0 and step >= 0");
-  hipLaunchKernelGGL(k_pack_validate_langevin, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, chx_stream(stream), x3, v3,
-                     mass, ref3, perm, n, reinterpret_cast<float4*>(x4_out), v_out, mass_out,
-                     reinterpret_cast<float4*>(ref4_out), ctrl_reset, (int)ctrl_keep, reinterpret_cast<const float4*>(snap4),
-                     make_box3(box), chx_cutoff_threshold_h(skin * 0.5f), (int)step, host_ctrl, sync2);
+  CHX_LAUNCH(k_pack_validate_langevin, dim3((unsigned)((n + 255) / 256)), dim3(256), chx_stream_q(stream), x3, v3, mass, ref3,
+             perm, n, reinterpret_cast<float4*>(x4_out), v_out, mass_out, reinterpret_cast<float4*>(ref4_out), ctrl_reset,
+             (int)ctrl_keep, reinterpret_cast<const float4*>(snap4), make_box3(box), chx_cutoff_threshold_h(skin * 0.5f),
+             (int)step, host_ctrl, sync2);
   return chx_check_launch("chx_pack_validate_langevin");
 }
 
@@ -759,8 +759,8 @@ extern "C" int chx_validate_snap(const float* x4, const float* snap4, int32_t n,
   CHX_REQUIRE(n >= 1, "n < 1");
   CHX_REQUIRE(x4 && snap4 && ctrl, "null pointer");
   CHX_REQUIRE(skin > 0.f && step >= 0, "need skin > 0 and step >= 0");
-  hipLaunchKernelGGL(k_validate_snap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, chx_stream(stream),
-                     reinterpret_cast<const float4*>(x4), reinterpret_cast<const float4*>(snap4), n, make_box3(box),
-                     chx_cutoff_threshold_h(skin * 0.5f), (int)step, ctrl, host_ctrl);
+  CHX_LAUNCH(k_validate_snap, dim3((unsigned)((n + 255) / 256)), dim3(256), chx_stream_q(stream),
+             reinterpret_cast<const float4*>(x4), reinterpret_cast<const float4*>(snap4), n, make_box3(box),
+             chx_cutoff_threshold_h(skin * 0.5f), (int)step, ctrl, host_ctrl);
   return chx_check_launch("chx_validate_snap");
 }

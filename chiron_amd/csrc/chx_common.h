@@ -31,6 +31,9 @@ static inline hipStream_t chx_stream(chx_stream_t s) {
 }
 // (the step launches themselves: they go behind the outstanding ones)
 static inline hipStream_t chx_stream_steps(chx_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+// (entry points whose launches all go through CHX_LAUNCH, chx_launch.h: they ride on the queue while it is open, so
+// they do not join)
+static inline hipStream_t chx_stream_q(chx_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // word t of a freshly reset control block (include/chx.h: chx_langevin_t::ctrl, chx_ctrl_reset)
 __host__ __device__ __forceinline__ int chx_ctrl_reset_word(int t) {

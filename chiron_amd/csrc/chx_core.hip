@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "chx_common.h"
+#include "chx_launch.h"
 
 static thread_local char g_err[512] = "";
 
@@ -148,8 +149,7 @@ extern "C" int chx_permute_unpack(const float* src, int32_t src_stride, const ui
   CHX_REQUIRE(src_stride == 3 || src_stride == 4, "src_stride must be 3 or 4");
   if (n == 0) return CHX_OK;
   CHX_REQUIRE(src && dst3, "null pointer");
-  hipLaunchKernelGGL(k_permute_unpack, dim3((n + 255) / 256), dim3(256), 0, chx_stream(stream), src,
-                     src_stride, perm, n, dst3);
+  CHX_LAUNCH(k_permute_unpack, dim3((n + 255) / 256), dim3(256), chx_stream_q(stream), src, src_stride, perm, n, dst3);
   return chx_check_launch("chx_permute_unpack");
 }
 
@@ -175,8 +175,8 @@ extern "C" int chx_unpack_langevin(const float* x4, const float* v, const uint32
   CHX_REQUIRE(n >= 0, "n < 0");
   if (n == 0) return CHX_OK;
   CHX_REQUIRE(x4 && v && x3_out && v3_out, "null pointer");
-  hipLaunchKernelGGL(k_unpack_langevin, dim3((n + 255) / 256), dim3(256), 0, chx_stream(stream),
-                     reinterpret_cast<const float4*>(x4), v, perm, n, x3_out, v3_out);
+  CHX_LAUNCH(k_unpack_langevin, dim3((n + 255) / 256), dim3(256), chx_stream_q(stream), reinterpret_cast<const float4*>(x4), v,
+             perm, n, x3_out, v3_out);
   return chx_check_launch("chx_unpack_langevin");
 }
 

@@ -8,6 +8,7 @@
 #include <math.h>
 
 #include "chx_common.h"
+#include "chx_launch.h"
 #include "chx_internal.h"
 #include "chx_cell.h"
 
@@ -441,19 +442,17 @@ int chx_cell_prepare(const float* xyz, int n, chx_box_t box, float cutoff_plus_s
   // (no zeroing launch: cell_count arrives zeroed -- the caller's allocation, then k_cell_sort of the previous chain)
   const unsigned pb = (unsigned)((n + 255) / 256);
   const bool slotted = rd.cell_slots != nullptr && rd.cell_slot_cap > 0 && status_len >= 8;
-  hipLaunchKernelGGL(k_cell_assign, dim3(pb), dim3(256), 0, st, xyz, n, b3, g, cell_of, cell_count, rd.xyz_copy,
-                     slotted ? rd.cell_slots : nullptr, rd.cell_slot_cap);
-  hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, st, cell_count, cell_start, ncell, status, status_len, rd.ctrl,
-                     rd.ctrl_keep);
-  if (!slotted)
-    hipLaunchKernelGGL(k_cell_scatter, dim3(pb), dim3(256), 0, st, cell_of, n, cell_start, cell_count, sorted_ids);
+  // (CHX_LAUNCH: on the step queue while a run() has packets outstanding there, chx_launch.h)
+  CHX_LAUNCH(k_cell_assign, dim3(pb), dim3(256), st, xyz, n, b3, g, cell_of, cell_count, rd.xyz_copy,
+             slotted ? rd.cell_slots : nullptr, rd.cell_slot_cap);
+  CHX_LAUNCH(k_cell_scan, dim3(1), dim3(1024), st, cell_count, cell_start, ncell, status, status_len, rd.ctrl, rd.ctrl_keep);
+  if (!slotted) CHX_LAUNCH(k_cell_scatter, dim3(pb), dim3(256), st, cell_of, n, cell_start, cell_count, sorted_ids);
   const bool lists = cand_list && cand_len && cand_cap > 0;
   // (with the lists: twice the wavefronts, the second half writes them -- k_cell_sort)
   const int64_t sort_waves = (int64_t)ncell * (lists ? 2 : 1);
-  hipLaunchKernelGGL(k_cell_sort, dim3((unsigned)((sort_waves * CHX_WAVE + 255) / 256)), dim3(256), 0, st,
-                     cell_start, ncell, sorted_ids, xyz, reinterpret_cast<float4*>(xs4_out), g.ncx, g.ncy, cell_count, rd, g,
-                     lists ? cand_list : nullptr, cand_len, cand_cap, slotted ? rd.cell_slots : nullptr, rd.cell_slot_cap,
-                     status);
+  CHX_LAUNCH(k_cell_sort, dim3((unsigned)((sort_waves * CHX_WAVE + 255) / 256)), dim3(256), st, cell_start, ncell, sorted_ids, xyz,
+             reinterpret_cast<float4*>(xs4_out), g.ncx, g.ncy, cell_count, rd, g, lists ? cand_list : nullptr, cand_len, cand_cap,
+             slotted ? rd.cell_slots : nullptr, rd.cell_slot_cap, status);
   return CHX_OK;
 }
 

@@ -125,7 +125,7 @@ class LangevinIntegrator:
     # memory, and its numpy view no longer aliases it): it starts without and allocates its own on first use.
     # MultiStateSampler deep-copies its sampler, chiron/multistate.py:266-268.
     _PER_PROCESS_STATE = ("_gen_ring", "_gen_next", "_pinned_ring", "_ring_next", "_dev_scratch", "_inner_scratch",
-                          "_run_cache", "_defer_scratch", "_rebuild_log", "_carry", "_params_cache", "_mass_q")
+                          "_run_cache", "_defer_scratch", "_rebuild_log", "_carry", "_params_cache", "_mass_q", "_graveyard")
 
     def __getstate__(self):
         return {k: v for k, v in self.__dict__.items() if k not in self._PER_PROCESS_STATE}
@@ -529,6 +529,16 @@ class _RunState:
         d.next ^= 1
         return b
 
+    def _bury(self, lst):
+        """Keep the arrays of the list that is about to be replaced alive until the NEXT rebuild (or the run's end).
+        The rebuild rides on the step queue behind the launches of the generation that just halted (no join): the
+        halting launch itself may still be reading the old force list when the host drops it, and the allocator would
+        hand its memory to whoever asks next -- possibly a torch kernel on the stream, which the queue does not order.
+        One rebuild later every launch of that generation has long run."""
+        d = lst.__dict__
+        self.integ._graveyard = (d.get("_force_list"), d.get("n_neighbors"), d.get("ref_positions"), d.get("_perm"),
+                                 d.get("_nl"), d.get("_first"), getattr(self, "fl", None), getattr(self, "perm", None))
+
     def _rebuild_internal(self, step: int, speculative: bool = True):
         """The carried force list ran out of its guarantee (the halt word fired at ``step`` on the list's own
         positions): build the next one here and now, from the halted state.  No reference event is involved; one that
@@ -537,12 +547,16 @@ class _RunState:
         x_user, v_user = self.state_user()
         ref_user = self._unpack(self.ref4)
         b = self._next_builder()
+        self._bury(b)
         # (like the halting scheme's rebuild: enqueue the build, carry on, read its status block once it has arrived --
         # a builder that has built before for this box; its first build goes the synchronous way)
+        # (the builder keeps a copy of the positions -- made by the binning launch, which rides on the step queue with the
+        # rest of the rebuild; a torch clone would run on the stream, beside the queue)
         spec = (speculative and _SPECULATIVE_REBUILD and b.__dict__.get("_perm") is not None
-                and b._build_speculative(x_user.clone(), publish=False, pack=self.pack_rider(v_user, ref_user), ctrl=self.ctrl,
-                                         ctrl_keep=3, half_rows=_RUN_HALF_ROWS))
+                and b._build_speculative(x_user, publish=False, pack=self.pack_rider(v_user, ref_user), ctrl=self.ctrl,
+                                         ctrl_keep=3, half_rows=_RUN_HALF_ROWS, copy_positions=True))
         if not spec:
+            ops.steps_join()  # (the synchronous build reads its status on the host: nothing may be pending on the queue)
             b._adopt_positions = True
             try:
                 b.build(x_user.clone(), b.box_vectors)
@@ -822,10 +836,12 @@ class _RunState:
             t0 = time.perf_counter()
         x_user, v_user = self.state_user()
         keep_events = 1 if self._defer is not None else 0
+        self._bury(self.nbr_list)
         spec = speculative and _SPECULATIVE_REBUILD and self.nbr_list._build_speculative(
             x_user, publish=False, pack=self.pack_rider(v_user), ctrl=self.ctrl, ctrl_keep=keep_events,
             half_rows=_RUN_HALF_ROWS)
         if not spec:
+            ops.steps_join()  # (the synchronous build reads its status on the host)
             self.nbr_list._adopt_positions = True  # x_user is a fresh tensor nobody else holds
             try:
                 self.nbr_list.build(x_user, self.nbr_list.box_vectors)
@@ -855,7 +871,7 @@ class _RunState:
             # the build's status block reaches the host with the pack launch of the load that followed the build;
             # a step launch of that load's generation has begun => it is there.  Otherwise wait for the stream.
             if int(self._gen.host[0]) < self._gen_step0:
-                torch.cuda.current_stream().synchronize()
+                _wait_for_steps_and_stream()  # (the build may have ridden on the step queue)
             ok = owner._confirm_build(wait=False)
         else:
             ok = owner._confirm_build()
@@ -931,6 +947,7 @@ class _RunState:
         launches are the last thing enqueued and the join is the whole wait -- the stream holds nothing behind the marker
         that let them start; with plain HIP launches (CHX_AQL=0, or no queue) an event on the stream is."""
         ops.steps_join()
+        self.integ._graveyard = None  # (everything that read the buried arrays has run)
         if not ops.step_queue_on():
             ev = torch.cuda.Event()
             ev.record()  # (the last thing on the stream: a caller's device-wide synchronize then finds nothing pending)

@@ -246,6 +246,7 @@ class NeighborListNsqrd(PairsBase):
                         self._scratch = {}
                     nl, first, n_nbr, sorted_ids, fl, deg, status = ops.nl_build_cell_fl(
                         self.ref_positions, self._box_h, cs, m, ncell, nc, g, chunks, self._scratch)
+                    ops.steps_join()  # (inside a run() the build's launches ride on the step queue: chx_steps_join)
                     st = status.cpu().tolist()  # the build's only host sync (the reference syncs at :709)
                     if _DEBUG_BUILD:
                         print(f"[chx build] n={n} m={m} g={g} chunks={chunks} status={st}", flush=True)
@@ -407,6 +408,7 @@ class NeighborListNsqrd(PairsBase):
         self._spec = None
         ev, m, g, chunks = spec
         if wait:
+            ops.steps_join()  # (a build enqueued inside a run() rides on the step queue, which the stream does not see)
             if getattr(self, "_spec_recorded", True):
                 ev.synchronize()
             else:

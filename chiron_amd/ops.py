@@ -180,6 +180,7 @@ def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: in
         cand = scratch.get("cand")
         slots = scratch.get("slots")
     else:
+        steps_join()  # (the zero fill below is a torch kernel on the stream: not beside launches riding on the step queue)
         cell_of = torch.empty((n,), **i32)
         cell_count = torch.zeros((ncell + 1,), **i32)  # (zero on entry, left zeroed by every build: include/chx.h)
         cell_start = torch.empty((ncell + 1,), **i32)

@@ -1022,5 +1022,17 @@ def test_step_code_object_is_current_and_holds_every_step_kernel():
                     names = [n for n in sizes if n.startswith(f"_Z9k_lj_stepILi{g}ELb{hot}ELb{prune}ELb{defer}EE")]
                     assert len(names) == 1, (g, hot, prune, defer)
                     assert sizes[names[0]] == 320
+    # the units whose kernels ride on the queue while a run() is in progress (csrc/chx_launch.h): unpack, the list build
+    # chain, pack -- one code object each, every kernel the rebuild launches present
+    want = {"core": ["k_unpack_langevin", "k_permute_unpack"],
+            "neighbors": ["k_cell_assign", "k_cell_scan", "k_cell_scatter", "k_cell_sort"],
+            "cell_fl": ["k_nl_build_cell_fl", "k_nl_build_cellwise_fl", "k_build_epilogue", "k_pack_langevin",
+                        "k_pack_validate_langevin", "k_validate_snap"]}
+    for unit, kernels in want.items():
+        path = build.queue_object({v: k for k, v in build.QUEUE_UNITS.items()}[unit])
+        assert os.path.exists(path), path
+        text = subprocess.run([readelf, "--notes", path], capture_output=True, text=True, timeout=120).stdout
+        for k in kernels:
+            assert k in text, (unit, k)
     ap = [n for n in sizes if n.startswith("_Z9k_ap_stepILi64ELb1EE") or n.startswith("_Z9k_ap_stepILi16ELb0EE")]
     assert len(ap) == 2 and all(276 <= sizes[n] <= 280 for n in ap), {n: sizes[n] for n in ap}  # (sizeof(ApKernarg) = 280)
