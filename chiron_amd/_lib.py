@@ -196,6 +196,7 @@ SIGNATURES = {
     "chx_set_poll_sleep_ns": (_I64, [_I64]),
     "chx_poll_stats": (C.c_int, [C.POINTER(_I64), _I32]),
     "chx_steps_join": (C.c_int, [_P]),
+    "chx_steps_open": (C.c_int, [_P]),
     "chx_step_queue_info": (C.c_int, [C.POINTER(_I64), _P]),
     "chx_step_queue_status": (C.c_char_p, []),
     "chx_ctrl_reset": (C.c_int, [_P, _P]),

@@ -557,6 +557,7 @@ extern "C" int chx_steps_join(chx_stream_t stream) {
   if (__atomic_load_n(&chx_aql_open_count, __ATOMIC_RELAXED) > 0) chx_aql_join(reinterpret_cast<hipStream_t>(stream));
   return g_queue_error ? CHX_ERR_LAUNCH : CHX_OK;
 }
+extern "C" int chx_steps_open(chx_stream_t stream) { return chx_aql_open(reinterpret_cast<hipStream_t>(stream)); }
 extern "C" int chx_step_queue_info(int64_t* out8_h, chx_stream_t stream) {
   const bool on = chx_aql_on();
   if (out8_h) {

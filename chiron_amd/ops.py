@@ -644,6 +644,12 @@ def steps_join() -> None:
     check(_lib.load().chx_steps_join(_stream()), "chx_steps_join")
 
 
+def steps_open() -> None:
+    """Put the gate up now (include/chx.h: chx_steps_open): the list build and the pack launches that follow ride on the
+    step queue with the steps, behind everything the stream holds at this point."""
+    check(_lib.load().chx_steps_open(_stream()), "chx_steps_open")
+
+
 _sq_probe = (C.c_int64 * 8)()
 
 

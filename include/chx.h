@@ -63,7 +63,7 @@ typedef void* chx_stream_t;
  *      "asynchronous on `stream`" then means: behind everything enqueued on `stream` before the call, and every LATER
  *      libchx call on `stream` runs behind them -- but a caller that enqueues work of its OWN on `stream` which reads
  *      what the steps write must call chx_steps_join first.  CHX_AQL=0 in the environment restores plain HIP launches.
- *      New entry points: chx_steps_join, chx_step_queue_info, chx_step_queue_status. */
+ *      New entry points: chx_steps_join, chx_steps_open, chx_step_queue_info, chx_step_queue_status. */
 #define CHX_ABI_VERSION 4
 
 /* high bit of a force-list entry: neighbor has the HIGHER original particle id */
@@ -504,6 +504,13 @@ int chx_langevin_fused_run(const chx_langevin_t* p_h, float* x_even, float* x_od
  * inside it).  When the queue cannot be set up (file missing, HSA runtime not found, CHX_AQL=0) the launches go through
  * HIP as in ABI 3; chx_step_queue_status() says why. */
 int chx_steps_join(chx_stream_t stream);
+/* Open the queue for `stream` without dispatching a step: the gate goes up behind everything enqueued on `stream` so far,
+ * and from here to the next chx_steps_join the queue-capable entry points -- chx_unpack_langevin, chx_permute_unpack,
+ * chx_cell_bin_fl, chx_nl_rows_cell_fl, chx_nl_build_cell_fl, chx_pack_langevin, chx_pack_validate_langevin,
+ * chx_validate_snap -- write their launches as packets behind it instead of launching on the stream (they do so whenever
+ * packets are outstanding: that is how a list rebuild inside a run stays behind the steps without a join).  A no-op when
+ * the queue is off or restricted to the step launches (CHX_AQL_SCOPE=steps). */
+int chx_steps_open(chx_stream_t stream);
 /* out8_h = {queue usable (0 / 1), release scope of a steady-state packet (0 none, 1 agent, -1 off), kernels in the code
  * object, packets dispatched for `stream`, joins, gates (HIP -> queue hand-overs), packets outstanding (0 / 1), 0}. */
 int chx_step_queue_info(int64_t* out8_h, chx_stream_t stream);
