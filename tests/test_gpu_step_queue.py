@@ -34,7 +34,7 @@ print("RESULT " + json.dumps({"hash": h, "rebuilds": rebuilds, "queue": ops.step
 
 def _run(env_extra, workload, steps):
     env = dict(os.environ)
-    for k in ("CHX_AQL", "CHX_AQL_FENCE"):
+    for k in ("CHX_AQL", "CHX_AQL_FENCE", "CHX_AQL_SCOPE", "CHX_AQL_OPEN_AT_START"):
         env.pop(k, None)
     env.update(env_extra)
     out = subprocess.run([sys.executable, "-c", _TRAJECTORY, workload, str(steps)], capture_output=True, text=True, timeout=600,
@@ -47,7 +47,7 @@ def _run(env_extra, workload, steps):
 @pytest.mark.parametrize("workload,steps", [("c3", 3000), ("c4", 600)], ids=["c3-32768", "c4-262144"])
 def test_step_queue_and_its_fence_modes_leave_every_bit_of_the_trajectory(workload, steps):
     """One trajectory from the bench's own start -- thousands of steps with list rebuilds and inner-list refreshes, then
-    short runs on carried-over lists -- in three fresh processes: plain HIP launches (CHX_AQL=0), the step queue with
+    short runs on carried-over lists -- in fresh processes: plain HIP launches (CHX_AQL=0), the step queue with
     HIP's agent-scope fences on every packet (CHX_AQL_FENCE=agent), and the default (steady-state packets carry no
     fences: their outputs are write-through stores, and what they read was written through or released).  A single
     stale read anywhere -- an L1, scalar-cache or L2 line that survived a dispatch, a store still dirty in one XCD's L2
@@ -55,6 +55,12 @@ def test_step_queue_and_its_fence_modes_leave_every_bit_of_the_trajectory(worklo
     hip = _run({"CHX_AQL": "0"}, workload, steps)
     fenced = _run({"CHX_AQL_FENCE": "agent"}, workload, steps)
     bare = _run({}, workload, steps)
+    # ... and the two narrower uses of the queue: the step launches only (a rebuild joins and goes through HIP), and the
+    # gate at the first step instead of at the start of run() (the run-start build goes through HIP)
+    steps_only = _run({"CHX_AQL_SCOPE": "steps"}, workload, steps)
+    late_gate = _run({"CHX_AQL_OPEN_AT_START": "0"}, workload, steps)
+    assert steps_only["hash"] == late_gate["hash"] == hip["hash"], (steps_only, late_gate, hip)
+    assert steps_only["queue"]["on"] and steps_only["queue"]["gates"] > bare["queue"]["gates"]  # (a gate per rebuild)
     assert not hip["queue"]["on"] and hip["queue"]["dispatched"] == 0
     assert fenced["queue"]["on"] and fenced["queue"]["hot_release"] == "agent"
     assert bare["queue"]["on"] and bare["queue"]["hot_release"] == "none", bare["queue"]
