@@ -211,7 +211,11 @@ class LangevinIntegrator:
         spec0 = packed0 = False
         carried = self._take_carry(sampler_state, nbr_list, number_of_steps) if is_lj else None
         if carried is not None:
-            pass  # (no build: _RunState validates the carried force list against x0 on the device)
+            # (no build: _RunState validates the carried force list against x0 on the device -- its pack launch rides on
+            # the step queue with the steps, behind one gate)
+            if _OPEN_AT_START and isinstance(x0, torch.Tensor) and x0.is_cuda:
+                _RunState.device_buffers(self, x0.shape[0], x0.device)  # (allocations before the gate: see below)
+                ops.steps_open()
         elif (nbr_list is not None and is_lj and _SPECULATIVE_REBUILD and isinstance(nbr_list, NeighborListNsqrd)
                 and getattr(nbr_list, "_box_token", None) is not None
                 and nbr_list._box_token is getattr(sampler_state, "_box_token", None)
