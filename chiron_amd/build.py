@@ -22,7 +22,7 @@ STEP_UNIT = "chx_lj.hip"
 STEP_OUT = os.path.join(HERE, "libchx_step.hsaco")
 # ... and the device halves of the units whose kernels ride on the queue while a run() is in progress (unpack, the list
 # build chain, pack: csrc/chx_launch.h): libchx_k_<unit>.hsaco, loaded when present
-QUEUE_UNITS = {"chx_core.hip": "core", "chx_neighbors.hip": "neighbors", "chx_cell_fl.hip": "cell_fl"}
+QUEUE_UNITS = {"chx_core.hip": "core", "chx_neighbors.hip": "neighbors", "chx_cell_fl.hip": "cell_fl", "chx_mc.hip": "mc"}
 
 
 def queue_object(unit: str) -> str:

@@ -108,6 +108,7 @@ struct Queue {
   uint32_t size = 0;     // packets in the ring: what the runtime made of the request (an intercepted queue may differ)
   bool open = false;     // packets outstanding since the last join
   bool fresh = false;    // the gate is up and no kernel packet has followed it yet
+  bool fresh_system = false;  // ... and the queue was opened on an idle stream, without a barrier packet: acquire at system scope
   hsa_signal_t done{};   // completion signal of the join barrier
   Gate gates[4];
   unsigned gate_next = 0;
@@ -123,7 +124,7 @@ struct Queue {
   static constexpr unsigned SEG = 32, AHEAD = 4, MAXSEG = 128;
   hsa_signal_t seg_sig[MAXSEG];
   bool seg_used[MAXSEG];
-  uint64_t n_dispatched = 0, n_joins = 0, n_gates = 0;
+  uint64_t n_dispatched = 0, n_joins = 0, n_gates = 0, n_idle_opens = 0;
 };
 
 constexpr uint32_t QSIZE = 1024;  // packets asked for; the launch window keeps ~a dozen outstanding
@@ -415,6 +416,19 @@ namespace {
 
 // the HIP -> queue hand-over: behind everything the stream holds
 void open_gate(Queue* Q, hipStream_t st) {
+  // Nothing pending on the stream (the usual case at the start of a run(): the caller has synchronised, or the previous
+  // run() ended with a join): there is nothing to wait behind, so no marker launch and no barrier packet -- the first
+  // packet goes out with a system-scope acquire instead.  (The stream belongs to the calling thread: nothing can be
+  // enqueued on it between this query and the packets that follow.)
+  if (hipStreamQuery(st) == hipSuccess) {
+    Q->open = true;
+    Q->fresh = true;
+    Q->fresh_system = true;
+    Q->n_idle_opens++;
+    __atomic_fetch_add(&chx_aql_open_count, 1, __ATOMIC_RELAXED);
+    return;
+  }
+  (void)hipGetLastError();  // (hipErrorNotReady is the expected answer, not an error to keep)
   Gate& g = Q->gates[Q->gate_next++ % 4];
   H.hsa_signal_store_relaxed(g.sig, 1);
   long long* value = reinterpret_cast<long long*>(const_cast<int64_t*>(&reinterpret_cast<amd_signal_t*>(g.sig.handle)->value));
@@ -441,7 +455,10 @@ int dispatch_core(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, con
   }
   int acquire = g_fence_none ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT;
   if (!Q->open) open_gate(Q, st);
-  if (Q->fresh) acquire = HSA_FENCE_SCOPE_AGENT, Q->fresh = false;  // first packet since the last join
+  if (Q->fresh) {  // first packet since the last join
+    acquire = Q->fresh_system ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
+    Q->fresh = Q->fresh_system = false;
+  }
   hsa_signal_t seg_sig{0};
   const uint64_t widx = reserve(Q, &seg_sig);
   // the argument block goes to device memory through the BAR; the read-back of its last word completes the posted
@@ -572,6 +589,7 @@ extern "C" int chx_step_queue_info(int64_t* out8_h, chx_stream_t stream) {
       out8_h[4] = (int64_t)it->second->n_joins;
       out8_h[5] = (int64_t)it->second->n_gates;
       out8_h[6] = it->second->open ? 1 : 0;
+      out8_h[7] = (int64_t)it->second->n_idle_opens;
     }
   }
   return CHX_OK;

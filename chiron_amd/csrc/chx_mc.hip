@@ -23,6 +23,7 @@
 #include "chx_common.h"
 #include "chx_internal.h"
 #include "chx_lj_row.h"
+#include "chx_launch.h"
 
 #include <limits.h>
 #include <stdlib.h>
@@ -442,12 +443,13 @@ __global__ __launch_bounds__(256) void k_mc_trial(McArgs a, long long trial, int
 template <int G>
 static void launch_trial(const McArgs& a, long long t, bool decide, int log_slot, hipStream_t st) {
   const unsigned blocks = (unsigned)(((int64_t)a.n * G + 255) / 256);
+  // (CHX_LAUNCH: an AQL packet on the step queue, which chx_mc_displace_chunk has opened -- chx_launch.h)
   if (a.fli != nullptr) {
-    if (decide) hipLaunchKernelGGL((k_mc_trial<G, true, true>), dim3(blocks), dim3(256), 0, st, a, t, log_slot, blocks);
-    else hipLaunchKernelGGL((k_mc_trial<G, false, true>), dim3(blocks), dim3(256), 0, st, a, t, log_slot, blocks);
+    if (decide) CHX_LAUNCH((k_mc_trial<G, true, true>), dim3(blocks), dim3(256), st, a, t, log_slot, blocks);
+    else CHX_LAUNCH((k_mc_trial<G, false, true>), dim3(blocks), dim3(256), st, a, t, log_slot, blocks);
   } else {
-    if (decide) hipLaunchKernelGGL((k_mc_trial<G, true, false>), dim3(blocks), dim3(256), 0, st, a, t, log_slot, blocks);
-    else hipLaunchKernelGGL((k_mc_trial<G, false, false>), dim3(blocks), dim3(256), 0, st, a, t, log_slot, blocks);
+    if (decide) CHX_LAUNCH((k_mc_trial<G, true, false>), dim3(blocks), dim3(256), st, a, t, log_slot, blocks);
+    else CHX_LAUNCH((k_mc_trial<G, false, false>), dim3(blocks), dim3(256), st, a, t, log_slot, blocks);
   }
 }
 
@@ -538,7 +540,14 @@ extern "C" int chx_mc_displace_chunk(const chx_mc_t* p, int64_t trial0, int32_t 
   }
   const uint4* tab = reinterpret_cast<const uint4*>(p->keytab);
   a.keyrow = tab;
-  hipLaunchKernelGGL(k_mc_prologue, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0, st, a, (long long)trial0);
+  // The chunk's launches ride on the step queue (include/chx.h: chx_steps_open): the gate goes up behind the key-table
+  // upload above, the host side of a trial is a packet instead of a HIP launch, and the packets carry no acquire fence.
+  // The CALLER joins (chx_steps_join) before it reads the chunk's results with anything but a libchx call.
+  {
+    const int rc_open = chx_aql_open(st);
+    if (rc_open != CHX_OK) return rc_open;
+  }
+  CHX_LAUNCH(k_mc_prologue, dim3((unsigned)((p->n + 255) / 256)), dim3(256), st, a, (long long)trial0);
   for (int i = 0; i < n_trials; ++i) {
     const long long t = trial0 + i;
     const bool decide = i > 0;  // (decides trial t - 1, logged at i - 1)
@@ -554,6 +563,6 @@ extern "C" int chx_mc_displace_chunk(const chx_mc_t* p, int64_t trial0, int32_t 
     }
   }
   a.keyrow = tab + n_trials;
-  hipLaunchKernelGGL(k_mc_decide, dim3(1), dim3(256), 0, st, a, (long long)(trial0 + n_trials), n_trials - 1);
+  CHX_LAUNCH(k_mc_decide, dim3(1), dim3(256), st, a, (long long)(trial0 + n_trials), n_trials - 1);
   return chx_check_launch("chx_mc_displace_chunk");
 }

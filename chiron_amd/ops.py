@@ -669,6 +669,7 @@ def step_queue_info() -> dict:
     status = lib.chx_step_queue_status()
     return {"on": bool(out[0]), "hot_release": {0: "none", 1: "agent"}.get(int(out[1]), "off"), "kernels": int(out[2]),
             "dispatched": int(out[3]), "joins": int(out[4]), "gates": int(out[5]), "open": bool(out[6]),
+            "idle_opens": int(out[7]),
             "status": status.decode() if status else ""}
 
 
@@ -705,8 +706,10 @@ def mc_displace(x: torch.Tensor, sigma_d: float, box: Box, key: PRNGKey, ctr: in
 
 
 def mc_displace_chunk(params: "_lib.McParams", trial0: int, n_trials: int) -> None:
-    """Enqueue ``n_trials`` device-resident displacement trials (include/chx.h: chx_mc_displace_chunk)."""
+    """Run ``n_trials`` device-resident displacement trials (include/chx.h: chx_mc_displace_chunk) and wait for them: the
+    launches ride on the step queue, and the caller reads the chunk's state and logs with torch (``.cpu()``) next."""
     check(_lib.load().chx_mc_displace_chunk(C.byref(params), trial0, n_trials, _stream()), "chx_mc_displace_chunk")
+    steps_join()
 
 
 def metropolis_select(x_cur, x_prop, log_ratio, u_cur, u_prop, key: PRNGKey, ctr: int, accepted, counters, uniform: float = -1.0) -> None:

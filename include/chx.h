@@ -507,12 +507,13 @@ int chx_steps_join(chx_stream_t stream);
 /* Open the queue for `stream` without dispatching a step: the gate goes up behind everything enqueued on `stream` so far,
  * and from here to the next chx_steps_join the queue-capable entry points -- chx_unpack_langevin, chx_permute_unpack,
  * chx_cell_bin_fl, chx_nl_rows_cell_fl, chx_nl_build_cell_fl, chx_pack_langevin, chx_pack_validate_langevin,
- * chx_validate_snap -- write their launches as packets behind it instead of launching on the stream (they do so whenever
+ * chx_validate_snap (chx_mc_displace_chunk opens the queue by itself) -- write their launches as packets behind it instead of launching on the stream (they do so whenever
  * packets are outstanding: that is how a list rebuild inside a run stays behind the steps without a join).  A no-op when
  * the queue is off or restricted to the step launches (CHX_AQL_SCOPE=steps). */
 int chx_steps_open(chx_stream_t stream);
-/* out8_h = {queue usable (0 / 1), release scope of a steady-state packet (0 none, 1 agent, -1 off), kernels in the code
- * object, packets dispatched for `stream`, joins, gates (HIP -> queue hand-overs), packets outstanding (0 / 1), 0}. */
+/* out8_h = {queue usable (0 / 1), release scope of a steady-state packet (0 none, 1 agent, -1 off), kernel names in the
+ * code objects, packets dispatched for `stream`, joins, gates (stream -> queue hand-overs through a marker launch),
+ * packets outstanding (0 / 1), openings on an idle stream (no marker needed: hipStreamQuery said so)}. */
 int chx_step_queue_info(int64_t* out8_h, chx_stream_t stream);
 const char* chx_step_queue_status(void);
 
@@ -586,7 +587,8 @@ int chx_metropolis_select(float* x_cur, const float* x_prop, int64_t count,
  * the chunk slot (T & 1) does.  The halt word is shared: always state[CHX_MC_HALT] of slot 0.  energy follows the same
  * rule: [2 s] = current potential energy (kJ/mol) of slot s, [2 s + 1] = last proposed.  accept_log / energy_log
  * (n_trials entries each, may be NULL) record the decision and the current energy after every trial, indexed by
- * trial - trial0.  ws: 2 * chx_lj_ws_count(n) doubles (the partials alternate between two halves).  Asynchronous. */
+ * trial - trial0.  ws: 2 * chx_lj_ws_count(n) doubles (the partials alternate between two halves).  Asynchronous; the
+ * launches ride on the step queue (ABI 4: chx_steps_join before the caller's own work on `stream` reads the results). */
 #define CHX_MC_CUR 0       /* which copy (0 / 1) of cur4[parity] holds the current configuration */
 #define CHX_MC_ACCEPTED 1  /* running counters */
 #define CHX_MC_PROPOSED 2

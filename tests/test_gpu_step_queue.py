@@ -59,13 +59,14 @@ def test_step_queue_and_its_fence_modes_leave_every_bit_of_the_trajectory(worklo
     # gate at the first step instead of at the start of run() (the run-start build goes through HIP)
     steps_only = _run({"CHX_AQL_SCOPE": "steps"}, workload, steps)
     late_gate = _run({"CHX_AQL_OPEN_AT_START": "0"}, workload, steps)
+    opened = lambda r: r["queue"]["gates"] + r["queue"]["idle_opens"]  # (through a marker launch / on an idle stream)
     assert steps_only["hash"] == late_gate["hash"] == hip["hash"], (steps_only, late_gate, hip)
-    assert steps_only["queue"]["on"] and steps_only["queue"]["gates"] > bare["queue"]["gates"]  # (a gate per rebuild)
+    assert steps_only["queue"]["on"] and opened(steps_only) > opened(bare)  # (steps only: an opening per rebuild)
     assert not hip["queue"]["on"] and hip["queue"]["dispatched"] == 0
     assert fenced["queue"]["on"] and fenced["queue"]["hot_release"] == "agent"
     assert bare["queue"]["on"] and bare["queue"]["hot_release"] == "none", bare["queue"]
     total = steps + 20 + 7 + 100 + 1
-    assert bare["queue"]["dispatched"] >= total and bare["queue"]["gates"] >= 5 and not bare["queue"]["open"]
+    assert bare["queue"]["dispatched"] >= total and opened(bare) >= 5 and not bare["queue"]["open"]
     assert hip["rebuilds"] > 0 or workload == "c4"
     assert hip["hash"] == fenced["hash"] == bare["hash"], (hip, fenced, bare)
     assert hip["rebuilds"] == fenced["rebuilds"] == bare["rebuilds"] and hip["carried"] == bare["carried"]
@@ -90,9 +91,16 @@ def test_step_queue_orders_with_the_stream_it_is_paired_with():
     # torch work in front (a big fill the steps' inputs do not depend on, then the inputs themselves rewritten): the
     # gate must hold the first step packet until both have run
     junk = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
-    junk.fill_(1.0)
+    for k in range(8):  # (a millisecond of work on the stream: the run() below finds it busy and must put a gate up)
+        junk.fill_(float(k))
     state2, nbr = integ.run(state, thermo, number_of_steps=30, nbr_list=nbr)
-    assert float(junk[-1].item()) == 1.0
+    assert float(junk[-1].item()) == 7.0
     info1 = ops.step_queue_info()
     assert info1["gates"] > info0["gates"] and info1["joins"] > info0["joins"] and not info1["open"]
+    # ... and a run() that finds the stream idle opens the queue without a marker launch
+    torch.cuda.synchronize()
+    state3, nbr = integ.run(state2, thermo, number_of_steps=30, nbr_list=nbr)
+    info2 = ops.step_queue_info()
+    assert info2["idle_opens"] > info1["idle_opens"] and info2["gates"] == info1["gates"]
+    assert torch.isfinite(state3.positions).all()
     assert torch.isfinite(state2.positions).all() and not torch.equal(state2.positions, x1)

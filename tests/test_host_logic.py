@@ -1027,7 +1027,8 @@ def test_step_code_object_is_current_and_holds_every_step_kernel():
     want = {"core": ["k_unpack_langevin", "k_permute_unpack"],
             "neighbors": ["k_cell_assign", "k_cell_scan", "k_cell_scatter", "k_cell_sort"],
             "cell_fl": ["k_nl_build_cell_fl", "k_nl_build_cellwise_fl", "k_build_epilogue", "k_pack_langevin",
-                        "k_pack_validate_langevin", "k_validate_snap"]}
+                        "k_pack_validate_langevin", "k_validate_snap"],
+            "mc": ["k_mc_trial", "k_mc_prologue", "k_mc_decide"]}
     for unit, kernels in want.items():
         path = build.queue_object({v: k for k, v in build.QUEUE_UNITS.items()}[unit])
         assert os.path.exists(path), path
