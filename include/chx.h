@@ -490,19 +490,21 @@ int chx_langevin_fused_run(const chx_langevin_t* p_h, float* x_even, float* x_od
                            int32_t n_steps, int32_t kicks_first, int32_t window,
                            int32_t* n_enqueued_out, chx_stream_t stream);
 
-/* The step queue.  The fused step kernels are dispatched as hand-written AQL kernel-dispatch packets on a user-mode HSA
+/* The step queue.  The fused step kernels -- and, while the queue is open, the kernels of the queue-capable entry points
+ * (chx_steps_open) -- are dispatched as hand-written AQL kernel-dispatch packets on a user-mode HSA
  * queue of the library's own, one per `stream` value, instead of through hipLaunchKernelGGL: the host side of a dispatch
  * is a copy of the 320-byte argument block into device memory, a 64-byte packet and a doorbell write (the HIP runtime's
  * launch path, and its slow regime, are out of the loop), and the packets of steady-state launches carry no cache
  * fences (their outputs are write-through stores; CHX_AQL_FENCE=agent restores HIP's agent-scope acquire / release on
  * every packet).  Ordering: the first packet after a join waits (barrier-AND packet on a signal that a marker kernel on
- * `stream` sets) for everything enqueued on `stream` before it; chx_steps_join waits ON THE HOST until every packet
+ * `stream` sets; no marker when hipStreamQuery finds the stream idle) for everything enqueued on `stream` before it; chx_steps_join waits ON THE HOST until every packet
  * dispatched for `stream` has completed (returns at once when none is outstanding).  Every libchx entry point that
  * launches on a stream joins first, so libchx calls always see one ordered stream; only work the CALLER enqueues on
  * `stream` by other means (its own kernels, copies, events) needs an explicit chx_steps_join in front when it depends on
- * the steps.  The kernels are loaded from libchx_step.hsaco beside the library (same source, same flags as the copies
- * inside it).  When the queue cannot be set up (file missing, HSA runtime not found, CHX_AQL=0) the launches go through
- * HIP as in ABI 3; chx_step_queue_status() says why. */
+ * the steps.  The kernels are loaded from libchx_step.hsaco (required) and libchx_k_*.hsaco (one per translation unit
+ * whose kernels may ride on the queue; optional) beside the library (same sources, same flags as the copies inside it).
+ * When the queue cannot be set up (file missing, HSA runtime not found, CHX_AQL=0) the launches go through HIP as in
+ * ABI 3; chx_step_queue_status() says why.  CHX_AQL_SCOPE=steps keeps the queue to the step launches. */
 int chx_steps_join(chx_stream_t stream);
 /* Open the queue for `stream` without dispatching a step: the gate goes up behind everything enqueued on `stream` so far,
  * and from here to the next chx_steps_join the queue-capable entry points -- chx_unpack_langevin, chx_permute_unpack,
