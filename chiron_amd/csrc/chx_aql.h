@@ -35,6 +35,11 @@ const AqlKernel* chx_aql_kernel_of(const void* host_fn, hipStream_t st);
 // One packet for any grid; `explicit_bytes` of packed arguments (the implicit arguments of code object v5 -- block
 // counts, group sizes, grid dimensions -- are appended when the kernel's segment asks for them); agent-scope release.
 int chx_aql_dispatch_any(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, const void* kernarg, size_t explicit_bytes);
+// The packet just written for `st` -- the list build's summary launch, which only reads what the step kernels read and
+// writes the build's status block -- may run BESIDE the next step packet: that one goes out without the barrier bit (it
+// still starts behind everything in front of the summary, whose own barrier bit held it back until then).  Any other
+// dispatch in between takes the permission away.  CHX_AQL_OVERLAP=0 switches it off.
+void chx_aql_allow_overlap(hipStream_t st);
 // open the queue for `st` (gate behind the stream's work) without dispatching anything: what follows on the queue-capable
 // entry points then rides on the queue
 int chx_aql_open(hipStream_t st);

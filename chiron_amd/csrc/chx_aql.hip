@@ -108,6 +108,7 @@ struct Queue {
   uint32_t size = 0;     // packets in the ring: what the runtime made of the request (an intercepted queue may differ)
   bool open = false;     // packets outstanding since the last join
   bool fresh = false;    // the gate is up and no kernel packet has followed it yet
+  bool overlap_ok = false;    // the packet just written may run beside the next STEP packet (chx_aql_allow_overlap)
   bool fresh_system = false;  // ... and the queue was opened on an idle stream, without a barrier packet: acquire at system scope
   hsa_signal_t done{};   // completion signal of the join barrier
   Gate gates[4];
@@ -440,7 +441,8 @@ void open_gate(Queue* Q, hipStream_t st) {
   __atomic_fetch_add(&chx_aql_open_count, 1, __ATOMIC_RELAXED);
 }
 
-int dispatch_core(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, const void* kernarg, size_t nbytes, int release) {
+int dispatch_core(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, const void* kernarg, size_t nbytes, int release,
+                  bool is_step = false) {
   // (the segment may be shorter than the caller's block -- trailing padding of a by-value struct -- never longer)
   const size_t seg = k->kernarg_size;
   if (nbytes + 256 > SLOT || nbytes > seg + 8) {
@@ -455,6 +457,9 @@ int dispatch_core(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, con
   }
   int acquire = g_fence_none ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT;
   if (!Q->open) open_gate(Q, st);
+  // (a step packet behind the list build's summary launch starts beside it: chx_aql_allow_overlap)
+  const bool barrier = !(is_step && Q->overlap_ok);
+  Q->overlap_ok = false;
   if (Q->fresh) {  // first packet since the last join
     acquire = Q->fresh_system ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
     Q->fresh = Q->fresh_system = false;
@@ -497,7 +502,7 @@ int dispatch_core(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, con
   pk->kernarg_address = ka;
   pk->reserved2 = 0;
   pk->completion_signal = seg_sig;
-  publish(Q, widx, (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+  publish(Q, widx, (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((barrier ? 1 : 0) << HSA_PACKET_HEADER_BARRIER) |
                               (acquire << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (release << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE)));
   Q->n_dispatched++;
   return CHX_OK;
@@ -513,7 +518,16 @@ int chx_aql_dispatch(hipStream_t st, const AqlKernel* k, unsigned blocks, const 
     chx_set_error("step queue: argument block of %zu bytes is shorter than the kernel's %u", nbytes, k->kernarg_size);
     return CHX_ERR_INVALID;
   }
-  return dispatch_core(st, k, dim3(blocks), dim3(256), kernarg, k->kernarg_size, release_agent ? HSA_FENCE_SCOPE_AGENT : chx_aql_hot_release());
+  return dispatch_core(st, k, dim3(blocks), dim3(256), kernarg, k->kernarg_size, release_agent ? HSA_FENCE_SCOPE_AGENT : chx_aql_hot_release(),
+                       true);
+}
+
+void chx_aql_allow_overlap(hipStream_t st) {
+  static const bool off = [] { const char* e = getenv("CHX_AQL_OVERLAP"); return e && e[0] == '0'; }();
+  if (off) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_queues.find(st);
+  if (it != g_queues.end() && it->second->open) it->second->overlap_ok = true;
 }
 
 int chx_aql_dispatch_any(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, const void* kernarg, size_t explicit_bytes) {
@@ -561,6 +575,7 @@ void chx_aql_join(hipStream_t st) {
     if (it != g_queues.end()) Q = it->second;
   }
   if (!Q || !Q->open) return;
+  Q->overlap_ok = false;
   H.hsa_signal_store_relaxed(Q->done, 1);
   push_barrier(Q, hsa_signal_t{0}, Q->done, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_SYSTEM);
   (void)wait_zero(Q->done, "the queue has not drained for 120 s");

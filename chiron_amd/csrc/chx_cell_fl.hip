@@ -564,6 +564,9 @@ extern "C" int chx_nl_rows_cell_fl(int32_t n, int32_t m, chx_box_t box, float cu
   }
   const unsigned sb = (unsigned)((n + 255) / 256 < 64 ? (n + 255) / 256 : 64);
   CHX_LAUNCH(k_build_epilogue, dim3(sb), dim3(256), st, n_nbr_out, deg_out, n, m, status8, publish_host_dst8);
+  // (on the step queue the first step launch behind the build need not wait for this summary: it reads n_nbr / deg, which
+  // the steps only read, and writes the status block, which they never touch)
+  chx_aql_allow_overlap(st);
   return chx_check_launch("chx_nl_rows_cell_fl");
 }
 

@@ -61,7 +61,9 @@ def test_step_queue_and_its_fence_modes_leave_every_bit_of_the_trajectory(worklo
     late_gate = _run({"CHX_AQL_OPEN_AT_START": "0"}, workload, steps)
     opened = lambda r: r["queue"]["gates"] + r["queue"]["idle_opens"]  # (through a marker launch / on an idle stream)
     assert steps_only["hash"] == late_gate["hash"] == hip["hash"], (steps_only, late_gate, hip)
-    assert steps_only["queue"]["on"] and opened(steps_only) > opened(bare)  # (steps only: an opening per rebuild)
+    # (steps only: an opening per rebuild -- unless every rebuild is a synchronous one anyway, CHX_SYNC_REBUILD=1)
+    assert steps_only["queue"]["on"] and opened(steps_only) >= opened(bare)
+    assert opened(steps_only) > opened(bare) or os.environ.get("CHX_SYNC_REBUILD") == "1"
     assert not hip["queue"]["on"] and hip["queue"]["dispatched"] == 0
     assert fenced["queue"]["on"] and fenced["queue"]["hot_release"] == "agent"
     assert bare["queue"]["on"] and bare["queue"]["hot_release"] == "none", bare["queue"]
