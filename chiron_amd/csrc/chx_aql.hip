@@ -45,6 +45,9 @@
 #include "chx_common.h"
 
 int chx_aql_open_count = 0;
+// the start-up check's kernels (chx_core.hip)
+const void* chx_selfcheck_fill_fn();
+const void* chx_selfcheck_read_fn();
 
 namespace {
 
@@ -291,6 +294,90 @@ bool init_locked() {
   return true;
 }
 
+bool g_selfchecked = false;
+int g_selfcheck_result = -1;  // -1 not run, 0 passed, > 0 stale words seen (fences switched back on)
+
+// forward: the packet helpers below
+uint64_t reserve(Queue* Q, hsa_signal_t* completion);
+inline void publish(Queue* Q, uint64_t widx, uint16_t header);
+bool wait_zero(hsa_signal_t sig, const char* what);
+inline void* slot_of(Queue* Q, uint64_t widx);
+
+// One raw kernel packet with explicit fence scopes (the self-check only).
+void raw_packet(Queue* Q, const AqlKernel* k, unsigned blocks, const void* args, size_t nbytes, int acquire, int release,
+                hsa_signal_t completion) {
+  hsa_signal_t seg{0};
+  const uint64_t widx = reserve(Q, &seg);
+  char* ka = Q->ring + SLOT * (widx % Q->size);
+  memcpy(ka, args, nbytes);
+  __builtin_ia32_sfence();
+  (void)*reinterpret_cast<volatile uint32_t*>(ka + ((nbytes - 4) & ~(size_t)3));
+  hsa_kernel_dispatch_packet_t* pk = static_cast<hsa_kernel_dispatch_packet_t*>(slot_of(Q, widx));
+  pk->setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
+  pk->workgroup_size_x = 256, pk->workgroup_size_y = 1, pk->workgroup_size_z = 1;
+  pk->reserved0 = 0;
+  pk->grid_size_x = blocks * 256u, pk->grid_size_y = 1, pk->grid_size_z = 1;
+  pk->private_segment_size = k->private_size;
+  pk->group_segment_size = k->group_size;
+  pk->kernel_object = k->object;
+  pk->kernarg_address = ka;
+  pk->reserved2 = 0;
+  pk->completion_signal = completion.handle ? completion : seg;
+  if (completion.handle && seg.handle) H.hsa_signal_store_relaxed(seg, 0);  // (the caller waits for everything anyway)
+  publish(Q, widx, (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                              (acquire << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (release << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE)));
+}
+
+// Start-up check of the assumption the fence-free packets rest on (chx_core.hip: k_selfcheck_*): 256 rounds of
+// rewrite (one workgroup, write-through) / re-read (1024 workgroups, plain vector and scalar loads) with acquire =
+// release = NONE on every packet.  One stale word -> every packet gets HIP's agent-scope fences for the life of the
+// process (and the status string says so).  About a millisecond, once per process.  CHX_AQL_SELFCHECK=0 skips it.
+void selfcheck_fences(Queue* Q, hipStream_t st) {
+  if (g_selfchecked || !g_fence_none) return;
+  g_selfchecked = true;
+  const char* e = getenv("CHX_AQL_SELFCHECK");
+  if (e && e[0] == '0') return;
+  auto name_of = [&](const void* fn) -> const AqlKernel* {
+    const char* nm = hipKernelNameRefByPtr(fn, st);
+    if (!nm) return nullptr;
+    auto f = g_kernels.find(nm);
+    return f == g_kernels.end() ? nullptr : &f->second;
+  };
+  const AqlKernel* kf = name_of(chx_selfcheck_fill_fn());
+  const AqlKernel* kr = name_of(chx_selfcheck_read_fn());
+  if (!kf || !kr) return;  // (libchx_k_core.hsaco absent: nothing to run the check with)
+  int32_t* mem = nullptr;
+  if (H.hsa_amd_memory_pool_allocate(g_dev_pool, 8192, 0, reinterpret_cast<void**>(&mem)) != HSA_STATUS_SUCCESS) return;
+  if (H.hsa_amd_agents_allow_access(1, &g_cpu, nullptr, mem) != HSA_STATUS_SUCCESS) return;
+  int32_t* buf = mem;
+  int32_t* bad = mem + 1536;  // (its own 128-byte lines, away from the 4 KB under test)
+  bad[0] = bad[1] = 0;
+  __builtin_ia32_sfence();
+  (void)*reinterpret_cast<volatile int32_t*>(bad + 1);
+  hsa_signal_t done;
+  if (H.hsa_signal_create(1, 0, nullptr, &done) != HSA_STATUS_SUCCESS) return;
+  const int rounds = 256;
+  for (int i = 0; i < rounds; ++i) {
+    struct { int32_t* b; int v; } fa = {buf, i + 1};
+    struct { const int32_t* b; int v; int32_t* bad; } ra = {buf, i + 1, bad};
+    raw_packet(Q, kf, 1, &fa, sizeof(fa), i == 0 ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE, hsa_signal_t{0});
+    const bool last = i == rounds - 1;
+    raw_packet(Q, kr, 1024, &ra, sizeof(ra), HSA_FENCE_SCOPE_NONE, last ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_NONE,
+               last ? done : hsa_signal_t{0});
+  }
+  if (!wait_zero(done, "the start-up check of the step queue did not finish")) return;
+  const int stale = reinterpret_cast<volatile int32_t*>(bad)[0] + reinterpret_cast<volatile int32_t*>(bad)[1];
+  g_selfcheck_result = stale;
+  if (stale != 0) {
+    g_fence_none = false;
+    snprintf(g_err, sizeof(g_err), "step queue: the start-up check read %d stale words behind acquire-less dispatches: every packet "
+                                   "carries agent-scope fences in this process", stale);
+    fprintf(stderr, "[chx] %s\n", g_err);
+  } else if (getenv("CHX_AQL_VERBOSE")) {
+    fprintf(stderr, "[chx] step queue: start-up check passed (%d rewrite / re-read rounds without fences, no stale word)\n", rounds);
+  }
+}
+
 Queue* queue_for(hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_queues.find(st);
@@ -315,6 +402,7 @@ Queue* queue_for(hipStream_t st) {
   }
   if (s != HSA_STATUS_SUCCESS) return fail("signals", s), delete Q, nullptr;
   g_queues[st] = Q;
+  selfcheck_fences(Q, st);  // (the process's first queue: once)
   return Q;
 }
 

@@ -229,6 +229,30 @@ extern "C" int chx_ctrl_reset(int32_t* ctrl, chx_stream_t stream) {
   return chx_check_launch("chx_ctrl_reset");
 }
 
+// ---------------------------------------------------------------------------
+// The step queue's start-up check (chx_aql.hip: selfcheck_fences): before it sends steady-state packets without cache
+// fences it makes sure, on THIS card with THIS firmware, that a dispatch without an acquire fence reads no stale data.
+// k_selfcheck_fill (one workgroup) rewrites a 4 KB buffer with write-through stores; k_selfcheck_read (every CU, several
+// workgroups each) reads all of it back with plain vector loads and one scalar load and counts the words that are not
+// the value just written -- after the previous round left the old value in every L1, scalar cache and L2.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_selfcheck_fill(int32_t* buf, int val) {
+  typedef int i4v __attribute__((ext_vector_type(4)));
+  const i4v t = {val, val, val, val};
+  int32_t* p = buf + 4 * threadIdx.x;
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+}
+__global__ __launch_bounds__(256) void k_selfcheck_read(const int32_t* buf, int val, int32_t* bad) {
+  const int4 t = reinterpret_cast<const int4*>(buf)[threadIdx.x];
+  const int s0 = buf[(blockIdx.x & 7) * 32];  // (uniform address: a scalar load)
+  const int n = (t.x != val) + (t.y != val) + (t.z != val) + (t.w != val);
+  if (n) atomicAdd(bad, n);
+  if (threadIdx.x == 0 && s0 != val) atomicAdd(bad + 1, 1);
+}
+// (referenced from the host so that the stubs, and with them the names hipKernelNameRefByPtr hands out, exist)
+const void* chx_selfcheck_fill_fn() { return reinterpret_cast<const void*>(&k_selfcheck_fill); }
+const void* chx_selfcheck_read_fn() { return reinterpret_cast<const void*>(&k_selfcheck_read); }
+
 // copy n <= 64 ints to host-mapped pinned memory with system-scope visibility
 __global__ void k_publish(const int32_t* __restrict__ src, int32_t* __restrict__ host_dst, int n) {
   if ((int)threadIdx.x < n) {
