@@ -54,6 +54,18 @@ int main() {
     EXPECT(sqrtf(t) < c && !(sqrtf(nextafterf(t, INFINITY)) < c));
   }
 
+  // ---- the step queue without a GPU: nothing to join, nothing to open, the queue reports itself off with a reason
+  EXPECT(chx_steps_join(nullptr) == CHX_OK);
+  EXPECT(chx_steps_open(nullptr) == CHX_OK);
+  {
+    int64_t info[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    EXPECT(chx_step_queue_info(info, nullptr) == CHX_OK);
+    EXPECT(info[0] == 0 && info[1] == -1 && info[3] == 0 && info[6] == 0);
+    EXPECT(chx_step_queue_info(nullptr, nullptr) == CHX_OK);
+    EXPECT(chx_step_queue_status() != nullptr && strlen(chx_step_queue_status()) > 0);
+    EXPECT(chx_steps_join(nullptr) == CHX_OK);
+  }
+
   // ---- chx_cell_grid_h
   int32_t nc[3] = {-7, -7, -7};
   chx_box_t open_box = {0, 0.f, 0.f, 0.f};
