@@ -162,6 +162,8 @@ struct AgentPick {
   hsa_agent_t first_gpu;
   hsa_agent_t match;
   bool matched;
+  int n_bdf;  // agents whose bus / device / function match (whatever their domain query said)
+  hsa_agent_t bdf_match;
 };
 hsa_status_t agent_cb(hsa_agent_t a, void* data) {
   AgentPick* p = static_cast<AgentPick*>(data);
@@ -174,6 +176,7 @@ hsa_status_t agent_cb(hsa_agent_t a, void* data) {
   H.hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf);
   H.hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain);
   if (p->have_want && !p->matched && bdf == p->want_bdf && domain == p->want_domain) p->match = a, p->matched = true;
+  if (p->have_want && bdf == p->want_bdf && p->n_bdf++ == 0) p->bdf_match = a;
   return HSA_STATUS_SUCCESS;
 }
 hsa_status_t pool_cb(hsa_amd_memory_pool_t pool, void*) {
@@ -256,6 +259,7 @@ bool init_locked() {
   }
   H.hsa_iterate_agents(agent_cb, &pick);
   if (pick.matched) g_gpu = pick.match, g_have_gpu = true;
+  else if (pick.n_bdf == 1) g_gpu = pick.bdf_match, g_have_gpu = true;  // (a runtime that does not report PCI domains)
   else if (pick.n_gpu == 1) g_gpu = pick.first_gpu, g_have_gpu = true;
   if (!g_have_gpu || !g_have_cpu) return fail("the HIP device was not found among the HSA agents"), false;
   H.hsa_amd_agent_iterate_memory_pools(g_gpu, pool_cb, nullptr);

@@ -103,6 +103,9 @@ def test_step_queue_orders_with_the_stream_it_is_paired_with():
     torch.cuda.synchronize()
     state3, nbr = integ.run(state2, thermo, number_of_steps=30, nbr_list=nbr)
     info2 = ops.step_queue_info()
-    assert info2["idle_opens"] > info1["idle_opens"] and info2["gates"] == info1["gates"]
+    if os.environ.get("CHX_AQL_SCOPE", "run")[0] not in "sS" and os.environ.get("CHX_AQL_OPEN_AT_START", "1") != "0":
+        assert info2["idle_opens"] > info1["idle_opens"] and info2["gates"] == info1["gates"]
+    else:  # (the run-start build went through HIP: the first step packet found the stream busy and waited at a gate)
+        assert info2["gates"] + info2["idle_opens"] > info1["gates"] + info1["idle_opens"]
     assert torch.isfinite(state3.positions).all()
     assert torch.isfinite(state2.positions).all() and not torch.equal(state2.positions, x1)
