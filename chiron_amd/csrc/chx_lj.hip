@@ -846,7 +846,10 @@ void chx_launch_ap_step(const StepArgs& a, long long step, int n_kicks, int do_a
       std::memset(&ka, 0, sizeof(ka));
       ka.a = a, ka.step = step, ka.n_kicks = n_kicks, ka.do_aoa = do_aoa, ka.use_cutoff = use_cutoff;
       const unsigned blocks = a.n <= 2048 ? (unsigned)((a.n + 3) / 4) : (unsigned)((a.n + 15) / 16);
-      if (chx_aql_dispatch(st, k, blocks, &ka, sizeof(ka), true) == CHX_OK) return;
+      // (an A-O-A launch of this kernel leaves write-through stores only -- positions and velocities, step_epilogue; no
+      // control words on the paths without a Verlet list -- so it needs no release fence; the force-only launch that ends a
+      // run also writes the state in user order with plain stores)
+      if (chx_aql_dispatch(st, k, blocks, &ka, sizeof(ka), do_aoa == 0) == CHX_OK) return;
     }
   }
   if (a.n <= 2048) {

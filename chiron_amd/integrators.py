@@ -56,6 +56,23 @@ _EV_LOG_CAP = 4096
 _CARRY_DEFAULT = __import__("os").environ.get("CHX_LIST_CARRY", "1") != "0"
 _CARRY_MAX_STEPS_DEFAULT = int(__import__("os").environ.get("CHX_LIST_CARRY_MAX_STEPS", "64"))
 
+_MODS = None
+
+
+def _mods():
+    """(NeighborListNsqrd, PairListNsqrd, LJPotential, get_list_of_mass, initialize_velocities): imported on first use
+    (the modules import each other) and kept -- a ``from . import`` statement inside run() costs over a microsecond per
+    call, on the path to the first launch of every short run()."""
+    global _MODS
+    if _MODS is None:
+        from .neighbors import NeighborListNsqrd, PairListNsqrd
+        from .potential import LJPotential
+        from .utils import get_list_of_mass, initialize_velocities
+
+        _MODS = (NeighborListNsqrd, PairListNsqrd, LJPotential, get_list_of_mass, initialize_velocities)
+    return _MODS
+
+
 def _wait_for_steps_and_stream(device_wide: bool = False) -> None:
     """Host wait for everything this thread has enqueued: the step launches (they run on the step queue paired with the
     stream, include/chx.h: chx_steps_join -- a wait for the stream alone does not cover them) and then the stream."""
@@ -154,9 +171,7 @@ class LangevinIntegrator:
     ) -> Tuple[SamplerState, object]:
         """chiron/integrators.py:75-218.  ``noise`` (number_of_steps, N, 3) optionally
         replaces the device PRNG in the O step (deterministic parity tests)."""
-        from .neighbors import NeighborListNsqrd, PairListNsqrd
-        from .potential import LJPotential
-        from .utils import get_list_of_mass, initialize_velocities
+        NeighborListNsqrd, PairListNsqrd, LJPotential, get_list_of_mass, initialize_velocities = _MODS or _mods()
 
         potential = thermodynamic_state.potential
         # (the Quantity around the topology's cached mass array costs 3.5 us to make: kept while the array is the same object)
@@ -355,7 +370,7 @@ class LangevinIntegrator:
         replica) take the ordinary path.  Such positions are covered by the list -- the run that returned them checked
         them against it in its last launch and renewed it if need be (``_RunState.final_kick``) -- unless somebody wrote
         to the tensor behind the version stamp's back: the device checks again (chx_validate_snap)."""
-        from .neighbors import NeighborListNsqrd
+        NeighborListNsqrd = (_MODS or _mods())[0]
 
         offer, self._carry = self.__dict__.get("_carry"), None
         if offer is None or not self.list_carry or not (0 < number_of_steps <= self.list_carry_max_steps):
@@ -463,7 +478,7 @@ class _RunState:
         """``packed``: the list build that preceded this call (``NeighborListNsqrd._build_speculative`` with the pack
         rider) has already written the state into the integrator's buffers in the new list's order and reset the
         control block."""
-        from .neighbors import NeighborListNsqrd, PairListNsqrd
+        NeighborListNsqrd, PairListNsqrd = (_MODS or _mods())[:2]
 
         self.integ = integ
         self.potential = potential
