@@ -281,6 +281,11 @@ def load() -> C.CDLL:
             if have != want:
                 raise ChxError(f"{LIB_PATH} was built from other sources (hash {have[:16]}, tree {want[:16]}): "
                                "run `python -c 'import __graft_entry__ as g; g.build()'`")
+            # the code objects the step queue dispatches from (libchx_step.hsaco, libchx_k_*.hsaco) belong to the same
+            # build: without them the library would quietly fall back to HIP launches (include/chx.h, "The step queue")
+            if os.environ.get("CHX_AQL", "1") != "0" and not _build.step_object_current():
+                raise ChxError(f"{_build.STEP_OUT} (the step queue's code objects) is missing or was built from other sources: "
+                               "run `python -c 'import __graft_entry__ as g; g.build()'` (CHX_AQL=0 runs without the queue)")
     _lib = lib
     return lib
 

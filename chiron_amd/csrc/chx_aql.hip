@@ -1,28 +1,35 @@
-// libchx: the step queue.  The fused step kernels (k_lj_step, k_ap_step) are dispatched as hand-written AQL kernel
-// dispatch packets on a private user-mode HSA queue instead of through hipLaunchKernelGGL.
+// libchx: the step queue.  Inside LangevinIntegrator.run() and inside a chunk of the device-resident Monte Carlo loop the
+// library's kernels are dispatched as hand-written AQL kernel-dispatch packets on a private user-mode HSA queue instead
+// of through hipLaunchKernelGGL: the fused step kernels always (chx_launch_step), unpack / the list build chain / pack /
+// the Monte Carlo trial while the queue is open (chx_launch.h).
 //
-// Why (round 5, scripts/ub/aql_probe.hip, profiles/r05_aql_probe.md):
-//   * the host side of a dispatch is a 320-byte copy, a 64-byte packet and a doorbell write -- 0.02-1 us against the
-//     2.5 us of a HIP launch (5+ us in the HIP runtime's slow launch regime, profiles/r03_launch_regime.md, which then
-//     starves a 5 us step kernel): the device's rate no longer depends on the launching thread;
+// Why (round 5, scripts/ub/aql_probe.hip, profiles/r05_step_queue.md):
+//   * the host side of a dispatch is a copy of the argument block into device memory, a 64-byte packet and a doorbell
+//     write -- about a microsecond against the 2.5 us of a HIP launch (5+ us in the HIP runtime's slow launch regime,
+//     profiles/r03_launch_regime.md, which starves a 5 us step kernel for the life of one fresh process in ten): the
+//     device's rate no longer depends on the launching thread;
 //   * the packet header carries the fence scopes.  HIP gives every kernel agent-scope acquire + release fences; a
-//     steady-state step launch needs neither: its outputs leave as write-through (sc1) stores, and the hardware
+//     steady-state step launch needs neither: its outputs leave as write-through (sc1) stores or atomics, and the hardware
 //     invalidates the vector L1 and the scalar cache at every dispatch whatever the acquire scope says (measured: 3000
 //     rewrite / re-read rounds over every CU, not one stale word with acquire = release = NONE and write-through
-//     stores; with plain stores and no release every word is stale -- the test has teeth).  Without the two cache
-//     operations a dependent launch boundary is 0.25 us shorter.  CHX_AQL_FENCE=agent keeps HIP's scopes.
+//     stores; with plain stores and no release every word is stale -- the test has teeth; the first queue of a process
+//     repeats it on the card at hand, selfcheck_fences).  Without the two cache operations a dependent launch boundary is
+//     0.25 us shorter.  Every other packet ends with an agent-scope release.  CHX_AQL_FENCE=agent keeps HIP's scopes;
+//   * a list rebuild inside a run is a sequence of packets behind the drained no-op launches: no join, no HIP launch.
 //
 // Ordering with the HIP stream the rest of libchx (and torch) launches on -- the Python layer thinks in ONE stream:
-//   HIP -> queue: the first packet after a join is preceded by a barrier-AND packet on a gate signal, and a one-thread
-//                 marker kernel launched on the HIP stream opens the gate: the packets run behind everything that was
-//                 enqueued on the stream before them;
-//   queue -> HIP: chx_aql_join() -- a barrier packet with a completion signal, and the host waits for it.  Every libchx
-//                 entry point joins before it launches on a stream (chx_stream), and the Python layer joins where it
-//                 used to wait for the stream.
-// The kernels come from libchx_step.hsaco, the device half of chx_lj.hip compiled on its own (chiron_amd/build.py): same
-// source, same flags, same ISA as the copies inside libchx.so.  The HSA runtime is the instance the process's HIP runtime
-// already uses (found through the loaded libamdhip64's directory, bound with dlsym: no second runtime, no link-time
-// dependency).
+//   stream -> queue: opening the queue (chx_aql_open; the first dispatch does it by itself).  Nothing pending on the
+//                 stream (hipStreamQuery): nothing to wait behind.  Otherwise a barrier-AND packet on a gate signal,
+//                 and a one-thread marker kernel launched on the stream opens the gate: the packets run behind
+//                 everything that was enqueued on the stream before them;
+//   queue -> stream: chx_aql_join() -- a barrier packet with a completion signal, and the host waits for it.  Every libchx
+//                 entry point that is not queue-capable joins before it launches on a stream (chx_stream), a
+//                 queue-capable one rides on the open queue (chx_launch.h), and the Python layer joins where it used to
+//                 wait for the stream.
+// The kernels come from libchx_step.hsaco (the device half of chx_lj.hip) and libchx_k_<unit>.hsaco, compiled by
+// chiron_amd/build.py from the same sources with the same flags as the copies inside libchx.so.  The HSA runtime is the
+// image the process's HIP runtime already runs on (the one that is initialised; bound with dlsym: no second runtime, no
+// link-time dependency).  At most 128 packets are outstanding (a completion signal per 32-packet segment).
 #include <cxxabi.h>
 #include <dlfcn.h>
 #include <fcntl.h>
@@ -271,7 +278,7 @@ bool init_locked() {
   if (s != HSA_STATUS_SUCCESS) return fail("hsa_executable_create_alt", s), false;
   const std::string dir = own_dir();
   std::vector<std::string> files = {dir + "/libchx_step.hsaco"};
-  for (const char* unit : {"core", "langevin", "neighbors", "cell_fl", "mc"}) files.push_back(dir + "/libchx_k_" + unit + ".hsaco");
+  for (const char* unit : {"core", "neighbors", "cell_fl", "mc"}) files.push_back(dir + "/libchx_k_" + unit + ".hsaco");
   int loaded = 0;
   for (size_t i = 0; i < files.size(); ++i) {
     const int fd = open(files[i].c_str(), O_RDONLY);

@@ -1037,3 +1037,27 @@ def test_step_code_object_is_current_and_holds_every_step_kernel():
             assert k in text, (unit, k)
     ap = [n for n in sizes if n.startswith("_Z9k_ap_stepILi64ELb1EE") or n.startswith("_Z9k_ap_stepILi16ELb0EE")]
     assert len(ap) == 2 and all(276 <= sizes[n] <= 280 for n in ap), {n: sizes[n] for n in ap}  # (sizeof(ApKernarg) = 280)
+
+
+def test_library_refuses_to_load_without_the_step_queues_code_objects():
+    """The step queue falls back to HIP launches when its code objects cannot be loaded -- a working path, but a silently
+    slower one.  With the sources beside the library (an in-tree build) a missing or stale libchx_step.hsaco is therefore
+    refused at load time, like a stale libchx.so; CHX_AQL=0 (no queue wanted) loads without."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("from chiron_amd import build\n"
+            "build.step_object_current = lambda: False\n"
+            "from chiron_amd import _lib\n"
+            "try:\n"
+            "    _lib.load()\n"
+            "    print('LOADED')\n"
+            "except _lib.ChxError as e:\n"
+            "    print('REFUSED', 'step queue' in str(e))\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("CHX_AQL", "CHX_LIB", "CHX_ALLOW_STALE_LIB")}
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.split()[-2:] == ["REFUSED", "True"], (out.stdout, out.stderr[-1500:])
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(env, CHX_AQL="0"), capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0 and out.stdout.split()[-1] == "LOADED", (out.stdout, out.stderr[-1500:])
