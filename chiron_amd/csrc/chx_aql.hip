@@ -171,6 +171,9 @@ struct AgentPick {
   bool matched;
   int n_bdf;  // agents whose bus / device / function match (whatever their domain query said)
   hsa_agent_t bdf_match;
+  char want_uuid[17];  // the HIP device's UUID (16 characters), "" when unknown
+  int n_uuid;
+  hsa_agent_t uuid_match;
 };
 hsa_status_t agent_cb(hsa_agent_t a, void* data) {
   AgentPick* p = static_cast<AgentPick*>(data);
@@ -184,6 +187,12 @@ hsa_status_t agent_cb(hsa_agent_t a, void* data) {
   H.hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain);
   if (p->have_want && !p->matched && bdf == p->want_bdf && domain == p->want_domain) p->match = a, p->matched = true;
   if (p->have_want && bdf == p->want_bdf && p->n_bdf++ == 0) p->bdf_match = a;
+  if (p->want_uuid[0]) {
+    char uuid[32] = "";  // "GPU-" + 16 hex characters
+    if (H.hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_UUID, uuid) == HSA_STATUS_SUCCESS &&
+        strncmp(uuid, "GPU-", 4) == 0 && strncmp(uuid + 4, p->want_uuid, 16) == 0 && p->n_uuid++ == 0)
+      p->uuid_match = a;
+  }
   return HSA_STATUS_SUCCESS;
 }
 hsa_status_t pool_cb(hsa_amd_memory_pool_t pool, void*) {
@@ -264,11 +273,26 @@ bool init_locked() {
       pick.want_bdf = (b << 8) | (d << 3) | f;
     }
   }
+  {
+    hipUUID uu;
+    memset(&uu, 0, sizeof(uu));
+    if (hipDeviceGetUuid(&uu, dev) == hipSuccess && uu.bytes[0] != 0) memcpy(pick.want_uuid, uu.bytes, 16);
+    else (void)hipGetLastError();
+  }
   H.hsa_iterate_agents(agent_cb, &pick);
-  if (pick.matched) g_gpu = pick.match, g_have_gpu = true;
+  // The queue must sit on the very card the HIP device is: by UUID when both runtimes report one; else by PCI address; a
+  // UUID that names one agent and a PCI address that names another switch the queue off rather than guess.
+  if (pick.n_uuid == 1 && pick.matched && pick.uuid_match.handle != pick.match.handle)
+    return fail("the HIP device's UUID and PCI address name different HSA agents"), false;
+  if (pick.n_uuid == 1) g_gpu = pick.uuid_match, g_have_gpu = true;
+  else if (pick.matched) g_gpu = pick.match, g_have_gpu = true;
   else if (pick.n_bdf == 1) g_gpu = pick.bdf_match, g_have_gpu = true;  // (a runtime that does not report PCI domains)
   else if (pick.n_gpu == 1) g_gpu = pick.first_gpu, g_have_gpu = true;
   if (!g_have_gpu || !g_have_cpu) return fail("the HIP device was not found among the HSA agents"), false;
+  if (getenv("CHX_AQL_VERBOSE"))
+    fprintf(stderr, "[chx] step queue: HIP device %d (%s, UUID %.16s) is the HSA agent matched by %s (%d GPU agents)\n", dev, bus,
+            pick.want_uuid[0] ? pick.want_uuid : "?", pick.n_uuid == 1 ? "UUID" : (pick.matched ? "PCI address" : (pick.n_bdf == 1 ? "bus/device/function" : "being the only one")),
+            pick.n_gpu);
   H.hsa_amd_agent_iterate_memory_pools(g_gpu, pool_cb, nullptr);
   if (!g_have_pool) return fail("no device memory pool"), false;
   // the kernels' code objects: libchx_step.hsaco (the step kernels: required) and libchx_k_*.hsaco (the other
