@@ -51,6 +51,15 @@
 #include "chx_aql.h"
 #include "chx_common.h"
 
+// write-combined stores through the BAR must have left the core before the read-back / the doorbell
+static inline void store_fence() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_sfence();
+#else
+  __sync_synchronize();
+#endif
+}
+
 int chx_aql_open_count = 0;
 // the start-up check's kernels (chx_core.hip)
 const void* chx_selfcheck_fill_fn();
@@ -345,7 +354,7 @@ void raw_packet(Queue* Q, const AqlKernel* k, unsigned blocks, const void* args,
   const uint64_t widx = reserve(Q, &seg);
   char* ka = Q->ring + SLOT * (widx % Q->size);
   memcpy(ka, args, nbytes);
-  __builtin_ia32_sfence();
+  store_fence();
   (void)*reinterpret_cast<volatile uint32_t*>(ka + ((nbytes - 4) & ~(size_t)3));
   hsa_kernel_dispatch_packet_t* pk = static_cast<hsa_kernel_dispatch_packet_t*>(slot_of(Q, widx));
   pk->setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
@@ -387,7 +396,7 @@ void selfcheck_fences(Queue* Q, hipStream_t st) {
   int32_t* buf = mem;
   int32_t* bad = mem + 1536;  // (its own 128-byte lines, away from the 4 KB under test)
   bad[0] = bad[1] = 0;
-  __builtin_ia32_sfence();
+  store_fence();
   (void)*reinterpret_cast<volatile int32_t*>(bad + 1);
   hsa_signal_t done;
   if (H.hsa_signal_create(1, 0, nullptr, &done) != HSA_STATUS_SUCCESS) return;
@@ -611,7 +620,7 @@ int dispatch_core(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, con
     memcpy(ka + ib, im, want);
     end = ib + want;
   }
-  __builtin_ia32_sfence();
+  store_fence();
   (void)*reinterpret_cast<volatile uint32_t*>(ka + ((end - 4) & ~(size_t)3));
   hsa_kernel_dispatch_packet_t* pk = static_cast<hsa_kernel_dispatch_packet_t*>(slot_of(Q, widx));
   const int ndim = grid.z * block.z > 1 ? 3 : (grid.y * block.y > 1 ? 2 : 1);
