@@ -212,6 +212,187 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
                                           first_out, n_nbr, fg, fcap, fl, deg, status, cl);
 }
 
+// SIXTEEN LANES per particle, four particles per wavefront, candidates FILTERED before they are tested (round 5): the
+// integrator's rebuilds at the sizes below the cell-wise kernel's (half rows counted only, a candidate list per cell).
+// The per-particle kernel above is bound by vector-instruction issue (PMC, C3 equilibrated: 461 instructions per row at
+// 4 cycles each on 1024 SIMDs = its 25 us): ~70 per batch of 64 candidates -- the reference's predicate in the reference's
+// orientation, two ballots, slot and address arithmetic, the loads of ids and positions -- although only one candidate
+// in six of the 27-cell neighbourhood lies within the cutoff, and ~200 per row of prologue and epilogue.  Here
+//   * a wavefront issues prologue and epilogue once per FOUR rows, and a batch of 16 wastes fewer lanes on a list's tail;
+//   * phase 1 runs every candidate through a CHEAP distance test (nearest image by rounding, 17 instructions, no id) with a
+//     threshold widened far beyond its rounding error, and appends the survivors -- their positions in the candidate
+//     list, in candidate order -- to the row's slice of LDS; phase 2 puts only those (one in six) through the exact
+//     predicate and writes the row as the per-particle kernel does: same candidates in the same order through the same
+//     arithmetic, so the same bits;
+//   * candidate indices and positions come through buffer descriptors (a 32-bit lane offset plus a scalar; a load past the
+//     end of its array returns zero), so no load is predicated and no index clamped, and the candidate indices of the first
+//     two iterations are requested together with the list's length: the positions of both are in flight in the third
+//     round trip.  The loop is unrolled twice over two register sets: nothing is moved from "next" to "current".
+// A row whose cell has no list (neighbourhood longer than the capacity) or with more survivors than its slice holds is
+// redone by the general routine, the whole wavefront on it.
+#define CHX_SUB 16
+#define CHX_SURV_CAP 192  // survivors kept per row (the force list's own capacity is 6 x 16 at the BASELINE geometry)
+// The filter's constants (host: sub_filter_of): 1/L per axis and the widened threshold.  Its nearest image, d - L rint(d/L),
+// differs per component from the reference's (chx_common.h: min_image) by a few ulp of the box length, the squared
+// distance by less than 6 sqrt(T) L 2^-20; the threshold is T widened by ten times that plus a thousandth of T, and a
+// pair more than a box length and a half apart on some axis (unwrapped coordinates: the rounding error grows with the
+// distance) passes untested.
+struct SubFilter {
+  float ilx, ily, ilz, t_wide;
+};
+static SubFilter sub_filter_of(const chx_box_t& box, float T) {
+  const float lmax = box.lx > box.ly ? (box.lx > box.lz ? box.lx : box.lz) : (box.ly > box.lz ? box.ly : box.lz);
+  return SubFilter{1.0f / box.lx, 1.0f / box.ly, 1.0f / box.lz, T * 1.001f + 6e-5f * lmax * sqrtf(T)};
+}
+__global__ __launch_bounds__(256) void k_nl_build_sub_fl(
+    const float4* __restrict__ xs4, int n, int m, Box3 box, float T, CellGrid g, const int32_t* __restrict__ cell_start,
+    const uint32_t* __restrict__ sorted_ids, int32_t* __restrict__ n_nbr, int fg, int fcap, uint32_t* __restrict__ fl,
+    int32_t* __restrict__ deg, int32_t* __restrict__ status, CandLists cl, SubFilter filt) {
+  __shared__ uint32_t cand_all[4][CHX_RANGE_WORDS];
+  __shared__ uint32_t surv_all[4][CHX_WAVE / CHX_SUB][CHX_SURV_CAP];
+  constexpr int U = 2, STEP = CHX_SUB * U;  // candidates per lane and half iteration of phase 1
+  const int lane = lane_id();
+  const int sub = lane & (CHX_SUB - 1), shift = lane & ~(CHX_SUB - 1);
+  const int w_raw = (int)((blockIdx.x * blockDim.x + threadIdx.x) / CHX_SUB);
+  if (__builtin_amdgcn_readfirstlane(w_raw) >= n) return;  // (wave-uniform: the wavefront's first row)
+  const bool row_live = w_raw < n;
+  const int w = row_live ? w_raw : n - 1;
+  const uint32_t i = sorted_ids[w];
+  const float4 xw = xs4[w];
+  const float xi = xw.x, yi = xw.y, zi = xw.z;
+  const int c = __float_as_int(xw.w);
+  const int c_lin = ((c >> 20) * g.ncy + ((c >> 10) & 1023)) * g.ncx + (c & 1023);
+  uint32_t* surv = surv_all[threadIdx.x >> 6][lane / CHX_SUB];
+  const int ncell = g.ncx * g.ncy * g.ncz;
+  const __amdgpu_buffer_rsrc_t r_lst = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(cl.list), 0, ncell * cl.cap * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_xs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(xs4), 0, n * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_id = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(sorted_ids), 0, n * 4, 0x00020000);
+  const int row0 = c_lin * cl.cap * 4;  // byte offset of the row's candidate list
+  const int lo = row0 + sub * 4;        // ... of this lane's first candidate index
+  auto load_xyz = [&](uint32_t k, float* x) __attribute__((always_inline)) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b96(r_xs, (int)(k << 4), 0, 0);
+    x[0] = __uint_as_float(v[0]);
+    x[1] = __uint_as_float(v[1]);
+    x[2] = __uint_as_float(v[2]);
+  };
+  // second round trip: the list's length and, beside it, the candidate indices of the first two half iterations (an index
+  // read past the end of a row's list -- the next cell's, or stale words: a list is allocated to its capacity -- fetches
+  // some position or zero, and the comparison with the list's length drops it)
+  const int listed = cl.len[c_lin];
+  uint32_t k0[U], kx[U];  // kx: the indices whose positions the next half iteration requests
+  float xa[U][3], xb[U][3];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    k0[u] = __builtin_amdgcn_raw_buffer_load_b32(r_lst, lo + 4 * CHX_SUB * u, 0, 0);
+    kx[u] = __builtin_amdgcn_raw_buffer_load_b32(r_lst, lo + 4 * CHX_SUB * u, 4 * STEP, 0);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) load_xyz(k0[u], xa[u]);
+  bool redo = row_live && listed > cl.cap;
+  const int total = (row_live && !redo) ? listed : 0;
+  const uint32_t below = (1u << sub) - 1u;
+  int ns = 0;  // survivors of this row so far
+  // one half iteration: the candidates [t0, t0 + STEP) of every row, whose positions are in xc; the positions of the next
+  // STEP (indices in k: loaded a half iteration ago) are requested into xn, then k is reloaded with the indices after those
+  auto half = [&](int t0, float (*xc)[3], float (*xn)[3], uint32_t* k) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) load_xyz(k[u], xn[u]);
+    const int ahead = __builtin_amdgcn_readfirstlane(4 * (t0 + 2 * STEP));  // (uniform: said so, or the load is issued lane by lane)
+#pragma unroll
+    for (int u = 0; u < U; ++u) k[u] = __builtin_amdgcn_raw_buffer_load_b32(r_lst, lo + 4 * CHX_SUB * u, ahead, 0);
+    const int left = total - t0;  // candidates of this row not yet looked at
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float dx = xi - xc[u][0], dy = yi - xc[u][1], dz = zi - xc[u][2];
+      const float qx = rintf(dx * filt.ilx), qy = rintf(dy * filt.ily), qz = rintf(dz * filt.ilz);
+      const float rx = fmaf(-qx, box.lx, dx), ry = fmaf(-qy, box.ly, dy), rz = fmaf(-qz, box.lz, dz);
+      const float d2 = fmaf(rz, rz, fmaf(ry, ry, rx * rx));
+      const float far = fmaxf(fmaxf(fabsf(qx), fabsf(qy)), fabsf(qz));
+      const bool pass = (sub + CHX_SUB * u < left) & ((d2 <= filt.t_wide) | (far > 1.5f));
+      const uint32_t b = (uint32_t)(__ballot(pass) >> shift) & 0xFFFFu;
+      const int slot = ns + __popc(b & below);
+      if (pass && slot < CHX_SURV_CAP) surv[slot] = (uint32_t)(t0 + sub + CHX_SUB * u);
+      ns += __popc(b);
+    }
+  };
+  for (int t0 = 0; __ballot(t0 < total) != 0ull; t0 += 2 * STEP) {
+    half(t0, xa, xb, kx);
+    if (__ballot(t0 + STEP < total) == 0ull) break;
+    half(t0 + STEP, xb, xa, kx);
+  }
+  if (ns > CHX_SURV_CAP) {
+    redo = true;
+    ns = 0;
+  }
+  __threadfence_block();  // (the survivors are read back by other lanes of this wavefront)
+  // phase 2: the survivors through the reference's predicate, 16 per row at a time (list position -> index -> id and
+  // position: the position of the next batch and the index of the one after it are in flight while a batch is worked)
+  const int sh = 31 - __clz(CHX_FL_QUAD * fg), lg = 31 - __clz(fg);
+  uint32_t* fl_row = fl + ((size_t)w << sh);
+  const uint32_t chunk_stride = (uint32_t)n << sh;  // (the launcher checks: the table has fewer than 2^31 words, this fits 24 bits)
+  int count_f = 0, count_h = 0;
+  auto index_of = [&](int sx) __attribute__((always_inline)) {  // (past the row's survivors: its first candidate, never tested)
+    const uint32_t t = sx < ns ? surv[sx] : 0u;
+    return __builtin_amdgcn_raw_buffer_load_b32(r_lst, row0 + (int)(t << 2), 0, 0);
+  };
+  uint32_t k_c = index_of(sub), k_n = index_of(sub + CHX_SUB);
+  uint32_t j_c = __builtin_amdgcn_raw_buffer_load_b32(r_id, (int)(k_c << 2), 0, 0);
+  float x_c[3];
+  load_xyz(k_c, x_c);
+  for (int s0 = 0; __ballot(s0 < ns) != 0ull; s0 += CHX_SUB) {
+    const int sx = s0 + sub;
+    const uint32_t k = k_c, j = j_c;
+    const float xk = x_c[0], yk = x_c[1], zk = x_c[2];
+    k_c = k_n;
+    j_c = __builtin_amdgcn_raw_buffer_load_b32(r_id, (int)(k_c << 2), 0, 0);
+    load_xyz(k_c, x_c);
+    k_n = index_of(sx + 2 * CHX_SUB);
+    const bool hi = j > i;
+    float rx, ry, rz;
+    bool bad;
+    displacement_oriented_fast(box, hi, xi, yi, zi, xk, yk, zk, rx, ry, rz, bad);
+    if (__builtin_expect(bad, 0)) displacement_oriented(box, hi, xi, yi, zi, xk, yk, zk, rx, ry, rz);
+    const bool ok = (sx < ns) & (j != i) & (norm2(rx, ry, rz) <= T);
+    const uint32_t b = (uint32_t)(__ballot(ok) >> shift) & 0xFFFFu;
+    const int slot = count_f + __popc(b & below);
+    if (ok && slot < fcap) {
+      const uint32_t e = (uint32_t)slot & ((1u << sh) - 1u);
+      fl_row[__umul24((uint32_t)slot >> sh, chunk_stride) + (CHX_FL_QUAD * (e & (uint32_t)(fg - 1)) + (e >> lg))] = k | (hi ? CHX_FL_HI : 0u);
+    }
+    count_f += __popc(b);
+    count_h += (ok && hi) ? 1 : 0;  // (per lane: summed over the row's lanes once, below)
+  }
+#pragma unroll
+  for (int o = CHX_SUB / 2; o > 0; o >>= 1) count_h += __shfl_xor(count_h, o, CHX_WAVE);
+  if (row_live && !redo) {
+    // unused slots of the chunks the force kernel can touch: the row's own index (build_row_of_particle)
+    const int wd = CHX_FL_QUAD * fg;
+    const int used = count_f < fcap ? count_f : fcap;
+    int end = (used + wd - 1) / wd * wd;
+    end = end < wd ? wd : end;
+    end = end < fcap ? end : fcap;
+    for (int sl = used + sub; sl < end; sl += CHX_SUB) {
+      const uint32_t e = (uint32_t)sl & ((1u << sh) - 1u);
+      fl_row[__umul24((uint32_t)sl >> sh, chunk_stride) + (CHX_FL_QUAD * (e & (uint32_t)(fg - 1)) + (e >> lg))] = (uint32_t)w;
+    }
+    if (sub == 0) {
+      n_nbr[i] = count_h;
+      deg[w] = used;
+      if (count_f > fcap) {
+        atomicAdd(&status[4], 1);
+        atomicMax(&status[3], count_f);
+      }
+    }
+  }
+  unsigned long long todo = __ballot(redo && sub == 0);
+  while (todo) {  // (wave-uniform)
+    const int l = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    build_row_of_particle<true, false>(__builtin_amdgcn_readlane(w, l), cand_all[threadIdx.x >> 6], xs4, n, m, box, T, g, cell_start,
+                                       sorted_ids, nullptr, nullptr, n_nbr, fg, fcap, fl, deg, status, cl);
+  }
+}
+
 // One wavefront per CELL: the (about ten at the BASELINE density) particles of a cell share their 27-cell
 // neighbourhood, so the candidates are fetched once per cell -- one per lane, 64 at a time -- and tested against
 // every particle of the cell in turn (its position broadcast from a lane: v_readlane), instead of once per particle.
@@ -549,9 +730,20 @@ extern "C" int chx_nl_rows_cell_fl(int32_t n, int32_t m, chx_box_t box, float cu
   const bool per_particle = forced == 1 || (forced == 0 && (int64_t)grid.ncx * grid.ncy * grid.ncz < 8192);
   if (per_particle) {
     const CandLists cl = {cand_cap > 0 ? cand_list : nullptr, cand_len, cand_cap};
-    CHX_LAUNCH(half ? k_nl_build_cell_fl<true> : k_nl_build_cell_fl<false>, dim3(wb), dim3(256), st, xs, n, m, make_box3(box), T,
-               grid, cell_of, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, chunks * CHX_FL_QUAD * g, fl_out,
-               deg_out, status8, cl);
+    // the integrator's rebuilds (no half rows) with candidate lists: sixteen lanes per row and a filter in front of the
+    // predicate (k_nl_build_sub_fl; its 32-bit table offsets and 24-bit chunk stride bound the size).  CHX_BUILD_SUB=0:
+    // the general kernel (tests, A/B)
+    static const bool sub_rows = [] { const char* e = getenv("CHX_BUILD_SUB"); return !e || e[0] != '0'; }();
+    if (!half && cl.list != nullptr && sub_rows && (int64_t)chunks * CHX_FL_QUAD * g * n < (int64_t)1 << 31 &&
+        (int64_t)CHX_FL_QUAD * g * n < 1 << 24) {
+      const unsigned qb = (unsigned)(((int64_t)n * CHX_SUB + 255) / 256);
+      CHX_LAUNCH(k_nl_build_sub_fl, dim3(qb), dim3(256), st, xs, n, m, make_box3(box), T, grid, cell_start, sorted_ids, n_nbr_out,
+                 g, chunks * CHX_FL_QUAD * g, fl_out, deg_out, status8, cl, sub_filter_of(box, T));
+    } else {
+      CHX_LAUNCH(half ? k_nl_build_cell_fl<true> : k_nl_build_cell_fl<false>, dim3(wb), dim3(256), st, xs, n, m, make_box3(box), T,
+                 grid, cell_of, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, chunks * CHX_FL_QUAD * g, fl_out,
+                 deg_out, status8, cl);
+    }
   } else {
     const int ncell = grid.ncx * grid.ncy * grid.ncz;
     static const int split_env = [] { const char* e = getenv("CHX_BUILD_SPLIT"); return e ? atoi(e) : 0; }();

@@ -350,7 +350,13 @@ class LangevinIntegrator:
         st.finish()
         if not tail:
             host_tail()
-        updated_sampler_state = sampler_state._copy_with(*st.final_state_user(), box_copy=tail["box"])  # :210-218
+        final_xv = st.final_state_user()
+        if mode != "fused":
+            # (the launches of the paths without a Verlet list ride on the step queue too -- k_ap_step, the copy into user
+            # order just made: a run() returns with the queue drained, whatever the path; the fused path has waited in
+            # _enqueue_kick)
+            ops.steps_join()
+        updated_sampler_state = sampler_state._copy_with(*final_xv, box_copy=tail["box"])  # :210-218
         st.offer_carry(updated_sampler_state)
         updated_sampler_state.current_PRNG_key = tail["key"]
         self.n_rebuilds = st.n_rebuilds

@@ -650,15 +650,20 @@ def steps_open() -> None:
     check(_lib.load().chx_steps_open(_stream()), "chx_steps_open")
 
 
-_sq_probe = (C.c_int64 * 8)()
+_queue_on = {}
 
 
 def step_queue_on() -> bool:
-    """Do the fused step launches of the calling thread go through the step queue?  (The queue belongs to the device it
-    was opened on; asked every time -- a ctypes call -- because the answer depends on the thread's current device.)"""
-    out = (C.c_int64 * 8)()
-    check(_lib.load().chx_step_queue_info(out, None), "chx_step_queue_info")
-    return bool(out[0])
+    """Do the fused step launches of the calling thread go through the step queue?  The queue belongs to the device it was
+    opened on, so the answer is a function of the thread's current device: asked once per device (a ctypes call and a
+    lock), then remembered -- run() asks behind its final join, on the path to its return."""
+    dev = torch.cuda.current_device()
+    on = _queue_on.get(dev)
+    if on is None:
+        out = (C.c_int64 * 8)()
+        check(_lib.load().chx_step_queue_info(out, None), "chx_step_queue_info")
+        on = _queue_on[dev] = bool(out[0])
+    return on
 
 
 def step_queue_info() -> dict:

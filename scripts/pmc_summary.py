@@ -5,7 +5,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         name = r.get("Kernel_Name", "")
-        if not (name.startswith("void k_lj") or name.startswith("k_")):
+        if not (name.startswith("void k_") or name.startswith("k_")):
             continue
         key = name.split("(")[0].replace("void ", "") + " grid=" + r.get("Grid_Size", "?")
         acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -32,6 +32,20 @@ wrap(OPS, "cell_grid", "0d cell grid known")
 wrap(OPS, "nl_build_cell_fl", "0e build call entered", "before")
 wrap(N.NeighborListNsqrd, "_build_speculative", "1 build enqueued")
 wrap(I.LangevinIntegrator, "_take_carry", "0 carry decided")
+wrap(OPS, "steps_open", "0b queue being opened", "before")
+wrap(OPS, "steps_open", "0b' queue opened")
+wrap(OPS, "steps_join", "3d join returned")
+_lib_obj = OPS._lib.load()
+for _name, _tag in (("chx_cell_bin_fl", "0f binning call"), ("chx_nl_rows_cell_fl", "0g rows call")):
+    _orig = getattr(_lib_obj, _name)
+    def _mk(orig, tag):
+        def f(*a):
+            marks.setdefault(tag + " entered", time.perf_counter())
+            r = orig(*a)
+            marks.setdefault(tag + " returned", time.perf_counter())
+            return r
+        return f
+    setattr(_lib_obj, _name, _mk(_orig, _tag))
 wrap(I._RunState, "_setup_carry", "1a carry set up", "before")
 wrap(I._RunState, "_load", "1b _load entered", "before")
 wrap(I._RunState, "_open_generation", "1c generation opened")

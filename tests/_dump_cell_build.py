@@ -14,7 +14,10 @@ for tag, (n, rho, skin, m0) in {"dilute": (4000, 0.1, 0.5, 180), "dense": (6000,
                                 "three_cells": (700, 0.5, 0.1, 60),
                                 # ~15 particles per cell: passes on either side of the cell-wise kernel's on-chip-row limit,
                                 # and half rows of the lowest ids longer than an on-chip row
-                                "mixed": (5000, 0.15, 0.5, 180)}.items():
+                                "mixed": (5000, 0.15, 0.5, 180),
+                                # ~215 neighbours per particle with candidate lists in place: more than the filtered row kernel
+                                # (k_nl_build_sub_fl) keeps per row on chip, every row goes back to the general routine
+                                "crowded": (3000, 0.7, 0.4, 260)}.items():
     x, box = O.lj_lattice(n, rho, 0.34, seed=17)
     x = (x + np.random.default_rng(3).normal(scale=0.03, size=x.shape)).astype(np.float32)
     if tag == "mixed":  # uniformly random instead of a jittered lattice: cell occupancies scatter like a Poisson variable
@@ -39,4 +42,24 @@ for tag, (n, rho, skin, m0) in {"dilute": (4000, 0.1, 0.5, 180), "dense": (6000,
         used = np.maximum((deg + w - 1) // w, 1)
         keep = np.arange(table.shape[0])[:, None] < used[None, :]
         out[tag + "_fl"] = np.where(keep[:, :, None], table, 0)
+    # The integrator's rebuilds (half rows counted, not written: ops.nl_build_cell_fl(half_rows=False)), which below the
+    # cell-wise kernel's sizes go through the sixteen-lanes-per-row kernel (k_nl_build_sub_fl, CHX_BUILD_SUB=0: the
+    # per-particle one) -- with the force-list capacity the build settled on and with a single chunk (rows overflow: the
+    # status words that report it)
+    if fl is not None:
+        from chiron_amd import ops
+        cs = nbr._cs_md
+        ncell, nc = ops.cell_grid(nbr._box_h, cs, n)
+        for sfx, chunks in (("", fl.chunks), ("_tight", 1)):
+            _, _, n_nbr, ids, table, deg, status = ops.nl_build_cell_fl(xt, nbr._box_h, cs, int(nbr.n_max_neighbors), ncell, nc,
+                                                                      fl.g, chunks, {}, half_rows=False)
+            torch.cuda.synchronize()
+            deg, table = deg.cpu().numpy(), table.cpu().numpy()
+            w = 4 * fl.g
+            keep = np.arange(table.shape[0])[:, None] < np.maximum((deg + w - 1) // w, 1)[None, :]
+            out[tag + "_run_fl" + sfx] = np.where(keep[:, :, None], table, 0)
+            out[tag + "_run_deg" + sfx] = deg
+            out[tag + "_run_n" + sfx] = n_nbr.cpu().numpy()
+            out[tag + "_run_ids" + sfx] = ids.cpu().numpy()
+            out[tag + "_run_status" + sfx] = status.cpu().numpy()[:7]
 np.savez(sys.argv[1], **out)

@@ -1883,16 +1883,19 @@ def test_both_cell_build_kernels_write_the_same_bits(tmp_path):
     # (round 4: the per-particle kernel reads per-cell candidate index lists written by the binning -- chx_cell.h --
     # unless CHX_BUILD_LISTS=0, or a cell's neighbourhood is longer than a list holds: the "dense" system; a third dump
     # runs it on the older range search)
-    for kern, lists in (("particle", "1"), ("cell", "1"), ("particle", "0")):
-        path = tmp_path / f"{kern}{lists}.npz"
-        env = dict(os.environ, CHX_BUILD_KERNEL=kern, CHX_BUILD_LISTS=lists)
+    # (round 5: the integrator's rebuilds -- half rows counted only -- take sixteen lanes per row, four rows per wavefront,
+    # where the per-particle kernel would run with candidate lists; a fourth dump switches that off: CHX_BUILD_SUB=0)
+    for kern, lists, sub in (("particle", "1", "1"), ("cell", "1", "1"), ("particle", "0", "1"), ("particle", "1", "0")):
+        path = tmp_path / f"{kern}{lists}{sub}.npz"
+        env = dict(os.environ, CHX_BUILD_KERNEL=kern, CHX_BUILD_LISTS=lists, CHX_BUILD_SUB=sub)
         r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_dump_cell_build.py"), str(path)],
                            env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        got[kern + lists] = np.load(path)
+        got[kern + lists + ("" if sub == "1" else "_nosub")] = np.load(path)
     a = got["particle1"]
-    assert len(a.files) >= 30
-    for other in ("cell1", "particle0"):
+    assert len(a.files) >= 80
+    assert int(a["dilute_run_status_tight"][4]) > 0  # (rows beyond a one-chunk force list: counted)
+    for other in ("cell1", "particle0", "particle1_nosub"):
         b = got[other]
         assert sorted(a.files) == sorted(b.files)
         for key in a.files:

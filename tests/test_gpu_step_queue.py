@@ -109,3 +109,29 @@ def test_step_queue_orders_with_the_stream_it_is_paired_with():
         assert info2["gates"] + info2["idle_opens"] > info1["gates"] + info1["idle_opens"]
     assert torch.isfinite(state3.positions).all()
     assert torch.isfinite(state2.positions).all() and not torch.equal(state2.positions, x1)
+
+
+def test_runs_without_a_verlet_list_return_with_the_step_queue_drained():
+    """The all-pairs paths (nbr_list=None, PairListNsqrd: k_ap_step) ride on the step queue as well; torch reads the
+    returned state on its own stream, which no longer orders behind them by itself: run() joins before it returns
+    (include/chx.h: the step queue).  Round 5 shipped this path without the join for a while: the suite passed on
+    timing, until a faster build kernel elsewhere shifted it."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from chiron_amd import ops, neighbors, unit as u
+
+    fluid, pot, state, thermo, nbr, integ = bench.make_system("c2", 300.0, 32, "cell")
+    if not ops.step_queue_on():
+        pytest.skip("the step queue is switched off (CHX_AQL=0)")
+    for lst in (None, neighbors.PairListNsqrd(neighbors.OrthogonalPeriodicSpace(), cutoff=3.0 * bench.SIGMA_NM * u.nanometer)):
+        for steps in (1, 40):
+            before = ops.step_queue_info()
+            out, _ = integ.run(state, thermo, number_of_steps=steps, nbr_list=lst)
+            info = ops.step_queue_info()
+            assert not info["open"], (lst, steps, info)
+            assert info["dispatched"] > before["dispatched"] and info["joins"] > before["joins"]
+            x = out.positions.cpu()
+            assert torch.isfinite(x).all()
+            if lst is not None:
+                box = state.box_vectors.cpu()
+                assert (x >= 0).all() and (x <= box[0, 0]).all()  # (wrapped every step: the final copy has run)
