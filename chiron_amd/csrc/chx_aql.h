@@ -19,7 +19,10 @@ int chx_aql_hot_release();
 // One kernel dispatch packet behind everything enqueued so far on `st` (HIP launches included: the first packet after
 // a join waits for a marker launched on `st`) and on the step queue paired with it.  `release_agent`: the packet ends with
 // an agent-scope release (a launch that leaves plain stores behind); otherwise with the scope chx_aql_hot_release() names.
-int chx_aql_dispatch(hipStream_t st, const AqlKernel* k, unsigned blocks, const void* kernarg, size_t nbytes, bool release_agent);
+// `final_packet`: the caller knows this to be the last launch of a run (the launch that also writes the state in user order):
+// it carries the join's completion signal and system-scope release itself, and a join that follows at once only waits.
+int chx_aql_dispatch(hipStream_t st, const AqlKernel* k, unsigned blocks, const void* kernarg, size_t nbytes, bool release_agent,
+                     bool final_packet = false);
 // Host wait until every packet dispatched for `st` has completed (no-op when none is outstanding).  Called by every
 // libchx entry point before it launches on `st` (chx_stream) and by the Python layer where it used to wait for the stream.
 void chx_aql_join(hipStream_t st);

@@ -130,6 +130,8 @@ struct Queue {
   bool overlap_ok = false;    // the packet just written may run beside the next STEP packet (chx_aql_allow_overlap)
   bool fresh_system = false;  // ... and the queue was opened on an idle stream, without a barrier packet: acquire at system scope
   hsa_signal_t done{};   // completion signal of the join barrier
+  hsa_signal_t fin{};    // ... of a packet dispatched as the LAST of a run (chx_aql_dispatch: final_packet)
+  bool final_sent = false;  // the newest packet carries `fin` and a system-scope release: a join only has to wait for it
   Gate gates[4];
   unsigned gate_next = 0;
   // Run-ahead bound.  The ring is cut into segments of SEG packets; the last packet of a segment carries that segment's
@@ -436,6 +438,7 @@ Queue* queue_for(hipStream_t st) {
   if (s == HSA_STATUS_SUCCESS) s = H.hsa_amd_agents_allow_access(1, &g_cpu, nullptr, Q->ring);
   if (s != HSA_STATUS_SUCCESS) return fail("kernarg ring in device memory", s), delete Q, nullptr;
   s = H.hsa_signal_create(0, 0, nullptr, &Q->done);
+  if (s == HSA_STATUS_SUCCESS) s = H.hsa_signal_create(0, 0, nullptr, &Q->fin);
   for (Gate& g : Q->gates)
     if (s == HSA_STATUS_SUCCESS) s = H.hsa_amd_signal_create(1, 0, nullptr, HSA_AMD_SIGNAL_AMD_GPU_ONLY, &g.sig);
   const unsigned nseg = Q->size / Queue::SEG;
@@ -498,6 +501,7 @@ inline void publish(Queue* Q, uint64_t widx, uint16_t header) {
   H.hsa_signal_store_screlease(Q->q->doorbell_signal, (hsa_signal_value_t)widx);
 }
 void push_barrier(Queue* Q, hsa_signal_t dep, hsa_signal_t completion, int acquire, int release) {
+  Q->final_sent = false;
   hsa_signal_t seg_sig{0};
   const uint64_t widx = reserve(Q, &seg_sig);
   if (seg_sig.handle != 0) {
@@ -574,7 +578,7 @@ void open_gate(Queue* Q, hipStream_t st) {
 }
 
 int dispatch_core(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, const void* kernarg, size_t nbytes, int release,
-                  bool is_step = false) {
+                  bool is_step = false, bool final_packet = false) {
   // (the segment may be shorter than the caller's block -- trailing padding of a by-value struct -- never longer)
   const size_t seg = k->kernarg_size;
   if (nbytes + 256 > SLOT || nbytes > seg + 8) {
@@ -598,6 +602,18 @@ int dispatch_core(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, con
   }
   hsa_signal_t seg_sig{0};
   const uint64_t widx = reserve(Q, &seg_sig);
+  // The last launch of a run(): what the join would put behind it -- a barrier packet with a system-scope release and a
+  // completion signal -- rides on the packet itself, and the join only waits (one packet less between the last wave and
+  // the host).  Not on a segment's last slot, whose signal the run-ahead bound needs; any packet that follows takes the
+  // shortcut away again (the join then goes the ordinary way; `fin` fires unobserved and is armed anew next time).
+  static const bool final_on = [] { const char* e = getenv("CHX_AQL_FINAL"); return !e || e[0] != '0'; }();
+  Q->final_sent = false;
+  if (final_packet && final_on && seg_sig.handle == 0) {
+    H.hsa_signal_store_relaxed(Q->fin, 1);
+    seg_sig = Q->fin;
+    release = HSA_FENCE_SCOPE_SYSTEM;
+    Q->final_sent = true;
+  }
   // the argument block goes to device memory through the BAR; the read-back of its last word completes the posted
   // writes before the doorbell can make the packet processor fetch them
   char* ka = Q->ring + SLOT * (widx % Q->size);
@@ -645,13 +661,14 @@ std::map<const void*, const AqlKernel*> g_by_host_fn;
 
 }  // namespace
 
-int chx_aql_dispatch(hipStream_t st, const AqlKernel* k, unsigned blocks, const void* kernarg, size_t nbytes, bool release_agent) {
+int chx_aql_dispatch(hipStream_t st, const AqlKernel* k, unsigned blocks, const void* kernarg, size_t nbytes, bool release_agent,
+                     bool final_packet) {
   if (nbytes < k->kernarg_size) {
     chx_set_error("step queue: argument block of %zu bytes is shorter than the kernel's %u", nbytes, k->kernarg_size);
     return CHX_ERR_INVALID;
   }
   return dispatch_core(st, k, dim3(blocks), dim3(256), kernarg, k->kernarg_size, release_agent ? HSA_FENCE_SCOPE_AGENT : chx_aql_hot_release(),
-                       true);
+                       true, final_packet);
 }
 
 void chx_aql_allow_overlap(hipStream_t st) {
@@ -708,9 +725,14 @@ void chx_aql_join(hipStream_t st) {
   }
   if (!Q || !Q->open) return;
   Q->overlap_ok = false;
-  H.hsa_signal_store_relaxed(Q->done, 1);
-  push_barrier(Q, hsa_signal_t{0}, Q->done, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_SYSTEM);
-  (void)wait_zero(Q->done, "the queue has not drained for 120 s");
+  if (Q->final_sent) {  // (the newest packet is a run's last launch: it releases at system scope and signals by itself)
+    (void)wait_zero(Q->fin, "the queue has not drained for 120 s");
+    Q->final_sent = false;
+  } else {
+    H.hsa_signal_store_relaxed(Q->done, 1);
+    push_barrier(Q, hsa_signal_t{0}, Q->done, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_SYSTEM);
+    (void)wait_zero(Q->done, "the queue has not drained for 120 s");
+  }
   Q->open = false;
   Q->n_joins++;
   __atomic_fetch_sub(&chx_aql_open_count, 1, __ATOMIC_RELAXED);

@@ -231,7 +231,8 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
 // A row whose cell has no list (neighbourhood longer than the capacity) or with more survivors than its slice holds is
 // redone by the general routine, the whole wavefront on it.
 #define CHX_SUB 16
-#define CHX_SURV_CAP 192  // survivors kept per row (the force list's own capacity is 6 x 16 at the BASELINE geometry)
+// CHX_SURV_CAP (template): survivors kept per row -- 192 where the force list's own capacity is below 160 (the BASELINE
+// geometry: 6 x 16), 640 (20 KB of LDS per workgroup) for denser fluids
 // The filter's constants (host: sub_filter_of): 1/L per axis and the widened threshold.  Its nearest image, d - L rint(d/L),
 // differs per component from the reference's (chx_common.h: min_image) by a few ulp of the box length, the squared
 // distance by less than 6 sqrt(T) L 2^-20; the threshold is T widened by ten times that plus a thousandth of T, and a
@@ -244,12 +245,13 @@ static SubFilter sub_filter_of(const chx_box_t& box, float T) {
   const float lmax = box.lx > box.ly ? (box.lx > box.lz ? box.lx : box.lz) : (box.ly > box.lz ? box.ly : box.lz);
   return SubFilter{1.0f / box.lx, 1.0f / box.ly, 1.0f / box.lz, T * 1.001f + 6e-5f * lmax * sqrtf(T)};
 }
+template <int CHX_SURV_CAP>
 __global__ __launch_bounds__(256) void k_nl_build_sub_fl(
     const float4* __restrict__ xs4, int n, int m, Box3 box, float T, CellGrid g, const int32_t* __restrict__ cell_start,
     const uint32_t* __restrict__ sorted_ids, int32_t* __restrict__ n_nbr, int fg, int fcap, uint32_t* __restrict__ fl,
     int32_t* __restrict__ deg, int32_t* __restrict__ status, CandLists cl, SubFilter filt) {
   __shared__ uint32_t cand_all[4][CHX_RANGE_WORDS];
-  __shared__ uint32_t surv_all[4][CHX_WAVE / CHX_SUB][CHX_SURV_CAP];
+  __shared__ uint16_t surv_all[4][CHX_WAVE / CHX_SUB][CHX_SURV_CAP];  // (positions in a candidate list: below its capacity, <= 8192)
   constexpr int U = 2, STEP = CHX_SUB * U;  // candidates per lane and half iteration of phase 1
   const int lane = lane_id();
   const int sub = lane & (CHX_SUB - 1), shift = lane & ~(CHX_SUB - 1);
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(256) void k_nl_build_sub_fl(
   const float xi = xw.x, yi = xw.y, zi = xw.z;
   const int c = __float_as_int(xw.w);
   const int c_lin = ((c >> 20) * g.ncy + ((c >> 10) & 1023)) * g.ncx + (c & 1023);
-  uint32_t* surv = surv_all[threadIdx.x >> 6][lane / CHX_SUB];
+  uint16_t* surv = surv_all[threadIdx.x >> 6][lane / CHX_SUB];
   const int ncell = g.ncx * g.ncy * g.ncz;
   const __amdgpu_buffer_rsrc_t r_lst = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(cl.list), 0, ncell * cl.cap * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_xs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(xs4), 0, n * 16, 0x00020000);
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(256) void k_nl_build_sub_fl(
       const bool pass = (sub + CHX_SUB * u < left) & ((d2 <= filt.t_wide) | (far > 1.5f));
       const uint32_t b = (uint32_t)(__ballot(pass) >> shift) & 0xFFFFu;
       const int slot = ns + __popc(b & below);
-      if (pass && slot < CHX_SURV_CAP) surv[slot] = (uint32_t)(t0 + sub + CHX_SUB * u);
+      if (pass && slot < CHX_SURV_CAP) surv[slot] = (uint16_t)(t0 + sub + CHX_SUB * u);
       ns += __popc(b);
     }
   };
@@ -727,32 +729,34 @@ extern "C" int chx_nl_rows_cell_fl(int32_t n, int32_t m, chx_box_t box, float cu
   // N = 32768 / 3375 cells 51 -> 83 us, or 51 -> 51 with four wavefronts per cell: too few, too long wavefronts
   // live on latency).  Both write the same bits; CHX_BUILD_KERNEL=particle|cell forces one (tests, A/B).
   static const int forced = [] { const char* e = getenv("CHX_BUILD_KERNEL"); return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'c' ? 2 : 0)); }();
-  const bool per_particle = forced == 1 || (forced == 0 && (int64_t)grid.ncx * grid.ncy * grid.ncz < 8192);
-  if (per_particle) {
-    const CandLists cl = {cand_cap > 0 ? cand_list : nullptr, cand_len, cand_cap};
-    // the integrator's rebuilds (no half rows) with candidate lists: sixteen lanes per row and a filter in front of the
-    // predicate (k_nl_build_sub_fl; its 32-bit table offsets and 24-bit chunk stride bound the size).  CHX_BUILD_SUB=0:
-    // the general kernel (tests, A/B)
-    static const bool sub_rows = [] { const char* e = getenv("CHX_BUILD_SUB"); return !e || e[0] != '0'; }();
-    if (!half && cl.list != nullptr && sub_rows && (int64_t)chunks * CHX_FL_QUAD * g * n < (int64_t)1 << 31 &&
-        (int64_t)CHX_FL_QUAD * g * n < 1 << 24) {
-      const unsigned qb = (unsigned)(((int64_t)n * CHX_SUB + 255) / 256);
-      CHX_LAUNCH(k_nl_build_sub_fl, dim3(qb), dim3(256), st, xs, n, m, make_box3(box), T, grid, cell_start, sorted_ids, n_nbr_out,
-                 g, chunks * CHX_FL_QUAD * g, fl_out, deg_out, status8, cl, sub_filter_of(box, T));
-    } else {
-      CHX_LAUNCH(half ? k_nl_build_cell_fl<true> : k_nl_build_cell_fl<false>, dim3(wb), dim3(256), st, xs, n, m, make_box3(box), T,
-                 grid, cell_of, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, chunks * CHX_FL_QUAD * g, fl_out,
-                 deg_out, status8, cl);
-    }
+  const CandLists cl = {cand_cap > 0 ? cand_list : nullptr, cand_len, cand_cap};
+  const int ncell = grid.ncx * grid.ncy * grid.ncz;
+  const int fcap = chunks * CHX_FL_QUAD * g;
+  // The integrator's rebuilds (no half rows) with candidate lists, at any size: sixteen lanes per row and a filter in front
+  // of the predicate (k_nl_build_sub_fl; its 32-bit offsets and 24-bit chunk stride bound the size; C4: 229 -> 161 us per
+  // build against the cell-wise kernel, C3: 47 -> 39 against the per-particle one).  A row with more survivors than the
+  // kernel keeps on chip is done twice: only where the force list's capacity -- sized from the longest row of earlier
+  // builds -- says that rows stay below it.  CHX_BUILD_SUB=0: the other kernels (tests, A/B).
+  static const bool sub_rows = [] { const char* e = getenv("CHX_BUILD_SUB"); return !e || e[0] != '0'; }();
+  static const int sub_max = [] { const char* e = getenv("CHX_BUILD_SUB_MAX"); return e ? atoi(e) : 576; }();
+  const bool sub = !half && cl.list != nullptr && sub_rows && forced != 2 && fcap <= sub_max && (int64_t)fcap * n < (int64_t)1 << 31 &&
+                   (int64_t)CHX_FL_QUAD * g * n < 1 << 24 && (int64_t)ncell * cand_cap * 4 < (int64_t)1 << 31 && n < 1 << 27;
+  const bool per_particle = forced == 1 || (forced == 0 && ncell < 8192);
+  if (sub) {
+    const unsigned qb = (unsigned)(((int64_t)n * CHX_SUB + 255) / 256);
+    CHX_LAUNCH(fcap <= 160 ? k_nl_build_sub_fl<192> : k_nl_build_sub_fl<640>, dim3(qb), dim3(256), st, xs, n, m, make_box3(box), T, grid,
+               cell_start, sorted_ids, n_nbr_out, g, fcap, fl_out, deg_out, status8, cl, sub_filter_of(box, T));
+  } else if (per_particle) {
+    CHX_LAUNCH(half ? k_nl_build_cell_fl<true> : k_nl_build_cell_fl<false>, dim3(wb), dim3(256), st, xs, n, m, make_box3(box), T,
+               grid, cell_of, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, fcap, fl_out, deg_out, status8, cl);
   } else {
-    const int ncell = grid.ncx * grid.ncy * grid.ncz;
     static const int split_env = [] { const char* e = getenv("CHX_BUILD_SPLIT"); return e ? atoi(e) : 0; }();
     int split = split_env > 0 ? split_env : (8192 + ncell - 1) / ncell;  // (only > 1 when the kernel is forced)
     split = split < 1 ? 1 : (split > 16 ? 16 : split);
     const unsigned cb = (unsigned)(((int64_t)ncell * split * CHX_WAVE + 255) / 256);
     CHX_LAUNCH(half ? k_nl_build_cellwise_fl<true> : k_nl_build_cellwise_fl<false>, dim3(cb), dim3(256), st, xs, n, m,
-               make_box3(box), T, grid, ncell, split, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g,
-               chunks * CHX_FL_QUAD * g, fl_out, deg_out, status8);
+               make_box3(box), T, grid, ncell, split, cell_start, sorted_ids, nl_rows_out, first_out, n_nbr_out, g, fcap, fl_out,
+               deg_out, status8);
   }
   const unsigned sb = (unsigned)((n + 255) / 256 < 64 ? (n + 255) / 256 : 64);
   CHX_LAUNCH(k_build_epilogue, dim3(sb), dim3(256), st, n_nbr_out, deg_out, n, m, status8, publish_host_dst8);

@@ -796,7 +796,7 @@ static int launch_step_g(const StepArgs& a, long long step, int n_kicks, int do_
       std::memset(&ka, 0, sizeof(ka));
       ka.ctrl_first = a.ctrl, ka.step = step, ka.epoch = epoch, ka.n_lead = a.n, ka.nblocks = blocks;
       ka.x_lead = a.x_cur, ka.sfl = sfl, ka.sdeg = sdeg, ka.a = a, ka.n_kicks = n_kicks, ka.do_aoa = do_aoa;
-      return chx_aql_dispatch(st, k, blocks, &ka, sizeof(ka), !(hot && !prune && !defer));
+      return chx_aql_dispatch(st, k, blocks, &ka, sizeof(ka), !(hot && !prune && !defer), a.x3_out != nullptr);
     }
   }
 #define CHX_LAUNCH_STEP(HOT_, PRUNE_, DEFER_)                                                                             \

@@ -322,8 +322,20 @@ class LangevinIntegrator:
         def host_tail():
             tail["key"] = chain_key if isinstance(key, JaxKey) else fold_in(key, number_of_steps)
             tail["box"] = sampler_state._box_copy()
+            # (and the two arrays the NEXT run()'s list build needs before its first launch can go out)
+            if mode == "fused" and spec0:
+                nbr_list._prepare_next_build(x0)
+
+        def before_last_wait():
+            # (_RunState._enqueue_kick, between the run's last launch and the wait for it: the state run() returns, around
+            # the arrays that launch is writing -- made here, not behind the wait)
+            fs = st.__dict__.get("_final_state")
+            if fs is not None and tail:
+                tail["xv"] = fs
+                tail["state"] = sampler_state._copy_with(*fs, box_copy=tail["box"])
 
         st._host_tail = host_tail
+        st._before_last_wait = before_last_wait
         done = 0
         while done < number_of_steps:
             stop = next_stop(done)
@@ -351,12 +363,15 @@ class LangevinIntegrator:
         if not tail:
             host_tail()
         final_xv = st.final_state_user()
+        ready = tail.get("state")
+        if ready is not None and tail["xv"][0] is not final_xv[0]:
+            ready = None  # (the last launch turned out a no-op -- the skin check fired in the very last step -- and was redone)
         if mode != "fused":
             # (the launches of the paths without a Verlet list ride on the step queue too -- k_ap_step, the copy into user
             # order just made: a run() returns with the queue drained, whatever the path; the fused path has waited in
             # _enqueue_kick)
             ops.steps_join()
-        updated_sampler_state = sampler_state._copy_with(*final_xv, box_copy=tail["box"])  # :210-218
+        updated_sampler_state = ready if ready is not None else sampler_state._copy_with(*final_xv, box_copy=tail["box"])  # :210-218
         st.offer_carry(updated_sampler_state)
         updated_sampler_state.current_PRNG_key = tail["key"]
         self.n_rebuilds = st.n_rebuilds
@@ -972,6 +987,19 @@ class _RunState:
         work, self._host_tail = getattr(self, "_host_tail", None), None
         if work is not None:
             work()  # (see LangevinIntegrator.run: the launches above are still queued)
+        if with_state:
+            pre = self.__dict__.get("_before_last_wait")
+            if pre is not None:
+                pre()
+            # A speculative build still unconfirmed (a run shorter than the distance _advance_windowed settles at): its
+            # status block is on the host as soon as a step launch of the generation behind it has begun.  Confirmed here,
+            # with the device still working, not behind the wait; a block that rejects the build -- or has not arrived -- is
+            # left to _settle() behind the wait, which then does what it always did.
+            pend = self.__dict__.get("_unsettled")
+            if pend is not None and self.mode == "fused" and int(self._gen.host[0]) >= self._gen_step0:
+                owner = pend[4] if len(pend) > 4 else self.nbr_list
+                if owner._build_status_good():
+                    self._settle()
         self._wait_for_launches()
 
     def _wait_for_launches(self):

@@ -327,6 +327,16 @@ class NeighborListNsqrd(PairsBase):
         self.n_builds += 1
 
     # -- unsynchronised rebuild (integrator only) ---------------------------------------------
+    def _prepare_next_build(self, like: torch.Tensor) -> None:
+        """The arrays a next speculative build allocates BEFORE its first launch (the copy of the positions, the internal
+        order), made now -- by an integrator whose launches are still running, with nothing else to do -- so that a short
+        run() that follows gets its first launch out 2.5 us earlier.  Plain empties; unused, they are simply dropped."""
+        if self.__dict__.get("_next_copy") is None:
+            self._next_copy = torch.empty_like(like)
+        sc = self.__dict__.get("_scratch")
+        if sc is not None and sc.get("next_ids") is None:
+            sc["next_ids"] = torch.empty((like.shape[0],), dtype=torch.int32, device=like.device)
+
     def _build_speculative(self, positions: torch.Tensor, publish: bool = True, pack=None, ctrl=None, ctrl_keep: int = 0,
                            copy_positions: bool = False, half_rows: bool = True) -> bool:
         """Rebuild from ``positions`` WITHOUT waiting for the build's status block.
@@ -371,7 +381,9 @@ class NeighborListNsqrd(PairsBase):
             host = self._status_host = torch.empty((8,), dtype=torch.int32, pin_memory=True)
         riders = {"publish": host}
         if copy_positions:
-            riders["copy"] = torch.empty_like(positions)
+            ready = self.__dict__.pop("_next_copy", None)  # (_prepare_next_build)
+            riders["copy"] = ready if ready is not None and ready.shape == positions.shape and ready.device == positions.device \
+                else torch.empty_like(positions)
         if pack is not None:
             riders["pack"] = pack
         if ctrl is not None:
@@ -398,6 +410,15 @@ class NeighborListNsqrd(PairsBase):
         self._force_list = ops.ForceList.prebuilt(fl, deg, sorted_ids, g, chunks, getattr(self, "_last_maxdeg", 0))
         self.n_builds += 1
         return True
+
+    def _build_status_good(self) -> bool:
+        """Does the status block of the last ``_build_speculative`` -- which the caller knows to have arrived -- accept the
+        build?  Looks only: ``_confirm_build`` is what acts on it."""
+        spec = getattr(self, "_spec", None)
+        if spec is None:
+            return True
+        st = self._status_host.tolist()
+        return st[0] == 0 and st[2] == 0 and st[4] == 0 and st[5] == 0 and st[1] <= spec[1]
 
     def _confirm_build(self, wait: bool = True) -> bool:
         """True if the last ``_build_speculative`` produced the list ``build()`` would have; otherwise
@@ -595,7 +616,7 @@ class NeighborListNsqrd(PairsBase):
                 new._force_list = None  # rebuilt lazily; it is a pure function of the list
             elif k == "_scratch":
                 new._scratch = None  # kernel work arrays are not part of the list
-            elif k in ("_spec", "_status_host", "_grid_cache"):
+            elif k in ("_spec", "_status_host", "_grid_cache", "_next_copy"):
                 setattr(new, k, None)
             elif k in ("_spec_event",):
                 continue  # plumbing of the speculative rebuild: the copy starts without any

@@ -154,6 +154,9 @@ def nl_build_cell(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: int, 
     return nl, mask, n_nbr, sorted_ids, status
 
 
+_BUILD_LISTS = os.environ.get("CHX_BUILD_LISTS", "1") != "0"
+
+
 def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: int, ncell: int, nc, g: int, chunks: int,
                      scratch: Optional[dict] = None, riders: Optional[dict] = None, half_rows: bool = True):
     """One-pass cell build (half-list rows without padding + force list).
@@ -173,8 +176,12 @@ def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: in
     n = xyz.shape[0]
     dev = xyz.device
     i32 = dict(dtype=torch.int32, device=dev)
-    sorted_ids = torch.empty((n,), **i32)
-    key = (n, ncell, str(dev))
+    key = (n, ncell, dev)
+    # (the internal order: a fresh array per build -- it becomes part of the list --, made ahead of time when the caller
+    # saw this build coming: neighbors.NeighborListNsqrd._prepare_next_build)
+    sorted_ids = scratch.pop("next_ids", None) if scratch is not None else None
+    if sorted_ids is None or sorted_ids.shape[0] != n or sorted_ids.device != dev:
+        sorted_ids = torch.empty((n,), **i32)
     if scratch is not None and scratch.get("key") == key:
         cell_of, cell_count, cell_start, status, xs4 = scratch["arrays"]
         cand = scratch.get("cand")
@@ -186,13 +193,7 @@ def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: in
         cell_start = torch.empty((ncell + 1,), **i32)
         status = torch.empty((_lib.BUILD_STATUS_WORDS,), **i32)
         xs4 = torch.empty((n, 4), dtype=torch.float32, device=dev)
-        # per-cell candidate index lists for the per-particle row kernel (grids below 8192 cells: beyond that the
-        # cell-wise kernel shares the neighbourhood scan among a cell's rows itself): capacity = 1.5 x the mean
-        # neighbourhood, a longer one keeps the range search (include/chx.h: chx_build_riders_t::cand_list)
-        cand = None
-        if ncell < 8192 and os.environ.get("CHX_BUILD_LISTS", "1") != "0":
-            cap = min(8192, (int(1.5 * 27.0 * n / ncell) + 64 + 63) // 64 * 64)
-            cand = (torch.empty((ncell, cap), **i32), torch.empty((ncell,), **i32), cap)
+        cand = None  # (per-cell candidate index lists: made below, the first time a build wants them)
         # per-cell id slots (include/chx.h: chx_build_riders_t::cell_slots): the chain needs no scatter launch.  Twice the
         # mean occupancy + 32; a cell beyond that voids the build (status[5]) and the caller turns the slots off
         slots = None
@@ -204,6 +205,20 @@ def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: in
             scratch["slots"] = slots
     if slots is not None and scratch is not None and scratch.get("no_slots"):
         slots = scratch["slots"] = None
+    # Per-cell candidate index lists (include/chx.h: chx_build_riders_t::cand_list) for the row kernels that read them: the
+    # per-particle kernel (grids below 8192 cells: beyond that the cell-wise kernel shares the neighbourhood scan among a
+    # cell's rows itself) and, at any size, the filtered kernel of the integrator's rebuilds (half_rows=False:
+    # k_nl_build_sub_fl).  Capacity = 1.5 x the mean neighbourhood; a longer one keeps the range search.  A build that
+    # will not read them does not have them written.
+    if (ncell < 8192 or not half_rows) and _BUILD_LISTS:
+        if cand is None:
+            cap = min(8192, (int(1.5 * 27.0 * n / ncell) + 64 + 63) // 64 * 64)
+            if ncell * cap * 4 < (1 << 30):  # (the kernels address a list with 32-bit byte offsets)
+                cand = (torch.empty((ncell, cap), **i32), torch.empty((ncell,), **i32), cap)
+                if scratch is not None:
+                    scratch["cand"] = cand
+    else:
+        cand = None
     rd = None
     publish = None
     if riders or cand is not None or slots is not None:
