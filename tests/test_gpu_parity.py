@@ -1894,7 +1894,8 @@ def test_both_cell_build_kernels_write_the_same_bits(tmp_path):
         got[kern + lists + ("" if sub == "1" else "_nosub")] = np.load(path)
     a = got["particle1"]
     assert len(a.files) >= 80
-    assert int(a["dilute_run_status_tight"][4]) > 0  # (rows beyond a one-chunk force list: counted)
+    if "CHX_FL_G" not in os.environ:  # (16 or 64 lanes per particle: a single chunk holds these rows)
+        assert int(a["dilute_run_status_tight"][4]) > 0  # (rows beyond a one-chunk force list: counted)
     for other in ("cell1", "particle0", "particle1_nosub"):
         b = got[other]
         assert sorted(a.files) == sorted(b.files)
