@@ -498,7 +498,10 @@ int chx_langevin_fused_run(const chx_langevin_t* p_h, float* x_even, float* x_od
  * fences (their outputs are write-through stores; CHX_AQL_FENCE=agent restores HIP's agent-scope acquire / release on
  * every packet).  Ordering: the first packet after a join waits (barrier-AND packet on a signal that a marker kernel on
  * `stream` sets; no marker when hipStreamQuery finds the stream idle) for everything enqueued on `stream` before it; chx_steps_join waits ON THE HOST until every packet
- * dispatched for `stream` has completed (returns at once when none is outstanding).  Every libchx entry point that
+ * dispatched for `stream` has completed (returns at once when none is outstanding) -- by a barrier packet with a completion
+ * signal and a system-scope release, unless the newest packet is a run's LAST launch (chx_langevin_fused_chunk with
+ * do_aoa = 0 and p_h->final_x3 set: the launch that also writes the state in user order), which carries both itself
+ * (CHX_AQL_FINAL=0: always the barrier packet).  Every libchx entry point that
  * launches on a stream joins first, so libchx calls always see one ordered stream; only work the CALLER enqueues on
  * `stream` by other means (its own kernels, copies, events) needs an explicit chx_steps_join in front when it depends on
  * the steps.  The kernels are loaded from libchx_step.hsaco (required) and libchx_k_*.hsaco (one per translation unit
