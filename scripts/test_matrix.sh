@@ -16,7 +16,7 @@ for env in "CHX_AQL=0" "CHX_AQL_FENCE=agent" "CHX_AQL=0 CHX_LAUNCH_WINDOW=3" "CH
            "CHX_PIN_CPUS=0" "CHX_LIST_CARRY=0" "CHX_LIST_CARRY_MAX_STEPS=100000" "CHX_BUILD_LISTS=0" \
            "CHX_RUN_HALF_ROWS=1 CHX_BUILD_SLOTS=0" "CHX_BUILD_SLOTS=0" "CHX_MC_INNER_SKIN=0" "CHX_MC_INNER_SKIN=0.03" \
            "CHX_CARRY_VALIDATE=0 CHX_PARAMS_CACHE=0" \
-           "CHX_AQL_SCOPE=steps" "CHX_AQL_OPEN_AT_START=0" "CHX_AQL_OVERLAP=0 CHX_AQL_SELFCHECK=0" "CHX_BUILD_SUB=0"; do
+           "CHX_AQL_SCOPE=steps" "CHX_AQL_OPEN_AT_START=0" "CHX_AQL_OVERLAP=0 CHX_AQL_SELFCHECK=0" "CHX_BUILD_SUB=0" "CHX_AQL_FINAL=0"; do
   k=$((k + 1))
   if [ $k -le $first ] || [ $k -gt $((first + count)) ]; then continue; fi
   echo "== $env" | tee -a $log
