@@ -34,7 +34,7 @@ print("RESULT " + json.dumps({"hash": h, "rebuilds": rebuilds, "queue": ops.step
 
 def _run(env_extra, workload, steps):
     env = dict(os.environ)
-    for k in ("CHX_AQL", "CHX_AQL_FENCE", "CHX_AQL_SCOPE", "CHX_AQL_OPEN_AT_START"):
+    for k in ("CHX_AQL", "CHX_AQL_FENCE", "CHX_AQL_SCOPE", "CHX_AQL_OPEN_AT_START", "CHX_AQL_FINAL", "CHX_BUILD_SUB"):
         env.pop(k, None)
     env.update(env_extra)
     out = subprocess.run([sys.executable, "-c", _TRAJECTORY, workload, str(steps)], capture_output=True, text=True, timeout=600,
@@ -46,7 +46,7 @@ def _run(env_extra, workload, steps):
 
 @pytest.mark.parametrize("workload,steps", [("c3", 3000), ("c4", 600)], ids=["c3-32768", "c4-262144"])
 def test_step_queue_and_its_fence_modes_leave_every_bit_of_the_trajectory(workload, steps):
-    """One trajectory from the bench's own start -- thousands of steps with list rebuilds and inner-list refreshes, then
+    """(Seven fresh processes per workload.)  One trajectory from the bench's own start -- thousands of steps with list rebuilds and inner-list refreshes, then
     short runs on carried-over lists -- in fresh processes: plain HIP launches (CHX_AQL=0), the step queue with
     HIP's agent-scope fences on every packet (CHX_AQL_FENCE=agent), and the default (steady-state packets carry no
     fences: their outputs are write-through stores, and what they read was written through or released).  A single
@@ -59,6 +59,14 @@ def test_step_queue_and_its_fence_modes_leave_every_bit_of_the_trajectory(worklo
     # gate at the first step instead of at the start of run() (the run-start build goes through HIP)
     steps_only = _run({"CHX_AQL_SCOPE": "steps"}, workload, steps)
     late_gate = _run({"CHX_AQL_OPEN_AT_START": "0"}, workload, steps)
+    # ... the join that always sends its own barrier packet (by default the launch that ends a run() carries the join's
+    # completion signal and system-scope release itself), and -- not a queue mode, but the same question -- the rebuilds'
+    # general row kernels instead of the filtered sixteen-lanes-per-row one: every force list of the trajectory, on the
+    # clustered fluid, must come out the same bits or the summation order of some force changes
+    plain_join = _run({"CHX_AQL_FINAL": "0"}, workload, steps)
+    old_rows = _run({"CHX_BUILD_SUB": "0"}, workload, steps)
+    assert plain_join["hash"] == old_rows["hash"] == bare["hash"], (plain_join, old_rows, bare)
+    assert old_rows["rebuilds"] == bare["rebuilds"] and plain_join["queue"]["joins"] == bare["queue"]["joins"]
     opened = lambda r: r["queue"]["gates"] + r["queue"]["idle_opens"]  # (through a marker launch / on an idle stream)
     assert steps_only["hash"] == late_gate["hash"] == hip["hash"], (steps_only, late_gate, hip)
     # (steps only: an opening per rebuild -- unless every rebuild is a synchronous one anyway, CHX_SYNC_REBUILD=1)
