@@ -363,6 +363,7 @@ class LangevinIntegrator:
         if not tail:
             host_tail()
         final_xv = st.final_state_user()
+        st._host_tail = st._before_last_wait = None  # (closures over `st`: no cycle may outlive the call)
         ready = tail.get("state")
         if ready is not None and tail["xv"][0] is not final_xv[0]:
             ready = None  # (the last launch turned out a no-op -- the skin check fired in the very last step -- and was redone)
@@ -988,7 +989,9 @@ class _RunState:
         if work is not None:
             work()  # (see LangevinIntegrator.run: the launches above are still queued)
         if with_state:
-            pre = self.__dict__.get("_before_last_wait")
+            # (taken away before it is called, like _host_tail: the closure holds this object, which must not hold it back
+            # -- a reference cycle keeps a run's arrays, the force list among them, alive until the cycle collector comes by)
+            pre, self._before_last_wait = self.__dict__.get("_before_last_wait"), None
             if pre is not None:
                 pre()
             # A speculative build still unconfirmed (a run shorter than the distance _advance_windowed settles at): its

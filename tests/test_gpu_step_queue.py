@@ -143,3 +143,28 @@ def test_runs_without_a_verlet_list_return_with_the_step_queue_drained():
             if lst is not None:
                 box = state.box_vectors.cpu()
                 assert (x >= 0).all() and (x <= box[0, 0]).all()  # (wrapped every step: the final copy has run)
+
+
+def test_a_run_state_dies_with_its_call():
+    """A run()'s internal state (force list, position buffers' views, closures handed to it for the host work it does
+    while launches are queued) must be freed by reference counting when the call returns -- not wait for the cycle
+    collector: at N = 262 144 and liquid density a force list is half a gigabyte, and four of them parked in cycles sent
+    torch's allocator back to hipMalloc (8 ms each) for every rebuild of the next calls (round 5, found by bench.py's
+    liquid leg reading 13.5 k steps/s in two windows of three and 19 k in the third)."""
+    import gc
+
+    sys.path.insert(0, ROOT)
+    import bench
+    from chiron_amd import integrators as I
+
+    fluid, pot, state, thermo, nbr, integ = bench.make_system("c2", 300.0, 32, "cell")
+    state, nbr = integ.run(state, thermo, number_of_steps=10, nbr_list=nbr)
+    gc.collect()
+    gc.disable()
+    try:
+        for steps in (20, 1, 300, 20):  # (with and without rebuilds inside; a carried and a fresh entry)
+            state, nbr = integ.run(state, thermo, number_of_steps=steps, nbr_list=nbr)
+            alive = [o for o in gc.get_objects() if type(o) is I._RunState]
+            assert not alive, (steps, len(alive))
+    finally:
+        gc.enable()
