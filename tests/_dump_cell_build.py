@@ -17,9 +17,14 @@ for tag, (n, rho, skin, m0) in {"dilute": (4000, 0.1, 0.5, 180), "dense": (6000,
                                 "mixed": (5000, 0.15, 0.5, 180),
                                 # ~215 neighbours per particle with candidate lists in place: more than the filtered row kernel
                                 # (k_nl_build_sub_fl) keeps per row on chip, every row goes back to the general routine
-                                "crowded": (3000, 0.7, 0.4, 260)}.items():
+                                "crowded": (3000, 0.7, 0.4, 260),
+                                # coordinates up to three box lengths outside the box: the filter of the filtered row kernel
+                                # passes such pairs untested, and the predicate takes its general minimum-image path
+                                "unwrapped": (3000, 0.3, 0.3, 180)}.items():
     x, box = O.lj_lattice(n, rho, 0.34, seed=17)
     x = (x + np.random.default_rng(3).normal(scale=0.03, size=x.shape)).astype(np.float32)
+    if tag == "unwrapped":
+        x = (x + np.random.default_rng(5).integers(-3, 4, size=x.shape) * np.diag(box)).astype(np.float32)
     if tag == "mixed":  # uniformly random instead of a jittered lattice: cell occupancies scatter like a Poisson variable
         x = (np.random.default_rng(4).uniform(size=x.shape) * np.diag(box)).astype(np.float32)
     nbr = neighbors.NeighborListCell(neighbors.OrthogonalPeriodicSpace(), cutoff=1.02 * u.nanometer, skin=skin * u.nanometer,
