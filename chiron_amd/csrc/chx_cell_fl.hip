@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
 }
 
 // SIXTEEN LANES per particle, four particles per wavefront, candidates FILTERED before they are tested (round 5): the
-// integrator's rebuilds at the sizes below the cell-wise kernel's (half rows counted only, a candidate list per cell).
+// integrator's rebuilds (half rows counted only) wherever the binning has written a candidate list per cell -- at any size.
 // The per-particle kernel above is bound by vector-instruction issue (PMC, C3 equilibrated: 461 instructions per row at
 // 4 cycles each on 1024 SIMDs = its 25 us): ~70 per batch of 64 candidates -- the reference's predicate in the reference's
 // orientation, two ballots, slot and address arithmetic, the loads of ids and positions -- although only one candidate
@@ -231,8 +231,8 @@ __global__ __launch_bounds__(256) void k_nl_build_cell_fl(
 // A row whose cell has no list (neighbourhood longer than the capacity) or with more survivors than its slice holds is
 // redone by the general routine, the whole wavefront on it.
 #define CHX_SUB 16
-// CHX_SURV_CAP (template): survivors kept per row -- 192 where the force list's own capacity is below 160 (the BASELINE
-// geometry: 6 x 16), 640 (20 KB of LDS per workgroup) for denser fluids
+// CHX_SURV_CAP (template): survivors kept per row -- 192 where the force list's own capacity is at most 160 (the BASELINE
+// geometry: 6 x 16), 640 (20 KB of LDS per workgroup) for denser fluids.
 // The filter's constants (host: sub_filter_of): 1/L per axis and the widened threshold.  Its nearest image, d - L rint(d/L),
 // differs per component from the reference's (chx_common.h: min_image) by a few ulp of the box length, the squared
 // distance by less than 6 sqrt(T) L 2^-20; the threshold is T widened by ten times that plus a thousandth of T, and a
