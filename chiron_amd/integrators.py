@@ -916,10 +916,10 @@ class _RunState:
         # (the list that was built: the caller's, or -- force list renewed on its own -- one of the private builders)
         owner = pend[4] if len(pend) > 4 else self.nbr_list
         if self.mode == "fused":
-            # the build's status block reaches the host with the pack launch of the load that followed the build;
-            # a step launch of that load's generation has begun => it is there.  Otherwise wait for the stream.
-            if int(self._gen.host[0]) < self._gen_step0:
-                _wait_for_steps_and_stream()  # (the build may have ridden on the step queue)
+            # the build's status block is published by the build's summary launch; the SECOND step launch of the
+            # generation behind the build has begun => it is there.  Otherwise wait for the queue and the stream.
+            if int(self._gen.host[0]) < self._gen_step0 + 1:  # (+ 1: the generation's first launch may run BESIDE the
+                _wait_for_steps_and_stream()                   # launch that publishes the block: chx_aql_allow_overlap)
             ok = owner._confirm_build(wait=False)
         else:
             ok = owner._confirm_build()
@@ -995,11 +995,13 @@ class _RunState:
             if pre is not None:
                 pre()
             # A speculative build still unconfirmed (a run shorter than the distance _advance_windowed settles at): its
-            # status block is on the host as soon as a step launch of the generation behind it has begun.  Confirmed here,
-            # with the device still working, not behind the wait; a block that rejects the build -- or has not arrived -- is
-            # left to _settle() behind the wait, which then does what it always did.
+            # status block is on the host once the SECOND step launch of the generation behind it has begun -- the first may
+            # run beside the build's summary launch, which publishes the block (chx_aql_allow_overlap); the second carries
+            # the barrier bit and starts behind both.  Confirmed here, with the device still working, not behind the wait;
+            # a block that rejects the build -- or may not have arrived: a run of one or two steps -- is left to _settle()
+            # behind the wait, which then does what it always did.
             pend = self.__dict__.get("_unsettled")
-            if pend is not None and self.mode == "fused" and int(self._gen.host[0]) >= self._gen_step0:
+            if pend is not None and self.mode == "fused" and int(self._gen.host[0]) >= self._gen_step0 + 1:
                 owner = pend[4] if len(pend) > 4 else self.nbr_list
                 if owner._build_status_good():
                     self._settle()
