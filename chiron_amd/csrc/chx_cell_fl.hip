@@ -740,7 +740,8 @@ extern "C" int chx_nl_rows_cell_fl(int32_t n, int32_t m, chx_box_t box, float cu
   static const bool sub_rows = [] { const char* e = getenv("CHX_BUILD_SUB"); return !e || e[0] != '0'; }();
   static const int sub_max = [] { const char* e = getenv("CHX_BUILD_SUB_MAX"); return e ? atoi(e) : 576; }();
   const bool sub = !half && cl.list != nullptr && sub_rows && forced != 2 && fcap <= sub_max && (int64_t)fcap * n < (int64_t)1 << 31 &&
-                   (int64_t)CHX_FL_QUAD * g * n < 1 << 24 && (int64_t)ncell * cand_cap * 4 < (int64_t)1 << 31 && n < 1 << 27;
+                   (int64_t)CHX_FL_QUAD * g * n < 1 << 24 && (int64_t)ncell * cand_cap * 4 < (int64_t)1 << 31 && n < 1 << 27 &&
+                   cand_cap <= 65536;  // (a survivor is kept as a 16-bit position in its candidate list)
   const bool per_particle = forced == 1 || (forced == 0 && ncell < 8192);
   if (sub) {
     const unsigned qb = (unsigned)(((int64_t)n * CHX_SUB + 255) / 256);
