@@ -352,7 +352,8 @@ class NeighborListNsqrd(PairsBase):
         ``_confirm_build`` waits for; with ``publish=False`` the caller has its own way of knowing that the build has run
         (the integrator: a later launch has begun) and confirms with ``_confirm_build(wait=False)``.
         Riders of the build's launches (include/chx.h: chx_build_riders_t): ``pack`` = (v3, mass, ref3 or None, x4_out,
-        v_out, mass_out, ref4_out) -- the Langevin state packed into the new internal order; ``ctrl`` / ``ctrl_keep`` --
+        v_out, mass_out, ref4_out) -- the Langevin state packed into the new internal order (the caller vouches for them:
+        contiguous fp32 device tensors of this list's particle count -- they are not checked again on the way down); ``ctrl`` / ``ctrl_keep`` --
         the integrator's control block, reset; ``copy_positions`` -- ``positions`` is somebody else's tensor: the list
         keeps a copy made by the binning launch instead of the tensor itself.  ``half_rows=False``: the reference-format
         half rows (``neighbor_list``) are counted, not written -- the integrator's step kernels read the force list only;
@@ -373,10 +374,11 @@ class NeighborListNsqrd(PairsBase):
             return False
         m = int(self.n_max_neighbors)
         g, chunks = self._fl_geometry(n)
-        if getattr(self, "_scratch", None) is None:
+        d = self.__dict__
+        if d.get("_scratch") is None:
             self._scratch = {}
-        self.__dict__.pop("_deferred", None)  # (a rebuild still pending from an earlier run() is superseded)
-        host = getattr(self, "_status_host", None)
+        d.pop("_deferred", None)  # (a rebuild still pending from an earlier run() is superseded)
+        host = d.get("_status_host")
         if host is None:
             host = self._status_host = torch.empty((8,), dtype=torch.int32, pin_memory=True)
         riders = {"publish": host}
@@ -391,7 +393,8 @@ class NeighborListNsqrd(PairsBase):
         self.ref_positions = riders["copy"] if copy_positions else positions  # (else: a fresh tensor nobody else holds)
         self._cutoff_and_skin = cs
         nl, first, n_nbr, sorted_ids, fl, deg, status = ops.nl_build_cell_fl(
-            positions, self._box_h, cs, m, ncell, nc, g, chunks, self._scratch, riders=riders, half_rows=half_rows)
+            positions, self._box_h, cs, m, ncell, nc, g, chunks, self._scratch, riders=riders, half_rows=half_rows,
+            checked=True)  # (positions: above; the copy: made here; the pack rider's arrays: the integrator's, see `pack`)
         ev = getattr(self, "_spec_event", None)
         if ev is None:
             ev = self._spec_event = torch.cuda.Event()  # (one event, recorded again by every speculative build)

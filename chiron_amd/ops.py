@@ -158,7 +158,8 @@ _BUILD_LISTS = os.environ.get("CHX_BUILD_LISTS", "1") != "0"
 
 
 def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: int, ncell: int, nc, g: int, chunks: int,
-                     scratch: Optional[dict] = None, riders: Optional[dict] = None, half_rows: bool = True):
+                     scratch: Optional[dict] = None, riders: Optional[dict] = None, half_rows: bool = True,
+                     checked: bool = False):
     """One-pass cell build (half-list rows without padding + force list).
 
     Returns (nl_rows, first, n_nbr, sorted_ids, fl, deg, status); nothing is synchronised here.
@@ -170,9 +171,13 @@ def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: in
     ``pack`` -- (v3, mass, ref3 or None, x4_out, v_out, mass_out, ref4_out or None): the Langevin state packed into
     the new internal order; ``ctrl`` / ``ctrl_keep`` -- control block to reset; ``publish`` -- pinned host tensor that
     receives status[0..7] from the chain's last launch.
+    ``checked``: the caller has verified that ``xyz`` and the tensors of the ``copy`` and ``pack`` riders are contiguous
+    fp32 device tensors (NeighborListNsqrd._build_speculative, LangevinIntegrator.run: on the path to a run()'s first
+    launch every check made twice is device idle time).
     """
-    xyz = _f32(xyz)
-    _require_device(xyz)
+    if not checked:
+        xyz = _f32(xyz)
+        _require_device(xyz)
     n = xyz.shape[0]
     dev = xyz.device
     i32 = dict(dtype=torch.int32, device=dev)
@@ -236,7 +241,13 @@ def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: in
                   pk[1] if pk is not None else None, pk[3] if pk is not None else None, pk[4] if pk is not None else None,
                   pk[5] if pk is not None else None, pk[6] if pk is not None else None, ct, pb)
         kept = scratch.get("rd") if scratch is not None else None
-        if kept is not None and len(kept[0]) == len(stable) and all(u is w for u, w in zip(kept[0], stable)):
+        same = kept is not None
+        if same:
+            for u, w in zip(kept[0], stable):
+                if u is not w:
+                    same = False
+                    break
+        if same:
             rd, publish = kept[1], kept[2]
         else:
             rd = _lib.BuildRiders()
@@ -261,21 +272,23 @@ def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: in
             if scratch is not None:
                 scratch["rd"] = (stable, rd, publish)
         if cp is not None:
-            _require_device(cp)
+            if not checked:
+                _require_device(cp)
             rd.xyz_copy_out = cp.data_ptr()
         else:
             rd.xyz_copy_out = None
         if pk is not None:
             v3, ref3 = pk[0], pk[2]
-            _require_device(v3)
-            if v3.dtype != torch.float32 or not v3.is_contiguous():
-                raise _lib.ChxError("pack rider: velocities and masses must be contiguous fp32 tensors")
+            if not checked:
+                _require_device(v3)
+                if v3.dtype != torch.float32 or not v3.is_contiguous():
+                    raise _lib.ChxError("pack rider: velocities and masses must be contiguous fp32 tensors")
             rd.v3 = v3.data_ptr()
             rd.ref3 = ref3.data_ptr() if ref3 is not None else None
         rd.ctrl_keep = int(riders.get("ctrl_keep", 0)) if ct is not None else 0
     lib = _lib.load()
     stream = _stream()
-    cs = C.c_float(cutoff_plus_skin)
+    cs = float(cutoff_plus_skin)  # (argtypes are declared: a float and the integer of a data_ptr() convert in C, without an object each)
     # the binning launches go to the device FIRST; the arrays the rows go into are allocated while they run (at the entry
     # of a short run() the device idles until the first launch is made: include/chx.h, chx_cell_bin_fl)
     # (the work arrays' pointers as ctypes objects, made once per set of arrays)
@@ -286,9 +299,9 @@ def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: in
         if scratch is not None:
             scratch["wptr"] = wp
     p_cell_of, p_cell_count, p_cell_start, p_status, p_xs4, p_cand0, p_cand1 = wp[2:]
-    p_sorted = _ptr(sorted_ids)
+    p_sorted = sorted_ids.data_ptr()
     check(
-        lib.chx_cell_bin_fl(_ptr(xyz), n, box, cs, nc, p_cell_of, p_cell_count, p_cell_start, p_sorted,
+        lib.chx_cell_bin_fl(xyz.data_ptr(), n, box, cs, nc, p_cell_of, p_cell_count, p_cell_start, p_sorted,
                             p_status, p_xs4, C.byref(rd) if rd is not None else None, stream),
         "chx_cell_bin_fl",
     )
