@@ -145,7 +145,7 @@ class LangevinIntegrator:
     # memory, and its numpy view no longer aliases it): it starts without and allocates its own on first use.
     # MultiStateSampler deep-copies its sampler, chiron/multistate.py:266-268.
     _PER_PROCESS_STATE = ("_gen_ring", "_gen_next", "_pinned_ring", "_ring_next", "_dev_scratch", "_inner_scratch",
-                          "_run_cache", "_defer_scratch", "_rebuild_log", "_carry", "_params_cache", "_mass_q", "_graveyard")
+                          "_run_cache", "_defer_scratch", "_rebuild_log", "_carry", "_params_cache", "_mass_q", "_graveyard", "_run_fast")
 
     def __getstate__(self):
         return {k: v for k, v in self.__dict__.items() if k not in self._PER_PROCESS_STATE}
@@ -174,43 +174,53 @@ class LangevinIntegrator:
         NeighborListNsqrd, PairListNsqrd, LJPotential, get_list_of_mass, initialize_velocities = _MODS or _mods()
 
         potential = thermodynamic_state.potential
-        # (the Quantity around the topology's cached mass array costs 3.5 us to make: kept while the array is the same object)
         topo = potential.topology
         raw = topo.masses_amu() if hasattr(topo, "masses_amu") else None
-        held = self.__dict__.get("_mass_q")
-        if raw is not None and held is not None and held[0] is raw:
-            mass = held[1]
-        else:
-            mass = get_list_of_mass(topo)
-            self._mass_q = (raw, mass) if raw is not None else None
         self.box_vectors = sampler_state.box_vectors
         self.progress_bar = progress_bar
         temperature = thermodynamic_state.temperature
         x0 = sampler_state.positions
-
-        # unit arithmetic is slow Python (exact rationals) and the mass upload a host->device copy:
-        # both are functions of objects that rarely change between run() calls
+        # Everything below up to the velocity rules is a function of six objects that rarely change between run() calls --
+        # the potential, its topology's mass array, the temperature, the time step, the collision rate -- and of the
+        # device: one tuple of them (references held, so an id cannot be recycled) stands for the five caches behind it.
         cache = self.__dict__.setdefault("_run_cache", {})
-        kT_key = ("kT", id(temperature))
-        if cache.get(kT_key, (None,))[0] is not temperature:
-            stale = [k for k in cache if k[0] == "kT"]
-            if len(stale) >= 16:  # a temperature ladder fits; anything longer-lived must not grow without bound
-                for k in stale:
-                    del cache[k]
-            cache[kT_key] = (temperature, float((self.kB * temperature).value_in_unit_system(unit.md_unit_system)))
-        kbT_unitless = cache[kT_key][1]
-        m_key = ("mass", id(potential.topology), x0.device)  # (a torch.device hashes and compares; str() of it costs 1 us)
-        if cache.get(m_key, (None,))[0] is not mass._value:
-            cache[m_key] = (mass._value, as_tensor(mass.value_in_unit_system(unit.md_unit_system)))
-        mass_unitless = cache[m_key][1]
-        if len(cache[m_key]) < 3:  # lightest particle: the speed scale of the pruned inner list's skin
-            cache[m_key] = cache[m_key] + (float(np.min(np.asarray(mass.value_in_unit_system(unit.md_unit_system)))),)
-        self._m_min = cache[m_key][2]
-        c_key = ("dt",)
-        if cache.get(c_key, (None, None))[:2] != (id(self.timestep), id(self.collision_rate)):
-            cache[c_key] = (id(self.timestep), id(self.collision_rate), langevin_constants(self.timestep, self.collision_rate),
-                            self.timestep, self.collision_rate)
-        half_dt, a, b = cache[c_key][2]
+        fast = self.__dict__.get("_run_fast")
+        if (fast is not None and raw is not None and fast[0] is potential and fast[1] is raw and fast[2] is temperature
+                and fast[3] is self.timestep and fast[4] is self.collision_rate and fast[5] == x0.device):
+            mass, kbT_unitless, mass_unitless, self._m_min, half_dt, a, b = fast[6]
+        else:
+            # (the Quantity around the topology's cached mass array costs 3.5 us to make: kept while the array is the same object)
+            held = self.__dict__.get("_mass_q")
+            if raw is not None and held is not None and held[0] is raw:
+                mass = held[1]
+            else:
+                mass = get_list_of_mass(topo)
+                self._mass_q = (raw, mass) if raw is not None else None
+
+            # unit arithmetic is slow Python (exact rationals) and the mass upload a host->device copy:
+            # both are functions of objects that rarely change between run() calls
+            kT_key = ("kT", id(temperature))
+            if cache.get(kT_key, (None,))[0] is not temperature:
+                stale = [k for k in cache if k[0] == "kT"]
+                if len(stale) >= 16:  # a temperature ladder fits; anything longer-lived must not grow without bound
+                    for k in stale:
+                        del cache[k]
+                cache[kT_key] = (temperature, float((self.kB * temperature).value_in_unit_system(unit.md_unit_system)))
+            kbT_unitless = cache[kT_key][1]
+            m_key = ("mass", id(potential.topology), x0.device)  # (a torch.device hashes and compares; str() of it costs 1 us)
+            if cache.get(m_key, (None,))[0] is not mass._value:
+                cache[m_key] = (mass._value, as_tensor(mass.value_in_unit_system(unit.md_unit_system)))
+            mass_unitless = cache[m_key][1]
+            if len(cache[m_key]) < 3:  # lightest particle: the speed scale of the pruned inner list's skin
+                cache[m_key] = cache[m_key] + (float(np.min(np.asarray(mass.value_in_unit_system(unit.md_unit_system)))),)
+            self._m_min = cache[m_key][2]
+            c_key = ("dt",)
+            if cache.get(c_key, (None, None))[:2] != (id(self.timestep), id(self.collision_rate)):
+                cache[c_key] = (id(self.timestep), id(self.collision_rate), langevin_constants(self.timestep, self.collision_rate),
+                                self.timestep, self.collision_rate)
+            half_dt, a, b = cache[c_key][2]
+            self._run_fast = (potential, raw, temperature, self.timestep, self.collision_rate, x0.device,
+                              (mass, kbT_unitless, mass_unitless, self._m_min, half_dt, a, b))
         # velocity (re)initialisation rules, :140-160
         needs_velocities = (self.refresh_velocities or sampler_state._velocities is None
                             or sampler_state._velocities.shape[0] != sampler_state.positions.shape[0])
