@@ -418,6 +418,72 @@ def test_branch_free_minimum_image_formula_is_exact():
         assert np.array_equal(fast.view(np.uint32), ref.view(np.uint32)), float(L)
 
 
+def test_row_filter_never_drops_a_pair_the_reference_predicate_keeps():
+    """The filtered row kernel of the rebuilds inside run() (csrc/chx_cell_fl.hip: k_nl_build_sub_fl, sub_filter_of) tests
+    every candidate with a CHEAP nearest image -- d - L rint(d / L), fused multiply-adds, one orientation -- against a
+    widened threshold and hands only the survivors to the reference's predicate (mod(d + L/2, L) - L/2 in the pair's
+    own orientation, chiron/neighbors.py:79, 773-782; r2 <= T(c)).  It may pass pairs the predicate then rejects; it must
+    never reject one the predicate would keep.  Both restated in NumPy fp32 on pairs piled up around the cutoff, across
+    the periodic seam, in boxes from 3 to 1000 nm (cubic and not), with coordinates up to five box lengths outside."""
+    from oracle import chiron_oracle as O
+
+    f32, f64 = np.float32, np.float64
+    rng = np.random.default_rng(7)
+
+    def threshold(c):  # largest fp32 t with sqrt(t) < c (chx_cutoff_threshold_h)
+        t = f32(c) * f32(c)
+        while np.sqrt(t) < c:
+            t = np.nextafter(t, f32(np.inf))
+        while not (np.sqrt(t) < c):
+            t = np.nextafter(t, f32(-np.inf))
+        return t
+
+    def fma(a, b, c):  # one rounding: the product of two fp32 numbers is exact in fp64
+        return (a.astype(f64) * b.astype(f64) + c.astype(f64)).astype(f32)
+
+    kept_total = dropped_far = 0
+    for box_l in ([3.7, 3.7, 3.7], [5.8601, 5.8601, 5.8601], [23.4402] * 3, [46.8805] * 3, [211.3, 211.3, 211.3], [997.0] * 3,
+                  [4.1, 23.0, 9.7], [60.0, 5.0, 310.0]):
+        L = np.array(box_l, dtype=f32)
+        box = np.diag(L).astype(f32)
+        for c in (f32(1.22), f32(1.52)):
+            if 3 * c > L.min():
+                continue  # (fewer than three cells per axis: the cell build is not used)
+            T = threshold(c)
+            lmax = L.max()
+            il = (f32(1.0) / L).astype(f32)
+            t_wide = f32(T * f32(1.001) + f32(6e-5) * lmax * np.sqrt(T))  # sub_filter_of
+            m = 400_000
+            xi = (rng.uniform(0, 1, (m, 3)) * L).astype(f32)
+            u = rng.normal(size=(m, 3))
+            u /= np.linalg.norm(u, axis=1, keepdims=True)
+            # distances: most within a few ulp .. 1e-3 of the cutoff on either side, some well inside, some far outside
+            rel = np.concatenate([rng.uniform(-1e-6, 1e-6, m // 4), rng.uniform(-1e-4, 1e-4, m // 4), rng.uniform(-2e-3, 2e-3, m // 4),
+                                  rng.uniform(-0.9, 1.0, m - 3 * (m // 4))])
+            s = (f64(c) * (1.0 + rel))[:, None]
+            shift = rng.integers(-1, 2, size=(m, 3)) * L.astype(f64)  # the neighbour through another image
+            xk = (xi.astype(f64) + s * u + shift).astype(f32)
+            far_out = rng.integers(-5, 6, size=(m, 3)) * (rng.uniform(size=(m, 1)) < 0.1)  # a tenth of the pairs unwrapped
+            xk = (xk.astype(f64) + far_out * L.astype(f64)).astype(f32)
+            # the reference's predicate, in both orientations (row i of the half list takes x_i - x_k, row k the opposite)
+            r_ik, _ = O.periodic_displacement(xi, xk, box)
+            r_ki, _ = O.periodic_displacement(xk, xi, box)
+            keep = np.zeros(m, dtype=bool)
+            for r in (r_ik, r_ki):
+                d2 = ((r[:, 0] * r[:, 0] + r[:, 1] * r[:, 1]) + r[:, 2] * r[:, 2]).astype(f32)
+                keep |= d2 <= T
+            # the filter, exactly as phase 1 evaluates it
+            d = (xi - xk).astype(f32)
+            q = np.rint((d * il).astype(f32)).astype(f32)
+            r = fma(-q, np.broadcast_to(L, q.shape), d)
+            d2f = fma(r[:, 2], r[:, 2], fma(r[:, 1], r[:, 1], (r[:, 0] * r[:, 0]).astype(f32)))
+            passed = (d2f <= t_wide) | (np.abs(q).max(axis=1) > f32(1.5))
+            assert not np.any(keep & ~passed), (box_l, float(c), int(np.sum(keep & ~passed)))
+            kept_total += int(keep.sum())
+            dropped_far += int(np.sum(~passed))
+    assert kept_total > 1_000_000 and dropped_far > 500_000  # (the test saw both sides of the cutoff, and the filter filters)
+
+
 def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
     """Error convention of include/chx.h: a negative status plus a message, never an exception or a
     launch, when the arguments cannot be right (these paths return before any HIP call)."""
