@@ -173,7 +173,12 @@ typedef struct {
   /* Optional workspace that makes the per-particle row kernel ~30 % faster: the binning writes every cell's 27-cell
    * neighbourhood out once as a list of candidate indices (cand_list: ncell * cand_cap words, cand_len: ncell ints),
    * which the ~10 rows of the cell then read instead of each working the neighbourhood's index ranges out and searching
-   * them.  A neighbourhood longer than cand_cap keeps the search; same bits either way.  NULL / 0 = off. */
+   * them.  A neighbourhood longer than cand_cap keeps the search; same bits either way.  NULL / 0 = off.
+   * Round 5: with the lists in place a build that writes NO half rows (nl_rows_out == NULL: the rebuilds inside the
+   * Langevin loop) takes a third row kernel at every grid size -- sixteen lanes per row, candidates through a cheap
+   * nearest-image test before the reference's predicate sees the survivors; same bits again, the row launch 25 -> 17.5 us
+   * at N = 32 768 and 183 -> 93 us at N = 262 144 (where the lists cost the binning 25 us and 98 MB).  It needs
+   * cand_cap <= 65536 and ncell * cand_cap < 2^29; CHX_BUILD_SUB=0 in the environment keeps the other kernels. */
   uint32_t* cand_list;
   int32_t* cand_len;
   int32_t cand_cap;
