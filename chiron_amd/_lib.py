@@ -199,6 +199,8 @@ SIGNATURES = {
     "chx_steps_open": (C.c_int, [_P]),
     "chx_step_queue_info": (C.c_int, [C.POINTER(_I64), _P]),
     "chx_step_queue_status": (C.c_char_p, []),
+    "chx_queue_debug": (C.c_int, [_I32]),
+    "chx_queue_debug_spins": (_I64, []),
     "chx_ctrl_reset": (C.c_int, [_P, _P]),
     "chx_publish": (C.c_int, [_P, _P, _I32, _P]),
     "chx_mc_displace": (C.c_int, [_P, _P, _P, _I32, _F, Box, _U32, _U32, _U32, _P, _P]),
@@ -216,7 +218,7 @@ SIGNATURES = {
     ),
 }
 
-ABI_VERSION = 4  # include/chx.h: CHX_ABI_VERSION (history there)
+ABI_VERSION = 5  # include/chx.h: CHX_ABI_VERSION (history there)
 
 _lib: Optional[C.CDLL] = None
 

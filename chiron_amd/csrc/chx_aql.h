@@ -36,8 +36,10 @@ bool chx_aql_active(hipStream_t st);
 // the kernel whose host-side stub is `host_fn` (hipKernelNameRefByPtr -> the code objects' symbol table), or NULL
 const AqlKernel* chx_aql_kernel_of(const void* host_fn, hipStream_t st);
 // One packet for any grid; `explicit_bytes` of packed arguments (the implicit arguments of code object v5 -- block
-// counts, group sizes, grid dimensions -- are appended when the kernel's segment asks for them); agent-scope release.
-int chx_aql_dispatch_any(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, const void* kernarg, size_t explicit_bytes);
+// counts, group sizes, grid dimensions -- are appended when the kernel's segment asks for them); agent-scope release, and
+// an agent-scope acquire unless `hot_acquire` (the Monte Carlo trial: the steps' acquire-less rule, chx_aql.hip).
+int chx_aql_dispatch_any(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, const void* kernarg, size_t explicit_bytes,
+                         bool hot_acquire = false);
 // The packet just written for `st` -- the list build's summary launch, which only reads what the step kernels read and
 // writes the build's status block -- may run BESIDE the next step packet: that one goes out without the barrier bit (it
 // still starts behind everything in front of the summary, whose own barrier bit held it back until then).  Any other

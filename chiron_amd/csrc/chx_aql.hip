@@ -64,6 +64,7 @@ int chx_aql_open_count = 0;
 // the start-up check's kernels (chx_core.hip)
 const void* chx_selfcheck_fill_fn();
 const void* chx_selfcheck_read_fn();
+const void* chx_debug_spin_fn();
 
 namespace {
 
@@ -132,6 +133,7 @@ struct Queue {
   hsa_signal_t done{};   // completion signal of the join barrier
   hsa_signal_t fin{};    // ... of a packet dispatched as the LAST of a run (chx_aql_dispatch: final_packet)
   bool final_sent = false;  // the newest packet carries `fin` and a system-scope release: a join only has to wait for it
+  bool fin_unobserved = false;  // a packet carrying `fin` was dispatched and nobody has waited for it since
   Gate gates[4];
   unsigned gate_next = 0;
   // Run-ahead bound.  The ring is cut into segments of SEG packets; the last packet of a segment carries that segment's
@@ -346,7 +348,7 @@ int g_selfcheck_result = -1;  // -1 not run, 0 passed, > 0 stale words seen (fen
 // forward: the packet helpers below
 uint64_t reserve(Queue* Q, hsa_signal_t* completion);
 inline void publish(Queue* Q, uint64_t widx, uint16_t header);
-bool wait_zero(hsa_signal_t sig, const char* what);
+bool wait_zero(hsa_signal_t sig, const char* what, Queue* Q = nullptr);
 inline void* slot_of(Queue* Q, uint64_t widx);
 
 // One raw kernel packet with explicit fence scopes (the self-check only).
@@ -455,17 +457,30 @@ Queue* queue_for(hipStream_t st) {
 
 inline void* slot_of(Queue* Q, uint64_t widx) { return reinterpret_cast<char*>(Q->q->base_address) + 64 * (widx % Q->size); }
 
-bool wait_zero(hsa_signal_t sig, const char* what) {
+// Host wait for a completion signal.  Gives up -- and marks the queue broken for the process -- when the queue has made
+// NO PROGRESS for two minutes (its read index stands still: a gate that waits behind minutes of stream work is not a
+// hang) or the runtime has reported an error; the failure is also left for the calling entry point's chx_check_launch.
+bool wait_zero(hsa_signal_t sig, const char* what, Queue* Q) {
   timespec t0;
   clock_gettime(CLOCK_MONOTONIC, &t0);
+  uint64_t seen = Q ? H.hsa_queue_load_read_index_scacquire(Q->q) : 0;
   while (H.hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, 1, 1000000ull, HSA_WAIT_STATE_ACTIVE) >= 1) {
-    if (g_queue_error) return false;
+    if (g_queue_error) {
+      chx_note_launch_failure(CHX_ERR_LAUNCH);
+      return false;
+    }
     timespec t1;
     clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (Q) {
+      const uint64_t now = H.hsa_queue_load_read_index_scacquire(Q->q);
+      if (now != seen) seen = now, t0 = t1;
+    }
     if (t1.tv_sec - t0.tv_sec > 120) {
       fail(what);
       fprintf(stderr, "[chx] %s\n", g_err);
       g_queue_error = 1;
+      chx_set_error("%s", g_err);
+      chx_note_launch_failure(CHX_ERR_LAUNCH);
       return false;
     }
   }
@@ -481,7 +496,7 @@ uint64_t reserve(Queue* Q, hsa_signal_t* completion) {
   if (slot % Queue::SEG == 0) {
     const unsigned back = (seg + nseg - Queue::AHEAD) % nseg;
     if (Q->seg_used[back]) {
-      (void)wait_zero(Q->seg_sig[back], "the step queue has made no progress for 120 s");
+      (void)wait_zero(Q->seg_sig[back], "the step queue has made no progress for 120 s", Q);
       Q->seg_used[back] = false;
     }
   }
@@ -577,8 +592,38 @@ void open_gate(Queue* Q, hipStream_t st) {
   __atomic_fetch_add(&chx_aql_open_count, 1, __ATOMIC_RELAXED);
 }
 
+// Debug mode (chx_queue_debug): a spin packet of g_debug_delay_us microseconds goes in front of (a) the first packet behind
+// a gate, (b) every packet that is not a hot one -- unpack, the list build chain, pack, prologues: the launches whose
+// outputs somebody outside the queue reads -- and (c) a run's final launch.  Whoever reads such an output without having
+// joined then reads it EARLY every time, not once in a thousand runs; together with the poison the Python layer puts
+// into those arrays when it allocates them (chiron_amd/ops.py: fresh) a missing join is a deterministic failure.
+int g_debug_delay_us = [] {
+  const char* e = getenv("CHX_QUEUE_DEBUG");
+  const int v = e ? atoi(e) : 0;
+  return v < 0 ? 0 : v;
+}();
+const AqlKernel* g_spin_kernel = nullptr;
+bool g_spin_looked = false;
+uint64_t g_debug_spins = 0;
+
+void debug_spin_packet(Queue* Q, hipStream_t st) {
+  if (!g_spin_looked) {
+    g_spin_looked = true;
+    const char* nm = hipKernelNameRefByPtr(chx_debug_spin_fn(), st);
+    if (nm) {
+      auto f = g_kernels.find(nm);
+      if (f != g_kernels.end()) g_spin_kernel = &f->second;
+    }
+    if (!g_spin_kernel) fprintf(stderr, "[chx] step queue debug mode: no code object holds k_debug_spin (no delays)\n");
+  }
+  if (!g_spin_kernel) return;
+  struct { long long ticks; } a = {(long long)g_debug_delay_us * 100ll};
+  raw_packet(Q, g_spin_kernel, 1, &a, sizeof(a), HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE, hsa_signal_t{0});
+  g_debug_spins++;
+}
+
 int dispatch_core(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, const void* kernarg, size_t nbytes, int release,
-                  bool is_step = false, bool final_packet = false) {
+                  bool is_step = false, bool final_packet = false, bool hot_acquire = false) {
   // (the segment may be shorter than the caller's block -- trailing padding of a by-value struct -- never longer)
   const size_t seg = k->kernarg_size;
   if (nbytes + 256 > SLOT || nbytes > seg + 8) {
@@ -591,8 +636,12 @@ int dispatch_core(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, con
     chx_set_error("%s", g_err);
     return CHX_ERR_LAUNCH;
   }
-  int acquire = g_fence_none ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT;
+  // Acquire scope: NONE only for the launches that are on a microsecond budget and whose inputs are known to live in
+  // device-local memory written through or released by their predecessors (the fused steps, the Monte Carlo trial); every
+  // other packet -- the list build chain, pack / unpack, prologues -- takes an agent-scope acquire like a HIP launch.
+  int acquire = (g_fence_none && (is_step || hot_acquire)) ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT;
   if (!Q->open) open_gate(Q, st);
+  if (g_debug_delay_us > 0 && (Q->fresh || !(is_step || hot_acquire) || final_packet)) debug_spin_packet(Q, st);
   // (a step packet behind the list build's summary launch starts beside it: chx_aql_allow_overlap)
   const bool barrier = !(is_step && Q->overlap_ok);
   Q->overlap_ok = false;
@@ -608,7 +657,14 @@ int dispatch_core(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, con
   // shortcut away again (the join then goes the ordinary way; `fin` fires unobserved and is armed anew next time).
   static const bool final_on = [] { const char* e = getenv("CHX_AQL_FINAL"); return !e || e[0] != '0'; }();
   Q->final_sent = false;
-  if (final_packet && final_on && seg_sig.handle == 0) {
+  if (final_packet && final_on && seg_sig.handle == 0 && Q->fin_unobserved) {
+    // an earlier packet still owns `fin` (it was followed by other packets, so no join waited for it): re-arming the signal
+    // under it would let its completion pass for this packet's.  Done already (value <= 0): the signal is free again;
+    // otherwise this launch goes without the shortcut and the join takes the barrier path.
+    if (H.hsa_signal_load_scacquire(Q->fin) <= 0) Q->fin_unobserved = false;
+  }
+  if (final_packet && final_on && seg_sig.handle == 0 && !Q->fin_unobserved) {
+    Q->fin_unobserved = true;
     H.hsa_signal_store_relaxed(Q->fin, 1);
     seg_sig = Q->fin;
     release = HSA_FENCE_SCOPE_SYSTEM;
@@ -679,8 +735,9 @@ void chx_aql_allow_overlap(hipStream_t st) {
   if (it != g_queues.end() && it->second->open) it->second->overlap_ok = true;
 }
 
-int chx_aql_dispatch_any(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, const void* kernarg, size_t explicit_bytes) {
-  return dispatch_core(st, k, grid, block, kernarg, explicit_bytes, HSA_FENCE_SCOPE_AGENT);
+int chx_aql_dispatch_any(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, const void* kernarg, size_t explicit_bytes,
+                         bool hot_acquire) {
+  return dispatch_core(st, k, grid, block, kernarg, explicit_bytes, HSA_FENCE_SCOPE_AGENT, false, false, hot_acquire);
 }
 
 bool chx_aql_active(hipStream_t st) {
@@ -726,12 +783,13 @@ void chx_aql_join(hipStream_t st) {
   if (!Q || !Q->open) return;
   Q->overlap_ok = false;
   if (Q->final_sent) {  // (the newest packet is a run's last launch: it releases at system scope and signals by itself)
-    (void)wait_zero(Q->fin, "the queue has not drained for 120 s");
+    (void)wait_zero(Q->fin, "the queue has not drained for 120 s", Q);
     Q->final_sent = false;
+    Q->fin_unobserved = false;
   } else {
     H.hsa_signal_store_relaxed(Q->done, 1);
     push_barrier(Q, hsa_signal_t{0}, Q->done, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_SYSTEM);
-    (void)wait_zero(Q->done, "the queue has not drained for 120 s");
+    (void)wait_zero(Q->done, "the queue has not drained for 120 s", Q);
   }
   Q->open = false;
   Q->n_joins++;
@@ -764,3 +822,9 @@ extern "C" int chx_step_queue_info(int64_t* out8_h, chx_stream_t stream) {
   return CHX_OK;
 }
 extern "C" const char* chx_step_queue_status(void) { return g_err; }
+extern "C" int chx_queue_debug(int32_t delay_us) {
+  const int old = g_debug_delay_us;
+  if (delay_us >= 0) g_debug_delay_us = delay_us;
+  return old;
+}
+extern "C" int64_t chx_queue_debug_spins(void) { return (int64_t)g_debug_spins; }

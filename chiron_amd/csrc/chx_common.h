@@ -11,6 +11,8 @@
 
 void chx_set_error(const char* fmt, ...);
 int chx_check_launch(const char* what);
+// (chx_launch.h: a dropped dispatch is reported by the entry point's chx_check_launch)
+void chx_note_launch_failure(int rc);
 
 #define CHX_REQUIRE(cond, msg)             \
   do {                                     \

@@ -16,7 +16,24 @@ void chx_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// A dispatch through the step queue that failed (chx_launch.h: a kernarg block that does not fit the kernel, a queue in
+// error) is remembered per thread until the entry point that made it reaches its chx_check_launch: the kernel was
+// dropped, and what follows on the queue would otherwise run on arrays nobody wrote.
+static thread_local int g_launch_rc = CHX_OK;
+void chx_note_launch_failure(int rc) {
+  if (rc != CHX_OK && g_launch_rc == CHX_OK) g_launch_rc = rc;
+}
+
 int chx_check_launch(const char* what) {
+  if (g_launch_rc != CHX_OK) {
+    const int rc = g_launch_rc;
+    g_launch_rc = CHX_OK;
+    (void)hipGetLastError();
+    char keep[400];
+    snprintf(keep, sizeof(keep), "%s", g_err);  // (the dispatcher's own text)
+    chx_set_error("%s: a launch was dropped (%s)", what, keep);
+    return rc;
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     chx_set_error("%s: %s", what, hipGetErrorString(e));
@@ -250,6 +267,15 @@ __global__ __launch_bounds__(256) void k_selfcheck_read(const int32_t* buf, int 
   if (threadIdx.x == 0 && s0 != val) atomicAdd(bad + 1, 1);
 }
 // (referenced from the host so that the stubs, and with them the names hipKernelNameRefByPtr hands out, exist)
+// The step queue's debug mode (chx_queue_debug, include/chx.h): a packet that does nothing for `ticks` periods of the
+// 100 MHz wall clock.  One lane watches the clock; the clock only moves forward, so the wave ends.
+__global__ __launch_bounds__(256) void k_debug_spin(long long ticks) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (ticks > 100000000ll) ticks = 100000000ll;  // one second at most
+  const long long t0 = (long long)wall_clock64();
+  while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+const void* chx_debug_spin_fn() { return reinterpret_cast<const void*>(&k_debug_spin); }
 const void* chx_selfcheck_fill_fn() { return reinterpret_cast<const void*>(&k_selfcheck_fill); }
 const void* chx_selfcheck_read_fn() { return reinterpret_cast<const void*>(&k_selfcheck_read); }
 

@@ -29,7 +29,7 @@ inline size_t pack(char* buf, size_t off, const T& v, const Rest&... rest) {
 }
 }  // namespace chx_launch_detail
 
-template <typename... KArgs, typename... Args>
+template <bool HOT = false, typename... KArgs, typename... Args>
 inline int chx_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, hipStream_t st, Args&&... args) {
   static_assert(sizeof...(KArgs) == sizeof...(Args), "argument count");
   if (chx_aql_active(st)) {
@@ -39,7 +39,9 @@ inline int chx_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, hipStream
       static_assert((0 + ... + (sizeof(KArgs) + 16)) <= sizeof(buf), "argument block too large for the packer's buffer");
       std::memset(buf, 0, sizeof(buf));
       const size_t n = chx_launch_detail::pack(buf, 0, static_cast<KArgs>(args)...);
-      return chx_aql_dispatch_any(st, k, grid, block, buf, n);
+      const int rc = chx_aql_dispatch_any(st, k, grid, block, buf, n, HOT);
+      chx_note_launch_failure(rc);  // (most call sites do not look at the return value: chx_check_launch reports it)
+      return rc;
     }
     chx_aql_join(st);  // (a kernel no loaded code object holds: keep the order at least, then launch through HIP)
   } else if (__atomic_load_n(&chx_aql_open_count, __ATOMIC_RELAXED) > 0) {
@@ -51,3 +53,6 @@ inline int chx_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, hipStream
   return CHX_OK;
 }
 #define CHX_LAUNCH(kernel, grid, block, st, ...) chx_launch(kernel, grid, block, st, __VA_ARGS__)
+// the same for a kernel on a microsecond budget whose inputs its predecessors on the queue wrote through or released: as a
+// packet it goes without an acquire fence (the Monte Carlo trial)
+#define CHX_LAUNCH_HOT(kernel, grid, block, st, ...) chx_launch<true>(kernel, grid, block, st, __VA_ARGS__)

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 
 #include "chx_common.h"
 #include "chx_internal.h"
@@ -776,17 +777,21 @@ static int launch_step_g(const StepArgs& a, long long step, int n_kicks, int do_
     // the step queue (chx_aql.h): the same kernel, dispatched as an AQL packet.  A steady-state launch leaves nothing
     // but write-through stores behind (step_epilogue; the control words are stored at agent scope) and carries no
     // release fence; a launch that refreshes the inner list or takes the general paths ends with an agent-scope release.
-    static const AqlKernel* table[2][2][2] = {{{nullptr, nullptr}, {nullptr, nullptr}}, {{nullptr, nullptr}, {nullptr, nullptr}}};
-    static bool looked[2][2][2] = {{{false, false}, {false, false}}, {{false, false}, {false, false}}};
+    // (looked up once per instantiation; several threads may step replicas of their own: one atomic word per entry, the
+    // look-up itself is idempotent)
+    static const AqlKernel absent{};
+    static std::atomic<const AqlKernel*> table[2][2][2];
     const int ih = hot ? 1 : 0, ip = prune ? 1 : 0, id = defer ? 1 : 0;
-    if (!looked[ih][ip][id]) {
+    const AqlKernel* k = table[ih][ip][id].load(std::memory_order_acquire);
+    if (k == nullptr) {
       char name[96];
       snprintf(name, sizeof(name), "void k_lj_step<%d, %s, %s, %s>", G, hot ? "true" : "false", prune ? "true" : "false",
                defer ? "true" : "false");
-      table[ih][ip][id] = chx_aql_kernel(name);
-      looked[ih][ip][id] = true;
+      k = chx_aql_kernel(name);
+      if (k == nullptr) k = &absent;
+      table[ih][ip][id].store(k, std::memory_order_release);
     }
-    const AqlKernel* k = table[ih][ip][id];
+    if (k == &absent) k = nullptr;
     if (k == nullptr) {  // (a code object from other sources than this library: refuse, do not mix launch paths)
       chx_set_error("chx_launch_step: libchx_step.hsaco holds no k_lj_step<%d, %d, %d, %d>", G, ih, ip, id);
       return CHX_ERR_LAUNCH;
@@ -849,7 +854,10 @@ void chx_launch_ap_step(const StepArgs& a, long long step, int n_kicks, int do_a
       // (an A-O-A launch of this kernel leaves write-through stores only -- positions and velocities, step_epilogue; no
       // control words on the paths without a Verlet list -- so it needs no release fence; the force-only launch that ends a
       // run also writes the state in user order with plain stores)
-      if (chx_aql_dispatch(st, k, blocks, &ka, sizeof(ka), do_aoa == 0) == CHX_OK) return;
+      // (a failed dispatch is reported by the entry point's chx_check_launch; never fall back to a HIP launch beside
+      // packets that are still outstanding)
+      chx_note_launch_failure(chx_aql_dispatch(st, k, blocks, &ka, sizeof(ka), do_aoa == 0));
+      return;
     }
   }
   if (a.n <= 2048) {

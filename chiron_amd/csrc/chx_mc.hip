@@ -445,11 +445,11 @@ static void launch_trial(const McArgs& a, long long t, bool decide, int log_slot
   const unsigned blocks = (unsigned)(((int64_t)a.n * G + 255) / 256);
   // (CHX_LAUNCH: an AQL packet on the step queue, which chx_mc_displace_chunk has opened -- chx_launch.h)
   if (a.fli != nullptr) {
-    if (decide) CHX_LAUNCH((k_mc_trial<G, true, true>), dim3(blocks), dim3(256), st, a, t, log_slot, blocks);
-    else CHX_LAUNCH((k_mc_trial<G, false, true>), dim3(blocks), dim3(256), st, a, t, log_slot, blocks);
+    if (decide) CHX_LAUNCH_HOT((k_mc_trial<G, true, true>), dim3(blocks), dim3(256), st, a, t, log_slot, blocks);
+    else CHX_LAUNCH_HOT((k_mc_trial<G, false, true>), dim3(blocks), dim3(256), st, a, t, log_slot, blocks);
   } else {
-    if (decide) CHX_LAUNCH((k_mc_trial<G, true, false>), dim3(blocks), dim3(256), st, a, t, log_slot, blocks);
-    else CHX_LAUNCH((k_mc_trial<G, false, false>), dim3(blocks), dim3(256), st, a, t, log_slot, blocks);
+    if (decide) CHX_LAUNCH_HOT((k_mc_trial<G, true, false>), dim3(blocks), dim3(256), st, a, t, log_slot, blocks);
+    else CHX_LAUNCH_HOT((k_mc_trial<G, false, false>), dim3(blocks), dim3(256), st, a, t, log_slot, blocks);
   }
 }
 

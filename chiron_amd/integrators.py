@@ -98,6 +98,15 @@ def _wait_for_steps_and_stream(device_wide: bool = False) -> None:
         torch.cuda.current_stream().synchronize()
 
 
+def _skip_join_hook() -> bool:
+    """Test hook (tests/test_gpu_step_queue.py): a deliberately MISSING join at the end of run(), which the step queue's
+    debug mode (ops.queue_debug) has to turn into poison in the returned state every time."""
+    if ops._debug_skip_final_join > 0:
+        ops._debug_skip_final_join -= 1
+        return True
+    return False
+
+
 def langevin_constants(timestep, collision_rate):
     """(half_dt, a, b) in fp32 exactly as chiron/integrators.py:132-137 forms them."""
     dt = float(timestep.value_in_unit_system(unit.md_unit_system))
@@ -396,7 +405,8 @@ class LangevinIntegrator:
             # (the launches of the paths without a Verlet list ride on the step queue too -- k_ap_step, the copy into user
             # order just made: a run() returns with the queue drained, whatever the path; the fused path has waited in
             # _enqueue_kick)
-            ops.steps_join()
+            if not _skip_join_hook():
+                ops.steps_join()
         updated_sampler_state = ready if ready is not None else sampler_state._copy_with(*final_xv, box_copy=tail["box"])  # :210-218
         st.offer_carry(updated_sampler_state)
         updated_sampler_state.current_PRNG_key = tail["key"]
@@ -866,7 +876,7 @@ class _RunState:
         return self.x_a if self.parity == 0 else self.x_b
 
     def _unpack(self, t: torch.Tensor) -> torch.Tensor:
-        out = torch.empty((self.n, 3), dtype=torch.float32, device=self.dev)
+        out = ops.fresh((self.n, 3), dtype=torch.float32, device=self.dev)
         ops.check(
             ops._lib.load().chx_permute_unpack(ops._ptr(t), t.shape[1], ops._ptr(self.perm), self.n, ops._ptr(out), ops._stream()),
             "chx_permute_unpack",
@@ -875,8 +885,8 @@ class _RunState:
 
     def state_user(self):
         """(positions, velocities) in user order, one launch."""
-        x3 = torch.empty((self.n, 3), dtype=torch.float32, device=self.dev)
-        v3 = torch.empty((self.n, 3), dtype=torch.float32, device=self.dev)
+        x3 = ops.fresh((self.n, 3), dtype=torch.float32, device=self.dev)
+        v3 = ops.fresh((self.n, 3), dtype=torch.float32, device=self.dev)
         ops.check(
             ops._lib.load().chx_unpack_langevin(ops._ptr(self._x_cur()), ops._ptr(self.v), ops._ptr(self.perm), self.n,
                                                 ops._ptr(x3), ops._ptr(v3), ops._stream()),
@@ -999,9 +1009,9 @@ class _RunState:
         p = self.params
         if with_state:
             f32 = dict(dtype=torch.float32, device=self.dev)
-            x3, v3 = torch.empty((self.n, 3), **f32), torch.empty((self.n, 3), **f32)
+            x3, v3 = ops.fresh((self.n, 3), **f32), ops.fresh((self.n, 3), **f32)
             # (list carry-over: the reference positions the caller's list will be rebuilt from, should anybody read it)
-            r3 = torch.empty((self.n, 3), **f32) if self._carried is not None else None
+            r3 = ops.fresh((self.n, 3), **f32) if self._carried is not None else None
             p.final_x3, p.final_v3 = x3.data_ptr(), v3.data_ptr()
             p.final_ref3 = r3.data_ptr() if r3 is not None else None
         try:
@@ -1036,6 +1046,8 @@ class _RunState:
         """Host wait until every launch of the run so far has run.  Through the step queue (the default) the step
         launches are the last thing enqueued and the join is the whole wait -- the stream holds nothing behind the marker
         that let them start; with plain HIP launches (CHX_AQL=0, or no queue) an event on the stream is."""
+        if _skip_join_hook():
+            return
         ops.steps_join()
         self.integ._graveyard = None  # (everything that read the buried arrays has run)
         if not ops.step_queue_on():

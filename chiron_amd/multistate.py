@@ -64,10 +64,13 @@ def neighbor_swap_decisions(u_kn: np.ndarray, state_of_replica: np.ndarray, iter
 
 
 class ReplicaExchange:
-    """One replica per process/GPU; temperature (and pressure) ladder exchange.
+    """Replicas sharded over processes/GPUs; temperature (and pressure) ladder exchange.
 
-    Works on any ``torch.distributed`` backend: ``nccl`` (= RCCL) on the GPU node,
-    ``gloo`` in the CPU tests.  With ``world_size == 1`` no process group is needed.
+    K thermodynamic states over W ranks, K a multiple of W: rank r owns the replicas r K/W ... (r + 1) K/W - 1
+    (BASELINE's C5 is K = W = 8, one replica per GPU; with fewer cards than states a rank propagates its K/W replicas
+    side by side, ``LangevinIntegrator.run_batch``).  Works on any ``torch.distributed`` backend: ``nccl`` (= RCCL) on the
+    GPU node, ``gloo`` in the CPU tests.  With ``world_size == 1`` no process group is needed -- but one is used when it
+    exists (a one-rank RCCL group runs the very collective the eight-rank job runs).
     """
 
     def __init__(self, thermodynamic_states: Sequence[ThermodynamicState], key: PRNGKey,
@@ -81,14 +84,17 @@ class ReplicaExchange:
         if rank is None:
             rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         self.rank, self.world_size = rank, world_size
-        if len(self.states) != world_size:
-            raise RuntimeError("Number of thermodynamic states and replicas (ranks) must be equal.")
+        K = len(self.states)
+        if K == 0 or K % world_size != 0:
+            raise RuntimeError("Number of thermodynamic states must be a (non-zero) multiple of the number of ranks.")
+        self.n_states = K
+        self.replicas_per_rank = K // world_size
         self.device = device
-        self.state_of_replica = np.arange(world_size, dtype=np.int64)  # multistate.py:277-279
+        self.state_of_replica = np.arange(K, dtype=np.int64)  # multistate.py:277-279
         self.iteration = 0
-        self.n_proposed = np.zeros((world_size, world_size), np.int64)
-        self.n_accepted = np.zeros((world_size, world_size), np.int64)
-        self.u_kn = np.zeros((world_size, world_size))
+        self.n_proposed = np.zeros((K, K), np.int64)
+        self.n_accepted = np.zeros((K, K), np.int64)
+        self.u_kn = np.zeros((K, K))
         self._betas = np.array(
             [float((1.0 / (unit.BOLTZMANN_CONSTANT_kB * s.temperature * unit.AVOGADRO_CONSTANT_NA)).value_in_unit(
                 unit.kilojoule_per_mole ** -1)) for s in self.states]
@@ -96,8 +102,22 @@ class ReplicaExchange:
         self._pressures = [s.pressure for s in self.states]
 
     @property
+    def my_replicas(self) -> range:
+        """Global indices of the replicas this rank propagates."""
+        return range(self.rank * self.replicas_per_rank, (self.rank + 1) * self.replicas_per_rank)
+
+    @property
+    def my_state_indices(self) -> List[int]:
+        return [int(self.state_of_replica[r]) for r in self.my_replicas]
+
+    @property
+    def my_states(self) -> List[ThermodynamicState]:
+        return [self.states[k] for k in self.my_state_indices]
+
+    @property
     def my_state_index(self) -> int:
-        return int(self.state_of_replica[self.rank])
+        """(one replica per rank)"""
+        return int(self.state_of_replica[self.my_replicas[0]])
 
     @property
     def my_state(self) -> ThermodynamicState:
@@ -114,40 +134,54 @@ class ReplicaExchange:
         return u
 
     def gather_energies(self, energy: torch.Tensor) -> np.ndarray:
-        """The one collective of the path: all-gather of one fp64 per rank (the reference's energy
-        matrix is fp64, chiron/multistate.py:290-292; the kernels' fp32 energies and host-side fp64
-        volumes both travel unrounded)."""
+        """The one collective of the path: all-gather of one fp64 per replica, K/W of them from every rank (the
+        reference's energy matrix is fp64, chiron/multistate.py:290-292; the kernels' fp32 energies and host-side fp64
+        volumes both travel unrounded).  With RCCL the gather runs on the device tensor in place; ``gloo`` gathers host
+        tensors (CPU tests, single-GPU rehearsals)."""
         import torch.distributed as dist
 
-        e = energy.detach().reshape(1).to(torch.float64)
-        if self.world_size == 1 and not (dist.is_available() and dist.is_initialized()):
+        e = energy.detach().reshape(-1).to(torch.float64)
+        if e.numel() != self.replicas_per_rank:
+            raise ValueError(f"expected {self.replicas_per_rank} energies (one per replica of this rank), got {e.numel()}")
+        if not (dist.is_available() and dist.is_initialized()):
+            if self.world_size != 1:
+                raise RuntimeError("ReplicaExchange over several ranks needs an initialised process group")
             return e.cpu().numpy()
         if dist.get_backend() == "gloo":
-            e = e.cpu()  # gloo gathers host tensors (CPU tests, single-GPU rehearsals); RCCL gathers in place on the device
-        out = torch.empty(self.world_size, dtype=torch.float64, device=e.device)
-        dist.all_gather_into_tensor(out, e)
+            e = e.cpu()
+        out = torch.empty(self.n_states, dtype=torch.float64, device=e.device)
+        dist.all_gather_into_tensor(out, e.contiguous())
         return out.cpu().numpy()
 
-    def exchange(self, energy: torch.Tensor, volume_nm3: Optional[float] = None):
-        """Gather, decide, relabel.  Returns (new_state_index, velocity_scale) for this rank."""
-        energies = self.gather_energies(energy)
+    def exchange_many(self, energies: torch.Tensor, volumes_nm3=None):
+        """Gather, decide, relabel.  ``energies``: the potential energies of this rank's replicas, in ``my_replicas``
+        order.  Returns one (new_state_index, velocity_scale) per replica of this rank."""
+        gathered = self.gather_energies(energies)
         vols = None
-        if volume_nm3 is not None:
-            vols = self.gather_energies(torch.as_tensor([volume_nm3], dtype=torch.float64, device=energy.device))
-        self.u_kn = self._reduced_row(energies, vols)
-        old = self.my_state_index
+        if volumes_nm3 is not None:
+            vols = self.gather_energies(torch.as_tensor(volumes_nm3, dtype=torch.float64, device=energies.device).reshape(-1))
+        self.u_kn = self._reduced_row(gathered, vols)
+        old = self.my_state_indices
         new, n_prop, n_acc = neighbor_swap_decisions(self.u_kn, self.state_of_replica, self.iteration, self.key)
         self.state_of_replica = new
         self.n_proposed += n_prop
         self.n_accepted += n_acc
         self.iteration += 1
-        new_idx = self.my_state_index
-        scale = 1.0
-        if new_idx != old:
-            t_old = self.states[old].temperature.value_in_unit(unit.kelvin)
-            t_new = self.states[new_idx].temperature.value_in_unit(unit.kelvin)
-            scale = math.sqrt(t_new / t_old)
-        return new_idx, scale
+        out = []
+        for o, n_ in zip(old, self.my_state_indices):
+            scale = 1.0
+            if n_ != o:
+                t_old = self.states[o].temperature.value_in_unit(unit.kelvin)
+                t_new = self.states[n_].temperature.value_in_unit(unit.kelvin)
+                scale = math.sqrt(t_new / t_old)
+            out.append((n_, scale))
+        return out
+
+    def exchange(self, energy: torch.Tensor, volume_nm3: Optional[float] = None):
+        """One replica per rank: returns (new_state_index, velocity_scale) for this rank."""
+        if self.replicas_per_rank != 1:
+            raise RuntimeError("this rank owns several replicas: use exchange_many")
+        return self.exchange_many(energy, None if volume_nm3 is None else [volume_nm3])[0]
 
 
 # ---------------------------------------------------------------------------

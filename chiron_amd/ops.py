@@ -305,11 +305,13 @@ def nl_build_cell_fl(xyz: torch.Tensor, box: Box, cutoff_plus_skin: float, m: in
                             p_status, p_xs4, C.byref(rd) if rd is not None else None, stream),
         "chx_cell_bin_fl",
     )
-    nl = torch.empty((n, m), **i32) if half_rows else None
-    first = torch.empty((n,), **i32) if half_rows else None
-    n_nbr = torch.empty((n,), **i32)
-    fl = torch.empty((chunks, n, FL_QUAD * g), **i32)
-    deg = torch.empty((n,), **i32)
+    # (`fresh`: what the row launches write is read from outside the queue -- by the force kernels of compute_energy, by
+    # whoever looks at the list; poison in the queue's debug mode)
+    nl = fresh((n, m), **i32) if half_rows else None
+    first = fresh((n,), **i32) if half_rows else None
+    n_nbr = fresh((n,), **i32)
+    fl = fresh((chunks, n, FL_QUAD * g), **i32)
+    deg = fresh((n,), **i32)
     check(
         lib.chx_nl_rows_cell_fl(n, m, box, cs, nc, p_cell_of, p_cell_start, p_sorted, p_status, p_xs4,
                                 _ptr(nl) if half_rows else None, _ptr(first) if half_rows else None, _ptr(n_nbr), g, chunks, _ptr(fl), _ptr(deg), publish,
@@ -662,6 +664,46 @@ def langevin_fused_run(params: LangevinParams, x_even: torch.Tensor, x_odd: torc
         "chx_langevin_fused_run",
     )
     return out.value
+
+
+# ---------------------------------------------------------------------------
+# Debug mode of the step queue (include/chx.h: chx_queue_debug): the deterministic detector for a missing join.
+# The C side delays the launches whose outputs are read from outside the queue; this side fills those outputs with
+# poison (NaN / -1) when it allocates them, on the stream, and waits for the fill -- so the poison is in place before the
+# packet that overwrites it is even written.  A reader that skipped steps_join() then reads poison every time.
+# CHX_QUEUE_DEBUG=<microseconds> switches both halves on for a whole process; queue_debug(us) at run time.
+# ---------------------------------------------------------------------------
+_debug_us = int(__import__("os").environ.get("CHX_QUEUE_DEBUG", "0") or 0)
+_debug_skip_final_join = 0  # test hook: that many of the joins that end a run() are skipped (tests/test_gpu_step_queue.py)
+
+
+def queue_debug(delay_us: Optional[int] = None) -> int:
+    """Set (or, with None, read) the step queue's debug delay in microseconds; 0 = off.  Returns the previous value."""
+    global _debug_us
+    old = _debug_us
+    if delay_us is not None:
+        _debug_us = max(0, int(delay_us))
+        _lib.load().chx_queue_debug(_debug_us)
+    return old
+
+
+def queue_debug_spins() -> int:
+    return int(_lib.load().chx_queue_debug_spins())
+
+
+def fresh(shape, dtype=torch.float32, device=None) -> torch.Tensor:
+    """``torch.empty`` for an array that a launch on the step queue is about to write and somebody OUTSIDE the queue will
+    read (the state a run() returns, a rebuilt list's arrays).  In debug mode the array starts out as poison."""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    if _debug_us > 0 and t.is_cuda:
+        t.fill_(float("nan") if t.is_floating_point() else -1)
+        torch.cuda.current_stream(t.device).synchronize()
+    return t
+
+
+def is_poison(t: torch.Tensor) -> bool:
+    """Does ``t`` still hold (any of) the poison ``fresh`` put there?  (Reads on the current stream, no join.)"""
+    return bool((torch.isnan(t) if t.is_floating_point() else (t == -1)).any().item())
 
 
 def steps_join() -> None:

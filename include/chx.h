@@ -64,7 +64,12 @@ typedef void* chx_stream_t;
  *      libchx call on `stream` runs behind them -- but a caller that enqueues work of its OWN on `stream` which reads
  *      what the steps write must call chx_steps_join first.  CHX_AQL=0 in the environment restores plain HIP launches.
  *      New entry points: chx_steps_join, chx_steps_open, chx_step_queue_info, chx_step_queue_status. */
-#define CHX_ABI_VERSION 4
+/*   5  round 6 -- compatible with 4 for every existing signature.  Added: chx_queue_debug / chx_queue_debug_spins (the step
+ *      queue's delay mode), chx_langevin_batch_run and chx_langevin_batch_kick (one launch per step for SEVERAL replicas).
+ *      Memory contract stated (it held before): every device pointer handed to an entry point that may ride on the step
+ *      queue must be device-local coarse-grained memory (hipMalloc / a torch CUDA tensor), not fine-grained, host-pinned or
+ *      peer memory -- the fused step and Monte Carlo trial packets carry no acquire fence. */
+#define CHX_ABI_VERSION 5
 
 /* high bit of a force-list entry: neighbor has the HIGHER original particle id */
 #define CHX_FL_HI 0x80000000u
@@ -526,6 +531,17 @@ int chx_steps_open(chx_stream_t stream);
  * packets outstanding (0 / 1), openings on an idle stream (no marker needed: hipStreamQuery said so)}. */
 int chx_step_queue_info(int64_t* out8_h, chx_stream_t stream);
 const char* chx_step_queue_status(void);
+/* Debug mode of the step queue (ABI 5; CHX_QUEUE_DEBUG=<microseconds> in the environment sets the initial value).  With a
+ * delay > 0 the queue puts a packet that idles that long (one lane watching the wall clock; at most a second) in front of
+ * the first packet behind every gate, of every packet that is not a fused step / Monte Carlo trial launch (unpack, the
+ * list build chain, pack, prologues) and of a run's final launch: the launches whose outputs are read from OUTSIDE the
+ * queue.  A consumer that has skipped chx_steps_join then reads those outputs before they are written EVERY time; the
+ * Python layer completes the detector by filling such outputs with NaN / -1 when it allocates them (chiron_amd.ops.fresh).
+ * Results are unchanged (tests/test_gpu_step_queue.py runs the trajectory hashes under it; profiles/r06_queue_debug.md holds the
+ * whole GPU suite's log under CHX_QUEUE_DEBUG=250).  delay_us < 0 only reads.  Returns the previous delay.
+ * chx_queue_debug_spins: idle packets dispatched so far (a test that sees 0 did not run in debug mode). */
+int chx_queue_debug(int32_t delay_us);
+int64_t chx_queue_debug_spins(void);
 
 /* How chx_langevin_fused_run waits when its launch queue is full: sleep_ns > 0 -- nanosleep that long between polls
  * (default 5000, or CHX_POLL_SLEEP_NS; the queue refills in bursts of window / 2 launches); 0 -- busy-wait

@@ -28,7 +28,7 @@ torch.cuda.synchronize()
 h = hashlib.sha256(state.positions.cpu().numpy().tobytes() + state.velocities.cpu().numpy().tobytes()
                    + nbr.ref_positions.cpu().numpy().tobytes()).hexdigest()
 print("RESULT " + json.dumps({"hash": h, "rebuilds": rebuilds, "queue": ops.step_queue_info(),
-                              "carried": getattr(integ, "n_carried_runs", 0)}))
+                              "carried": getattr(integ, "n_carried_runs", 0), "idle_packets": ops.queue_debug_spins()}))
 """ % ROOT
 
 
@@ -168,3 +168,62 @@ def test_a_run_state_dies_with_its_call():
             assert not alive, (steps, len(alive))
     finally:
         gc.enable()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The queue's debug mode (include/chx.h: chx_queue_debug; chiron_amd/ops.py: fresh): a missing join must fail EVERY time
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("workload,steps", [("c3", 1500)], ids=["c3-32768"])
+def test_debug_delays_do_not_change_a_bit(workload, steps):
+    """CHX_QUEUE_DEBUG=250: a 250 us idle packet in front of every launch whose output leaves the queue, poison in every
+    such output before it is written -- same hash as the plain run, and the idle packets were really dispatched."""
+    plain = _run({}, workload, steps)
+    slow = _run({"CHX_QUEUE_DEBUG": "250"}, workload, steps)
+    assert slow["hash"] == plain["hash"] and slow["rebuilds"] == plain["rebuilds"], (slow, plain)
+    # (five runs with a gate and a final launch each, a handful of rebuild chains of six launches)
+    assert plain["idle_packets"] == 0 and slow["idle_packets"] >= 10 + 6 * slow["rebuilds"], (slow, plain)
+
+
+@pytest.mark.parametrize("path", ["verlet", "all_pairs"])
+def test_a_missing_join_reads_poison_every_time(path):
+    """The bug class of round 5 (a run() that returned without joining the step queue and passed on timing), made
+    deterministic: with the debug mode on, a run() whose final join is deliberately skipped (test hook) hands back a state
+    that still holds the poison -- ten times out of ten -- and the same run() with its join hands back finite numbers."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from chiron_amd import neighbors, ops, unit as u
+
+    if path == "verlet":
+        fluid, pot, state, thermo, lst, integ = bench.make_system("c3", 300.0, 32, "cell")
+    else:
+        fluid, pot, state, thermo, _, integ = bench.make_system("c2", 300.0, 32, "cell")
+        lst = neighbors.PairListNsqrd(neighbors.OrthogonalPeriodicSpace(), cutoff=3.0 * bench.SIGMA_NM * u.nanometer)
+    if not ops.step_queue_on():
+        pytest.skip("the step queue is switched off (CHX_AQL=0)")
+    integ.list_carry = False
+    state, lst = integ.run(state, thermo, number_of_steps=10, nbr_list=lst)  # velocities, buffers, code paths warm
+    old = ops.queue_debug(300)
+    try:
+        spins0 = ops.queue_debug_spins()
+        caught = 0
+        for _ in range(10):
+            ops._debug_skip_final_join = 1
+            try:
+                out, lst2 = integ.run(state, thermo, number_of_steps=12, nbr_list=lst)
+                # the consumer's view, on the torch stream, without a join: the run's final launch has not written yet
+                poisoned = ops.is_poison(out.positions) or ops.is_poison(out.velocities)
+            finally:
+                ops._debug_skip_final_join = 0
+                ops.steps_join()  # (the join the run() skipped)
+                torch.cuda.synchronize()
+            caught += int(poisoned)
+            # ... and behind the join the same arrays hold the run's result
+            assert torch.isfinite(out.positions).all() and torch.isfinite(out.velocities).all()
+        assert caught == 10, f"the missing join was caught {caught} times out of 10"
+        assert ops.queue_debug_spins() > spins0
+        # the intact run(): never poison
+        for _ in range(3):
+            out, lst2 = integ.run(state, thermo, number_of_steps=12, nbr_list=lst)
+            assert not ops.is_poison(out.positions) and not ops.is_poison(out.velocities)
+    finally:
+        ops.queue_debug(old)

@@ -350,7 +350,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/chx.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
-    assert lib.chx_version() == _lib.ABI_VERSION == 4
+    assert lib.chx_version() == _lib.ABI_VERSION == 5
     # struct layouts agree with the header (x86-64 SysV)
     assert ctypes.sizeof(_lib.Box) == 16
     assert ctypes.sizeof(_lib.LangevinParams) == 272 == lib.chx_sizeof_langevin_t()
@@ -537,7 +537,7 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
     p.n = 0
     failed(lib.chx_mc_displace_chunk(ctypes.byref(p), 0, 1, None), "n <= 0")
     # the threshold helper and the grid helper are pure host functions
-    assert lib.chx_version() == _lib.ABI_VERSION == 4
+    assert lib.chx_version() == _lib.ABI_VERSION == 5
 
 
 def test_sampler_state_copy_with_and_box_token():
