@@ -133,6 +133,21 @@ class BuildRiders(C.Structure):
     ]
 
 
+class BatchItem(C.Structure):
+    """include/chx.h: chx_batch_item_t"""
+
+    _fields_ = [
+        ("p", C.POINTER(LangevinParams)),
+        ("x_even", C.c_void_p),
+        ("x_odd", C.c_void_p),
+        ("step0", C.c_int64),
+        ("n_steps", C.c_int32),
+        ("kicks_first", C.c_int32),
+        ("n_enqueued", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
 BUILD_STATUS_WORDS = 8  # include/chx.h: chx_nl_build_cell_fl, status8
 
 _P = C.c_void_p
@@ -193,6 +208,9 @@ SIGNATURES = {
     "chx_langevin_resume": (C.c_int, [C.POINTER(LangevinParams), _P]),
     "chx_langevin_fused_chunk": (C.c_int, [C.POINTER(LangevinParams), _P, _P, _I64, _I32, _I32, _I32, _P]),
     "chx_langevin_fused_run": (C.c_int, [C.POINTER(LangevinParams), _P, _P, _I64, _I32, _I32, _I32, C.POINTER(C.c_int32), _P]),
+    "chx_langevin_batch_run": (C.c_int, [C.POINTER(BatchItem), _I32, _I32, _P]),
+    "chx_langevin_batch_kick": (C.c_int, [C.POINTER(BatchItem), _I32, _P]),
+    "chx_sizeof_batch_item_t": (_I64, []),
     "chx_set_poll_sleep_ns": (_I64, [_I64]),
     "chx_poll_stats": (C.c_int, [C.POINTER(_I64), _I32]),
     "chx_steps_join": (C.c_int, [_P]),
@@ -269,7 +287,7 @@ def load() -> C.CDLL:
         raise ChxError(f"libchx ABI version {lib.chx_version()} != {ABI_VERSION} (include/chx.h: CHX_ABI_VERSION)")
     # the structs are mirrored by hand above: a layout drift would corrupt kernel arguments silently
     for name, mirror in (("chx_sizeof_langevin_t", LangevinParams), ("chx_sizeof_mc_t", McParams),
-                         ("chx_sizeof_build_riders_t", BuildRiders)):
+                         ("chx_sizeof_build_riders_t", BuildRiders), ("chx_sizeof_batch_item_t", BatchItem)):
         if getattr(lib, name)() != C.sizeof(mirror):
             raise ChxError(f"{name}() = {getattr(lib, name)()} but ctypes mirror {mirror.__name__} is {C.sizeof(mirror)} bytes")
     # a library built from other sources than the ones beside it is refused (CHX_LIB: deliberate A/B runs).  A

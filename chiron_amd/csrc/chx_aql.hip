@@ -152,7 +152,7 @@ struct Queue {
 };
 
 constexpr uint32_t QSIZE = 1024;  // packets asked for; the launch window keeps ~a dozen outstanding
-constexpr size_t SLOT = 1024;     // bytes per kernarg slot (the step kernel's block: 320; any kernel's + 256 implicit)
+constexpr size_t SLOT = 4096;     // bytes per kernarg slot (the step kernel's block: 320; a batched step's: 8 x 328; any kernel's + 256 implicit)
 
 std::mutex g_mu;
 int g_state = 0;  // 0 untried, 1 on, -1 off
@@ -623,7 +623,7 @@ void debug_spin_packet(Queue* Q, hipStream_t st) {
 }
 
 int dispatch_core(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, const void* kernarg, size_t nbytes, int release,
-                  bool is_step = false, bool final_packet = false, bool hot_acquire = false) {
+                  bool is_step = false, bool final_packet = false, bool hot_acquire = false, bool beside_previous = false) {
   // (the segment may be shorter than the caller's block -- trailing padding of a by-value struct -- never longer)
   const size_t seg = k->kernarg_size;
   if (nbytes + 256 > SLOT || nbytes > seg + 8) {
@@ -643,7 +643,7 @@ int dispatch_core(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, con
   if (!Q->open) open_gate(Q, st);
   if (g_debug_delay_us > 0 && (Q->fresh || !(is_step || hot_acquire) || final_packet)) debug_spin_packet(Q, st);
   // (a step packet behind the list build's summary launch starts beside it: chx_aql_allow_overlap)
-  const bool barrier = !(is_step && Q->overlap_ok);
+  const bool barrier = !(is_step && (Q->overlap_ok || (beside_previous && !Q->fresh)));
   Q->overlap_ok = false;
   if (Q->fresh) {  // first packet since the last join
     acquire = Q->fresh_system ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
@@ -725,6 +725,16 @@ int chx_aql_dispatch(hipStream_t st, const AqlKernel* k, unsigned blocks, const 
   }
   return dispatch_core(st, k, dim3(blocks), dim3(256), kernarg, k->kernarg_size, release_agent ? HSA_FENCE_SCOPE_AGENT : chx_aql_hot_release(),
                        true, final_packet);
+}
+
+int chx_aql_dispatch_grid(hipStream_t st, const AqlKernel* k, dim3 grid, const void* kernarg, size_t nbytes, bool release_agent,
+                          bool beside_previous) {
+  if (nbytes < k->kernarg_size) {
+    chx_set_error("step queue: argument block of %zu bytes is shorter than the kernel's %u", nbytes, k->kernarg_size);
+    return CHX_ERR_INVALID;
+  }
+  return dispatch_core(st, k, grid, dim3(256), kernarg, k->kernarg_size, release_agent ? HSA_FENCE_SCOPE_AGENT : chx_aql_hot_release(),
+                       true, false, false, beside_previous);
 }
 
 void chx_aql_allow_overlap(hipStream_t st) {

@@ -70,6 +70,8 @@ static inline int chx_lj_fl_blocks(int n, int g) { return (int)(((int64_t)n * g 
 int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, int64_t step0,
                         int n_steps, int kicks_first, int do_aoa, hipStream_t st, int window = 0,
                         int32_t* n_enqueued = nullptr);
+// the same for several replicas at once, one dispatch per step (chx_launch_window.hip)
+int chx_launch_lj_steps_batch(chx_batch_item_t* items, int n_items, int do_aoa, int window, hipStream_t st);
 int chx_launch_lj_allpairs(const float* x, int stride, int n, chx_box_t box, float sigma,
                            float epsilon, float cutoff, float* f3, float* energy, double* ws,
                            int32_t* ctrl, hipStream_t st);

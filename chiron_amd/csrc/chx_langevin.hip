@@ -336,6 +336,49 @@ extern "C" int chx_langevin_fused_run(const chx_langevin_t* p, float* x_even, fl
   return chx_check_launch("chx_langevin_fused_run");
 }
 
+static int validate_batch(chx_batch_item_t* items, int32_t n_items, bool kick, const char* who) {
+  CHX_REQUIRE(items && n_items >= 1, "no items");
+  for (int r = 0; r < n_items; ++r) {
+    const chx_batch_item_t& it = items[r];
+    const chx_langevin_t* p = it.p;
+    CHX_REQUIRE(p, "null params");
+    CHX_REQUIRE(p->n >= 1, "n < 1");
+    CHX_REQUIRE(it.x_even && it.x_odd && it.x_even != it.x_odd, "need two distinct position buffers");
+    CHX_REQUIRE(p->v && p->mass && p->ctrl, "null pointer");
+    CHX_REQUIRE(p->fl && p->deg && p->fl_chunks >= 1, "the batched launch needs the force-list path");
+    CHX_REQUIRE(p->host_ctrl, "the batched launch publishes to host_ctrl");
+    CHX_REQUIRE(!p->snap4, "the batched launch does not take a decoupled force list (snap4)");
+    CHX_REQUIRE(p->g == 1 || p->g == 2 || p->g == 4 || p->g == 8, "lanes per particle must be 1, 2, 4 or 8");
+    CHX_REQUIRE(!p->box.periodic || (p->box.lx > 0 && p->box.ly > 0 && p->box.lz > 0), "box lengths must be > 0");
+    CHX_REQUIRE(kick || it.n_steps >= 0, "n_steps < 0");
+    CHX_REQUIRE(it.kicks_first >= 0 && it.kicks_first <= 2, "kicks_first must be 0, 1 or 2");
+    CHX_REQUIRE(it.step0 >= 0 && it.step0 + (kick ? 1 : it.n_steps) < (1ll << 31) - 1, "step index out of range");
+    for (int q = 0; q < r; ++q) CHX_REQUIRE(items[q].p->ctrl != p->ctrl, "two items share a control block");
+  }
+  (void)who;
+  return CHX_OK;
+}
+
+extern "C" int64_t chx_sizeof_batch_item_t(void) { return (int64_t)sizeof(chx_batch_item_t); }
+
+extern "C" int chx_langevin_batch_run(chx_batch_item_t* items, int32_t n_items, int32_t window, chx_stream_t stream) {
+  int rc = validate_batch(items, n_items, false, "chx_langevin_batch_run");
+  if (rc != CHX_OK) return rc;
+  CHX_REQUIRE(window >= 1, "window < 1");
+  rc = chx_launch_lj_steps_batch(items, n_items, 1, window, chx_stream_steps(stream));
+  if (rc != CHX_OK) return rc;
+  return chx_check_launch("chx_langevin_batch_run");
+}
+
+extern "C" int chx_langevin_batch_kick(chx_batch_item_t* items, int32_t n_items, chx_stream_t stream) {
+  int rc = validate_batch(items, n_items, true, "chx_langevin_batch_kick");
+  if (rc != CHX_OK) return rc;
+  for (int r = 0; r < n_items; ++r) items[r].n_steps = 1;
+  rc = chx_launch_lj_steps_batch(items, n_items, 0, 0, chx_stream_steps(stream));
+  if (rc != CHX_OK) return rc;
+  return chx_check_launch("chx_langevin_batch_kick");
+}
+
 extern "C" int chx_langevin_resume(const chx_langevin_t* p, chx_stream_t stream) {
   int rc = validate_langevin(p);
   if (rc != CHX_OK) return rc;

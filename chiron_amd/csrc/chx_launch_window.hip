@@ -68,14 +68,8 @@ static PollPolicy poll_policy() {
   return PollPolicy{ns};
 }
 
-// launch i of the chunk reads (i even ? x_even : x_odd) and writes the other buffer
-// window > 0 (needs p->host_ctrl, readable by the host at the same address): launch step s only once fewer than
-// `window` earlier launches are still waiting to begin, and stop at the first step the halt word rules out;
-// *n_enqueued = launches made.  What the host polls is the copy of the control block every launch stores into
-// host_ctrl when it begins (word 0 = its step index, word 3 = the halt word).
-int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, int64_t step0,
-                        int n_steps, int kicks_first, int do_aoa, hipStream_t st, int window, int32_t* n_enqueued) {
-  if (n_enqueued) *n_enqueued = 0;
+// the launch-invariant part of a replica's argument block (x_cur / x_next are set per launch)
+static StepArgs make_step_args(const chx_langevin_t* p, int do_aoa, bool& use_inner) {
   StepArgs a;
   a.n = p->n;
   a.v = p->v;
@@ -99,7 +93,7 @@ int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, in
   a.noise_step0 = p->noise_step0;
   a.ctrl = p->ctrl;
   a.host_ctrl = p->fl != nullptr ? p->host_ctrl : nullptr;
-  const bool use_inner = p->fl_inner && p->deg_inner && p->prune_every > 0 && p->inner_skin > 0.f;  // (ref_inner4: unused)
+  use_inner = p->fl_inner && p->deg_inner && p->prune_every > 0 && p->inner_skin > 0.f;  // (ref_inner4: unused)
   a.fli = use_inner ? p->fl_inner : nullptr;
   a.degi = use_inner ? p->deg_inner : nullptr;
   {
@@ -119,6 +113,19 @@ int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, in
   a.x3_out = do_aoa ? nullptr : p->final_x3;
   a.v3_out = do_aoa ? nullptr : p->final_v3;
   a.ref3_out = do_aoa ? nullptr : p->final_ref3;
+  return a;
+}
+
+// launch i of the chunk reads (i even ? x_even : x_odd) and writes the other buffer
+// window > 0 (needs p->host_ctrl, readable by the host at the same address): launch step s only once fewer than
+// `window` earlier launches are still waiting to begin, and stop at the first step the halt word rules out;
+// *n_enqueued = launches made.  What the host polls is the copy of the control block every launch stores into
+// host_ctrl when it begins (word 0 = its step index, word 3 = the halt word).
+int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, int64_t step0,
+                        int n_steps, int kicks_first, int do_aoa, hipStream_t st, int window, int32_t* n_enqueued) {
+  if (n_enqueued) *n_enqueued = 0;
+  bool use_inner = false;
+  StepArgs a = make_step_args(p, do_aoa, use_inner);
   const bool throttle = window > 0 && a.host_ctrl != nullptr;
   const PollPolicy poll = poll_policy();
   for (int i = 0; i < n_steps; ++i) {
@@ -190,3 +197,119 @@ int chx_launch_lj_steps(const chx_langevin_t* p, float* x_even, float* x_odd, in
   return CHX_OK;
 }
 
+
+
+// ---------------------------------------------------------------------------
+// Several replicas, one launch per step (include/chx.h: chx_langevin_batch_run / chx_langevin_batch_kick).
+// Launch i of the call advances every replica r with i < n_steps[r] by one step -- replica r's step step0[r] + i, from
+// (i even ? x_even[r] : x_odd[r]) -- in ONE dispatch (k_lj_step_batch; one packet per class of launch when the replicas'
+// launches differ in kind, side by side).  The window is counted on the first participating replica's control block (all
+// items of a launch begin together); the halt words of ALL participants are watched, and the call returns at the first
+// one seen: that replica's list has to be rebuilt behind the no-ops it has queued, the others simply continue with the
+// next call.
+// ---------------------------------------------------------------------------
+int chx_launch_lj_steps_batch(chx_batch_item_t* items, int n_items, int do_aoa, int window, hipStream_t st) {
+  constexpr int MAXR = 64;
+  if (n_items < 1 || n_items > MAXR) {
+    chx_set_error("chx_langevin_batch: %d replicas (1 .. %d)", n_items, MAXR);
+    return CHX_ERR_INVALID;
+  }
+  StepArgs args[MAXR];
+  bool inner[MAXR];
+  int max_steps = 0;
+  for (int r = 0; r < n_items; ++r) {
+    args[r] = make_step_args(items[r].p, do_aoa, inner[r]);
+    items[r].n_enqueued = 0;
+    max_steps = items[r].n_steps > max_steps ? items[r].n_steps : max_steps;
+  }
+  const bool throttle = do_aoa && window > 0;
+  const PollPolicy poll = poll_policy();
+  auto halted = [&](int i) {  // has some participant of launch i been ruled out by its halt word?
+    for (int r = 0; r < n_items; ++r) {
+      if (i >= items[r].n_steps) continue;
+      const volatile int32_t* hc = args[r].host_ctrl;
+      if ((long long)hc[3] <= items[r].step0 + i) return true;
+    }
+    return false;
+  };
+  for (int i = 0; i < max_steps; ++i) {
+    if (throttle) {
+      if (halted(i)) return CHX_OK;
+      int lead = -1;
+      for (int r = 0; r < n_items && lead < 0; ++r)
+        if (i < items[r].n_steps) lead = r;
+      const volatile int32_t* hc = args[lead].host_ctrl;
+      const long long s = items[lead].step0 + i;
+      if (s - hc[0] > window) {
+        const int low = poll.sleep_ns > 0 ? window - window / 2 : window;
+        int last = hc[0];
+        bool timing = false;
+        timespec t0{};
+        if (poll.sleep_ns > 0) __atomic_fetch_add(&g_poll_stats[0], 1, __ATOMIC_RELAXED);
+        for (unsigned spins = 0;; ++spins) {
+          if (halted(i)) return CHX_OK;
+          const int begun = hc[0];
+          if (s - begun <= low) break;
+          if (poll.sleep_ns > 0) {
+            const timespec nap = {0, poll.sleep_ns};
+            nanosleep(&nap, nullptr);
+            __atomic_fetch_add(&g_poll_stats[1], 1, __ATOMIC_RELAXED);
+          } else {
+            cpu_relax();
+          }
+          if (poll.sleep_ns > 0 || (spins & 0xFFFF) == 0xFFFF) {
+            timespec t1;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if (begun != last || !timing) last = begun, t0 = t1, timing = true;
+            else if (t1.tv_sec - t0.tv_sec > 60) {
+              chx_set_error("chx_langevin_batch_run: no step launch has begun for 60 s (step %lld, newest begun %d)", s, begun);
+              return CHX_ERR_LAUNCH;
+            }
+          }
+        }
+      }
+    }
+    // this launch's items, sorted into classes (lanes per particle, hot, refresh of the inner list)
+    BatchItem pack[CHX_BATCH_MAX];
+    bool taken[MAXR];
+    for (int r = 0; r < n_items; ++r) taken[r] = i >= items[r].n_steps;
+    bool first_packet = true;
+    for (;;) {
+      int count = 0, cg = 0;
+      bool chot = false, cprune = false;
+      for (int r = 0; r < n_items && count < CHX_BATCH_MAX; ++r) {
+        if (taken[r]) continue;
+        const chx_langevin_t* p = items[r].p;
+        const long long step = items[r].step0 + i;
+        const int nk = i == 0 ? items[r].kicks_first : 2;
+        const bool since = inner[r] && (step >= p->prune_phase);
+        const bool prune = since && ((step - p->prune_phase) % p->prune_every == 0);
+        const int epoch = since ? (int)((step - p->prune_phase) / p->prune_every) : -1;
+        StepArgs& a = args[r];
+        const bool hot = nk == 2 && do_aoa && a.wrap && a.box.periodic && a.ref4 && a.fli && a.perm && !a.noise;
+        if (count == 0) cg = p->g, chot = hot, cprune = prune;
+        else if (p->g != cg || hot != chot || prune != cprune) continue;
+        taken[r] = true;
+        a.x_cur = reinterpret_cast<const float4*>((i & 1) ? items[r].x_odd : items[r].x_even);
+        a.x_next = (i & 1) ? items[r].x_even : items[r].x_odd;
+        BatchItem& it = pack[count++];
+        it.a = a;
+        it.step = step;
+        const bool spec_inner = a.fli != nullptr && !prune && epoch >= 0;  // (as launch_step_g chooses)
+        it.sfl = spec_inner ? a.fli : a.fl;
+        it.sdeg = spec_inner ? a.degi : a.deg;
+        it.nblocks = (unsigned)(((int64_t)a.n * p->g + 255) / 256);
+        it.epoch = epoch;
+        it.n_kicks = nk;
+        it.do_aoa = do_aoa;
+      }
+      if (count == 0) break;
+      const int rc = chx_launch_step_batch(pack, count, cg, chot, cprune, !first_packet, st);
+      if (rc != CHX_OK) return rc;
+      first_packet = false;
+    }
+    for (int r = 0; r < n_items; ++r)
+      if (i < items[r].n_steps) items[r].n_enqueued = i + 1;
+  }
+  return CHX_OK;
+}

@@ -457,9 +457,9 @@ __device__ __forceinline__ bool step_epilogue(const StepArgs& a, const StepParti
 // "inner list is stale" words hold the epoch in which they were raised, so a refresh invalidates
 // them without anybody having to clear a word another block may be reading.
 template <int G, bool HOT, bool PRUNE, bool DEFER>
-__global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long step, int epoch, int n_lead,
-                                                 unsigned nblocks, const float4* x_lead, const uint32_t* sfl,
-                                                 const int32_t* sdeg, StepArgs a, int n_kicks, int do_aoa) {
+__device__ __forceinline__ void lj_step_body(int32_t* ctrl_first, long long step, int epoch, int n_lead, unsigned nblocks,
+                                             const float4* x_lead, const uint32_t* sfl, const int32_t* sdeg,
+                                             const StepArgs& a, int n_kicks, int do_aoa) {
   // (Leading scalar arguments are the ones the dispatcher preloads into SGPRs: the control block, the step
   // index and everything the FIRST vector loads need -- particle count, grid size (gridDim would be a fetch
   // from the dispatch packet), the position buffer and the list this launch most probably walks (sfl, sdeg:
@@ -580,6 +580,32 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
       if (a.host_ctrl != nullptr) __hip_atomic_store(&a.host_ctrl[w], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+}
+
+// One replica, one launch per step: the arguments the first loads need lead the block (see lj_step_body).
+template <int G, bool HOT, bool PRUNE, bool DEFER>
+__global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long step, int epoch, int n_lead,
+                                                 unsigned nblocks, const float4* x_lead, const uint32_t* sfl,
+                                                 const int32_t* sdeg, StepArgs a, int n_kicks, int do_aoa) {
+  lj_step_body<G, HOT, PRUNE, DEFER>(ctrl_first, step, epoch, n_lead, nblocks, x_lead, sfl, sdeg, a, n_kicks, do_aoa);
+}
+
+// SEVERAL replicas, one launch per step (include/chx.h: chx_langevin_batch_run; chiron/multistate.py:497-510 is a serial
+// loop over replicas).  A step of an N = 32 768 replica is a latency chain that fills a quarter of the card; eight of
+// them in one grid are a throughput problem the size of N = 262 144.  blockIdx.y picks the replica's item from the
+// argument block (a scalar load with a uniform offset: the block is never copied), blockIdx.x is the replica's block;
+// everything else is lj_step_body -- the same instructions in the same order as the one-replica launch, so a replica's
+// trajectory does not depend on whether it is stepped alone or in a batch.  The items of one packet share the
+// instantiation (HOT / PRUNE); a step whose replicas fall into several classes -- a refresh of the inner list here, a
+// first step there -- goes out as one packet per class, the later ones without the barrier bit: they run side by side.
+// Each replica has its own control block: a replica whose skin check has fired turns into a no-op (its halt word) while
+// the others carry on.
+template <int G, bool HOT, bool PRUNE>
+__global__ __launch_bounds__(256) void k_lj_step_batch(BatchArgs b) {
+  const BatchItem& it = b.item[blockIdx.y];
+  if (blockIdx.x >= it.nblocks) return;  // (replicas of different sizes share the grid's x extent)
+  lj_step_body<G, HOT, PRUNE, false>(it.a.ctrl, it.step, it.epoch, it.a.n, it.nblocks, it.a.x_cur, it.sfl, it.sdeg, it.a, it.n_kicks,
+                                     it.do_aoa);
 }
 
 // ---------------------------------------------------------------------------
@@ -836,6 +862,64 @@ int chx_launch_step(const StepArgs& a, int g, long long step, int n_kicks, int d
     default:
       chx_set_error("chx_launch_step: unsupported g = %d", g);
       return CHX_ERR_INVALID;
+  }
+}
+
+// one batched packet (chx_step.h)
+template <int G>
+static int launch_step_batch_g(const BatchItem* items, int count, bool hot, bool prune, bool beside, hipStream_t st) {
+  alignas(16) static thread_local BatchArgs ba;
+  unsigned maxb = 0;
+  for (int i = 0; i < count; ++i) {
+    ba.item[i] = items[i];
+    maxb = items[i].nblocks > maxb ? items[i].nblocks : maxb;
+  }
+  for (int i = count; i < CHX_BATCH_MAX; ++i) ba.item[i].nblocks = 0;  // (never addressed: the grid's y extent is `count`)
+  static const bool dbg = getenv("CHX_DEBUG_SYNC") != nullptr;
+  if (dbg) fprintf(stderr, "[chx] k_lj_step_batch<%d, %d, %d> x %d items, first step %lld\n", G, (int)hot, (int)prune, count, items[0].step);
+  if (chx_aql_on()) {
+    static const AqlKernel absent{};
+    static std::atomic<const AqlKernel*> table[2][2];
+    const int ih = hot ? 1 : 0, ip = prune ? 1 : 0;
+    const AqlKernel* k = table[ih][ip].load(std::memory_order_acquire);
+    if (k == nullptr) {
+      char name[96];
+      snprintf(name, sizeof(name), "void k_lj_step_batch<%d, %s, %s>", G, hot ? "true" : "false", prune ? "true" : "false");
+      k = chx_aql_kernel(name);
+      if (k == nullptr) k = &absent;
+      table[ih][ip].store(k, std::memory_order_release);
+    }
+    if (k == &absent) {
+      chx_set_error("chx_launch_step_batch: libchx_step.hsaco holds no k_lj_step_batch<%d, %d, %d>", G, ih, ip);
+      return CHX_ERR_LAUNCH;
+    }
+    // (fences as for the one-replica launch: a packet of steady-state items leaves write-through stores only)
+    return chx_aql_dispatch_grid(st, k, dim3(maxb, (unsigned)count), &ba, sizeof(ba), !(hot && !prune), beside);
+  }
+#define CHX_LAUNCH_BATCH(HOT_, PRUNE_) \
+  hipLaunchKernelGGL((k_lj_step_batch<G, HOT_, PRUNE_>), dim3(maxb, (unsigned)count), dim3(256), 0, st, ba)
+  if (hot && prune) CHX_LAUNCH_BATCH(true, true);
+  else if (hot) CHX_LAUNCH_BATCH(true, false);
+  else if (prune) CHX_LAUNCH_BATCH(false, true);
+  else CHX_LAUNCH_BATCH(false, false);
+#undef CHX_LAUNCH_BATCH
+  if (dbg) (void)hipStreamSynchronize(st);
+  return CHX_OK;
+}
+
+int chx_launch_step_batch(const BatchItem* items, int count, int g, bool hot, bool prune, bool beside_previous, hipStream_t st) {
+  if (count < 1 || count > CHX_BATCH_MAX) {
+    chx_set_error("chx_launch_step_batch: %d items (1 .. %d)", count, CHX_BATCH_MAX);
+    return CHX_ERR_INVALID;
+  }
+  switch (g) {
+    case 1: return launch_step_batch_g<1>(items, count, hot, prune, beside_previous, st);
+    case 2: return launch_step_batch_g<2>(items, count, hot, prune, beside_previous, st);
+    case 4: return launch_step_batch_g<4>(items, count, hot, prune, beside_previous, st);
+    case 8: return launch_step_batch_g<8>(items, count, hot, prune, beside_previous, st);
+    default:
+      chx_set_error("chx_launch_step_batch: unsupported g = %d (1, 2, 4, 8)", g);
+      return CHX_ERR_UNSUPPORTED;
   }
 }
 

@@ -54,3 +54,23 @@ struct StepArgs {
 int chx_launch_step(const StepArgs& a, int g, long long step, int n_kicks, int do_aoa, bool prune, int epoch, hipStream_t st);
 // The same without a neighbor list: all-pairs force + BAOAB (k_ap_step).
 void chx_launch_ap_step(const StepArgs& a, long long step, int n_kicks, int do_aoa, int use_cutoff, hipStream_t st);
+
+// ---- several replicas in one launch (k_lj_step_batch; include/chx.h: chx_langevin_batch_run) ----
+#define CHX_BATCH_MAX 8   // items per packet; more replicas than that go out as several packets side by side
+struct BatchItem {
+  StepArgs a;
+  long long step;
+  const uint32_t* sfl;   // the list this replica's launch most probably walks (lj_step_body's speculative loads)
+  const int32_t* sdeg;
+  unsigned nblocks;
+  int epoch;
+  int n_kicks;
+  int do_aoa;
+};
+struct BatchArgs {
+  BatchItem item[CHX_BATCH_MAX];
+};
+// One packet: `count` items of ONE class (all hot or none, all refreshing their inner list or none, the same lanes per
+// particle g).  `beside_previous`: the packet may run beside the one dispatched just before it (the other classes of the
+// same step); the first packet of a step waits for everything before it.
+int chx_launch_step_batch(const BatchItem* items, int count, int g, bool hot, bool prune, bool beside_previous, hipStream_t st);

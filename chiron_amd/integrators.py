@@ -195,6 +195,56 @@ class LangevinIntegrator:
     ) -> Tuple[SamplerState, object]:
         """chiron/integrators.py:75-218.  ``noise`` (number_of_steps, N, 3) optionally
         replaces the device PRNG in the O step (deterministic parity tests)."""
+        ctx = self._begin(sampler_state, thermodynamic_state, number_of_steps, nbr_list, progress_bar, noise)
+        st, potential, mode = ctx.st, ctx.potential, ctx.mode
+
+        bar = None
+        if progress_bar:
+            try:
+                from tqdm import tqdm
+
+                bar = tqdm(total=number_of_steps)
+            except Exception:  # pragma: no cover
+                bar = None
+        has_reporter = hasattr(self, "reporter") and self.reporter is not None
+        wants_reports = has_reporter or self.save_traj_in_memory
+        base = self._move_iteration * number_of_steps
+
+        def next_stop(step: int) -> int:
+            """First step count at which the host has to look at the state again."""
+            if not wants_reports:
+                return number_of_steps
+            to_report = (-(step + base)) % self.report_interval  # steps until the next reporting step
+            return min(number_of_steps, step + to_report + 1)
+
+        done = 0
+        while done < number_of_steps:
+            stop = next_stop(done)
+            before = done
+            done = st.advance_to(done, stop, final=(stop == number_of_steps))
+            if bar is not None:
+                bar.update(done - before)
+            last = done - 1
+            elapsed_step = last + base
+            if done == stop and elapsed_step % self.report_interval == 0:  # :197-205
+                if has_reporter:
+                    # (carried-over list: the list the steps run on is the one that is valid for these positions; the
+                    # caller's list is brought up to the reference's last rebuild when the run ends)
+                    self._report(st.positions_user(), potential, st.report_list(), last, self._move_iteration, elapsed_step)
+                if self.save_traj_in_memory:
+                    self.traj.append(st.positions_user())
+        if bar is not None:
+            bar.close()
+        if number_of_steps > 0:
+            st.final_kick(number_of_steps)
+        elif mode == "fused":
+            st._settle()
+        return self._end(ctx)
+
+    def _begin(self, sampler_state, thermodynamic_state, number_of_steps, nbr_list, progress_bar=False, noise=None,
+               allow_carry: bool = True) -> "_RunContext":
+        """Everything of ``run()`` in front of its first step: velocity rules, key, the list build of
+        chiron/integrators.py:169 (enqueued first), the device-resident run state.  ``run_batch`` calls it once per replica."""
         NeighborListNsqrd, PairListNsqrd, LJPotential, get_list_of_mass, initialize_velocities = _MODS or _mods()
 
         potential = thermodynamic_state.potential
@@ -258,7 +308,9 @@ class LangevinIntegrator:
         # already; a run that has to draw them first packs behind the build instead.
         is_lj = isinstance(potential, LJPotential)
         spec0 = packed0 = False
-        carried = self._take_carry(sampler_state, nbr_list, number_of_steps) if is_lj else None
+        carried = self._take_carry(sampler_state, nbr_list, number_of_steps) if (is_lj and allow_carry) else None
+        if not allow_carry:
+            self._carry = None
         if carried is not None:
             # (no build: _RunState validates the carried force list against x0 on the device -- its pack launch rides on
             # the step queue with the steps, behind one gate)
@@ -328,25 +380,6 @@ class LangevinIntegrator:
         if spec0:
             st._unsettled = (nbr_list.ref_positions, v0, 0, 1)
 
-        bar = None
-        if progress_bar:
-            try:
-                from tqdm import tqdm
-
-                bar = tqdm(total=number_of_steps)
-            except Exception:  # pragma: no cover
-                bar = None
-        has_reporter = hasattr(self, "reporter") and self.reporter is not None
-        wants_reports = has_reporter or self.save_traj_in_memory
-        base = self._move_iteration * number_of_steps
-
-        def next_stop(step: int) -> int:
-            """First step count at which the host has to look at the state again."""
-            if not wants_reports:
-                return number_of_steps
-            to_report = (-(step + base)) % self.report_interval  # steps until the next reporting step
-            return min(number_of_steps, step + to_report + 1)
-
         # Host work that does not depend on the steps' results -- the key the reference returns (:216: the one its loop
         # ended with; the counter-based stream folds the step count in) and the copy of the box for the returned state --
         # is done while the last launches are still queued, right before the host waits for them (_enqueue_kick); behind
@@ -370,29 +403,11 @@ class LangevinIntegrator:
 
         st._host_tail = host_tail
         st._before_last_wait = before_last_wait
-        done = 0
-        while done < number_of_steps:
-            stop = next_stop(done)
-            before = done
-            done = st.advance_to(done, stop, final=(stop == number_of_steps))
-            if bar is not None:
-                bar.update(done - before)
-            last = done - 1
-            elapsed_step = last + base
-            if done == stop and elapsed_step % self.report_interval == 0:  # :197-205
-                if has_reporter:
-                    # (carried-over list: the list the steps run on is the one that is valid for these positions; the
-                    # caller's list is brought up to the reference's last rebuild when the run ends)
-                    self._report(st.positions_user(), potential, st.report_list(), last, self._move_iteration, elapsed_step)
-                if self.save_traj_in_memory:
-                    self.traj.append(st.positions_user())
-        if bar is not None:
-            bar.close()
-        if number_of_steps > 0:
-            st.final_kick(number_of_steps)
-        elif mode == "fused":
-            st._settle()
+        return _RunContext(st, potential, mode, nbr_list, sampler_state, number_of_steps, tail, host_tail)
 
+    def _end(self, ctx: "_RunContext") -> Tuple[SamplerState, object]:
+        """Everything of ``run()`` behind its last launch: the state that is returned (chiron/integrators.py:210-218)."""
+        st, mode, sampler_state, tail, host_tail = ctx.st, ctx.mode, ctx.sampler_state, ctx.tail, ctx.host_tail
         st.finish()
         if not tail:
             host_tail()
@@ -482,6 +497,169 @@ class LangevinIntegrator:
         if nbr_list is not None:
             d["box_vectors"] = nbr_list.box_vectors
         self.reporter.report(d)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Several replicas side by side: one launch per step for all of them
+# ---------------------------------------------------------------------------------------------------------------------
+def batch_applies(integrators, sampler_states, thermodynamic_states, nbr_lists, number_of_steps: int) -> bool:
+    """Can ``run_batch`` step these replicas in one launch per step?  LJ potential on a Verlet list on the GPU, fp32
+    positions, one integrator per replica (its device buffers live on it), nothing that wants to look at the state
+    between steps (reporter, trajectory in memory)."""
+    NeighborListNsqrd, _, LJPotential = (_MODS or _mods())[:3]
+    if number_of_steps <= 0 or len(integrators) < 2 or len({id(i) for i in integrators}) != len(integrators):
+        return False
+    if len({id(l) for l in nbr_lists}) != len(nbr_lists):
+        return False
+    for integ, ss, ts, nl in zip(integrators, sampler_states, thermodynamic_states, nbr_lists):
+        x = ss.positions
+        if not (isinstance(ts.potential, LJPotential) and isinstance(nl, NeighborListNsqrd) and isinstance(x, torch.Tensor)
+                and x.is_cuda and x.dtype == torch.float32 and x.device == sampler_states[0].positions.device):
+            return False
+        if (getattr(integ, "reporter", None) is not None) or integ.save_traj_in_memory:
+            return False
+    return True
+
+
+def run_batch(integrators, sampler_states, thermodynamic_states, number_of_steps: int, nbr_lists):
+    """``integrators[r].run(sampler_states[r], thermodynamic_states[r], number_of_steps, nbr_lists[r])`` for every r, with ONE
+    launch per step for all replicas instead of one per replica and step (include/chx.h: chx_langevin_batch_run).  The
+    reference's multistate loop is serial (chiron/multistate.py:497-510); a step of an N = 32 768 replica is a latency
+    chain that occupies a quarter of an MI355X, eight of them in one grid fill it.  Each replica keeps its own box,
+    temperature, key, lists, control block and rebuild schedule; its launches are the one-replica launches instruction for
+    instruction, so the returned states are bit-identical to the serial calls.  Falls back to those when the batch does
+    not apply (``batch_applies``).  Returns [(SamplerState, nbr_list)] in order."""
+    R = len(integrators)
+    if not (len(sampler_states) == len(thermodynamic_states) == len(nbr_lists) == R):
+        raise ValueError("run_batch: one integrator, sampler state, thermodynamic state and neighbor list per replica")
+    if not batch_applies(integrators, sampler_states, thermodynamic_states, nbr_lists, number_of_steps):
+        return [i.run(s, t, number_of_steps=number_of_steps, nbr_list=n)
+                for i, s, t, n in zip(integrators, sampler_states, thermodynamic_states, nbr_lists)]
+    ctxs = [i._begin(s, t, number_of_steps, n, allow_carry=False)
+            for i, s, t, n in zip(integrators, sampler_states, thermodynamic_states, nbr_lists)]
+    if any(c.mode != "fused" for c in ctxs):  # (cannot happen behind batch_applies)
+        raise RuntimeError("run_batch: a replica is not on the fused neighbor-list path")
+    _advance_batch([c.st for c in ctxs], number_of_steps, integrators[0].launch_window, integrators[0].chunk_size)
+    return [i._end(c) for i, c in zip(integrators, ctxs)]
+
+
+def _advance_batch(sts, n_steps: int, window: int, chunk: int) -> None:
+    """Steps [0, n_steps) and the trailing kick of every run state in ``sts``, batched.  The per-replica logic is
+    ``_RunState._advance_windowed`` / ``final_kick`` -- halt word, rebuild behind the queued no-ops, speculative builds
+    settled later -- with the launches of all replicas that are not waiting for a rebuild going out together; a replica
+    that has halted sits out until its list is rebuilt and then continues from its halt step (the replicas drift apart
+    by the launches they sat out and finish a few launches after each other)."""
+    R = len(sts)
+    enq = [0] * R        # first step not enqueued yet, per replica
+    kicked = [False] * R
+    window = max(1, int(window))
+    while True:
+        # ---- enqueue until every replica has its steps out, or a halt word is seen ----
+        saw_halt = False
+        while not saw_halt:
+            todo = [r for r in range(R) if enq[r] < n_steps]
+            if not todo:
+                break
+            entries = []
+            for r in todo:
+                st = sts[r]
+                even, odd = (st.x_a, st.x_b) if st.parity == 0 else (st.x_b, st.x_a)
+                entries.append((st.params, even, odd, enq[r], min(chunk, n_steps - enq[r]), st.kicks_next))
+            # (the last launches go out unthrottled, as in _advance_windowed)
+            tail_now = all(n_steps - enq[r] <= chunk for r in todo)
+            sent = ops.langevin_batch_run(entries, (1 << 20) if tail_now else window)
+            for r, e, k in zip(todo, entries, sent):
+                st = sts[r]
+                if k:
+                    st.parity ^= k & 1
+                    st.kicks_next = 2
+                    enq[r] += k
+                if k < e[4]:
+                    saw_halt = True
+            for st in sts:  # host work of the runs' END that does not depend on the steps, under the queued launches
+                work = getattr(st, "_host_tail", None)
+                if work is not None:
+                    st._host_tail = None
+                    work()
+            for r in todo:
+                st = sts[r]
+                pend = getattr(st, "_unsettled", None)
+                if pend is not None and enq[r] - pend[2] >= max(chunk, window + 1):
+                    if not st._settle():
+                        enq[r] = st._unsettled_step
+        all_out = all(e == n_steps for e in enq)
+        if all_out:
+            need = [r for r in range(R) if not kicked[r]]
+            if need:
+                entries = []
+                for r in need:
+                    st = sts[r]
+                    f32 = dict(dtype=torch.float32, device=st.dev)
+                    x3, v3 = ops.fresh((st.n, 3), **f32), ops.fresh((st.n, 3), **f32)
+                    st.params.final_x3, st.params.final_v3, st.params.final_ref3 = x3.data_ptr(), v3.data_ptr(), None
+                    st._final_state = (x3, v3)
+                    st._final_ref = None
+                    even, odd = (st.x_a, st.x_b) if st.parity == 0 else (st.x_b, st.x_a)
+                    entries.append((st.params, even, odd, n_steps, 1, 1))
+                try:
+                    ops.langevin_batch_kick(entries)
+                finally:
+                    for r in need:
+                        sts[r].params.final_x3 = sts[r].params.final_v3 = sts[r].params.final_ref3 = None
+                for r in need:
+                    kicked[r] = True
+                    st = sts[r]
+                    work, st._host_tail = getattr(st, "_host_tail", None), None
+                    if work is not None:
+                        work()
+                    pre, st._before_last_wait = st.__dict__.get("_before_last_wait"), None
+                    if pre is not None:
+                        pre()
+            if not _skip_join_hook():
+                ops.steps_join()
+            for st in sts:
+                st.integ._graveyard = None
+        # ---- what the device found: rejected speculative builds, halt words ----
+        again = False
+        for r, st in enumerate(sts):
+            halt_seen = int(st._gen.host[3]) <= enq[r]
+            if not (all_out or halt_seen):
+                continue
+            if not st._settle():
+                enq[r] = st._unsettled_step
+                kicked[r] = False
+                st._final_state = None
+                again = True
+                continue
+            halt = int(st._gen.host[3])
+            if halt > n_steps or halt > enq[r]:
+                continue
+            # the skin check fired while producing x_halt: steps < halt ran, what is queued behind is no-ops, and the
+            # rebuild goes out behind them (chiron/integrators.py:239-242)
+            st._final_state = None
+            kicked[r] = False
+            st.integ.noop_launches = getattr(st.integ, "noop_launches", 0) + max(0, enq[r] - halt)
+            st.parity = (st._gen_parity0 + halt - st._gen_step0) & 1
+            st._close_generation()
+            st._halt_rebuild(halt, speculative=True)
+            enq[r] = halt
+            again = True
+        if all_out and not again:
+            break
+    for st in sts:
+        st._kick_sent = False
+        st._close_generation()
+        st._retire_all()
+
+
+class _RunContext:
+    """What ``LangevinIntegrator._begin`` hands to the stepping loop and to ``_end``."""
+
+    __slots__ = ("st", "potential", "mode", "nbr_list", "sampler_state", "number_of_steps", "tail", "host_tail")
+
+    def __init__(self, st, potential, mode, nbr_list, sampler_state, number_of_steps, tail, host_tail):
+        self.st, self.potential, self.mode, self.nbr_list = st, potential, mode, nbr_list
+        self.sampler_state, self.number_of_steps, self.tail, self.host_tail = sampler_state, number_of_steps, tail, host_tail
 
 
 class _Decoupled:

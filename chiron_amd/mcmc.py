@@ -93,6 +93,26 @@ class LangevinDynamicsMove(MCMCMove):
         return updated_sampler_state, thermodynamic_state, updated_nbr_list
 
 
+def langevin_moves_update_batch(moves, sampler_states, thermodynamic_states, nbr_lists):
+    """``moves[r].update(sampler_states[r], thermodynamic_states[r], nbr_lists[r])`` for every r -- each a
+    ``LangevinDynamicsMove`` with the same number of steps -- through ``integrators.run_batch``: one launch per step for all
+    replicas (bit-identical states; serial calls when the batch does not apply).  Returns a list of the moves' return
+    triples."""
+    from .integrators import run_batch
+
+    steps = moves[0].number_of_moves
+    out = run_batch([m.integrator for m in moves], sampler_states, thermodynamic_states, steps, nbr_lists)
+    result = []
+    for m, (state, lst), thermo in zip(moves, out, thermodynamic_states):
+        m._number_of_attempts_made += steps
+        if m.save_traj_in_memory:
+            m.traj.append(m.integrator.traj)
+            m.integrator.traj = []
+        m._move_iteration += 1
+        result.append((state, thermo, lst))
+    return result
+
+
 class MCMove(MCMCMove):
     """chiron/mcmc.py:202-548"""
 
@@ -645,3 +665,39 @@ class MCMCSampler:
             if move.reporter is not None:
                 move.reporter.flush_buffer()
         return sampler_state, thermodynamic_state, nbr_list
+
+    @staticmethod
+    def batchable(samplers) -> bool:
+        """Are these samplers -- one per replica -- schedules of ``LangevinDynamicsMove`` only, the same number of moves
+        with the same step counts in each, no reporters?  Then ``run_batch`` can advance their replicas side by side."""
+        try:
+            schedules = [s.move.move_schedule for s in samplers]
+        except AttributeError:
+            return False
+        if len(samplers) < 2 or len({id(s) for s in samplers}) != len(samplers) or not schedules[0]:
+            return False
+        for sch in schedules:
+            if len(sch) != len(schedules[0]):
+                return False
+            for (_, mv), (_, ref) in zip(sch, schedules[0]):
+                if not (type(mv) is LangevinDynamicsMove and mv.reporter is None and not mv.save_traj_in_memory
+                        and mv.number_of_moves == ref.number_of_moves):
+                    return False
+        return True
+
+    @staticmethod
+    def run_batch(samplers, sampler_states, thermodynamic_states, n_iterations: int, nbr_lists):
+        """``samplers[r].run(sampler_states[r], thermodynamic_states[r], n_iterations, nbr_lists[r])`` for every r with the
+        replicas' Langevin moves stepped side by side (chiron/mcmc.py:1074-1155 per replica; same deep copies, same move
+        order).  The caller has checked ``batchable(samplers)``."""
+        sampler_states = [copy.deepcopy(s) for s in sampler_states]
+        thermodynamic_states = [copy.deepcopy(t) for t in thermodynamic_states]
+        nbr_lists = [copy.deepcopy(n) for n in nbr_lists]
+        for _ in range(n_iterations):
+            for k in range(len(samplers[0].move.move_schedule)):
+                moves = [s.move.move_schedule[k][1] for s in samplers]
+                out = langevin_moves_update_batch(moves, sampler_states, thermodynamic_states, nbr_lists)
+                sampler_states = [o[0] for o in out]
+                thermodynamic_states = [o[1] for o in out]
+                nbr_lists = [o[2] for o in out]
+        return list(zip(sampler_states, thermodynamic_states, nbr_lists))

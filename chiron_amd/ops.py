@@ -666,6 +666,32 @@ def langevin_fused_run(params: LangevinParams, x_even: torch.Tensor, x_odd: torc
     return out.value
 
 
+def _batch_items(entries):
+    """ctypes array of chx_batch_item_t for ``entries`` = [(params, x_even, x_odd, step0, n_steps, kicks_first), ...]"""
+    arr = (_lib.BatchItem * len(entries))()
+    for it, (params, x_even, x_odd, step0, n_steps, kicks_first) in zip(arr, entries):
+        it.p = C.pointer(params)
+        it.x_even, it.x_odd = x_even.data_ptr(), x_odd.data_ptr()
+        it.step0, it.n_steps, it.kicks_first, it.n_enqueued = step0, n_steps, kicks_first, 0
+    return arr
+
+
+def langevin_batch_run(entries, window: int):
+    """One launch per step for SEVERAL replicas (include/chx.h: chx_langevin_batch_run).  ``entries``: one
+    (params, x_even, x_odd, step0, n_steps, kicks_first) per replica.  Returns the launches each replica took part in --
+    fewer than asked for when the host saw some replica's halt word."""
+    arr = _batch_items(entries)
+    check(_lib.load().chx_langevin_batch_run(arr, len(entries), window, _stream()), "chx_langevin_batch_run")
+    return [int(it.n_enqueued) for it in arr]
+
+
+def langevin_batch_kick(entries) -> None:
+    """The force-only launch that ends a run, for several replicas in one dispatch (chx_langevin_batch_kick);
+    ``entries`` as for ``langevin_batch_run`` (n_steps is ignored)."""
+    arr = _batch_items(entries)
+    check(_lib.load().chx_langevin_batch_kick(arr, len(entries), _stream()), "chx_langevin_batch_kick")
+
+
 # ---------------------------------------------------------------------------
 # Debug mode of the step queue (include/chx.h: chx_queue_debug): the deterministic detector for a missing join.
 # The C side delays the launches whose outputs are read from outside the queue; this side fills those outputs with

@@ -500,6 +500,35 @@ int chx_langevin_fused_run(const chx_langevin_t* p_h, float* x_even, float* x_od
                            int32_t n_steps, int32_t kicks_first, int32_t window,
                            int32_t* n_enqueued_out, chx_stream_t stream);
 
+/* SEVERAL replicas, one launch per step (ABI 5).  The reference advances the replicas of a multistate simulation one after
+ * the other (chiron/multistate.py:497-510); a step of a medium-size replica is a latency chain that leaves most of the card
+ * idle, so here launch i of a call advances EVERY replica r with i < n_steps[r] by one step -- replica r's step
+ * step0[r] + i, reading (i even ? x_even[r] : x_odd[r]) and writing the other buffer, kicks_first[r] half-kicks in its
+ * first launch -- in one dispatch (one packet per kind of launch when the replicas' launches differ in kind, side by side).
+ * Each replica keeps its own parameter block (box, temperature, key, lists, control block: exactly what
+ * chx_langevin_fused_run takes; snap4 must be NULL, host_ctrl is required) and its own halt word: a replica whose skin
+ * check has fired turns into a no-op while the others carry on.  Every replica's arithmetic is the one-replica launch's,
+ * instruction for instruction: a trajectory does not depend on whether its replica is stepped alone or in a batch.
+ * chx_langevin_batch_run keeps at most `window` launches queued ahead of the device (counted on the first participating
+ * replica's host_ctrl) and RETURNS at the first halt word it sees among the participants -- n_enqueued[r] = launches in
+ * which replica r took part, the same i for all that did --, so that the caller can rebuild that replica's list behind
+ * the no-ops and call again (with per-replica step0 / n_steps: replicas drift apart by the launches they sat out).
+ * chx_langevin_batch_kick: the force-only launch that ends a run (chx_langevin_fused_chunk with do_aoa = 0), for every item
+ * at step0[r], in one dispatch; p->final_x3 / final_v3 as there.  Lanes per particle g in {1, 2, 4, 8}. */
+typedef struct {
+  const chx_langevin_t* p;
+  float* x_even;
+  float* x_odd;
+  int64_t step0;
+  int32_t n_steps;     /* launches wanted for this replica in this call (batch_kick: ignored, one launch) */
+  int32_t kicks_first;
+  int32_t n_enqueued;  /* out */
+  int32_t reserved;
+} chx_batch_item_t;
+int chx_langevin_batch_run(chx_batch_item_t* items_h, int32_t n_items, int32_t window, chx_stream_t stream);
+int chx_langevin_batch_kick(chx_batch_item_t* items_h, int32_t n_items, chx_stream_t stream);
+int64_t chx_sizeof_batch_item_t(void);
+
 /* The step queue.  The fused step kernels -- and, while the queue is open, the kernels of the queue-capable entry points
  * (chx_steps_open) -- are dispatched as hand-written AQL kernel-dispatch packets on a user-mode HSA
  * queue of the library's own, one per `stream` value, instead of through hipLaunchKernelGGL: the host side of a dispatch

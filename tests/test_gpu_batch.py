@@ -1,0 +1,176 @@
+"""Several replicas in one launch per step (include/chx.h: chx_langevin_batch_run; chiron_amd.integrators.run_batch).
+
+The reference advances the replicas of a multistate simulation one after the other (chiron/multistate.py:497-510).  The
+batched launch must not change one bit of any replica's trajectory: same states, keys, lists and rebuild steps as the
+serial ``LangevinIntegrator.run`` calls -- replicas of different temperature, size and density in one batch, with list
+rebuilds and inner-list refreshes falling on different steps in different replicas."""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SIGMA, EPS_KCAL = 0.34, 0.238
+
+
+def _replica(n, rho, temperature, seed, skin=0.5, dt_fs=1.0):
+    from chiron_amd import unit as u
+    from chiron_amd.integrators import LangevinIntegrator
+    from chiron_amd.neighbors import NeighborListCell, OrthogonalPeriodicSpace
+    from chiron_amd.potential import LJPotential
+    from chiron_amd.rng import PRNGKey
+    from chiron_amd.states import SamplerState, ThermodynamicState
+    from chiron_amd.testsystems import LennardJonesFluid
+
+    sigma, eps = SIGMA * u.nanometer, EPS_KCAL * u.kilocalories_per_mole
+    fluid = LennardJonesFluid(n, reduced_density=rho, sigma=sigma, epsilon=eps, seed=seed)
+    pot = LJPotential(fluid.topology, sigma=sigma, epsilon=eps, cutoff=3.0 * sigma)
+    state = SamplerState(fluid.positions, PRNGKey(77, seed), box_vectors=fluid.box_vectors)
+    thermo = ThermodynamicState(pot, temperature=temperature * u.kelvin)
+    nbr = NeighborListCell(OrthogonalPeriodicSpace(), cutoff=3.0 * sigma, skin=skin * u.nanometer,
+                           n_max_neighbors=180 if rho <= 0.2 else 400)
+    integ = LangevinIntegrator(timestep=dt_fs * u.femtoseconds, collision_rate=1.0 / u.picoseconds, list_carry=False)
+    return integ, state, thermo, nbr
+
+
+def _same(a, b):
+    (sa, la), (sb, lb) = a, b
+    assert torch.equal(sa.positions, sb.positions), "positions differ"
+    assert torch.equal(sa.velocities, sb.velocities), "velocities differ"
+    assert tuple(sa.current_PRNG_key) == tuple(sb.current_PRNG_key)
+    assert torch.equal(la.ref_positions, lb.ref_positions)
+    assert torch.equal(la.n_neighbors, lb.n_neighbors)
+    assert la.n_builds == lb.n_builds
+
+
+@pytest.mark.parametrize("shape", ["ladder", "mixed"])
+def test_run_batch_gives_the_serial_runs_bit_for_bit(shape):
+    """Five replicas, three consecutive calls each (the second and third continue the first), serial and batched.
+    ``ladder``: one system at five temperatures with a thin skin and a long step -- rebuilds every few dozen steps, at
+    different steps in every replica; ``mixed``: different sizes (different grids, different lanes per particle) and
+    densities in one batch."""
+    from chiron_amd import ops
+    from chiron_amd.integrators import run_batch
+
+    if shape == "ladder":
+        spec = [(6000, 0.3, 300.0 * 1.1 ** k, 11, 0.08, 3.0) for k in range(5)]
+    else:
+        spec = [(4096, 0.1, 300.0, 1, 0.5, 1.0), (2048, 0.1, 330.0, 2, 0.5, 1.0), (6000, 0.6, 300.0, 3, 0.3, 2.0),
+                (4096, 0.1, 360.0, 4, 0.1, 2.0), (10000, 0.05, 300.0, 5, 0.5, 1.0)]
+    serial = [_replica(*s) for s in spec]
+    batched = [_replica(*s) for s in spec]
+    out_s = [(st, nb) for _, st, _, nb in serial]
+    out_b = [(st, nb) for _, st, _, nb in batched]
+    rebuilds = 0
+    for steps in (150, 33, 1):
+        out_s = [integ.run(st, th, number_of_steps=steps, nbr_list=nb) for (integ, _, th, _), (st, nb) in zip(serial, out_s)]
+        rebuilds_s = [integ.n_rebuilds for integ, _, _, _ in serial]
+        before = ops.step_queue_info()
+        out_b = run_batch([r[0] for r in batched], [o[0] for o in out_b], [r[2] for r in batched], steps, [o[1] for o in out_b])
+        after = ops.step_queue_info()
+        torch.cuda.synchronize()
+        for a, b in zip(out_s, out_b):
+            _same(a, b)
+        assert rebuilds_s == [integ.n_rebuilds for integ, _, _, _ in batched]
+        rebuilds += sum(rebuilds_s)
+        if ops.step_queue_on():
+            # the batch took far fewer dispatches than one per replica and step (the build chains are per replica)
+            serial_packets = len(spec) * (steps + 1)
+            assert after["dispatched"] - before["dispatched"] < serial_packets or steps == 1
+            assert not after["open"]
+    if shape == "ladder":
+        assert rebuilds >= 10, rebuilds  # (rebuilds inside the batched segments, at replica-specific steps)
+
+
+def test_run_batch_at_the_metric_size_eight_replicas():
+    """BASELINE's C5 shape on one card: eight N = 32 768 replicas on a temperature ladder, 400 steps (one or two list
+    rebuilds and a dozen inner-list refreshes each), batched against serial."""
+    import bench
+    from chiron_amd.integrators import run_batch
+
+    def make(k):
+        fluid, pot, state, thermo, nbr, integ = bench.make_system("c3", 300.0 * 1.05 ** k, 32, "cell")
+        integ.list_carry = False
+        from chiron_amd.rng import PRNGKey
+
+        state.current_PRNG_key = PRNGKey(1234, k)
+        return integ, state, thermo, nbr
+
+    serial = [make(k) for k in range(8)]
+    batched = [make(k) for k in range(8)]
+    out_s = [integ.run(st, th, number_of_steps=400, nbr_list=nb) for integ, st, th, nb in serial]
+    out_b = run_batch([r[0] for r in batched], [r[1] for r in batched], [r[2] for r in batched], 400, [r[3] for r in batched])
+    torch.cuda.synchronize()
+    for a, b in zip(out_s, out_b):
+        _same(a, b)
+    assert sum(r[0].n_rebuilds for r in batched) == sum(r[0].n_rebuilds for r in serial) >= 8
+    # the replicas really are different trajectories
+    assert not torch.equal(out_b[0][0].positions, out_b[1][0].positions)
+
+
+def test_multistate_sampler_batches_its_replicas():
+    """``MultiStateSampler`` (chiron/multistate.py:414-445, :497-510) with Langevin moves: the batched propagation (the
+    default) against the reference's serial loop -- energy matrix history, state assignment with swaps on, every
+    replica's state, key and list."""
+    from chiron_amd import unit as u
+    from chiron_amd.mcmc import LangevinDynamicsMove, MCMCSampler, MoveSchedule
+    from chiron_amd.multistate import MultiStateSampler
+    from chiron_amd.rng import PRNGKey
+
+    K = 6
+    base = [_replica(5000, 0.3, 300.0 * 1.08 ** k, 21, 0.06, 4.0) for k in range(K)]
+
+    def run(batch):
+        thermo = [copy.deepcopy(b[2]) for b in base]
+        states = []
+        for k, b in enumerate(base):
+            st = copy.deepcopy(b[1])
+            st.current_PRNG_key = PRNGKey(4321, k)
+            states.append(st)
+        lists = [copy.deepcopy(b[3]) for b in base]
+        move = LangevinDynamicsMove(timestep=4.0 * u.femtoseconds, number_of_steps=100)
+        ms = MultiStateSampler(MCMCSampler(MoveSchedule([("LangevinDynamicsMove", move)])), swap="neighbors", batch_replicas=batch)
+        ms.create(thermo, states, lists)
+        ms.run(n_iterations=4, n_mcmc_iterations=1)
+        torch.cuda.synchronize()
+        return ms
+
+    a, b = run(False), run(True)
+    assert np.array_equal(a._reporter.get_property("u_kn"), b._reporter.get_property("u_kn"))
+    assert list(a._replica_thermodynamic_states) == list(b._replica_thermodynamic_states)
+    for sa, sb, la, lb in zip(a._sampler_states, b._sampler_states, a._nbr_lists, b._nbr_lists):
+        _same((sa, la), (sb, lb))
+        assert la.n_builds > 4
+    # (the batched sampler really took the batched path: its moves' integrators never saw a serial run's carry offer)
+    assert all(len(t) == 4 for t in b._traj)
+
+
+def test_batch_entry_points_refuse_what_they_cannot_run():
+    """Argument validation of the C entry points (errors, not faults)."""
+    import ctypes as C
+
+    from chiron_amd import _lib, ops
+
+    lib = _lib.load()
+    arr = (_lib.BatchItem * 1)()
+    assert lib.chx_langevin_batch_run(arr, 0, 8, None) == -1       # no items
+    assert lib.chx_langevin_batch_run(arr, 1, 8, None) == -1       # null params
+    integ, state, thermo, nbr = _replica(2048, 0.1, 300.0, 1)
+    integ.keep_run_state = True
+    integ.run(state, thermo, number_of_steps=2, nbr_list=nbr)
+    st = integ._last_run_state
+    ok = [(st.params, st.x_a, st.x_b, 0, 1, 1)]
+    bad = ops._batch_items(ok)
+    bad[0].x_odd = bad[0].x_even
+    assert lib.chx_langevin_batch_run(bad, 1, 8, None) == -1       # one position buffer
+    two = ops._batch_items(ok + ok)
+    assert lib.chx_langevin_batch_run(two, 2, 8, None) == -1       # two items on one control block
+    assert lib.chx_langevin_batch_run(ops._batch_items(ok), 1, 0, None) == -1  # window < 1
+    assert b"control block" in lib.chx_last_error() or b"window" in lib.chx_last_error()

@@ -992,7 +992,9 @@ def test_multistate_concurrent_replicas_give_the_serial_results(ca, O, with_mc):
         schedule = [("LangevinDynamicsMove", move)]
         if with_mc:  # (the device-resident Monte Carlo loop in both lanes at once: its key chain is made on the host)
             schedule.append(("MC", ca.mcmc.MonteCarloDisplacementMove(displacement_sigma=0.004 * u.nanometer, number_of_moves=40)))
-        ms = MultiStateSampler(MCMCSampler(MoveSchedule(schedule)), swap="neighbors", concurrent_replicas=workers)
+        # (batch_replicas=False: this test is about the threads-and-streams path; the batched path has tests/test_gpu_batch.py)
+        ms = MultiStateSampler(MCMCSampler(MoveSchedule(schedule)), swap="neighbors", concurrent_replicas=workers,
+                               batch_replicas=False)
         ms.create(thermo, states, lists)
         ms.run(n_iterations=4, n_mcmc_iterations=1)
         torch.cuda.synchronize()

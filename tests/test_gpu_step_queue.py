@@ -34,7 +34,7 @@ print("RESULT " + json.dumps({"hash": h, "rebuilds": rebuilds, "queue": ops.step
 
 def _run(env_extra, workload, steps):
     env = dict(os.environ)
-    for k in ("CHX_AQL", "CHX_AQL_FENCE", "CHX_AQL_SCOPE", "CHX_AQL_OPEN_AT_START", "CHX_AQL_FINAL", "CHX_BUILD_SUB"):
+    for k in ("CHX_AQL", "CHX_AQL_FENCE", "CHX_AQL_SCOPE", "CHX_AQL_OPEN_AT_START", "CHX_AQL_FINAL", "CHX_BUILD_SUB", "CHX_QUEUE_DEBUG"):
         env.pop(k, None)
     env.update(env_extra)
     out = subprocess.run([sys.executable, "-c", _TRAJECTORY, workload, str(steps)], capture_output=True, text=True, timeout=600,
@@ -200,8 +200,12 @@ def test_a_missing_join_reads_poison_every_time(path):
         lst = neighbors.PairListNsqrd(neighbors.OrthogonalPeriodicSpace(), cutoff=3.0 * bench.SIGMA_NM * u.nanometer)
     if not ops.step_queue_on():
         pytest.skip("the step queue is switched off (CHX_AQL=0)")
-    integ.list_carry = False
+    # (Verlet list: the runs continue each other on a carried-over list -- a run() that builds its list on entry confirms the
+    # build's status block before it returns, and under the debug delay that confirmation waits for the queue: the join
+    # under test would be masked by another one)
+    integ.list_carry = path == "verlet"
     state, lst = integ.run(state, thermo, number_of_steps=10, nbr_list=lst)  # velocities, buffers, code paths warm
+    state, lst = integ.run(state, thermo, number_of_steps=10, nbr_list=lst)
     old = ops.queue_debug(300)
     try:
         spins0 = ops.queue_debug_spins()
@@ -219,11 +223,17 @@ def test_a_missing_join_reads_poison_every_time(path):
             caught += int(poisoned)
             # ... and behind the join the same arrays hold the run's result
             assert torch.isfinite(out.positions).all() and torch.isfinite(out.velocities).all()
+            if path == "verlet":
+                state, lst = out, lst2
         assert caught == 10, f"the missing join was caught {caught} times out of 10"
         assert ops.queue_debug_spins() > spins0
         # the intact run(): never poison
         for _ in range(3):
             out, lst2 = integ.run(state, thermo, number_of_steps=12, nbr_list=lst)
             assert not ops.is_poison(out.positions) and not ops.is_poison(out.velocities)
+            if path == "verlet":
+                state, lst = out, lst2
+        if path == "verlet":
+            assert integ.n_carried_runs >= 10  # (the runs under test did start on carried lists)
     finally:
         ops.queue_debug(old)
