@@ -224,9 +224,10 @@ int chx_launch_lj_steps_batch(chx_batch_item_t* items, int n_items, int do_aoa, 
   }
   const bool throttle = do_aoa && window > 0;
   const PollPolicy poll = poll_policy();
+  auto active = [&](int r, int i) { return i < items[r].n_steps; };  // does item r take part in launch i?
   auto halted = [&](int i) {  // has some participant of launch i been ruled out by its halt word?
     for (int r = 0; r < n_items; ++r) {
-      if (i >= items[r].n_steps) continue;
+      if (!active(r, i)) continue;
       const volatile int32_t* hc = args[r].host_ctrl;
       if ((long long)hc[3] <= items[r].step0 + i) return true;
     }
@@ -237,7 +238,7 @@ int chx_launch_lj_steps_batch(chx_batch_item_t* items, int n_items, int do_aoa, 
       if (halted(i)) return CHX_OK;
       int lead = -1;
       for (int r = 0; r < n_items && lead < 0; ++r)
-        if (i < items[r].n_steps) lead = r;
+        if (active(r, i)) lead = r;
       const volatile int32_t* hc = args[lead].host_ctrl;
       const long long s = items[lead].step0 + i;
       if (s - hc[0] > window) {
@@ -269,47 +270,71 @@ int chx_launch_lj_steps_batch(chx_batch_item_t* items, int n_items, int do_aoa, 
         }
       }
     }
-    // this launch's items, sorted into classes (lanes per particle, hot, refresh of the inner list)
-    BatchItem pack[CHX_BATCH_MAX];
-    bool taken[MAXR];
-    for (int r = 0; r < n_items; ++r) taken[r] = i >= items[r].n_steps;
-    bool first_packet = true;
-    for (;;) {
-      int count = 0, cg = 0;
-      bool chot = false, cprune = false;
-      for (int r = 0; r < n_items && count < CHX_BATCH_MAX; ++r) {
-        if (taken[r]) continue;
+    // this launch's items, sorted into classes (lanes per particle, steady-state launch or not): one packet per class (and
+    // per CHX_BATCH_MAX items), the smallest first.  Whether an item refreshes its inner list is a flag of the item, not a
+    // class: as packets of their own the refreshes (one replica in eight every fourth step) cost 2 us per step, and
+    // neither order nor a missing barrier bit made consecutive packets of the queue overlap (measured, round 6).
+    struct Class {
+      int g, count;
+      bool hot;
+      int member[MAXR];
+    };
+    static thread_local Class cls[MAXR];
+    int ncls = 0;
+    int epoch_of[MAXR], nk_of[MAXR];
+    bool prune_of[MAXR];
+    for (int r = 0; r < n_items; ++r) {
+      if (!active(r, i)) continue;
+      const chx_langevin_t* p = items[r].p;
+      const long long step = items[r].step0 + i;
+      const int nk = i == 0 ? items[r].kicks_first : 2;
+      const bool since = inner[r] && (step >= p->prune_phase);
+      const bool prune = since && ((step - p->prune_phase) % p->prune_every == 0);
+      epoch_of[r] = since ? (int)((step - p->prune_phase) / p->prune_every) : -1;
+      nk_of[r] = nk;
+      prune_of[r] = prune;
+      const StepArgs& a = args[r];
+      const bool hot = nk == 2 && do_aoa && a.wrap && a.box.periodic && a.ref4 && a.fli && a.perm && !a.noise;
+      int c = 0;
+      while (c < ncls && !(cls[c].g == p->g && cls[c].hot == hot && cls[c].count < CHX_BATCH_MAX)) ++c;
+      if (c == ncls) cls[ncls++] = Class{p->g, 0, hot, {}};
+      cls[c].member[cls[c].count++] = r;
+    }
+    int order[MAXR];
+    for (int c = 0; c < ncls; ++c) order[c] = c;
+    for (int x = 1; x < ncls; ++x)  // (insertion sort by item count, ascending; a handful of classes at most)
+      for (int y = x; y > 0 && cls[order[y]].count < cls[order[y - 1]].count; --y) {
+        const int t = order[y];
+        order[y] = order[y - 1], order[y - 1] = t;
+      }
+    static const bool beside_on = [] { const char* e = getenv("CHX_BATCH_BESIDE"); return !e || e[0] != '0'; }();
+    for (int oc = 0; oc < ncls; ++oc) {
+      const Class& C = cls[order[oc]];
+      BatchItem pack[CHX_BATCH_MAX];
+      for (int m = 0; m < C.count; ++m) {
+        const int r = C.member[m];
         const chx_langevin_t* p = items[r].p;
-        const long long step = items[r].step0 + i;
-        const int nk = i == 0 ? items[r].kicks_first : 2;
-        const bool since = inner[r] && (step >= p->prune_phase);
-        const bool prune = since && ((step - p->prune_phase) % p->prune_every == 0);
-        const int epoch = since ? (int)((step - p->prune_phase) / p->prune_every) : -1;
         StepArgs& a = args[r];
-        const bool hot = nk == 2 && do_aoa && a.wrap && a.box.periodic && a.ref4 && a.fli && a.perm && !a.noise;
-        if (count == 0) cg = p->g, chot = hot, cprune = prune;
-        else if (p->g != cg || hot != chot || prune != cprune) continue;
-        taken[r] = true;
         a.x_cur = reinterpret_cast<const float4*>((i & 1) ? items[r].x_odd : items[r].x_even);
         a.x_next = (i & 1) ? items[r].x_even : items[r].x_odd;
-        BatchItem& it = pack[count++];
+        BatchItem& it = pack[m];
         it.a = a;
-        it.step = step;
-        const bool spec_inner = a.fli != nullptr && !prune && epoch >= 0;  // (as launch_step_g chooses)
+        it.step = items[r].step0 + i;
+        const bool spec_inner = a.fli != nullptr && !prune_of[r] && epoch_of[r] >= 0;  // (as launch_step_g chooses)
         it.sfl = spec_inner ? a.fli : a.fl;
         it.sdeg = spec_inner ? a.degi : a.deg;
         it.nblocks = (unsigned)(((int64_t)a.n * p->g + 255) / 256);
-        it.epoch = epoch;
-        it.n_kicks = nk;
+        it.epoch = epoch_of[r];
+        it.n_kicks = nk_of[r];
         it.do_aoa = do_aoa;
+        it.prune = prune_of[r] ? 1 : 0;
+        it.pad = 0;
       }
-      if (count == 0) break;
-      const int rc = chx_launch_step_batch(pack, count, cg, chot, cprune, !first_packet, st);
+      const int rc = chx_launch_step_batch(pack, C.count, C.g, C.hot, beside_on && oc > 0, st);
       if (rc != CHX_OK) return rc;
-      first_packet = false;
     }
     for (int r = 0; r < n_items; ++r)
-      if (i < items[r].n_steps) items[r].n_enqueued = i + 1;
+      if (active(r, i)) items[r].n_enqueued = i + 1;
   }
   return CHX_OK;
 }

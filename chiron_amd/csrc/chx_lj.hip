@@ -595,17 +595,24 @@ __global__ __launch_bounds__(256) void k_lj_step(int32_t* ctrl_first, long long 
 // them in one grid are a throughput problem the size of N = 262 144.  blockIdx.y picks the replica's item from the
 // argument block (a scalar load with a uniform offset: the block is never copied), blockIdx.x is the replica's block;
 // everything else is lj_step_body -- the same instructions in the same order as the one-replica launch, so a replica's
-// trajectory does not depend on whether it is stepped alone or in a batch.  The items of one packet share the
-// instantiation (HOT / PRUNE); a step whose replicas fall into several classes -- a refresh of the inner list here, a
-// first step there -- goes out as one packet per class, the later ones without the barrier bit: they run side by side.
+// trajectory does not depend on whether it is stepped alone or in a batch.  The items of one packet share the HOT
+// switch (steady-state launch or not); whether an item refreshes its inner list is a per-item flag.  A step whose replicas
+// fall into several classes -- a first step here, steady state there -- goes out as one packet per class, the later ones
+// without the barrier bit.
 // Each replica has its own control block: a replica whose skin check has fired turns into a no-op (its halt word) while
 // the others carry on.
-template <int G, bool HOT, bool PRUNE>
-__global__ __launch_bounds__(256) void k_lj_step_batch(BatchArgs b) {
+template <int G, bool HOT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOT ? 7 : 4))) void k_lj_step_batch(BatchArgs b) {
   const BatchItem& it = b.item[blockIdx.y];
   if (blockIdx.x >= it.nblocks) return;  // (replicas of different sizes share the grid's x extent)
-  lj_step_body<G, HOT, PRUNE, false>(it.a.ctrl, it.step, it.epoch, it.a.n, it.nblocks, it.a.x_cur, it.sfl, it.sdeg, it.a, it.n_kicks,
-                                     it.do_aoa);
+  // (block-uniform: a replica that refreshes its inner list in this step takes the pruning instantiation, the others the
+  // plain one -- in the same grid, so that the refresh of one replica in eight does not cost a dispatch of its own)
+  if (it.prune)
+    lj_step_body<G, HOT, true, false>(it.a.ctrl, it.step, it.epoch, it.a.n, it.nblocks, it.a.x_cur, it.sfl, it.sdeg, it.a, it.n_kicks,
+                                      it.do_aoa);
+  else
+    lj_step_body<G, HOT, false, false>(it.a.ctrl, it.step, it.epoch, it.a.n, it.nblocks, it.a.x_cur, it.sfl, it.sdeg, it.a, it.n_kicks,
+                                       it.do_aoa);
 }
 
 // ---------------------------------------------------------------------------
@@ -867,56 +874,54 @@ int chx_launch_step(const StepArgs& a, int g, long long step, int n_kicks, int d
 
 // one batched packet (chx_step.h)
 template <int G>
-static int launch_step_batch_g(const BatchItem* items, int count, bool hot, bool prune, bool beside, hipStream_t st) {
+static int launch_step_batch_g(const BatchItem* items, int count, bool hot, bool beside, hipStream_t st) {
   alignas(16) static thread_local BatchArgs ba;
   unsigned maxb = 0;
+  bool any_prune = false;
   for (int i = 0; i < count; ++i) {
     ba.item[i] = items[i];
     maxb = items[i].nblocks > maxb ? items[i].nblocks : maxb;
+    any_prune |= items[i].prune != 0;
   }
   for (int i = count; i < CHX_BATCH_MAX; ++i) ba.item[i].nblocks = 0;  // (never addressed: the grid's y extent is `count`)
   static const bool dbg = getenv("CHX_DEBUG_SYNC") != nullptr;
-  if (dbg) fprintf(stderr, "[chx] k_lj_step_batch<%d, %d, %d> x %d items, first step %lld\n", G, (int)hot, (int)prune, count, items[0].step);
+  if (dbg) fprintf(stderr, "[chx] k_lj_step_batch<%d, %d> x %d items, first step %lld\n", G, (int)hot, count, items[0].step);
   if (chx_aql_on()) {
     static const AqlKernel absent{};
-    static std::atomic<const AqlKernel*> table[2][2];
-    const int ih = hot ? 1 : 0, ip = prune ? 1 : 0;
-    const AqlKernel* k = table[ih][ip].load(std::memory_order_acquire);
+    static std::atomic<const AqlKernel*> table[2];
+    const int ih = hot ? 1 : 0;
+    const AqlKernel* k = table[ih].load(std::memory_order_acquire);
     if (k == nullptr) {
       char name[96];
-      snprintf(name, sizeof(name), "void k_lj_step_batch<%d, %s, %s>", G, hot ? "true" : "false", prune ? "true" : "false");
+      snprintf(name, sizeof(name), "void k_lj_step_batch<%d, %s>", G, hot ? "true" : "false");
       k = chx_aql_kernel(name);
       if (k == nullptr) k = &absent;
-      table[ih][ip].store(k, std::memory_order_release);
+      table[ih].store(k, std::memory_order_release);
     }
     if (k == &absent) {
-      chx_set_error("chx_launch_step_batch: libchx_step.hsaco holds no k_lj_step_batch<%d, %d, %d>", G, ih, ip);
+      chx_set_error("chx_launch_step_batch: libchx_step.hsaco holds no k_lj_step_batch<%d, %d>", G, ih);
       return CHX_ERR_LAUNCH;
     }
-    // (fences as for the one-replica launch: a packet of steady-state items leaves write-through stores only)
-    return chx_aql_dispatch_grid(st, k, dim3(maxb, (unsigned)count), &ba, sizeof(ba), !(hot && !prune), beside);
+    // (fences as for the one-replica launch: a packet of steady-state items that refresh nothing leaves write-through
+    // stores only)
+    return chx_aql_dispatch_grid(st, k, dim3(maxb, (unsigned)count), &ba, sizeof(ba), !(hot && !any_prune), beside);
   }
-#define CHX_LAUNCH_BATCH(HOT_, PRUNE_) \
-  hipLaunchKernelGGL((k_lj_step_batch<G, HOT_, PRUNE_>), dim3(maxb, (unsigned)count), dim3(256), 0, st, ba)
-  if (hot && prune) CHX_LAUNCH_BATCH(true, true);
-  else if (hot) CHX_LAUNCH_BATCH(true, false);
-  else if (prune) CHX_LAUNCH_BATCH(false, true);
-  else CHX_LAUNCH_BATCH(false, false);
-#undef CHX_LAUNCH_BATCH
+  if (hot) hipLaunchKernelGGL((k_lj_step_batch<G, true>), dim3(maxb, (unsigned)count), dim3(256), 0, st, ba);
+  else hipLaunchKernelGGL((k_lj_step_batch<G, false>), dim3(maxb, (unsigned)count), dim3(256), 0, st, ba);
   if (dbg) (void)hipStreamSynchronize(st);
   return CHX_OK;
 }
 
-int chx_launch_step_batch(const BatchItem* items, int count, int g, bool hot, bool prune, bool beside_previous, hipStream_t st) {
+int chx_launch_step_batch(const BatchItem* items, int count, int g, bool hot, bool beside_previous, hipStream_t st) {
   if (count < 1 || count > CHX_BATCH_MAX) {
     chx_set_error("chx_launch_step_batch: %d items (1 .. %d)", count, CHX_BATCH_MAX);
     return CHX_ERR_INVALID;
   }
   switch (g) {
-    case 1: return launch_step_batch_g<1>(items, count, hot, prune, beside_previous, st);
-    case 2: return launch_step_batch_g<2>(items, count, hot, prune, beside_previous, st);
-    case 4: return launch_step_batch_g<4>(items, count, hot, prune, beside_previous, st);
-    case 8: return launch_step_batch_g<8>(items, count, hot, prune, beside_previous, st);
+    case 1: return launch_step_batch_g<1>(items, count, hot, beside_previous, st);
+    case 2: return launch_step_batch_g<2>(items, count, hot, beside_previous, st);
+    case 4: return launch_step_batch_g<4>(items, count, hot, beside_previous, st);
+    case 8: return launch_step_batch_g<8>(items, count, hot, beside_previous, st);
     default:
       chx_set_error("chx_launch_step_batch: unsupported g = %d (1, 2, 4, 8)", g);
       return CHX_ERR_UNSUPPORTED;

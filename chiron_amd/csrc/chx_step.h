@@ -66,11 +66,13 @@ struct BatchItem {
   int epoch;
   int n_kicks;
   int do_aoa;
+  int prune;             // this replica's launch refreshes its inner list (k_lj_step's PRUNE instantiation)
+  int pad;
 };
 struct BatchArgs {
   BatchItem item[CHX_BATCH_MAX];
 };
-// One packet: `count` items of ONE class (all hot or none, all refreshing their inner list or none, the same lanes per
-// particle g).  `beside_previous`: the packet may run beside the one dispatched just before it (the other classes of the
-// same step); the first packet of a step waits for everything before it.
-int chx_launch_step_batch(const BatchItem* items, int count, int g, bool hot, bool prune, bool beside_previous, hipStream_t st);
+// One packet: `count` items of ONE class (all steady-state launches or none, the same lanes per particle g).
+// `beside_previous`: the packet may run beside the one dispatched just before it (the other classes of the same step); the
+// first packet of a step waits for everything before it.
+int chx_launch_step_batch(const BatchItem* items, int count, int g, bool hot, bool beside_previous, hipStream_t st);

@@ -547,8 +547,11 @@ def _advance_batch(sts, n_steps: int, window: int, chunk: int) -> None:
     """Steps [0, n_steps) and the trailing kick of every run state in ``sts``, batched.  The per-replica logic is
     ``_RunState._advance_windowed`` / ``final_kick`` -- halt word, rebuild behind the queued no-ops, speculative builds
     settled later -- with the launches of all replicas that are not waiting for a rebuild going out together; a replica
-    that has halted sits out until its list is rebuilt and then continues from its halt step (the replicas drift apart
-    by the launches they sat out and finish a few launches after each other)."""
+    that has halted is a no-op in the launches still queued, its rebuild goes out behind them on the same queue, and it
+    continues from its halt step (the replicas drift apart by the launches they sat out and finish a few launches after
+    each other).  (Rebuilding a halted replica's list on a second queue BESIDE the others' steps was built and measured
+    in round 6: the step launch of eight replicas saturates the card, the build's kernels slowed it by as much as they
+    gained -- 415 k against 440 k replica-steps/s -- and the scheme is gone.)"""
     R = len(sts)
     enq = [0] * R        # first step not enqueued yet, per replica
     kicked = [False] * R
