@@ -75,6 +75,12 @@ def parse():
     ap.add_argument("--extra-overlap", type=int, default=1,
                     help="also report the aggregate rate of TWO independent replicas of the workload driven from two "
                          "threads / HIP streams on the one card (1 GPU runs; not the headline: one replica per GPU)")
+    ap.add_argument("--extra-c5", type=int, default=1,
+                    help="also run BASELINE's C5 shape on the ONE card (1 GPU runs): --c5-replicas replicas of the workload on a "
+                         "temperature ladder, stepped side by side (one launch per step for all of them), label exchange "
+                         "through a one-rank RCCL group")
+    ap.add_argument("--c5-replicas", type=int, default=8)
+    ap.add_argument("--c5-steps", type=int, default=4000, help="steps per timed window of the C5 leg (three windows)")
     ap.add_argument("--steady-steps", type=int, default=20000,
                     help="timed steps of the steady-state figure reported next to `value` (0 = skip)")
     ap.add_argument("--steady-warmup", type=int, default=2000)
@@ -110,7 +116,7 @@ class _RankChild:
     def __init__(self, args, rank: int, port: int, attempt: int, qualify: bool, single: bool = False):
         import subprocess
 
-        self.rank, self.attempt, self.rate = rank, attempt, None
+        self.rank, self.attempt, self.rate, self.value_k = rank, attempt, None, None
         env = dict(os.environ)
         if single:  # (a candidate for the one process of `--gpus 1`: no rank environment, so no process group either)
             env.update(CHX_BENCH_CHILD="1", CHX_BENCH_ATTEMPT=str(attempt))
@@ -144,8 +150,10 @@ class _RankChild:
                     return None
                 buf += chunk
         try:
-            self.rate = float(buf.split(b"\n")[0])
-        except ValueError:
+            fields = buf.split(b"\n")[0].split()
+            self.rate = float(fields[0])
+            self.value_k = float(fields[1]) if len(fields) > 1 else None  # (the driver's K-step figure in that process)
+        except (ValueError, IndexError):
             self.rate = None
         return self.rate
 
@@ -302,7 +310,13 @@ def launch_single(args):
         for o in cands:
             if o is not chosen:
                 o.discard()
-        summary = {"ratio": QUALIFY_RATIO, "candidates_steps_per_s": log, "chosen_attempt": chosen.attempt}
+        others = [o for o in cands if o is not chosen]
+        summary = {"ratio": QUALIFY_RATIO, "candidates_steps_per_s": log, "chosen_attempt": chosen.attempt,
+                   # (round-5 review: the process is picked by its stand-alone rate -- what the one NOT picked read, on the
+                   # driver's own K-step figure as well, stands beside the headline)
+                   "chosen_rate_steps_per_s": chosen.rate, "chosen_value_k_steps_per_s": chosen.value_k,
+                   "unselected_rate_steps_per_s": [o.rate for o in others],
+                   "unselected_value_k_steps_per_s": [o.value_k for o in others]}
         if len([r for r in log if r < QUALIFY_RATIO * best]):
             print(f"bench.py launcher: candidate rates {['%.0f' % r for r in log]} steps/s stand-alone; running the bench in "
                   f"attempt {chosen.attempt}", file=sys.stderr, flush=True)
@@ -326,7 +340,10 @@ def qualification_phase(measure):
         return None
     report_w, go_r = (int(v) for v in spec.split(","))
     rate = measure()
-    os.write(report_w, f"{rate:.3f}\n".encode())
+    if isinstance(rate, tuple):  # (stand-alone rate, the driver's K-step figure in this process)
+        os.write(report_w, f"{rate[0]:.3f} {rate[1]:.3f}\n".encode())
+    else:
+        os.write(report_w, f"{rate:.3f}\n".encode())
     os.close(report_w)
     buf = b""
     while b"\n" not in buf:
@@ -414,6 +431,158 @@ def two_replica_overlap(args, steps: int):
     return {"replicas": 2, "steps_each": steps, "aggregate_steps_per_s": round(2 * steps / wall, 2),
             "per_replica_steps_per_s": [round(r, 2) for r in rates],
             "note": "two threads, two HIP streams, one process, one card; not the headline configuration"}
+
+
+def c5_one_gpu_block(args):
+    """BASELINE's C5 -- K thermodynamic states of the metric's fluid, replica exchange -- on ONE card: the K replicas are
+    propagated side by side (chiron_amd.integrators.run_batch: one launch per MD step for all of them; the reference's
+    loop over replicas is serial, chiron/multistate.py:497-510) and exchange labels every --exchange-interval steps through
+    the job's collective -- ``ReplicaExchange`` over a ONE-RANK RCCL group here (the very all_gather_into_tensor of fp64
+    device tensors the eight-rank job makes over xGMI).  Reports the aggregate rate of three windows, the serial loop's rate
+    on the same replicas, and the batched kernel event-timed with its roofline entry."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from chiron_amd import ops, unit
+    from chiron_amd.integrators import _RunState, langevin_constants, run_batch
+    from chiron_amd.multistate import ReplicaExchange
+    from chiron_amd.rng import PRNGKey
+    from chiron_amd.states import ThermodynamicState
+
+    K = args.c5_replicas
+    reps = []
+    for k in range(K):
+        fluid, pot, state, thermo, nbr, integ = make_system(args.workload, 300.0 * (1.05 ** k), args.chunk, args.build)
+        integ.list_carry = False
+        state.current_PRNG_key = PRNGKey(1234, k)
+        reps.append([integ, state, thermo, nbr, pot, fluid])
+    n = reps[0][5].n_particles
+    own_group = False
+    backend = None
+    if not (dist.is_available() and dist.is_initialized()):
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+        own_group = True
+    try:
+        backend = dist.get_backend()
+        ladder = [ThermodynamicState(reps[0][4], temperature=300.0 * (1.05 ** k) * unit.kelvin) for k in range(K)]
+        rex = ReplicaExchange(ladder, PRNGKey(2024, 7))
+        rex.gather_energies(torch.zeros(K, dtype=torch.float64, device="cuda"))  # (communicator set-up: not in a window)
+
+        def segment(n_steps, batched=True):
+            thermo = rex.my_states
+            if batched:
+                out = run_batch([r[0] for r in reps], [r[1] for r in reps], thermo, n_steps, [r[3] for r in reps])
+            else:
+                out = [r[0].run(r[1], t, number_of_steps=n_steps, nbr_list=r[3]) for r, t in zip(reps, thermo)]
+            for r, (st, nb) in zip(reps, out):
+                r[1], r[3] = st, nb
+
+        def exchange():
+            e = torch.cat([r[4].compute_energy(r[1].positions, r[3]).reshape(1) for r in reps]).to(torch.float64)
+            for r, (_, scale) in zip(reps, rex.exchange_many(e)):
+                if scale != 1.0:
+                    r[1].velocities = ops.scale(r[1].velocities, scale)
+
+        def window(n_steps, batched=True):
+            done = ex = 0
+            t0 = time.perf_counter()
+            while done < n_steps:
+                seg = min(args.exchange_interval, n_steps - done)
+                segment(seg, batched)
+                done += seg
+                if done % args.exchange_interval == 0:
+                    exchange()
+                    ex += 1
+            torch.cuda.synchronize()
+            return K * n_steps / (time.perf_counter() - t0), ex
+
+        window(2 * args.exchange_interval)  # off the lattice, buffers, first exchange
+        rates, exs = zip(*[window(args.c5_steps) for _ in range(3)])
+        serial_rates = [window(args.c5_steps, batched=False)[0] for _ in range(2)]
+        mid = sorted(rates)[1]
+        # the batched launch alone, event-timed on the replicas as the windows left them (skin check off, every sample
+        # from the same state: see time_kernels)
+        sts = []
+        for integ, state, thermo, nbr, pot, fluid in reps:
+            half_dt, a, b = langevin_constants(integ.timestep, integ.collision_rate)
+            nbr.build_from_state(state)
+            from chiron_amd._device import as_tensor
+            from chiron_amd.utils import get_list_of_mass
+
+            mass = as_tensor(get_list_of_mass(fluid.topology).value_in_unit_system(unit.md_unit_system))
+            kT = float((integ.kB * thermo.temperature).value_in_unit_system(unit.md_unit_system))
+            st = _RunState(integ, pot, nbr, state.positions, state.velocities, mass, kT, half_dt, a, b, state.current_PRNG_key, None, "fused")
+            st.params.skin = 1.0e6
+            sts.append(st)
+        step = [0]
+        per_call = 32
+
+        def one_chunk():
+            ent = []
+            for st in sts:
+                even, odd = (st.x_a, st.x_b) if (step[0] & 1) == 0 else (st.x_b, st.x_a)
+                ent.append((st.params, even, odd, step[0], per_call, 2))
+            ops.langevin_batch_run(ent, 1 << 20)
+            step[0] += per_call
+
+        def fresh_state():
+            for st, r in zip(sts, reps):
+                st._load(r[1].positions, r[1].velocities, 0)
+                st.params.skin = 1.0e6
+            step[0] = 0
+            one_chunk()
+            one_chunk()
+
+        samples = []
+        for _ in range(7):
+            fresh_state()
+            ops.steps_join()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                one_chunk()
+            ops.steps_join()
+            e1.record()
+            torch.cuda.synchronize()
+            samples.append(e0.elapsed_time(e1) * 1e-3 / (10 * per_call))
+        t_k = sorted(samples)[3]
+        p_nl = sum(int(torch.minimum(r[3].n_neighbors, torch.tensor(r[3].n_max_neighbors, device="cuda")).sum().item()) for r in reps)
+        algorithmic = 96 * n * K + 16 * p_nl
+        out = {
+            "workload": f"{K} replicas of LJ fluid N={n} (temperature ladder 300 K x 1.05^k) on ONE MI355X, one launch per MD step for "
+                        f"all of them (k_lj_step_batch), label exchange every {args.exchange_interval} steps",
+            "replicas": K, "n_particles_each": n,
+            "aggregate_replica_steps_per_s": round(mid, 1), "windows": [round(v, 1) for v in rates],
+            "timed_steps_per_window": args.c5_steps, "exchanges_per_window": exs[0],
+            "serial_loop_replica_steps_per_s": round(max(serial_rates), 1),
+            "speedup_over_serial_loop": round(mid / max(serial_rates), 3),
+            "collective_backend": backend, "group_world_size": dist.get_world_size(), "replicas_per_rank": rex.replicas_per_rank,
+            "swap_acceptance": float(rex.n_accepted.sum() / max(1, rex.n_proposed.sum())),
+            "state_of_replica": [int(v) for v in rex.state_of_replica],
+            "kernel": "k_lj_step_batch<4, true> (the fused step of every replica in one grid: blockIdx.y = replica)",
+            "kernel_us": round(1e6 * t_k, 3), "kernel_us_samples": [round(1e6 * v, 3) for v in samples],
+            "algorithmic_bytes": algorithmic, "list_pairs_all_replicas": p_nl,
+            "achieved": round(algorithmic / t_k / 1e9, 2), "frac": round(algorithmic / t_k / 1e9 / HBM_PEAK_GBS, 5),
+            "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "note": "frac by ALGORITHMIC bytes (96 N + 16 P_nl per replica, SURVEY 8d) like the one-replica step's: useful work per "
+                    "second against the HBM peak, not measured traffic",
+        }
+        return out
+    finally:
+        if own_group:
+            try:
+                dist.destroy_process_group()
+            except Exception:  # pragma: no cover
+                pass
 
 
 def read_sclk_mhz(device_index: int = 0):
@@ -689,6 +858,7 @@ def roofline_entry(kind: str, n: int, p_nl: int, seconds: float, extra=None):
         "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5),
         "traffic": None,
+        "hbm_frac_measured": None,  # (real HBM traffic / time / peak; filled when the PMC passes of this state are on file)
         "algorithmic_bytes": algorithmic,
         "kernel_us": round(seconds * 1e6, 3),
         "n_particles": n,
@@ -712,6 +882,7 @@ def roofline_entry(kind: str, n: int, p_nl: int, seconds: float, extra=None):
             if pmc_pairs and abs(pmc_pairs - p_nl) <= 0.02 * p_nl and same_layout:
                 d["traffic"] = int(pmc["traffic_bytes"])
                 d["hbm_GBps_measured"] = round(pmc["traffic_bytes"] / seconds / 1e9, 2)
+                d["hbm_frac_measured"] = round(pmc["traffic_bytes"] / seconds / 1e9 / HBM_PEAK_GBS, 5)
                 d["traffic_source"] = (f"{pmc.get('source', 'profiles/pmc_traffic.json')}: separate rocprofv3 --pmc passes over this "
                                        f"kernel on the same box geometry equilibrated for {pmc.get('equilibration_steps')} steps "
                                        f"(P_nl = {pmc_pairs}, this run {p_nl}); not collected in this run")
@@ -790,9 +961,20 @@ def nest_rooflines(out: dict) -> None:
         if not isinstance(e, dict) or "frac" not in e:
             continue
         roof[name] = {k: e[k] for k in ("kernel", "frac", "achieved", "kernel_us", "algorithmic_bytes", "list_pairs", "n_particles",
-                                        "traffic", "hbm_GBps_measured", "lanes_per_particle", "equilibration_steps") if k in e}
-        for k in ("frac", "achieved", "kernel_us", "algorithmic_bytes", "list_pairs"):
-            roof[f"{name}_{k}"] = e[k]
+                                        "traffic", "hbm_GBps_measured", "hbm_frac_measured", "lanes_per_particle",
+                                        "equilibration_steps") if k in e}
+        for k in ("frac", "achieved", "kernel_us", "algorithmic_bytes", "list_pairs", "hbm_frac_measured"):
+            roof[f"{name}_{k}"] = e.get(k)
+    c5 = out.get("c5_one_gpu")
+    if isinstance(c5, dict) and "kernel_us" in c5:
+        roof["c5_batched_step"] = {k: c5[k] for k in ("kernel", "frac", "achieved", "kernel_us", "algorithmic_bytes", "replicas",
+                                                      "n_particles_each", "list_pairs_all_replicas")}
+        for k in ("frac", "kernel_us", "achieved", "algorithmic_bytes"):
+            roof[f"c5_batched_step_{k}"] = c5[k]
+        out.setdefault("config", {})["c5_one_gpu_replica_steps_per_s"] = c5["aggregate_replica_steps_per_s"]
+        out["config"]["c5_one_gpu_replicas"] = c5["replicas"]
+        out["config"]["c5_one_gpu_collective_backend"] = c5["collective_backend"]
+        out["config"]["c5_one_gpu_speedup_over_serial_loop"] = c5["speedup_over_serial_loop"]
     c2 = out.get("c2")
     if isinstance(c2, dict) and "kernel_us" in c2:
         roof["c2"] = {k: c2[k] for k in ("kernel", "kernel_us", "pairs_per_launch", "pairs_per_s", "steps_per_s", "algorithmic_bytes", "bound")}
@@ -1009,8 +1191,19 @@ def main():
                 st0, nb0 = ig0.run(st0, th0, number_of_steps=10000, nbr_list=nb0)
                 torch.cuda.synchronize()
                 rates_q.append(10000.0 / (time.perf_counter() - t_w))
+            # ... and the driver's own figure in THIS process -- W warm-up steps, K timed steps, median of five -- so that the
+            # line can say what the candidate that was not chosen would have reported (launcher of --gpus 1 only)
+            vals_q = []
+            if os.environ.get("CHX_BENCH_CHILD") == "1" and args.steps <= 1000:
+                for _ in range(5):
+                    st0, nb0 = ig0.run(st0, th0, number_of_steps=args.warmup, nbr_list=nb0)
+                    torch.cuda.synchronize()
+                    t_w = time.perf_counter()
+                    st0, nb0 = ig0.run(st0, th0, number_of_steps=args.steps, nbr_list=nb0)
+                    torch.cuda.synchronize()
+                    vals_q.append(args.steps / (time.perf_counter() - t_w))
             prebuilt[2], prebuilt[4] = st0, nb0
-            return sorted(rates_q)[1]
+            return (sorted(rates_q)[1], sorted(vals_q)[2]) if vals_q else sorted(rates_q)[1]
 
         qual = qualification_phase(measure)
 
@@ -1241,6 +1434,14 @@ def main():
         # reference-format half rows on demand -- their counts always, the rows when `neighbor_list` is first read)
         out["config"]["half_rows_inside_run"] = "written" if _integ_mod._RUN_HALF_ROWS else "counted; built on first read of neighbor_list"
         out["config"]["requalification"] = qual
+        if isinstance(qual, dict) and "unselected_rate_steps_per_s" in qual:
+            # (scalars: the driver's record keeps scalar members only)
+            un_r = [v for v in qual["unselected_rate_steps_per_s"] if v]
+            un_v = [v for v in qual["unselected_value_k_steps_per_s"] if v]
+            out["config"]["unselected_candidate_rate_steps_per_s"] = max(un_r) if un_r else None
+            out["config"]["unselected_candidate_value_steps_per_s"] = max(un_v) if un_v else None
+            out["config"]["chosen_candidate_rate_steps_per_s"] = qual.get("chosen_rate_steps_per_s")
+            out["config"]["chosen_candidate_prelim_value_steps_per_s"] = qual.get("chosen_value_k_steps_per_s")
         if world == 1:
             try:
                 state, nbr, out["short_run"] = short_run_block(integ, rex.my_state, state, nbr, args.steps if args.steps <= 64 else 20)
@@ -1251,6 +1452,11 @@ def main():
                 out["two_replicas_one_gpu"] = two_replica_overlap(args, args.steps if args.steps >= 2000 else 20000)
             except Exception as exc:  # pragma: no cover - diagnostics only
                 out["two_replicas_one_gpu"] = {"error": repr(exc)}
+        if world == 1 and args.extra_c5 and not use_dist:
+            try:
+                out["c5_one_gpu"] = c5_one_gpu_block(args)
+            except Exception as exc:  # pragma: no cover - diagnostics only
+                out["c5_one_gpu"] = {"error": repr(exc)}
         if world == 1 and args.extra_mc:
             try:
                 out["mc_displacement"] = mc_block(args)
@@ -1294,6 +1500,13 @@ def main():
                         os.sched_setaffinity(0, mask_now)
                     except OSError:  # pragma: no cover
                         pass
+        try:
+            # the assumption the fence-free packets rest on, checked again now that the process has shared the card with
+            # other legs' queues for minutes (the queue's first use checked it once): stale words read, 0 = holds
+            out["config"]["fence_selfcheck_at_end"] = ops.step_queue_selfcheck()
+            out["config"]["step_queue_status_at_end"] = ops.step_queue_info()["status"] or "ok"
+        except Exception as exc:  # pragma: no cover - diagnostics only
+            out["config"]["fence_selfcheck_at_end"] = repr(exc)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

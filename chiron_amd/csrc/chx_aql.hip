@@ -380,11 +380,13 @@ void raw_packet(Queue* Q, const AqlKernel* k, unsigned blocks, const void* args,
 // rewrite (one workgroup, write-through) / re-read (1024 workgroups, plain vector and scalar loads) with acquire =
 // release = NONE on every packet.  One stale word -> every packet gets HIP's agent-scope fences for the life of the
 // process (and the status string says so).  About a millisecond, once per process.  CHX_AQL_SELFCHECK=0 skips it.
-void selfcheck_fences(Queue* Q, hipStream_t st) {
-  if (g_selfchecked || !g_fence_none) return;
-  g_selfchecked = true;
-  const char* e = getenv("CHX_AQL_SELFCHECK");
-  if (e && e[0] == '0') return;
+void selfcheck_fences(Queue* Q, hipStream_t st, bool again = false) {
+  if (!again) {
+    if (g_selfchecked || !g_fence_none) return;
+    g_selfchecked = true;
+    const char* e = getenv("CHX_AQL_SELFCHECK");
+    if (e && e[0] == '0') return;
+  }
   auto name_of = [&](const void* fn) -> const AqlKernel* {
     const char* nm = hipKernelNameRefByPtr(fn, st);
     if (!nm) return nullptr;
@@ -832,6 +834,17 @@ extern "C" int chx_step_queue_info(int64_t* out8_h, chx_stream_t stream) {
   return CHX_OK;
 }
 extern "C" const char* chx_step_queue_status(void) { return g_err; }
+extern "C" int chx_step_queue_selfcheck(chx_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!chx_aql_on()) return -1;
+  chx_aql_join(st);
+  Queue* Q = queue_for(st);
+  if (!Q || g_queue_error) return -1;
+  if (!g_fence_none) return g_selfcheck_result > 0 ? g_selfcheck_result : -1;  // (fences are on: nothing rests on the assumption)
+  g_selfcheck_result = -1;
+  selfcheck_fences(Q, st, true);
+  return g_selfcheck_result;
+}
 extern "C" int chx_queue_debug(int32_t delay_us) {
   const int old = g_debug_delay_us;
   if (delay_us >= 0) g_debug_delay_us = delay_us;

@@ -774,6 +774,12 @@ def step_queue_info() -> dict:
             "status": status.decode() if status else ""}
 
 
+def step_queue_selfcheck() -> int:
+    """Repeat the step queue's start-up check of its fence-free packets now (include/chx.h: chx_step_queue_selfcheck):
+    stale words read (0 = fine), -1 = not applicable."""
+    return int(_lib.load().chx_step_queue_selfcheck(_stream()))
+
+
 def ctrl_reset(ctrl: torch.Tensor) -> None:
     _require_device(ctrl)
     check(_lib.load().chx_ctrl_reset(_ptr(ctrl), _stream()), "chx_ctrl_reset")

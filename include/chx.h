@@ -560,6 +560,13 @@ int chx_steps_open(chx_stream_t stream);
  * packets outstanding (0 / 1), openings on an idle stream (no marker needed: hipStreamQuery said so)}. */
 int chx_step_queue_info(int64_t* out8_h, chx_stream_t stream);
 const char* chx_step_queue_status(void);
+/* Run the start-up check of the fence-free packets AGAIN, now, on the queue paired with `stream` (joined first): 256 rounds
+ * of rewrite (write-through stores, one workgroup) / re-read (1024 workgroups, plain vector and scalar loads) with
+ * acquire = release = NONE on every packet, about a millisecond.  Returns the number of stale words read (0 = the
+ * assumption holds on this card now; > 0: every later packet of the process carries agent-scope fences), -1 when the
+ * queue is off, already fenced, or the check's kernels are not loaded.  The first queue of a process runs it once by
+ * itself; a long-lived process that shares its card with others may want to ask again (bench.py does, at its end). */
+int chx_step_queue_selfcheck(chx_stream_t stream);
 /* Debug mode of the step queue (ABI 5; CHX_QUEUE_DEBUG=<microseconds> in the environment sets the initial value).  With a
  * delay > 0 the queue puts a packet that idles that long (one lane watching the wall clock; at most a second) in front of
  * the first packet behind every gate, of every packet that is not a fused step / Monte Carlo trial launch (unpack, the

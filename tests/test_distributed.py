@@ -229,7 +229,12 @@ def test_bench_single_gpu_run_is_chosen_among_fresh_candidates():
     assert len(lines) == 1
     cfg = lines[0]["config"]
     assert cfg["attempt"] == 1 and cfg["group_world_size"] == 1
-    assert cfg["requalification"] == {"ratio": 0.97, "candidates_steps_per_s": [85000.0, 100000.0, 100000.0], "chosen_attempt": 1}
+    # (what the candidates that were NOT chosen read stands beside the chosen one's: round-5 review; the K-step figures are
+    # measured on the GPU path only)
+    assert cfg["requalification"] == {"ratio": 0.97, "candidates_steps_per_s": [85000.0, 100000.0, 100000.0], "chosen_attempt": 1,
+                                      "chosen_rate_steps_per_s": 100000.0, "chosen_value_k_steps_per_s": None,
+                                      "unselected_rate_steps_per_s": [85000.0, 100000.0],
+                                      "unselected_value_k_steps_per_s": [None, None]}
     assert "running the bench in attempt 1" in res.stderr
     # two candidates that agree: the first runs, nothing is said
     res, lines = _run_bench(args, env_extra={"CHX_BENCH_FAKE_RATES": "0:1=0.99"})
