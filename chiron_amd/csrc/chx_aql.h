@@ -35,7 +35,7 @@ void chx_aql_join(hipStream_t st);
 extern int chx_aql_open_count;
 
 // ---- any libchx kernel through the queue (round 5, second half: the whole of run() rides on it) ----
-// Packets are outstanding for `st` and the queue takes other kernels than the steps (CHX_AQL_SCOPE=steps: it does not):
+// Packets are outstanding for `st`:
 // a launch that goes to the queue now stays behind them without a join.
 bool chx_aql_active(hipStream_t st);
 // the kernel whose host-side stub is `host_fn` (hipKernelNameRefByPtr -> the code objects' symbol table), or NULL
@@ -48,7 +48,7 @@ int chx_aql_dispatch_any(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 blo
 // The packet just written for `st` -- the list build's summary launch, which only reads what the step kernels read and
 // writes the build's status block -- may run BESIDE the next step packet: that one goes out without the barrier bit (it
 // still starts behind everything in front of the summary, whose own barrier bit held it back until then).  Any other
-// dispatch in between takes the permission away.  CHX_AQL_OVERLAP=0 switches it off.
+// dispatch in between takes the permission away.
 void chx_aql_allow_overlap(hipStream_t st);
 // open the queue for `st` (gate behind the stream's work) without dispatching anything: what follows on the queue-capable
 // entry points then rides on the queue

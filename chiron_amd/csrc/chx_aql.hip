@@ -152,12 +152,11 @@ struct Queue {
 };
 
 constexpr uint32_t QSIZE = 1024;  // packets asked for; the launch window keeps ~a dozen outstanding
-constexpr size_t SLOT = 4096;     // bytes per kernarg slot (the step kernel's block: 320; a batched step's: 8 x 328; any kernel's + 256 implicit)
+constexpr size_t SLOT = 4096;     // bytes per kernarg slot (the step kernel's block: 320; a batched step's: 8 x 304; any kernel's + 256 implicit)
 
 std::mutex g_mu;
 int g_state = 0;  // 0 untried, 1 on, -1 off
 bool g_fence_none = true;
-bool g_scope_run = true;  // every queue-capable launch rides on an open queue (CHX_AQL_SCOPE=steps: the step launches only)
 int g_device = -1;  // the HIP device the queue's agent is (the one current when the queue was set up)
 hsa_agent_t g_gpu{}, g_cpu{};
 hsa_amd_memory_pool_t g_dev_pool{};
@@ -260,8 +259,6 @@ std::string own_dir() {
 bool init_locked() {
   const char* e = getenv("CHX_AQL");
   if (e && e[0] == '0') return fail("off (CHX_AQL=0)"), false;
-  const char* sc = getenv("CHX_AQL_SCOPE");
-  g_scope_run = !(sc && (sc[0] == 's' || sc[0] == 'S'));
   const char* fe = getenv("CHX_AQL_FENCE");
   g_fence_none = !(fe && (fe[0] == 'a' || fe[0] == 'A'));  // "agent": HIP's scopes on every packet
   int dev = 0;
@@ -657,15 +654,14 @@ int dispatch_core(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, con
   // completion signal -- rides on the packet itself, and the join only waits (one packet less between the last wave and
   // the host).  Not on a segment's last slot, whose signal the run-ahead bound needs; any packet that follows takes the
   // shortcut away again (the join then goes the ordinary way; `fin` fires unobserved and is armed anew next time).
-  static const bool final_on = [] { const char* e = getenv("CHX_AQL_FINAL"); return !e || e[0] != '0'; }();
   Q->final_sent = false;
-  if (final_packet && final_on && seg_sig.handle == 0 && Q->fin_unobserved) {
+  if (final_packet && seg_sig.handle == 0 && Q->fin_unobserved) {
     // an earlier packet still owns `fin` (it was followed by other packets, so no join waited for it): re-arming the signal
     // under it would let its completion pass for this packet's.  Done already (value <= 0): the signal is free again;
     // otherwise this launch goes without the shortcut and the join takes the barrier path.
     if (H.hsa_signal_load_scacquire(Q->fin) <= 0) Q->fin_unobserved = false;
   }
-  if (final_packet && final_on && seg_sig.handle == 0 && !Q->fin_unobserved) {
+  if (final_packet && seg_sig.handle == 0 && !Q->fin_unobserved) {
     Q->fin_unobserved = true;
     H.hsa_signal_store_relaxed(Q->fin, 1);
     seg_sig = Q->fin;
@@ -740,8 +736,6 @@ int chx_aql_dispatch_grid(hipStream_t st, const AqlKernel* k, dim3 grid, const v
 }
 
 void chx_aql_allow_overlap(hipStream_t st) {
-  static const bool off = [] { const char* e = getenv("CHX_AQL_OVERLAP"); return e && e[0] == '0'; }();
-  if (off) return;
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_queues.find(st);
   if (it != g_queues.end() && it->second->open) it->second->overlap_ok = true;
@@ -753,7 +747,7 @@ int chx_aql_dispatch_any(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 blo
 }
 
 bool chx_aql_active(hipStream_t st) {
-  if (!g_scope_run || __atomic_load_n(&chx_aql_open_count, __ATOMIC_RELAXED) <= 0 || g_queue_error) return false;
+  if (__atomic_load_n(&chx_aql_open_count, __ATOMIC_RELAXED) <= 0 || g_queue_error) return false;
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_queues.find(st);
   return it != g_queues.end() && it->second->open;
@@ -775,7 +769,7 @@ const AqlKernel* chx_aql_kernel_of(const void* host_fn, hipStream_t st) {
 }
 
 int chx_aql_open(hipStream_t st) {
-  if (!chx_aql_on() || !g_scope_run) return CHX_OK;
+  if (!chx_aql_on()) return CHX_OK;
   Queue* Q = queue_for(st);
   if (!Q || g_queue_error) {
     chx_set_error("%s", g_err);

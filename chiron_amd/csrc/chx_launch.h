@@ -44,10 +44,6 @@ inline int chx_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, hipStream
       return rc;
     }
     chx_aql_join(st);  // (a kernel no loaded code object holds: keep the order at least, then launch through HIP)
-  } else if (__atomic_load_n(&chx_aql_open_count, __ATOMIC_RELAXED) > 0) {
-    // packets are outstanding but the queue does not take this launch (CHX_AQL_SCOPE=steps): a launch on the stream has to
-    // wait for them, like every other entry point's (chx_stream)
-    chx_aql_join(st);
   }
   hipLaunchKernelGGL(kernel, grid, block, 0, st, static_cast<KArgs>(args)...);
   return CHX_OK;

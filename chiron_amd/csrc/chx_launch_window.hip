@@ -307,7 +307,6 @@ int chx_launch_lj_steps_batch(chx_batch_item_t* items, int n_items, int do_aoa, 
         const int t = order[y];
         order[y] = order[y - 1], order[y - 1] = t;
       }
-    static const bool beside_on = [] { const char* e = getenv("CHX_BATCH_BESIDE"); return !e || e[0] != '0'; }();
     for (int oc = 0; oc < ncls; ++oc) {
       const Class& C = cls[order[oc]];
       BatchItem pack[CHX_BATCH_MAX];
@@ -330,7 +329,7 @@ int chx_launch_lj_steps_batch(chx_batch_item_t* items, int n_items, int do_aoa, 
         it.prune = prune_of[r] ? 1 : 0;
         it.pad = 0;
       }
-      const int rc = chx_launch_step_batch(pack, C.count, C.g, C.hot, beside_on && oc > 0, st);
+      const int rc = chx_launch_step_batch(pack, C.count, C.g, C.hot, oc > 0, st);
       if (rc != CHX_OK) return rc;
     }
     for (int r = 0; r < n_items; ++r)

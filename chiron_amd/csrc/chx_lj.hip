@@ -863,12 +863,11 @@ int chx_launch_step(const StepArgs& a, int g, long long step, int n_kicks, int d
     case 2: return launch_step_g<2>(a, step, n_kicks, do_aoa, prune, epoch, st);
     case 4: return launch_step_g<4>(a, step, n_kicks, do_aoa, prune, epoch, st);
     case 8: return launch_step_g<8>(a, step, n_kicks, do_aoa, prune, epoch, st);
-    case 16: return launch_step_g<16>(a, step, n_kicks, do_aoa, prune, epoch, st);
-    case 32: return launch_step_g<32>(a, step, n_kicks, do_aoa, prune, epoch, st);
-    case 64: return launch_step_g<64>(a, step, n_kicks, do_aoa, prune, epoch, st);
     default:
-      chx_set_error("chx_launch_step: unsupported g = %d", g);
-      return CHX_ERR_INVALID;
+      // (round 6: the fused step is instantiated for the lane counts a list builder ever chooses -- the pair-force kernel
+      // alone takes up to 64)
+      chx_set_error("chx_launch_step: unsupported g = %d (the fused step takes 1, 2, 4 or 8 lanes per particle)", g);
+      return CHX_ERR_UNSUPPORTED;
   }
 }
 

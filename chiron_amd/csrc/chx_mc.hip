@@ -487,8 +487,8 @@ extern "C" int chx_mc_displace_chunk(const chx_mc_t* p, int64_t trial0, int32_t 
               "null pointer");
   CHX_REQUIRE(p->keytab && p->keytab_h, "null key table");
   CHX_REQUIRE(p->fl_chunks >= 1, "fl_chunks < 1");
-  CHX_REQUIRE(p->g == 1 || p->g == 2 || p->g == 4 || p->g == 8 || p->g == 16 || p->g == 32 || p->g == 64,
-              "g must be a power of two <= 64");
+  CHX_REQUIRE(p->g == 1 || p->g == 2 || p->g == 4 || p->g == 8,
+              "lanes per particle must be 1, 2, 4 or 8");
   CHX_REQUIRE(!p->box.periodic || (p->box.lx > 0 && p->box.ly > 0 && p->box.lz > 0),
               "box lengths must be > 0");
   if (n_trials == 0) return CHX_OK;
@@ -557,9 +557,7 @@ extern "C" int chx_mc_displace_chunk(const chx_mc_t* p, int64_t trial0, int32_t 
       case 2: launch_trial<2>(a, t, decide, i - 1, st); break;
       case 4: launch_trial<4>(a, t, decide, i - 1, st); break;
       case 8: launch_trial<8>(a, t, decide, i - 1, st); break;
-      case 16: launch_trial<16>(a, t, decide, i - 1, st); break;
-      case 32: launch_trial<32>(a, t, decide, i - 1, st); break;
-      default: launch_trial<64>(a, t, decide, i - 1, st); break;
+      default: launch_trial<8>(a, t, decide, i - 1, st); break;
     }
   }
   a.keyrow = tab + n_trials;

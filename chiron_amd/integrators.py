@@ -41,10 +41,6 @@ _SPECULATIVE_REBUILD = __import__("os").environ.get("CHX_SYNC_REBUILD") != "1"
 # __getattr__).  CHX_RUN_HALF_ROWS=1: write them with every build, as the reference does (A/B, tests).
 _RUN_HALF_ROWS = __import__("os").environ.get("CHX_RUN_HALF_ROWS") == "1"
 _CARRY_VALIDATE = __import__("os").environ.get("CHX_CARRY_VALIDATE", "1") != "0"
-# the step queue's gate goes up at the START of a run() whose list build is enqueued speculatively, so that the build
-# chain rides on the queue too (A/B switch; profiles/r05_step_queue.md)
-_OPEN_AT_START = __import__("os").environ.get("CHX_AQL_OPEN_AT_START", "1") != "0"
-_PARAMS_CACHE = __import__("os").environ.get("CHX_PARAMS_CACHE", "1") != "0"
 _EV_LOG_CAP = 4096
 # List carry-over (LangevinIntegrator(list_carry=...)): a short run() that continues the trajectory of the previous one
 # (same integrator, same list object, the very position tensor that run returned, untouched) starts on the force list its
@@ -314,7 +310,7 @@ class LangevinIntegrator:
         if carried is not None:
             # (no build: _RunState validates the carried force list against x0 on the device -- its pack launch rides on
             # the step queue with the steps, behind one gate)
-            if _OPEN_AT_START and isinstance(x0, torch.Tensor) and x0.is_cuda:
+            if isinstance(x0, torch.Tensor) and x0.is_cuda:
                 _RunState.device_buffers(self, x0.shape[0], x0.device)  # (allocations before the gate: see below)
                 ops.steps_open()
         elif (nbr_list is not None and is_lj and _SPECULATIVE_REBUILD and isinstance(nbr_list, NeighborListNsqrd)
@@ -328,10 +324,9 @@ class LangevinIntegrator:
                 buf = _RunState.device_buffers(self, x0.shape[0], x0.device)
                 pack = (v_in, mass_unitless, None, buf["x_a"], buf["v"], buf["mass"], buf["ref4"])
                 ctrl = buf["ctrl"]
-            if _OPEN_AT_START:
-                # (the build rides on the step queue with the steps: one gate for the whole run(), here -- behind whatever
-                # produced x0 and the velocities on the stream, and behind the allocation of the integrator's buffers above)
-                ops.steps_open()
+            # (the build rides on the step queue with the steps: one gate for the whole run(), here -- behind whatever
+            # produced x0 and the velocities on the stream, and behind the allocation of the integrator's buffers above)
+            ops.steps_open()
             spec0 = nbr_list._build_speculative(x0, publish=False, pack=pack, ctrl=ctrl, copy_positions=True,
                                                 half_rows=_RUN_HALF_ROWS)
             packed0 = bool(spec0) and pack is not None
@@ -939,7 +934,7 @@ class _RunState:
         objs = (self.x_a, self.v, self.f, self.ref4, self.mass, self.ctrl, self.ws, box, self.noise)
         vals = (n, self.mode, wrap, skin, self.half_dt, self.a, self.b, self.kT, lj,
                 self.is_pairlist and self.nbr_list.cutoff is None)
-        cached = self.integ.__dict__.get("_params_cache") if _PARAMS_CACHE else None
+        cached = self.integ.__dict__.get("_params_cache")
         if (cached is not None and cached[1] == vals and len(cached[0]) == len(objs)
                 and all(u is w for u, w in zip(cached[0], objs))):
             p = cached[2]

@@ -468,8 +468,8 @@ def _choose_g(maxdeg: int, n: int) -> int:
     lanes = (1 << 19) if n >= (1 << 18) else ((1 << 18) if (n >= (1 << 16) or maxdeg > 128) else (1 << 17))
     while g < 8 and n * g < lanes:
         g *= 2
-    while g < 64 and maxdeg > 96 * g:  # (96: at rho* = 0.8, N = 262144 four lanes per particle beat eight by 6 %)
-        g *= 2
+    while g < 8 and maxdeg > 96 * g:  # (96: at rho* = 0.8, N = 262144 four lanes per particle beat eight by 6 %)
+        g *= 2  # (never beyond 8: the fused step and Monte Carlo trial kernels are instantiated for 1, 2, 4, 8 -- round 6)
     while g > 1 and g > max(1, maxdeg):
         g //= 2
     return g

@@ -540,20 +540,20 @@ int64_t chx_sizeof_batch_item_t(void);
  * dispatched for `stream` has completed (returns at once when none is outstanding) -- by a barrier packet with a completion
  * signal and a system-scope release, unless the newest packet is a run's LAST launch (chx_langevin_fused_chunk with
  * do_aoa = 0 and p_h->final_x3 set: the launch that also writes the state in user order), which carries both itself
- * (CHX_AQL_FINAL=0: always the barrier packet).  Every libchx entry point that
+ * .  Every libchx entry point that
  * launches on a stream joins first, so libchx calls always see one ordered stream; only work the CALLER enqueues on
  * `stream` by other means (its own kernels, copies, events) needs an explicit chx_steps_join in front when it depends on
  * the steps.  The kernels are loaded from libchx_step.hsaco (required) and libchx_k_*.hsaco (one per translation unit
  * whose kernels may ride on the queue; optional) beside the library (same sources, same flags as the copies inside it).
  * When the queue cannot be set up (file missing, HSA runtime not found, CHX_AQL=0) the launches go through HIP as in
- * ABI 3; chx_step_queue_status() says why.  CHX_AQL_SCOPE=steps keeps the queue to the step launches. */
+ * ABI 3; chx_step_queue_status() says why. */
 int chx_steps_join(chx_stream_t stream);
 /* Open the queue for `stream` without dispatching a step: the gate goes up behind everything enqueued on `stream` so far,
  * and from here to the next chx_steps_join the queue-capable entry points -- chx_unpack_langevin, chx_permute_unpack,
  * chx_cell_bin_fl, chx_nl_rows_cell_fl, chx_nl_build_cell_fl, chx_pack_langevin, chx_pack_validate_langevin,
  * chx_validate_snap (chx_mc_displace_chunk opens the queue by itself) -- write their launches as packets behind it instead of launching on the stream (they do so whenever
  * packets are outstanding: that is how a list rebuild inside a run stays behind the steps without a join).  A no-op when
- * the queue is off or restricted to the step launches (CHX_AQL_SCOPE=steps). */
+ * the queue is off. */
 int chx_steps_open(chx_stream_t stream);
 /* out8_h = {queue usable (0 / 1), release scope of a steady-state packet (0 none, 1 agent, -1 off), kernel names in the
  * code objects, packets dispatched for `stream`, joins, gates (stream -> queue hand-overs through a marker launch),

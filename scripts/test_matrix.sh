@@ -8,15 +8,14 @@ mkdir -p gpurun_out
 first=${1:-0}; count=${2:-100}; k=0
 log=gpurun_out/test_matrix_$first.log
 : > $log
-for env in "CHX_AQL=0" "CHX_AQL_FENCE=agent" "CHX_AQL=0 CHX_LAUNCH_WINDOW=3" "CHX_AQL_FENCE=agent CHX_FL_G=8" "CHX_SYNC_REBUILD=1" "CHX_LAUNCH_WINDOW=1" "CHX_LAUNCH_WINDOW=3 CHX_FL_G=2" "CHX_LAUNCH_WINDOW=500" "CHX_MC_DECIDE_LAUNCH=1" \
-           "CHX_BUILD_KERNEL=cell" "CHX_BUILD_KERNEL=cell CHX_BUILD_SPLIT=3" "CHX_BUILD_KERNEL=particle" \
-           "CHX_FL_G=1" "CHX_FL_G=8" "CHX_FL_G=16" "CHX_FL_G=64" "CHX_PRUNE_EVERY=0" "CHX_PRUNE_EVERY=1" \
-           "CHX_PRUNE_EVERY=7 CHX_INNER_SKIN=0.02" "CHX_PRUNE_EVERY=50 CHX_INNER_SKIN=0.3" \
-           "CHX_POLL=spin" "CHX_POLL_SLEEP_NS=50000" "CHX_POLL_TIMERSLACK=0" \
-           "CHX_PIN_CPUS=0" "CHX_LIST_CARRY=0" "CHX_LIST_CARRY_MAX_STEPS=100000" "CHX_BUILD_LISTS=0" \
-           "CHX_RUN_HALF_ROWS=1 CHX_BUILD_SLOTS=0" "CHX_BUILD_SLOTS=0" "CHX_MC_INNER_SKIN=0" "CHX_MC_INNER_SKIN=0.03" \
-           "CHX_CARRY_VALIDATE=0 CHX_PARAMS_CACHE=0" \
-           "CHX_AQL_SCOPE=steps" "CHX_AQL_OPEN_AT_START=0" "CHX_AQL_OVERLAP=0 CHX_AQL_SELFCHECK=0" "CHX_BUILD_SUB=0" "CHX_AQL_FINAL=0"; do
+# (round 6: the queue's narrower modes -- steps only, gate at the first step, plain join, no overlap --, the parameter-cache
+# switch and the lane counts 16 / 64 of the fused kernels are gone with their switches; what is left is what a user or a
+# maintainer can still reach)
+for env in "CHX_AQL=0" "CHX_AQL_FENCE=agent" "CHX_QUEUE_DEBUG=250" "CHX_AQL=0 CHX_LAUNCH_WINDOW=3" "CHX_SYNC_REBUILD=1" "CHX_LAUNCH_WINDOW=1" \
+           "CHX_LAUNCH_WINDOW=500" "CHX_FL_G=1" "CHX_FL_G=2 CHX_LAUNCH_WINDOW=3" "CHX_FL_G=8" "CHX_PRUNE_EVERY=0" "CHX_PRUNE_EVERY=1" \
+           "CHX_PRUNE_EVERY=7 CHX_INNER_SKIN=0.02" "CHX_PRUNE_EVERY=50 CHX_INNER_SKIN=0.3" "CHX_POLL=spin" "CHX_PIN_CPUS=0" \
+           "CHX_LIST_CARRY=0" "CHX_LIST_CARRY_MAX_STEPS=100000" "CHX_BUILD_KERNEL=cell" "CHX_BUILD_LISTS=0" "CHX_BUILD_SUB=0" \
+           "CHX_RUN_HALF_ROWS=1 CHX_BUILD_SLOTS=0" "CHX_MC_INNER_SKIN=0" "CHX_CARRY_VALIDATE=0"; do
   k=$((k + 1))
   if [ $k -le $first ] || [ $k -gt $((first + count)) ]; then continue; fi
   echo "== $env" | tee -a $log

@@ -34,7 +34,7 @@ print("RESULT " + json.dumps({"hash": h, "rebuilds": rebuilds, "queue": ops.step
 
 def _run(env_extra, workload, steps):
     env = dict(os.environ)
-    for k in ("CHX_AQL", "CHX_AQL_FENCE", "CHX_AQL_SCOPE", "CHX_AQL_OPEN_AT_START", "CHX_AQL_FINAL", "CHX_BUILD_SUB", "CHX_QUEUE_DEBUG"):
+    for k in ("CHX_AQL", "CHX_AQL_FENCE", "CHX_BUILD_SUB", "CHX_QUEUE_DEBUG"):
         env.pop(k, None)
     env.update(env_extra)
     out = subprocess.run([sys.executable, "-c", _TRAJECTORY, workload, str(steps)], capture_output=True, text=True, timeout=600,
@@ -46,32 +46,23 @@ def _run(env_extra, workload, steps):
 
 @pytest.mark.parametrize("workload,steps", [("c3", 3000), ("c4", 600)], ids=["c3-32768", "c4-262144"])
 def test_step_queue_and_its_fence_modes_leave_every_bit_of_the_trajectory(workload, steps):
-    """(Seven fresh processes per workload.)  One trajectory from the bench's own start -- thousands of steps with list rebuilds and inner-list refreshes, then
-    short runs on carried-over lists -- in fresh processes: plain HIP launches (CHX_AQL=0), the step queue with
-    HIP's agent-scope fences on every packet (CHX_AQL_FENCE=agent), and the default (steady-state packets carry no
-    fences: their outputs are write-through stores, and what they read was written through or released).  A single
-    stale read anywhere -- an L1, scalar-cache or L2 line that survived a dispatch, a store still dirty in one XCD's L2
-    -- changes the hash."""
+    """(Four fresh processes per workload.)  One trajectory from the bench's own start -- thousands of steps with list
+    rebuilds and inner-list refreshes, then short runs on carried-over lists -- in fresh processes: plain HIP launches
+    (CHX_AQL=0), the step queue with HIP's agent-scope fences on every packet (CHX_AQL_FENCE=agent), and the default
+    (steady-state packets carry no fences: their outputs are write-through stores, and what they read was written through
+    or released).  A single stale read anywhere -- an L1, scalar-cache or L2 line that survived a dispatch, a store still
+    dirty in one XCD's L2 -- changes the hash.  (Round 6 retired the queue's narrower modes -- steps only, gate at the first
+    step, the join that always sends its own barrier packet -- together with their switches.)"""
     hip = _run({"CHX_AQL": "0"}, workload, steps)
     fenced = _run({"CHX_AQL_FENCE": "agent"}, workload, steps)
     bare = _run({}, workload, steps)
-    # ... and the two narrower uses of the queue: the step launches only (a rebuild joins and goes through HIP), and the
-    # gate at the first step instead of at the start of run() (the run-start build goes through HIP)
-    steps_only = _run({"CHX_AQL_SCOPE": "steps"}, workload, steps)
-    late_gate = _run({"CHX_AQL_OPEN_AT_START": "0"}, workload, steps)
-    # ... the join that always sends its own barrier packet (by default the launch that ends a run() carries the join's
-    # completion signal and system-scope release itself), and -- not a queue mode, but the same question -- the rebuilds'
-    # general row kernels instead of the filtered sixteen-lanes-per-row one: every force list of the trajectory, on the
-    # clustered fluid, must come out the same bits or the summation order of some force changes
-    plain_join = _run({"CHX_AQL_FINAL": "0"}, workload, steps)
+    # ... and -- not a queue mode, but the same question -- the rebuilds' general row kernels instead of the filtered
+    # sixteen-lanes-per-row one: every force list of the trajectory, on the clustered fluid, must come out the same bits or
+    # the summation order of some force changes
     old_rows = _run({"CHX_BUILD_SUB": "0"}, workload, steps)
-    assert plain_join["hash"] == old_rows["hash"] == bare["hash"], (plain_join, old_rows, bare)
-    assert old_rows["rebuilds"] == bare["rebuilds"] and plain_join["queue"]["joins"] == bare["queue"]["joins"]
+    assert old_rows["hash"] == bare["hash"], (old_rows, bare)
+    assert old_rows["rebuilds"] == bare["rebuilds"]
     opened = lambda r: r["queue"]["gates"] + r["queue"]["idle_opens"]  # (through a marker launch / on an idle stream)
-    assert steps_only["hash"] == late_gate["hash"] == hip["hash"], (steps_only, late_gate, hip)
-    # (steps only: an opening per rebuild -- unless every rebuild is a synchronous one anyway, CHX_SYNC_REBUILD=1)
-    assert steps_only["queue"]["on"] and opened(steps_only) >= opened(bare)
-    assert opened(steps_only) > opened(bare) or os.environ.get("CHX_SYNC_REBUILD") == "1"
     assert not hip["queue"]["on"] and hip["queue"]["dispatched"] == 0
     assert fenced["queue"]["on"] and fenced["queue"]["hot_release"] == "agent"
     assert bare["queue"]["on"] and bare["queue"]["hot_release"] == "none", bare["queue"]
@@ -111,10 +102,7 @@ def test_step_queue_orders_with_the_stream_it_is_paired_with():
     torch.cuda.synchronize()
     state3, nbr = integ.run(state2, thermo, number_of_steps=30, nbr_list=nbr)
     info2 = ops.step_queue_info()
-    if os.environ.get("CHX_AQL_SCOPE", "run")[0] not in "sS" and os.environ.get("CHX_AQL_OPEN_AT_START", "1") != "0":
-        assert info2["idle_opens"] > info1["idle_opens"] and info2["gates"] == info1["gates"]
-    else:  # (the run-start build went through HIP: the first step packet found the stream busy and waited at a gate)
-        assert info2["gates"] + info2["idle_opens"] > info1["gates"] + info1["idle_opens"]
+    assert info2["idle_opens"] > info1["idle_opens"] and info2["gates"] == info1["gates"]
     assert torch.isfinite(state3.positions).all()
     assert torch.isfinite(state2.positions).all() and not torch.equal(state2.positions, x1)
 

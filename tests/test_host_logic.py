@@ -1085,13 +1085,18 @@ def test_step_code_object_is_current_and_holds_every_step_kernel():
         elif line.startswith(".name:") and size is not None:
             sizes[line.split(":", 1)[1].strip()] = size
             size = None
-    for g in (1, 2, 4, 8, 16, 32, 64):
+    for g in (1, 2, 4, 8):  # (the lane counts a list builder chooses; round 6 dropped 16 / 32 / 64 from the fused kernels)
         for hot in (0, 1):
             for prune in (0, 1):
                 for defer in (0, 1):
                     names = [n for n in sizes if n.startswith(f"_Z9k_lj_stepILi{g}ELb{hot}ELb{prune}ELb{defer}EE")]
                     assert len(names) == 1, (g, hot, prune, defer)
                     assert sizes[names[0]] == 320
+            # the batched launch (several replicas in one grid): CHX_BATCH_MAX = 8 items of 304 bytes
+            names = [n for n in sizes if n.startswith(f"_Z15k_lj_step_batchILi{g}ELb{hot}EE")]
+            assert len(names) == 1, (g, hot)
+            assert sizes[names[0]] == 8 * 304, sizes[names[0]]
+    assert not [n for n in sizes if n.startswith("_Z9k_lj_stepILi16E") or n.startswith("_Z9k_lj_stepILi64E")]
     # the units whose kernels ride on the queue while a run() is in progress (csrc/chx_launch.h): unpack, the list build
     # chain, pack -- one code object each, every kernel the rebuild launches present
     want = {"core": ["k_unpack_langevin", "k_permute_unpack"],
