@@ -457,6 +457,7 @@ def c5_one_gpu_block(args):
         fluid, pot, state, thermo, nbr, integ = make_system(args.workload, 300.0 * (1.05 ** k), args.chunk, args.build)
         integ.list_carry = False
         state.current_PRNG_key = PRNGKey(1234, k)
+        nbr.set_replicas_sharing_card(K)  # (what MultiStateSampler tells its lists: lanes per particle for K x N in flight)
         reps.append([integ, state, thermo, nbr, pot, fluid])
     n = reps[0][5].n_particles
     own_group = False
@@ -568,7 +569,8 @@ def c5_one_gpu_block(args):
             "collective_backend": backend, "group_world_size": dist.get_world_size(), "replicas_per_rank": rex.replicas_per_rank,
             "swap_acceptance": float(rex.n_accepted.sum() / max(1, rex.n_proposed.sum())),
             "state_of_replica": [int(v) for v in rex.state_of_replica],
-            "kernel": "k_lj_step_batch<4, true> (the fused step of every replica in one grid: blockIdx.y = replica)",
+            "kernel": f"k_lj_step_batch<{reps[0][3].force_list.g}, true> (the fused step of every replica in one grid: blockIdx.y = replica)",
+            "lanes_per_particle": reps[0][3].force_list.g,
             "kernel_us": round(1e6 * t_k, 3), "kernel_us_samples": [round(1e6 * v, 3) for v in samples],
             "algorithmic_bytes": algorithmic, "list_pairs_all_replicas": p_nl,
             "achieved": round(algorithmic / t_k / 1e9, 2), "frac": round(algorithmic / t_k / 1e9 / HBM_PEAK_GBS, 5),

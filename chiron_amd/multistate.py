@@ -263,6 +263,10 @@ class MultiStateSampler:
         assert len(self._thermodynamic_states) == len(self._nbr_lists)
         for nbr_list, state in zip(self._nbr_lists, self._sampler_states):
             if nbr_list is not None:
+                # (a speed hint: these replicas share one card -- the same in the serial and the batched loop, so that the
+                # two stay bit-identical)
+                if hasattr(nbr_list, "set_replicas_sharing_card") and getattr(state.positions, "is_cuda", False):
+                    nbr_list.set_replicas_sharing_card(len(self._nbr_lists))
                 nbr_list.build(state.positions, state.box_vectors)
         K = len(thermodynamic_states)
         self._replica_thermodynamic_states = np.arange(K, dtype=int)

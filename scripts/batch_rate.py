@@ -21,6 +21,8 @@ def make(k):
     fluid, pot, state, thermo, nbr, integ = bench.make_system(wl, 300.0 * 1.05 ** k, 32, "cell")
     integ.list_carry = False
     state.current_PRNG_key = PRNGKey(1234, k)
+    if os.environ.get("BATCH_HINT", "1") != "0":
+        nbr.set_replicas_sharing_card(R)  # (what MultiStateSampler tells its lists)
     return [integ, state, thermo, nbr]
 
 
