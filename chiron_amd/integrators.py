@@ -615,6 +615,10 @@ def _advance_batch(sts, n_steps: int, window: int, chunk: int) -> None:
                         pre()
             if not _skip_join_hook():
                 ops.steps_join()
+                if not ops.step_queue_on():
+                    # (plain HIP launches, CHX_AQL=0: the launches are on the stream, and what follows reads the halt words
+                    # on the host -- _RunState._wait_for_launches does the same)
+                    torch.cuda.current_stream().synchronize()
             for st in sts:
                 st.integ._graveyard = None
         # ---- what the device found: rejected speculative builds, halt words ----
