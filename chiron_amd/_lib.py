@@ -218,6 +218,7 @@ SIGNATURES = {
     "chx_step_queue_info": (C.c_int, [C.POINTER(_I64), _P]),
     "chx_step_queue_status": (C.c_char_p, []),
     "chx_step_queue_selfcheck": (C.c_int, [_P]),
+    "chx_step_queue_selfcheck_runs": (_I64, []),
     "chx_queue_debug": (C.c_int, [_I32]),
     "chx_queue_debug_spins": (_I64, []),
     "chx_ctrl_reset": (C.c_int, [_P, _P]),

@@ -149,6 +149,7 @@ struct Queue {
   hsa_signal_t seg_sig[MAXSEG];
   bool seg_used[MAXSEG];
   uint64_t n_dispatched = 0, n_joins = 0, n_gates = 0, n_idle_opens = 0;
+  uint64_t checked_at = 0;  // n_dispatched when the fence-free packets' assumption was last checked on this queue
 };
 
 constexpr uint32_t QSIZE = 1024;  // packets asked for; the launch window keeps ~a dozen outstanding
@@ -341,6 +342,7 @@ bool init_locked() {
 
 bool g_selfchecked = false;
 int g_selfcheck_result = -1;  // -1 not run, 0 passed, > 0 stale words seen (fences switched back on)
+int64_t g_selfcheck_runs = 0;  // times the check has run in this process
 
 // forward: the packet helpers below
 uint64_t reserve(Queue* Q, hsa_signal_t* completion);
@@ -393,16 +395,23 @@ void selfcheck_fences(Queue* Q, hipStream_t st, bool again = false) {
   const AqlKernel* kf = name_of(chx_selfcheck_fill_fn());
   const AqlKernel* kr = name_of(chx_selfcheck_read_fn());
   if (!kf || !kr) return;  // (libchx_k_core.hsaco absent: nothing to run the check with)
-  int32_t* mem = nullptr;
-  if (H.hsa_amd_memory_pool_allocate(g_dev_pool, 8192, 0, reinterpret_cast<void**>(&mem)) != HSA_STATUS_SUCCESS) return;
-  if (H.hsa_amd_agents_allow_access(1, &g_cpu, nullptr, mem) != HSA_STATUS_SUCCESS) return;
+  // (the check's 8 KB and its signal are made once and kept: the check comes back -- chx_step_queue_selfcheck, and every
+  // RECHECK_EVERY packets of a queue)
+  static int32_t* mem = nullptr;
+  static hsa_signal_t done{0};
+  if (mem == nullptr) {
+    int32_t* m = nullptr;
+    if (H.hsa_amd_memory_pool_allocate(g_dev_pool, 8192, 0, reinterpret_cast<void**>(&m)) != HSA_STATUS_SUCCESS) return;
+    if (H.hsa_amd_agents_allow_access(1, &g_cpu, nullptr, m) != HSA_STATUS_SUCCESS) return;
+    if (H.hsa_signal_create(1, 0, nullptr, &done) != HSA_STATUS_SUCCESS) return;
+    mem = m;
+  }
   int32_t* buf = mem;
   int32_t* bad = mem + 1536;  // (its own 128-byte lines, away from the 4 KB under test)
   bad[0] = bad[1] = 0;
   store_fence();
   (void)*reinterpret_cast<volatile int32_t*>(bad + 1);
-  hsa_signal_t done;
-  if (H.hsa_signal_create(1, 0, nullptr, &done) != HSA_STATUS_SUCCESS) return;
+  H.hsa_signal_store_relaxed(done, 1);
   const int rounds = 256;
   for (int i = 0; i < rounds; ++i) {
     struct { int32_t* b; int v; } fa = {buf, i + 1};
@@ -415,6 +424,7 @@ void selfcheck_fences(Queue* Q, hipStream_t st, bool again = false) {
   if (!wait_zero(done, "the start-up check of the step queue did not finish")) return;
   const int stale = reinterpret_cast<volatile int32_t*>(bad)[0] + reinterpret_cast<volatile int32_t*>(bad)[1];
   g_selfcheck_result = stale;
+  g_selfcheck_runs++;
   if (stale != 0) {
     g_fence_none = false;
     snprintf(g_err, sizeof(g_err), "step queue: the start-up check read %d stale words behind acquire-less dispatches: every packet "
@@ -800,6 +810,20 @@ void chx_aql_join(hipStream_t st) {
   Q->open = false;
   Q->n_joins++;
   __atomic_fetch_sub(&chx_aql_open_count, 1, __ATOMIC_RELAXED);
+  // The assumption the fence-free packets rest on -- checked when the process opened its first queue -- is checked AGAIN
+  // every RECHECK_EVERY packets of a queue, here, with the queue drained (a millisecond per ~5 s of stepping): a card that
+  // is shared with other processes, a clock or firmware state that changed under a long run.  One stale word switches
+  // every later packet of the process to HIP's agent-scope fences (chx_step_queue_status says so).
+  static const uint64_t RECHECK_EVERY = [] {
+    const char* e = getenv("CHX_AQL_RECHECK_EVERY");  // (tests: a short period)
+    const long long v = e ? atoll(e) : 0;
+    return v > 0 ? (uint64_t)v : (1ull << 20);
+  }();
+  if (g_fence_none && g_selfcheck_result == 0 && Q->n_dispatched - Q->checked_at >= RECHECK_EVERY) {
+    Q->checked_at = Q->n_dispatched;
+    std::lock_guard<std::mutex> lk(g_mu);  // (the check's buffer and signal are shared by the process's queues)
+    selfcheck_fences(Q, st, true);
+  }
 }
 
 // ---- C ABI (include/chx.h) ----
@@ -836,9 +860,14 @@ extern "C" int chx_step_queue_selfcheck(chx_stream_t stream) {
   if (!Q || g_queue_error) return -1;
   if (!g_fence_none) return g_selfcheck_result > 0 ? g_selfcheck_result : -1;  // (fences are on: nothing rests on the assumption)
   g_selfcheck_result = -1;
-  selfcheck_fences(Q, st, true);
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    selfcheck_fences(Q, st, true);
+  }
+  Q->checked_at = Q->n_dispatched;
   return g_selfcheck_result;
 }
+extern "C" int64_t chx_step_queue_selfcheck_runs(void) { return g_selfcheck_runs; }
 extern "C" int chx_queue_debug(int32_t delay_us) {
   const int old = g_debug_delay_us;
   if (delay_us >= 0) g_debug_delay_us = delay_us;

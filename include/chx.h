@@ -565,8 +565,10 @@ const char* chx_step_queue_status(void);
  * acquire = release = NONE on every packet, about a millisecond.  Returns the number of stale words read (0 = the
  * assumption holds on this card now; > 0: every later packet of the process carries agent-scope fences), -1 when the
  * queue is off, already fenced, or the check's kernels are not loaded.  The first queue of a process runs it once by
- * itself; a long-lived process that shares its card with others may want to ask again (bench.py does, at its end). */
+ * itself, and every queue repeats it by itself every 2^20 packets, at a join (a millisecond per ~5 s of stepping); a
+ * caller may ask at any other time (bench.py does, at its end). */
 int chx_step_queue_selfcheck(chx_stream_t stream);
+int64_t chx_step_queue_selfcheck_runs(void); /* times the check has run in this process (start-up, periodic, on demand) */
 /* Debug mode of the step queue (ABI 5; CHX_QUEUE_DEBUG=<microseconds> in the environment sets the initial value).  With a
  * delay > 0 the queue puts a packet that idles that long (one lane watching the wall clock; at most a second) in front of
  * the first packet behind every gate, of every packet that is not a fused step / Monte Carlo trial launch (unpack, the

@@ -28,13 +28,15 @@ torch.cuda.synchronize()
 h = hashlib.sha256(state.positions.cpu().numpy().tobytes() + state.velocities.cpu().numpy().tobytes()
                    + nbr.ref_positions.cpu().numpy().tobytes()).hexdigest()
 print("RESULT " + json.dumps({"hash": h, "rebuilds": rebuilds, "queue": ops.step_queue_info(),
-                              "carried": getattr(integ, "n_carried_runs", 0), "idle_packets": ops.queue_debug_spins()}))
+                              "carried": getattr(integ, "n_carried_runs", 0), "idle_packets": ops.queue_debug_spins(),
+                              "fence_checks": int(ops._lib.load().chx_step_queue_selfcheck_runs()),
+                              "status": ops.step_queue_info()["status"]}))
 """ % ROOT
 
 
 def _run(env_extra, workload, steps):
     env = dict(os.environ)
-    for k in ("CHX_AQL", "CHX_AQL_FENCE", "CHX_BUILD_SUB", "CHX_QUEUE_DEBUG"):
+    for k in ("CHX_AQL", "CHX_AQL_FENCE", "CHX_BUILD_SUB", "CHX_QUEUE_DEBUG", "CHX_AQL_RECHECK_EVERY"):
         env.pop(k, None)
     env.update(env_extra)
     out = subprocess.run([sys.executable, "-c", _TRAJECTORY, workload, str(steps)], capture_output=True, text=True, timeout=600,
@@ -226,3 +228,17 @@ def test_a_missing_join_reads_poison_every_time(path):
             assert integ.n_carried_runs >= 10  # (the runs under test did start on carried lists)
     finally:
         ops.queue_debug(old)
+
+
+def test_the_fence_free_assumption_is_checked_again_while_a_process_lives():
+    """The steady-state packets carry no cache fences on the strength of a check the process's first queue runs once
+    (csrc/chx_aql.hip: selfcheck_fences).  Round-5 review: nothing re-checked later -- under another process on the card,
+    after a clock or firmware state change.  Every queue now repeats the check every 2^20 packets, at a join; with the
+    period shortened to 1500 packets a 3000-step trajectory runs it several times, still reports no stale word, keeps its
+    fence-free packets and produces the plain run's bits."""
+    plain = _run({}, "c3", 3000)
+    often = _run({"CHX_AQL_RECHECK_EVERY": "1500"}, "c3", 3000)
+    assert plain["fence_checks"] == 1, plain
+    assert often["fence_checks"] >= 3, often
+    assert often["status"] == "" and often["queue"]["hot_release"] == "none", often
+    assert often["hash"] == plain["hash"]
