@@ -234,10 +234,10 @@ def test_the_fence_free_assumption_is_checked_again_while_a_process_lives():
     """The steady-state packets carry no cache fences on the strength of a check the process's first queue runs once
     (csrc/chx_aql.hip: selfcheck_fences).  Round-5 review: nothing re-checked later -- under another process on the card,
     after a clock or firmware state change.  Every queue now repeats the check every 2^20 packets, at a join; with the
-    period shortened to 1500 packets a 3000-step trajectory runs it several times, still reports no stale word, keeps its
-    fence-free packets and produces the plain run's bits."""
+    period shortened to 25 packets the trajectory's five run() calls run it again at three of their joins (the 3000-, the
+    20- and the 100-step call), still report no stale word, keep their fence-free packets and produce the plain run's bits."""
     plain = _run({}, "c3", 3000)
-    often = _run({"CHX_AQL_RECHECK_EVERY": "1500"}, "c3", 3000)
+    often = _run({"CHX_AQL_RECHECK_EVERY": "25"}, "c3", 3000)
     assert plain["fence_checks"] == 1, plain
     assert often["fence_checks"] >= 3, often
     assert often["status"] == "" and often["queue"]["hot_release"] == "none", often
