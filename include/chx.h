@@ -539,9 +539,8 @@ int64_t chx_sizeof_batch_item_t(void);
  * `stream` sets; no marker when hipStreamQuery finds the stream idle) for everything enqueued on `stream` before it; chx_steps_join waits ON THE HOST until every packet
  * dispatched for `stream` has completed (returns at once when none is outstanding) -- by a barrier packet with a completion
  * signal and a system-scope release, unless the newest packet is a run's LAST launch (chx_langevin_fused_chunk with
- * do_aoa = 0 and p_h->final_x3 set: the launch that also writes the state in user order), which carries both itself
- * .  Every libchx entry point that
- * launches on a stream joins first, so libchx calls always see one ordered stream; only work the CALLER enqueues on
+ * do_aoa = 0 and p_h->final_x3 set: the launch that also writes the state in user order), which carries both itself.
+ * Every libchx entry point that launches on a stream joins first, so libchx calls always see one ordered stream; only work the CALLER enqueues on
  * `stream` by other means (its own kernels, copies, events) needs an explicit chx_steps_join in front when it depends on
  * the steps.  The kernels are loaded from libchx_step.hsaco (required) and libchx_k_*.hsaco (one per translation unit
  * whose kernels may ride on the queue; optional) beside the library (same sources, same flags as the copies inside it).
