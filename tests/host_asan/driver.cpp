@@ -225,6 +225,36 @@ int main() {
     EXPECT_INVALID(chx_langevin_fused_run(&lp, F, F, 7, 5, 2, 4, &sent, nullptr));
     lp.host_ctrl = I;
   }
+  // several replicas per launch (ABI 5): the argument checks run before anything touches a device
+  {
+    chx_batch_item_t items[2];
+    memset(items, 0, sizeof(items));
+    EXPECT_INVALID(chx_langevin_batch_run(nullptr, 1, 4, nullptr));
+    EXPECT_INVALID(chx_langevin_batch_run(items, 0, 4, nullptr));
+    EXPECT_INVALID(chx_langevin_batch_run(items, 1, 4, nullptr));  // null parameter block
+    lp.g = 4;
+    items[0].p = &lp, items[0].x_even = F, items[0].x_odd = F, items[0].n_steps = 1, items[0].kicks_first = 1;
+    EXPECT_INVALID(chx_langevin_batch_run(items, 1, 4, nullptr));  // one position buffer for both parities
+    items[0].x_odd = F + 16;
+    items[1] = items[0];
+    EXPECT_INVALID(chx_langevin_batch_run(items, 2, 4, nullptr));  // two items on one control block
+    EXPECT_INVALID(chx_langevin_batch_run(items, 1, 0, nullptr));  // window < 1
+    items[0].kicks_first = 3;
+    EXPECT_INVALID(chx_langevin_batch_kick(items, 1, nullptr));
+    items[0].kicks_first = 1;
+    lp.g = 16;
+    EXPECT_INVALID(chx_langevin_batch_run(items, 1, 4, nullptr));  // lane counts above 8 are not instantiated
+    lp.g = 3;
+    EXPECT(chx_sizeof_batch_item_t() == (int64_t)sizeof(chx_batch_item_t));
+  }
+  // the queue's debug mode and the on-demand fence check without a GPU: a setting, and "not applicable"
+  {
+    const int old = chx_queue_debug(-1);
+    EXPECT(chx_queue_debug(125) == old && chx_queue_debug(old) == 125);
+    EXPECT(chx_queue_debug_spins() == 0);
+    EXPECT(chx_step_queue_selfcheck(nullptr) == -1);
+    EXPECT(chx_step_queue_selfcheck_runs() == 0);
+  }
   EXPECT_INVALID(chx_mc_displace_chunk(nullptr, 0, 1, nullptr));
   chx_mc_t mp;
   memset(&mp, 0, sizeof(mp));
