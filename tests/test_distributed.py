@@ -402,3 +402,90 @@ def test_bench_refuses_to_become_a_multi_rank_launcher_under_a_profiler():
         assert out.returncode == 2, (out.returncode, out.stderr[-1500:])
         assert "under a profiler" in out.stderr and "launcher" in out.stderr
         assert out.stdout.strip() == ""  # no rank ran, no JSON line
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 6: K thermodynamic states over W ranks (a rank propagates its K / W replicas side by side)
+# ---------------------------------------------------------------------------------------------------------------------
+def _worker_many(rank: int, world: int, port: int, out_dir: str, k_states: int):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rex = ReplicaExchange(_ladder(k_states), PRNGKey(11, 22))
+        per = k_states // world
+        assert rex.replicas_per_rank == per and list(rex.my_replicas) == list(range(rank * per, (rank + 1) * per))
+        maps, scales = [], []
+        for it in range(6):
+            mine = torch.tensor([-100.0 * (r + 1) + 7.0 * it * ((r % 3) - 1) for r in rex.my_replicas], dtype=torch.float32)
+            moves = rex.exchange_many(mine)
+            assert [m[0] for m in moves] == rex.my_state_indices
+            maps.append(rex.state_of_replica.copy())
+            scales.append([m[1] for m in moves])
+        np.save(os.path.join(out_dir, f"maps_{rank}.npy"), np.array(maps))
+        np.save(os.path.join(out_dir, f"scales_{rank}.npy"), np.array(scales))
+        np.save(os.path.join(out_dir, f"ukn_{rank}.npy"), rex.u_kn)
+        with pytest.raises(RuntimeError):
+            rex.exchange(torch.tensor([1.0]))  # (several replicas on this rank: the one-replica call refuses)
+        with pytest.raises(ValueError):
+            rex.gather_energies(torch.zeros(per + 1))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replica_exchange_eight_states_over_two_ranks_gloo(tmp_path):
+    """BASELINE's C5 has K = W = 8; with fewer cards a rank owns K / W replicas and contributes K / W energies to the one
+    all-gather.  Two ranks, eight states: both ranks reach the same maps, which are the serial rule's on the gathered
+    matrix; every rank's velocity scales are those of ITS replicas' moves."""
+    world, K = 2, 8
+    port = _free_port()
+    mp.spawn(_worker_many, args=(world, port, str(tmp_path), K), nprocs=world, join=True)
+    m0, m1 = np.load(tmp_path / "maps_0.npy"), np.load(tmp_path / "maps_1.npy")
+    assert np.array_equal(m0, m1) and np.array_equal(np.load(tmp_path / "ukn_0.npy"), np.load(tmp_path / "ukn_1.npy"))
+    betas = np.array([1.0 / (8.31446261815324e-3 * 300.0 * 1.5 ** r) for r in range(K)])
+    cur = np.arange(K)
+    key = PRNGKey(11, 22)
+    temps = [300.0 * 1.5 ** r for r in range(K)]
+    scales = np.concatenate([np.load(tmp_path / "scales_0.npy"), np.load(tmp_path / "scales_1.npy")], axis=1)
+    swapped = 0
+    for it in range(6):
+        e = np.array([np.float32(-100.0 * (r + 1) + 7.0 * it * ((r % 3) - 1)) for r in range(K)], dtype=np.float64)
+        u = e[:, None] * betas[None, :]
+        new, _, _ = neighbor_swap_decisions(u, cur, it, key)
+        assert sorted(new) == list(range(K)) and np.array_equal(new, m0[it])
+        for r in range(K):
+            want = np.sqrt(temps[new[r]] / temps[cur[r]]) if new[r] != cur[r] else 1.0
+            assert np.isclose(scales[it][r], want)
+            swapped += int(new[r] != cur[r])
+        cur = new
+    assert swapped >= 4  # (the colder replicas sit in the deeper basins: downhill swaps happen)
+
+
+def test_batchable_samplers_and_fallbacks():
+    """What MultiStateSampler may step side by side (chiron_amd.mcmc.MCMCSampler.batchable; no GPU involved): schedules of
+    Langevin moves only, the same step counts in each, no reporters, one sampler per replica; anything else keeps the
+    reference's serial loop.  ``batch_applies`` turns CPU tensors away, so on this box ``run_batch`` is the serial calls."""
+    from chiron_amd.integrators import LangevinIntegrator, batch_applies
+    from chiron_amd.mcmc import LangevinDynamicsMove, MCMCSampler, MonteCarloDisplacementMove, MoveSchedule
+    from chiron_amd.states import SamplerState
+
+    def sampler(steps=10, extra=None, reporter=None):
+        sched = [("l", LangevinDynamicsMove(number_of_steps=steps, reporter=reporter))]
+        if extra is not None:
+            sched.append(("x", extra))
+        return MCMCSampler(MoveSchedule(sched))
+
+    assert MCMCSampler.batchable([sampler(), sampler(), sampler()])
+    assert not MCMCSampler.batchable([sampler()])                      # one replica: nothing to batch
+    same = sampler()
+    assert not MCMCSampler.batchable([same, same])                     # one sampler object for two replicas
+    assert not MCMCSampler.batchable([sampler(10), sampler(11)])       # different step counts
+    assert not MCMCSampler.batchable([sampler(), sampler(extra=MonteCarloDisplacementMove(number_of_moves=2))])
+    assert not MCMCSampler.batchable([sampler(extra=MonteCarloDisplacementMove(number_of_moves=2)) for _ in range(2)])
+    assert not MCMCSampler.batchable([sampler(reporter=object()), sampler()])
+    assert not MCMCSampler.batchable([_FakeMCMC(), _FakeMCMC()])
+    pot = IdealGasPotential(Topology.homogeneous(4))
+    box = unit.Quantity(np.diag([5.0, 5.0, 5.0]), unit.nanometer)
+    states = [SamplerState(unit.Quantity(np.zeros((4, 3)), unit.nanometer), PRNGKey(7, k), box_vectors=box) for k in range(2)]
+    thermo = [ThermodynamicState(pot, temperature=300.0 * unit.kelvin) for _ in range(2)]
+    assert not batch_applies([LangevinIntegrator(), LangevinIntegrator()], states, thermo, [None, None], 5)
