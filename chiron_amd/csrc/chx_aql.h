@@ -25,9 +25,11 @@ int chx_aql_dispatch(hipStream_t st, const AqlKernel* k, unsigned blocks, const 
                      bool final_packet = false);
 // The same for a two-dimensional grid of 256-thread workgroups (the batched step launch: x = a replica's blocks, y = the
 // replica).  `beside_previous`: no barrier bit -- the packet may start while the one dispatched just before it runs (the
-// classes of one batched step); it still stays behind everything that one waited for.
+// classes of one batched step); it still stays behind everything that one waited for.  `leaves_queue`: the launch writes
+// something that is read from outside the queue (the batch of trailing kicks: the states run_batch returns) -- what the
+// debug mode delays.
 int chx_aql_dispatch_grid(hipStream_t st, const AqlKernel* k, dim3 grid, const void* kernarg, size_t nbytes, bool release_agent,
-                          bool beside_previous);
+                          bool beside_previous, bool leaves_queue = false);
 // Host wait until every packet dispatched for `st` has completed (no-op when none is outstanding).  Called by every
 // libchx entry point before it launches on `st` (chx_stream) and by the Python layer where it used to wait for the stream.
 void chx_aql_join(hipStream_t st);

@@ -632,7 +632,8 @@ void debug_spin_packet(Queue* Q, hipStream_t st) {
 }
 
 int dispatch_core(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, const void* kernarg, size_t nbytes, int release,
-                  bool is_step = false, bool final_packet = false, bool hot_acquire = false, bool beside_previous = false) {
+                  bool is_step = false, bool final_packet = false, bool hot_acquire = false, bool beside_previous = false,
+                  bool leaves_queue = false) {
   // (the segment may be shorter than the caller's block -- trailing padding of a by-value struct -- never longer)
   const size_t seg = k->kernarg_size;
   if (nbytes + 256 > SLOT || nbytes > seg + 8) {
@@ -650,7 +651,7 @@ int dispatch_core(hipStream_t st, const AqlKernel* k, dim3 grid, dim3 block, con
   // other packet -- the list build chain, pack / unpack, prologues -- takes an agent-scope acquire like a HIP launch.
   int acquire = (g_fence_none && (is_step || hot_acquire)) ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT;
   if (!Q->open) open_gate(Q, st);
-  if (g_debug_delay_us > 0 && (Q->fresh || !(is_step || hot_acquire) || final_packet)) debug_spin_packet(Q, st);
+  if (g_debug_delay_us > 0 && (Q->fresh || !(is_step || hot_acquire) || final_packet || leaves_queue)) debug_spin_packet(Q, st);
   // (a step packet behind the list build's summary launch starts beside it: chx_aql_allow_overlap)
   const bool barrier = !(is_step && (Q->overlap_ok || (beside_previous && !Q->fresh)));
   Q->overlap_ok = false;
@@ -736,13 +737,13 @@ int chx_aql_dispatch(hipStream_t st, const AqlKernel* k, unsigned blocks, const 
 }
 
 int chx_aql_dispatch_grid(hipStream_t st, const AqlKernel* k, dim3 grid, const void* kernarg, size_t nbytes, bool release_agent,
-                          bool beside_previous) {
+                          bool beside_previous, bool leaves_queue) {
   if (nbytes < k->kernarg_size) {
     chx_set_error("step queue: argument block of %zu bytes is shorter than the kernel's %u", nbytes, k->kernarg_size);
     return CHX_ERR_INVALID;
   }
   return dispatch_core(st, k, grid, dim3(256), kernarg, k->kernarg_size, release_agent ? HSA_FENCE_SCOPE_AGENT : chx_aql_hot_release(),
-                       true, false, false, beside_previous);
+                       true, false, false, beside_previous, leaves_queue);
 }
 
 void chx_aql_allow_overlap(hipStream_t st) {

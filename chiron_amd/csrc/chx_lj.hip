@@ -876,11 +876,12 @@ template <int G>
 static int launch_step_batch_g(const BatchItem* items, int count, bool hot, bool beside, hipStream_t st) {
   alignas(16) static thread_local BatchArgs ba;
   unsigned maxb = 0;
-  bool any_prune = false;
+  bool any_prune = false, any_final = false;
   for (int i = 0; i < count; ++i) {
     ba.item[i] = items[i];
     maxb = items[i].nblocks > maxb ? items[i].nblocks : maxb;
     any_prune |= items[i].prune != 0;
+    any_final |= items[i].a.x3_out != nullptr || items[i].a.v3_out != nullptr;
   }
   for (int i = count; i < CHX_BATCH_MAX; ++i) ba.item[i].nblocks = 0;  // (never addressed: the grid's y extent is `count`)
   static const bool dbg = getenv("CHX_DEBUG_SYNC") != nullptr;
@@ -903,7 +904,7 @@ static int launch_step_batch_g(const BatchItem* items, int count, bool hot, bool
     }
     // (fences as for the one-replica launch: a packet of steady-state items that refresh nothing leaves write-through
     // stores only)
-    return chx_aql_dispatch_grid(st, k, dim3(maxb, (unsigned)count), &ba, sizeof(ba), !(hot && !any_prune), beside);
+    return chx_aql_dispatch_grid(st, k, dim3(maxb, (unsigned)count), &ba, sizeof(ba), !(hot && !any_prune), beside, any_final);
   }
   if (hot) hipLaunchKernelGGL((k_lj_step_batch<G, true>), dim3(maxb, (unsigned)count), dim3(256), 0, st, ba);
   else hipLaunchKernelGGL((k_lj_step_batch<G, false>), dim3(maxb, (unsigned)count), dim3(256), 0, st, ba);

@@ -1134,7 +1134,11 @@ class _RunState:
             # the build's status block is published by the build's summary launch; the SECOND step launch of the
             # generation behind the build has begun => it is there.  Otherwise wait for the queue and the stream.
             if int(self._gen.host[0]) < self._gen_step0 + 1:  # (+ 1: the generation's first launch may run BESIDE the
-                _wait_for_steps_and_stream()                   # launch that publishes the block: chx_aql_allow_overlap)
+                # launch that publishes the block: chx_aql_allow_overlap.)  Not there yet by that token: wait for the
+                # block itself -- the build's last store -- rather than for everything queued behind the build (round 6:
+                # a full join here also hid, under the queue's debug delays, a join that was missing elsewhere)
+                if not owner._wait_for_status():
+                    _wait_for_steps_and_stream()
             ok = owner._confirm_build(wait=False)
         else:
             ok = owner._confirm_build()

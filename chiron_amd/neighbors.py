@@ -393,6 +393,11 @@ class NeighborListNsqrd(PairsBase):
         host = d.get("_status_host")
         if host is None:
             host = self._status_host = torch.empty((8,), dtype=torch.int32, pin_memory=True)
+        if d.get("_status_np") is None:
+            self._status_np = host.numpy()  # (a view: reading a word costs a tenth of a tensor op)
+        # (word 7 of the block the build's last launch publishes is always 0: until then it says "not yet" --
+        # _wait_for_status; the previous speculative build has been confirmed by now, nothing else writes there)
+        self._status_np[7] = 0x7FFFFFFF
         riders = {"publish": host}
         if copy_positions:
             ready = self.__dict__.pop("_next_copy", None)  # (_prepare_next_build)
@@ -424,6 +429,22 @@ class NeighborListNsqrd(PairsBase):
         self._perm = sorted_ids
         self._force_list = ops.ForceList.prebuilt(fl, deg, sorted_ids, g, chunks, getattr(self, "_last_maxdeg", 0))
         self.n_builds += 1
+        return True
+
+    def _wait_for_status(self, timeout_s: float = 0.05) -> bool:
+        """Host wait until the last ``_build_speculative``'s status block has ARRIVED (its word 7 turns 0), at most
+        ``timeout_s``: a wait for the build alone, not for everything queued behind it -- what a caller with launches of
+        its own still in flight wants before ``_confirm_build(wait=False)``.  False: not seen in time (wait for the
+        queue instead)."""
+        import time
+
+        st = self.__dict__.get("_status_np")
+        if st is None:
+            return False
+        t_end = time.perf_counter() + timeout_s
+        while int(st[7]) != 0:
+            if time.perf_counter() > t_end:
+                return False
         return True
 
     def _build_status_good(self) -> bool:
@@ -631,7 +652,7 @@ class NeighborListNsqrd(PairsBase):
                 new._force_list = None  # rebuilt lazily; it is a pure function of the list
             elif k == "_scratch":
                 new._scratch = None  # kernel work arrays are not part of the list
-            elif k in ("_spec", "_status_host", "_grid_cache", "_next_copy"):
+            elif k in ("_spec", "_status_host", "_status_np", "_grid_cache", "_next_copy"):
                 setattr(new, k, None)
             elif k in ("_spec_event",):
                 continue  # plumbing of the speculative rebuild: the copy starts without any

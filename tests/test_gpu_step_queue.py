@@ -175,7 +175,7 @@ def test_debug_delays_do_not_change_a_bit(workload, steps):
     assert plain["idle_packets"] == 0 and slow["idle_packets"] >= 10, (slow, plain)
 
 
-@pytest.mark.parametrize("path", ["verlet", "all_pairs"])
+@pytest.mark.parametrize("path", ["verlet", "verlet_build_on_entry", "all_pairs"])
 def test_a_missing_join_reads_poison_every_time(path):
     """The bug class of round 5 (a run() that returned without joining the step queue and passed on timing), made
     deterministic: with the debug mode on, a run() whose final join is deliberately skipped (test hook) hands back a state
@@ -184,16 +184,17 @@ def test_a_missing_join_reads_poison_every_time(path):
     import bench
     from chiron_amd import neighbors, ops, unit as u
 
-    if path == "verlet":
+    if path.startswith("verlet"):
         fluid, pot, state, thermo, lst, integ = bench.make_system("c3", 300.0, 32, "cell")
     else:
         fluid, pot, state, thermo, _, integ = bench.make_system("c2", 300.0, 32, "cell")
         lst = neighbors.PairListNsqrd(neighbors.OrthogonalPeriodicSpace(), cutoff=3.0 * bench.SIGMA_NM * u.nanometer)
     if not ops.step_queue_on():
         pytest.skip("the step queue is switched off (CHX_AQL=0)")
-    # (Verlet list: the runs continue each other on a carried-over list -- a run() that builds its list on entry confirms the
-    # build's status block before it returns, and under the debug delay that confirmation waits for the queue: the join
-    # under test would be masked by another one)
+    # (Verlet list, two ways: runs that continue each other on a carried-over list, and runs that build their list on entry
+    # -- those confirm the build's status block before they return, which until round 6 waited for the whole queue when
+    # the block had not arrived and so, under the debug delays, hid the very join under test: the confirmation now waits
+    # for the block alone, NeighborListNsqrd._wait_for_status)
     integ.list_carry = path == "verlet"
     state, lst = integ.run(state, thermo, number_of_steps=10, nbr_list=lst)  # velocities, buffers, code paths warm
     state, lst = integ.run(state, thermo, number_of_steps=10, nbr_list=lst)
@@ -242,3 +243,47 @@ def test_the_fence_free_assumption_is_checked_again_while_a_process_lives():
     assert often["fence_checks"] >= 3, often
     assert often["status"] == "" and often["queue"]["hot_release"] == "none", often
     assert often["hash"] == plain["hash"]
+
+
+def test_a_missing_join_in_the_batched_loop_reads_poison_every_time():
+    """The same detector on ``integrators.run_batch`` (several replicas per launch): its one join -- behind the batch of
+    trailing kicks -- skipped on purpose: every replica's returned state is still poison, ten times out of ten."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from chiron_amd import ops
+    from chiron_amd.integrators import run_batch
+    from chiron_amd.rng import PRNGKey
+
+    reps = []
+    for k in range(3):
+        fluid, pot, state, thermo, nbr, integ = bench.make_system("n8k", 300.0 * 1.05 ** k, 32, "cell")
+        integ.list_carry = False
+        state.current_PRNG_key = PRNGKey(5, k)
+        reps.append([integ, state, thermo, nbr])
+    if not ops.step_queue_on():
+        pytest.skip("the step queue is switched off (CHX_AQL=0)")
+
+    def go(n):
+        return run_batch([r[0] for r in reps], [r[1] for r in reps], [r[2] for r in reps], n, [r[3] for r in reps])
+
+    for r, (s, l) in zip(reps, go(10)):
+        r[1], r[3] = s, l
+    old = ops.queue_debug(300)
+    try:
+        caught = 0
+        for _ in range(10):
+            ops._debug_skip_final_join = 1
+            try:
+                out = go(12)
+                poisoned = all(ops.is_poison(s.positions) or ops.is_poison(s.velocities) for s, _ in out)
+            finally:
+                ops._debug_skip_final_join = 0
+                ops.steps_join()
+                torch.cuda.synchronize()
+            caught += int(poisoned)
+            assert all(torch.isfinite(s.positions).all() and torch.isfinite(s.velocities).all() for s, _ in out)
+        assert caught == 10, f"the missing join was caught {caught} times out of 10"
+        out = go(12)
+        assert not any(ops.is_poison(s.positions) or ops.is_poison(s.velocities) for s, _ in out)
+    finally:
+        ops.queue_debug(old)
