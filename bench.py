@@ -12,8 +12,11 @@ replicas exchange labels every --exchange-interval steps through one RCCL all-ga
 (weak scaling: value = total replica-steps per second).
 
 Rank 0 prints ONE JSON line with the throughput, the roofline of the dominant kernel
-(pair force, algorithmic bytes 24 N + 16 P_nl per launch, HIP-event timed) and a CPU
-baseline (the C restatement of the reference algorithm, oracle/oracle.c, 1 thread).
+(the fused step launch, algorithmic bytes 96 N + 16 P_nl per launch, HIP-event timed; the
+pair-force kernels at C3 / C4 / liquid density and the batched step beside it) and a CPU
+baseline (the C restatement of the reference algorithm, oracle/oracle.c).  On one GPU the
+line also carries BASELINE's C5 shape on that one card (`c5_one_gpu`: eight replicas stepped
+side by side, label exchange through a one-rank RCCL group).
 """
 from __future__ import annotations
 
