@@ -504,6 +504,8 @@ def batch_applies(integrators, sampler_states, thermodynamic_states, nbr_lists, 
     NeighborListNsqrd, _, LJPotential = (_MODS or _mods())[:3]
     if number_of_steps <= 0 or len(integrators) < 2 or len({id(i) for i in integrators}) != len(integrators):
         return False
+    if len(integrators) > 64:  # (chx_langevin_batch_run takes up to 64 items a call)
+        return False
     if len({id(l) for l in nbr_lists}) != len(nbr_lists):
         return False
     for integ, ss, ts, nl in zip(integrators, sampler_states, thermodynamic_states, nbr_lists):

@@ -176,3 +176,29 @@ def test_batch_entry_points_refuse_what_they_cannot_run():
     assert lib.chx_langevin_batch_run(two, 2, 8, None) == -1       # two items on one control block
     assert lib.chx_langevin_batch_run(ops._batch_items(ok), 1, 0, None) == -1  # window < 1
     assert b"control block" in lib.chx_last_error() or b"window" in lib.chx_last_error()
+
+
+def test_run_batch_with_the_threefry_stream_and_unequal_histories():
+    """Replicas that do not take the steady-state launch: one draws its noise from the JAX-compatible threefry stream (its
+    O-step noise is materialised and injected: the launch's general instantiation), one arrives without velocities (they are
+    drawn on entry), one is an ordinary Philox replica -- three classes of launch in one batch, against the serial calls."""
+    from chiron_amd.integrators import run_batch
+    from chiron_amd.rng import JaxKey
+
+    def make():
+        reps = [list(_replica(3000, 0.3, 300.0 + 20.0 * k, 31 + k, 0.2, 2.0)) for k in range(3)]
+        reps[0][1].current_PRNG_key = JaxKey.from_seed(1234)
+        return reps
+
+    serial, batched = make(), make()
+    # (replica 1 keeps velocities from a first call, the others start without: different front halves in one batch)
+    s1 = serial[1][0].run(serial[1][1], serial[1][2], number_of_steps=5, nbr_list=serial[1][3])
+    b1 = batched[1][0].run(batched[1][1], batched[1][2], number_of_steps=5, nbr_list=batched[1][3])
+    serial[1] = (serial[1][0], s1[0], serial[1][2], s1[1])
+    batched[1] = (batched[1][0], b1[0], batched[1][2], b1[1])
+    out_s = [integ.run(st, th, number_of_steps=90, nbr_list=nb) for integ, st, th, nb in serial]
+    out_b = run_batch([r[0] for r in batched], [r[1] for r in batched], [r[2] for r in batched], 90, [r[3] for r in batched])
+    torch.cuda.synchronize()
+    for a, b in zip(out_s, out_b):
+        _same(a, b)
+    assert type(out_b[0][0].current_PRNG_key) is type(out_s[0][0].current_PRNG_key)
