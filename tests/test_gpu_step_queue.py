@@ -198,7 +198,9 @@ def test_a_missing_join_reads_poison_every_time(path):
     integ.list_carry = path == "verlet"
     state, lst = integ.run(state, thermo, number_of_steps=10, nbr_list=lst)  # velocities, buffers, code paths warm
     state, lst = integ.run(state, thermo, number_of_steps=10, nbr_list=lst)
-    old = ops.queue_debug(300)
+    ops.is_poison(state.positions)  # (torch's own kernels of the check loaded before anything is timed against them)
+    # (2 ms of delay: the consumer's read below must come before the delayed launch writes, whatever the host is doing)
+    old = ops.queue_debug(2000)
     try:
         spins0 = ops.queue_debug_spins()
         caught = 0
@@ -268,7 +270,8 @@ def test_a_missing_join_in_the_batched_loop_reads_poison_every_time():
 
     for r, (s, l) in zip(reps, go(10)):
         r[1], r[3] = s, l
-    old = ops.queue_debug(300)
+    ops.is_poison(reps[0][1].positions)  # (torch's kernels of the check loaded before anything is timed against them)
+    old = ops.queue_debug(2000)
     try:
         caught = 0
         for _ in range(10):
