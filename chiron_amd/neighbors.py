@@ -431,7 +431,7 @@ class NeighborListNsqrd(PairsBase):
         self.n_builds += 1
         return True
 
-    def _wait_for_status(self, timeout_s: float = 0.05) -> bool:
+    def _wait_for_status(self, timeout_s: float = 0.25) -> bool:
         """Host wait until the last ``_build_speculative``'s status block has ARRIVED (its word 7 turns 0), at most
         ``timeout_s``: a wait for the build alone, not for everything queued behind it -- what a caller with launches of
         its own still in flight wants before ``_confirm_build(wait=False)``.  False: not seen in time (wait for the
