@@ -199,8 +199,8 @@ def test_a_missing_join_reads_poison_every_time(path):
     state, lst = integ.run(state, thermo, number_of_steps=10, nbr_list=lst)  # velocities, buffers, code paths warm
     state, lst = integ.run(state, thermo, number_of_steps=10, nbr_list=lst)
     ops.is_poison(state.positions)  # (torch's own kernels of the check loaded before anything is timed against them)
-    # (2 ms of delay: the consumer's read below must come before the delayed launch writes, whatever the host is doing)
-    old = ops.queue_debug(2000)
+    # (10 ms of delay: the consumer's read below must come before the delayed launch writes, whatever the host is doing)
+    old = ops.queue_debug(10000)
     try:
         spins0 = ops.queue_debug_spins()
         caught = 0
@@ -271,7 +271,7 @@ def test_a_missing_join_in_the_batched_loop_reads_poison_every_time():
     for r, (s, l) in zip(reps, go(10)):
         r[1], r[3] = s, l
     ops.is_poison(reps[0][1].positions)  # (torch's kernels of the check loaded before anything is timed against them)
-    old = ops.queue_debug(2000)
+    old = ops.queue_debug(10000)
     try:
         caught = 0
         for _ in range(10):
