@@ -472,7 +472,12 @@ def c5_one_gpu_block(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ["MASTER_PORT"] = str(port)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+        import datetime
+
+        # (a one-rank group: nothing to wait for but the local store; a minute is generous, and a failure here only costs
+        # this leg -- the caller catches it and the line goes out without `c5_one_gpu`)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()),
+                                timeout=datetime.timedelta(seconds=60))
         own_group = True
     try:
         backend = dist.get_backend()
